@@ -1,0 +1,152 @@
+/* libvxm_hip.so — C ABI of the MI355X-native VxmDense hot path (gfx950 only).
+ *
+ * The reference (voxelmorph/voxelmorph @ 0.2) has no FFI layer: its "operator API" for this
+ * path is the Python class surface in voxelmorph/torch/{layers,networks,losses}.py, every
+ * method of which expands into PyTorch ATen calls.  Each entry point below replaces one such
+ * ATen op chain (reference file:line given per function, paths relative to the reference
+ * root).  The Python host mirror (voxelmorph_amd/torch/*) binds these with ctypes; the stub a
+ * reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 (unless stated) owned by the caller; the library
+ *    never allocates, frees or retains device memory.  Workspace sizes come from the
+ *    *_workspace_bytes() queries.
+ *  - tensors are NCDHW contiguous like the reference's; arguments named
+ *    *_bstride are the element stride between batch samples, so that a channel slice of a
+ *    larger buffer can be passed without a copy.
+ *  - `stream` is a hipStream_t; all calls are asynchronous on it and never synchronise.
+ *  - return value: 0 = VXM_OK, otherwise a vxm_status; vxm_last_error_string() describes the
+ *    last failure on the calling thread.  Nothing throws or aborts across the ABI.
+ */
+#ifndef VXM_HIP_H
+#define VXM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    VXM_OK = 0,
+    VXM_ERR_BAD_SHAPE = 1,     /* mirrors the reference asserts (layers.py:59, networks.py:51,196) */
+    VXM_ERR_UNSUPPORTED = 2,
+    VXM_ERR_NULL_POINTER = 3,
+    VXM_ERR_WORKSPACE = 4,
+    VXM_ERR_HIP = 5            /* hipGetLastError() != hipSuccess after a launch */
+} vxm_status;
+
+enum { VXM_INTERP_LINEAR = 0, VXM_INTERP_NEAREST = 1 };   /* SpatialTransformer mode, layers.py:11 */
+enum { VXM_PENALTY_L1 = 0, VXM_PENALTY_L2 = 1 };          /* Grad penalty, losses.py:98 */
+
+int vxm_version(void);
+const char* vxm_last_error_string(void);
+
+/* ---- SpatialTransformer.forward, layers.py:30-48 (add + normalise + permute + index +
+ * grid_sampler_3d, align_corners=True, padding zeros).  out[b,c,p] = sample(src[b,c], p+flow[b,:,p]).
+ * mode nearest is bit-exact with the reference (round-half-even after its fp32 normalise /
+ * un-normalise round trip). */
+int vxm_warp3d_fwd(const float* src, const float* flow, float* out, int B, int C, int D, int H, int W,
+                   int mode, void* stream);
+/* backward of the above: gflow [B,3,D,H,W] (nullable), gsrc [B,C,D,H,W] (nullable, overwritten). */
+int vxm_warp3d_bwd(const float* src, const float* flow, const float* gout, float* gsrc, float* gflow,
+                   int B, int C, int D, int H, int W, int mode, void* stream);
+
+/* ---- VecInt.forward, layers.py:64-68: v0 = vec/2^n; v_{k+1} = v_k + warp(v_k, v_k).
+ * steps: [nsteps][B,3,D,H,W]; steps[k] receives v_{k+1}; the result is steps[nsteps-1]. */
+int vxm_vecint_fwd(const float* vec, float* steps, int B, int D, int H, int W, int nsteps, void* stream);
+/* backward: gout = dL/dv_n; gvec = dL/dvec.  work: 2*B*3*D*H*W floats of scratch. */
+int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, float* gvec, float* work,
+                   int B, int D, int H, int W, int nsteps, void* stream);
+
+/* ---- ResizeTransform.forward, layers.py:85-97 (upsample_trilinear3d align_corners=True and the
+ * `factor *` rescale, before the resize when factor>1, after when factor<1). */
+int vxm_resize3d_fwd(const float* x, float* out, int B, int C, int D, int H, int W, int oD, int oH, int oW,
+                     float factor, void* stream);
+int vxm_resize3d_bwd(const float* gout, float* gx, int B, int C, int D, int H, int W, int oD, int oH, int oW,
+                     float factor, void* stream);
+
+/* ---- ConvBlock / flow conv, networks.py:299-305,211,257: 3x3x3, stride 1, pad 1 conv + bias +
+ * LeakyReLU(act_slope) (act_slope = 1 -> no activation).  fp32 MFMA implicit GEMM.
+ * The input is a *virtual concat* of up to two channel segments, so that Unet.forward's
+ * `cat([upsample(x), skip])` (networks.py:137-138) is never materialised:
+ *   segment 0: x0 [B,C0,*] (if x0_up != 0 it is stored at half resolution [D/2,H/2,W/2] and
+ *              read through nearest x2 upsampling), segment 1: x1 [B,C1,D,H,W] (nullable, C1=0).
+ * wpacked comes from vxm_conv3d_k3_pack_weights.  If mask_src != NULL the result is multiplied
+ * by LeakyReLU'(mask_src) (slope mask_slope) — used when this launch computes a backward-data
+ * product that feeds the previous ConvBlock (fused leaky_relu_backward). */
+size_t vxm_conv3d_k3_packed_elems(int Cin, int Cout);
+/* w: [Cout,Cin,3,3,3] (reference layout).  transpose_flip=0: forward operator; 1: the adjoint
+ * (backward-data) operator, i.e. w'[ci][co][t] = w[co][ci][26-t], packed as a Cout->Cin conv. */
+int vxm_conv3d_k3_pack_weights(const float* w, float* wpacked, int Cin, int Cout, int transpose_flip,
+                               void* stream);
+int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
+                      const float* x1, int C1, int64_t x1_bstride,
+                      const float* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout,
+                      float act_slope, const float* mask_src, int64_t mask_bstride, float mask_slope,
+                      int B, int D, int H, int W, void* stream);
+/* convolution_backward w.r.t. weight and bias: gw [Cout,C0+C1,3,3,3], gb [Cout] (nullable).
+ * dz [B,Cout,D,H,W] is the gradient w.r.t. the conv output *before* the activation. */
+size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D, int H, int W);
+int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0_up,
+                             const float* x1, int C1, int64_t x1_bstride,
+                             const float* dz, int64_t dz_bstride, int Cout, float* gw, float* gb,
+                             void* workspace, size_t workspace_bytes, int B, int D, int H, int W, void* stream);
+
+/* dz = g * LeakyReLU'(y)  (leaky_relu_backward; y is the activation OUTPUT, sign(y)=sign(z)). */
+int vxm_lrelu_bwd(const float* g, int64_t g_bstride, const float* y, int64_t y_bstride, float* dz,
+                  int64_t dz_bstride, float slope, int B, int C, int64_t V, void* stream);
+
+/* ---- MaxPool3d(2), networks.py:83-84,130.  x [B,C,D,H,W] (x_bstride) -> y [B,C,D/2,H/2,W/2]. */
+int vxm_maxpool2_fwd(const float* x, int64_t x_bstride, float* y, int B, int C, int D, int H, int W,
+                     void* stream);
+/* fused backward of {max_pool3d, the skip branch of the concat, leaky_relu}:
+ * dz[b,c,p] = (gskip[b,c,p] + (p is the arg-max of its 2x2x2 block ? gpool[b,c,p>>1] : 0)) * LeakyReLU'(x[b,c,p])
+ * gskip nullable; slope = 1 gives the plain max-pool backward.  First max in scan order wins ties,
+ * like ATen's max_pool3d_with_indices. */
+int vxm_maxpool2_bwd(const float* x, int64_t x_bstride, const float* gpool, const float* gskip,
+                     int64_t gskip_bstride, float* dz, float slope, int B, int C, int D, int H, int W,
+                     void* stream);
+/* fused backward of {Upsample(2,'nearest') (networks.py:85,137), leaky_relu}:
+ * dz[b,c,q] = (sum over the 2x2x2 children p of q of g[b,c,p]) * LeakyReLU'(y[b,c,q]);  y nullable. */
+int vxm_upsample2_bwd(const float* g, int64_t g_bstride, const float* y, float* dz, float slope,
+                      int B, int C, int D, int H, int W /* low-res dims */, void* stream);
+/* materialise cat([upsample2(x0), x1]) (only needed when a Unet ends on a concat). */
+int vxm_upsample2_cat(const float* x0, int C0, const float* x1, int C1, float* out, int B, int D, int H, int W,
+                      void* stream);
+
+/* ---- losses (losses.py).  Every *_fwd writes a 0-dim fp32 loss; `acc` is a caller-provided
+ * scratch of doubles (zeroed by the call) that the matching *_bwd reads back.  gloss points to
+ * the upstream scalar gradient ON DEVICE (no host sync). */
+/* NCC.loss, losses.py:15-67 (win^3 box sums as separable running sums, zero padded).
+ * sums: 5*B*D*H*W floats (I,J,I^2,J^2,IJ box sums, kept for backward); work: 5*B*D*H*W floats. */
+int vxm_ncc_fwd(const float* I, const float* J, float* loss, float* sums, float* work, double* acc,
+                int B, int D, int H, int W, int win, void* stream);
+/* gJ = dL/dJ (y_pred).  work: 6*B*D*H*W floats. */
+int vxm_ncc_bwd(const float* I, const float* J, const float* sums, const float* gloss, float* gJ,
+                float* work, int B, int D, int H, int W, int win, void* stream);
+/* Grad.loss, losses.py:102-135.  mult = loss_mult (1 if None).  acc: 3*B doubles. */
+int vxm_gradloss_fwd(const float* y, float* loss, double* acc, int B, int C, int D, int H, int W,
+                     int penalty, float mult, void* stream);
+int vxm_gradloss_bwd(const float* y, const float* gloss, float* gy, int B, int C, int D, int H, int W,
+                     int penalty, float mult, void* stream);
+/* MSE.loss, losses.py:75-76.  acc: 1 double. */
+int vxm_mse_fwd(const float* a, const float* b, float* loss, double* acc, int64_t n, void* stream);
+int vxm_mse_bwd(const float* a, const float* b, const float* gloss, float* ga, float* gb, int64_t n,
+                void* stream);
+/* Dice.loss, losses.py:84-90.  acc: 2*B*C doubles (top/2, bottom sums). */
+int vxm_dice_fwd(const float* yt, const float* yp, float* loss, double* acc, int B, int C, int64_t V,
+                 void* stream);
+int vxm_dice_bwd(const float* yt, const float* yp, const double* acc, const float* gloss, float* gyt,
+                 float* gyp, int B, int C, int64_t V, void* stream);
+
+/* ---- torch.optim.Adam.step (scripts/torch/train.py:161,220) over ONE flat fp32 buffer (which is
+ * also the RCCL all-reduce bucket).  g is pre-multiplied by gscale (1/world_size). */
+int vxm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int step, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VXM_HIP_H */

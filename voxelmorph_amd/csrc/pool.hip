@@ -1,0 +1,184 @@
+// Pooling / upsampling / activation-gradient glue kernels of the U-Net (HBM-bound, elementwise).
+//
+// Replaces (paths relative to the reference root):
+//   voxelmorph/torch/networks.py:83-84,130   MaxPool3d(2)            (max_pool3d_with_indices)
+//   voxelmorph/torch/networks.py:85,137-138  Upsample(2,'nearest') + cat   (backward side; the
+//                                            forward side is folded into the conv gather)
+//   voxelmorph/torch/networks.py:300,304     LeakyReLU(0.2) backward (leaky_relu_backward)
+// and fuses each backward with the leaky_relu_backward of the ConvBlock that produced the tensor.
+#include "vxm_common.h"
+#include "vxm_device.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) k_lrelu_bwd(const float* __restrict__ g, long long g_bs, const float* __restrict__ y, long long y_bs,
+                                                   float* __restrict__ dz, long long dz_bs, float slope, long long n /* C*V */) {
+    const size_t b = blockIdx.y;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dz[b * dz_bs + i] = g[b * g_bs + i] * vxm_lrelu_grad(y[b * y_bs + i], slope);
+}
+
+// one thread per pooled voxel
+__global__ void __launch_bounds__(256) k_maxpool2_fwd(const float* __restrict__ x, long long x_bs, float* __restrict__ y, int C, int D, int H, int W) {
+    const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
+    const long long V2 = (long long)D2 * H2 * W2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= V2 * C) return;
+    const size_t b = blockIdx.y;
+    const int c = (int)(i / V2);
+    const int q = (int)(i - (long long)c * V2);
+    const int w = q % W2, t = q / W2, h = t % H2, d = t / H2;
+    const float* p = x + b * x_bs + ((size_t)c * D + 2 * d) * H * W + (size_t)(2 * h) * W + 2 * w;
+    float m = p[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const float v = p[(size_t)((k >> 2) & 1) * H * W + (size_t)((k >> 1) & 1) * W + (k & 1)];
+        m = (v > m || v != v) ? v : m;              // ATen: (val > maxval) || isnan(val)
+    }
+    y[b * (size_t)C * V2 + i] = m;
+}
+
+// one thread per pooled voxel: routes gpool to the first arg-max of its 2x2x2 block, adds the
+// skip-branch gradient and applies LeakyReLU' of the pooled tensor (= ConvBlock output).
+__global__ void __launch_bounds__(256) k_maxpool2_bwd(const float* __restrict__ x, long long x_bs, const float* __restrict__ gpool,
+                                                      const float* __restrict__ gskip, long long gs_bs, float* __restrict__ dz,
+                                                      float slope, int C, int D, int H, int W) {
+    const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
+    const long long V2 = (long long)D2 * H2 * W2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= V2 * C) return;
+    const size_t b = blockIdx.y;
+    const int c = (int)(i / V2);
+    const int q = (int)(i - (long long)c * V2);
+    const int w = q % W2, t = q / W2, h = t % H2, d = t / H2;
+    const size_t off = ((size_t)c * D + 2 * d) * H * W + (size_t)(2 * h) * W + 2 * w;
+    const float* p = x + b * x_bs + off;
+    float vals[8];
+    float m = p[0];
+    int arg = 0;
+    vals[0] = m;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+        const float v = p[(size_t)((k >> 2) & 1) * H * W + (size_t)((k >> 1) & 1) * W + (k & 1)];
+        vals[k] = v;
+        if (v > m || v != v) { m = v; arg = k; }
+    }
+    const float gp = gpool[b * (size_t)C * V2 + i];
+    const size_t V = (size_t)D * H * W;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const size_t o = off + (size_t)((k >> 2) & 1) * H * W + (size_t)((k >> 1) & 1) * W + (k & 1);
+        float g = (k == arg) ? gp : 0.0f;
+        if (gskip) g += gskip[b * gs_bs + o];
+        dz[b * (size_t)C * V + o] = g * vxm_lrelu_grad(vals[k], slope);
+    }
+}
+
+// The volume may have odd extents (MaxPool floors): voxels outside the pooled region get only the
+// skip gradient.  Handled by a second tiny kernel over the uncovered border.
+__global__ void __launch_bounds__(256) k_maxpool2_bwd_border(const float* __restrict__ x, long long x_bs, const float* __restrict__ gskip,
+                                                             long long gs_bs, float* __restrict__ dz, float slope, int C, int D, int H, int W) {
+    const long long V = (long long)D * H * W;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= V * C) return;
+    const size_t b = blockIdx.y;
+    const int q = (int)(i % V);
+    const int w = q % W, t = q / W, h = t % H, d = t / H;
+    if (d < (D & ~1) && h < (H & ~1) && w < (W & ~1)) return;
+    const float g = gskip ? gskip[b * gs_bs + i] : 0.0f;
+    dz[b * (size_t)C * V + i] = g * vxm_lrelu_grad(x[b * x_bs + i], slope);
+}
+
+// one thread per low-res voxel
+__global__ void __launch_bounds__(256) k_upsample2_bwd(const float* __restrict__ g, long long g_bs, const float* __restrict__ y,
+                                                       float* __restrict__ dz, float slope, int C, int D, int H, int W) {
+    const long long V = (long long)D * H * W;     // low-res
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= V * C) return;
+    const size_t b = blockIdx.y;
+    const int c = (int)(i / V);
+    const int q = (int)(i - (long long)c * V);
+    const int w = q % W, t = q / W, h = t % H, d = t / H;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float* p = g + b * g_bs + ((size_t)c * 2 * D + 2 * d) * H2 * W2 + (size_t)(2 * h) * W2 + 2 * w;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += p[(size_t)((k >> 2) & 1) * H2 * W2 + (size_t)((k >> 1) & 1) * W2 + (k & 1)];
+    const float m = y ? vxm_lrelu_grad(y[b * (size_t)C * V + i], slope) : 1.0f;
+    dz[b * (size_t)C * V + i] = s * m;
+}
+
+// one thread per output voxel of cat([upsample2(x0), x1])
+__global__ void __launch_bounds__(256) k_upsample2_cat(const float* __restrict__ x0, int C0, const float* __restrict__ x1, int C1,
+                                                       float* __restrict__ out, int D, int H, int W) {
+    const long long V = (long long)D * H * W;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= V * (C0 + C1)) return;
+    const size_t b = blockIdx.y;
+    const int c = (int)(i / V);
+    const int q = (int)(i - (long long)c * V);
+    float v;
+    if (c < C0) {
+        const int w = q % W, t = q / W, h = t % H, d = t / H;
+        const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
+        v = x0[b * (size_t)C0 * D2 * H2 * W2 + ((size_t)c * D2 + (d >> 1)) * H2 * W2 + (size_t)(h >> 1) * W2 + (w >> 1)];
+    } else {
+        v = x1[b * (size_t)C1 * V + (size_t)(c - C0) * V + q];
+    }
+    out[b * (size_t)(C0 + C1) * V + i] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vxm_lrelu_bwd(const float* g, int64_t g_bstride, const float* y, int64_t y_bstride, float* dz, int64_t dz_bstride, float slope,
+                  int B, int C, int64_t V, void* stream) {
+    VXM_REQUIRE(g && y && dz, VXM_ERR_NULL_POINTER, "vxm_lrelu_bwd: null pointer");
+    VXM_REQUIRE(B > 0 && B <= 65535 && C > 0 && V > 0, VXM_ERR_BAD_SHAPE, "vxm_lrelu_bwd: bad shape");
+    const long long n = (long long)C * V;
+    const unsigned nb = (unsigned)(vxm_blocks(n, 256) > 65536u ? 65536u : vxm_blocks(n, 256));
+    hipLaunchKernelGGL(k_lrelu_bwd, dim3(nb, B), dim3(256), 0, VXM_STREAM(stream), g, (long long)g_bstride, y, (long long)y_bstride, dz,
+                       (long long)dz_bstride, slope, n);
+    return vxm_check_launch("vxm_lrelu_bwd");
+}
+
+int vxm_maxpool2_fwd(const float* x, int64_t x_bstride, float* y, int B, int C, int D, int H, int W, void* stream) {
+    VXM_REQUIRE(x && y, VXM_ERR_NULL_POINTER, "vxm_maxpool2_fwd: null pointer");
+    VXM_REQUIRE(B > 0 && B <= 65535 && C > 0 && D >= 2 && H >= 2 && W >= 2, VXM_ERR_BAD_SHAPE, "vxm_maxpool2_fwd: bad shape %dx%dx%d", D, H, W);
+    const long long n = (long long)C * (D / 2) * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(k_maxpool2_fwd, dim3(vxm_blocks(n, 256), B), dim3(256), 0, VXM_STREAM(stream), x, (long long)x_bstride, y, C, D, H, W);
+    return vxm_check_launch("vxm_maxpool2_fwd");
+}
+
+int vxm_maxpool2_bwd(const float* x, int64_t x_bstride, const float* gpool, const float* gskip, int64_t gskip_bstride, float* dz,
+                     float slope, int B, int C, int D, int H, int W, void* stream) {
+    VXM_REQUIRE(x && gpool && dz, VXM_ERR_NULL_POINTER, "vxm_maxpool2_bwd: null pointer");
+    VXM_REQUIRE(B > 0 && B <= 65535 && C > 0 && D >= 2 && H >= 2 && W >= 2, VXM_ERR_BAD_SHAPE, "vxm_maxpool2_bwd: bad shape %dx%dx%d", D, H, W);
+    const long long n = (long long)C * (D / 2) * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(k_maxpool2_bwd, dim3(vxm_blocks(n, 256), B), dim3(256), 0, VXM_STREAM(stream), x, (long long)x_bstride, gpool, gskip,
+                       (long long)gskip_bstride, dz, slope, C, D, H, W);
+    if ((D | H | W) & 1)
+        hipLaunchKernelGGL(k_maxpool2_bwd_border, dim3(vxm_blocks((long long)C * D * H * W, 256), B), dim3(256), 0, VXM_STREAM(stream), x,
+                           (long long)x_bstride, gskip, (long long)gskip_bstride, dz, slope, C, D, H, W);
+    return vxm_check_launch("vxm_maxpool2_bwd");
+}
+
+int vxm_upsample2_bwd(const float* g, int64_t g_bstride, const float* y, float* dz, float slope, int B, int C, int D, int H, int W,
+                      void* stream) {
+    VXM_REQUIRE(g && dz, VXM_ERR_NULL_POINTER, "vxm_upsample2_bwd: null pointer");
+    VXM_REQUIRE(B > 0 && B <= 65535 && C > 0 && D > 0 && H > 0 && W > 0, VXM_ERR_BAD_SHAPE, "vxm_upsample2_bwd: bad shape");
+    hipLaunchKernelGGL(k_upsample2_bwd, dim3(vxm_blocks((long long)C * D * H * W, 256), B), dim3(256), 0, VXM_STREAM(stream), g,
+                       (long long)g_bstride, y, dz, slope, C, D, H, W);
+    return vxm_check_launch("vxm_upsample2_bwd");
+}
+
+int vxm_upsample2_cat(const float* x0, int C0, const float* x1, int C1, float* out, int B, int D, int H, int W, void* stream) {
+    VXM_REQUIRE(x0 && out && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_upsample2_cat: null pointer");
+    VXM_REQUIRE(B > 0 && B <= 65535 && C0 > 0 && C1 >= 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, VXM_ERR_BAD_SHAPE, "vxm_upsample2_cat: bad shape");
+    hipLaunchKernelGGL(k_upsample2_cat, dim3(vxm_blocks((long long)(C0 + C1) * D * H * W, 256), B), dim3(256), 0, VXM_STREAM(stream), x0, C0,
+                       x1, C1, out, D, H, W);
+    return vxm_check_launch("vxm_upsample2_cat");
+}
+
+}  // extern "C"

@@ -1,0 +1,360 @@
+// SpatialTransformer / VecInt / ResizeTransform kernels for gfx950 (HBM-bound, coalesced along W).
+//
+// Reference op chains replaced (paths relative to the reference root):
+//   voxelmorph/torch/layers.py:30-48  SpatialTransformer.forward  (16 ATen launches -> 1 kernel)
+//   voxelmorph/torch/layers.py:64-68  VecInt.forward              (1 + 7*17 launches -> 7 kernels)
+//   voxelmorph/torch/layers.py:85-97  ResizeTransform.forward     (2 launches -> 1 kernel)
+// Layout: NCDHW fp32; one thread per output voxel, the 64 lanes of a wave walk W so the flow /
+// output planes are read and written as 256-byte rows; the 8-corner gathers hit L1/L2 because
+// neighbouring lanes sample neighbouring source voxels for the smooth fields of this path.
+#include "vxm_common.h"
+#include "vxm_device.h"
+
+namespace {
+
+struct Corners {
+    int idx[8];      // linear offset inside one [D,H,W] plane (valid only where ok bit set)
+    float w[8];      // trilinear weight
+    unsigned ok;     // bit k: corner k inside the volume (padding_mode='zeros')
+    float wz0, wz1, wy0, wy1, wx0, wx1;
+};
+
+// ATen grid_sampler_3d corner/weight construction: x0 = floor(x); weights (x1 - x) and (x - x0).
+__device__ __forceinline__ void make_corners(float z, float y, float x, int D, int H, int W, Corners& c) {
+    const float fz = floorf(z), fy = floorf(y), fx = floorf(x);
+    c.wz1 = z - fz; c.wz0 = (fz + 1.0f) - z;
+    c.wy1 = y - fy; c.wy0 = (fy + 1.0f) - y;
+    c.wx1 = x - fx; c.wx0 = (fx + 1.0f) - x;
+    // clamp before the int conversion so that wildly out-of-range coordinates stay defined
+    const int z0 = (int)fminf(fmaxf(fz, -2.0f), (float)D), y0 = (int)fminf(fmaxf(fy, -2.0f), (float)H),
+              x0 = (int)fminf(fmaxf(fx, -2.0f), (float)W);
+    c.ok = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
+        const int zz = z0 + dz, yy = y0 + dy, xx = x0 + dx;
+        const bool in = (zz >= 0) & (zz < D) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+        c.ok |= (in ? 1u : 0u) << k;
+        c.idx[k] = in ? (zz * H + yy) * W + xx : 0;
+        c.w[k] = (dz ? c.wz1 : c.wz0) * (dy ? c.wy1 : c.wy0) * (dx ? c.wx1 : c.wx0);
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_warp3d_fwd(const float* __restrict__ src, const float* __restrict__ flow,
+                                                    float* __restrict__ out, int C, int D, int H, int W) {
+    const int V = D * H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= V) return;
+    const int b = blockIdx.y;
+    const int w = p % W, t = p / W, h = t % H, d = t / H;
+    const float* fl = flow + (size_t)b * 3 * V;
+    const float z = vxm_src_coord(d, fl[p], D), y = vxm_src_coord(h, fl[V + p], H),
+                x = vxm_src_coord(w, fl[2 * (size_t)V + p], W);
+    const float* s = src + (size_t)b * C * V;
+    float* o = out + (size_t)b * C * V + p;
+    if (MODE == VXM_INTERP_NEAREST) {
+        const float rz = rintf(z), ry = rintf(y), rx = rintf(x);       // nearbyint: round-half-even
+        const bool in = (rz >= 0.0f) & (rz <= (float)(D - 1)) & (ry >= 0.0f) & (ry <= (float)(H - 1)) &
+                        (rx >= 0.0f) & (rx <= (float)(W - 1));
+        const int idx = in ? ((int)rz * H + (int)ry) * W + (int)rx : 0;
+        for (int c = 0; c < C; ++c) o[(size_t)c * V] = in ? s[(size_t)c * V + idx] : 0.0f;
+        return;
+    }
+    Corners cn;
+    make_corners(z, y, x, D, H, W, cn);
+    for (int c = 0; c < C; ++c) {
+        const float* sc = s + (size_t)c * V;
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = (cn.ok >> k) & 1 ? sc[cn.idx[k]] : 0.0f;
+            acc += v * cn.w[k];
+        }
+        o[(size_t)c * V] = acc;
+    }
+}
+
+// grid_sampler_3d_backward composed with the reference's normalisation chain: in voxel units
+// d out / d flow_a = sum_corners sign_a * prod_{b != a} w_b * src[corner]  (in-bounds corners only).
+template <int MODE>
+__global__ void __launch_bounds__(256) k_warp3d_bwd(const float* __restrict__ src, const float* __restrict__ flow,
+                                                    const float* __restrict__ gout, float* __restrict__ gsrc,
+                                                    float* __restrict__ gflow, int C, int D, int H, int W) {
+    const int V = D * H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= V) return;
+    const int b = blockIdx.y;
+    const int w = p % W, t = p / W, h = t % H, d = t / H;
+    const float* fl = flow + (size_t)b * 3 * V;
+    const float z = vxm_src_coord(d, fl[p], D), y = vxm_src_coord(h, fl[V + p], H),
+                x = vxm_src_coord(w, fl[2 * (size_t)V + p], W);
+    const float* s = src + (size_t)b * C * V;
+    const float* go = gout + (size_t)b * C * V + p;
+    float* gs = gsrc ? gsrc + (size_t)b * C * V : nullptr;
+    float* gf = gflow ? gflow + (size_t)b * 3 * V + p : nullptr;
+    if (MODE == VXM_INTERP_NEAREST) {
+        if (gf) { gf[0] = 0.0f; gf[V] = 0.0f; gf[2 * (size_t)V] = 0.0f; }
+        if (gs) {
+            const float rz = rintf(z), ry = rintf(y), rx = rintf(x);
+            const bool in = (rz >= 0.0f) & (rz <= (float)(D - 1)) & (ry >= 0.0f) & (ry <= (float)(H - 1)) &
+                            (rx >= 0.0f) & (rx <= (float)(W - 1));
+            if (in) {
+                const int idx = ((int)rz * H + (int)ry) * W + (int)rx;
+                for (int c = 0; c < C; ++c) atomicAdd(gs + (size_t)c * V + idx, go[(size_t)c * V]);
+            }
+        }
+        return;
+    }
+    Corners cn;
+    make_corners(z, y, x, D, H, W, cn);
+    float gz = 0.0f, gy = 0.0f, gx = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        const float g = go[(size_t)c * V];
+        const float* sc = s + (size_t)c * V;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (!((cn.ok >> k) & 1)) continue;
+            const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
+            const float v = sc[cn.idx[k]] * g;
+            const float wz = dz ? cn.wz1 : cn.wz0, wy = dy ? cn.wy1 : cn.wy0, wx = dx ? cn.wx1 : cn.wx0;
+            gz += (dz ? v : -v) * (wy * wx);
+            gy += (dy ? v : -v) * (wz * wx);
+            gx += (dx ? v : -v) * (wz * wy);
+            if (gs) atomicAdd(gs + (size_t)c * V + cn.idx[k], g * cn.w[k]);
+        }
+    }
+    if (gf) { gf[0] = gz; gf[V] = gy; gf[2 * (size_t)V] = gx; }
+}
+
+// One scaling-and-squaring step: out = v + warp(v, v), v = in * scale (scale is a power of two:
+// the product is exact, so folding it here equals the reference's separate `vec * self.scale`).
+__global__ void __launch_bounds__(256) k_vecint_step_fwd(const float* __restrict__ in, float scale,
+                                                         float* __restrict__ out, int D, int H, int W) {
+    const int V = D * H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= V) return;
+    const int b = blockIdx.y;
+    const int w = p % W, t = p / W, h = t % H, d = t / H;
+    const float* vin = in + (size_t)b * 3 * V;
+    const float v0 = vin[p] * scale, v1 = vin[V + p] * scale, v2 = vin[2 * (size_t)V + p] * scale;
+    Corners cn;
+    make_corners(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W, cn);
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (!((cn.ok >> k) & 1)) continue;
+        const int i = cn.idx[k];
+        a0 += (vin[i] * scale) * cn.w[k];
+        a1 += (vin[V + i] * scale) * cn.w[k];
+        a2 += (vin[2 * (size_t)V + i] * scale) * cn.w[k];
+    }
+    float* o = out + (size_t)b * 3 * V + p;
+    o[0] = v0 + a0; o[V] = v1 + a1; o[2 * (size_t)V] = v2 + a2;
+}
+
+// backward of one step.  With v = in*scale, out_c(p) = v_c(p) + sum_k w_k(v(p)) v_c(q_k):
+//   d/d v_c(p)   : g_c(p)                                   (identity)
+//                  + sum_c' g_c'(p) d(sample_c')/d flow_c     (v is also the flow)
+//   d/d v_c(q_k) : g_c(p) w_k                                 (v is also the sampled source; scatter)
+// gin must be zero on entry; every contribution is an fp32 atomic (order-dependent in the last
+// bits, like ATen's grid_sampler_3d_backward + index_put(accumulate)).
+__global__ void __launch_bounds__(256) k_vecint_step_bwd(const float* __restrict__ in, float scale,
+                                                         const float* __restrict__ gout, float* __restrict__ gin,
+                                                         int D, int H, int W) {
+    const int V = D * H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= V) return;
+    const int b = blockIdx.y;
+    const int w = p % W, t = p / W, h = t % H, d = t / H;
+    const float* vin = in + (size_t)b * 3 * V;
+    const float* go = gout + (size_t)b * 3 * V + p;
+    float* gi = gin + (size_t)b * 3 * V;
+    const float v0 = vin[p] * scale, v1 = vin[V + p] * scale, v2 = vin[2 * (size_t)V + p] * scale;
+    const float g0 = go[0], g1 = go[V], g2 = go[2 * (size_t)V];
+    Corners cn;
+    make_corners(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W, cn);
+    float gz = g0, gy = g1, gx = g2;                 // identity term
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (!((cn.ok >> k) & 1)) continue;
+        const int i = cn.idx[k];
+        const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
+        const float wz = dz ? cn.wz1 : cn.wz0, wy = dy ? cn.wy1 : cn.wy0, wx = dx ? cn.wx1 : cn.wx0;
+        const float s = (vin[i] * scale) * g0 + (vin[V + i] * scale) * g1 + (vin[2 * (size_t)V + i] * scale) * g2;
+        gz += (dz ? s : -s) * (wy * wx);
+        gy += (dy ? s : -s) * (wz * wx);
+        gx += (dx ? s : -s) * (wz * wy);
+        const float wk = cn.w[k] * scale;
+        atomicAdd(gi + i, g0 * wk);
+        atomicAdd(gi + V + i, g1 * wk);
+        atomicAdd(gi + 2 * (size_t)V + i, g2 * wk);
+    }
+    atomicAdd(gi + p, gz * scale);
+    atomicAdd(gi + V + p, gy * scale);
+    atomicAdd(gi + 2 * (size_t)V + p, gx * scale);
+}
+
+// ATen upsample_trilinear3d(align_corners=True) index/lambda: real = ratio*dst; i0 = (int)real;
+// i1 = i0 + (i0 < in-1); l1 = real - i0; l0 = 1 - l1.
+__device__ __forceinline__ void lin_src(int dst, float ratio, int n_in, int& i0, int& i1, float& l0, float& l1) {
+    const float r = ratio * (float)dst;
+    i0 = min((int)r, n_in - 1);
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l1 = fminf(fmaxf(r - (float)i0, 0.0f), 1.0f);
+    l0 = 1.0f - l1;
+}
+
+__global__ void __launch_bounds__(256) k_resize3d_fwd(const float* __restrict__ x, float* __restrict__ out, int D, int H,
+                                                      int W, int oD, int oH, int oW, float rd, float rh, float rw,
+                                                      float pre, float post) {
+    const int oV = oD * oH * oW;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= oV) return;
+    const size_t bc = blockIdx.y;
+    const int w = p % oW, t = p / oW, h = t % oH, d = t / oH;
+    int z0, z1, y0, y1, x0, x1;
+    float lz0, lz1, ly0, ly1, lx0, lx1;
+    lin_src(d, rd, D, z0, z1, lz0, lz1);
+    lin_src(h, rh, H, y0, y1, ly0, ly1);
+    lin_src(w, rw, W, x0, x1, lx0, lx1);
+    const float* s = x + bc * (size_t)D * H * W;
+#define AT(zz, yy, xx) (pre * s[((size_t)(zz) * H + (yy)) * W + (xx)])
+    const float v = lz0 * (ly0 * (lx0 * AT(z0, y0, x0) + lx1 * AT(z0, y0, x1)) + ly1 * (lx0 * AT(z0, y1, x0) + lx1 * AT(z0, y1, x1))) +
+                    lz1 * (ly0 * (lx0 * AT(z1, y0, x0) + lx1 * AT(z1, y0, x1)) + ly1 * (lx0 * AT(z1, y1, x0) + lx1 * AT(z1, y1, x1)));
+#undef AT
+    out[bc * (size_t)oV + p] = post * v;
+}
+
+// adjoint of the above (scatter; gx zeroed by the caller)
+__global__ void __launch_bounds__(256) k_resize3d_bwd(const float* __restrict__ gout, float* __restrict__ gx, int D, int H,
+                                                      int W, int oD, int oH, int oW, float rd, float rh, float rw,
+                                                      float scale) {
+    const int oV = oD * oH * oW;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= oV) return;
+    const size_t bc = blockIdx.y;
+    const int w = p % oW, t = p / oW, h = t % oH, d = t / oH;
+    int z0, z1, y0, y1, x0, x1;
+    float lz0, lz1, ly0, ly1, lx0, lx1;
+    lin_src(d, rd, D, z0, z1, lz0, lz1);
+    lin_src(h, rh, H, y0, y1, ly0, ly1);
+    lin_src(w, rw, W, x0, x1, lx0, lx1);
+    const float g = gout[bc * (size_t)oV + p] * scale;
+    float* o = gx + bc * (size_t)D * H * W;
+#define ADD(zz, yy, xx, wt) atomicAdd(o + ((size_t)(zz) * H + (yy)) * W + (xx), g * (wt))
+    ADD(z0, y0, x0, lz0 * ly0 * lx0); ADD(z0, y0, x1, lz0 * ly0 * lx1);
+    ADD(z0, y1, x0, lz0 * ly1 * lx0); ADD(z0, y1, x1, lz0 * ly1 * lx1);
+    ADD(z1, y0, x0, lz1 * ly0 * lx0); ADD(z1, y0, x1, lz1 * ly0 * lx1);
+    ADD(z1, y1, x0, lz1 * ly1 * lx0); ADD(z1, y1, x1, lz1 * ly1 * lx1);
+#undef ADD
+}
+
+int check_vol(const char* fn, int B, int C, int D, int H, int W) {
+    VXM_REQUIRE(B > 0 && C > 0 && D > 1 && H > 1 && W > 1, VXM_ERR_BAD_SHAPE,
+                "%s: bad shape B=%d C=%d D=%d H=%d W=%d (3-D volumes with every extent > 1)", fn, B, C, D, H, W);
+    VXM_REQUIRE((long long)C * D * H * W < (1ll << 31) && B <= 65535, VXM_ERR_BAD_SHAPE,
+                "%s: per-sample element count must fit int32 and B <= 65535", fn);
+    return VXM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vxm_warp3d_fwd(const float* src, const float* flow, float* out, int B, int C, int D, int H, int W, int mode,
+                   void* stream) {
+    if (int e = check_vol("vxm_warp3d_fwd", B, C, D, H, W)) return e;
+    VXM_REQUIRE(src && flow && out, VXM_ERR_NULL_POINTER, "vxm_warp3d_fwd: null pointer");
+    VXM_REQUIRE(mode == VXM_INTERP_LINEAR || mode == VXM_INTERP_NEAREST, VXM_ERR_UNSUPPORTED,
+                "vxm_warp3d_fwd: mode %d (only 'bilinear' and 'nearest', layers.py:11)", mode);
+    const dim3 grid(vxm_blocks((long long)D * H * W, 256), B);
+    if (mode == VXM_INTERP_NEAREST)
+        hipLaunchKernelGGL(k_warp3d_fwd<VXM_INTERP_NEAREST>, grid, dim3(256), 0, VXM_STREAM(stream), src, flow, out, C, D, H, W);
+    else
+        hipLaunchKernelGGL(k_warp3d_fwd<VXM_INTERP_LINEAR>, grid, dim3(256), 0, VXM_STREAM(stream), src, flow, out, C, D, H, W);
+    return vxm_check_launch("vxm_warp3d_fwd");
+}
+
+int vxm_warp3d_bwd(const float* src, const float* flow, const float* gout, float* gsrc, float* gflow, int B, int C,
+                   int D, int H, int W, int mode, void* stream) {
+    if (int e = check_vol("vxm_warp3d_bwd", B, C, D, H, W)) return e;
+    VXM_REQUIRE(src && flow && gout, VXM_ERR_NULL_POINTER, "vxm_warp3d_bwd: null pointer");
+    VXM_REQUIRE(mode == VXM_INTERP_LINEAR || mode == VXM_INTERP_NEAREST, VXM_ERR_UNSUPPORTED, "vxm_warp3d_bwd: mode %d", mode);
+    if (!gsrc && !gflow) return VXM_OK;
+    const size_t V = (size_t)D * H * W;
+    if (gsrc) hipMemsetAsync(gsrc, 0, sizeof(float) * B * C * V, VXM_STREAM(stream));
+    const dim3 grid(vxm_blocks((long long)V, 256), B);
+    if (mode == VXM_INTERP_NEAREST)
+        hipLaunchKernelGGL(k_warp3d_bwd<VXM_INTERP_NEAREST>, grid, dim3(256), 0, VXM_STREAM(stream), src, flow, gout, gsrc, gflow, C, D, H, W);
+    else
+        hipLaunchKernelGGL(k_warp3d_bwd<VXM_INTERP_LINEAR>, grid, dim3(256), 0, VXM_STREAM(stream), src, flow, gout, gsrc, gflow, C, D, H, W);
+    return vxm_check_launch("vxm_warp3d_bwd");
+}
+
+int vxm_vecint_fwd(const float* vec, float* steps, int B, int D, int H, int W, int nsteps, void* stream) {
+    if (int e = check_vol("vxm_vecint_fwd", B, 3, D, H, W)) return e;
+    VXM_REQUIRE(nsteps >= 1 && nsteps < 31, VXM_ERR_BAD_SHAPE, "vxm_vecint_fwd: nsteps should be >= 1, found: %d", nsteps);
+    VXM_REQUIRE(vec && steps, VXM_ERR_NULL_POINTER, "vxm_vecint_fwd: null pointer");
+    const size_t n = (size_t)B * 3 * D * H * W;
+    const dim3 grid(vxm_blocks((long long)D * H * W, 256), B);
+    const float scale = 1.0f / (float)(1u << nsteps);
+    for (int k = 0; k < nsteps; ++k) {
+        const float* in = k == 0 ? vec : steps + (size_t)(k - 1) * n;
+        hipLaunchKernelGGL(k_vecint_step_fwd, grid, dim3(256), 0, VXM_STREAM(stream), in, k == 0 ? scale : 1.0f,
+                           steps + (size_t)k * n, D, H, W);
+    }
+    return vxm_check_launch("vxm_vecint_fwd");
+}
+
+int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, float* gvec, float* work, int B, int D,
+                   int H, int W, int nsteps, void* stream) {
+    if (int e = check_vol("vxm_vecint_bwd", B, 3, D, H, W)) return e;
+    VXM_REQUIRE(nsteps >= 1 && nsteps < 31, VXM_ERR_BAD_SHAPE, "vxm_vecint_bwd: nsteps should be >= 1, found: %d", nsteps);
+    VXM_REQUIRE(vec && steps && gout && gvec && work, VXM_ERR_NULL_POINTER, "vxm_vecint_bwd: null pointer");
+    const size_t n = (size_t)B * 3 * D * H * W;
+    const dim3 grid(vxm_blocks((long long)D * H * W, 256), B);
+    const float scale = 1.0f / (float)(1u << nsteps);
+    const float* g = gout;
+    for (int k = nsteps - 1; k >= 0; --k) {
+        const float* in = k == 0 ? vec : steps + (size_t)(k - 1) * n;
+        float* gn = k == 0 ? gvec : work + (size_t)(k & 1) * n;
+        hipMemsetAsync(gn, 0, sizeof(float) * n, VXM_STREAM(stream));
+        hipLaunchKernelGGL(k_vecint_step_bwd, grid, dim3(256), 0, VXM_STREAM(stream), in, k == 0 ? scale : 1.0f, g, gn, D, H, W);
+        g = gn;
+    }
+    return vxm_check_launch("vxm_vecint_bwd");
+}
+
+static int resize_args(const char* fn, int B, int C, int D, int H, int W, int oD, int oH, int oW, float factor) {
+    if (int e = check_vol(fn, B, C, D, H, W)) return e;
+    VXM_REQUIRE(oD > 0 && oH > 0 && oW > 0 && factor > 0.0f, VXM_ERR_BAD_SHAPE, "%s: bad output shape %dx%dx%d / factor %g", fn, oD, oH, oW, factor);
+    VXM_REQUIRE((long long)B * C <= 65535, VXM_ERR_BAD_SHAPE, "%s: B*C must be <= 65535", fn);
+    return VXM_OK;
+}
+
+int vxm_resize3d_fwd(const float* x, float* out, int B, int C, int D, int H, int W, int oD, int oH, int oW, float factor,
+                     void* stream) {
+    if (int e = resize_args("vxm_resize3d_fwd", B, C, D, H, W, oD, oH, oW, factor)) return e;
+    VXM_REQUIRE(x && out, VXM_ERR_NULL_POINTER, "vxm_resize3d_fwd: null pointer");
+    const float rd = oD > 1 ? (float)(D - 1) / (float)(oD - 1) : 0.0f, rh = oH > 1 ? (float)(H - 1) / (float)(oH - 1) : 0.0f,
+                rw = oW > 1 ? (float)(W - 1) / (float)(oW - 1) : 0.0f;
+    const float pre = factor > 1.0f ? factor : 1.0f, post = factor < 1.0f ? factor : 1.0f;
+    hipLaunchKernelGGL(k_resize3d_fwd, dim3(vxm_blocks((long long)oD * oH * oW, 256), B * C), dim3(256), 0, VXM_STREAM(stream),
+                       x, out, D, H, W, oD, oH, oW, rd, rh, rw, pre, post);
+    return vxm_check_launch("vxm_resize3d_fwd");
+}
+
+int vxm_resize3d_bwd(const float* gout, float* gx, int B, int C, int D, int H, int W, int oD, int oH, int oW, float factor,
+                     void* stream) {
+    if (int e = resize_args("vxm_resize3d_bwd", B, C, D, H, W, oD, oH, oW, factor)) return e;
+    VXM_REQUIRE(gout && gx, VXM_ERR_NULL_POINTER, "vxm_resize3d_bwd: null pointer");
+    const float rd = oD > 1 ? (float)(D - 1) / (float)(oD - 1) : 0.0f, rh = oH > 1 ? (float)(H - 1) / (float)(oH - 1) : 0.0f,
+                rw = oW > 1 ? (float)(W - 1) / (float)(oW - 1) : 0.0f;
+    hipMemsetAsync(gx, 0, sizeof(float) * (size_t)B * C * D * H * W, VXM_STREAM(stream));
+    hipLaunchKernelGGL(k_resize3d_bwd, dim3(vxm_blocks((long long)oD * oH * oW, 256), B * C), dim3(256), 0, VXM_STREAM(stream),
+                       gout, gx, D, H, W, oD, oH, oW, rd, rh, rw, factor);
+    return vxm_check_launch("vxm_resize3d_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,566 @@
+"""torch.autograd.Function wrappers over the C ABI (include/vxm_hip.h).
+
+Each Function replaces one ATen op chain of the reference (file:line in the docstrings) with
+calls into libvxm_hip.so on the current HIP stream.  PyTorch is used for device memory
+(torch.empty through the caching allocator), streams and autograd bookkeeping only.
+"""
+import math
+
+import torch
+
+from .. import _lib
+from .._lib import call, ptr, require_device, stream
+
+INTERP = {"bilinear": 0, "nearest": 1}
+PENALTY = {"l1": 0, "l2": 1}
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _vol3(t, what):
+    if t.dim() != 5:
+        raise NotImplementedError("%s: the MI355X path implements 3-D volumes [B,C,D,H,W]; got %d-D "
+                                  "(2-D support is listed as 'next' in DESIGN.md)" % (what, t.dim() - 2))
+
+
+# --------------------------------------------------------------------------- layers
+class WarpFn(torch.autograd.Function):
+    """SpatialTransformer.forward (voxelmorph/torch/layers.py:30-48)."""
+
+    @staticmethod
+    def forward(ctx, src, flow, mode):
+        _vol3(src, "SpatialTransformer")
+        require_device(src, flow)
+        src, flow = _c(src), _c(flow)
+        B, C, D, H, W = src.shape
+        if tuple(flow.shape) != (B, 3, D, H, W):
+            raise ValueError("flow shape %s does not match src %s" % (tuple(flow.shape), tuple(src.shape)))
+        out = torch.empty_like(src)
+        call("vxm_warp3d_fwd", ptr(src), ptr(flow), ptr(out), B, C, D, H, W, INTERP[mode], stream())
+        ctx.save_for_backward(src, flow)
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        src, flow = ctx.saved_tensors
+        B, C, D, H, W = src.shape
+        gout = _c(gout)
+        gsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
+        gflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
+        call("vxm_warp3d_bwd", ptr(src), ptr(flow), ptr(gout), ptr(gsrc), ptr(gflow), B, C, D, H, W,
+             INTERP[ctx.mode], stream())
+        return gsrc, gflow, None
+
+
+class VecIntFn(torch.autograd.Function):
+    """VecInt.forward (voxelmorph/torch/layers.py:64-68), nsteps >= 1."""
+
+    @staticmethod
+    def forward(ctx, vec, nsteps):
+        _vol3(vec, "VecInt")
+        require_device(vec)
+        vec = _c(vec)
+        B, C, D, H, W = vec.shape
+        if C != 3:
+            raise ValueError("VecInt expects a 3-channel field, got %d" % C)
+        steps = torch.empty((nsteps,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+        call("vxm_vecint_fwd", ptr(vec), ptr(steps), B, D, H, W, nsteps, stream())
+        ctx.save_for_backward(vec, steps)
+        ctx.nsteps = nsteps
+        return steps[nsteps - 1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        vec, steps = ctx.saved_tensors
+        B, _, D, H, W = vec.shape
+        gout = _c(gout)
+        gvec = torch.empty_like(vec)
+        work = torch.empty((2,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+        call("vxm_vecint_bwd", ptr(vec), ptr(steps), ptr(gout), ptr(gvec), ptr(work), B, D, H, W, ctx.nsteps, stream())
+        return gvec, None
+
+
+class ResizeFn(torch.autograd.Function):
+    """ResizeTransform.forward (voxelmorph/torch/layers.py:85-97), factor != 1."""
+
+    @staticmethod
+    def forward(ctx, x, factor):
+        _vol3(x, "ResizeTransform")
+        require_device(x)
+        x = _c(x)
+        B, C, D, H, W = x.shape
+        oD, oH, oW = (int(math.floor(s * factor)) for s in (D, H, W))
+        out = torch.empty((B, C, oD, oH, oW), dtype=x.dtype, device=x.device)
+        call("vxm_resize3d_fwd", ptr(x), ptr(out), B, C, D, H, W, oD, oH, oW, float(factor), stream())
+        ctx.shape = (B, C, D, H, W, oD, oH, oW)
+        ctx.factor = float(factor)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        B, C, D, H, W, oD, oH, oW = ctx.shape
+        gout = _c(gout)
+        gx = torch.empty((B, C, D, H, W), dtype=gout.dtype, device=gout.device)
+        call("vxm_resize3d_bwd", ptr(gout), ptr(gx), B, C, D, H, W, oD, oH, oW, ctx.factor, stream())
+        return gx, None
+
+
+# --------------------------------------------------------------------------- losses
+class NCCFn(torch.autograd.Function):
+    """NCC.loss (voxelmorph/torch/losses.py:15-67)."""
+
+    @staticmethod
+    def forward(ctx, y_true, y_pred, win):
+        _vol3(y_true, "NCC")
+        require_device(y_true, y_pred)
+        I, J = _c(y_true), _c(y_pred)
+        B, C, D, H, W = I.shape
+        if C != 1 or I.shape != J.shape:
+            raise ValueError("NCC: expected two [B,1,D,H,W] tensors (the reference's box filter has one "
+                             "input channel, losses.py:29), got %s / %s" % (tuple(I.shape), tuple(J.shape)))
+        loss = torch.empty((), dtype=I.dtype, device=I.device)
+        sums = torch.empty((5, B, D, H, W), dtype=I.dtype, device=I.device)
+        work = torch.empty((5, B, D, H, W), dtype=I.dtype, device=I.device)
+        acc = torch.empty(1, dtype=torch.float64, device=I.device)
+        call("vxm_ncc_fwd", ptr(I), ptr(J), ptr(loss), ptr(sums), ptr(work), ptr(acc), B, D, H, W, win, stream())
+        ctx.save_for_backward(I, J, sums)
+        ctx.win = win
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        I, J, sums = ctx.saved_tensors
+        B, _, D, H, W = I.shape
+        gloss = _c(gloss)
+        gI = gJ = None
+        work = torch.empty((6, B, D, H, W), dtype=I.dtype, device=I.device)
+        if ctx.needs_input_grad[1]:
+            gJ = torch.empty_like(J)
+            call("vxm_ncc_bwd", ptr(I), ptr(J), ptr(sums), ptr(gloss), ptr(gJ), ptr(work), B, D, H, W, ctx.win, stream())
+        if ctx.needs_input_grad[0]:
+            # cc is symmetric in (I, J): swap the roles (box-sum planes 0<->1 and 2<->3)
+            swapped = torch.stack([sums[1], sums[0], sums[3], sums[2], sums[4]])
+            gI = torch.empty_like(I)
+            call("vxm_ncc_bwd", ptr(J), ptr(I), ptr(swapped), ptr(gloss), ptr(gI), ptr(work), B, D, H, W, ctx.win, stream())
+        return gI, gJ, None
+
+
+class GradLossFn(torch.autograd.Function):
+    """Grad.loss (voxelmorph/torch/losses.py:102-135)."""
+
+    @staticmethod
+    def forward(ctx, y, penalty, mult):
+        _vol3(y, "Grad")
+        require_device(y)
+        y = _c(y)
+        B, C, D, H, W = y.shape
+        loss = torch.empty((), dtype=y.dtype, device=y.device)
+        acc = torch.empty(3 * B, dtype=torch.float64, device=y.device)
+        call("vxm_gradloss_fwd", ptr(y), ptr(loss), ptr(acc), B, C, D, H, W, PENALTY[penalty], float(mult), stream())
+        ctx.save_for_backward(y)
+        ctx.args = (penalty, float(mult))
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (y,) = ctx.saved_tensors
+        B, C, D, H, W = y.shape
+        gy = torch.empty_like(y)
+        call("vxm_gradloss_bwd", ptr(y), ptr(_c(gloss)), ptr(gy), B, C, D, H, W, PENALTY[ctx.args[0]], ctx.args[1], stream())
+        return gy, None, None
+
+
+class MSEFn(torch.autograd.Function):
+    """MSE.loss (voxelmorph/torch/losses.py:75-76)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        require_device(a, b)
+        a, b = _c(a), _c(b)
+        if a.shape != b.shape:
+            raise ValueError("MSE: shapes differ %s / %s" % (tuple(a.shape), tuple(b.shape)))
+        loss = torch.empty((), dtype=a.dtype, device=a.device)
+        acc = torch.empty(1, dtype=torch.float64, device=a.device)
+        call("vxm_mse_fwd", ptr(a), ptr(b), ptr(loss), ptr(acc), a.numel(), stream())
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        a, b = ctx.saved_tensors
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        call("vxm_mse_bwd", ptr(a), ptr(b), ptr(_c(gloss)), ptr(ga), ptr(gb), a.numel(), stream())
+        return ga, gb
+
+
+class DiceFn(torch.autograd.Function):
+    """Dice.loss (voxelmorph/torch/losses.py:84-90)."""
+
+    @staticmethod
+    def forward(ctx, y_true, y_pred):
+        require_device(y_true, y_pred)
+        yt, yp = _c(y_true), _c(y_pred)
+        if yt.shape != yp.shape or yt.dim() < 3:
+            raise ValueError("Dice: expected two [B,C,*vol] tensors of one shape")
+        B, C = yt.shape[:2]
+        V = yt[0, 0].numel()
+        loss = torch.empty((), dtype=yt.dtype, device=yt.device)
+        acc = torch.empty(2 * B * C, dtype=torch.float64, device=yt.device)
+        call("vxm_dice_fwd", ptr(yt), ptr(yp), ptr(loss), ptr(acc), B, C, V, stream())
+        ctx.save_for_backward(yt, yp, acc)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        yt, yp, acc = ctx.saved_tensors
+        B, C = yt.shape[:2]
+        gyt = torch.empty_like(yt) if ctx.needs_input_grad[0] else None
+        gyp = torch.empty_like(yp) if ctx.needs_input_grad[1] else None
+        call("vxm_dice_bwd", ptr(yt), ptr(yp), ptr(acc), ptr(_c(gloss)), ptr(gyt), ptr(gyp), B, C, yt[0, 0].numel(), stream())
+        return gyt, gyp
+
+
+# --------------------------------------------------------------------------- conv helpers
+def pack_weights(w, flip):
+    """[Cout,Cin,3,3,3] -> MFMA A-fragment order (forward operator, or its adjoint if flip)."""
+    cout, cin = w.shape[:2]
+    n = _lib.lib().vxm_conv3d_k3_packed_elems(cout if flip else cin, cin if flip else cout)
+    wp = torch.empty(n, dtype=w.dtype, device=w.device)
+    call("vxm_conv3d_k3_pack_weights", ptr(_c(w)), ptr(wp), cin, cout, 1 if flip else 0, stream())
+    return wp
+
+
+def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
+    call("vxm_conv3d_k3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
+         cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, stream())
+
+
+class _Workspace:
+    """Grow-only scratch shared by the bwd-weight launches of one backward pass."""
+
+    def __init__(self, device):
+        self.buf = None
+        self.device = device
+
+    def get(self, nbytes):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H, W):
+    need = _lib.lib().vxm_conv3d_k3_bwd_weight_workspace_bytes(c0 + c1, cout, B, D, H, W)
+    buf = ws.get(need)
+    call("vxm_conv3d_k3_bwd_weight", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W,
+         cout, ptr(gw), ptr(gb), ptr(buf), buf.numel(), B, D, H, W, stream())
+
+
+class ConvFn(torch.autograd.Function):
+    """One ConvBlock / bare conv (voxelmorph/torch/networks.py:299-305, 211): conv3d(k3,p1) + bias +
+    LeakyReLU(slope) (slope=1: no activation).  Generic single-tensor form used by the standalone
+    modules; the U-Net uses the fused engine below."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope):
+        _vol3(x, "ConvBlock")
+        require_device(x, w, b)
+        x, w = _c(x), _c(w)
+        B, cin, D, H, W = x.shape
+        cout = w.shape[0]
+        if w.shape[1] != cin or tuple(w.shape[2:]) != (3, 3, 3):
+            raise ValueError("conv weight %s does not fit input with %d channels (3x3x3 kernels only)" % (tuple(w.shape), cin))
+        V = D * H * W
+        y = torch.empty((B, cout, D, H, W), dtype=x.dtype, device=x.device)
+        conv_launch(x, cin, cin * V, False, None, 0, 0, pack_weights(w, False), b, y, cout * V, cout, slope, None, 0, 1.0, B, D, H, W)
+        ctx.save_for_backward(x, w, y)
+        ctx.slope = slope
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        B, cin, D, H, W = x.shape
+        cout = w.shape[0]
+        V = D * H * W
+        gy = _c(gy)
+        if ctx.slope != 1.0:
+            dz = torch.empty_like(gy)
+            call("vxm_lrelu_bwd", ptr(gy), cout * V, ptr(y), cout * V, ptr(dz), cout * V, float(ctx.slope), B, cout, V, stream())
+        else:
+            dz = gy
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            conv_launch(dz, cout, cout * V, False, None, 0, 0, pack_weights(w, True), None, gx, cin * V, cin, 1.0, None, 0, 1.0, B, D, H, W)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty_like(w)
+            gb = torch.empty(cout, dtype=w.dtype, device=w.device) if ctx.has_bias else None
+            conv_bwd_weight(_Workspace(x.device), x, cin, cin * V, False, None, 0, 0, dz, cout, gw, gb, B, D, H, W)
+        return gx, gw, gb, None
+
+
+# --------------------------------------------------------------------------- fused U-Net engine
+class UnetPlan:
+    """Static op list of `Unet.forward` (voxelmorph/torch/networks.py:122-144) plus optional trailing
+    bare convs (the VxmDense flow conv, networks.py:211,257).
+
+    Tensors are numbered; ids 0/1 are the network inputs (virtual concat of source and target,
+    networks.py:253).  A conv reads a *virtual tensor* (seg0 id, seg0 upsampled x2?, seg1 id or None),
+    which is how `cat([upsample(x), skip])` (networks.py:137-138) is consumed without being built.
+    """
+
+    def __init__(self, in_channels, enc_nf, dec_nf, final_nf, nb_levels, nb_conv_per_level=1, half_res=False,
+                 extra=()):
+        self.ops = []
+        self.ch = {}
+        self.lvl = {}
+        self.convs = []          # (cin, cout, slope) in parameter order
+        nid = 0
+        for c in in_channels:
+            self.ch[nid] = c
+            self.lvl[nid] = 0
+            nid += 1
+        self.n_inputs = nid
+        cur = (0, False, 1 if nid == 2 else None)
+        hist = []
+
+        def vt_ch(vt):
+            return self.ch[vt[0]] + (self.ch[vt[2]] if vt[2] is not None else 0)
+
+        def vt_lvl(vt):
+            return self.lvl[vt[0]] - (1 if vt[1] else 0)
+
+        def add_conv(vt, cout, slope):
+            nonlocal nid
+            dst = nid
+            nid += 1
+            self.ch[dst] = cout
+            self.lvl[dst] = vt_lvl(vt)
+            self.ops.append(dict(kind="conv", k=len(self.convs), src=vt, dst=dst, slope=slope))
+            self.convs.append((vt_ch(vt), cout, slope))
+            return (dst, False, None)
+
+        for level in range(nb_levels - 1):                      # encoder, networks.py:125-130
+            for c in range(nb_conv_per_level):
+                cur = add_conv(cur, enc_nf[level * nb_conv_per_level + c], 0.2)
+            hist.append(cur[0])
+            dst = nid
+            nid += 1
+            self.ch[dst] = self.ch[cur[0]]
+            self.lvl[dst] = self.lvl[cur[0]] + 1
+            self.ops.append(dict(kind="pool", src=cur[0], dst=dst))
+            cur = (dst, False, None)
+        for level in range(nb_levels - 1):                      # decoder, networks.py:133-138
+            for c in range(nb_conv_per_level):
+                cur = add_conv(cur, dec_nf[level * nb_conv_per_level + c], 0.2)
+            if not half_res or level < (nb_levels - 2):
+                cur = (cur[0], True, hist.pop())
+        for nf in final_nf:                                     # remaining, networks.py:141-142
+            cur = add_conv(cur, nf, 0.2)
+        self.unet_out_channels = vt_ch(cur)
+        for cout, slope in extra:
+            cur = add_conv(cur, cout, slope)
+        if cur[1] or cur[2] is not None:                        # network ends on a concat: materialise it
+            dst = nid
+            nid += 1
+            self.ch[dst] = vt_ch(cur)
+            self.lvl[dst] = vt_lvl(cur)
+            self.ops.append(dict(kind="cat", src=cur, dst=dst))
+            cur = (dst, False, None)
+        self.out = cur[0]
+        self.n_tensors = nid
+        # consumers of every tensor (to decide where gradients come from in backward)
+        self.consumers = {i: [] for i in range(nid)}
+        for n, op in enumerate(self.ops):
+            if op["kind"] == "pool":
+                self.consumers[op["src"]].append(n)
+            else:
+                for sid in (op["src"][0], op["src"][2]):
+                    if sid is not None:
+                        self.consumers[sid].append(n)
+        self.producer = {op["dst"]: n for n, op in enumerate(self.ops)}
+
+
+def _dims(shape3, lvl):
+    return tuple(s >> lvl for s in shape3)
+
+
+class UnetFn(torch.autograd.Function):
+    """Whole U-Net (+ trailing convs) forward/backward on the HIP kernels: 12 MFMA conv launches,
+    4 pool launches forward; backward = per conv one bwd-data launch (the forward kernel with the
+    adjoint weights and the previous block's LeakyReLU' fused in the epilogue) + one bwd-weight
+    launch, plus the fused pool / upsample gradient kernels.  No ATen op is issued."""
+
+    @staticmethod
+    def forward(ctx, plan, *tensors):
+        inputs = [_c(t) for t in tensors[:plan.n_inputs]]
+        params = tensors[plan.n_inputs:]
+        require_device(*inputs)
+        require_device(*params)
+        for t in inputs:
+            _vol3(t, "Unet")
+        B = inputs[0].shape[0]
+        shape3 = tuple(inputs[0].shape[2:])
+        nlev = max(plan.lvl.values())
+        if any(s % (1 << nlev) for s in shape3):
+            raise ValueError("Unet: volume %s must be divisible by %d (MaxPool floors and the skip concat "
+                             "would not line up, networks.py:130,138)" % (shape3, 1 << nlev))
+        dev, dt = inputs[0].device, inputs[0].dtype
+        T = {i: t for i, t in enumerate(inputs)}
+        for i, t in T.items():
+            if t.shape[1] != plan.ch[i] or t.shape[0] != B or tuple(t.shape[2:]) != shape3:
+                raise ValueError("Unet: input %d has shape %s, expected [%d,%d,%s]" % (i, tuple(t.shape), B, plan.ch[i], shape3))
+        for op in plan.ops:
+            dst = op["dst"]
+            D, H, W = _dims(shape3, plan.lvl[dst])
+            V = D * H * W
+            out = torch.empty((B, plan.ch[dst], D, H, W), dtype=dt, device=dev)
+            if op["kind"] == "conv":
+                s0, up0, s1 = op["src"]
+                w, b = params[2 * op["k"]], params[2 * op["k"] + 1]
+                x0, x1 = T[s0], (T[s1] if s1 is not None else None)
+                conv_launch(x0, plan.ch[s0], x0[0].numel(), up0, x1, plan.ch[s1] if s1 is not None else 0,
+                            x1[0].numel() if x1 is not None else 0, pack_weights(w, False), b, out, plan.ch[dst] * V,
+                            plan.ch[dst], op["slope"], None, 0, 1.0, B, D, H, W)
+            elif op["kind"] == "pool":
+                src = T[op["src"]]
+                sD, sH, sW = src.shape[2:]
+                call("vxm_maxpool2_fwd", ptr(src), src[0].numel(), ptr(out), B, plan.ch[dst], sD, sH, sW, stream())
+            else:
+                s0, up0, s1 = op["src"]
+                call("vxm_upsample2_cat", ptr(T[s0]), plan.ch[s0], ptr(T[s1]), plan.ch[s1], ptr(out), B, D, H, W, stream())
+            T[dst] = out
+        ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B = plan, T, params, shape3, B
+        return T[plan.out]
+
+    @staticmethod
+    def backward(ctx, gout):
+        plan, T, params, shape3, B = ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B
+        dev, dt = gout.device, gout.dtype
+        gout = _c(gout)
+        ws = _Workspace(dev)
+        n_in = plan.n_inputs
+        grads = [None] * (n_in + len(params))
+        DZ = {}      # tensor id -> gradient w.r.t. the pre-activation of its producing conv
+        GP = {}      # pool-output id -> gradient w.r.t. the pooled tensor
+        GS = {}      # tensor id -> (buffer, element offset, batch stride): skip-branch gradient view
+        GC = {}      # decoder tensor id -> (buffer, batch stride): gradient of its upsampled copy
+
+        def finish_conv_output(tid, graw, graw_bs):
+            """graw = dL/d(activation output) of tensor tid -> DZ[tid] (leaky_relu_backward)."""
+            op = plan.ops[plan.producer[tid]]
+            D, H, W = _dims(shape3, plan.lvl[tid])
+            V, C = D * H * W, plan.ch[tid]
+            if op["slope"] == 1.0 and graw_bs == C * V:
+                DZ[tid] = graw
+                return
+            dz = torch.empty((B, C, D, H, W), dtype=dt, device=dev)
+            call("vxm_lrelu_bwd", ptr(graw), graw_bs, ptr(T[tid]), C * V, ptr(dz), C * V, float(op["slope"]), B, C, V, stream())
+            DZ[tid] = dz
+
+        # gradient of the network output
+        out_op = plan.ops[plan.producer[plan.out]]
+        if out_op["kind"] == "conv":
+            finish_conv_output(plan.out, gout, gout[0].numel())
+        else:
+            GCAT = gout
+
+        for n in range(len(plan.ops) - 1, -1, -1):
+            op = plan.ops[n]
+            dst = op["dst"]
+            D, H, W = _dims(shape3, plan.lvl[dst])
+            V = D * H * W
+            if op["kind"] == "cat":
+                s0, _, s1 = op["src"]
+                c0 = plan.ch[s0]
+                GC[s0] = (GCAT, GCAT[0].numel())
+                GS[s1] = (GCAT, c0 * V, GCAT[0].numel())
+                _resolve_decoder(plan, T, DZ, GC, s0, B, shape3, dt, dev)
+                continue
+            if op["kind"] == "pool":
+                src = op["src"]
+                sD, sH, sW = _dims(shape3, plan.lvl[src])
+                C = plan.ch[src]
+                dz = torch.empty((B, C, sD, sH, sW), dtype=dt, device=dev)
+                gs = GS.get(src)
+                prod = plan.ops[plan.producer[src]] if src in plan.producer else None
+                slope = prod["slope"] if prod is not None and prod["kind"] == "conv" else 1.0
+                gskip = None
+                gs_bs = 0
+                if gs is not None:
+                    gskip = gs[0].view(-1)[gs[1]:]
+                    gs_bs = gs[2]
+                call("vxm_maxpool2_bwd", ptr(T[src]), T[src][0].numel(), ptr(GP[dst]), ptr(gskip), gs_bs, ptr(dz),
+                     float(slope), B, C, sD, sH, sW, stream())
+                DZ[src] = dz
+                continue
+            # ---- conv
+            s0, up0, s1 = op["src"]
+            w, b = params[2 * op["k"]], params[2 * op["k"] + 1]
+            cout = plan.ch[dst]
+            c0 = plan.ch[s0]
+            c1 = plan.ch[s1] if s1 is not None else 0
+            cin = c0 + c1
+            dz = DZ.pop(dst)
+            x0, x1 = T[s0], (T[s1] if s1 is not None else None)
+            gw = torch.empty_like(w)
+            gb = torch.empty_like(b)
+            conv_bwd_weight(ws, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
+                            gw, gb, B, D, H, W)
+            grads[n_in + 2 * op["k"]] = gw
+            grads[n_in + 2 * op["k"] + 1] = gb
+            feeds_inputs = s0 < n_in
+            if feeds_inputs and not any(ctx.needs_input_grad[1 + i] for i in range(n_in)):
+                continue
+            wp_t = pack_weights(w, True)
+            fuse = (not up0) and s1 is None and (not feeds_inputs) and len(plan.consumers[s0]) == 1 \
+                and plan.ops[plan.producer[s0]]["kind"] == "conv"
+            gx = torch.empty((B, cin, D, H, W), dtype=dt, device=dev)
+            if fuse:   # dX * LeakyReLU'(y_prev) in the epilogue == DZ of the previous ConvBlock
+                pslope = plan.ops[plan.producer[s0]]["slope"]
+                conv_launch(dz, cout, cout * V, False, None, 0, 0, wp_t, None, gx, cin * V, cin, 1.0,
+                            T[s0] if pslope != 1.0 else None, cin * V, pslope, B, D, H, W)
+                DZ[s0] = gx
+                continue
+            conv_launch(dz, cout, cout * V, False, None, 0, 0, wp_t, None, gx, cin * V, cin, 1.0, None, 0, 1.0, B, D, H, W)
+            if feeds_inputs:
+                for i, sid in enumerate([s0] + ([s1] if s1 is not None else [])):
+                    lo = 0 if i == 0 else c0
+                    grads[sid] = gx[:, lo:lo + plan.ch[sid]]
+                continue
+            if up0:
+                GC[s0] = (gx, cin * V)
+                _resolve_decoder(plan, T, DZ, GC, s0, B, shape3, dt, dev)
+            else:
+                prod = plan.ops[plan.producer[s0]]
+                if prod["kind"] == "pool":
+                    GP[s0] = gx if s1 is None else gx[:, :c0].contiguous()
+                else:      # conv output with several consumers (not produced by the reference topologies)
+                    finish_conv_output(s0, gx, cin * V)
+            if s1 is not None:
+                GS[s1] = (gx, c0 * V, cin * V)
+                if not any(plan.ops[m]["kind"] == "pool" for m in plan.consumers[s1]):
+                    g = GS.pop(s1)
+                    finish_conv_output(s1, g[0].view(-1)[g[1]:], g[2])
+        return (None,) + tuple(grads)
+
+
+def _resolve_decoder(plan, T, DZ, GC, tid, B, shape3, dt, dev):
+    """Upsample(2,'nearest') backward (sum over the 2x2x2 children) fused with LeakyReLU' of the
+    decoder ConvBlock that produced tensor `tid`."""
+    buf, bs = GC.pop(tid)
+    D, H, W = _dims(shape3, plan.lvl[tid])
+    C = plan.ch[tid]
+    prod = plan.ops[plan.producer[tid]]
+    dz = torch.empty((B, C, D, H, W), dtype=dt, device=dev)
+    if prod["kind"] == "conv":
+        call("vxm_upsample2_bwd", ptr(buf), bs, ptr(T[tid]) if prod["slope"] != 1.0 else None, ptr(dz),
+             float(prod["slope"]), B, C, D, H, W, stream())
+        DZ[tid] = dz
+    else:
+        raise NotImplementedError("upsampling a non-conv tensor is not produced by Unet topologies")

@@ -1,0 +1,47 @@
+"""Drop-in mirror of `voxelmorph/torch/losses.py` (reference) on the MI355X HIP kernels.
+
+Every class keeps the reference's `loss(y_true, y_pred) -> 0-dim tensor` contract.
+"""
+from . import functional as VF
+
+
+class NCC:
+    """Local (over window) normalized cross correlation loss (reference: losses.py:7-67)."""
+
+    def __init__(self, win=None):
+        self.win = win
+
+    def loss(self, y_true, y_pred):
+        ndims = len(list(y_true.size())) - 2
+        assert ndims in [1, 2, 3], "volumes should be 1 to 3 dimensions. found: %d" % ndims
+        win = [9] * ndims if self.win is None else list(self.win)
+        if ndims != 3 or len(set(win)) != 1 or win[0] % 2 == 0:
+            raise NotImplementedError("the MI355X NCC kernel implements cubic odd windows on 3-D volumes; got win=%s" % (win,))
+        return VF.NCCFn.apply(y_true, y_pred, int(win[0]))
+
+
+class MSE:
+    """Mean squared error loss (reference: losses.py:70-76)."""
+
+    def loss(self, y_true, y_pred):
+        return VF.MSEFn.apply(y_true, y_pred)
+
+
+class Dice:
+    """N-D dice for segmentation (reference: losses.py:79-90)."""
+
+    def loss(self, y_true, y_pred):
+        return VF.DiceFn.apply(y_true, y_pred)
+
+
+class Grad:
+    """N-D gradient loss (reference: losses.py:93-135)."""
+
+    def __init__(self, penalty='l1', loss_mult=None):
+        self.penalty = penalty
+        self.loss_mult = loss_mult
+
+    def loss(self, _, y_pred):
+        if self.penalty != 'l1':
+            assert self.penalty == 'l2', 'penalty can only be l1 or l2. Got: %s' % self.penalty
+        return VF.GradLossFn.apply(y_pred, self.penalty, 1.0 if self.loss_mult is None else float(self.loss_mult))

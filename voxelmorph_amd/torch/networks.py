@@ -1,0 +1,194 @@
+"""Drop-in mirror of `voxelmorph/torch/networks.py` (reference): Unet, ConvBlock, VxmDense.
+
+Parameter names, shapes and initialisation follow the reference so that `state_dict()` keys match
+(`unet_model.encoder.{l}.{c}.main.weight`, ..., `flow.weight`); the forward/backward run on the
+fused HIP engine of `functional.py` instead of ~680 ATen launches per step.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.distributions.normal import Normal
+
+from . import functional as VF
+from . import layers
+from .modelio import LoadableModel, store_config_args
+
+
+def default_unet_features():
+    """reference: voxelmorph/py/utils.py:16-21"""
+    return [[16, 32, 32, 32], [32, 32, 32, 32, 32, 16, 16]]
+
+
+class _Conv3dParams(nn.Module):
+    """Weight/bias holder initialised like torch.nn.Conv3d (kaiming_uniform(a=sqrt(5)) + fan-in bias)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3, 3))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_channels * 27)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, slope=1.0):
+        return VF.ConvFn.apply(x, self.weight, self.bias, slope)
+
+
+class ConvBlock(nn.Module):
+    """Conv3d(3, stride 1, pad 1) + LeakyReLU(0.2) (reference: networks.py:290-305)."""
+
+    def __init__(self, ndims, in_channels, out_channels, stride=1):
+        super().__init__()
+        if ndims != 3 or stride != 1:
+            raise NotImplementedError("the MI355X ConvBlock implements 3-D, stride-1 3x3x3 convolutions")
+        self.main = _Conv3dParams(in_channels, out_channels)
+        self.activation = nn.LeakyReLU(0.2)          # attribute kept for parity; fused into the conv epilogue
+
+    def forward(self, x):
+        return self.main(x, slope=0.2)
+
+
+class Unet(nn.Module):
+    """U-Net with the reference's feature bookkeeping (networks.py:12-144).
+
+    Default features: encoder [16, 32, 32, 32], decoder [32, 32, 32, 32, 32, 16, 16].
+    """
+
+    def __init__(self, inshape=None, infeats=None, nb_features=None, nb_levels=None, max_pool=2, feat_mult=1,
+                 nb_conv_per_level=1, half_res=False):
+        super().__init__()
+        ndims = len(inshape)
+        assert ndims in [1, 2, 3], 'ndims should be one of 1, 2, or 3. found: %d' % ndims
+        if ndims != 3:
+            raise NotImplementedError("the MI355X Unet implements 3-D volumes (DESIGN.md, 'next' rows)")
+        self.half_res = half_res
+        if nb_features is None:
+            nb_features = default_unet_features()
+        if isinstance(nb_features, int):
+            if nb_levels is None:
+                raise ValueError('must provide unet nb_levels if nb_features is an integer')
+            feats = np.round(nb_features * feat_mult ** np.arange(nb_levels)).astype(int)
+            nb_features = [np.repeat(feats[:-1], nb_conv_per_level), np.repeat(np.flip(feats), nb_conv_per_level)]
+        elif nb_levels is not None:
+            raise ValueError('cannot use nb_levels if nb_features is not an integer')
+        enc_nf, dec_nf = [[int(f) for f in fs] for fs in nb_features]
+        nb_dec_convs = len(enc_nf)
+        final_convs = dec_nf[nb_dec_convs:]
+        dec_nf = dec_nf[:nb_dec_convs]
+        self.nb_levels = int(nb_dec_convs / nb_conv_per_level) + 1
+        if isinstance(max_pool, int):
+            max_pool = [max_pool] * self.nb_levels
+        if any(p != 2 for p in max_pool):
+            raise NotImplementedError("the MI355X Unet implements max_pool=2")
+        self.nb_conv_per_level = nb_conv_per_level
+        self._enc_nf, self._dec_nf, self._final_nf = enc_nf, dec_nf, list(final_convs)
+        self._infeats = infeats
+
+        prev_nf = infeats
+        encoder_nfs = [prev_nf]
+        self.encoder = nn.ModuleList()
+        for level in range(self.nb_levels - 1):
+            convs = nn.ModuleList()
+            for conv in range(nb_conv_per_level):
+                nf = enc_nf[level * nb_conv_per_level + conv]
+                convs.append(ConvBlock(ndims, prev_nf, nf))
+                prev_nf = nf
+            self.encoder.append(convs)
+            encoder_nfs.append(prev_nf)
+        encoder_nfs = encoder_nfs[::-1]
+        self.decoder = nn.ModuleList()
+        for level in range(self.nb_levels - 1):
+            convs = nn.ModuleList()
+            for conv in range(nb_conv_per_level):
+                nf = dec_nf[level * nb_conv_per_level + conv]
+                convs.append(ConvBlock(ndims, prev_nf, nf))
+                prev_nf = nf
+            self.decoder.append(convs)
+            if not half_res or level < (self.nb_levels - 2):
+                prev_nf += encoder_nfs[level]
+        self.remaining = nn.ModuleList()
+        for nf in final_convs:
+            self.remaining.append(ConvBlock(ndims, prev_nf, nf))
+            prev_nf = nf
+        self.final_nf = prev_nf
+        self._plans = {}
+
+    def conv_params(self):
+        """[w0, b0, w1, b1, ...] in execution order (encoder, decoder, remaining)."""
+        out = []
+        for group in list(self.encoder) + list(self.decoder):
+            for blk in group:
+                out += [blk.main.weight, blk.main.bias]
+        for blk in self.remaining:
+            out += [blk.main.weight, blk.main.bias]
+        return out
+
+    def plan(self, in_channels, extra=()):
+        key = (tuple(in_channels), tuple(extra))
+        if key not in self._plans:
+            if sum(in_channels) != self._infeats:
+                raise ValueError("Unet built for %d input features, got %s" % (self._infeats, list(in_channels)))
+            self._plans[key] = VF.UnetPlan(list(in_channels), self._enc_nf, self._dec_nf, self._final_nf, self.nb_levels,
+                                           self.nb_conv_per_level, self.half_res, extra=extra)
+        return self._plans[key]
+
+    def forward(self, x):
+        return VF.UnetFn.apply(self.plan([x.shape[1]]), x, *self.conv_params())
+
+
+class VxmDense(LoadableModel):
+    """VoxelMorph network for (unsupervised) nonlinear registration between two images
+    (reference: networks.py:147-287; same constructor arguments, attributes and return values)."""
+
+    @store_config_args
+    def __init__(self, inshape, nb_unet_features=None, nb_unet_levels=None, unet_feat_mult=1, nb_unet_conv_per_level=1,
+                 int_steps=7, int_downsize=2, bidir=False, use_probs=False, src_feats=1, trg_feats=1, unet_half_res=False):
+        super().__init__()
+        self.training = True
+        ndims = len(inshape)
+        assert ndims in [1, 2, 3], 'ndims should be one of 1, 2, or 3. found: %d' % ndims
+        self.unet_model = Unet(inshape, infeats=(src_feats + trg_feats), nb_features=nb_unet_features,
+                               nb_levels=nb_unet_levels, feat_mult=unet_feat_mult,
+                               nb_conv_per_level=nb_unet_conv_per_level, half_res=unet_half_res)
+        self.flow = _Conv3dParams(self.unet_model.final_nf, ndims)
+        self.flow.weight = nn.Parameter(Normal(0, 1e-5).sample(self.flow.weight.shape))
+        self.flow.bias = nn.Parameter(torch.zeros(self.flow.bias.shape))
+        if use_probs:
+            raise NotImplementedError('Flow variance has not been implemented in pytorch - set use_probs to False')
+        if not unet_half_res and int_steps > 0 and int_downsize > 1:
+            self.resize = layers.ResizeTransform(int_downsize, ndims)
+        else:
+            self.resize = None
+        if int_steps > 0 and int_downsize > 1:
+            self.fullsize = layers.ResizeTransform(1 / int_downsize, ndims)
+        else:
+            self.fullsize = None
+        self.bidir = bidir
+        down_shape = [int(dim / int_downsize) for dim in inshape]
+        self.integrate = layers.VecInt(down_shape, int_steps) if int_steps > 0 else None
+        self.transformer = layers.SpatialTransformer(inshape)
+        self._feats = (src_feats, trg_feats)
+
+    def forward(self, source, target, registration=False):
+        # U-Net + flow conv as ONE fused autograd node; source/target enter as a virtual concat
+        plan = self.unet_model.plan(self._feats, extra=((self.flow.out_channels, 1.0),))
+        flow_field = VF.UnetFn.apply(plan, source, target, *self.unet_model.conv_params(), self.flow.weight, self.flow.bias)
+        pos_flow = flow_field
+        if self.resize:
+            pos_flow = self.resize(pos_flow)
+        preint_flow = pos_flow
+        neg_flow = -pos_flow if self.bidir else None
+        if self.integrate:
+            pos_flow = self.integrate(pos_flow)
+            neg_flow = self.integrate(neg_flow) if self.bidir else None
+            if self.fullsize:
+                pos_flow = self.fullsize(pos_flow)
+                neg_flow = self.fullsize(neg_flow) if self.bidir else None
+        y_source = self.transformer(source, pos_flow)
+        y_target = self.transformer(target, neg_flow) if self.bidir else None
+        if not registration:
+            return (y_source, y_target, preint_flow) if self.bidir else (y_source, preint_flow)
+        return y_source, pos_flow
