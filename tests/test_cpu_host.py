@@ -1,0 +1,214 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol, the host mirror keeps the
+reference's API surface / checkpoint format, the product refuses to run without a HIP device, and the
+data-parallel path is correct by construction (world_size-2 gloo)."""
+import inspect
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+import voxelmorph_amd as vxm                      # noqa: E402
+from voxelmorph_amd import _lib                   # noqa: E402
+from oracle import ref_loader                     # noqa: E402
+from oracle import vxm_oracle as orc              # noqa: E402
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built_library():
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["bash", os.path.join(ROOT, "voxelmorph_amd", "csrc", "build.sh")])
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "vxm_hip.h")).read()
+    declared = set(re.findall(r"\b(vxm_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = set(re.findall(r" T (vxm_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+    h = _lib.lib()                                  # ctypes load + argtypes for every entry point
+    assert h.vxm_version() >= 100
+    assert h.vxm_conv3d_k3_packed_elems(48, 32) == 6 * 27 * 2 * 2 * 64
+    assert h.vxm_conv3d_k3_bwd_weight_workspace_bytes(64, 32, 1, 8, 8, 16) > 0
+
+
+def test_kernels_are_gfx950_only():
+    blob = open(_lib.LIB_PATH, "rb").read()
+    archs = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
+    assert archs == {b"gfx950"}, archs
+
+
+def test_no_cpu_fallback():
+    st = vxm.layers.SpatialTransformer((8, 8, 8))
+    with pytest.raises(_lib.VxmHipError, match="no CPU fallback"):
+        st(torch.zeros(1, 1, 8, 8, 8), torch.zeros(1, 3, 8, 8, 8))
+    with pytest.raises(_lib.VxmHipError):
+        vxm.losses.MSE().loss(torch.zeros(4), torch.zeros(4))
+    model = vxm.networks.VxmDense((16, 16, 16))
+    with pytest.raises(_lib.VxmHipError):
+        model(torch.zeros(1, 1, 16, 16, 16), torch.zeros(1, 1, 16, 16, 16))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "voxelmorph_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("oracle/", "").lower() or f == "_none_", (dirpath, f)
+
+
+def test_api_surface_matches_reference_signatures():
+    sig = inspect.signature(vxm.networks.VxmDense.__init__)
+    assert list(sig.parameters)[1:] == ["inshape", "nb_unet_features", "nb_unet_levels", "unet_feat_mult",
+                                        "nb_unet_conv_per_level", "int_steps", "int_downsize", "bidir", "use_probs",
+                                        "src_feats", "trg_feats", "unet_half_res"]
+    assert sig.parameters["int_steps"].default == 7 and sig.parameters["int_downsize"].default == 2
+    assert list(inspect.signature(vxm.layers.SpatialTransformer.__init__).parameters)[1:] == ["size", "mode"]
+    assert list(inspect.signature(vxm.layers.VecInt.__init__).parameters)[1:] == ["inshape", "nsteps"]
+    assert list(inspect.signature(vxm.layers.ResizeTransform.__init__).parameters)[1:] == ["vel_resize", "ndims"]
+    assert list(inspect.signature(vxm.networks.Unet.__init__).parameters)[1:] == [
+        "inshape", "infeats", "nb_features", "nb_levels", "max_pool", "feat_mult", "nb_conv_per_level", "half_res"]
+    assert list(inspect.signature(vxm.losses.Grad.__init__).parameters)[1:] == ["penalty", "loss_mult"]
+    m = vxm.networks.VxmDense((32, 32, 32))
+    for attr in ("unet_model", "flow", "resize", "fullsize", "bidir", "integrate", "transformer", "config"):
+        assert hasattr(m, attr)
+    assert m.integrate.nsteps == 7 and m.integrate.scale == 1 / 128 and m.resize.factor == 0.5 and m.fullsize.factor == 2
+    assert m.resize.mode == "trilinear" and m.transformer.grid.dtype == torch.float32
+    assert m.transformer.grid.shape == (1, 3, 32, 32, 32) and float(m.transformer.grid[0, 1, 3, 7, 2]) == 7.0
+    assert float(m.flow.weight.abs().max()) < 1e-3 and float(m.flow.bias.abs().max()) == 0.0       # networks.py:214-215
+    with pytest.raises(NotImplementedError):
+        vxm.networks.VxmDense((32, 32, 32), use_probs=True)
+    with pytest.raises(AssertionError):
+        vxm.layers.VecInt((8, 8, 8), -1)
+    with pytest.raises(ValueError):
+        vxm.networks.Unet((32, 32, 32), infeats=2, nb_features=8)          # int features need nb_levels
+    with pytest.raises(ValueError):
+        vxm.networks.Unet((32, 32, 32), infeats=2, nb_features=[[8], [8]], nb_levels=2)
+    m0 = vxm.networks.VxmDense((32, 32, 32), int_steps=0)
+    assert m0.integrate is None and m0.resize is None and m0.fullsize is None
+
+
+def test_state_dict_and_checkpoint_format(g_network, tmp_path):
+    m = vxm.networks.VxmDense((16, 16, 16))
+    keys = list(m.state_dict().keys())
+    assert keys == [str(k) for k in g_network["state_keys"]]
+    assert [str(tuple(v.shape)) for v in m.state_dict().values()] == [str(s) for s in g_network["state_shapes"]]
+    assert sum(p.numel() for p in m.parameters()) == int(g_network["n_params"]) == 327331
+    path = os.path.join(tmp_path, "ck.pt")
+    m.save(path)
+    ck = torch.load(path)
+    assert set(ck) == {"config", "model_state"} and not any(k.endswith(".grid") for k in ck["model_state"])
+    assert ck["config"] == dict(inshape=(16, 16, 16), nb_unet_features=None, nb_unet_levels=None, unet_feat_mult=1,
+                                nb_unet_conv_per_level=1, int_steps=7, int_downsize=2, bidir=False, use_probs=False,
+                                src_feats=1, trg_feats=1, unet_half_res=False)
+    again = vxm.networks.VxmDense.load(path, "cpu")
+    for (k, a), (_, b) in zip(m.state_dict().items(), again.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="reference tree not present")
+def test_checkpoint_interop_with_live_reference(tmp_path):
+    ref = ref_loader.load_reference()
+    mine = vxm.networks.VxmDense((16, 16, 16), int_steps=5)
+    p1 = os.path.join(tmp_path, "mine.pt")
+    mine.save(p1)
+    theirs = ref.networks.VxmDense.load(p1, "cpu")                  # our file -> reference loader
+    for k, v in mine.state_dict().items():
+        assert torch.equal(v, theirs.state_dict()[k]), k
+    p2 = os.path.join(tmp_path, "theirs.pt")
+    theirs.save(p2)
+    back = vxm.networks.VxmDense.load(p2, "cpu")                    # reference file -> our loader
+    assert back.config == theirs.config
+    for k, v in theirs.state_dict().items():
+        assert torch.equal(v, back.state_dict()[k]), k
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(nb_features=[[4, 8], [8, 8, 4]]), dict(nb_features=8, nb_levels=3, nb_conv_per_level=2),
+                                dict(half_res=True), dict(nb_features=[[8, 8], [8, 8]])])
+def test_unet_plan_matches_reference_bookkeeping(kw):
+    net = vxm.networks.Unet((32, 32, 32), infeats=2, **kw)
+    plan = net.plan([2])
+    shapes = orc.state_dict_shapes((32, 32, 32), **kw)[:-2]          # drop the flow conv
+    want = [(s[1], s[0]) for n, s in shapes if n.endswith("weight")]
+    assert [(c[0], c[1]) for c in plan.convs] == want
+    assert plan.ch[plan.out] == net.final_nf
+    names = ["unet_model." + n for n, _ in net.named_parameters()]
+    assert names == [n for n, _ in shapes]
+
+
+def test_shard_range_and_flat_bucket():
+    from voxelmorph_amd import dist as vdist
+    from voxelmorph_amd.optim import FlatAdam
+    assert vdist.shard_range(32, 3, 8) == (12, 16)
+    with pytest.raises(AssertionError, match="multiple of the nr of gpus"):
+        vdist.shard_range(6, 0, 4)
+    m = vxm.networks.VxmDense((16, 16, 16))
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    opt = FlatAdam(m, lr=1e-4)
+    assert opt.n == 327331 and opt.flat_param.is_contiguous()
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    ptrs = [p.data_ptr() for p in m.parameters()]
+    assert ptrs[0] == opt.flat_param.data_ptr() and sorted(ptrs) == ptrs            # views into one bucket, in order
+    with pytest.raises(_lib.VxmHipError):
+        opt.step()                                                                 # Adam is a HIP kernel
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import voxelmorph_amd as vxm
+from voxelmorph_amd import dist as vdist
+from voxelmorph_amd.optim import FlatAdam
+from oracle import vxm_oracle as orc
+rank, local, world = vdist.init_from_env(backend="gloo")
+inshape = (16, 16, 16)
+rng = np.random.default_rng(3)
+src = torch.from_numpy(rng.random((2, 1) + inshape).astype(np.float32))
+trg = torch.from_numpy(rng.random((2, 1) + inshape).astype(np.float32))
+lo, hi = vdist.shard_range(2, rank, world)
+model = vxm.networks.VxmDense(inshape, int_steps=2)
+model.load_state_dict(orc.seeded_state_dict(inshape, seed=rank, flow_std=0.1), strict=False)   # ranks start different
+opt = FlatAdam(model, lr=1e-4, direct_grads=False)
+opt.broadcast_params(0)                                                                        # ... and are made equal
+sd = {k: v for k, v in model.named_parameters()}
+loss, _ = orc.train_step_loss(src[lo:hi], trg[lo:hi], sd, "mse", 0.01, int_steps=2)         # oracle = compute on CPU
+loss.backward()
+opt.load_grads_from_params()
+opt.reduce_grads()
+mean_grad = opt.flat_grad / world
+# single-process reference on the global batch
+ref = vxm.networks.VxmDense(inshape, int_steps=2)
+ref.load_state_dict(orc.seeded_state_dict(inshape, seed=0, flow_std=0.1), strict=False)
+rsd = {k: v for k, v in ref.named_parameters()}
+rl, _ = orc.train_step_loss(src, trg, rsd, "mse", 0.01, int_steps=2)
+rl.backward()
+rg = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+rel = float((mean_grad - rg).norm() / rg.norm())
+lt = torch.tensor([float(loss)], dtype=torch.float64)
+dist.all_reduce(lt)
+assert rel < 1e-5, rel
+assert abs(float(lt) / world - float(rl)) < 1e-6
+assert vdist.max_over_ranks(float(rank), "cpu") == world - 1
+vdist.barrier()
+print("rank", rank, "ok", rel)
+"""
+
+
+def test_data_parallel_equivalence_gloo_world2(tmp_path):
+    script = os.path.join(tmp_path, "worker.py")
+    with open(script, "w") as f:
+        f.write(_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", script],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2

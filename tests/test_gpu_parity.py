@@ -1,0 +1,400 @@
+"""Parity tests proper: the HIP path (through the C ABI, via voxelmorph_amd) against the oracle and the
+golden fixtures produced by the unmodified reference.  Run on the MI355X box: `pytest -m gpu`.
+
+Tolerances (SURVEY.md §8c / BASELINE.md §4): nearest warp + index grid bit-exact; trilinear warp
+<= 1e-5 abs; integrated flows <= 1e-4 abs; conv activations rel-L2 <= 1e-5; NCC <= 1e-3 vs the fp32
+oracle and <= 1e-5 vs the fp64 arbiter; parameter gradients rel-L2 <= 1e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import vxm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vxm():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    import voxelmorph_amd
+    from voxelmorph_amd import _lib
+    _lib.lib()                     # fails loudly if libvxm_hip.so is missing
+    return voxelmorph_amd
+
+
+def G(a, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    return t.requires_grad_() if grad else t
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+# ------------------------------------------------------------------ SpatialTransformer
+def test_warp_trilinear_golden(vxm, g_layers):
+    st = vxm.layers.SpatialTransformer(g_layers["warp_src"].shape[2:]).cuda()
+    s, f = G(g_layers["warp_src"], True), G(g_layers["warp_flow"], True)
+    out = st(s, f)
+    np.testing.assert_allclose(N(out), g_layers["warp_out"], atol=1e-5, rtol=0)
+    out.backward(G(g_layers["warp_gout"]))
+    np.testing.assert_allclose(N(s.grad), g_layers["warp_gsrc"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(N(f.grad), g_layers["warp_gflow"], atol=2e-5, rtol=0)
+
+
+def test_warp_nearest_bit_exact_golden(vxm, g_layers):
+    vol = g_layers["near_seg"].shape[2:]
+    st = vxm.layers.SpatialTransformer(vol, mode="nearest").cuda()
+    out = st(G(g_layers["near_seg"]), G(g_layers["near_flow"]))
+    assert np.array_equal(N(out), g_layers["near_out"])
+    ident = st(G(g_layers["near_seg"]), torch.zeros(1, 3, *vol, device="cuda"))
+    assert np.array_equal(N(ident), g_layers["near_seg"])
+
+
+@pytest.mark.parametrize("vol", [(20, 24, 28), (17, 33, 65), (40, 48, 56)])
+def test_warp_nearest_bit_exact_vs_oracle(vxm, vol):
+    rng = np.random.default_rng(sum(vol))
+    seg = rng.integers(0, 40, size=(2, 3) + vol).astype(np.float32)
+    flow = np.concatenate([rng.integers(-9, 10, size=(1, 3) + vol) * 0.5,           # ties
+                           rng.standard_normal((1, 3) + vol) * 4.0]).astype(np.float32)  # generic + out of range
+    out = vxm.layers.SpatialTransformer(vol, mode="nearest").cuda()(G(seg), G(flow))
+    ref = c_oracle.warp3d(seg, flow, mode="nearest")
+    assert np.array_equal(N(out), ref), "mismatches: %d" % int((N(out) != ref).sum())
+    ref_t = orc.spatial_transformer(torch.from_numpy(seg), torch.from_numpy(flow), mode="nearest").numpy()
+    assert np.array_equal(N(out), ref_t)
+
+
+@pytest.mark.parametrize("vol,C", [((12, 20, 70), 1), ((33, 18, 21), 4)])
+def test_warp_trilinear_vs_oracle(vxm, vol, C):
+    rng = np.random.default_rng(5)
+    src = rng.random((2, C) + vol).astype(np.float32)
+    flow = (rng.standard_normal((2, 3) + vol) * 3).astype(np.float32)
+    gout = rng.standard_normal((2, C) + vol).astype(np.float32)
+    s, f = G(src, True), G(flow, True)
+    out = vxm.layers.SpatialTransformer(vol).cuda()(s, f)
+    out.backward(G(gout))
+    so, fo = torch.from_numpy(src).requires_grad_(), torch.from_numpy(flow).requires_grad_()
+    ref = orc.spatial_transformer(so, fo)
+    ref.backward(torch.from_numpy(gout))
+    np.testing.assert_allclose(N(out), ref.detach().numpy(), atol=1e-5, rtol=0)
+    np.testing.assert_allclose(N(s.grad), so.grad.numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(N(f.grad), fo.grad.numpy(), atol=5e-5, rtol=0)
+    np.testing.assert_allclose(N(out), c_oracle.warp3d(src, flow), atol=1e-5, rtol=0)
+
+
+def test_warp_errors(vxm):
+    st = vxm.layers.SpatialTransformer((8, 8, 8)).cuda()
+    with pytest.raises(RuntimeError):
+        st(torch.zeros(1, 1, 8, 8, 8), torch.zeros(1, 3, 8, 8, 8))        # CPU tensors: no fallback
+    with pytest.raises(RuntimeError):
+        st(torch.zeros(1, 1, 8, 8, 8).cuda(), torch.zeros(1, 3, 4, 8, 8).cuda())
+    with pytest.raises(ValueError):
+        vxm.layers.SpatialTransformer((8, 8, 8), mode="bicubic")
+
+
+# ------------------------------------------------------------------ VecInt / Resize
+def test_vecint_golden(vxm, g_layers):
+    vol = g_layers["vecint_in"].shape[2:]
+    vi = vxm.layers.VecInt(vol, 7).cuda()
+    v = G(g_layers["vecint_in"], True)
+    out = vi(v)
+    np.testing.assert_allclose(N(out), g_layers["vecint_out"], atol=1e-4, rtol=0)
+    out.backward(G(g_layers["vecint_gout"]))
+    np.testing.assert_allclose(N(v.grad), g_layers["vecint_gin"], atol=2e-4, rtol=1e-4)
+    with pytest.raises(AssertionError):
+        vxm.layers.VecInt(vol, -1)
+    z = vxm.layers.VecInt(vol, 7).cuda()(torch.zeros(1, 3, *vol, device="cuda"))
+    assert float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("nsteps", [1, 4])
+def test_vecint_vs_oracle(vxm, nsteps):
+    vol = (16, 20, 36)
+    rng = np.random.default_rng(nsteps)
+    vec = (rng.standard_normal((2, 3) + vol) * 2).astype(np.float32)
+    gout = rng.standard_normal((2, 3) + vol).astype(np.float32)
+    v = G(vec, True)
+    out = vxm.layers.VecInt(vol, nsteps).cuda()(v)
+    out.backward(G(gout))
+    vo = torch.from_numpy(vec).requires_grad_()
+    ref = orc.vecint(vo, nsteps)
+    ref.backward(torch.from_numpy(gout))
+    np.testing.assert_allclose(N(out), ref.detach().numpy(), atol=1e-4, rtol=0)
+    np.testing.assert_allclose(N(v.grad), vo.grad.numpy(), atol=2e-4, rtol=1e-4)
+
+
+def test_resize_golden(vxm, g_layers):
+    x = G(g_layers["resize_in"], True)
+    down = vxm.layers.ResizeTransform(2, 3)(x)
+    np.testing.assert_allclose(N(down), g_layers["resize_down"], atol=2e-6, rtol=0)
+    down.backward(G(g_layers["resize_gdown"]))
+    np.testing.assert_allclose(N(x.grad), g_layers["resize_down_gin"], atol=1e-5, rtol=0)
+    x2 = G(g_layers["resize_in"], True)
+    up = vxm.layers.ResizeTransform(0.5, 3)(x2)
+    np.testing.assert_allclose(N(up), g_layers["resize_up"], atol=2e-6, rtol=0)
+    up.backward(G(g_layers["resize_gup"]))
+    np.testing.assert_allclose(N(x2.grad), g_layers["resize_up_gin"], atol=2e-5, rtol=0)
+    assert vxm.layers.ResizeTransform(1, 3)(x) is x
+
+
+# ------------------------------------------------------------------ losses
+def test_ncc_golden(vxm, g_losses):
+    I, J = G(g_losses["I"]), G(g_losses["J"], True)
+    l = vxm.losses.NCC().loss(I, J)
+    assert abs(float(l) - float(g_losses["ncc"])) < 1e-3                       # vs fp32 reference
+    assert abs(float(l) - orc.ncc_explicit(g_losses["I"], g_losses["J"])) < 1e-5  # vs fp64 arbiter
+    l.backward()
+    assert rel_l2(N(J.grad), g_losses["ncc_gJ"]) < 1e-3
+    J5 = G(g_losses["J"], True)
+    l5 = vxm.losses.NCC(win=[5, 5, 5]).loss(I, J5)
+    assert abs(float(l5) - float(g_losses["ncc5"])) < 1e-3
+    l5.backward()
+    assert rel_l2(N(J5.grad), g_losses["ncc5_gJ"]) < 1e-3
+    with pytest.raises(NotImplementedError):
+        vxm.losses.NCC(win=[9, 9, 5]).loss(I, J)
+
+
+def test_ncc_grad_vs_fp64(vxm):
+    rng = np.random.default_rng(2)
+    vol = (24, 20, 40)
+    I = rng.random((1, 1) + vol).astype(np.float32)
+    J = (0.5 * I + 0.5 * rng.random((1, 1) + vol)).astype(np.float32)
+    Jg = G(J, True)
+    Ig = G(I, True)
+    l = vxm.losses.NCC().loss(Ig, Jg)
+    l.backward()
+    Jd = torch.from_numpy(J).double().requires_grad_()
+    Id = torch.from_numpy(I).double().requires_grad_()
+    ld = orc.ncc_loss(Id, Jd)
+    ld.backward()
+    assert abs(float(l) - float(ld)) < 1e-5
+    assert rel_l2(N(Jg.grad), Jd.grad.numpy()) < 1e-3
+    assert rel_l2(N(Ig.grad), Id.grad.numpy()) < 1e-3
+
+
+def test_grad_mse_dice_golden(vxm, g_losses):
+    for pen, mult in (("l1", None), ("l2", 2)):
+        fl = G(g_losses["flow"], True)
+        l = vxm.losses.Grad(pen, loss_mult=mult).loss(None, fl)
+        np.testing.assert_allclose(float(l), g_losses["grad_%s" % pen], rtol=1e-5)
+        l.backward()
+        np.testing.assert_allclose(N(fl.grad), g_losses["grad_%s_g" % pen], atol=1e-8, rtol=1e-4)
+    with pytest.raises(AssertionError):
+        vxm.losses.Grad("l3").loss(None, G(g_losses["flow"]))
+    J = G(g_losses["J"], True)
+    m = vxm.losses.MSE().loss(G(g_losses["I"]), J)
+    np.testing.assert_allclose(float(m), g_losses["mse"], rtol=1e-5)
+    m.backward()
+    np.testing.assert_allclose(N(J.grad), g_losses["mse_gJ"], atol=1e-9, rtol=1e-4)
+    yp = G(g_losses["dice_pred"], True)
+    d = vxm.losses.Dice().loss(G(g_losses["dice_true"]), yp)
+    np.testing.assert_allclose(float(d), g_losses["dice"], rtol=1e-5)
+    d.backward()
+    np.testing.assert_allclose(N(yp.grad), g_losses["dice_g"], atol=1e-9, rtol=1e-4)
+
+
+# ------------------------------------------------------------------ conv / pool / U-Net
+@pytest.mark.parametrize("cin,cout,vol,slope", [
+    (2, 16, (8, 8, 16), 0.2), (16, 32, (8, 12, 16), 0.2), (32, 32, (5, 6, 7), 0.2), (48, 32, (4, 8, 32), 0.2),
+    (64, 32, (8, 4, 16), 0.2), (16, 3, (9, 10, 33), 1.0), (5, 7, (6, 7, 19), 0.2), (20, 40, (4, 4, 16), 0.2),
+])
+def test_conv_block_vs_oracle(vxm, cin, cout, vol, slope):
+    from voxelmorph_amd.torch import functional as VF
+    rng = np.random.default_rng(cin * 100 + cout)
+    x = rng.standard_normal((2, cin) + vol).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, 3, 3, 3)) / np.sqrt(27 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    gy = rng.standard_normal((2, cout) + vol).astype(np.float32)
+    xg, wg, bg = G(x, True), G(w, True), G(b, True)
+    y = VF.ConvFn.apply(xg, wg, bg, slope)
+    y.backward(G(gy))
+    xo, wo, bo = (torch.from_numpy(a).double().requires_grad_() for a in (x, w, b))
+    yo = orc.conv_block(xo, wo, bo, slope)
+    yo.backward(torch.from_numpy(gy).double())
+    assert rel_l2(N(y), yo.detach().numpy()) < 1e-5
+    assert rel_l2(N(xg.grad), xo.grad.numpy()) < 1e-5
+    assert rel_l2(N(wg.grad), wo.grad.numpy()) < 1e-5
+    assert rel_l2(N(bg.grad), bo.grad.numpy()) < 1e-5
+
+
+def test_conv_block_module_matches_c_arbiter(vxm):
+    blk = vxm.networks.ConvBlock(3, 3, 4).cuda()
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((1, 3, 5, 6, 7)).astype(np.float32)
+    y = blk(G(x))
+    ref = c_oracle.conv3d_k3(x, N(blk.main.weight), N(blk.main.bias))
+    np.testing.assert_allclose(N(y), ref, atol=2e-5)
+
+
+def test_maxpool_ties_first_index(vxm):
+    """All-equal input: ATen routes the gradient to the first element of each 2x2x2 block."""
+    from voxelmorph_amd._lib import call, ptr, stream
+    x = torch.ones(1, 2, 4, 4, 4, device="cuda")
+    gp = torch.arange(16, dtype=torch.float32, device="cuda").reshape(1, 2, 2, 2, 2) + 1
+    dz = torch.empty_like(x)
+    call("vxm_maxpool2_bwd", ptr(x), x[0].numel(), ptr(gp), None, 0, ptr(dz), 1.0, 1, 2, 4, 4, 4, stream())
+    xo = torch.ones(1, 2, 4, 4, 4, requires_grad=True)
+    torch.nn.functional.max_pool3d(xo, 2).backward(gp.cpu())
+    assert torch.equal(dz.cpu(), xo.grad)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(nb_features=[[4, 8], [8, 8, 4]]), dict(nb_features=8, nb_levels=3, nb_conv_per_level=2),
+                                dict(half_res=True), dict(nb_features=[[8, 8], [8, 8]])])
+def test_unet_vs_oracle(vxm, kw):
+    inshape = (16, 16, 32)
+    net = vxm.networks.Unet(inshape, infeats=2, **kw).cuda()
+    sd = {("unet_model." + k): v for k, v in net.state_dict().items()}
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 2) + inshape).astype(np.float32)
+    xg = G(x, True)
+    y = net(xg)
+    sdo = {k: v.detach().cpu().double().requires_grad_() for k, v in sd.items()}
+    xo = torch.from_numpy(x).double().requires_grad_()
+    okw = {k: v for k, v in kw.items()}
+    yo = orc.unet_forward(xo, sdo, **okw)
+    assert y.shape == yo.shape and y.shape[1] == net.final_nf
+    assert rel_l2(N(y), yo.detach().numpy()) < 1e-5
+    gy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(G(gy))
+    yo.backward(torch.from_numpy(gy).double())
+    for name, p in net.named_parameters():
+        assert rel_l2(N(p.grad), sdo["unet_model." + name].grad.numpy()) < 1e-4, name
+    assert rel_l2(N(xg.grad), xo.grad.numpy()) < 1e-4
+
+
+# ------------------------------------------------------------------ VxmDense (golden, produced by the reference)
+CASES = {
+    "diffeo": dict(int_steps=7, int_downsize=2, bidir=False, loss="ncc", lam=1.0),
+    "dense": dict(int_steps=0, int_downsize=2, bidir=False, loss="mse", lam=0.01),
+    "bidir": dict(int_steps=3, int_downsize=2, bidir=True, loss="mse", lam=0.01),
+}
+
+
+def _build(vxm, g_network, cfg):
+    inshape = tuple(int(v) for v in g_network["inshape"])
+    model = vxm.networks.VxmDense(inshape, int_steps=cfg["int_steps"], int_downsize=cfg["int_downsize"], bidir=cfg["bidir"])
+    sd = orc.seeded_state_dict(inshape, seed=5, flow_std=0.2)
+    res = model.load_state_dict(sd, strict=False)
+    assert all(k.endswith(".grid") for k in res.missing_keys) and not res.unexpected_keys
+    return model.cuda()
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_vxm_dense_golden(vxm, g_network, tag):
+    cfg = CASES[tag]
+    model = _build(vxm, g_network, cfg)
+    src, trg = G(g_network["source"]), G(g_network["target"])
+    pred = model(src, trg)
+    img_fn = vxm.losses.NCC().loss if cfg["loss"] == "ncc" else vxm.losses.MSE().loss
+    if cfg["bidir"]:
+        img = 0.5 * img_fn(trg, pred[0]) + 0.5 * img_fn(src, pred[1])
+        np.testing.assert_allclose(N(pred[1]), g_network[tag + "_y_target"], atol=2e-5, rtol=0)
+    else:
+        img = img_fn(trg, pred[0])
+    reg = vxm.losses.Grad("l2", loss_mult=cfg["int_downsize"]).loss(None, pred[-1])
+    loss = img + cfg["lam"] * reg
+    np.testing.assert_allclose(N(pred[0]), g_network[tag + "_y_source"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(N(pred[-1]), g_network[tag + "_preint"], atol=2e-5, rtol=0)
+    ref = g_network[tag + "_loss"]
+    assert abs(float(loss) - ref[0]) < 1e-3 * max(1.0, abs(ref[0]))
+    assert abs(float(reg) - ref[2]) < 1e-4 * max(1.0, abs(ref[2]))
+    loss.backward()
+    names = [str(n) for n in g_network[tag + "_grad_names"]]
+    norms = g_network[tag + "_grad_norms"]
+    params = dict(model.named_parameters())
+    tol = 2e-3 if cfg["loss"] == "ncc" else 1e-4      # NCC's fp32 formula is ill-conditioned
+    for n, r in zip(names, norms):
+        got = float(params[n].grad.double().norm())
+        assert abs(got - r) <= tol * max(r, 1e-12), (n, got, r)
+    for key in g_network.files:
+        if key.startswith(tag + "_grad_") and key not in (tag + "_grad_names", tag + "_grad_norms"):
+            pname = key[len(tag + "_grad_"):]
+            assert rel_l2(N(params[pname].grad), g_network[key]) < tol, pname
+    with torch.no_grad():
+        _, pos = model(src, trg, registration=True)
+    np.testing.assert_allclose(N(pos), g_network[tag + "_pos_flow"], atol=1e-4, rtol=0)
+    # one Adam step through the fused flat-buffer optimiser (train.py:161,218-220)
+    from voxelmorph_amd.optim import FlatAdam
+    opt = FlatAdam(model, lr=1e-4)
+    opt.load_grads_from_params()
+    opt.step()
+    assert rel_l2(N(model.flow.weight), g_network[tag + "_flow_weight_after_adam"]) < 1e-4
+    assert rel_l2(N(model.unet_model.encoder[0][0].main.weight), g_network[tag + "_enc0_weight_after_adam"]) < 1e-5
+
+
+def test_checkpoint_roundtrip_reference_format(vxm, g_network, tmp_path):
+    model = _build(vxm, g_network, CASES["diffeo"])
+    path = os.path.join(tmp_path, "m.pt")
+    model.save(path)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"config", "model_state"}
+    keys = [str(k) for k in g_network["state_keys"] if not str(k).endswith(".grid")]
+    assert list(ck["model_state"].keys()) == keys
+    assert ck["config"]["int_steps"] == 7 and ck["config"]["inshape"] == tuple(int(v) for v in g_network["inshape"])
+    again = vxm.networks.VxmDense.load(path, "cuda")
+    for (k, a), (_, b) in zip(model.state_dict().items(), again.state_dict().items()):
+        assert torch.equal(a.cpu(), b.cpu()), k
+
+
+# ------------------------------------------------------------------ full benchmark size (160x192x224): properties
+FULL = (160, 192, 224)
+
+
+def test_full_size_identity_and_nearest(vxm):
+    rng = np.random.default_rng(0)
+    seg = torch.from_numpy(rng.integers(0, 46, size=(1, 1) + FULL).astype(np.float32)).cuda()
+    zero = torch.zeros(1, 3, *FULL, device="cuda")
+    assert torch.equal(vxm.layers.SpatialTransformer(FULL, mode="nearest").cuda()(seg, zero), seg)      # index grid exact
+    img = torch.rand(1, 1, *FULL, device="cuda")
+    out = vxm.layers.SpatialTransformer(FULL).cuda()(img, zero)
+    assert float((out - img).abs().max()) <= 1e-5
+    # integer shift by +1 voxel along W == slicing (away from the border), for both modes
+    shift = zero.clone()
+    shift[:, 2] = 1.0
+    for mode in ("nearest", "bilinear"):
+        o = vxm.layers.SpatialTransformer(FULL, mode=mode).cuda()(img, shift)
+        assert float((o[..., :-1] - img[..., 1:]).abs().max()) <= 1e-5
+        assert float(o[..., -1].abs().max()) == 0.0                                                   # zeros padding
+
+
+def test_full_size_dice_of_warped_labels_matches_oracle(vxm):
+    rng = np.random.default_rng(1)
+    lab = rng.integers(0, 30, size=(1, 1, 40, 48, 56)).astype(np.float32)
+    seg = np.kron(lab, np.ones((1, 1, 4, 4, 4), np.float32))                 # blocky label map at 160x192x224
+    flow = orc.resize_explicit((rng.standard_normal((1, 3, 20, 24, 28)) * 0.6).astype(np.float32), 1 / 8)   # smooth, |v| ~ 5
+    warped = N(vxm.layers.SpatialTransformer(FULL, mode="nearest").cuda()(G(seg), G(flow)))
+    ref = c_oracle.warp3d(seg, flow, mode="nearest")
+    assert np.array_equal(warped, ref)
+    labels = np.arange(1, 30)
+    d_gpu = orc.dice_metric(warped[0, 0], seg[0, 0], labels).mean()
+    d_ref = orc.dice_metric(ref[0, 0], seg[0, 0], labels).mean()
+    assert abs(d_gpu - d_ref) <= 1e-3
+
+
+def test_full_size_train_step_runs_and_is_linear_in_lr(vxm):
+    from voxelmorph_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    model = vxm.networks.VxmDense(FULL, int_steps=7, int_downsize=2).cuda()
+    opt = FlatAdam(model, lr=1e-4)
+    src, trg = torch.rand(1, 1, *FULL, device="cuda"), torch.rand(1, 1, *FULL, device="cuda")
+    losses = []
+    for _ in range(2):
+        opt.zero_grad()
+        y, pre = model(src, trg)
+        loss = vxm.losses.NCC().loss(trg, y) + vxm.losses.Grad("l2", loss_mult=2).loss(None, pre)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and -1.0 <= losses[0] <= 0.0
+    assert y.shape == (1, 1) + FULL and pre.shape == (1, 3, 80, 96, 112)
+    assert float(opt.flat_grad.abs().sum()) > 0

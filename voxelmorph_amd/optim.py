@@ -1,0 +1,75 @@
+"""Flat-buffer Adam for the VxmDense path.
+
+The reference trains with `torch.optim.Adam(model.parameters(), lr)` (scripts/torch/train.py:161)
+over 24 small tensors and, multi-GPU, `torch.nn.DataParallel` (train.py:151-154).  Here all 327,331
+parameters live in ONE contiguous fp32 buffer and so do their gradients: the gradient buffer is the
+single RCCL all-reduce bucket (1.31 MB) and one `vxm_adam_step` launch updates everything, with the
+1/world_size averaging folded in.  Update rule and defaults match torch.optim.Adam.
+"""
+import torch
+
+from ._lib import call, ptr, require_device, stream
+
+
+class FlatAdam:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, direct_grads=True):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatAdam: model has no trainable parameters")
+        dev = self.params[0].device
+        self.n = sum(p.numel() for p in self.params)
+        self.flat_param = torch.empty(self.n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(self.n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros_like(self.flat_grad)
+        self.exp_avg_sq = torch.zeros_like(self.flat_grad)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        self.group = process_group
+        self.world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+        off = 0
+        self._views = []
+        for p in self.params:
+            n = p.numel()
+            self.flat_param[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_param[off:off + n].view(p.shape)
+            gview = self.flat_grad[off:off + n].view(p.shape)
+            self._views.append(gview)
+            # the fused U-Net backward writes parameter gradients straight into the bucket
+            p._vxm_grad_sink = gview if direct_grads else None
+            off += n
+        self.direct = direct_grads
+
+    def broadcast_params(self, src=0):
+        """One-off: make every rank start from rank `src`'s weights (replaces DataParallel's per-step
+        broadcast_coalesced)."""
+        if self.world > 1:
+            torch.distributed.broadcast(self.flat_param, src, group=self.group)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def load_grads_from_params(self):
+        """Gather autograd-produced `p.grad` tensors into the flat bucket (non-direct mode / tests)."""
+        for p, g in zip(self.params, self._views):
+            if p.grad is not None and p.grad.data_ptr() != g.data_ptr():
+                g.copy_(p.grad)
+
+    def reduce_grads(self):
+        """The only data-path collective: SUM all-reduce of the flat gradient bucket (RCCL over xGMI when
+        the backend is 'nccl'; gloo in the CPU tests).  The 1/world average is applied by the Adam kernel."""
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+
+    def step(self):
+        if not self.direct:
+            self.load_grads_from_params()
+        self.reduce_grads()
+        require_device(self.flat_param)            # the update itself is a HIP kernel: no CPU fallback
+        self.step_count += 1
+        call("vxm_adam_step", ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
+             float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count,
+             1.0 / self.world, stream())

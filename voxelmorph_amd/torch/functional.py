@@ -9,6 +9,7 @@ import math
 import torch
 
 from .. import _lib
+from .. import profiler as _prof
 from .._lib import call, ptr, require_device, stream
 
 INTERP = {"bilinear": 0, "nearest": 1}
@@ -38,7 +39,8 @@ class WarpFn(torch.autograd.Function):
         if tuple(flow.shape) != (B, 3, D, H, W):
             raise ValueError("flow shape %s does not match src %s" % (tuple(flow.shape), tuple(src.shape)))
         out = torch.empty_like(src)
-        call("vxm_warp3d_fwd", ptr(src), ptr(flow), ptr(out), B, C, D, H, W, INTERP[mode], stream())
+        with _prof.region("warp3d_fwd", nbytes=4.0 * B * D * H * W * (2 * C + 3)):
+            call("vxm_warp3d_fwd", ptr(src), ptr(flow), ptr(out), B, C, D, H, W, INTERP[mode], stream())
         ctx.save_for_backward(src, flow)
         ctx.mode = mode
         return out
@@ -50,8 +52,9 @@ class WarpFn(torch.autograd.Function):
         gout = _c(gout)
         gsrc = torch.empty_like(src) if ctx.needs_input_grad[0] else None
         gflow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
-        call("vxm_warp3d_bwd", ptr(src), ptr(flow), ptr(gout), ptr(gsrc), ptr(gflow), B, C, D, H, W,
-             INTERP[ctx.mode], stream())
+        with _prof.region("warp3d_bwd", nbytes=4.0 * B * D * H * W * (2 * C + 6 + (C if gsrc is not None else 0))):
+            call("vxm_warp3d_bwd", ptr(src), ptr(flow), ptr(gout), ptr(gsrc), ptr(gflow), B, C, D, H, W,
+                 INTERP[ctx.mode], stream())
         return gsrc, gflow, None
 
 
@@ -67,7 +70,8 @@ class VecIntFn(torch.autograd.Function):
         if C != 3:
             raise ValueError("VecInt expects a 3-channel field, got %d" % C)
         steps = torch.empty((nsteps,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
-        call("vxm_vecint_fwd", ptr(vec), ptr(steps), B, D, H, W, nsteps, stream())
+        with _prof.region("vecint_fwd", nbytes=24.0 * B * D * H * W * nsteps):
+            call("vxm_vecint_fwd", ptr(vec), ptr(steps), B, D, H, W, nsteps, stream())
         ctx.save_for_backward(vec, steps)
         ctx.nsteps = nsteps
         return steps[nsteps - 1]
@@ -79,7 +83,8 @@ class VecIntFn(torch.autograd.Function):
         gout = _c(gout)
         gvec = torch.empty_like(vec)
         work = torch.empty((2,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
-        call("vxm_vecint_bwd", ptr(vec), ptr(steps), ptr(gout), ptr(gvec), ptr(work), B, D, H, W, ctx.nsteps, stream())
+        with _prof.region("vecint_bwd", nbytes=36.0 * B * D * H * W * ctx.nsteps):
+            call("vxm_vecint_bwd", ptr(vec), ptr(steps), ptr(gout), ptr(gvec), ptr(work), B, D, H, W, ctx.nsteps, stream())
         return gvec, None
 
 
@@ -94,7 +99,8 @@ class ResizeFn(torch.autograd.Function):
         B, C, D, H, W = x.shape
         oD, oH, oW = (int(math.floor(s * factor)) for s in (D, H, W))
         out = torch.empty((B, C, oD, oH, oW), dtype=x.dtype, device=x.device)
-        call("vxm_resize3d_fwd", ptr(x), ptr(out), B, C, D, H, W, oD, oH, oW, float(factor), stream())
+        with _prof.region("resize3d_fwd", nbytes=4.0 * B * C * (D * H * W + oD * oH * oW)):
+            call("vxm_resize3d_fwd", ptr(x), ptr(out), B, C, D, H, W, oD, oH, oW, float(factor), stream())
         ctx.shape = (B, C, D, H, W, oD, oH, oW)
         ctx.factor = float(factor)
         return out
@@ -104,7 +110,8 @@ class ResizeFn(torch.autograd.Function):
         B, C, D, H, W, oD, oH, oW = ctx.shape
         gout = _c(gout)
         gx = torch.empty((B, C, D, H, W), dtype=gout.dtype, device=gout.device)
-        call("vxm_resize3d_bwd", ptr(gout), ptr(gx), B, C, D, H, W, oD, oH, oW, ctx.factor, stream())
+        with _prof.region("resize3d_bwd", nbytes=4.0 * B * C * (D * H * W + oD * oH * oW)):
+            call("vxm_resize3d_bwd", ptr(gout), ptr(gx), B, C, D, H, W, oD, oH, oW, ctx.factor, stream())
         return gx, None
 
 
@@ -125,7 +132,8 @@ class NCCFn(torch.autograd.Function):
         sums = torch.empty((5, B, D, H, W), dtype=I.dtype, device=I.device)
         work = torch.empty((5, B, D, H, W), dtype=I.dtype, device=I.device)
         acc = torch.empty(1, dtype=torch.float64, device=I.device)
-        call("vxm_ncc_fwd", ptr(I), ptr(J), ptr(loss), ptr(sums), ptr(work), ptr(acc), B, D, H, W, win, stream())
+        with _prof.region("ncc_fwd", nbytes=8.0 * B * D * H * W):
+            call("vxm_ncc_fwd", ptr(I), ptr(J), ptr(loss), ptr(sums), ptr(work), ptr(acc), B, D, H, W, win, stream())
         ctx.save_for_backward(I, J, sums)
         ctx.win = win
         return loss
@@ -139,7 +147,8 @@ class NCCFn(torch.autograd.Function):
         work = torch.empty((6, B, D, H, W), dtype=I.dtype, device=I.device)
         if ctx.needs_input_grad[1]:
             gJ = torch.empty_like(J)
-            call("vxm_ncc_bwd", ptr(I), ptr(J), ptr(sums), ptr(gloss), ptr(gJ), ptr(work), B, D, H, W, ctx.win, stream())
+            with _prof.region("ncc_bwd", nbytes=12.0 * B * D * H * W):
+                call("vxm_ncc_bwd", ptr(I), ptr(J), ptr(sums), ptr(gloss), ptr(gJ), ptr(work), B, D, H, W, ctx.win, stream())
         if ctx.needs_input_grad[0]:
             # cc is symmetric in (I, J): swap the roles (box-sum planes 0<->1 and 2<->3)
             swapped = torch.stack([sums[1], sums[0], sums[3], sums[2], sums[4]])
@@ -234,9 +243,15 @@ def pack_weights(w, flip):
     return wp
 
 
+def conv_variant(cin, cout):
+    """Kernel template instance the C ABI dispatches to (conv.hip: conv_cfg)."""
+    return "conv3d_k3<CK=%d,NCT=%d>" % (4 if cin <= 4 else 8, 1 if cout <= 16 else 2)
+
+
 def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
-    call("vxm_conv3d_k3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
-         cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, stream())
+    with _prof.region(conv_variant(c0 + c1, cout), flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+        call("vxm_conv3d_k3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
+             cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, stream())
 
 
 class _Workspace:
@@ -255,8 +270,9 @@ class _Workspace:
 def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H, W):
     need = _lib.lib().vxm_conv3d_k3_bwd_weight_workspace_bytes(c0 + c1, cout, B, D, H, W)
     buf = ws.get(need)
-    call("vxm_conv3d_k3_bwd_weight", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W,
-         cout, ptr(gw), ptr(gb), ptr(buf), buf.numel(), B, D, H, W, stream())
+    with _prof.region("conv3d_k3_bwd_weight<NCT=%d>" % (1 if cout <= 16 else 2), flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+        call("vxm_conv3d_k3_bwd_weight", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W,
+             cout, ptr(gw), ptr(gb), ptr(buf), buf.numel(), B, D, H, W, stream())
 
 
 class ConvFn(torch.autograd.Function):
@@ -508,12 +524,15 @@ class UnetFn(torch.autograd.Function):
             cin = c0 + c1
             dz = DZ.pop(dst)
             x0, x1 = T[s0], (T[s1] if s1 is not None else None)
-            gw = torch.empty_like(w)
-            gb = torch.empty_like(b)
+            # parameter gradients go straight into the optimiser's flat bucket when one is attached
+            # (voxelmorph_amd.optim.FlatAdam): no per-tensor accumulate / copy launches
+            gw_sink, gb_sink = getattr(w, "_vxm_grad_sink", None), getattr(b, "_vxm_grad_sink", None)
+            gw = gw_sink if gw_sink is not None else torch.empty_like(w)
+            gb = gb_sink if gb_sink is not None else torch.empty_like(b)
             conv_bwd_weight(ws, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
                             gw, gb, B, D, H, W)
-            grads[n_in + 2 * op["k"]] = gw
-            grads[n_in + 2 * op["k"] + 1] = gb
+            grads[n_in + 2 * op["k"]] = None if gw_sink is not None else gw
+            grads[n_in + 2 * op["k"] + 1] = None if gb_sink is not None else gb
             feeds_inputs = s0 < n_in
             if feeds_inputs and not any(ctx.needs_input_grad[1 + i] for i in range(n_in)):
                 continue
