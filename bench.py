@@ -46,7 +46,9 @@ def cpu_baseline(full_shape, sample_shape, int_steps):
     voxel ratio to volume-pairs/s at the full shape.  Reported baseline, not the optimisation target."""
     import numpy as np
     from oracle import vxm_oracle as orc
-    cores = os.cpu_count() or 1
+    # torch's intra-op pool degrades badly beyond one socket's worth of threads (256 threads on the
+    # 2x64-core bench host ran 10x slower than 8 threads elsewhere): use at most 32 and report that number
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     rng = np.random.default_rng(1234)
     src = torch.from_numpy(rng.random((1, 1) + sample_shape).astype(np.float32))

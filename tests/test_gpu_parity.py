@@ -136,12 +136,12 @@ def test_vecint_vs_oracle(vxm, nsteps):
 def test_resize_golden(vxm, g_layers):
     x = G(g_layers["resize_in"], True)
     down = vxm.layers.ResizeTransform(2, 3)(x)
-    np.testing.assert_allclose(N(down), g_layers["resize_down"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(N(down), g_layers["resize_down"], atol=1e-6, rtol=2e-6)
     down.backward(G(g_layers["resize_gdown"]))
     np.testing.assert_allclose(N(x.grad), g_layers["resize_down_gin"], atol=1e-5, rtol=0)
     x2 = G(g_layers["resize_in"], True)
     up = vxm.layers.ResizeTransform(0.5, 3)(x2)
-    np.testing.assert_allclose(N(up), g_layers["resize_up"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(N(up), g_layers["resize_up"], atol=1e-6, rtol=2e-6)     # values up to ~8 (x2 rescale)
     up.backward(G(g_layers["resize_gup"]))
     np.testing.assert_allclose(N(x2.grad), g_layers["resize_up_gin"], atol=2e-5, rtol=0)
     assert vxm.layers.ResizeTransform(1, 3)(x) is x
@@ -357,13 +357,17 @@ def test_full_size_identity_and_nearest(vxm):
     assert torch.equal(vxm.layers.SpatialTransformer(FULL, mode="nearest").cuda()(seg, zero), seg)      # index grid exact
     img = torch.rand(1, 1, *FULL, device="cuda")
     out = vxm.layers.SpatialTransformer(FULL).cuda()(img, zero)
-    assert float((out - img).abs().max()) <= 1e-5
+    # not exact in the reference either: its normalise/un-normalise round trip perturbs integer coordinates
+    # by up to 7.6e-6 per axis, i.e. up to ~2.3e-5 on U[0,1) noise
+    assert float((out - img).abs().max()) <= 3e-5
+    ref = orc.spatial_transformer(img.cpu(), zero.cpu())            # the oracle carries the same perturbation
+    assert float((out.cpu() - ref).abs().max()) <= 1e-5
     # integer shift by +1 voxel along W == slicing (away from the border), for both modes
     shift = zero.clone()
     shift[:, 2] = 1.0
     for mode in ("nearest", "bilinear"):
         o = vxm.layers.SpatialTransformer(FULL, mode=mode).cuda()(img, shift)
-        assert float((o[..., :-1] - img[..., 1:]).abs().max()) <= 1e-5
+        assert float((o[..., :-1] - img[..., 1:]).abs().max()) <= (0.0 if mode == "nearest" else 3e-5)
         assert float(o[..., -1].abs().max()) == 0.0                                                   # zeros padding
 
 

@@ -38,28 +38,52 @@ struct ConvIn {                // virtual concat of two channel segments (see in
     int C0, C1, up0;
 };
 
-// Value of virtual input channel c of sample b at voxel (d,h,w); zero outside the volume
-// (padding=1) and for channel padding.
-__device__ __forceinline__ float load_in(const ConvIn& in, int b, int c, int d, int h, int w, int D, int H, int W) {
-    if ((unsigned)d >= (unsigned)D || (unsigned)h >= (unsigned)H || (unsigned)w >= (unsigned)W) return 0.0f;
-    if (c < in.C0) {
-        if (in.up0) {
-            const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
-            return in.x0[(size_t)b * in.bs0 + ((size_t)c * D2 + (d >> 1)) * H2 * W2 + (size_t)(h >> 1) * W2 + (w >> 1)];
-        }
-        return in.x0[(size_t)b * in.bs0 + ((size_t)c * D + d) * H * W + (size_t)h * W + w];
-    }
-    c -= in.C0;
-    if (c < in.C1) return in.x1[(size_t)b * in.bs1 + ((size_t)c * D + d) * H * W + (size_t)h * W + w];
-    return 0.0f;
-}
-
 __device__ __forceinline__ void tile_origin(int tile, int D, int H, int W, int& b, int& d0, int& h0, int& w0) {
     const int nw = (W + TW - 1) / TW, nh = (H + TH - 1) / TH, nd = (D + TD - 1) / TD;
     const int tw = tile % nw; int t = tile / nw;
     const int th = t % nh; t /= nh;
     const int td = t % nd; b = t / nd;
     d0 = td * TD; h0 = th * TH; w0 = tw * TW;
+}
+
+// Row-slab gather used by both conv kernels: one wave-instruction fetches 3 haloed rows (18 floats
+// each, lanes 54..63 idle) of one (channel, depth) slab, so the channel / depth part of the address
+// is wave-uniform (SALU) and the row / column part is a per-lane constant of the tile.
+struct SlabLane {
+    int rr, wx;        // row inside the 3-row group, column inside the haloed row
+    int gh0, gw;       // global row of row-group 0 and global column of this lane (may be -1 / >= extent)
+    bool act, wok;     // lane carries data; column inside the volume
+};
+
+__device__ __forceinline__ SlabLane make_slab_lane(int lane, int h0, int w0, int W) {
+    SlabLane L;
+    L.rr = lane / HW; L.wx = lane - L.rr * HW;
+    L.act = lane < 3 * HW;
+    L.gw = w0 + L.wx - 1; L.gh0 = h0 + L.rr - 1;
+    L.wok = L.act && (unsigned)L.gw < (unsigned)W;
+    return L;
+}
+
+// Value of virtual input channel cg at depth d for this lane's (row, column).  b, cg, d, hb are
+// wave-uniform: the 64-bit base is SALU math (s_cselect, no branches), the lane contributes a 32-bit
+// offset.  The load is UNCONDITIONAL on a clamped in-bounds address and the padding zeros are applied
+// by a select afterwards: branch-free, so the unrolled loads of one chunk issue back-to-back.
+__device__ __forceinline__ float slab_load(const float* x0, const float* x1, long long bs0, long long bs1, int C0, int C1, int up0,
+                                           const SlabLane& L, int b, int cg, int d, int hb, int D, int H, int W) {
+    const bool uok = (unsigned)d < (unsigned)D && cg < C0 + C1;       // uniform validity
+    const int cgc = min(cg, C0 + C1 - 1), dc = min(max(d, 0), D - 1);
+    const bool s0 = cgc < C0;
+    const int sh = (s0 && up0) ? 1 : 0;                               // x2 nearest upsampling of segment 0
+    const float* p = s0 ? x0 + (size_t)b * bs0 : x1 + (size_t)b * bs1;
+    const int cc = s0 ? cgc : cgc - C0;
+    const int Ds = D >> sh, Hs = H >> sh, Ws = W >> sh;
+    const float* base = p + ((size_t)cc * Ds + (dc >> sh)) * Hs * Ws;
+    const int gh = L.gh0 + 3 * hb;
+    const bool ok = L.wok && (unsigned)gh < (unsigned)H;
+    // 32-bit BYTE offset (planes are < 4 GB): lets the load use the SGPR-base + 32-bit-VGPR-offset form
+    const unsigned boff = ok ? (unsigned)((gh >> sh) * Ws + (L.gw >> sh)) << 2 : 0u;
+    const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
+    return (ok && uok) ? v : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -79,12 +103,15 @@ __global__ void __launch_bounds__(256) k_conv3d_k3(ConvIn in, const float* __res
     constexpr int KS = CK / 4;
     constexpr int WCHUNK = 27 * KS * NCT * 64;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform -> SALU address math
     const int kq = lane >> 4, n = lane & 15;
     int b, d0, h0, w0;
     tile_origin(blockIdx.x, D, H, W, b, d0, h0, w0);
     const int g = blockIdx.y;                       // output-channel group of 16*NCT
-    const int Cin = in.C0 + in.C1;
+    const float* const ix0 = in.x0; const float* const ix1 = in.x1;
+    const long long ibs0 = in.bs0, ibs1 = in.bs1;
+    const int iC0 = in.C0, iC1 = in.C1, iup0 = in.up0;
 
     f32x4 acc[NCT][4];
 #pragma unroll
@@ -94,23 +121,42 @@ __global__ void __launch_bounds__(256) k_conv3d_k3(ConvIn in, const float* __res
 
     const int bbase = kq * FWD_PS + (wave * HH) * FWD_TWP + n;
 
-    for (int q = 0; q < Q; ++q) {
-        // ---- stage the haloed input tile of channels [q*CK, q*CK+CK)
-        for (int i = tid; i < CK * HVOX; i += 256) {
-            const int c = i / HVOX, rem = i - c * HVOX;
-            const int dz = rem / (HH * HW), r2 = rem - dz * (HH * HW);
-            const int hy = r2 / HW, wx = r2 - hy * HW;
-            const int cg = q * CK + c;
-            const float v = cg < Cin ? load_in(in, b, cg, d0 + dz - 1, h0 + hy - 1, w0 + wx - 1, D, H, W) : 0.0f;
-            Xs[c * FWD_PS + (dz * HH + hy) * FWD_TWP + wx] = v;
+    // ---- staging: global -> registers (prefetched under the previous chunk's MFMAs) -> LDS
+    constexpr int XIT = CK * 3;                         // 3-row slab groups per wave per chunk
+    constexpr int WIT = (WCHUNK / 4 + 255) / 256;       // float4 weight pieces per thread per chunk
+    const SlabLane L = make_slab_lane(lane, h0, w0, W);
+    const int lds_lane = L.rr * FWD_TWP + L.wx;
+    float xv[XIT];
+    f32x4 wv[WIT];
+
+    auto prefetch = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int c = wave * (CK / 4) + it / 12, dz = (it % 12) >> 1, hb = it & 1;   // channel / depth: wave-uniform
+            xv[it] = slab_load(ix0, ix1, ibs0, ibs1, iC0, iC1, iup0, L, b, q * CK + c, d0 + dz - 1, hb, D, H, W);
         }
-        // ---- stage the packed weights of this (group, chunk)
-        {
-            const float4* src = reinterpret_cast<const float4*>(wp + ((size_t)g * Q + q) * WCHUNK);
-            float4* dst = reinterpret_cast<float4*>(Ws);
-            for (int i = tid; i < WCHUNK / 4; i += 256) dst[i] = src[i];
+        const f32x4* src = reinterpret_cast<const f32x4*>(wp + ((size_t)g * Q + q) * WCHUNK);
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = tid + it * 256;
+            wv[it] = src[min(i, WCHUNK / 4 - 1)];      // clamped: the LDS store below is predicated
+        }
+    };
+
+    prefetch(0);
+    for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int c = wave * (CK / 4) + it / 12, dz = (it % 12) >> 1, hb = it & 1;
+            if (L.act) Xs[c * FWD_PS + (dz * HH + hb * 3) * FWD_TWP + lds_lane] = xv[it];
+        }
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < WCHUNK / 4) reinterpret_cast<f32x4*>(Ws)[i] = wv[it];
         }
         __syncthreads();
+        if (q + 1 < Q) prefetch(q + 1);                 // loads stay in flight across the MFMA phase
         // ---- 27 taps x KS k-steps x (NCT x 4) MFMAs
 #pragma unroll
         for (int t = 0; t < 27; ++t) {
@@ -131,29 +177,58 @@ __global__ void __launch_bounds__(256) k_conv3d_k3(ConvIn in, const float* __res
         __syncthreads();
     }
 
-    // ---- epilogue: bias + LeakyReLU (+ fused leaky_relu_backward mask), NCDHW store
+    // ---- epilogue: bias + LeakyReLU (+ fused leaky_relu_backward mask), NCDHW store.
+    // All bias / mask loads are issued first (clamped addresses, no branches), then the math + stores.
     const int d = d0 + wave, w = w0 + n;
-    if (d >= D || w >= W) return;
     const size_t V = (size_t)D * H * W;
+    const bool vox_ok = d < D && w < W;
+    const size_t vox_off = ((size_t)min(d, D - 1) * H) * W + min(w, W - 1);
+    float bz[NCT][4], mk[NCT][4][4];
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bz[ct][j] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mk[ct][j][r] = 1.0f;
+        }
+    if (bias) {                                   // hoisted uniform tests: the loads inside issue back-to-back
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bz[ct][j] = bias[min((g * NCT + ct) * 16 + kq * 4 + j, Cout - 1)];
+    }
+    if (mask) {
+        const float* mb = mask + (size_t)b * mask_bs + vox_off;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = min((g * NCT + ct) * 16 + kq * 4 + j, Cout - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mk[ct][j][r] = mb[(size_t)co * V + (size_t)min(h0 + r, H - 1) * W];
+            }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mk[ct][j][r] = vxm_lrelu_grad(mk[ct][j][r], mask_slope);
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int co = (g * NCT + ct) * 16 + kq * 4 + j;
-            if (co >= Cout) continue;
-            const float bz = bias ? bias[co] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int h = h0 + r;
-                if (h >= H) continue;
-                const size_t off = (size_t)co * V + ((size_t)d * H + h) * W + w;
-                float v = acc[ct][r][j] + bz;
-                v = v > 0.0f ? v : v * act_slope;
-                if (mask) v *= vxm_lrelu_grad(mask[(size_t)b * mask_bs + off], mask_slope);
-                y[(size_t)b * y_bs + off] = v;
+                float v = acc[ct][r][j] + bz[ct][j];
+                v = (v > 0.0f ? v : v * act_slope) * mk[ct][j][r];
+                if (vox_ok && h < H && co < Cout)
+                    y[(size_t)b * y_bs + (size_t)co * V + ((size_t)d * H + h) * W + w] = v;
             }
         }
-    }
 }
 
 struct ConvCfg { int CK, NCT, Q, G; size_t elems; };
@@ -200,9 +275,13 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight(ConvIn in, 
     VXM_DYN_SMEM(float, smem);
     float* Xs = smem;                          // [16][BW_PSX]
     float* Zs = smem + BW_CKI * BW_PSX;        // [16*NCT][BW_PZ]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int kq = lane >> 4, n = lane & 15;
-    const int Cin = in.C0 + in.C1;
+    const float* const ix0 = in.x0; const float* const ix1 = in.x1;
+    const long long ibs0 = in.bs0, ibs1 = in.bs1;
+    const int iC0 = in.C0, iC1 = in.C1, iup0 = in.up0;
+    const int Cin = iC0 + iC1;
     const int c0 = blockIdx.y * BW_CKI;
     const int ckc = min(BW_CKI, Cin - c0);
     const int nent = 27 * ckc, ntile = (nent + 15) / 16;
@@ -233,24 +312,54 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight(ConvIn in, 
     const int ntiles = B * nd * nh * nw;
     const size_t V = (size_t)D * H * W;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // ---- staging through registers, prefetched one voxel tile ahead (under the MFMA phase)
+    constexpr int XIT = (BW_CKI * 12 + 8) / 9;          // 3-row slab groups of X per wave (192 / 9 waves)
+    constexpr int ZIT = (64 * NCT + 8) / 9;             // 4-row groups of dZ per wave
+    const int zr = lane >> 4, zx = lane & 15;            // dZ rows are 16 floats: 4 rows per wave-instruction
+    float xv[XIT], zv[ZIT];
+
+    auto prefetch = [&](int tile) __attribute__((always_inline)) {
         int b, d0, h0, w0;
         tile_origin(tile, D, H, W, b, d0, h0, w0);
-        for (int i = tid; i < ckc * HVOX; i += BW_THREADS) {
-            const int c = i / HVOX, rem = i - c * HVOX;
-            const int zz = rem / (HH * HW), r2 = rem - zz * (HH * HW);
-            const int hy = r2 / HW, wx = r2 - hy * HW;
-            Xs[c * BW_PSX + rem] = load_in(in, b, c0 + c, d0 + zz - 1, h0 + hy - 1, w0 + wx - 1, D, H, W);
+        const SlabLane L = make_slab_lane(lane, h0, w0, W);
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int gidx = wave + 9 * it;              // wave-uniform
+            const int c = gidx / 12, r = gidx - c * 12;
+            xv[it] = c < ckc ? slab_load(ix0, ix1, ibs0, ibs1, iC0, iC1, iup0, L, b, c0 + c, d0 + (r >> 1) - 1, r & 1, D, H, W) : 0.0f;
         }
-        for (int i = tid; i < 16 * NCT * 256; i += BW_THREADS) {
-            const int co = i >> 8, v = i & 255;
-            const int d = d0 + (v >> 6), h = h0 + ((v >> 4) & 3), w = w0 + (v & 15);
-            float val = 0.0f;
-            if (cog + co < Cout && d < D && h < H && w < W)
-                val = dz[(size_t)b * dz_bs + (size_t)(cog + co) * V + ((size_t)d * H + h) * W + w];
-            Zs[co * BW_PZ + v] = val;
+        const int h = h0 + zr, w = w0 + zx;
+        const bool lane_ok = h < H && w < W;
+        const unsigned lane_off = lane_ok ? (unsigned)(h * W + w) << 2 : 0u;     // byte offset
+#pragma unroll
+        for (int it = 0; it < ZIT; ++it) {
+            const int gz = wave + 9 * it;                // wave-uniform
+            const int co = gz >> 2, d = d0 + (gz & 3);
+            const bool uok = gz < 64 * NCT && cog + co < Cout && d < D;
+            const float* base = dz + (size_t)b * dz_bs + ((size_t)min(cog + co, Cout - 1) * D + min(d, D - 1)) * H * W;
+            const float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + lane_off);   // clamped in-bounds
+            zv[it] = (uok && lane_ok) ? val : 0.0f;
+        }
+    };
+
+    const int srr = lane / HW, swx = lane - srr * HW;
+    const bool sact = lane < 3 * HW;
+    int tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int gidx = wave + 9 * it;
+            const int c = gidx / 12, r = gidx - c * 12;
+            if (c < ckc && sact) Xs[c * BW_PSX + ((r >> 1) * HH + (r & 1) * 3 + srr) * HW + swx] = xv[it];
+        }
+#pragma unroll
+        for (int it = 0; it < ZIT; ++it) {
+            const int gz = wave + 9 * it;
+            if (gz < 64 * NCT) Zs[(gz >> 2) * BW_PZ + ((gz & 3) * 4 + zr) * 16 + zx] = zv[it];
         }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
 #pragma unroll 4
         for (int s = 0; s < 64; ++s) {
             // voxels 4s..4s+3 of the tile: row = s>>2 -> (dz, hy) = (row>>2, row&3), wx = 4*(s&3) + kq

@@ -250,6 +250,54 @@ __global__ void __launch_bounds__(256) k_resize3d_bwd(const float* __restrict__ 
 #undef ADD
 }
 
+// Gather form of the adjoint (deterministic, no atomics): input voxel i receives, per axis, the
+// outputs o whose source index pair (i0, i1) contains i.  Those satisfy ratio*o in [i-1, i+1), i.e. at
+// most floor(2/ratio)+1 consecutive outputs; the KC candidates starting one below floor((i-1)/ratio)
+// are a superset and each is re-evaluated with the forward's exact index/lambda arithmetic.
+constexpr int RS_KC = 7;
+__device__ __forceinline__ void axis_taps(int i, float ratio, int n_in, int n_out, int& olo, float (&w)[RS_KC]) {
+    olo = ratio > 0.0f ? max(0, (int)floorf((float)(i - 1) / ratio) - 1) : 0;
+#pragma unroll
+    for (int k = 0; k < RS_KC; ++k) {
+        const int o = olo + k;
+        int i0, i1;
+        float l0, l1;
+        lin_src(min(o, n_out - 1), ratio, n_in, i0, i1, l0, l1);
+        const float wt = (i0 == i ? l0 : 0.0f) + (i1 == i ? l1 : 0.0f);
+        w[k] = o < n_out ? wt : 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_resize3d_bwd_gather(const float* __restrict__ gout, float* __restrict__ gx, int D, int H, int W,
+                                                             int oD, int oH, int oW, float rd, float rh, float rw, float scale) {
+    const int V = D * H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= V) return;
+    const size_t bc = blockIdx.y;
+    const int w = p % W, t = p / W, h = t % H, d = t / H;
+    int od0, oh0, ow0;
+    float wd[RS_KC], wh[RS_KC], ww[RS_KC];
+    axis_taps(d, rd, D, oD, od0, wd);
+    axis_taps(h, rh, H, oH, oh0, wh);
+    axis_taps(w, rw, W, oW, ow0, ww);
+    const float* g = gout + bc * (size_t)oD * oH * oW;
+    float acc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < RS_KC; ++a) {
+        if (wd[a] == 0.0f) continue;
+#pragma unroll
+        for (int e = 0; e < RS_KC; ++e) {
+            if (wh[e] == 0.0f) continue;
+            const float wdh = wd[a] * wh[e];
+            const float* row = g + ((size_t)(od0 + a) * oH + (oh0 + e)) * oW + ow0;
+#pragma unroll
+            for (int c = 0; c < RS_KC; ++c)
+                if (ww[c] != 0.0f) acc += wdh * ww[c] * row[c];
+        }
+    }
+    gx[bc * (size_t)V + p] = acc * scale;
+}
+
 int check_vol(const char* fn, int B, int C, int D, int H, int W) {
     VXM_REQUIRE(B > 0 && C > 0 && D > 1 && H > 1 && W > 1, VXM_ERR_BAD_SHAPE,
                 "%s: bad shape B=%d C=%d D=%d H=%d W=%d (3-D volumes with every extent > 1)", fn, B, C, D, H, W);
@@ -351,9 +399,15 @@ int vxm_resize3d_bwd(const float* gout, float* gx, int B, int C, int D, int H, i
     VXM_REQUIRE(gout && gx, VXM_ERR_NULL_POINTER, "vxm_resize3d_bwd: null pointer");
     const float rd = oD > 1 ? (float)(D - 1) / (float)(oD - 1) : 0.0f, rh = oH > 1 ? (float)(H - 1) / (float)(oH - 1) : 0.0f,
                 rw = oW > 1 ? (float)(W - 1) / (float)(oW - 1) : 0.0f;
-    hipMemsetAsync(gx, 0, sizeof(float) * (size_t)B * C * D * H * W, VXM_STREAM(stream));
-    hipLaunchKernelGGL(k_resize3d_bwd, dim3(vxm_blocks((long long)oD * oH * oW, 256), B * C), dim3(256), 0, VXM_STREAM(stream),
-                       gout, gx, D, H, W, oD, oH, oW, rd, rh, rw, factor);
+    const float rmin = fminf(oD > 1 ? rd : 1.0f, fminf(oH > 1 ? rh : 1.0f, oW > 1 ? rw : 1.0f));
+    if (rmin > 0.4f) {       // floor(2/ratio) + 3 <= RS_KC: every contributing output is among the candidates
+        hipLaunchKernelGGL(k_resize3d_bwd_gather, dim3(vxm_blocks((long long)D * H * W, 256), B * C), dim3(256), 0, VXM_STREAM(stream),
+                           gout, gx, D, H, W, oD, oH, oW, rd, rh, rw, factor);
+    } else {                 // very large upsampling factors: scatter with atomics
+        (void)hipMemsetAsync(gx, 0, sizeof(float) * (size_t)B * C * D * H * W, VXM_STREAM(stream));
+        hipLaunchKernelGGL(k_resize3d_bwd, dim3(vxm_blocks((long long)oD * oH * oW, 256), B * C), dim3(256), 0, VXM_STREAM(stream),
+                           gout, gx, D, H, W, oD, oH, oW, rd, rh, rw, factor);
+    }
     return vxm_check_launch("vxm_resize3d_bwd");
 }
 
