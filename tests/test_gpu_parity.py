@@ -136,12 +136,12 @@ def test_vecint_vs_oracle(vxm, nsteps):
 def test_resize_golden(vxm, g_layers):
     x = G(g_layers["resize_in"], True)
     down = vxm.layers.ResizeTransform(2, 3)(x)
-    np.testing.assert_allclose(N(down), g_layers["resize_down"], atol=1e-6, rtol=2e-6)
+    np.testing.assert_allclose(N(down), g_layers["resize_down"], atol=2e-6, rtol=0)
     down.backward(G(g_layers["resize_gdown"]))
     np.testing.assert_allclose(N(x.grad), g_layers["resize_down_gin"], atol=1e-5, rtol=0)
     x2 = G(g_layers["resize_in"], True)
     up = vxm.layers.ResizeTransform(0.5, 3)(x2)
-    np.testing.assert_allclose(N(up), g_layers["resize_up"], atol=1e-6, rtol=2e-6)     # values up to ~8 (x2 rescale)
+    np.testing.assert_allclose(N(up), g_layers["resize_up"], atol=5e-6, rtol=0)     # fp32 rounding of O(10) values (x2 rescale), different association than ATen
     up.backward(G(g_layers["resize_gup"]))
     np.testing.assert_allclose(N(x2.grad), g_layers["resize_up_gin"], atol=2e-5, rtol=0)
     assert vxm.layers.ResizeTransform(1, 3)(x) is x
