@@ -264,17 +264,63 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------
 // backward-weight kernel
 // ------------------------------------------------------------------------------------------
-constexpr int BW_PSX = 674;       // haloed plane (648) padded so that stride = 2 mod 32
-constexpr int BW_PZ = 258;        // dZ plane (256 voxels) padded likewise
-constexpr int BW_THREADS = 576;   // 9 waves
-constexpr int BW_CKI = 16;        // input channels per chunk
+// LDS-DMA staging (buffer_load_dword ... lds): a wave-instruction writes 64 consecutive LDS dwords from 64
+// arbitrary global addresses; lanes whose offset is out of the buffer's range write 0.0 (probed on
+// gfx950, tools/probe/ldsdma_probe.hip), which is exactly the conv's zero padding.  So a haloed X plane
+// [6][6][18] (648 floats, lane-linear) is 11 wave-instructions whose 11 per-lane offsets depend on the
+// TILE only (the channel moves the wave-uniform soffset), and a dZ plane [4][4][16] is 4.  No staging
+// VGPRs, no ds_write pass, ~3 instructions per 256 bytes.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr int VXM_OOB = (int)0x80000000;            // voffset beyond any num_records -> the lane loads 0.0
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vxm_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void vxm_lds_dma4(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 4, voff, soff, 0, 0);
+}
+
+constexpr int BW_XJ = 11;         // wave-loads per haloed X plane (648 floats)
+constexpr int BW_PSX = 706;       // X plane stride: >= 64*BW_XJ and = 2 mod 32 (conflict-free B-operand reads)
+constexpr int BW_PZ = 258;        // dZ plane (256 voxels) stride, = 2 mod 32
+constexpr int BW_WAVES = 8;
+constexpr int BW_THREADS = 64 * BW_WAVES;
+constexpr int BW_SLOTS = 4;       // N-tiles per wave: 27 taps over 8 waves = 4,4,4,3,3,3,3,3 -> 7,7,7,6 per SIMD
+constexpr int BW_CKI = 16;        // input channels per chunk (2 per wave to stage)
+template <int NCT> constexpr int bw_buf_floats() { return BW_CKI * BW_PSX + 16 * NCT * BW_PZ; }
+
+// The 64 k-steps (4 voxels each) of one 4x4x16 tile for a wave that owns S N-tiles: per step NCT A-fragments
+// (dZ) + S B-fragments (shifted X) from LDS feed S x NCT MFMAs.  Fully unrolled: every LDS offset is an
+// immediate.  Voxels 4s..4s+3: row = s>>2 -> (dz, hy) = (row>>2, row&3), wx = 4 (s&3) + kq (kq is in boff).
+template <int NCT, int S>
+__device__ __forceinline__ void bw_ksteps(const float* __restrict__ Xb, const float* __restrict__ Zb, const int (&boff)[BW_SLOTS], int aoff,
+                                          f32x4 (&acc)[BW_SLOTS][NCT]) {
+#pragma unroll
+    for (int s = 0; s < 64; ++s) {
+        const int row = s >> 2;
+        const int xbase = ((row >> 2) * HH + (row & 3)) * HW + 4 * (s & 3);
+        float a[NCT], bv[S];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) a[ct] = Zb[aoff + ct * 16 * BW_PZ + 4 * s];
+#pragma unroll
+        for (int i = 0; i < S; ++i) bv[i] = Xb[boff[i] + xbase];
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = vxm_mfma16(a[ct], bv[i], acc[i][ct]);
+    }
+}
+
+// One block per CU (8 waves, 2 per SIMD), persistent over the voxel tiles of "its" XCD's contiguous tile
+// range (neighbouring tiles share halo lines in that XCD's L2).  Two LDS tile buffers (2 x 78 KB): the
+// LDS-DMA loads of tile t+1 are issued up front, run under the 64 k-steps of MFMAs of tile t, and one
+// vmcnt(0) + barrier per tile hands the buffer over.
 template <int NCT>
 __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight(ConvIn in, const float* __restrict__ dz, long long dz_bs, int Cout,
-                                                                    float* __restrict__ part, int B, int D, int H, int W) {
+                                                                    float* __restrict__ part, int B, int D, int H, int W,
+                                                                    int nx, int m, int Qc, int G) {
     VXM_DYN_SMEM(float, smem);
-    float* Xs = smem;                          // [16][BW_PSX]
-    float* Zs = smem + BW_CKI * BW_PSX;        // [16*NCT][BW_PZ]
+    constexpr int BUF = bw_buf_floats<NCT>();
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
     const int kq = lane >> 4, n = lane & 15;
@@ -282,109 +328,135 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight(ConvIn in, 
     const long long ibs0 = in.bs0, ibs1 = in.bs1;
     const int iC0 = in.C0, iC1 = in.C1, iup0 = in.up0;
     const int Cin = iC0 + iC1;
-    const int c0 = blockIdx.y * BW_CKI;
+    // 1-D grid, XCD index fastest: block b -> (xcd = b % nx, combo = (b / nx) % (Qc G), jb = b / (nx Qc G)).
+    // Block b is observed to run on XCD b % 8 (speed only, never correctness): XCD x owns the contiguous
+    // tile range [nt x / nx, nt (x+1) / nx) -- neighbouring tiles share halo lines in that XCD's L2 -- and
+    // the m blocks of one (chunk, co-group) combo on it stride through that range.
+    const int xcd = blockIdx.x % nx, kk = blockIdx.x / nx;
+    const int combo = kk % (Qc * G), jb = kk / (Qc * G);
+    const int c0 = (combo % Qc) * BW_CKI;
     const int ckc = min(BW_CKI, Cin - c0);
     const int nent = 27 * ckc, ntile = (nent + 15) / 16;
-    const int cog = blockIdx.z * 16 * NCT;
+    const int cog = (combo / Qc) * 16 * NCT;
+    const int HWp = H * W, V = D * HWp;
+    const int Hs = H >> 1, Ws = W >> 1;
+    const int V0 = iup0 ? (D >> 1) * Hs * Ws : V;     // plane size of segment 0
 
     // N-tile j of this wave (slot i): entries e = j*16 + n  ->  (tap = e / ckc, channel = e % ckc)
-    int boff[3];
-    bool tile_ok[3];
+    int boff[BW_SLOTS];
+    const int nslots = wave < ntile ? (ntile - wave + BW_WAVES - 1) / BW_WAVES : 0;     // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int j = wave + 9 * i;
-        tile_ok[i] = j < ntile;
+    for (int i = 0; i < BW_SLOTS; ++i) {
+        const int j = wave + BW_WAVES * i;
         const int e = j * 16 + n;
         int off = 0;
         if (e < nent) {
             const int t = e / ckc, cl = e - t * ckc;
             off = cl * BW_PSX + ((t / 9) * HH + (t / 3) % 3) * HW + t % 3;
         }
-        boff[i] = off;
+        boff[i] = off + kq;                       // + voxel k of the MFMA B operand
     }
-    f32x4 acc[3][NCT];
+    const int aoff = n * BW_PZ + kq;              // MFMA A operand: dZ[co = n][voxel 4s + kq]
+    f32x4 acc[BW_SLOTS][NCT];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < BW_SLOTS; ++i)
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nw = (W + TW - 1) / TW, nh = (H + TH - 1) / TH, nd = (D + TD - 1) / TD;
-    const int ntiles = B * nd * nh * nw;
-    const size_t V = (size_t)D * H * W;
-
-    // ---- staging through registers, prefetched one voxel tile ahead (under the MFMA phase)
-    constexpr int XIT = (BW_CKI * 12 + 8) / 9;          // 3-row slab groups of X per wave (192 / 9 waves)
-    constexpr int ZIT = (64 * NCT + 8) / 9;             // 4-row groups of dZ per wave
-    const int zr = lane >> 4, zx = lane & 15;            // dZ rows are 16 floats: 4 rows per wave-instruction
-    float xv[XIT], zv[ZIT];
-
-    auto prefetch = [&](int tile) __attribute__((always_inline)) {
-        int b, d0, h0, w0;
-        tile_origin(tile, D, H, W, b, d0, h0, w0);
-        const SlabLane L = make_slab_lane(lane, h0, w0, W);
+    // lane constants of the staging pattern: element e = 64 j + lane of the haloed plane -> (dz, hy, wx)
+    int pk[BW_XJ];
 #pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            const int gidx = wave + 9 * it;              // wave-uniform
-            const int c = gidx / 12, r = gidx - c * 12;
-            xv[it] = c < ckc ? slab_load(ix0, ix1, ibs0, ibs1, iC0, iC1, iup0, L, b, c0 + c, d0 + (r >> 1) - 1, r & 1, D, H, W) : 0.0f;
+    for (int j = 0; j < BW_XJ; ++j) {
+        const int e = 64 * j + lane;
+        const int pdz = e / (HH * HW), r = e - pdz * (HH * HW), phy = r / HW, pwx = r - phy * HW;
+        pk[j] = e < HVOX ? (pdz | (phy << 8) | (pwx << 16)) : -1;
+    }
+    const int zr = lane >> 4, zx = lane & 15;     // dZ slab [4 rows][16]: one wave-load per (co, depth)
+
+    const int ntiles = B * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    const int nj = m;
+    const int lo = (int)((long long)ntiles * xcd / nx), hi = (int)((long long)ntiles * (xcd + 1) / nx);
+
+    auto stage = [&](int tile, float* Xn, float* Zn) __attribute__((always_inline)) {
+        int sb, sd0, sh0, sw0;
+        tile_origin(tile, D, H, W, sb, sd0, sh0, sw0);
+        // per-lane byte offsets inside a plane for the 11 wave-loads (full-res and x2-upsampled source)
+        int vo[BW_XJ], vu[BW_XJ];
+#pragma unroll
+        for (int j = 0; j < BW_XJ; ++j) {
+            const int gd = sd0 - 1 + (pk[j] & 0xff), gh = sh0 - 1 + ((pk[j] >> 8) & 0xff), gw = sw0 - 1 + ((pk[j] >> 16) & 0xff);
+            const bool ok = pk[j] >= 0 && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            vo[j] = ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB;
+            vu[j] = ok ? (((gd >> 1) * Hs + (gh >> 1)) * Ws + (gw >> 1)) << 2 : VXM_OOB;
         }
-        const int h = h0 + zr, w = w0 + zx;
-        const bool lane_ok = h < H && w < W;
-        const unsigned lane_off = lane_ok ? (unsigned)(h * W + w) << 2 : 0u;     // byte offset
+        const __amdgpu_buffer_rsrc_t r0 = vxm_rsrc(ix0 + (size_t)sb * ibs0, (unsigned)iC0 * (unsigned)V0 * 4u);
+        const __amdgpu_buffer_rsrc_t r1 = vxm_rsrc(iC1 ? ix1 + (size_t)sb * ibs1 : ix0, (unsigned)iC1 * (unsigned)V * 4u);
 #pragma unroll
-        for (int it = 0; it < ZIT; ++it) {
-            const int gz = wave + 9 * it;                // wave-uniform
-            const int co = gz >> 2, d = d0 + (gz & 3);
-            const bool uok = gz < 64 * NCT && cog + co < Cout && d < D;
-            const float* base = dz + (size_t)b * dz_bs + ((size_t)min(cog + co, Cout - 1) * D + min(d, D - 1)) * H * W;
-            const float val = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + lane_off);   // clamped in-bounds
-            zv[it] = (uok && lane_ok) ? val : 0.0f;
+        for (int hc = 0; hc < 2; ++hc) {                       // this wave stages channels 2 wave, 2 wave + 1 of the chunk
+            const int cl = 2 * wave + hc, cg = c0 + cl;
+            if (cl < ckc) {                                     // wave-uniform
+                float* dst = Xn + cl * BW_PSX;
+                if (cg < iC0) {
+                    const int soff = cg * V0 * 4;
+                    if (iup0) {
+#pragma unroll
+                        for (int j = 0; j < BW_XJ; ++j) vxm_lds_dma4(r0, dst + 64 * j, vu[j], soff);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < BW_XJ; ++j) vxm_lds_dma4(r0, dst + 64 * j, vo[j], soff);
+                    }
+                } else {
+                    const int soff = (cg - iC0) * V * 4;
+#pragma unroll
+                    for (int j = 0; j < BW_XJ; ++j) vxm_lds_dma4(r1, dst + 64 * j, vo[j], soff);
+                }
+            }
+        }
+        // dZ: planes co = 2 NCT wave + i, four depth slabs each
+        const __amdgpu_buffer_rsrc_t rz = vxm_rsrc(dz + (size_t)sb * dz_bs, (unsigned)Cout * (unsigned)V * 4u);
+        const int zh = sh0 + zr, zw = sw0 + zx;
+        const int zvo = (zh < H && zw < W) ? (zh * W + zw) << 2 : VXM_OOB;
+#pragma unroll
+        for (int i = 0; i < 2 * NCT; ++i) {
+            const int co = 2 * NCT * wave + i;
+#pragma unroll
+            for (int dd = 0; dd < TD; ++dd) {
+                const bool uok = cog + co < Cout && sd0 + dd < D;         // wave-uniform
+                const int soff = uok ? ((cog + co) * D + sd0 + dd) * HWp * 4 : 0;
+                vxm_lds_dma4(rz, Zn + co * BW_PZ + 64 * dd, uok ? zvo : VXM_OOB, soff);
+            }
         }
     };
 
-    const int srr = lane / HW, swx = lane - srr * HW;
-    const bool sact = lane < 3 * HW;
-    int tile = blockIdx.x;
-    if (tile < ntiles) prefetch(tile);
-    for (; tile < ntiles; tile += gridDim.x) {
-#pragma unroll
-        for (int it = 0; it < XIT; ++it) {
-            const int gidx = wave + 9 * it;
-            const int c = gidx / 12, r = gidx - c * 12;
-            if (c < ckc && sact) Xs[c * BW_PSX + ((r >> 1) * HH + (r & 1) * 3 + srr) * HW + swx] = xv[it];
+    int tile = lo + jb;
+    if (tile < hi) stage(tile, smem, smem + BW_CKI * BW_PSX);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int iter = 0; tile < hi; tile += nj, ++iter) {
+        float* Xn = smem + ((iter + 1) & 1) * BUF;
+        if (tile + nj < hi) stage(tile + nj, Xn, Xn + BW_CKI * BW_PSX);      // in flight under the MFMAs below
+        const float* Xb = smem + (iter & 1) * BUF;
+        const float* Zb = Xb + BW_CKI * BW_PSX;
+        // branch-free k-loop, specialised on this wave's number of N-tiles (uniform dispatch OUTSIDE the loop:
+        // a per-slot test inside it splits every MFMA group into its own basic block and serialises
+        // ds_read -> wait -> MFMA)
+        switch (nslots) {
+            case 4: bw_ksteps<NCT, 4>(Xb, Zb, boff, aoff, acc); break;
+            case 3: bw_ksteps<NCT, 3>(Xb, Zb, boff, aoff, acc); break;
+            case 2: bw_ksteps<NCT, 2>(Xb, Zb, boff, aoff, acc); break;
+            case 1: bw_ksteps<NCT, 1>(Xb, Zb, boff, aoff, acc); break;
+            default: break;
         }
-#pragma unroll
-        for (int it = 0; it < ZIT; ++it) {
-            const int gz = wave + 9 * it;
-            if (gz < 64 * NCT) Zs[(gz >> 2) * BW_PZ + ((gz & 3) * 4 + zr) * 16 + zx] = zv[it];
-        }
-        __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x);
-#pragma unroll 4
-        for (int s = 0; s < 64; ++s) {
-            // voxels 4s..4s+3 of the tile: row = s>>2 -> (dz, hy) = (row>>2, row&3), wx = 4*(s&3) + kq
-            const int row = s >> 2;
-            const int xbase = ((row >> 2) * HH + (row & 3)) * HW + 4 * (s & 3) + kq;
-            float a[NCT];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) a[ct] = Zs[(ct * 16 + n) * BW_PZ + 4 * s + kq];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                if (!tile_ok[i]) continue;         // wave-uniform
-                const float bv = Xs[boff[i] + xbase];
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = vxm_mfma16(a[ct], bv, acc[i][ct]);
-            }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
-    // partial gW of this block: part[blockIdx.x][co][ci][tap]
-    float* out = part + (size_t)blockIdx.x * Cout * Cin * 27;
+    // partial gW of this block: part[xcd * m + jb][co][ci][tap] (the combos of one slot tile the array)
+    float* out = part + (size_t)(xcd * m + jb) * Cout * Cin * 27;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        if (!tile_ok[i]) continue;
-        const int e = (wave + 9 * i) * 16 + n;
+    for (int i = 0; i < BW_SLOTS; ++i) {
+        if (i >= nslots) continue;
+        const int e = (wave + BW_WAVES * i) * 16 + n;
         if (e >= nent) continue;
         const int t = e / ckc, ci = c0 + (e - t * ckc);
 #pragma unroll
@@ -397,12 +469,26 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight(ConvIn in, 
     }
 }
 
+// gw[i] = sum_p part[p][i] in a fixed order (deterministic): 64 outputs x 4 partial-slices per block,
+// 4 independent accumulators per thread so that the (latency-bound) loads overlap.
 __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, float* __restrict__ gw, int nparts, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.0f;
-    for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + i];
-    gw[i] = s;
+    __shared__ float red[4][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + x;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (i < n) {
+        int p = y;
+        for (; p + 12 < nparts; p += 16) {
+            s0 += part[(size_t)p * n + i];
+            s1 += part[(size_t)(p + 4) * n + i];
+            s2 += part[(size_t)(p + 8) * n + i];
+            s3 += part[(size_t)(p + 12) * n + i];
+        }
+        for (; p < nparts; p += 4) s0 += part[(size_t)p * n + i];
+    }
+    red[y][x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (y == 0 && i < n) gw[i] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
 }
 
 // bias gradient: gb[co] = sum_{b,v} dz[b,co,v]; one block per (co, slice), fp64 atomics into acc.
@@ -424,15 +510,23 @@ __global__ void k_bias_finish(const double* __restrict__ acc, float* __restrict_
     if (i < Cout) gb[i] = (float)acc[i];
 }
 
-int bw_nbx(int Cin, int Cout, int B, int D, int H, int W, int& Qc, int& G, int& NCT) {
-    NCT = Cout <= 16 ? 1 : 2;
-    Qc = (Cin + BW_CKI - 1) / BW_CKI;
-    G = (Cout + 16 * NCT - 1) / (16 * NCT);
+struct BwPlan { int NCT, Qc, G, nx, m, nparts, nblocks; };
+BwPlan bw_plan(int Cin, int Cout, int B, int D, int H, int W) {
+    BwPlan p;
+    p.NCT = Cout <= 16 ? 1 : 2;
+    p.Qc = (Cin + BW_CKI - 1) / BW_CKI;
+    p.G = (Cout + 16 * p.NCT - 1) / (16 * p.NCT);
     const long long tiles = (long long)B * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    long long nbx = 1024 / ((long long)Qc * G);
-    if (nbx < 1) nbx = 1;
-    if (nbx > tiles) nbx = tiles;
-    return (int)nbx;
+    p.nx = (int)(tiles < 8 ? tiles : 8);
+    const int cb = p.Qc * p.G;
+    long long m = 512 / ((long long)p.nx * cb);        // one resident block per CU (156 KB of LDS): ~2 rounds of 256 CUs
+    const long long per_x = (tiles + p.nx - 1) / p.nx;
+    if (m > per_x) m = per_x;
+    if (m < 1) m = 1;
+    p.m = (int)m;
+    p.nparts = p.nx * p.m;
+    p.nblocks = p.nparts * cb;
+    return p;
 }
 
 int check_conv(const char* fn, int C0, int C1, int x0_up, int Cout, int B, int D, int H, int W) {
@@ -440,7 +534,8 @@ int check_conv(const char* fn, int C0, int C1, int x0_up, int Cout, int B, int D
                 "%s: bad shape B=%d C0=%d C1=%d Cout=%d D=%d H=%d W=%d", fn, B, C0, C1, Cout, D, H, W);
     VXM_REQUIRE(!x0_up || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), VXM_ERR_BAD_SHAPE,
                 "%s: upsampled segment needs even extents, got %dx%dx%d", fn, D, H, W);
-    VXM_REQUIRE((long long)(C0 + C1 > Cout ? C0 + C1 : Cout) * D * H * W < (1ll << 40), VXM_ERR_BAD_SHAPE, "%s: volume too large", fn);
+    VXM_REQUIRE((long long)(C0 + C1 > Cout ? C0 + C1 : Cout) * D * H * W < (1ll << 29), VXM_ERR_BAD_SHAPE,
+                "%s: a tensor of one sample must stay below 2 GiB (32-bit byte offsets in the buffer descriptors)", fn);
     return VXM_OK;
 }
 
@@ -486,9 +581,8 @@ int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, co
 
 size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D, int H, int W) {
     if (Cin <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    int Qc, G, NCT;
-    const int nbx = bw_nbx(Cin, Cout, B, D, H, W, Qc, G, NCT);
-    return 256 + sizeof(double) * (size_t)((Cout + 31) / 32 * 32) + sizeof(float) * (size_t)nbx * Cout * Cin * 27;
+    const BwPlan p = bw_plan(Cin, Cout, B, D, H, W);
+    return 256 + sizeof(double) * (size_t)((Cout + 31) / 32 * 32) + sizeof(float) * (size_t)p.nparts * Cout * Cin * 27;
 }
 
 int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
@@ -499,28 +593,29 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
     const int Cin = C0 + C1;
     VXM_REQUIRE(workspace_bytes >= vxm_conv3d_k3_bwd_weight_workspace_bytes(Cin, Cout, B, D, H, W), VXM_ERR_WORKSPACE,
                 "vxm_conv3d_k3_bwd_weight: workspace too small (%zu bytes)", workspace_bytes);
-    int Qc, G, NCT;
-    const int nbx = bw_nbx(Cin, Cout, B, D, H, W, Qc, G, NCT);
+    const BwPlan p = bw_plan(Cin, Cout, B, D, H, W);
     // workspace: [Cout doubles (bias accumulators), padded][partials]
     uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
     double* bacc = reinterpret_cast<double*>(base);
     float* part = reinterpret_cast<float*>(base + sizeof(double) * (size_t)((Cout + 31) / 32 * 32));
     ConvIn in{x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up};
-    const dim3 grid(nbx, Qc, G);
-    const size_t lds = sizeof(float) * ((size_t)BW_CKI * BW_PSX + 16 * NCT * BW_PZ);
-    // 74 KB of dynamic LDS (> the 64 KB default cap): opt in once per kernel
+    const dim3 grid(p.nblocks);
+    const size_t lds = sizeof(float) * 2 * (size_t)(p.NCT == 1 ? bw_buf_floats<1>() : bw_buf_floats<2>());
+    // up to 156 KB of dynamic LDS (> the 64 KB default cap): opt in once per kernel
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         lds_opt_in = true;
     }
-    if (NCT == 1)
-        hipLaunchKernelGGL(k_conv3d_k3_bwd_weight<1>, grid, dim3(BW_THREADS), lds, VXM_STREAM(stream), in, dz, (long long)dz_bstride, Cout, part, B, D, H, W);
+    if (p.NCT == 1)
+        hipLaunchKernelGGL(k_conv3d_k3_bwd_weight<1>, grid, dim3(BW_THREADS), lds, VXM_STREAM(stream), in, dz, (long long)dz_bstride, Cout, part,
+                           B, D, H, W, p.nx, p.m, p.Qc, p.G);
     else
-        hipLaunchKernelGGL(k_conv3d_k3_bwd_weight<2>, grid, dim3(BW_THREADS), lds, VXM_STREAM(stream), in, dz, (long long)dz_bstride, Cout, part, B, D, H, W);
+        hipLaunchKernelGGL(k_conv3d_k3_bwd_weight<2>, grid, dim3(BW_THREADS), lds, VXM_STREAM(stream), in, dz, (long long)dz_bstride, Cout, part,
+                           B, D, H, W, p.nx, p.m, p.Qc, p.G);
     const int n = Cout * Cin * 27;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n, 256)), dim3(256), 0, VXM_STREAM(stream), part, gw, nbx, n);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, p.nparts, n);
     if (gb) {
         (void)hipMemsetAsync(bacc, 0, sizeof(double) * Cout, VXM_STREAM(stream));
         const size_t V = (size_t)D * H * W;
