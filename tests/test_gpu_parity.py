@@ -207,6 +207,7 @@ def test_grad_mse_dice_golden(vxm, g_losses):
 @pytest.mark.parametrize("cin,cout,vol,slope", [
     (2, 16, (8, 8, 16), 0.2), (16, 32, (8, 12, 16), 0.2), (32, 32, (5, 6, 7), 0.2), (48, 32, (4, 8, 32), 0.2),
     (64, 32, (8, 4, 16), 0.2), (16, 3, (9, 10, 33), 1.0), (5, 7, (6, 7, 19), 0.2), (20, 40, (4, 4, 16), 0.2),
+    (17, 16, (5, 7, 28), 0.2), (32, 48, (6, 9, 36), 1.0), (3, 3, (3, 3, 4), 0.2),
 ])
 def test_conv_block_vs_oracle(vxm, cin, cout, vol, slope):
     from voxelmorph_amd.torch import functional as VF
@@ -225,6 +226,45 @@ def test_conv_block_vs_oracle(vxm, cin, cout, vol, slope):
     assert rel_l2(N(xg.grad), xo.grad.numpy()) < 1e-5
     assert rel_l2(N(wg.grad), wo.grad.numpy()) < 1e-5
     assert rel_l2(N(bg.grad), bo.grad.numpy()) < 1e-5
+
+
+def test_conv_bwd_weight_bitwise_deterministic(vxm):
+    """The backward-weight path has a fixed summation order: repeated launches on the same inputs must agree
+    bit for bit (a race in the tile hand-over or the partial reduction would show here)."""
+    from voxelmorph_amd.torch import functional as VF
+    rng = np.random.default_rng(11)
+    B, cin, cout, vol = 2, 48, 32, (12, 20, 48)
+    V = vol[0] * vol[1] * vol[2]
+    x0 = G(rng.standard_normal((B, 32, vol[0] // 2, vol[1] // 2, vol[2] // 2)))
+    x1 = G(rng.standard_normal((B, 16) + vol))
+    dz = G(rng.standard_normal((B, cout) + vol))
+    ws = VF._Workspace(x0.device)
+    outs = []
+    for _ in range(25):
+        gw = torch.full((cout, cin, 3, 3, 3), float("nan"), device="cuda")
+        gb = torch.full((cout,), float("nan"), device="cuda")
+        VF.conv_bwd_weight(ws, x0, 32, x0[0].numel(), True, x1, 16, x1[0].numel(), dz, cout, gw, gb, B, *vol)
+        outs.append((gw, gb))
+    torch.cuda.synchronize()
+    for gw, gb in outs[1:]:
+        assert torch.equal(gw, outs[0][0]) and torch.equal(gb, outs[0][1])
+    xin = torch.cat([torch.nn.functional.interpolate(x0, scale_factor=2, mode="nearest"), x1], 1).cpu().double().requires_grad_()
+    w = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv3d(xin, w, None, padding=1).backward(dz.cpu().double())
+    assert rel_l2(N(outs[0][0]), w.grad.numpy()) < 1e-5
+
+
+def test_conv_generic_kernel_in_subprocess():
+    """VXM_CONV_GENERIC=1 routes backward-weight through the LDS-DMA kernel (the path taken when W % 4 != 0 or the
+    tensors are not 16-byte aligned); the switch is read once per process, hence the subprocess."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VXM_CONV_GENERIC="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        "-k", "conv_block_vs_oracle or unet_vs_oracle or bitwise_deterministic"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_conv_block_module_matches_c_arbiter(vxm):

@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--json", type=str, default="")
     args = ap.parse_args()
+    from voxelmorph_amd import _lib
+    if os.environ.get("VXM_LIB"):                 # developer experiments: alternative build of the library
+        _lib.LIB_PATH = os.path.abspath(os.environ["VXM_LIB"])
     from voxelmorph_amd.torch import functional as VF
     shape = tuple(int(s) for s in args.shape.split(","))
     only = set(args.only.split(",")) if args.only else None

@@ -23,6 +23,7 @@
 // (for a 16-channel chunk: the 3 kw taps of one (kd,kh)); blocks are persistent over voxel tiles,
 // keep their partial gW in registers and write it once; a second kernel reduces the per-block
 // partials in a fixed order (deterministic).
+#include <cstdlib>
 #include "vxm_common.h"
 #include "vxm_device.h"
 
@@ -262,63 +263,292 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
-// backward-weight kernel
+// backward-weight kernels
 // ------------------------------------------------------------------------------------------
-// LDS-DMA staging (buffer_load_dword ... lds): a wave-instruction writes 64 consecutive LDS dwords from 64
-// arbitrary global addresses; lanes whose offset is out of the buffer's range write 0.0 (probed on
-// gfx950, tools/probe/ldsdma_probe.hip), which is exactly the conv's zero padding.  So a haloed X plane
-// [6][6][18] (648 floats, lane-linear) is 11 wave-instructions whose 11 per-lane offsets depend on the
-// TILE only (the channel moves the wave-uniform soffset), and a dZ plane [4][4][16] is 4.  No staging
-// VGPRs, no ds_write pass, ~3 instructions per 256 bytes.
+// gW[co,(ci,tap)] = sum_voxels dZ[co,v] * X[ci, v+tap]:  M = 16 output channels (A operand, dZ), N = 16
+// (tap, ci) entries (B operand, shifted X), K = 4 voxels per v_mfma_f32_16x16x4_f32.  A block owns one
+// 16-input-channel chunk x one 16*NCT output-channel group, keeps its partial gW in registers while it walks
+// voxel tiles (4x4x16), and writes it once; k_reduce_partials sums the per-block partials in a fixed order.
+// Tiles are zero padded through the buffer descriptor: a lane whose offset is beyond num_records loads 0.0
+// (and an LDS-DMA lane writes 0.0 -- probed on gfx950, tools/probe/ldsdma_probe.hip).
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int VXM_OOB = (int)0x80000000;            // voffset beyond any num_records -> the lane loads 0.0
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t vxm_rsrc(const float* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ void vxm_lds_dma4(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 4, voff, soff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 4, voff, soff, 0, 0);      // lane l -> LDS base + 4 l
+}
+__device__ __forceinline__ void vxm_lds_dma16(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, soff, 0, 0);     // lane l -> LDS base + 16 l
 }
 
-constexpr int BW_XJ = 11;         // wave-loads per haloed X plane (648 floats)
-constexpr int BW_PSX = 706;       // X plane stride: >= 64*BW_XJ and = 2 mod 32 (conflict-free B-operand reads)
-constexpr int BW_PZ = 258;        // dZ plane (256 voxels) stride, = 2 mod 32
-constexpr int BW_WAVES = 8;
+constexpr int BW_WAVES = 16;      // one 1024-thread block per CU: 4 waves per SIMD share the MFMA pipe
 constexpr int BW_THREADS = 64 * BW_WAVES;
-constexpr int BW_SLOTS = 4;       // N-tiles per wave: 27 taps over 8 waves = 4,4,4,3,3,3,3,3 -> 7,7,7,6 per SIMD
-constexpr int BW_CKI = 16;        // input channels per chunk (2 per wave to stage)
-template <int NCT> constexpr int bw_buf_floats() { return BW_CKI * BW_PSX + 16 * NCT * BW_PZ; }
+constexpr int BW_SLOTS = 2;       // N-tiles per wave: 27 taps over 16 waves = 11 x 2 + 5 x 1 -> 7,7,7,6 per SIMD
+constexpr int BW_CKI = 16;        // input channels per chunk (wave w stages channel w)
+constexpr int BW_PZ = 260;        // dZ plane (256 voxels) stride of the LDS-DMA kernel: 16-byte aligned planes for the dwordx4
+                                  // form (A-operand reads of channels n and n+8 share a bank: 2-way on the A reads only)
 
-// The 64 k-steps (4 voxels each) of one 4x4x16 tile for a wave that owns S N-tiles: per step NCT A-fragments
-// (dZ) + S B-fragments (shifted X) from LDS feed S x NCT MFMAs.  Fully unrolled: every LDS offset is an
-// immediate.  Voxels 4s..4s+3: row = s>>2 -> (dz, hy) = (row>>2, row&3), wx = 4 (s&3) + kq (kq is in boff).
-template <int NCT, int S>
+// The k-steps S0..S1-1 (4 voxels each) of one 4x4x16 tile for a wave that owns S N-tiles: per step NCT
+// A-fragments (dZ) + S B-fragments (shifted X) from LDS feed S x NCT MFMAs.  Fully unrolled (every LDS offset an
+// immediate), branch-free, operands of step s+1 requested before the MFMAs of step s (register double buffer).
+// X plane layout [6][6][RS]; voxels 4s..4s+3: row = s>>2 -> (dz, hy) = (row>>2, row&3), wx = 4 (s&3) + kq (kq in boff).
+template <int NCT, int S, int S0, int S1, int RS, int PZ>
 __device__ __forceinline__ void bw_ksteps(const float* __restrict__ Xb, const float* __restrict__ Zb, const int (&boff)[BW_SLOTS], int aoff,
                                           f32x4 (&acc)[BW_SLOTS][NCT]) {
-#pragma unroll
-    for (int s = 0; s < 64; ++s) {
+    float a[2][NCT], bv[2][S];
+    auto fetch = [&](int s, float (&af)[NCT], float (&bf)[S]) __attribute__((always_inline)) {
         const int row = s >> 2;
-        const int xbase = ((row >> 2) * HH + (row & 3)) * HW + 4 * (s & 3);
-        float a[NCT], bv[S];
+        const int xbase = ((row >> 2) * HH + (row & 3)) * RS + 4 * (s & 3);
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) a[ct] = Zb[aoff + ct * 16 * BW_PZ + 4 * s];
+        for (int ct = 0; ct < NCT; ++ct) af[ct] = Zb[aoff + ct * 16 * PZ + 4 * s];
 #pragma unroll
-        for (int i = 0; i < S; ++i) bv[i] = Xb[boff[i] + xbase];
+        for (int i = 0; i < S; ++i) bf[i] = Xb[boff[i] + xbase];
+    };
+    fetch(S0, a[S0 & 1], bv[S0 & 1]);
+#pragma unroll
+    for (int s = S0; s < S1; ++s) {
+        if (s + 1 < S1) fetch(s + 1, a[(s + 1) & 1], bv[(s + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);          // keep the prefetch above the MFMAs
 #pragma unroll
         for (int i = 0; i < S; ++i)
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = vxm_mfma16(a[ct], bv[i], acc[i][ct]);
+            for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = vxm_mfma16(a[s & 1][ct], bv[s & 1][i], acc[i][ct]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+// uniform dispatch on the wave's N-tile count OUTSIDE the k-loop (a per-slot test inside it splits every MFMA
+// group into its own basic block and serialises ds_read -> wait -> MFMA)
+template <int NCT, int S0, int S1, int RS, int PZ>
+__device__ __forceinline__ void bw_ksteps_n(int nslots, const float* Xb, const float* Zb, const int (&boff)[BW_SLOTS], int aoff,
+                                            f32x4 (&acc)[BW_SLOTS][NCT]) {
+    switch (nslots) {
+        case 2: bw_ksteps<NCT, 2, S0, S1, RS, PZ>(Xb, Zb, boff, aoff, acc); break;
+        case 1: bw_ksteps<NCT, 1, S0, S1, RS, PZ>(Xb, Zb, boff, aoff, acc); break;
+        default: break;
     }
 }
 
-// One block per CU (8 waves, 2 per SIMD), persistent over the voxel tiles of "its" XCD's contiguous tile
-// range (neighbouring tiles share halo lines in that XCD's L2).  Two LDS tile buffers (2 x 78 KB): the
-// LDS-DMA loads of tile t+1 are issued up front, run under the 64 k-steps of MFMAs of tile t, and one
-// vmcnt(0) + barrier per tile hands the buffer over.
+// 1-D grid of T blocks (one per CU): block b -> combo = b % (Qc G) (input-channel chunk x output-channel group), the
+// idx = b / (Qc G)-th of the cnt blocks of that combo, which walks the idx-th of cnt CONTIGUOUS ranges of the tile
+// list (consecutive tiles of a block share halo lines through its own L1/L2; cnt differs by at most one between
+// combos, so 256 CUs stay busy when Qc G does not divide 256).
+struct BwBlock { int idx, c0, ckc, nent, ntile, cog, lo, hi; };
+__device__ __forceinline__ BwBlock bw_block(int Cin, int NCT, int B, int D, int H, int W, int Qc, int G) {
+    BwBlock k;
+    const int cb = Qc * G, T = gridDim.x;
+    const int combo = blockIdx.x % cb;
+    k.idx = blockIdx.x / cb;
+    const int cnt = (T - combo + cb - 1) / cb;
+    k.c0 = (combo % Qc) * BW_CKI;
+    k.ckc = min(BW_CKI, Cin - k.c0);
+    k.nent = 27 * k.ckc;
+    k.ntile = (k.nent + 15) / 16;
+    k.cog = (combo / Qc) * 16 * NCT;
+    const int ntiles = B * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    k.lo = (int)((long long)ntiles * k.idx / cnt);
+    k.hi = (int)((long long)ntiles * (k.idx + 1) / cnt);
+    return k;
+}
+// partial gW of this block: part[idx][co][ci][tap] (the combos of one idx tile the array)
 template <int NCT>
-__global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight(ConvIn in, const float* __restrict__ dz, long long dz_bs, int Cout,
-                                                                    float* __restrict__ part, int B, int D, int H, int W,
-                                                                    int nx, int m, int Qc, int G) {
+__device__ __forceinline__ void bw_write_partial(const BwBlock& k, float* __restrict__ part, int Cout, int Cin, int wave, int lane, int nslots,
+                                                 const f32x4 (&acc)[BW_SLOTS][NCT]) {
+    const int kq = lane >> 4, n = lane & 15;
+    float* out = part + (size_t)k.idx * Cout * Cin * 27;
+#pragma unroll
+    for (int i = 0; i < BW_SLOTS; ++i) {
+        if (i >= nslots) continue;
+        const int e = (wave + BW_WAVES * i) * 16 + n;
+        if (e >= k.nent) continue;
+        const int t = e / k.ckc, ci = k.c0 + (e - t * k.ckc);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = k.cog + ct * 16 + kq * 4 + j;
+                if (co < Cout) out[((size_t)co * Cin + ci) * 27 + t] = acc[i][ct][j];
+            }
+    }
+}
+
+// ---- fast path (W % 4 == 0, 16-byte aligned tensors): register-staged tiles from wide buffer loads ------------
+// X plane in LDS: [6][6][20] with the 16 interior columns at 2..17 (8-byte aligned -> ds_write_b64), the halo
+// columns at 1 and 18; plane stride 738 = 2 mod 32 (conflict-free B-operand reads).  Per tile a wave issues 3
+// dwordx4 (interior rows of its channel; dwordx2 + duplicate for the x2-upsampled segment), 2 dword (halo
+// columns) and NCT dwordx4 (dZ) buffer loads up front, runs the 64 k-steps of the CURRENT tile out of LDS while
+// they are in flight, then writes them into the OTHER LDS tile buffer; one barrier per tile.  2 x 80.5 KB of LDS.
+constexpr int BV_RS = 20;
+constexpr int BV_PSX = 738;
+constexpr int BV_PZ = 258;        // dZ plane stride = 2 mod 32: conflict-free A-operand reads (planes 8-byte aligned: ds_write_b64)
+template <int NCT> constexpr int bv_lds_floats() { return BW_CKI * BV_PSX + 16 * NCT * BV_PZ; }
+
+template <int NCT>
+__global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_vec(ConvIn in, const float* __restrict__ dz, long long dz_bs, int Cout,
+                                                                           float* __restrict__ part, int B, int D, int H, int W,
+                                                                           int Qc, int G) {
+    VXM_DYN_SMEM(float, smem);
+    constexpr int BUF = bv_lds_floats<NCT>();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
+    const int kq = lane >> 4, n = lane & 15;
+    const float* const ix0 = in.x0; const float* const ix1 = in.x1;
+    const long long ibs0 = in.bs0, ibs1 = in.bs1;
+    const int iC0 = in.C0, iC1 = in.C1, iup0 = in.up0;
+    const int Cin = iC0 + iC1;
+    const BwBlock k = bw_block(Cin, NCT, B, D, H, W, Qc, G);
+    const int HWp = H * W, V = D * HWp;
+    const int Hs = H >> 1, Ws = W >> 1;
+    const int V0 = iup0 ? (D >> 1) * Hs * Ws : V;     // plane size of segment 0
+
+    // N-tile j of this wave (slot i): entries e = j*16 + n  ->  (tap = e / ckc, channel = e % ckc)
+    int boff[BW_SLOTS];
+    const int nslots = wave < k.ntile ? (k.ntile - wave + BW_WAVES - 1) / BW_WAVES : 0;     // wave-uniform
+#pragma unroll
+    for (int i = 0; i < BW_SLOTS; ++i) {
+        const int e = (wave + BW_WAVES * i) * 16 + n;
+        int off = 2;
+        if (e < k.nent) {
+            const int t = e / k.ckc, cl = e - t * k.ckc;
+            off = cl * BV_PSX + ((t / 9) * HH + (t / 3) % 3) * BV_RS + t % 3 + 1;       // column = wx + kw - 1 + 2
+        }
+        boff[i] = off + kq;                       // + voxel k of the MFMA B operand
+    }
+    const int aoff = n * BV_PZ + kq;              // MFMA A operand: dZ[co = n][voxel 4s + kq]
+    f32x4 acc[BW_SLOTS][NCT];
+#pragma unroll
+    for (int i = 0; i < BW_SLOTS; ++i)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging roles of this lane (tile independent).  Interior: slot 64 j + lane (< 144) of a plane -> row
+    // 16 j + (lane >> 2), columns 4 (lane & 3)..+3;  halo: slot 64 j + lane (< 72) -> row 32 j + (lane >> 1), side
+    // lane & 1;  dZ: lane -> (row = lane >> 2, columns 4 (lane & 3)..+3).  LDS offsets = lane base + immediate.
+    const int lq = lane & 3, lr4 = lane >> 2, lr2 = lane >> 1, hside = lane & 1;
+    const int ibase = lr4 * BV_RS + 2 + 4 * lq;          // + 16 j rows
+    const int hbase = lr2 * BV_RS + (hside ? 18 : 1);    // + 32 j rows
+    auto ivalid = [&](int j) __attribute__((always_inline)) { return j < 2 || lane < 16; };
+    auto hvalid = [&](int j) __attribute__((always_inline)) { return j < 1 || lane < 8; };
+
+    f32x4 xi[3];             // interior pieces of this wave's channel
+    float xh[2];             // halo pieces
+    f32x4 zv[NCT];           // dZ planes
+
+    auto load_tile = [&](int tile) __attribute__((always_inline)) {
+        int sb, sd0, sh0, sw0;
+        tile_origin(tile, D, H, W, sb, sd0, sh0, sw0);
+        const __amdgpu_buffer_rsrc_t r0 = vxm_rsrc(ix0 + (size_t)sb * ibs0, (unsigned)iC0 * (unsigned)V0 * 4u);
+        const __amdgpu_buffer_rsrc_t r1 = vxm_rsrc(iC1 ? ix1 + (size_t)sb * ibs1 : ix0, (unsigned)iC1 * (unsigned)V * 4u);
+        const __amdgpu_buffer_rsrc_t rz = vxm_rsrc(dz + (size_t)sb * dz_bs, (unsigned)Cout * (unsigned)V * 4u);
+        // per-lane byte offsets inside a plane (full-res source, and the x2-upsampled source of segment 0)
+        int vi[3], viu[3], vh[2], vhu[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int rr = 16 * j + lr4;
+            const int gd = sd0 - 1 + rr / HH, gh = sh0 - 1 + rr % HH, gw = sw0 + 4 * lq;
+            const bool ok = ivalid(j) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw < W;
+            vi[j] = ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB;
+            viu[j] = ok ? (((gd >> 1) * Hs + (gh >> 1)) * Ws + (gw >> 1)) << 2 : VXM_OOB;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int rr = 32 * j + lr2;
+            const int gd = sd0 - 1 + rr / HH, gh = sh0 - 1 + rr % HH, gw = hside ? sw0 + TW : sw0 - 1;
+            const bool ok = hvalid(j) && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            vh[j] = ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB;
+            vhu[j] = ok ? (((gd >> 1) * Hs + (gh >> 1)) * Ws + (gw >> 1)) << 2 : VXM_OOB;
+        }
+        {                                                       // this wave stages channel `wave` of the chunk
+            const int cl = wave, cg = k.c0 + cl;
+            if (cl < k.ckc) {                                   // wave-uniform
+                if (cg < iC0 && iup0) {                         // x2 nearest upsampling: 2 source floats -> 4 columns
+                    const int soff = cg * V0 * 4;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r0, viu[j], soff, 0));
+                        xi[j] = (f32x4){t.x, t.x, t.y, t.y};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) xh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, vhu[j], soff, 0));
+                } else {
+                    const bool s0 = cg < iC0;
+                    const __amdgpu_buffer_rsrc_t r = s0 ? r0 : r1;
+                    const int soff = (s0 ? cg * V0 : (cg - iC0) * V) * 4;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) xi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vi[j], soff, 0));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) xh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vh[j], soff, 0));
+                }
+            }
+        }
+        // dZ: planes co = NCT wave + i; lane -> (row = (dd, hy), 4 floats at wx = 4 lq)
+        const int zd = sd0 + (lr4 >> 2), zh = sh0 + (lr4 & 3), zw = sw0 + 4 * lq;
+        const int zvo = (zd < D && zh < H && zw < W) ? ((zd * H + zh) * W + zw) << 2 : VXM_OOB;
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) {
+            const int co = NCT * wave + i;
+            const bool uok = k.cog + co < Cout;                 // wave-uniform
+            zv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, uok ? zvo : VXM_OOB, uok ? (k.cog + co) * V * 4 : 0, 0));
+        }
+    };
+    auto store_tile = [&](float* Xn, float* Zn) __attribute__((always_inline)) {
+        if (wave < k.ckc) {
+            float* dst = Xn + wave * BV_PSX;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (ivalid(j)) {
+                    *reinterpret_cast<f32x2*>(dst + ibase + 16 * j * BV_RS) = (f32x2){xi[j].x, xi[j].y};
+                    *reinterpret_cast<f32x2*>(dst + ibase + 16 * j * BV_RS + 2) = (f32x2){xi[j].z, xi[j].w};
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (hvalid(j)) dst[hbase + 32 * j * BV_RS] = xh[j];
+        }
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) {
+            float* zp = Zn + (NCT * wave + i) * BV_PZ + 4 * lane;
+            *reinterpret_cast<f32x2*>(zp) = (f32x2){zv[i].x, zv[i].y};
+            *reinterpret_cast<f32x2*>(zp + 2) = (f32x2){zv[i].z, zv[i].w};
+        }
+    };
+
+    int tile = k.lo;
+    if (tile < k.hi) {
+        load_tile(tile);
+        store_tile(smem, smem + BW_CKI * BV_PSX);
+    }
+    __syncthreads();
+    for (int iter = 0; tile < k.hi; ++tile, ++iter) {
+        const bool more = tile + 1 < k.hi;
+        if (more) load_tile(tile + 1);                 // in flight under the MFMAs below
+        const float* Xb = smem + (iter & 1) * BUF;
+        bw_ksteps_n<NCT, 0, 64, BV_RS, BV_PZ>(nslots, Xb, Xb + BW_CKI * BV_PSX, boff, aoff, acc);
+        float* Xn = smem + ((iter + 1) & 1) * BUF;     // last read before the previous barrier
+        if (more) store_tile(Xn, Xn + BW_CKI * BV_PSX);
+        __syncthreads();
+    }
+    bw_write_partial<NCT>(k, part, Cout, Cin, wave, lane, nslots, acc);
+}
+
+// ---- generic path (any W / alignment): LDS-DMA staging -------------------------------------------------------
+// buffer_load_dword ... lds: a wave-instruction writes 64 consecutive LDS dwords from 64 arbitrary global
+// addresses, so a haloed X plane [6][6][18] (648 floats, lane-linear) is 11 wave-instructions whose per-lane
+// offsets depend on the TILE only, and a dZ plane is 4 (1 dwordx4 when W % 4 == 0).  No staging VGPRs, but each
+// LDS-DMA instruction costs the CU ~200 cycles (measured), which is why the wide-load path above is the default.
+// One 16-wave block per CU (2 x 78 KB LDS tile buffers), loads of tile t+1 issued before the k-steps of tile t.
+constexpr int BW_XJ = 11;         // wave-loads per haloed X plane (648 floats)
+constexpr int BW_PSX = 706;       // X plane stride: >= 64*BW_XJ and = 2 mod 32 (conflict-free B-operand reads)
+template <int NCT> constexpr int bw_buf_floats() { return BW_CKI * BW_PSX + 16 * NCT * BW_PZ; }
+
+template <int NCT>
+__global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_dma(ConvIn in, const float* __restrict__ dz, long long dz_bs, int Cout,
+                                                                        float* __restrict__ part, int B, int D, int H, int W,
+                                                                        int Qc, int G) {
     VXM_DYN_SMEM(float, smem);
     constexpr int BUF = bw_buf_floats<NCT>();
     const int tid = threadIdx.x, lane = tid & 63;
@@ -328,35 +558,24 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight(ConvIn in, 
     const long long ibs0 = in.bs0, ibs1 = in.bs1;
     const int iC0 = in.C0, iC1 = in.C1, iup0 = in.up0;
     const int Cin = iC0 + iC1;
-    // 1-D grid, XCD index fastest: block b -> (xcd = b % nx, combo = (b / nx) % (Qc G), jb = b / (nx Qc G)).
-    // Block b is observed to run on XCD b % 8 (speed only, never correctness): XCD x owns the contiguous
-    // tile range [nt x / nx, nt (x+1) / nx) -- neighbouring tiles share halo lines in that XCD's L2 -- and
-    // the m blocks of one (chunk, co-group) combo on it stride through that range.
-    const int xcd = blockIdx.x % nx, kk = blockIdx.x / nx;
-    const int combo = kk % (Qc * G), jb = kk / (Qc * G);
-    const int c0 = (combo % Qc) * BW_CKI;
-    const int ckc = min(BW_CKI, Cin - c0);
-    const int nent = 27 * ckc, ntile = (nent + 15) / 16;
-    const int cog = (combo / Qc) * 16 * NCT;
+    const BwBlock k = bw_block(Cin, NCT, B, D, H, W, Qc, G);
     const int HWp = H * W, V = D * HWp;
     const int Hs = H >> 1, Ws = W >> 1;
     const int V0 = iup0 ? (D >> 1) * Hs * Ws : V;     // plane size of segment 0
 
-    // N-tile j of this wave (slot i): entries e = j*16 + n  ->  (tap = e / ckc, channel = e % ckc)
     int boff[BW_SLOTS];
-    const int nslots = wave < ntile ? (ntile - wave + BW_WAVES - 1) / BW_WAVES : 0;     // wave-uniform
+    const int nslots = wave < k.ntile ? (k.ntile - wave + BW_WAVES - 1) / BW_WAVES : 0;     // wave-uniform
 #pragma unroll
     for (int i = 0; i < BW_SLOTS; ++i) {
-        const int j = wave + BW_WAVES * i;
-        const int e = j * 16 + n;
+        const int e = (wave + BW_WAVES * i) * 16 + n;
         int off = 0;
-        if (e < nent) {
-            const int t = e / ckc, cl = e - t * ckc;
+        if (e < k.nent) {
+            const int t = e / k.ckc, cl = e - t * k.ckc;
             off = cl * BW_PSX + ((t / 9) * HH + (t / 3) % 3) * HW + t % 3;
         }
-        boff[i] = off + kq;                       // + voxel k of the MFMA B operand
+        boff[i] = off + kq;
     }
-    const int aoff = n * BW_PZ + kq;              // MFMA A operand: dZ[co = n][voxel 4s + kq]
+    const int aoff = n * BW_PZ + kq;
     f32x4 acc[BW_SLOTS][NCT];
 #pragma unroll
     for (int i = 0; i < BW_SLOTS; ++i)
@@ -371,16 +590,11 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight(ConvIn in, 
         const int pdz = e / (HH * HW), r = e - pdz * (HH * HW), phy = r / HW, pwx = r - phy * HW;
         pk[j] = e < HVOX ? (pdz | (phy << 8) | (pwx << 16)) : -1;
     }
-    const int zr = lane >> 4, zx = lane & 15;     // dZ slab [4 rows][16]: one wave-load per (co, depth)
-
-    const int ntiles = B * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    const int nj = m;
-    const int lo = (int)((long long)ntiles * xcd / nx), hi = (int)((long long)ntiles * (xcd + 1) / nx);
+    const int zr = lane >> 4, zx = lane & 15;     // dword dZ slab [4 rows][16]: one wave-load per (co, depth)
 
     auto stage = [&](int tile, float* Xn, float* Zn) __attribute__((always_inline)) {
         int sb, sd0, sh0, sw0;
         tile_origin(tile, D, H, W, sb, sd0, sh0, sw0);
-        // per-lane byte offsets inside a plane for the 11 wave-loads (full-res and x2-upsampled source)
         int vo[BW_XJ], vu[BW_XJ];
 #pragma unroll
         for (int j = 0; j < BW_XJ; ++j) {
@@ -391,10 +605,9 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight(ConvIn in, 
         }
         const __amdgpu_buffer_rsrc_t r0 = vxm_rsrc(ix0 + (size_t)sb * ibs0, (unsigned)iC0 * (unsigned)V0 * 4u);
         const __amdgpu_buffer_rsrc_t r1 = vxm_rsrc(iC1 ? ix1 + (size_t)sb * ibs1 : ix0, (unsigned)iC1 * (unsigned)V * 4u);
-#pragma unroll
-        for (int hc = 0; hc < 2; ++hc) {                       // this wave stages channels 2 wave, 2 wave + 1 of the chunk
-            const int cl = 2 * wave + hc, cg = c0 + cl;
-            if (cl < ckc) {                                     // wave-uniform
+        {                                                       // this wave stages channel `wave` of the chunk
+            const int cl = wave, cg = k.c0 + cl;
+            if (cl < k.ckc) {                                   // wave-uniform
                 float* dst = Xn + cl * BW_PSX;
                 if (cg < iC0) {
                     const int soff = cg * V0 * 4;
@@ -412,71 +625,63 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight(ConvIn in, 
                 }
             }
         }
-        // dZ: planes co = 2 NCT wave + i, four depth slabs each
+        // dZ: planes co = NCT wave + i
         const __amdgpu_buffer_rsrc_t rz = vxm_rsrc(dz + (size_t)sb * dz_bs, (unsigned)Cout * (unsigned)V * 4u);
-        const int zh = sh0 + zr, zw = sw0 + zx;
-        const int zvo = (zh < H && zw < W) ? (zh * W + zw) << 2 : VXM_OOB;
+        if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0 && (dz_bs & 3) == 0) {
+            // one dwordx4 wave-load per plane: lane -> (row = lane >> 2 -> (dd, hy) = (row >> 2, row & 3), wx = 4 (lane & 3))
+            const int zrow = lane >> 2, zd = sd0 + (zrow >> 2), zh = sh0 + (zrow & 3), zw = sw0 + 4 * (lane & 3);
+            const int zvo = (zd < D && zh < H && zw < W) ? ((zd * H + zh) * W + zw) << 2 : VXM_OOB;
 #pragma unroll
-        for (int i = 0; i < 2 * NCT; ++i) {
-            const int co = 2 * NCT * wave + i;
+            for (int i = 0; i < NCT; ++i) {
+                const int co = NCT * wave + i;
+                const bool uok = k.cog + co < Cout;                           // wave-uniform
+                vxm_lds_dma16(rz, Zn + co * BW_PZ, uok ? zvo : VXM_OOB, uok ? (k.cog + co) * V * 4 : 0);
+            }
+        } else {
+            const int zh = sh0 + zr, zw = sw0 + zx;
+            const int zvo = (zh < H && zw < W) ? (zh * W + zw) << 2 : VXM_OOB;
 #pragma unroll
-            for (int dd = 0; dd < TD; ++dd) {
-                const bool uok = cog + co < Cout && sd0 + dd < D;         // wave-uniform
-                const int soff = uok ? ((cog + co) * D + sd0 + dd) * HWp * 4 : 0;
-                vxm_lds_dma4(rz, Zn + co * BW_PZ + 64 * dd, uok ? zvo : VXM_OOB, soff);
+            for (int i = 0; i < NCT; ++i) {
+                const int co = NCT * wave + i;
+#pragma unroll
+                for (int dd = 0; dd < TD; ++dd) {
+                    const bool uok = k.cog + co < Cout && sd0 + dd < D;       // wave-uniform
+                    const int soff = uok ? ((k.cog + co) * D + sd0 + dd) * HWp * 4 : 0;
+                    vxm_lds_dma4(rz, Zn + co * BW_PZ + 64 * dd, uok ? zvo : VXM_OOB, soff);
+                }
             }
         }
     };
 
-    int tile = lo + jb;
-    if (tile < hi) stage(tile, smem, smem + BW_CKI * BW_PSX);
+    int tile = k.lo;
+    if (tile < k.hi) stage(tile, smem, smem + BW_CKI * BW_PSX);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int iter = 0; tile < hi; tile += nj, ++iter) {
+    for (int iter = 0; tile < k.hi; ++tile, ++iter) {
         float* Xn = smem + ((iter + 1) & 1) * BUF;
-        if (tile + nj < hi) stage(tile + nj, Xn, Xn + BW_CKI * BW_PSX);      // in flight under the MFMAs below
         const float* Xb = smem + (iter & 1) * BUF;
         const float* Zb = Xb + BW_CKI * BW_PSX;
-        // branch-free k-loop, specialised on this wave's number of N-tiles (uniform dispatch OUTSIDE the loop:
-        // a per-slot test inside it splits every MFMA group into its own basic block and serialises
-        // ds_read -> wait -> MFMA)
-        switch (nslots) {
-            case 4: bw_ksteps<NCT, 4>(Xb, Zb, boff, aoff, acc); break;
-            case 3: bw_ksteps<NCT, 3>(Xb, Zb, boff, aoff, acc); break;
-            case 2: bw_ksteps<NCT, 2>(Xb, Zb, boff, aoff, acc); break;
-            case 1: bw_ksteps<NCT, 1>(Xb, Zb, boff, aoff, acc); break;
-            default: break;
-        }
+        if (tile + 1 < k.hi) stage(tile + 1, Xn, Xn + BW_CKI * BW_PSX);      // in flight under the MFMAs below
+        bw_ksteps_n<NCT, 0, 64, HW, BW_PZ>(nslots, Xb, Zb, boff, aoff, acc);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-
-    // partial gW of this block: part[xcd * m + jb][co][ci][tap] (the combos of one slot tile the array)
-    float* out = part + (size_t)(xcd * m + jb) * Cout * Cin * 27;
-#pragma unroll
-    for (int i = 0; i < BW_SLOTS; ++i) {
-        if (i >= nslots) continue;
-        const int e = (wave + BW_WAVES * i) * 16 + n;
-        if (e >= nent) continue;
-        const int t = e / ckc, ci = c0 + (e - t * ckc);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = cog + ct * 16 + kq * 4 + j;
-                if (co < Cout) out[((size_t)co * Cin + ci) * 27 + t] = acc[i][ct][j];
-            }
-    }
+    bw_write_partial<NCT>(k, part, Cout, Cin, wave, lane, nslots, acc);
 }
 
-// gw[i] = sum_p part[p][i] in a fixed order (deterministic): 64 outputs x 4 partial-slices per block,
-// 4 independent accumulators per thread so that the (latency-bound) loads overlap.
-__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, float* __restrict__ gw, int nparts, int n) {
+// gw[i] = sum_p part[p][i] in a fixed order (deterministic): 64 outputs x 4 partial-slices per block, 4 independent
+// accumulators per thread so that the (latency-bound) loads overlap.  Element i = (co, ci, tap) belongs to combo
+// (ci / 16, co / cog_size), which has cnt = ceil((T - combo) / cb) partial slots.
+__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, float* __restrict__ gw, int n, int Cin,
+                                                         int T, int Qc, int G, int cog_size) {
     __shared__ float red[4][64];
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + x;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     if (i < n) {
+        const int co = i / (Cin * 27), ci = (i / 27) % Cin;
+        const int cb = Qc * G, combo = ci / BW_CKI + Qc * (co / cog_size);
+        const int nparts = (T - combo + cb - 1) / cb;
         int p = y;
         for (; p + 12 < nparts; p += 16) {
             s0 += part[(size_t)p * n + i];
@@ -510,22 +715,25 @@ __global__ void k_bias_finish(const double* __restrict__ acc, float* __restrict_
     if (i < Cout) gb[i] = (float)acc[i];
 }
 
-struct BwPlan { int NCT, Qc, G, nx, m, nparts, nblocks; };
+// VXM_CONV_GENERIC=1 routes every backward-weight launch through the generic (LDS-DMA) kernel, so that the
+// parity tests can exercise it on shapes the wide-load kernel would otherwise take.
+bool bw_force_generic() {
+    static const bool f = [] { const char* e = getenv("VXM_CONV_GENERIC"); return e && e[0] == '1'; }();
+    return f;
+}
+
+struct BwPlan { int NCT, Qc, G, T, nparts; };
 BwPlan bw_plan(int Cin, int Cout, int B, int D, int H, int W) {
     BwPlan p;
     p.NCT = Cout <= 16 ? 1 : 2;
     p.Qc = (Cin + BW_CKI - 1) / BW_CKI;
     p.G = (Cout + 16 * p.NCT - 1) / (16 * p.NCT);
     const long long tiles = (long long)B * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-    p.nx = (int)(tiles < 8 ? tiles : 8);
     const int cb = p.Qc * p.G;
-    long long m = 512 / ((long long)p.nx * cb);        // one resident block per CU (156 KB of LDS): ~2 rounds of 256 CUs
-    const long long per_x = (tiles + p.nx - 1) / p.nx;
-    if (m > per_x) m = per_x;
-    if (m < 1) m = 1;
-    p.m = (int)m;
-    p.nparts = p.nx * p.m;
-    p.nblocks = p.nparts * cb;
+    long long T = tiles * cb < 256 ? tiles * cb : 256;       // one resident 16-wave block per CU
+    if (T < cb) T = cb;                                       // every combo needs a block
+    p.T = (int)T;
+    p.nparts = (p.T + cb - 1) / cb;
     return p;
 }
 
@@ -599,23 +807,32 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
     double* bacc = reinterpret_cast<double*>(base);
     float* part = reinterpret_cast<float*>(base + sizeof(double) * (size_t)((Cout + 31) / 32 * 32));
     ConvIn in{x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up};
-    const dim3 grid(p.nblocks);
-    const size_t lds = sizeof(float) * 2 * (size_t)(p.NCT == 1 ? bw_buf_floats<1>() : bw_buf_floats<2>());
+    const dim3 grid(p.T);
     // up to 156 KB of dynamic LDS (> the 64 KB default cap): opt in once per kernel
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight_vec<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight_vec<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight_dma<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight_dma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         lds_opt_in = true;
     }
-    if (p.NCT == 1)
-        hipLaunchKernelGGL(k_conv3d_k3_bwd_weight<1>, grid, dim3(BW_THREADS), lds, VXM_STREAM(stream), in, dz, (long long)dz_bstride, Cout, part,
-                           B, D, H, W, p.nx, p.m, p.Qc, p.G);
-    else
-        hipLaunchKernelGGL(k_conv3d_k3_bwd_weight<2>, grid, dim3(BW_THREADS), lds, VXM_STREAM(stream), in, dz, (long long)dz_bstride, Cout, part,
-                           B, D, H, W, p.nx, p.m, p.Qc, p.G);
+    // wide-load path: rows of 4-float groups must not straddle row ends and must be 16-byte aligned in memory
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool vec = (W & 3) == 0 && al16(x0) && (C1 == 0 || al16(x1)) && al16(dz) && (x0_bstride & 3) == 0 && (x1_bstride & 3) == 0 &&
+                     (dz_bstride & 3) == 0 && !bw_force_generic();
+#define BW_LAUNCH(KERNEL, LDSF) hipLaunchKernelGGL(KERNEL, grid, dim3(BW_THREADS), sizeof(float) * (size_t)(LDSF), VXM_STREAM(stream), in, dz, \
+        (long long)dz_bstride, Cout, part, B, D, H, W, p.Qc, p.G)
+    if (vec) {
+        if (p.NCT == 1) BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<1>, 2 * bv_lds_floats<1>());
+        else BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<2>, 2 * bv_lds_floats<2>());
+    } else {
+        if (p.NCT == 1) BW_LAUNCH(k_conv3d_k3_bwd_weight_dma<1>, 2 * bw_buf_floats<1>());
+        else BW_LAUNCH(k_conv3d_k3_bwd_weight_dma<2>, 2 * bw_buf_floats<2>());
+    }
+#undef BW_LAUNCH
     const int n = Cout * Cin * 27;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, p.nparts, n);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, n, Cin, p.T, p.Qc, p.G, 16 * p.NCT);
     if (gb) {
         (void)hipMemsetAsync(bacc, 0, sizeof(double) * Cout, VXM_STREAM(stream));
         const size_t V = (size_t)D * H * W;
