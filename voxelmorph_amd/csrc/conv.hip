@@ -236,7 +236,8 @@ struct ConvCfg { int CK, NCT, Q, G; size_t elems; };
 ConvCfg conv_cfg(int Cin, int Cout) {
     ConvCfg c;
     c.CK = Cin <= 4 ? 4 : 8;
-    c.NCT = Cout <= 16 ? 1 : 2;
+    // 16-channel output tiles per block: 3 when that wastes fewer MFMA rows than 2 (e.g. Cout = 48: 3 x 16, not 2 x 32)
+    c.NCT = Cout <= 16 ? 1 : (Cout <= 32 ? 2 : ((Cout + 47) / 48 * 48 < (Cout + 31) / 32 * 32 ? 3 : 2));
     c.Q = (Cin + c.CK - 1) / c.CK;
     c.G = (Cout + 16 * c.NCT - 1) / (16 * c.NCT);
     c.elems = (size_t)c.G * c.Q * 27 * (c.CK / 4) * c.NCT * 64;
@@ -779,10 +780,19 @@ int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, co
     const size_t lds = sizeof(float) * ((size_t)c.CK * FWD_PS + 27 * (c.CK / 4) * c.NCT * 64);
 #define LAUNCH(CK_, NCT_) hipLaunchKernelGGL((k_conv3d_k3<CK_, NCT_>), grid, dim3(256), lds, VXM_STREAM(stream), in, wpacked, bias, y, \
         (long long)y_bstride, Cout, act_slope, mask_src, (long long)mask_bstride, mask_slope, D, H, W, c.Q)
+    if (lds > 64 * 1024) {           // <8,3>: opt in to > 64 KB of dynamic LDS once
+        static bool opt_in = false;
+        if (!opt_in) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3<8, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            opt_in = true;
+        }
+    }
     if (c.CK == 4 && c.NCT == 1) LAUNCH(4, 1);
-    else if (c.CK == 4) LAUNCH(4, 2);
+    else if (c.CK == 4 && c.NCT == 2) LAUNCH(4, 2);
+    else if (c.CK == 4) LAUNCH(4, 3);
     else if (c.NCT == 1) LAUNCH(8, 1);
-    else LAUNCH(8, 2);
+    else if (c.NCT == 2) LAUNCH(8, 2);
+    else LAUNCH(8, 3);
 #undef LAUNCH
     return vxm_check_launch("vxm_conv3d_k3_fwd");
 }

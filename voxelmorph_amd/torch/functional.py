@@ -245,7 +245,13 @@ def pack_weights(w, flip):
 
 def conv_variant(cin, cout):
     """Kernel template instance the C ABI dispatches to (conv.hip: conv_cfg)."""
-    return "conv3d_k3<CK=%d,NCT=%d>" % (4 if cin <= 4 else 8, 1 if cout <= 16 else 2)
+    if cout <= 16:
+        nct = 1
+    elif cout <= 32:
+        nct = 2
+    else:
+        nct = 3 if (cout + 47) // 48 * 48 < (cout + 31) // 32 * 32 else 2
+    return "conv3d_k3<CK=%d,NCT=%d>" % (4 if cin <= 4 else 8, nct)
 
 
 def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
