@@ -254,6 +254,19 @@ def test_conv_bwd_weight_bitwise_deterministic(vxm):
     assert rel_l2(N(outs[0][0]), w.grad.numpy()) < 1e-5
 
 
+def test_conv_wide_forward_kernel_on_small_volumes_in_subprocess():
+    """VXM_CONV_WIDE_MIN_TILES=1 sends every eligible forward / backward-data launch through the 8-wave wide-load
+    kernel (normally reserved for the large layers), so that the oracle parity tests cover it at small sizes."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VXM_CONV_WIDE_MIN_TILES="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        "-k", "conv_block_vs_oracle or unet_vs_oracle or vxm_dense_golden"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_conv_generic_kernel_in_subprocess():
     """VXM_CONV_GENERIC=1 routes backward-weight through the LDS-DMA kernel (the path taken when W % 4 != 0 or the
     tensors are not 16-byte aligned); the switch is read once per process, hence the subprocess."""

@@ -88,7 +88,6 @@ def main():
         gw = torch.empty_like(w)
         gb = torch.empty_like(b)
         wp = VF.pack_weights(w, False)
-        wpt = VF.pack_weights(w, True)
         ws = VF._Workspace(dev)
         flops = 2.0 * 27 * cin * cout * B * V
 
@@ -97,7 +96,7 @@ def main():
                            cout, slope, None, 0, 1.0, B, D, H, W)
 
         def bwd_data():
-            VF.conv_launch(dz, cout, cout * V, False, None, 0, 0, wpt, None, gx, cin * V, cin, 1.0, None, 0, 1.0, B, D, H, W)
+            VF.conv_bwd_data(dz, cout, w, gx, cin, None, 1.0, B, D, H, W)
 
         def bwd_weight():
             VF.conv_bwd_weight(ws, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,

@@ -88,9 +88,31 @@ __device__ __forceinline__ float slab_load(const float* x0, const float* x1, lon
 }
 
 // ------------------------------------------------------------------------------------------
+// buffer-descriptor helpers.  Tiles are zero padded through the descriptor: a lane whose offset is beyond
+// num_records loads 0.0 (and an LDS-DMA lane writes 0.0 -- probed on gfx950, tools/probe/ldsdma_probe.hip).
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int VXM_OOB = (int)0x80000000;            // voffset beyond any num_records -> the lane loads 0.0
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vxm_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void vxm_lds_dma4(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 4, voff, soff, 0, 0);      // lane l -> LDS base + 4 l
+}
+__device__ __forceinline__ void vxm_lds_dma16(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, soff, 0, 0);     // lane l -> LDS base + 16 l
+}
+
+
+// ------------------------------------------------------------------------------------------
 // forward / backward-data kernel
 // ------------------------------------------------------------------------------------------
 constexpr int FWD_TWP = 20;
+constexpr int BV_RS_FWD = 20;          // row stride of the wide-load tile layouts (interior at columns 2..17)
 constexpr int FWD_PS = HD * HH * FWD_TWP;        // 720
 
 template <int CK, int NCT>
@@ -232,6 +254,245 @@ __global__ void __launch_bounds__(256) k_conv3d_k3(ConvIn in, const float* __res
         }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// forward / backward-data kernel, 8-wave version for the large layers (W % 4 == 0, 16-byte aligned tensors)
+// ------------------------------------------------------------------------------------------
+// Same implicit GEMM as k_conv3d_k3, restructured so that the per-chunk staging costs almost nothing:
+//  * block = 8 waves, output tile 8(D) x 4(H) x 16(W) voxels, wave w = depth slice w; two blocks per CU;
+//  * wave w stages channel w of every 8-channel chunk: its per-lane source offsets are computed ONCE per block
+//    (they depend on the tile only; the channel moves the wave-uniform soffset), the zero padding comes from the
+//    buffer descriptor, interior rows are dwordx4 loads (dwordx2 + duplicate through the x2-upsampled segment);
+//  * the loads of chunk q+1 (X plane pieces + packed weights) are in flight in registers under the MFMAs of chunk q;
+//  * the MFMA loop is fully unrolled, branch-free, with the operands of step s+1 requested before the MFMAs of s.
+// X chunk in LDS: [8][10][6][20], interior columns at 2..17, halo columns at 1 / 18; plane stride 1200 = 16 mod 32.
+constexpr int T8_TD = 8;
+constexpr int T8_PS = (T8_TD + 2) * HH * BV_RS_FWD;   // 1200
+constexpr int T8_THREADS = 512;
+
+template <int NCT>
+__global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                              float* __restrict__ y, long long y_bs, int Cout, float act_slope,
+                                                              const float* __restrict__ mask, long long mask_bs, float mask_slope,
+                                                              int B, int D, int H, int W, int Q) {
+    VXM_DYN_SMEM(float, smem);
+    constexpr int CK = 8, KS = 2, RS = BV_RS_FWD;
+    constexpr int WCHUNK = 27 * KS * NCT * 64;
+    constexpr int WIT = (WCHUNK / 4 + T8_THREADS - 1) / T8_THREADS;
+    float* const Xs = smem;                         // [CK][T8_PS]
+    float* const Ws = smem + CK * T8_PS;            // [27][KS][NCT][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, n = lane & 15;
+    const float* const ix0 = in.x0; const float* const ix1 = in.x1;
+    const int iC0 = in.C0, iC1 = in.C1, iup0 = in.up0;
+
+    // tile of this block: block b runs on XCD b % 8 (observed; speed only), XCD x takes the contiguous tile range
+    // [nt x / 8, nt (x+1) / 8) so that concurrently running neighbours share halo lines and weights in one L2
+    const int nw = (W + TW - 1) / TW, nh = (H + TH - 1) / TH, nd = (D + T8_TD - 1) / T8_TD;
+    const int ntiles = B * nd * nh * nw;
+    int tile = blockIdx.x;
+    if (ntiles >= 64) {
+        const int x = tile & 7, j = tile >> 3;
+        const int lo = (int)((long long)ntiles * x / 8), hi = (int)((long long)ntiles * (x + 1) / 8);
+        tile = lo + j;
+        if (tile >= hi) return;                    // grid is rounded up to 8 x ceil(nt / 8)
+    } else if (tile >= ntiles) {
+        return;
+    }
+    const int tw = tile % nw; int tq = tile / nw;
+    const int th = tq % nh; tq /= nh;
+    const int td = tq % nd; const int b = tq / nd;
+    const int d0 = td * T8_TD, h0 = th * TH, w0 = tw * TW;
+    const int g = blockIdx.y;                       // output-channel group of 16*NCT
+
+    const int V = D * H * W;
+    const int Hs = H >> 1, Ws2 = W >> 1;
+    const int V0 = iup0 ? (D >> 1) * Hs * Ws2 : V;
+    const __amdgpu_buffer_rsrc_t r0 = vxm_rsrc(ix0 + (size_t)b * in.bs0, (unsigned)iC0 * (unsigned)V0 * 4u);
+    const __amdgpu_buffer_rsrc_t r1 = vxm_rsrc(iC1 ? ix1 + (size_t)b * in.bs1 : ix0, (unsigned)iC1 * (unsigned)V * 4u);
+
+    // staging roles of this lane: interior slot 64 j + lane (< 240) -> row 16 j + (lane >> 2) of the [10][6] row grid,
+    // columns 4 (lane & 3)..+3; halo slot 64 j + lane (< 120) -> row 32 j + (lane >> 1), side lane & 1.
+    const int lq = lane & 3, lr4 = lane >> 2, lr2 = lane >> 1, hside = lane & 1;
+    const int ibase = lr4 * RS + 2 + 4 * lq;
+    const int hbase = lr2 * RS + (hside ? 18 : 1);
+    int vi[4], vh[2];              // byte offsets inside a plane; for the upsampled segment: of the half-resolution source
+    int viu[4], vhu[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rr = 16 * j + lr4;
+        const int gd = d0 - 1 + rr / HH, gh = h0 - 1 + rr % HH, gw = w0 + 4 * lq;
+        const bool ok = rr < (T8_TD + 2) * HH && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw < W;
+        vi[j] = ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB;
+        viu[j] = ok ? (((gd >> 1) * Hs + (gh >> 1)) * Ws2 + (gw >> 1)) << 2 : VXM_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rr = 32 * j + lr2;
+        const int gd = d0 - 1 + rr / HH, gh = h0 - 1 + rr % HH, gw = hside ? w0 + TW : w0 - 1;
+        const bool ok = rr < (T8_TD + 2) * HH && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        vh[j] = ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB;
+        vhu[j] = ok ? (((gd >> 1) * Hs + (gh >> 1)) * Ws2 + (gw >> 1)) << 2 : VXM_OOB;
+    }
+
+    f32x4 acc[NCT][4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 xi[4];
+    float xh[2];
+    f32x4 wv[WIT];
+    auto load_chunk = [&](int q) __attribute__((always_inline)) {
+        const int cg = q * CK + wave;               // channel staged by this wave (wave-uniform)
+        if (cg < iC0 + iC1) {
+            if (cg < iC0 && iup0) {
+                const int soff = cg * V0 * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r0, viu[j], soff, 0));
+                    xi[j] = (f32x4){t.x, t.x, t.y, t.y};
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, vhu[j], soff, 0));
+            } else {
+                const bool s0 = cg < iC0;
+                const __amdgpu_buffer_rsrc_t r = s0 ? r0 : r1;
+                const int soff = (s0 ? cg * V0 : (cg - iC0) * V) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vi[j], soff, 0));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vh[j], soff, 0));
+            }
+        } else {                                    // channel padding of the last chunk
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xi[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            xh[0] = xh[1] = 0.0f;
+        }
+        const __amdgpu_buffer_rsrc_t rw = vxm_rsrc(wp + ((size_t)g * Q + q) * WCHUNK, WCHUNK * 4u);
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            wv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + T8_THREADS * it) * 16, 0, 0));
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+        float* dst = Xs + wave * T8_PS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < 3 || lane < 48) {               // 240 interior slots
+                *reinterpret_cast<f32x2*>(dst + ibase + 16 * j * RS) = (f32x2){xi[j].x, xi[j].y};
+                *reinterpret_cast<f32x2*>(dst + ibase + 16 * j * RS + 2) = (f32x2){xi[j].z, xi[j].w};
+            }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            if (j < 1 || lane < 56) dst[hbase + 32 * j * RS] = xh[j];       // 120 halo slots
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = tid + T8_THREADS * it;
+            if (i < WCHUNK / 4) reinterpret_cast<f32x4*>(Ws)[i] = wv[it];
+        }
+    };
+
+    const int bbase = kq * T8_PS + wave * HH * RS + n + 1;      // + 4 s planes, + (kd, r + kh) rows, + kw
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int q = 0; q < Q; ++q) {
+        if (q + 1 < Q) load_chunk(q + 1);           // in flight under the MFMAs below
+        // ---- 27 taps x KS k-steps x (NCT x 4) MFMAs, operands double-buffered in registers
+        float a[2][NCT], bv[2][4];
+        auto fetch = [&](int st, float (&af)[NCT], float (&bf)[4]) __attribute__((always_inline)) {
+            const int t = st / KS, s = st % KS;
+            const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) af[ct] = Ws[((t * KS + s) * NCT + ct) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bf[r] = Xs[bbase + s * 4 * T8_PS + (kd * HH + r + kh) * RS + kw];
+        };
+        fetch(0, a[0], bv[0]);
+#pragma unroll
+        for (int st = 0; st < 27 * KS; ++st) {
+            if (st + 1 < 27 * KS) fetch(st + 1, a[(st + 1) & 1], bv[(st + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ct][r] = vxm_mfma16(a[st & 1][ct], bv[st & 1][r], acc[ct][r]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (q + 1 < Q) {
+            __syncthreads();                        // every wave is done reading chunk q
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias + LeakyReLU (+ fused leaky_relu_backward mask), NCDHW store
+    const int d = d0 + wave, w = w0 + n;
+    const bool vox_ok = d < D && w < W;
+    const size_t vox_off = ((size_t)min(d, D - 1) * H) * W + min(w, W - 1);
+    float bz[NCT][4], mk[NCT][4][4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bz[ct][j] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mk[ct][j][r] = 1.0f;
+        }
+    if (bias) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bz[ct][j] = bias[min((g * NCT + ct) * 16 + kq * 4 + j, Cout - 1)];
+    }
+    if (mask) {
+        const float* mb = mask + (size_t)b * mask_bs + vox_off;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = min((g * NCT + ct) * 16 + kq * 4 + j, Cout - 1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mk[ct][j][r] = mb[(size_t)co * V + (size_t)min(h0 + r, H - 1) * W];
+            }
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mk[ct][j][r] = vxm_lrelu_grad(mk[ct][j][r], mask_slope);
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = (g * NCT + ct) * 16 + kq * 4 + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int h = h0 + r;
+                float v = acc[ct][r][j] + bz[ct][j];
+                v = (v > 0.0f ? v : v * act_slope) * mk[ct][j][r];
+                if (vox_ok && h < H && co < Cout)
+                    y[(size_t)b * y_bs + (size_t)co * V + ((size_t)d * H + h) * W + w] = v;
+            }
+        }
+}
+
+// VXM_CONV_GENERIC=1 routes every conv launch through the generic kernels (any W / alignment; LDS-DMA backward-
+// weight), so that the parity tests can exercise them on shapes the wide-load kernels would otherwise take.
+bool bw_force_generic() {
+    static const bool f = [] { const char* e = getenv("VXM_CONV_GENERIC"); return e && e[0] == '1'; }();
+    return f;
+}
+// The 8-wave forward kernel is used from this many 8x4x16 tiles up (below, its 512-voxel tiles leave CUs idle);
+// VXM_CONV_WIDE_MIN_TILES overrides the threshold so that the parity tests can run it on small volumes.
+long long wide_min_tiles() {
+    static const long long v = [] { const char* e = getenv("VXM_CONV_WIDE_MIN_TILES"); return e ? atoll(e) : 1024ll; }();
+    return v;
+}
+
 struct ConvCfg { int CK, NCT, Q, G; size_t elems; };
 ConvCfg conv_cfg(int Cin, int Cout) {
     ConvCfg c;
@@ -272,22 +533,6 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
 // voxel tiles (4x4x16), and writes it once; k_reduce_partials sums the per-block partials in a fixed order.
 // Tiles are zero padded through the buffer descriptor: a lane whose offset is beyond num_records loads 0.0
 // (and an LDS-DMA lane writes 0.0 -- probed on gfx950, tools/probe/ldsdma_probe.hip).
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int VXM_OOB = (int)0x80000000;            // voffset beyond any num_records -> the lane loads 0.0
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t vxm_rsrc(const float* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ void vxm_lds_dma4(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 4, voff, soff, 0, 0);      // lane l -> LDS base + 4 l
-}
-__device__ __forceinline__ void vxm_lds_dma16(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, soff, 0, 0);     // lane l -> LDS base + 16 l
-}
-
 constexpr int BW_WAVES = 16;      // one 1024-thread block per CU: 4 waves per SIMD share the MFMA pipe
 constexpr int BW_THREADS = 64 * BW_WAVES;
 constexpr int BW_SLOTS = 2;       // N-tiles per wave: 27 taps over 16 waves = 11 x 2 + 5 x 1 -> 7,7,7,6 per SIMD
@@ -716,13 +961,6 @@ __global__ void k_bias_finish(const double* __restrict__ acc, float* __restrict_
     if (i < Cout) gb[i] = (float)acc[i];
 }
 
-// VXM_CONV_GENERIC=1 routes every backward-weight launch through the generic (LDS-DMA) kernel, so that the
-// parity tests can exercise it on shapes the wide-load kernel would otherwise take.
-bool bw_force_generic() {
-    static const bool f = [] { const char* e = getenv("VXM_CONV_GENERIC"); return e && e[0] == '1'; }();
-    return f;
-}
-
 struct BwPlan { int NCT, Qc, G, T, nparts; };
 BwPlan bw_plan(int Cin, int Cout, int B, int D, int H, int W) {
     BwPlan p;
@@ -774,6 +1012,28 @@ int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, co
     VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_fwd: null pointer");
     const ConvCfg c = conv_cfg(C0 + C1, Cout);
     ConvIn in{x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up};
+    // large layers: the 8-wave wide-load kernel (needs 4-float groups that neither straddle row ends nor break alignment)
+    {
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+        const bool vec = c.CK == 8 && c.NCT <= 2 && (W & 3) == 0 && al16(x0) && (C1 == 0 || al16(x1)) && (x0_bstride & 3) == 0 &&
+                         (x1_bstride & 3) == 0 && al16(wpacked) && tiles8 >= wide_min_tiles() && tiles8 < (1ll << 30) && !bw_force_generic();
+        if (vec) {
+            static bool opt_in = false;
+            if (!opt_in) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_t8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                opt_in = true;
+            }
+            const dim3 grid8((unsigned)((tiles8 + 7) / 8 * 8), c.G);
+            const size_t lds8 = sizeof(float) * ((size_t)8 * T8_PS + 27 * 2 * c.NCT * 64);
+#define LAUNCH8(NCT_) hipLaunchKernelGGL((k_conv3d_k3_t8<NCT_>), grid8, dim3(T8_THREADS), lds8, VXM_STREAM(stream), in, wpacked, bias, y, \
+        (long long)y_bstride, Cout, act_slope, mask_src, (long long)mask_bstride, mask_slope, B, D, H, W, c.Q)
+            if (c.NCT == 1) LAUNCH8(1);
+            else LAUNCH8(2);
+#undef LAUNCH8
+            return vxm_check_launch("vxm_conv3d_k3_fwd");
+        }
+    }
     const long long tiles = (long long)B * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_fwd: too many tiles");
     const dim3 grid((unsigned)tiles, c.G);

@@ -12,6 +12,7 @@ from .. import _lib
 from .. import profiler as _prof
 from .._lib import call, ptr, require_device, stream
 
+SPLIT_48 = True     # conv_bwd_data: produce 48-channel results as 32 + 16 (module-level switch for A/B timing)
 INTERP = {"bilinear": 0, "nearest": 1}
 PENALTY = {"l1": 0, "l2": 1}
 
@@ -260,6 +261,22 @@ def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, ma
              cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, stream())
 
 
+def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W):
+    """convolution_backward w.r.t. the input = the forward kernel with the flipped / transposed weights
+    (networks.py:299 autograd twin), optionally multiplied by LeakyReLU'(mask) of the previous ConvBlock.
+    A 48-channel result (16 mod 32) is produced as 32 + 16 channels: two launches of the 8-wave kernel's 2- and
+    1-tile instances beat one launch of the 3-tile instance (which only exists in the 4-wave kernel)."""
+    V = D * H * W
+    if cin > 32 and cin % 32 == 16 and SPLIT_48:
+        bounds = list(range(0, cin - 16, 32)) + [cin - 16, cin]
+    else:
+        bounds = [0, cin]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        ws = w if (lo, hi) == (0, cin) else w[:, lo:hi].contiguous()
+        conv_launch(dz, cout, cout * V, False, None, 0, 0, pack_weights(ws, True), None, gx[:, lo:hi], cin * V, hi - lo, 1.0,
+                    mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W)
+
+
 class _Workspace:
     """Grow-only scratch shared by the bwd-weight launches of one backward pass."""
 
@@ -318,7 +335,7 @@ class ConvFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            conv_launch(dz, cout, cout * V, False, None, 0, 0, pack_weights(w, True), None, gx, cin * V, cin, 1.0, None, 0, 1.0, B, D, H, W)
+            conv_bwd_data(dz, cout, w, gx, cin, None, 1.0, B, D, H, W)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw = torch.empty_like(w)
             gb = torch.empty(cout, dtype=w.dtype, device=w.device) if ctx.has_bias else None
@@ -542,17 +559,15 @@ class UnetFn(torch.autograd.Function):
             feeds_inputs = s0 < n_in
             if feeds_inputs and not any(ctx.needs_input_grad[1 + i] for i in range(n_in)):
                 continue
-            wp_t = pack_weights(w, True)
             fuse = (not up0) and s1 is None and (not feeds_inputs) and len(plan.consumers[s0]) == 1 \
                 and plan.ops[plan.producer[s0]]["kind"] == "conv"
             gx = torch.empty((B, cin, D, H, W), dtype=dt, device=dev)
             if fuse:   # dX * LeakyReLU'(y_prev) in the epilogue == DZ of the previous ConvBlock
                 pslope = plan.ops[plan.producer[s0]]["slope"]
-                conv_launch(dz, cout, cout * V, False, None, 0, 0, wp_t, None, gx, cin * V, cin, 1.0,
-                            T[s0] if pslope != 1.0 else None, cin * V, pslope, B, D, H, W)
+                conv_bwd_data(dz, cout, w, gx, cin, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W)
                 DZ[s0] = gx
                 continue
-            conv_launch(dz, cout, cout * V, False, None, 0, 0, wp_t, None, gx, cin * V, cin, 1.0, None, 0, 1.0, B, D, H, W)
+            conv_bwd_data(dz, cout, w, gx, cin, None, 1.0, B, D, H, W)
             if feeds_inputs:
                 for i, sid in enumerate([s0] + ([s1] if s1 is not None else [])):
                     lo = 0 if i == 0 else c0
