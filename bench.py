@@ -77,6 +77,27 @@ def cpu_baseline(full_shape, sample_shape, int_steps):
     }
 
 
+def hbm_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
+    (profiles/*_hbm_counters.json, written by tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc
+    passes, kernel-trace only).  Units and gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes:
+    both counters are in KiB; FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes, so the
+    read side is doubled.  Returns (bytes_per_launch or None, source)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_counters.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            ctr = json.load(f)
+    except (OSError, ValueError):
+        return None, None
+    ent = ctr.get(kernel)
+    if not ent or "FETCH_SIZE" not in ent or "WRITE_SIZE" not in ent:
+        return None, None
+    return (2.0 * ent["FETCH_SIZE"]["mean"] + ent["WRITE_SIZE"]["mean"]) * 1024.0, os.path.relpath(files[-1], ROOT)
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -164,6 +185,9 @@ def main():
         roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_per_launch": ds["bytes"] / ds["launches"], "avg_launch_ms": ds["ms"] / ds["launches"]}
+    roof["traffic"], src = hbm_traffic(dom)
+    if src:
+        roof["traffic_unit"] = "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, KiB counters; rocprofv3 --pmc of this command: %s)" % src
     out = {
         "metric": "volume-pairs/sec VxmDense 160x192x224 int_steps=7 NCC train",
         "value": world * B * args.steps / elapsed, "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps,

@@ -1,15 +1,67 @@
 #!/usr/bin/env python
-"""Dump the per-kernel summary (calls, total/avg duration, %) of a rocprofv3 --kernel-trace --stats run
-(rocpd sqlite database) as CSV text for profiles/."""
-import sqlite3
+"""Summaries of rocprofv3 CSV output for profiles/ (tracked):
+
+  rocprof_summary.py stats  DIR OUT.csv     per-kernel calls / total / average duration from *_kernel_trace.csv
+                                            (the same numbers `rocprofv3 --kernel-trace --stats` prints)
+  rocprof_summary.py pmc    DIR OUT.json    per-kernel mean of every counter in *_counter_collection.csv, DIR may be
+                                            given several times (one per --pmc pass)
+
+Kernel names are shortened to the function name with its template arguments.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
 import sys
 
-db, out = sys.argv[1], sys.argv[2]
-c = sqlite3.connect(db)
-rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
-with open(out, "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats summary (durations in microseconds), source: %s\n" % db.split("/")[-1])
-    f.write("kernel,calls,total_us,avg_us,percent\n")
-    for name, calls, tot, avg, pct in rows:
-        f.write('"%s",%d,%.3f,%.3f,%.3f\n' % (name.replace('"', "'"), calls, tot, avg, pct))
-print("wrote", out, len(rows), "kernels")
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    m = re.match(r"(?:void )?([A-Za-z_0-9:]+(?:<[^(]*>)?)\(", name)
+    s = m.group(1) if m else name.split("(")[0]
+    return s[-90:]
+
+
+def stats(root, out):
+    agg = collections.OrderedDict()
+    for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
+        for r in csv.DictReader(open(f)):
+            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            a = agg.setdefault(short(r["Kernel_Name"]), [0, 0.0, 1e30, 0.0])
+            a[0] += 1
+            a[1] += d
+            a[2] = min(a[2], d)
+            a[3] = max(a[3], d)
+    tot = sum(a[1] for a in agg.values()) or 1.0
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats summary (durations in microseconds), source dir: %s\n" % os.path.basename(root.rstrip("/")))
+        f.write("kernel,calls,total_us,avg_us,min_us,max_us,percent\n")
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            f.write('"%s",%d,%.3f,%.3f,%.3f,%.3f,%.3f\n' % (k, a[0], a[1], a[1] / a[0], a[2], a[3], 100 * a[1] / tot))
+    print("wrote", out, len(agg), "kernels")
+
+
+def pmc(roots, out):
+    agg = collections.OrderedDict()
+    for root in roots:
+        for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+            for r in csv.DictReader(open(f)):
+                k = agg.setdefault(short(r["Kernel_Name"]), collections.OrderedDict())
+                c = k.setdefault(r["Counter_Name"], [0, 0.0])
+                c[0] += 1
+                c[1] += float(r["Counter_Value"])
+    res = collections.OrderedDict()
+    for k, ctrs in agg.items():
+        res[k] = {c: {"dispatches": v[0], "mean": v[1] / v[0]} for c, v in ctrs.items()}
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    print("wrote", out, len(res), "kernels")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2:-1], sys.argv[-1])

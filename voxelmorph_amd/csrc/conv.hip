@@ -494,6 +494,7 @@ long long wide_min_tiles() {
 }
 
 struct ConvCfg { int CK, NCT, Q, G; size_t elems; };
+static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 ConvCfg conv_cfg(int Cin, int Cout) {
     ConvCfg c;
     c.CK = Cin <= 4 ? 4 : 8;
@@ -503,6 +504,17 @@ ConvCfg conv_cfg(int Cin, int Cout) {
     c.G = (Cout + 16 * c.NCT - 1) / (16 * c.NCT);
     c.elems = (size_t)c.G * c.Q * 27 * (c.CK / 4) * c.NCT * 64;
     return c;
+}
+
+bool fwd_wide_ok(const ConvCfg& c, const float* x0, int64_t bs0, const float* x1, int C1, int64_t bs1, const float* wpacked,
+                 int B, int D, int H, int W) {
+    const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    return c.CK == 8 && c.NCT <= 2 && (W & 3) == 0 && al16(x0) && (C1 == 0 || al16(x1)) && (bs0 & 3) == 0 && (bs1 & 3) == 0 &&
+           al16(wpacked) && tiles8 >= wide_min_tiles() && tiles8 < (1ll << 30) && !bw_force_generic();
+}
+bool bwd_weight_wide_ok(const float* x0, int64_t bs0, const float* x1, int C1, int64_t bs1, const float* dz, int64_t dz_bs, int W) {
+    return (W & 3) == 0 && al16(x0) && (C1 == 0 || al16(x1)) && al16(dz) && (bs0 & 3) == 0 && (bs1 & 3) == 0 && (dz_bs & 3) == 0 &&
+           !bw_force_generic();
 }
 
 // w: [Cw_out][Cw_in][27] (reference layout).  Packed operator has Cin_p inputs / Cout_p outputs.
@@ -1014,10 +1026,8 @@ int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, co
     ConvIn in{x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up};
     // large layers: the 8-wave wide-load kernel (needs 4-float groups that neither straddle row ends nor break alignment)
     {
-        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-        const bool vec = c.CK == 8 && c.NCT <= 2 && (W & 3) == 0 && al16(x0) && (C1 == 0 || al16(x1)) && (x0_bstride & 3) == 0 &&
-                         (x1_bstride & 3) == 0 && al16(wpacked) && tiles8 >= wide_min_tiles() && tiles8 < (1ll << 30) && !bw_force_generic();
+        const bool vec = fwd_wide_ok(c, x0, x0_bstride, x1, C1, x1_bstride, wpacked, B, D, H, W);
         if (vec) {
             static bool opt_in = false;
             if (!opt_in) {
@@ -1057,6 +1067,18 @@ int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, co
     return vxm_check_launch("vxm_conv3d_k3_fwd");
 }
 
+int vxm_conv3d_k3_fwd_variant(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
+                              const float* wpacked, int Cout, int B, int D, int H, int W) {
+    if (C0 <= 0 || C1 < 0 || Cout <= 0) return -1;
+    const ConvCfg c = conv_cfg(C0 + C1, Cout);
+    return (fwd_wide_ok(c, x0, x0_bstride, x1, C1, x1_bstride, wpacked, B, D, H, W) ? 100 : 0) + 10 * c.CK + c.NCT;
+}
+
+int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
+                                     const float* dz, int64_t dz_bstride, int Cout, int W) {
+    return (bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W) ? 10 : 0) + (Cout <= 16 ? 1 : 2);
+}
+
 size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D, int H, int W) {
     if (Cin <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     const BwPlan p = bw_plan(Cin, Cout, B, D, H, W);
@@ -1088,9 +1110,7 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
         lds_opt_in = true;
     }
     // wide-load path: rows of 4-float groups must not straddle row ends and must be 16-byte aligned in memory
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    const bool vec = (W & 3) == 0 && al16(x0) && (C1 == 0 || al16(x1)) && al16(dz) && (x0_bstride & 3) == 0 && (x1_bstride & 3) == 0 &&
-                     (dz_bstride & 3) == 0 && !bw_force_generic();
+    const bool vec = bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W);
 #define BW_LAUNCH(KERNEL, LDSF) hipLaunchKernelGGL(KERNEL, grid, dim3(BW_THREADS), sizeof(float) * (size_t)(LDSF), VXM_STREAM(stream), in, dz, \
         (long long)dz_bstride, Cout, part, B, D, H, W, p.Qc, p.G)
     if (vec) {

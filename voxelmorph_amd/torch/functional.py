@@ -244,19 +244,12 @@ def pack_weights(w, flip):
     return wp
 
 
-def conv_variant(cin, cout):
-    """Kernel template instance the C ABI dispatches to (conv.hip: conv_cfg)."""
-    if cout <= 16:
-        nct = 1
-    elif cout <= 32:
-        nct = 2
-    else:
-        nct = 3 if (cout + 47) // 48 * 48 < (cout + 31) // 32 * 32 else 2
-    return "conv3d_k3<CK=%d,NCT=%d>" % (4 if cin <= 4 else 8, nct)
-
-
 def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
-    with _prof.region(conv_variant(c0 + c1, cout), flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+    name = None
+    if _prof.ACTIVE is not None:          # label the region with the kernel the C ABI will dispatch to
+        v = _lib.lib().vxm_conv3d_k3_fwd_variant(ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), cout, B, D, H, W)
+        name = "k_conv3d_k3_t8<%d>" % (v % 10) if v >= 100 else "k_conv3d_k3<%d,%d>" % (v // 10, v % 10)
+    with _prof.region(name, flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_conv3d_k3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
              cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, stream())
 
@@ -293,7 +286,11 @@ class _Workspace:
 def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H, W):
     need = _lib.lib().vxm_conv3d_k3_bwd_weight_workspace_bytes(c0 + c1, cout, B, D, H, W)
     buf = ws.get(need)
-    with _prof.region("conv3d_k3_bwd_weight<NCT=%d>" % (1 if cout <= 16 else 2), flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+    name = None
+    if _prof.ACTIVE is not None:
+        v = _lib.lib().vxm_conv3d_k3_bwd_weight_variant(ptr(x0), bs0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, W)
+        name = "k_conv3d_k3_bwd_weight_%s<%d>" % ("vec" if v >= 10 else "dma", v % 10)
+    with _prof.region(name, flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_conv3d_k3_bwd_weight", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W,
              cout, ptr(gw), ptr(gb), ptr(buf), buf.numel(), B, D, H, W, stream())
 
