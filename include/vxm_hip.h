@@ -126,11 +126,14 @@ int vxm_upsample2_cat(const float* x0, int C0, const float* x1, int C1, float* o
 /* ---- losses (losses.py).  Every *_fwd writes a 0-dim fp32 loss; `acc` is a caller-provided
  * scratch of doubles (zeroed by the call) that the matching *_bwd reads back.  gloss points to
  * the upstream scalar gradient ON DEVICE (no host sync). */
-/* NCC.loss, losses.py:15-67 (win^3 box sums as separable running sums, zero padded).
- * sums: 5*B*D*H*W floats (I,J,I^2,J^2,IJ box sums, kept for backward); work: 5*B*D*H*W floats. */
+/* NCC.loss, losses.py:15-67 (win^3 zero-padded box sums).  Windows 3..9: one fused kernel marches pixel columns
+ * along D (2-D box sums through LDS, a register ring over depth) and keeps the partials (a,b,c) = d cc/d(sum J,
+ * sum J^2, sum IJ) for backward in `sums` (3*B*D*H*W floats used, `work` unused).  Larger windows: separable passes;
+ * `sums` keeps the five box sums (5*B*D*H*W floats) and `work` is a 5*B*D*H*W scratch. */
 int vxm_ncc_fwd(const float* I, const float* J, float* loss, float* sums, float* work, double* acc,
                 int B, int D, int H, int W, int win, void* stream);
-/* gJ = dL/dJ (y_pred).  work: 6*B*D*H*W floats. */
+/* gJ = dL/dJ (y_pred) from what vxm_ncc_fwd left in `sums` for the same (I, J, win).  work: unused for windows
+ * 3..9, else 6*B*D*H*W floats. */
 int vxm_ncc_bwd(const float* I, const float* J, const float* sums, const float* gloss, float* gJ,
                 float* work, int B, int D, int H, int W, int win, void* stream);
 /* Grad.loss, losses.py:102-135.  mult = loss_mult (1 if None).  acc: 3*B doubles. */

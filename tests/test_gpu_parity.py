@@ -182,6 +182,23 @@ def test_ncc_grad_vs_fp64(vxm):
     assert rel_l2(N(Ig.grad), Id.grad.numpy()) < 1e-3
 
 
+@pytest.mark.parametrize("win", [3, 7, 9, 11])
+def test_ncc_windows_batches_segments_vs_fp64(vxm, win):
+    """Fused march (win <= 9: several depth segments, ragged tiles, batch 2) and the separable passes (win 11)."""
+    rng = np.random.default_rng(win)
+    vol = (45, 19, 37)
+    I = rng.random((2, 1) + vol).astype(np.float32)
+    J = (0.6 * I + 0.4 * rng.random((2, 1) + vol)).astype(np.float32)
+    Jg = G(J, True)
+    l = vxm.losses.NCC(win=[win] * 3).loss(G(I), Jg)
+    l.backward()
+    Jd = torch.from_numpy(J).double().requires_grad_()
+    ld = orc.ncc_loss(torch.from_numpy(I).double(), Jd, win=[win] * 3)
+    ld.backward()
+    assert abs(float(l) - float(ld)) < 1e-5
+    assert rel_l2(N(Jg.grad), Jd.grad.numpy()) < 1e-3
+
+
 def test_grad_mse_dice_golden(vxm, g_losses):
     for pen, mult in (("l1", None), ("l2", 2)):
         fl = G(g_losses["flow"], True)
@@ -305,6 +322,10 @@ def test_maxpool_ties_first_index(vxm):
                                 dict(half_res=True), dict(nb_features=[[8, 8], [8, 8]])])
 def test_unet_vs_oracle(vxm, kw):
     inshape = (16, 16, 32)
+    # seeded weights: with unseeded ones the test is flaky by construction -- now and then a pre-activation lands within
+    # fp32 rounding of 0, LeakyReLU' differs between the fp32 path and the fp64 oracle at that voxel, and at the deepest
+    # levels (a few hundred activations) one such flip moves a parameter gradient by more than the tolerance
+    torch.manual_seed(20240607)
     net = vxm.networks.Unet(inshape, infeats=2, **kw).cuda()
     sd = {("unet_model." + k): v for k, v in net.state_dict().items()}
     rng = np.random.default_rng(4)

@@ -128,6 +128,169 @@ __global__ void __launch_bounds__(256) k_ncc_grad_w(const float* __restrict__ u2
     gJ[p] = scale * (sa + 2.0f * J[p] * sb + I[p] * sc);
 }
 
+// ---- fused NCC for windows <= 9: one kernel marches a (8 x 32)-pixel column along D.  Per depth slice the haloed
+// products tile goes through LDS (W box sum, then H box sum: direct 2R+1-tap sums in the same order as the generic
+// passes above, so the values are identical), the last 2R+1 slices of 2-D sums live in a register shift ring, and
+// the 3-D sums of the slice R behind the front give cc, its fp64 block reduction and the three partials
+// (a, b, c) = d cc / d(J sum, J^2 sum, IJ sum) that backward box-filters.  HBM traffic: I, J once (+ L2-served halo),
+// 3 planes written -- instead of 5 planes x 3 passes.
+constexpr int NF_TH = 8, NF_TW = 32, NF_SEG = 40;     // tile, and slices per block along D
+
+template <int R>
+__global__ void __launch_bounds__(256) k_ncc_fused_fwd(const float* __restrict__ I, const float* __restrict__ J, float* __restrict__ abc,
+                                                       double* __restrict__ acc, int D, int H, int W, long long BV) {
+    constexpr int WIN = 2 * R + 1, PH = NF_TH + 2 * R, PW = NF_TW + 2 * R, PWP = PW + 1;
+    __shared__ float P[5][PH][PWP];
+    __shared__ float Rw[5][PH][NF_TW];
+    __shared__ double red[4];
+    const int tid = threadIdx.x, wx = tid & 31, hy = tid >> 5;
+    const int ntw = (W + NF_TW - 1) / NF_TW;
+    const int w0 = (blockIdx.x % ntw) * NF_TW, h0 = (blockIdx.x / ntw) * NF_TH;
+    const int dlo = blockIdx.y * NF_SEG, dhi = min(D, dlo + NF_SEG);
+    const size_t HW = (size_t)H * W, vol = (size_t)blockIdx.z * D * HW;
+    const float n = (float)(WIN * WIN * WIN);
+    const int gh = h0 + hy, gw = w0 + wx;
+    const bool pix_ok = gh < H && gw < W;
+    float ring[WIN][5];
+#pragma unroll
+    for (int k = 0; k < WIN; ++k)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) ring[k][q] = 0.0f;
+    double cc_sum = 0.0;
+    for (int z = dlo - R; z < dhi + R; ++z) {
+        float s2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        if (z >= 0 && z < D) {                              // block-uniform; slices outside the volume are zero padding
+            const float* Iz = I + vol + (size_t)z * HW;
+            const float* Jz = J + vol + (size_t)z * HW;
+            for (int idx = tid; idx < PH * PW; idx += 256) {
+                const int r = idx / PW, c = idx - r * PW;
+                const int y = h0 - R + r, x = w0 - R + c;
+                float a = 0.0f, b = 0.0f;
+                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) { a = Iz[(size_t)y * W + x]; b = Jz[(size_t)y * W + x]; }
+                P[0][r][c] = a; P[1][r][c] = b; P[2][r][c] = a * a; P[3][r][c] = b * b; P[4][r][c] = a * b;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < PH * NF_TW; idx += 256) {
+                const int r = idx >> 5, c = idx & 31;
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < WIN; ++k) t += P[q][r][c + k];
+                    Rw[q][r][c] = t;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) s2[q] += Rw[q][hy + k][wx];
+        }
+#pragma unroll
+        for (int k = 0; k + 1 < WIN; ++k)
+#pragma unroll
+            for (int q = 0; q < 5; ++q) ring[k][q] = ring[k + 1][q];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) ring[WIN - 1][q] = s2[q];
+        const int d = z - R;
+        if (d >= dlo && pix_ok) {
+            float s[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                float t = 0.0f;
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) t += ring[k][q];
+                s[q] = t;
+            }
+            float cross, Ivar, Jvar;
+            ncc_terms(s[0], s[1], s[2], s[3], s[4], n, cross, Ivar, Jvar);
+            const float den = Ivar * Jvar + 1e-5f;
+            cc_sum += (double)(cross * cross / den);
+            if (abc) {
+                const float t = cross / den, t2 = t * t * Ivar;       // as k_ncc_abc_d
+                const size_t p = vol + (size_t)d * HW + (size_t)gh * W + gw;
+                abc[p] = 2.0f * t * (-s[0] / n) + t2 * (2.0f * s[1] / n);
+                abc[BV + p] = -t2;
+                abc[2 * BV + p] = 2.0f * t;
+            }
+        }
+    }
+    block_atomic_add(cc_sum, acc, red);
+}
+
+// backward: 3-D box filter of (a, b, c) by the same march, chain rule onto J fused into the output:
+// dL/dJ = gloss * (-1/N) * [ S(a) + 2 J S(b) + I S(c) ]
+template <int R>
+__global__ void __launch_bounds__(256) k_ncc_fused_bwd(const float* __restrict__ I, const float* __restrict__ J, const float* __restrict__ abc,
+                                                       const float* __restrict__ gloss, float* __restrict__ gJ, int D, int H, int W,
+                                                       long long BV) {
+    constexpr int WIN = 2 * R + 1, PH = NF_TH + 2 * R, PW = NF_TW + 2 * R, PWP = PW + 1;
+    __shared__ float P[3][PH][PWP];
+    __shared__ float Rw[3][PH][NF_TW];
+    const int tid = threadIdx.x, wx = tid & 31, hy = tid >> 5;
+    const int ntw = (W + NF_TW - 1) / NF_TW;
+    const int w0 = (blockIdx.x % ntw) * NF_TW, h0 = (blockIdx.x / ntw) * NF_TH;
+    const int dlo = blockIdx.y * NF_SEG, dhi = min(D, dlo + NF_SEG);
+    const size_t HW = (size_t)H * W, vol = (size_t)blockIdx.z * D * HW;
+    const int gh = h0 + hy, gw = w0 + wx;
+    const bool pix_ok = gh < H && gw < W;
+    const float scale = -gloss[0] / (float)BV;
+    float ring[WIN][3];
+#pragma unroll
+    for (int k = 0; k < WIN; ++k)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ring[k][q] = 0.0f;
+    for (int z = dlo - R; z < dhi + R; ++z) {
+        float s2[3] = {0.f, 0.f, 0.f};
+        if (z >= 0 && z < D) {
+            const size_t zoff = vol + (size_t)z * HW;
+            for (int idx = tid; idx < PH * PW; idx += 256) {
+                const int r = idx / PW, c = idx - r * PW;
+                const int y = h0 - R + r, x = w0 - R + c;
+                const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                const size_t p = zoff + (size_t)y * W + x;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) P[q][r][c] = ok ? abc[q * BV + p] : 0.0f;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < PH * NF_TW; idx += 256) {
+                const int r = idx >> 5, c = idx & 31;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < WIN; ++k) t += P[q][r][c + k];
+                    Rw[q][r][c] = t;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) s2[q] += Rw[q][hy + k][wx];
+        }
+#pragma unroll
+        for (int k = 0; k + 1 < WIN; ++k)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ring[k][q] = ring[k + 1][q];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ring[WIN - 1][q] = s2[q];
+        const int d = z - R;
+        if (d >= dlo && pix_ok) {
+            float s[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float t = 0.0f;
+#pragma unroll
+                for (int k = 0; k < WIN; ++k) t += ring[k][q];
+                s[q] = t;
+            }
+            const size_t p = vol + (size_t)d * HW + (size_t)gh * W + gw;
+            gJ[p] = scale * (s[0] + 2.0f * J[p] * s[1] + I[p] * s[2]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ Grad
 template <int L2>
 __device__ __forceinline__ float pen(float t) { return L2 ? t * t : fabsf(t); }
@@ -275,9 +438,19 @@ int vxm_ncc_fwd(const float* I, const float* J, float* loss, float* sums, float*
     const int r = win / 2;
     hipStream_t s = VXM_STREAM(stream);
     (void)hipMemsetAsync(acc, 0, sizeof(double), s);
-    hipLaunchKernelGGL(k_ncc_prod_w, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, I, J, sums, BV, W, r);
-    hipLaunchKernelGGL(k_box_axis, dim3(vxm_blocks(5 * BV, 256)), dim3(256), 0, s, sums, work, 5 * BV, H, (long long)W, r);
-    hipLaunchKernelGGL(k_ncc_cc, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, work, sums, acc, BV, D, (long long)H * W, r, (float)win * win * win);
+    if (win >= 3 && win <= 9 && B <= 65535) {          // fused march; `sums` receives the (a, b, c) planes for backward
+        const dim3 grid(((W + NF_TW - 1) / NF_TW) * ((H + NF_TH - 1) / NF_TH), (D + NF_SEG - 1) / NF_SEG, B);
+        switch (r) {
+            case 1: hipLaunchKernelGGL(k_ncc_fused_fwd<1>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV); break;
+            case 2: hipLaunchKernelGGL(k_ncc_fused_fwd<2>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV); break;
+            case 3: hipLaunchKernelGGL(k_ncc_fused_fwd<3>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV); break;
+            default: hipLaunchKernelGGL(k_ncc_fused_fwd<4>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV); break;
+        }
+    } else {                                            // generic separable passes; `sums` receives the five box sums
+        hipLaunchKernelGGL(k_ncc_prod_w, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, I, J, sums, BV, W, r);
+        hipLaunchKernelGGL(k_box_axis, dim3(vxm_blocks(5 * BV, 256)), dim3(256), 0, s, sums, work, 5 * BV, H, (long long)W, r);
+        hipLaunchKernelGGL(k_ncc_cc, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, work, sums, acc, BV, D, (long long)H * W, r, (float)win * win * win);
+    }
     hipLaunchKernelGGL(k_finish_mean, dim3(1), dim3(64), 0, s, acc, loss, -1.0 / (double)BV);
     return vxm_check_launch("vxm_ncc_fwd");
 }
@@ -289,6 +462,16 @@ int vxm_ncc_bwd(const float* I, const float* J, const float* sums, const float* 
     const long long V = (long long)D * H * W, BV = V * B;
     const int r = win / 2;
     hipStream_t s = VXM_STREAM(stream);
+    if (win >= 3 && win <= 9 && B <= 65535) {
+        const dim3 grid(((W + NF_TW - 1) / NF_TW) * ((H + NF_TH - 1) / NF_TH), (D + NF_SEG - 1) / NF_SEG, B);
+        switch (r) {
+            case 1: hipLaunchKernelGGL(k_ncc_fused_bwd<1>, grid, dim3(256), 0, s, I, J, sums, gloss, gJ, D, H, W, BV); break;
+            case 2: hipLaunchKernelGGL(k_ncc_fused_bwd<2>, grid, dim3(256), 0, s, I, J, sums, gloss, gJ, D, H, W, BV); break;
+            case 3: hipLaunchKernelGGL(k_ncc_fused_bwd<3>, grid, dim3(256), 0, s, I, J, sums, gloss, gJ, D, H, W, BV); break;
+            default: hipLaunchKernelGGL(k_ncc_fused_bwd<4>, grid, dim3(256), 0, s, I, J, sums, gloss, gJ, D, H, W, BV); break;
+        }
+        return vxm_check_launch("vxm_ncc_bwd");
+    }
     float* u1 = work;
     float* u2 = work + 3 * BV;
     hipLaunchKernelGGL(k_ncc_abc_d, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, sums, u1, BV, D, (long long)H * W, r, (float)win * win * win);

@@ -130,13 +130,15 @@ class NCCFn(torch.autograd.Function):
             raise ValueError("NCC: expected two [B,1,D,H,W] tensors (the reference's box filter has one "
                              "input channel, losses.py:29), got %s / %s" % (tuple(I.shape), tuple(J.shape)))
         loss = torch.empty((), dtype=I.dtype, device=I.device)
-        sums = torch.empty((5, B, D, H, W), dtype=I.dtype, device=I.device)
-        work = torch.empty((5, B, D, H, W), dtype=I.dtype, device=I.device)
+        fused = 3 <= win <= 9          # vxm_ncc_fwd: windows up to 9 take the fused march and keep (a, b, c), 3 planes
+        sums = torch.empty((3 if fused else 5, B, D, H, W), dtype=I.dtype, device=I.device)
+        work = torch.empty((1,) if fused else (5, B, D, H, W), dtype=I.dtype, device=I.device)
         acc = torch.empty(1, dtype=torch.float64, device=I.device)
         with _prof.region("ncc_fwd", nbytes=8.0 * B * D * H * W):
             call("vxm_ncc_fwd", ptr(I), ptr(J), ptr(loss), ptr(sums), ptr(work), ptr(acc), B, D, H, W, win, stream())
         ctx.save_for_backward(I, J, sums)
         ctx.win = win
+        ctx.fused = fused
         return loss
 
     @staticmethod
@@ -145,14 +147,20 @@ class NCCFn(torch.autograd.Function):
         B, _, D, H, W = I.shape
         gloss = _c(gloss)
         gI = gJ = None
-        work = torch.empty((6, B, D, H, W), dtype=I.dtype, device=I.device)
+        work = torch.empty((1,) if ctx.fused else (6, B, D, H, W), dtype=I.dtype, device=I.device)
         if ctx.needs_input_grad[1]:
             gJ = torch.empty_like(J)
             with _prof.region("ncc_bwd", nbytes=12.0 * B * D * H * W):
                 call("vxm_ncc_bwd", ptr(I), ptr(J), ptr(sums), ptr(gloss), ptr(gJ), ptr(work), B, D, H, W, ctx.win, stream())
         if ctx.needs_input_grad[0]:
-            # cc is symmetric in (I, J): swap the roles (box-sum planes 0<->1 and 2<->3)
-            swapped = torch.stack([sums[1], sums[0], sums[3], sums[2], sums[4]])
+            # cc is symmetric in (I, J): swap the roles
+            if ctx.fused:              # (a, b, c) were kept for J only: one more forward march with the roles swapped
+                swapped = torch.empty_like(sums)
+                tmp_loss = torch.empty((), dtype=I.dtype, device=I.device)
+                acc = torch.empty(1, dtype=torch.float64, device=I.device)
+                call("vxm_ncc_fwd", ptr(J), ptr(I), ptr(tmp_loss), ptr(swapped), ptr(work), ptr(acc), B, D, H, W, ctx.win, stream())
+            else:                      # box-sum planes 0<->1 and 2<->3
+                swapped = torch.stack([sums[1], sums[0], sums[3], sums[2], sums[4]])
             gI = torch.empty_like(I)
             call("vxm_ncc_bwd", ptr(J), ptr(I), ptr(swapped), ptr(gloss), ptr(gI), ptr(work), B, D, H, W, ctx.win, stream())
         return gI, gJ, None
