@@ -12,42 +12,64 @@
 
 namespace {
 
-struct Corners {
-    int idx[8];      // linear offset inside one [D,H,W] plane (valid only where ok bit set)
-    float w[8];      // trilinear weight
-    unsigned ok;     // bit k: corner k inside the volume (padding_mode='zeros')
-    float wz0, wz1, wy0, wy1, wx0, wx1;
-};
-
-// ATen grid_sampler_3d corner/weight construction: x0 = floor(x); weights (x1 - x) and (x - x0).
-__device__ __forceinline__ void make_corners(float z, float y, float x, int D, int H, int W, Corners& c) {
-    const float fz = floorf(z), fy = floorf(y), fx = floorf(x);
-    c.wz1 = z - fz; c.wz0 = (fz + 1.0f) - z;
-    c.wy1 = y - fy; c.wy0 = (fy + 1.0f) - y;
-    c.wx1 = x - fx; c.wx0 = (fx + 1.0f) - x;
-    // clamp before the int conversion so that wildly out-of-range coordinates stay defined
-    const int z0 = (int)fminf(fmaxf(fz, -2.0f), (float)D), y0 = (int)fminf(fmaxf(fy, -2.0f), (float)H),
-              x0 = (int)fminf(fmaxf(fx, -2.0f), (float)W);
-    c.ok = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
-        const int zz = z0 + dz, yy = y0 + dy, xx = x0 + dx;
-        const bool in = (zz >= 0) & (zz < D) & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-        c.ok |= (in ? 1u : 0u) << k;
-        c.idx[k] = in ? (zz * H + yy) * W + xx : 0;
-        c.w[k] = (dz ? c.wz1 : c.wz0) * (dy ? c.wy1 : c.wy0) * (dx ? c.wx1 : c.wx0);
-    }
+// One axis of ATen's grid_sampler_3d corner construction: x0 = floor(x), weights (x0 + 1 - x) and (x - x0).
+// The two corner indices are clamped into the volume (so that every gather address is valid) and the in-volume
+// tests kept separately: padding_mode='zeros' is applied by zeroing the WEIGHT (forward) or the VALUE (backward)
+// of an outside corner, which leaves the in-volume terms bit-identical and needs no branches.
+struct AxisTaps { int i0, i1; float w0, w1; bool ok0, ok1; };
+__device__ __forceinline__ AxisTaps axis_corners(float x, int S) {
+    AxisTaps a;
+    const float f = floorf(x);
+    a.w1 = x - f; a.w0 = (f + 1.0f) - x;
+    const int i = (int)fminf(fmaxf(f, -2.0f), (float)S);      // clamp before the int conversion: wild coordinates stay defined
+    a.ok0 = (unsigned)i < (unsigned)S; a.ok1 = (unsigned)(i + 1) < (unsigned)S;
+    a.i0 = min(max(i, 0), S - 1); a.i1 = min(max(i + 1, 0), S - 1);
+    return a;
 }
+// the 8 corners in ATen's order k = 4 dz + 2 dy + dx: plane offsets, trilinear weights (wz wy) wx, validity
+struct Corners8 {
+    int idx[8];
+    float w[8];
+    bool ok[8];
+    float wz[2], wy[2], wx[2];
+};
+__device__ __forceinline__ Corners8 corners8(float z, float y, float x, int D, int H, int W) {
+    const AxisTaps az = axis_corners(z, D), ay = axis_corners(y, H), ax = axis_corners(x, W);
+    Corners8 c;
+    c.wz[0] = az.w0; c.wz[1] = az.w1; c.wy[0] = ay.w0; c.wy[1] = ay.w1; c.wx[0] = ax.w0; c.wx[1] = ax.w1;
+    const int iz[2] = {az.i0, az.i1}, iy[2] = {ay.i0, ay.i1}, ix[2] = {ax.i0, ax.i1};
+    const bool oz[2] = {az.ok0, az.ok1}, oy[2] = {ay.ok0, ay.ok1}, ox[2] = {ax.ok0, ax.ok1};
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int row = (iz[dz] * H + iy[dy]) * W;
+            const float wzy = c.wz[dz] * c.wy[dy];
+            const bool ozy = oz[dz] && oy[dy];
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int k = 4 * dz + 2 * dy + dx;
+                c.idx[k] = row + ix[dx];
+                c.ok[k] = ozy && ox[dx];
+                c.w[k] = c.ok[k] ? wzy * c.wx[dx] : 0.0f;
+            }
+        }
+    return c;
+}
+
+// Thread -> voxel without a per-voxel div/mod chain: grid = (ceil(H W / 256), D, B); one division by W per thread.
+#define VXM_VOXEL_INDEX(D_, H_, W_)                                  \
+    const int HW_ = (H_) * (W_), V = (D_) * HW_;                     \
+    const int p2_ = blockIdx.x * 256 + threadIdx.x;                  \
+    if (p2_ >= HW_) return;                                          \
+    const int d = blockIdx.y, b = blockIdx.z;                        \
+    const int h = p2_ / (W_), w = p2_ - h * (W_);                    \
+    const int p = d * HW_ + p2_
 
 template <int MODE>
 __global__ void __launch_bounds__(256) k_warp3d_fwd(const float* __restrict__ src, const float* __restrict__ flow,
                                                     float* __restrict__ out, int C, int D, int H, int W) {
-    const int V = D * H * W;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= V) return;
-    const int b = blockIdx.y;
-    const int w = p % W, t = p / W, h = t % H, d = t / H;
+    VXM_VOXEL_INDEX(D, H, W);
     const float* fl = flow + (size_t)b * 3 * V;
     const float z = vxm_src_coord(d, fl[p], D), y = vxm_src_coord(h, fl[V + p], H),
                 x = vxm_src_coord(w, fl[2 * (size_t)V + p], W);
@@ -61,16 +83,15 @@ __global__ void __launch_bounds__(256) k_warp3d_fwd(const float* __restrict__ sr
         for (int c = 0; c < C; ++c) o[(size_t)c * V] = in ? s[(size_t)c * V + idx] : 0.0f;
         return;
     }
-    Corners cn;
-    make_corners(z, y, x, D, H, W, cn);
+    const Corners8 cn = corners8(z, y, x, D, H, W);
     for (int c = 0; c < C; ++c) {
         const float* sc = s + (size_t)c * V;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = sc[cn.idx[k]];              // 8 independent gathers in flight
         float acc = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float v = (cn.ok >> k) & 1 ? sc[cn.idx[k]] : 0.0f;
-            acc += v * cn.w[k];
-        }
+        for (int k = 0; k < 8; ++k) acc += v[k] * cn.w[k];
         o[(size_t)c * V] = acc;
     }
 }
@@ -81,11 +102,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_warp3d_bwd(const float* __restrict__ src, const float* __restrict__ flow,
                                                     const float* __restrict__ gout, float* __restrict__ gsrc,
                                                     float* __restrict__ gflow, int C, int D, int H, int W) {
-    const int V = D * H * W;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= V) return;
-    const int b = blockIdx.y;
-    const int w = p % W, t = p / W, h = t % H, d = t / H;
+    VXM_VOXEL_INDEX(D, H, W);
     const float* fl = flow + (size_t)b * 3 * V;
     const float z = vxm_src_coord(d, fl[p], D), y = vxm_src_coord(h, fl[V + p], H),
                 x = vxm_src_coord(w, fl[2 * (size_t)V + p], W);
@@ -106,22 +123,22 @@ __global__ void __launch_bounds__(256) k_warp3d_bwd(const float* __restrict__ sr
         }
         return;
     }
-    Corners cn;
-    make_corners(z, y, x, D, H, W, cn);
+    const Corners8 cn = corners8(z, y, x, D, H, W);
     float gz = 0.0f, gy = 0.0f, gx = 0.0f;
     for (int c = 0; c < C; ++c) {
         const float g = go[(size_t)c * V];
         const float* sc = s + (size_t)c * V;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = sc[cn.idx[k]];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (!((cn.ok >> k) & 1)) continue;
             const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
-            const float v = sc[cn.idx[k]] * g;
-            const float wz = dz ? cn.wz1 : cn.wz0, wy = dy ? cn.wy1 : cn.wy0, wx = dx ? cn.wx1 : cn.wx0;
-            gz += (dz ? v : -v) * (wy * wx);
-            gy += (dy ? v : -v) * (wz * wx);
-            gx += (dx ? v : -v) * (wz * wy);
-            if (gs) atomicAdd(gs + (size_t)c * V + cn.idx[k], g * cn.w[k]);
+            const float vk = cn.ok[k] ? v[k] * g : 0.0f;
+            gz += (dz ? vk : -vk) * (cn.wy[dy] * cn.wx[dx]);
+            gy += (dy ? vk : -vk) * (cn.wz[dz] * cn.wx[dx]);
+            gx += (dx ? vk : -vk) * (cn.wz[dz] * cn.wy[dy]);
+            if (gs && cn.ok[k]) atomicAdd(gs + (size_t)c * V + cn.idx[k], g * cn.w[k]);
         }
     }
     if (gf) { gf[0] = gz; gf[V] = gy; gf[2 * (size_t)V] = gx; }
@@ -131,23 +148,22 @@ __global__ void __launch_bounds__(256) k_warp3d_bwd(const float* __restrict__ sr
 // the product is exact, so folding it here equals the reference's separate `vec * self.scale`).
 __global__ void __launch_bounds__(256) k_vecint_step_fwd(const float* __restrict__ in, float scale,
                                                          float* __restrict__ out, int D, int H, int W) {
-    const int V = D * H * W;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= V) return;
-    const int b = blockIdx.y;
-    const int w = p % W, t = p / W, h = t % H, d = t / H;
+    VXM_VOXEL_INDEX(D, H, W);
     const float* vin = in + (size_t)b * 3 * V;
     const float v0 = vin[p] * scale, v1 = vin[V + p] * scale, v2 = vin[2 * (size_t)V + p] * scale;
-    Corners cn;
-    make_corners(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W, cn);
+    const Corners8 cn = corners8(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W);
+    float s0[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                                     // 24 independent gathers in flight
+        const int i = cn.idx[k];
+        s0[k] = vin[i]; s1[k] = vin[V + i]; s2[k] = vin[2 * (size_t)V + i];
+    }
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        if (!((cn.ok >> k) & 1)) continue;
-        const int i = cn.idx[k];
-        a0 += (vin[i] * scale) * cn.w[k];
-        a1 += (vin[V + i] * scale) * cn.w[k];
-        a2 += (vin[2 * (size_t)V + i] * scale) * cn.w[k];
+        a0 += (s0[k] * scale) * cn.w[k];
+        a1 += (s1[k] * scale) * cn.w[k];
+        a2 += (s2[k] * scale) * cn.w[k];
     }
     float* o = out + (size_t)b * 3 * V + p;
     o[0] = v0 + a0; o[V] = v1 + a1; o[2 * (size_t)V] = v2 + a2;
@@ -162,33 +178,34 @@ __global__ void __launch_bounds__(256) k_vecint_step_fwd(const float* __restrict
 __global__ void __launch_bounds__(256) k_vecint_step_bwd(const float* __restrict__ in, float scale,
                                                          const float* __restrict__ gout, float* __restrict__ gin,
                                                          int D, int H, int W) {
-    const int V = D * H * W;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= V) return;
-    const int b = blockIdx.y;
-    const int w = p % W, t = p / W, h = t % H, d = t / H;
+    VXM_VOXEL_INDEX(D, H, W);
     const float* vin = in + (size_t)b * 3 * V;
     const float* go = gout + (size_t)b * 3 * V + p;
     float* gi = gin + (size_t)b * 3 * V;
     const float v0 = vin[p] * scale, v1 = vin[V + p] * scale, v2 = vin[2 * (size_t)V + p] * scale;
     const float g0 = go[0], g1 = go[V], g2 = go[2 * (size_t)V];
-    Corners cn;
-    make_corners(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W, cn);
+    const Corners8 cn = corners8(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W);
+    float s0[8], s1[8], s2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = cn.idx[k];
+        s0[k] = vin[i]; s1[k] = vin[V + i]; s2[k] = vin[2 * (size_t)V + i];
+    }
     float gz = g0, gy = g1, gx = g2;                 // identity term
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        if (!((cn.ok >> k) & 1)) continue;
         const int i = cn.idx[k];
         const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
-        const float wz = dz ? cn.wz1 : cn.wz0, wy = dy ? cn.wy1 : cn.wy0, wx = dx ? cn.wx1 : cn.wx0;
-        const float s = (vin[i] * scale) * g0 + (vin[V + i] * scale) * g1 + (vin[2 * (size_t)V + i] * scale) * g2;
-        gz += (dz ? s : -s) * (wy * wx);
-        gy += (dy ? s : -s) * (wz * wx);
-        gx += (dx ? s : -s) * (wz * wy);
-        const float wk = cn.w[k] * scale;
-        atomicAdd(gi + i, g0 * wk);
-        atomicAdd(gi + V + i, g1 * wk);
-        atomicAdd(gi + 2 * (size_t)V + i, g2 * wk);
+        const float sk = cn.ok[k] ? (s0[k] * scale) * g0 + (s1[k] * scale) * g1 + (s2[k] * scale) * g2 : 0.0f;
+        gz += (dz ? sk : -sk) * (cn.wy[dy] * cn.wx[dx]);
+        gy += (dy ? sk : -sk) * (cn.wz[dz] * cn.wx[dx]);
+        gx += (dx ? sk : -sk) * (cn.wz[dz] * cn.wy[dy]);
+        if (cn.ok[k]) {
+            const float wk = cn.w[k] * scale;
+            atomicAdd(gi + i, g0 * wk);
+            atomicAdd(gi + V + i, g1 * wk);
+            atomicAdd(gi + 2 * (size_t)V + i, g2 * wk);
+        }
     }
     atomicAdd(gi + p, gz * scale);
     atomicAdd(gi + V + p, gy * scale);
@@ -205,28 +222,7 @@ __device__ __forceinline__ void lin_src(int dst, float ratio, int n_in, int& i0,
     l0 = 1.0f - l1;
 }
 
-__global__ void __launch_bounds__(256) k_resize3d_fwd(const float* __restrict__ x, float* __restrict__ out, int D, int H,
-                                                      int W, int oD, int oH, int oW, float rd, float rh, float rw,
-                                                      float pre, float post) {
-    const int oV = oD * oH * oW;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= oV) return;
-    const size_t bc = blockIdx.y;
-    const int w = p % oW, t = p / oW, h = t % oH, d = t / oH;
-    int z0, z1, y0, y1, x0, x1;
-    float lz0, lz1, ly0, ly1, lx0, lx1;
-    lin_src(d, rd, D, z0, z1, lz0, lz1);
-    lin_src(h, rh, H, y0, y1, ly0, ly1);
-    lin_src(w, rw, W, x0, x1, lx0, lx1);
-    const float* s = x + bc * (size_t)D * H * W;
-#define AT(zz, yy, xx) (pre * s[((size_t)(zz) * H + (yy)) * W + (xx)])
-    const float v = lz0 * (ly0 * (lx0 * AT(z0, y0, x0) + lx1 * AT(z0, y0, x1)) + ly1 * (lx0 * AT(z0, y1, x0) + lx1 * AT(z0, y1, x1))) +
-                    lz1 * (ly0 * (lx0 * AT(z1, y0, x0) + lx1 * AT(z1, y0, x1)) + ly1 * (lx0 * AT(z1, y1, x0) + lx1 * AT(z1, y1, x1)));
-#undef AT
-    out[bc * (size_t)oV + p] = post * v;
-}
-
-// adjoint of the above (scatter; gx zeroed by the caller)
+// adjoint of the trilinear resize as a scatter (gx zeroed by the caller); only used for very large upsampling factors
 __global__ void __launch_bounds__(256) k_resize3d_bwd(const float* __restrict__ gout, float* __restrict__ gx, int D, int H,
                                                       int W, int oD, int oH, int oW, float rd, float rh, float rw,
                                                       float scale) {
@@ -268,41 +264,110 @@ __device__ __forceinline__ void axis_taps(int i, float ratio, int n_in, int n_ou
     }
 }
 
-__global__ void __launch_bounds__(256) k_resize3d_bwd_gather(const float* __restrict__ gout, float* __restrict__ gx, int D, int H, int W,
-                                                             int oD, int oH, int oW, float rd, float rh, float rw, float scale) {
-    const int V = D * H * W;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= V) return;
-    const size_t bc = blockIdx.y;
-    const int w = p % W, t = p / W, h = t % H, d = t / H;
-    int od0, oh0, ow0;
-    float wd[RS_KC], wh[RS_KC], ww[RS_KC];
-    axis_taps(d, rd, D, oD, od0, wd);
-    axis_taps(h, rh, H, oH, oh0, wh);
-    axis_taps(w, rw, W, oW, ow0, ww);
-    const float* g = gout + bc * (size_t)oD * oH * oW;
-    float acc = 0.0f;
-#pragma unroll
-    for (int a = 0; a < RS_KC; ++a) {
-        if (wd[a] == 0.0f) continue;
-#pragma unroll
-        for (int e = 0; e < RS_KC; ++e) {
-            if (wh[e] == 0.0f) continue;
-            const float wdh = wd[a] * wh[e];
-            const float* row = g + ((size_t)(od0 + a) * oH + (oh0 + e)) * oW + ow0;
-#pragma unroll
-            for (int c = 0; c < RS_KC; ++c)
-                if (ww[c] != 0.0f) acc += wdh * ww[c] * row[c];
-        }
+// ---- tiled forms: a block owns a 4 x 8 x 32 (D x H x W) tile, its 44 per-axis interpolation records are computed
+// once (44 lin_src / axis_taps evaluations instead of 3 per thread and depth) and staged in LDS, and the
+// thread's w / h never need a div / mod.  Same arithmetic and summation order as the per-voxel kernels above.
+constexpr int RT_W = 32, RT_H = 8, RT_D = 4, RT_N = RT_W + RT_H + RT_D;
+
+__device__ __forceinline__ void rt_tile(int nW, int nH, int& d0, int& h0, int& w0) {
+    const int tw = (nW + RT_W - 1) / RT_W, th = (nH + RT_H - 1) / RT_H;
+    int t = blockIdx.x;
+    w0 = (t % tw) * RT_W; t /= tw;
+    h0 = (t % th) * RT_H;
+    d0 = (t / th) * RT_D;
+}
+
+__global__ void __launch_bounds__(256) k_resize3d_fwd_tiled(const float* __restrict__ x, float* __restrict__ out, int D, int H, int W,
+                                                            int oD, int oH, int oW, float rd, float rh, float rw, float pre, float post) {
+    __shared__ int si0[RT_N], si1[RT_N];
+    __shared__ float sl0[RT_N], sl1[RT_N];
+    int d0, h0, w0;
+    rt_tile(oW, oH, d0, h0, w0);
+    const int tid = threadIdx.x;
+    if (tid < RT_N) {
+        const int ax = tid < RT_W ? 2 : (tid < RT_W + RT_H ? 1 : 0);
+        const int dst = ax == 2 ? w0 + tid : (ax == 1 ? h0 + tid - RT_W : d0 + tid - RT_W - RT_H);
+        const int n_out = ax == 2 ? oW : (ax == 1 ? oH : oD), n_in = ax == 2 ? W : (ax == 1 ? H : D);
+        int i0, i1;
+        float l0, l1;
+        lin_src(min(dst, n_out - 1), ax == 2 ? rw : (ax == 1 ? rh : rd), n_in, i0, i1, l0, l1);
+        si0[tid] = i0; si1[tid] = i1; sl0[tid] = l0; sl1[tid] = l1;
     }
-    gx[bc * (size_t)V + p] = acc * scale;
+    __syncthreads();
+    const int tx = tid & 31, ty = tid >> 5;
+    const int w = w0 + tx, h = h0 + ty;
+    if (w >= oW || h >= oH) return;
+    const size_t bc = blockIdx.y;
+    const float* s = x + bc * (size_t)D * H * W;
+    const int x0 = si0[tx], x1 = si1[tx], y0 = si0[RT_W + ty], y1 = si1[RT_W + ty];
+    const float lx0 = sl0[tx], lx1 = sl1[tx], ly0 = sl0[RT_W + ty], ly1 = sl1[RT_W + ty];
+#pragma unroll
+    for (int dd = 0; dd < RT_D; ++dd) {
+        const int d = d0 + dd;
+        if (d >= oD) break;
+        const int z0 = si0[RT_W + RT_H + dd], z1 = si1[RT_W + RT_H + dd];
+        const float lz0 = sl0[RT_W + RT_H + dd], lz1 = sl1[RT_W + RT_H + dd];
+#define AT(zz, yy, xx) (pre * s[((size_t)(zz) * H + (yy)) * W + (xx)])
+        const float v = lz0 * (ly0 * (lx0 * AT(z0, y0, x0) + lx1 * AT(z0, y0, x1)) + ly1 * (lx0 * AT(z0, y1, x0) + lx1 * AT(z0, y1, x1))) +
+                        lz1 * (ly0 * (lx0 * AT(z1, y0, x0) + lx1 * AT(z1, y0, x1)) + ly1 * (lx0 * AT(z1, y1, x0) + lx1 * AT(z1, y1, x1)));
+#undef AT
+        out[bc * (size_t)oD * oH * oW + ((size_t)d * oH + h) * oW + w] = post * v;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_resize3d_bwd_gather_tiled(const float* __restrict__ gout, float* __restrict__ gx, int D, int H,
+                                                                   int W, int oD, int oH, int oW, float rd, float rh, float rw,
+                                                                   float scale) {
+    __shared__ int solo[RT_N], sklo[RT_N], skhi[RT_N];
+    __shared__ float sw[RT_N][RS_KC + 1];
+    int d0, h0, w0;
+    rt_tile(W, H, d0, h0, w0);
+    const int tid = threadIdx.x;
+    if (tid < RT_N) {
+        const int ax = tid < RT_W ? 2 : (tid < RT_W + RT_H ? 1 : 0);
+        const int i = ax == 2 ? w0 + tid : (ax == 1 ? h0 + tid - RT_W : d0 + tid - RT_W - RT_H);
+        const int n_in = ax == 2 ? W : (ax == 1 ? H : D), n_out = ax == 2 ? oW : (ax == 1 ? oH : oD);
+        int olo;
+        float wt[RS_KC];
+        axis_taps(min(i, n_in - 1), ax == 2 ? rw : (ax == 1 ? rh : rd), n_in, n_out, olo, wt);
+        int klo = RS_KC, khi = 0;
+#pragma unroll
+        for (int k = 0; k < RS_KC; ++k) {
+            sw[tid][k] = wt[k];
+            if (wt[k] != 0.0f) { klo = min(klo, k); khi = k + 1; }
+        }
+        solo[tid] = olo; sklo[tid] = klo; skhi[tid] = khi;
+    }
+    __syncthreads();
+    const int tx = tid & 31, ty = tid >> 5;
+    const int w = w0 + tx, h = h0 + ty;
+    if (w >= W || h >= H) return;
+    const size_t bc = blockIdx.y;
+    const float* g = gout + bc * (size_t)oD * oH * oW;
+    const int ow0 = solo[tx], cl = sklo[tx], ch = skhi[tx];
+    const int oh0 = solo[RT_W + ty], el = sklo[RT_W + ty], eh = skhi[RT_W + ty];
+    for (int dd = 0; dd < RT_D; ++dd) {
+        const int d = d0 + dd;
+        if (d >= D) break;
+        const int od0 = solo[RT_W + RT_H + dd], al = sklo[RT_W + RT_H + dd], ah = skhi[RT_W + RT_H + dd];
+        float acc = 0.0f;
+        for (int a = al; a < ah; ++a) {
+            const float wd = sw[RT_W + RT_H + dd][a];
+            for (int e = el; e < eh; ++e) {
+                const float wdh = wd * sw[RT_W + ty][e];
+                const float* row = g + ((size_t)(od0 + a) * oH + (oh0 + e)) * oW + ow0;
+                for (int c = cl; c < ch; ++c) acc += wdh * sw[tx][c] * row[c];
+            }
+        }
+        gx[bc * (size_t)D * H * W + ((size_t)d * H + h) * W + w] = acc * scale;
+    }
 }
 
 int check_vol(const char* fn, int B, int C, int D, int H, int W) {
     VXM_REQUIRE(B > 0 && C > 0 && D > 1 && H > 1 && W > 1, VXM_ERR_BAD_SHAPE,
                 "%s: bad shape B=%d C=%d D=%d H=%d W=%d (3-D volumes with every extent > 1)", fn, B, C, D, H, W);
-    VXM_REQUIRE((long long)C * D * H * W < (1ll << 31) && B <= 65535, VXM_ERR_BAD_SHAPE,
-                "%s: per-sample element count must fit int32 and B <= 65535", fn);
+    VXM_REQUIRE((long long)C * D * H * W < (1ll << 31) && B <= 65535 && D <= 65535, VXM_ERR_BAD_SHAPE,
+                "%s: per-sample element count must fit int32, B and D <= 65535", fn);
     return VXM_OK;
 }
 
@@ -316,7 +381,7 @@ int vxm_warp3d_fwd(const float* src, const float* flow, float* out, int B, int C
     VXM_REQUIRE(src && flow && out, VXM_ERR_NULL_POINTER, "vxm_warp3d_fwd: null pointer");
     VXM_REQUIRE(mode == VXM_INTERP_LINEAR || mode == VXM_INTERP_NEAREST, VXM_ERR_UNSUPPORTED,
                 "vxm_warp3d_fwd: mode %d (only 'bilinear' and 'nearest', layers.py:11)", mode);
-    const dim3 grid(vxm_blocks((long long)D * H * W, 256), B);
+    const dim3 grid(vxm_blocks((long long)H * W, 256), D, B);
     if (mode == VXM_INTERP_NEAREST)
         hipLaunchKernelGGL(k_warp3d_fwd<VXM_INTERP_NEAREST>, grid, dim3(256), 0, VXM_STREAM(stream), src, flow, out, C, D, H, W);
     else
@@ -332,7 +397,7 @@ int vxm_warp3d_bwd(const float* src, const float* flow, const float* gout, float
     if (!gsrc && !gflow) return VXM_OK;
     const size_t V = (size_t)D * H * W;
     if (gsrc) hipMemsetAsync(gsrc, 0, sizeof(float) * B * C * V, VXM_STREAM(stream));
-    const dim3 grid(vxm_blocks((long long)V, 256), B);
+    const dim3 grid(vxm_blocks((long long)H * W, 256), D, B);
     if (mode == VXM_INTERP_NEAREST)
         hipLaunchKernelGGL(k_warp3d_bwd<VXM_INTERP_NEAREST>, grid, dim3(256), 0, VXM_STREAM(stream), src, flow, gout, gsrc, gflow, C, D, H, W);
     else
@@ -345,7 +410,7 @@ int vxm_vecint_fwd(const float* vec, float* steps, int B, int D, int H, int W, i
     VXM_REQUIRE(nsteps >= 1 && nsteps < 31, VXM_ERR_BAD_SHAPE, "vxm_vecint_fwd: nsteps should be >= 1, found: %d", nsteps);
     VXM_REQUIRE(vec && steps, VXM_ERR_NULL_POINTER, "vxm_vecint_fwd: null pointer");
     const size_t n = (size_t)B * 3 * D * H * W;
-    const dim3 grid(vxm_blocks((long long)D * H * W, 256), B);
+    const dim3 grid(vxm_blocks((long long)H * W, 256), D, B);
     const float scale = 1.0f / (float)(1u << nsteps);
     for (int k = 0; k < nsteps; ++k) {
         const float* in = k == 0 ? vec : steps + (size_t)(k - 1) * n;
@@ -361,7 +426,7 @@ int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, floa
     VXM_REQUIRE(nsteps >= 1 && nsteps < 31, VXM_ERR_BAD_SHAPE, "vxm_vecint_bwd: nsteps should be >= 1, found: %d", nsteps);
     VXM_REQUIRE(vec && steps && gout && gvec && work, VXM_ERR_NULL_POINTER, "vxm_vecint_bwd: null pointer");
     const size_t n = (size_t)B * 3 * D * H * W;
-    const dim3 grid(vxm_blocks((long long)D * H * W, 256), B);
+    const dim3 grid(vxm_blocks((long long)H * W, 256), D, B);
     const float scale = 1.0f / (float)(1u << nsteps);
     const float* g = gout;
     for (int k = nsteps - 1; k >= 0; --k) {
@@ -388,7 +453,9 @@ int vxm_resize3d_fwd(const float* x, float* out, int B, int C, int D, int H, int
     const float rd = oD > 1 ? (float)(D - 1) / (float)(oD - 1) : 0.0f, rh = oH > 1 ? (float)(H - 1) / (float)(oH - 1) : 0.0f,
                 rw = oW > 1 ? (float)(W - 1) / (float)(oW - 1) : 0.0f;
     const float pre = factor > 1.0f ? factor : 1.0f, post = factor < 1.0f ? factor : 1.0f;
-    hipLaunchKernelGGL(k_resize3d_fwd, dim3(vxm_blocks((long long)oD * oH * oW, 256), B * C), dim3(256), 0, VXM_STREAM(stream),
+    const long long tiles = (long long)((oW + RT_W - 1) / RT_W) * ((oH + RT_H - 1) / RT_H) * ((oD + RT_D - 1) / RT_D);
+    VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_resize3d_fwd: too many tiles");
+    hipLaunchKernelGGL(k_resize3d_fwd_tiled, dim3((unsigned)tiles, B * C), dim3(256), 0, VXM_STREAM(stream),
                        x, out, D, H, W, oD, oH, oW, rd, rh, rw, pre, post);
     return vxm_check_launch("vxm_resize3d_fwd");
 }
@@ -401,7 +468,9 @@ int vxm_resize3d_bwd(const float* gout, float* gx, int B, int C, int D, int H, i
                 rw = oW > 1 ? (float)(W - 1) / (float)(oW - 1) : 0.0f;
     const float rmin = fminf(oD > 1 ? rd : 1.0f, fminf(oH > 1 ? rh : 1.0f, oW > 1 ? rw : 1.0f));
     if (rmin > 0.4f) {       // floor(2/ratio) + 3 <= RS_KC: every contributing output is among the candidates
-        hipLaunchKernelGGL(k_resize3d_bwd_gather, dim3(vxm_blocks((long long)D * H * W, 256), B * C), dim3(256), 0, VXM_STREAM(stream),
+        const long long tiles = (long long)((W + RT_W - 1) / RT_W) * ((H + RT_H - 1) / RT_H) * ((D + RT_D - 1) / RT_D);
+        VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_resize3d_bwd: too many tiles");
+        hipLaunchKernelGGL(k_resize3d_bwd_gather_tiled, dim3((unsigned)tiles, B * C), dim3(256), 0, VXM_STREAM(stream),
                            gout, gx, D, H, W, oD, oH, oW, rd, rh, rw, factor);
     } else {                 // very large upsampling factors: scatter with atomics
         (void)hipMemsetAsync(gx, 0, sizeof(float) * (size_t)B * C * D * H * W, VXM_STREAM(stream));
