@@ -556,9 +556,11 @@ constexpr int BW_PZ = 260;        // dZ plane (256 voxels) stride of the LDS-DMA
 // A-fragments (dZ) + S B-fragments (shifted X) from LDS feed S x NCT MFMAs.  Fully unrolled (every LDS offset an
 // immediate), branch-free, operands of step s+1 requested before the MFMAs of step s (register double buffer).
 // X plane layout [6][6][RS]; voxels 4s..4s+3: row = s>>2 -> (dz, hy) = (row>>2, row&3), wx = 4 (s&3) + kq (kq in boff).
-template <int NCT, int S, int S0, int S1, int RS, int PZ>
+// BIAS: the wave also sums its dZ fragments (VALU adds beside the MFMAs): lane (co = n, kq) collects the voxels
+// 4 s + kq of output channel co -> the bias gradient sum_v dZ[co, v] without another pass over dZ.
+template <int NCT, int S, int S0, int S1, int RS, int PZ, bool BIAS>
 __device__ __forceinline__ void bw_ksteps(const float* __restrict__ Xb, const float* __restrict__ Zb, const int (&boff)[BW_SLOTS], int aoff,
-                                          f32x4 (&acc)[BW_SLOTS][NCT]) {
+                                          f32x4 (&acc)[BW_SLOTS][NCT], float (&bsum)[NCT]) {
     float a[2][NCT], bv[2][S];
     auto fetch = [&](int s, float (&af)[NCT], float (&bf)[S]) __attribute__((always_inline)) {
         const int row = s >> 2;
@@ -577,17 +579,26 @@ __device__ __forceinline__ void bw_ksteps(const float* __restrict__ Xb, const fl
         for (int i = 0; i < S; ++i)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = vxm_mfma16(a[s & 1][ct], bv[s & 1][i], acc[i][ct]);
+        if (BIAS) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) bsum[ct] += a[s & 1][ct];
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 // uniform dispatch on the wave's N-tile count OUTSIDE the k-loop (a per-slot test inside it splits every MFMA
 // group into its own basic block and serialises ds_read -> wait -> MFMA)
 template <int NCT, int S0, int S1, int RS, int PZ>
-__device__ __forceinline__ void bw_ksteps_n(int nslots, const float* Xb, const float* Zb, const int (&boff)[BW_SLOTS], int aoff,
-                                            f32x4 (&acc)[BW_SLOTS][NCT]) {
+__device__ __forceinline__ void bw_ksteps_n(int nslots, bool bias, const float* Xb, const float* Zb, const int (&boff)[BW_SLOTS], int aoff,
+                                            f32x4 (&acc)[BW_SLOTS][NCT], float (&bsum)[NCT]) {
+    if (bias) {             // wave 0 of the chunk-0 blocks (it always owns at least one N-tile)
+        if (nslots == 2) bw_ksteps<NCT, 2, S0, S1, RS, PZ, true>(Xb, Zb, boff, aoff, acc, bsum);
+        else bw_ksteps<NCT, 1, S0, S1, RS, PZ, true>(Xb, Zb, boff, aoff, acc, bsum);
+        return;
+    }
     switch (nslots) {
-        case 2: bw_ksteps<NCT, 2, S0, S1, RS, PZ>(Xb, Zb, boff, aoff, acc); break;
-        case 1: bw_ksteps<NCT, 1, S0, S1, RS, PZ>(Xb, Zb, boff, aoff, acc); break;
+        case 2: bw_ksteps<NCT, 2, S0, S1, RS, PZ, false>(Xb, Zb, boff, aoff, acc, bsum); break;
+        case 1: bw_ksteps<NCT, 1, S0, S1, RS, PZ, false>(Xb, Zb, boff, aoff, acc, bsum); break;
         default: break;
     }
 }
@@ -614,11 +625,22 @@ __device__ __forceinline__ BwBlock bw_block(int Cin, int NCT, int B, int D, int 
     return k;
 }
 // partial gW of this block: part[idx][co][ci][tap] (the combos of one idx tile the array)
+// slot layout: [Cout][Cin][27] weight-gradient partial followed by [Cout] bias-gradient partial
 template <int NCT>
 __device__ __forceinline__ void bw_write_partial(const BwBlock& k, float* __restrict__ part, int Cout, int Cin, int wave, int lane, int nslots,
-                                                 const f32x4 (&acc)[BW_SLOTS][NCT]) {
+                                                 const f32x4 (&acc)[BW_SLOTS][NCT], bool bias, float (&bsum)[NCT]) {
     const int kq = lane >> 4, n = lane & 15;
-    float* out = part + (size_t)k.idx * Cout * Cin * 27;
+    float* out = part + (size_t)k.idx * ((size_t)Cout * Cin * 27 + Cout);
+    if (bias) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            float t = bsum[ct];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            const int co = k.cog + ct * 16 + n;
+            if (kq == 0 && co < Cout) out[(size_t)Cout * Cin * 27 + co] = t;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < BW_SLOTS; ++i) {
         if (i >= nslots) continue;
@@ -647,7 +669,7 @@ constexpr int BV_PZ = 258;        // dZ plane stride = 2 mod 32: conflict-free A
 template <int NCT> constexpr int bv_lds_floats() { return BW_CKI * BV_PSX + 16 * NCT * BV_PZ; }
 
 template <int NCT>
-__global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_vec(ConvIn in, const float* __restrict__ dz, long long dz_bs, int Cout,
+__global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_vec(ConvIn in, const float* __restrict__ dz, long long dz_bs, int Cout, int want_bias,
                                                                            float* __restrict__ part, int B, int D, int H, int W,
                                                                            int Qc, int G) {
     VXM_DYN_SMEM(float, smem);
@@ -683,6 +705,10 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_vec(ConvIn 
     for (int i = 0; i < BW_SLOTS; ++i)
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool bias = want_bias && k.c0 == 0 && wave == 0;       // wave-uniform: one wave per output-channel group
+    float bsum[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) bsum[ct] = 0.0f;
 
     // staging roles of this lane (tile independent).  Interior: slot 64 j + lane (< 144) of a plane -> row
     // 16 j + (lane >> 2), columns 4 (lane & 3)..+3;  halo: slot 64 j + lane (< 72) -> row 32 j + (lane >> 1), side
@@ -785,12 +811,12 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_vec(ConvIn 
         const bool more = tile + 1 < k.hi;
         if (more) load_tile(tile + 1);                 // in flight under the MFMAs below
         const float* Xb = smem + (iter & 1) * BUF;
-        bw_ksteps_n<NCT, 0, 64, BV_RS, BV_PZ>(nslots, Xb, Xb + BW_CKI * BV_PSX, boff, aoff, acc);
+        bw_ksteps_n<NCT, 0, 64, BV_RS, BV_PZ>(nslots, bias, Xb, Xb + BW_CKI * BV_PSX, boff, aoff, acc, bsum);
         float* Xn = smem + ((iter + 1) & 1) * BUF;     // last read before the previous barrier
         if (more) store_tile(Xn, Xn + BW_CKI * BV_PSX);
         __syncthreads();
     }
-    bw_write_partial<NCT>(k, part, Cout, Cin, wave, lane, nslots, acc);
+    bw_write_partial<NCT>(k, part, Cout, Cin, wave, lane, nslots, acc, bias, bsum);
 }
 
 // ---- generic path (any W / alignment): LDS-DMA staging -------------------------------------------------------
@@ -804,7 +830,7 @@ constexpr int BW_PSX = 706;       // X plane stride: >= 64*BW_XJ and = 2 mod 32 
 template <int NCT> constexpr int bw_buf_floats() { return BW_CKI * BW_PSX + 16 * NCT * BW_PZ; }
 
 template <int NCT>
-__global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_dma(ConvIn in, const float* __restrict__ dz, long long dz_bs, int Cout,
+__global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_dma(ConvIn in, const float* __restrict__ dz, long long dz_bs, int Cout, int want_bias,
                                                                         float* __restrict__ part, int B, int D, int H, int W,
                                                                         int Qc, int G) {
     VXM_DYN_SMEM(float, smem);
@@ -839,6 +865,10 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_dma(ConvIn 
     for (int i = 0; i < BW_SLOTS; ++i)
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool bias = want_bias && k.c0 == 0 && wave == 0;       // wave-uniform: one wave per output-channel group
+    float bsum[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) bsum[ct] = 0.0f;
 
     // lane constants of the staging pattern: element e = 64 j + lane of the haloed plane -> (dz, hy, wx)
     int pk[BW_XJ];
@@ -920,57 +950,44 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_dma(ConvIn 
         const float* Xb = smem + (iter & 1) * BUF;
         const float* Zb = Xb + BW_CKI * BW_PSX;
         if (tile + 1 < k.hi) stage(tile + 1, Xn, Xn + BW_CKI * BW_PSX);      // in flight under the MFMAs below
-        bw_ksteps_n<NCT, 0, 64, HW, BW_PZ>(nslots, Xb, Zb, boff, aoff, acc);
+        bw_ksteps_n<NCT, 0, 64, HW, BW_PZ>(nslots, bias, Xb, Zb, boff, aoff, acc, bsum);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    bw_write_partial<NCT>(k, part, Cout, Cin, wave, lane, nslots, acc);
+    bw_write_partial<NCT>(k, part, Cout, Cin, wave, lane, nslots, acc, bias, bsum);
 }
 
-// gw[i] = sum_p part[p][i] in a fixed order (deterministic): 64 outputs x 4 partial-slices per block, 4 independent
-// accumulators per thread so that the (latency-bound) loads overlap.  Element i = (co, ci, tap) belongs to combo
-// (ci / 16, co / cog_size), which has cnt = ceil((T - combo) / cb) partial slots.
-__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, float* __restrict__ gw, int n, int Cin,
-                                                         int T, int Qc, int G, int cog_size) {
+// gw[i] = sum_p part[p][i] (and gb[co] = sum_p part[p][n + co]) in a fixed order (deterministic): 64 outputs x 4
+// partial-slices per block, 4 independent accumulators per thread so that the (latency-bound) loads overlap.
+// Element i = (co, ci, tap) belongs to combo (ci / 16, co / cog_size), which has cnt = ceil((T - combo) / cb) slots;
+// the bias partials live in the chunk-0 combos.
+__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb,
+                                                         int n, int Cin, int Cout, int T, int Qc, int G, int cog_size) {
     __shared__ float red[4][64];
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + x;
+    const int ntot = n + (gb ? Cout : 0);
+    const size_t stride = (size_t)n + Cout;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    if (i < n) {
-        const int co = i / (Cin * 27), ci = (i / 27) % Cin;
+    if (i < ntot) {
+        const int co = i < n ? i / (Cin * 27) : i - n, ci = i < n ? (i / 27) % Cin : 0;
         const int cb = Qc * G, combo = ci / BW_CKI + Qc * (co / cog_size);
         const int nparts = (T - combo + cb - 1) / cb;
         int p = y;
         for (; p + 12 < nparts; p += 16) {
-            s0 += part[(size_t)p * n + i];
-            s1 += part[(size_t)(p + 4) * n + i];
-            s2 += part[(size_t)(p + 8) * n + i];
-            s3 += part[(size_t)(p + 12) * n + i];
+            s0 += part[(size_t)p * stride + i];
+            s1 += part[(size_t)(p + 4) * stride + i];
+            s2 += part[(size_t)(p + 8) * stride + i];
+            s3 += part[(size_t)(p + 12) * stride + i];
         }
-        for (; p < nparts; p += 4) s0 += part[(size_t)p * n + i];
+        for (; p < nparts; p += 4) s0 += part[(size_t)p * stride + i];
     }
     red[y][x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (y == 0 && i < n) gw[i] = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
-}
-
-// bias gradient: gb[co] = sum_{b,v} dz[b,co,v]; one block per (co, slice), fp64 atomics into acc.
-__global__ void __launch_bounds__(256) k_bias_grad(const float* __restrict__ dz, long long dz_bs, double* __restrict__ acc, int B, size_t V) {
-    const int co = blockIdx.x;
-    double s = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const float* p = dz + (size_t)b * dz_bs + (size_t)co * V;
-        for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < V; i += (size_t)gridDim.y * 256) s += (double)p[i];
+    if (y == 0 && i < ntot) {
+        const float t = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
+        if (i < n) gw[i] = t; else gb[i - n] = t;
     }
-    s = vxm_wave_sum(s);
-    __shared__ double red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc + co, red[0] + red[1] + red[2] + red[3]);
-}
-__global__ void k_bias_finish(const double* __restrict__ acc, float* __restrict__ gb, int Cout) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i < Cout) gb[i] = (float)acc[i];
 }
 
 struct BwPlan { int NCT, Qc, G, T, nparts; };
@@ -1082,7 +1099,7 @@ int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int64_t x0_bstride, const 
 size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D, int H, int W) {
     if (Cin <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     const BwPlan p = bw_plan(Cin, Cout, B, D, H, W);
-    return 256 + sizeof(double) * (size_t)((Cout + 31) / 32 * 32) + sizeof(float) * (size_t)p.nparts * Cout * Cin * 27;
+    return 256 + sizeof(float) * (size_t)p.nparts * ((size_t)Cout * Cin * 27 + Cout);
 }
 
 int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
@@ -1094,10 +1111,9 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
     VXM_REQUIRE(workspace_bytes >= vxm_conv3d_k3_bwd_weight_workspace_bytes(Cin, Cout, B, D, H, W), VXM_ERR_WORKSPACE,
                 "vxm_conv3d_k3_bwd_weight: workspace too small (%zu bytes)", workspace_bytes);
     const BwPlan p = bw_plan(Cin, Cout, B, D, H, W);
-    // workspace: [Cout doubles (bias accumulators), padded][partials]
+    // workspace: per-block partials [nparts][Cout*Cin*27 + Cout]
     uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
-    double* bacc = reinterpret_cast<double*>(base);
-    float* part = reinterpret_cast<float*>(base + sizeof(double) * (size_t)((Cout + 31) / 32 * 32));
+    float* part = reinterpret_cast<float*>(base);
     ConvIn in{x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up};
     const dim3 grid(p.T);
     // up to 156 KB of dynamic LDS (> the 64 KB default cap): opt in once per kernel
@@ -1112,7 +1128,7 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
     // wide-load path: rows of 4-float groups must not straddle row ends and must be 16-byte aligned in memory
     const bool vec = bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W);
 #define BW_LAUNCH(KERNEL, LDSF) hipLaunchKernelGGL(KERNEL, grid, dim3(BW_THREADS), sizeof(float) * (size_t)(LDSF), VXM_STREAM(stream), in, dz, \
-        (long long)dz_bstride, Cout, part, B, D, H, W, p.Qc, p.G)
+        (long long)dz_bstride, Cout, gb ? 1 : 0, part, B, D, H, W, p.Qc, p.G)
     if (vec) {
         if (p.NCT == 1) BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<1>, 2 * bv_lds_floats<1>());
         else BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<2>, 2 * bv_lds_floats<2>());
@@ -1122,14 +1138,9 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
     }
 #undef BW_LAUNCH
     const int n = Cout * Cin * 27;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, n, Cin, p.T, p.Qc, p.G, 16 * p.NCT);
-    if (gb) {
-        (void)hipMemsetAsync(bacc, 0, sizeof(double) * Cout, VXM_STREAM(stream));
-        const size_t V = (size_t)D * H * W;
-        const unsigned ny = (unsigned)(V / 16384 > 0 ? (V / 16384 > 256 ? 256 : V / 16384) : 1);
-        hipLaunchKernelGGL(k_bias_grad, dim3(Cout, ny), dim3(256), 0, VXM_STREAM(stream), dz, (long long)dz_bstride, bacc, B, V);
-        hipLaunchKernelGGL(k_bias_finish, dim3((Cout + 63) / 64), dim3(64), 0, VXM_STREAM(stream), bacc, gb, Cout);
-    }
+    // the bias gradient rides along: its per-block partials sit behind the weight partials of every slot
+    hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n + (gb ? Cout : 0), 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, gb, n, Cin, Cout,
+                       p.T, p.Qc, p.G, 16 * p.NCT);
     return vxm_check_launch("vxm_conv3d_k3_bwd_weight");
 }
 
