@@ -233,6 +233,17 @@ def vxm_dense_forward(source, target, sd, int_steps=7, int_downsize=2, bidir=Fal
     return y_source, pos
 
 
+def vxm_semisupervised_forward(source, target, seg_src, sd, seg_resolution=2, int_steps=7, int_downsize=2, **unet_kwargs):
+    """`VxmDenseSemiSupervisedSeg` (TF backend only in the reference: tf/networks.py:287-388) restated with the torch
+    layers of the path: seg_flow = RescaleTransform(1/seg_resolution)(pos_flow) (tf/networks.py:336-337) is
+    `ResizeTransform(seg_resolution)` (torch/layers.py:76-97); the down-sampled one-hot source segmentation is warped
+    with a linear SpatialTransformer (tf/networks.py:338-339).  Returns (y_source, preint_flow, y_seg_src, pos_flow)."""
+    y_source, preint = vxm_dense_forward(source, target, sd, int_steps=int_steps, int_downsize=int_downsize, **unet_kwargs)
+    _, pos = vxm_dense_forward(source, target, sd, int_steps=int_steps, int_downsize=int_downsize, registration=True, **unet_kwargs)
+    seg_flow = resize_transform(pos, seg_resolution)
+    return y_source, preint, spatial_transformer(seg_src, seg_flow), pos
+
+
 def state_dict_shapes(inshape, src_feats=1, trg_feats=1, **unet_kwargs):
     """Parameter names/shapes in the reference's state-dict order."""
     nd = len(inshape)

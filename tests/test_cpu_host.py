@@ -94,6 +94,24 @@ def test_api_surface_matches_reference_signatures():
     assert m0.integrate is None and m0.resize is None and m0.fullsize is None
 
 
+def test_semisupervised_seg_model_surface(tmp_path):
+    """Constructor arguments / attributes of the TF reference model (tf/networks.py:293-367) on the torch-side API,
+    config capture + checkpoint round trip through LoadableModel, and the no-CPU-fallback rule."""
+    m = vxm.networks.VxmDenseSemiSupervisedSeg((16, 16, 16), nb_labels=4, seg_resolution=2, int_steps=3)
+    assert isinstance(m.vxm_model, vxm.networks.VxmDense) and m.vxm_model.integrate.nsteps == 3
+    assert tuple(m.seg_transformer.grid.shape) == (1, 3, 8, 8, 8) and m.seg_resize.factor == 0.5
+    assert m.config["nb_labels"] == 4 and m.config["int_steps"] == 3
+    mb = vxm.networks.VxmDenseSemiSupervisedSeg((16, 16, 16), nb_labels=4, bidir_labels=True)
+    assert mb.bidir and mb.vxm_model.bidir
+    path = str(tmp_path / "semi.pt")
+    m.save(path)
+    m2 = vxm.networks.VxmDenseSemiSupervisedSeg.load(path, "cpu")
+    assert [k for k in m2.state_dict()] == [k for k in m.state_dict()]
+    x = torch.zeros(1, 1, 16, 16, 16)
+    with pytest.raises(_lib.VxmHipError):
+        m(x, x, torch.zeros(1, 4, 8, 8, 8))
+
+
 def test_state_dict_and_checkpoint_format(g_network, tmp_path):
     m = vxm.networks.VxmDense((16, 16, 16))
     keys = list(m.state_dict().keys())

@@ -406,6 +406,46 @@ def test_vxm_dense_golden(vxm, g_network, tag):
     assert rel_l2(N(model.unet_model.encoder[0][0].main.weight), g_network[tag + "_enc0_weight_after_adam"]) < 1e-5
 
 
+def test_semisupervised_seg_vs_oracle(vxm):
+    """BASELINE.json configs[4] wiring (VxmDense + warped half-resolution one-hot segmentation + Dice) against the
+    oracle composition, forward and parameter gradients; label evaluation by the bit-exact nearest warp."""
+    inshape, nb_labels = (32, 32, 32), 5
+    rng = np.random.default_rng(21)
+    src = rng.random((2, 1) + inshape).astype(np.float32)
+    trg = rng.random((2, 1) + inshape).astype(np.float32)
+    lab = rng.integers(0, nb_labels, size=(2,) + tuple(s // 2 for s in inshape))
+    seg_src = np.stack([(lab == k) for k in range(nb_labels)], 1).astype(np.float32)
+    lab_t = rng.integers(0, nb_labels, size=lab.shape)
+    seg_trg = np.stack([(lab_t == k) for k in range(nb_labels)], 1).astype(np.float32)
+    sd = orc.seeded_state_dict(inshape, seed=3, flow_std=0.2)
+    model = vxm.networks.VxmDenseSemiSupervisedSeg(inshape, nb_labels, int_steps=5, int_downsize=2)
+    res = model.vxm_model.load_state_dict(sd, strict=False)
+    assert all(k.endswith(".grid") for k in res.missing_keys) and not res.unexpected_keys
+    model = model.cuda()
+    y, pre, yseg = model(G(src), G(trg), G(seg_src))
+    loss = vxm.losses.MSE().loss(G(trg), y) + 0.02 * vxm.losses.Grad("l2", loss_mult=2).loss(None, pre) \
+        + 0.01 * vxm.losses.Dice().loss(G(seg_trg), yseg)
+    loss.backward()
+    sdo = {k: v.clone().double().requires_grad_() for k, v in sd.items()}
+    to = lambda a: torch.from_numpy(a).double()
+    yo, preo, ysego, poso = orc.vxm_semisupervised_forward(to(src), to(trg), to(seg_src), sdo, int_steps=5)
+    losso = orc.mse_loss(to(trg), yo) + 0.02 * orc.grad_loss(preo, "l2", 2) + 0.01 * orc.dice_loss(to(seg_trg), ysego)
+    losso.backward()
+    np.testing.assert_allclose(N(yseg), ysego.detach().numpy(), atol=2e-5)
+    assert abs(float(loss) - float(losso)) < 1e-5
+    for name, p in model.vxm_model.named_parameters():
+        assert rel_l2(N(p.grad), sdo[name].grad.numpy()) < 2e-4, name
+    # evaluation protocol (scripts/tf/test.py:80-112): nearest warp of the full-resolution label map, then Dice
+    full = rng.integers(0, nb_labels, size=(2, 1) + inshape).astype(np.float32)
+    moved = model.apply_transform(G(src), G(trg), G(full), interp_method="nearest")
+    ref = c_oracle.warp3d(full, poso.detach().float().numpy(), mode="nearest")
+    agree = float((N(moved) == ref).mean())
+    assert agree > 0.999          # the flow itself differs by fp32 rounding between the two paths: ties may flip
+    d_hip = orc.dice_metric(N(moved)[0, 0], full[0, 0], labels=list(range(1, nb_labels)))
+    d_ref = orc.dice_metric(ref[0, 0], full[0, 0], labels=list(range(1, nb_labels)))
+    assert np.abs(np.asarray(d_hip) - np.asarray(d_ref)).max() < 1e-3
+
+
 def test_checkpoint_roundtrip_reference_format(vxm, g_network, tmp_path):
     model = _build(vxm, g_network, CASES["diffeo"])
     path = os.path.join(tmp_path, "m.pt")

@@ -479,12 +479,19 @@ class UnetFn(torch.autograd.Function):
                 s0, up0, s1 = op["src"]
                 call("vxm_upsample2_cat", ptr(T[s0]), plan.ch[s0], ptr(T[s1]), plan.ch[s1], ptr(out), B, D, H, W, stream())
             T[dst] = out
+        # The returned tensor must not be reachable from ctx except through save_for_backward: out.grad_fn is this
+        # node, so `ctx.T[plan.out] = out` would be a reference cycle that keeps EVERY activation of the step alive
+        # until Python's cyclic GC runs (tens of GB per step at 160x192x224).
+        out = T.pop(plan.out)
+        ctx.save_for_backward(out)
         ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B = plan, T, params, shape3, B
-        return T[plan.out]
+        return out
 
     @staticmethod
     def backward(ctx, gout):
-        plan, T, params, shape3, B = ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B
+        plan, params, shape3, B = ctx.plan, ctx.params, ctx.shape3, ctx.B
+        T = dict(ctx.T)
+        T[plan.out] = ctx.saved_tensors[0]
         dev, dt = gout.device, gout.dtype
         gout = _c(gout)
         ws = _Workspace(dev)

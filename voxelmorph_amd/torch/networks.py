@@ -172,7 +172,8 @@ class VxmDense(LoadableModel):
         self.transformer = layers.SpatialTransformer(inshape)
         self._feats = (src_feats, trg_feats)
 
-    def forward(self, source, target, registration=False):
+    def _forward_all(self, source, target):
+        """(y_source, y_target, preint_flow, pos_flow, neg_flow) of networks.py:244-287 (None where not bidir)."""
         # U-Net + flow conv as ONE fused autograd node; source/target enter as a virtual concat
         plan = self.unet_model.plan(self._feats, extra=((self.flow.out_channels, 1.0),))
         flow_field = VF.UnetFn.apply(plan, source, target, *self.unet_model.conv_params(), self.flow.weight, self.flow.bias)
@@ -189,6 +190,59 @@ class VxmDense(LoadableModel):
                 neg_flow = self.fullsize(neg_flow) if self.bidir else None
         y_source = self.transformer(source, pos_flow)
         y_target = self.transformer(target, neg_flow) if self.bidir else None
+        return y_source, y_target, preint_flow, pos_flow, neg_flow
+
+    def forward(self, source, target, registration=False):
+        y_source, y_target, preint_flow, pos_flow, _ = self._forward_all(source, target)
         if not registration:
             return (y_source, y_target, preint_flow) if self.bidir else (y_source, preint_flow)
         return y_source, pos_flow
+
+
+class VxmDenseSemiSupervisedSeg(LoadableModel):
+    """VoxelMorph network for (semi-supervised) nonlinear registration between two images: VxmDense plus a warped
+    down-sampled source segmentation for an auxiliary Dice loss.
+
+    The reference implements this model only for its TensorFlow backend (voxelmorph/tf/networks.py:287-388, trained by
+    scripts/tf/train_semisupervised_seg.py:117-140); this is the same wiring on the torch-side API of this package:
+    `seg_flow = RescaleTransform(1/seg_resolution)(pos_flow)` (tf/networks.py:336-337) is `ResizeTransform(seg_resolution)`
+    here (torch/layers.py:76-97: resample by 1/seg_resolution and rescale), and the one-hot segmentation
+    [B, nb_labels, *inshape/seg_resolution] is warped with a linear SpatialTransformer (tf/networks.py:338-339).
+
+    forward(source, target, seg_src[, seg_trg]) returns VxmDense's training outputs followed by the warped
+    segmentation(s): (y_source, [y_target,] preint_flow, y_seg_src[, y_seg_trg]).
+    """
+
+    @store_config_args
+    def __init__(self, inshape, nb_labels, nb_unet_features=None, seg_resolution=2, bidir=False, bidir_labels=False, **kwargs):
+        super().__init__()
+        if bidir_labels:                       # tf/networks.py:319-321
+            bidir = True
+        self.vxm_model = VxmDense(inshape, nb_unet_features=nb_unet_features, bidir=bidir, **kwargs)
+        ndims = len(inshape)
+        self.nb_labels = nb_labels
+        self.bidir, self.bidir_labels = bidir, bidir_labels
+        inshape_ds = [int(s) for s in (np.array(inshape) / seg_resolution).astype(int)]      # tf/networks.py:332
+        self.seg_resize = layers.ResizeTransform(seg_resolution, ndims)
+        self.seg_transformer = layers.SpatialTransformer(inshape_ds)
+
+    def forward(self, source, target, seg_src, seg_trg=None):
+        y_source, y_target, preint_flow, pos_flow, neg_flow = self.vxm_model._forward_all(source, target)
+        outs = [y_source] + ([y_target] if self.bidir else []) + [preint_flow]
+        outs.append(self.seg_transformer(seg_src, self.seg_resize(pos_flow)))
+        if self.bidir_labels:
+            if seg_trg is None:
+                raise ValueError("bidir_labels=True needs the target segmentation as fourth input")
+            outs.append(self.seg_transformer(seg_trg, self.seg_resize(neg_flow)))
+        return tuple(outs)
+
+    def register(self, src, trg):
+        """Predicts the transform from src to trg tensors (tf/networks.py:370-374)."""
+        return self.vxm_model(src, trg, registration=True)[1]
+
+    def apply_transform(self, src, trg, img, interp_method='linear'):
+        """Predicts the transform from src to trg and applies it to img (tf/networks.py:376-388);
+        interp_method 'nearest' gives the bit-exact label warp used for Dice evaluation."""
+        flow = self.register(src, trg)
+        mode = 'bilinear' if interp_method == 'linear' else interp_method
+        return layers.SpatialTransformer(flow.shape[2:], mode=mode).to(flow.device)(img, flow)
