@@ -112,6 +112,32 @@ def test_semisupervised_seg_model_surface(tmp_path):
         m(x, x, torch.zeros(1, 4, 8, 8, 8))
 
 
+def test_data_path_host_side(tmp_path):
+    """voxelmorph_amd.data: the npz / npy subset of py/utils.load_volfile and the no-CPU rule of the loader;
+    scripts/train.py keeps the reference's flags and defaults (scripts/torch/train.py:52-91)."""
+    from voxelmorph_amd import data as vdata
+    v = np.random.default_rng(0).random((4, 5, 6))
+    np.savez(tmp_path / "a.npz", vol=v, seg=np.zeros((4, 5, 6)))
+    np.save(tmp_path / "b.npy", v)
+    np.savez(tmp_path / "c.npz", only=v)
+    assert np.array_equal(vdata.load_volfile(str(tmp_path / "a.npz")), v)
+    assert np.array_equal(vdata.load_volfile(str(tmp_path / "a.npz"), np_var="seg"), np.zeros((4, 5, 6)))
+    assert np.array_equal(vdata.load_volfile(str(tmp_path / "b.npy")), v)
+    assert np.array_equal(vdata.load_volfile(str(tmp_path / "c.npz")), v)          # single variable: taken whatever its name
+    assert vdata.load_volfile(v) is not None
+    with pytest.raises(ValueError):
+        vdata.load_volfile(str(tmp_path / "missing.npz"))
+    with pytest.raises(ValueError):
+        vdata.PairLoader([v, v], device="cpu")
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import train as train_cli
+    a = train_cli.parse(["--img-list", "x.txt"])
+    assert (a.batch_size, a.epochs, a.steps_per_epoch, a.lr, a.int_steps, a.int_downsize, a.image_loss, a.weight, a.bidir) == \
+        (1, 1500, 100, 1e-4, 7, 2, "mse", 0.01, False)
+    (tmp_path / "list.txt").write_text("a\nb\n\n")
+    assert train_cli.read_file_list(str(tmp_path / "list.txt"), prefix="p/", suffix=".npz") == ["p/a.npz", "p/b.npz"]
+
+
 def test_state_dict_and_checkpoint_format(g_network, tmp_path):
     m = vxm.networks.VxmDense((16, 16, 16))
     keys = list(m.state_dict().keys())

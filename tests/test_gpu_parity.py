@@ -446,6 +446,63 @@ def test_semisupervised_seg_vs_oracle(vxm):
     assert np.abs(np.asarray(d_hip) - np.asarray(d_ref)).max() < 1e-3
 
 
+def test_pair_loader_resident_and_streaming(vxm):
+    """Data path: batches are [B,1,D,H,W] fp32 on the device, every sample is one of the source
+    volumes bit for bit, ranks draw different pairs, the zero flow target has the reference's role (generators.py:98-105)."""
+    from voxelmorph_amd import data as vdata
+    rng = np.random.default_rng(1)
+    vols = [rng.random((8, 12, 16)) for _ in range(5)]              # float64 like the reference's npz volumes
+    ref = np.stack(vols).astype(np.float32)
+    for resident_bytes in (1 << 30, 0):                              # resident in HBM / streamed through pinned staging
+        ld = vdata.scan_to_scan(vols, batch_size=3, bidir=True, device="cuda", rank=0, seed=7, resident_bytes=resident_bytes)
+        assert ld.resident == (resident_bytes > 0)
+        for _ in range(4):
+            (s1, s2), (t1, t2, z) = next(ld)
+            assert s1.shape == (3, 1, 8, 12, 16) and s1.dtype == torch.float32 and s1.is_cuda and s1.is_contiguous()
+            assert t1 is s2 and t2 is s1 and z.shape == (3, 3, 8, 12, 16) and float(z.abs().max()) == 0.0
+            for t in (s1, s2):
+                for b in range(3):
+                    assert any(np.array_equal(N(t)[b, 0], ref[i]) for i in range(5))
+    a = vdata.PairLoader(vols, batch_size=4, device="cuda", rank=0, seed=7)
+    b = vdata.PairLoader(vols, batch_size=4, device="cuda", rank=1, seed=7)
+    assert not all(torch.equal(next(a)[0][0], next(b)[0][0]) for _ in range(4))
+
+
+def test_train_and_register_cli_end_to_end(vxm, tmp_path):
+    """scripts/train.py (flags of scripts/torch/train.py) for a few steps on synthetic volumes, then scripts/register.py
+    (flags of scripts/torch/register.py) on its checkpoint: moved / warp / nearest-warped labels come out, and the
+    training loss goes down."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(3)
+    base = rng.random((32, 32, 32)).astype(np.float32)
+    names = []
+    for i in range(4):
+        v = np.roll(base, shift=i, axis=2) + 0.05 * rng.random(base.shape).astype(np.float32)
+        np.savez(tmp_path / ("v%d.npz" % i), vol=v, seg=(v > 0.5).astype(np.float32))
+        names.append(str(tmp_path / ("v%d.npz" % i)))
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "train.py"), "--img-list", str(tmp_path / "list.txt"),
+                        "--model-dir", str(tmp_path / "models"), "--epochs", "3", "--steps-per-epoch", "6", "--image-loss", "ncc",
+                        "--lambda", "1", "--lr", "1e-3"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    losses = [float(ln.split("loss:")[1].split()[0]) for ln in r.stdout.splitlines() if "loss:" in ln]
+    assert len(losses) == 3 and losses[-1] < losses[0]
+    ckpt = tmp_path / "models" / "0003.pt"
+    assert ckpt.exists() and (tmp_path / "models" / "0000.pt").exists()
+    np.savez(tmp_path / "seg.npz", vol=(base > 0.5).astype(np.float32))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "register.py"), "--moving", names[0], "--fixed", names[1],
+                        "--moved", str(tmp_path / "moved.npz"), "--warp", str(tmp_path / "warp.npz"), "--model", str(ckpt),
+                        "--seg", str(tmp_path / "seg.npz"), "--moved-seg", str(tmp_path / "mseg.npz"), "--jacobian"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert np.load(tmp_path / "moved.npz")["vol"].shape == (32, 32, 32)
+    assert np.load(tmp_path / "warp.npz")["vol"].shape == (3, 32, 32, 32)
+    assert set(np.unique(np.load(tmp_path / "mseg.npz")["vol"])) <= {0.0, 1.0}
+    assert "non-positive Jacobian fraction" in r.stdout
+
+
 def test_checkpoint_roundtrip_reference_format(vxm, g_network, tmp_path):
     model = _build(vxm, g_network, CASES["diffeo"])
     path = os.path.join(tmp_path, "m.pt")
