@@ -225,6 +225,7 @@ def test_grad_mse_dice_golden(vxm, g_losses):
     (2, 16, (8, 8, 16), 0.2), (16, 32, (8, 12, 16), 0.2), (32, 32, (5, 6, 7), 0.2), (48, 32, (4, 8, 32), 0.2),
     (64, 32, (8, 4, 16), 0.2), (16, 3, (9, 10, 33), 1.0), (5, 7, (6, 7, 19), 0.2), (20, 40, (4, 4, 16), 0.2),
     (17, 16, (5, 7, 28), 0.2), (32, 48, (6, 9, 36), 1.0), (3, 3, (3, 3, 4), 0.2),
+    (16, 3, (6, 8, 20), 1.0), (24, 2, (5, 6, 16), 0.2),        # few output channels: role-swapped backward-weight
 ])
 def test_conv_block_vs_oracle(vxm, cin, cout, vol, slope):
     from voxelmorph_amd.torch import functional as VF

@@ -517,6 +517,14 @@ bool bwd_weight_wide_ok(const float* x0, int64_t bs0, const float* x1, int C1, i
            !bw_force_generic();
 }
 
+// Few output channels (the 16 -> 3 flow conv): M = co would use 3 of 16 MFMA rows.  The product is computed with the
+// roles swapped instead, gW[co,ci,tap] = sum_u X[ci,u] dZ[co,u - tap]: X becomes the (halo-free) A operand with M = ci,
+// the zero-padded dZ the shifted B operand with N = (tap, co) = 81 entries -> 6 N-tiles instead of 27: the same kernel
+// called with (x, dz) exchanged; the result comes out as [ci][co][26 - tap] and the reducer writes it back in place.
+bool bwd_weight_swap_ok(int C0, int C1, int x0_up, int Cout, bool vec) {
+    return vec && Cout <= 4 && C1 == 0 && !x0_up && C0 >= 8;
+}
+
 // w: [Cw_out][Cw_in][27] (reference layout).  Packed operator has Cin_p inputs / Cout_p outputs.
 __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, float* __restrict__ wp, int Cw_in, int Cw_out,
                                                       int flip, int Cin_p, int Cout_p, int CK, int NCT, int Q, size_t elems) {
@@ -961,8 +969,10 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_dma(ConvIn 
 // partial-slices per block, 4 independent accumulators per thread so that the (latency-bound) loads overlap.
 // Element i = (co, ci, tap) belongs to combo (ci / 16, co / cog_size), which has cnt = ceil((T - combo) / cb) slots;
 // the bias partials live in the chunk-0 combos.
+// swapflip: the partials are those of the role-swapped product (see vxm_conv3d_k3_bwd_weight): element (co' = ci, ci' = co, t)
+// goes to gw[co][ci][26 - t].
 __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb,
-                                                         int n, int Cin, int Cout, int T, int Qc, int G, int cog_size) {
+                                                         int n, int Cin, int Cout, int T, int Qc, int G, int cog_size, int swapflip) {
     __shared__ float red[4][64];
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + x;
@@ -986,8 +996,35 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
     __syncthreads();
     if (y == 0 && i < ntot) {
         const float t = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
-        if (i < n) gw[i] = t; else gb[i - n] = t;
+        if (i >= n) gb[i - n] = t;
+        else if (!swapflip) gw[i] = t;
+        else {
+            const int cop = i / (Cin * 27), cip = (i / 27) % Cin, tap = i % 27;        // Cin = inner extent of the partial = original Cout
+            gw[((size_t)cip * Cout + cop) * 27 + (26 - tap)] = t;                       // Cout = outer extent = original Cin
+        }
     }
+}
+
+// bias gradient of the role-swapped path: gb[co] = sum_{b,v} dz[b,co,v] in two deterministic stages
+constexpr int CS_SLICES = 256;
+__global__ void __launch_bounds__(256) k_channel_sum_partial(const float* __restrict__ dz, long long dz_bs, float* __restrict__ ws, int B, size_t V) {
+    __shared__ float red[4];
+    const int co = blockIdx.x;
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float* p = dz + (size_t)b * dz_bs + (size_t)co * V;
+        for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < V; i += (size_t)CS_SLICES * 256) s += p[i];
+    }
+    s = vxm_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[co * CS_SLICES + blockIdx.y] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(64) k_channel_sum_finish(const float* __restrict__ ws, float* __restrict__ gb) {
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < CS_SLICES; i += 64) s += ws[blockIdx.x * CS_SLICES + i];
+    s = vxm_wave_sum(s);
+    if (threadIdx.x == 0) gb[blockIdx.x] = s;
 }
 
 struct BwPlan { int NCT, Qc, G, T, nparts; };
@@ -1093,13 +1130,19 @@ int vxm_conv3d_k3_fwd_variant(const float* x0, int C0, int64_t x0_bstride, const
 
 int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
                                      const float* dz, int64_t dz_bstride, int Cout, int W) {
-    return (bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W) ? 10 : 0) + (Cout <= 16 ? 1 : 2);
+    return (bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W) ? 10 : 0) + (Cout <= 16 ? 1 : 2);     // NCT of the unswapped plan
 }
 
 size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D, int H, int W) {
     if (Cin <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     const BwPlan p = bw_plan(Cin, Cout, B, D, H, W);
-    return 256 + sizeof(float) * (size_t)p.nparts * ((size_t)Cout * Cin * 27 + Cout);
+    size_t need = sizeof(float) * (size_t)p.nparts * ((size_t)Cout * Cin * 27 + Cout);
+    if (Cout <= 4) {                                   // role-swapped product (+ the channel-sum scratch of its bias gradient)
+        const BwPlan q = bw_plan(Cout, Cin, B, D, H, W);
+        const size_t alt = sizeof(float) * ((size_t)q.nparts * ((size_t)Cout * Cin * 27 + Cin) + (size_t)Cout * CS_SLICES);
+        if (alt > need) need = alt;
+    }
+    return 256 + need;
 }
 
 int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
@@ -1110,13 +1153,13 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
     const int Cin = C0 + C1;
     VXM_REQUIRE(workspace_bytes >= vxm_conv3d_k3_bwd_weight_workspace_bytes(Cin, Cout, B, D, H, W), VXM_ERR_WORKSPACE,
                 "vxm_conv3d_k3_bwd_weight: workspace too small (%zu bytes)", workspace_bytes);
-    const BwPlan p = bw_plan(Cin, Cout, B, D, H, W);
-    // workspace: per-block partials [nparts][Cout*Cin*27 + Cout]
+    // wide-load path: rows of 4-float groups must not straddle row ends and must be 16-byte aligned in memory
+    const bool vec = bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W);
+    const bool swap = bwd_weight_swap_ok(C0, C1, x0_up, Cout, vec);
+    // workspace: per-block partials [nparts][Cout*Cin*27 + (Cout | Cin)] (+ channel-sum scratch when swapped)
     uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
     float* part = reinterpret_cast<float*>(base);
-    ConvIn in{x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up};
-    const dim3 grid(p.T);
-    // up to 156 KB of dynamic LDS (> the 64 KB default cap): opt in once per kernel
+    // up to 161 KB of dynamic LDS (> the 64 KB default cap): opt in once per kernel
     static bool lds_opt_in = false;
     if (!lds_opt_in) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight_vec<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1125,22 +1168,37 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight_dma<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         lds_opt_in = true;
     }
-    // wide-load path: rows of 4-float groups must not straddle row ends and must be 16-byte aligned in memory
-    const bool vec = bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W);
-#define BW_LAUNCH(KERNEL, LDSF) hipLaunchKernelGGL(KERNEL, grid, dim3(BW_THREADS), sizeof(float) * (size_t)(LDSF), VXM_STREAM(stream), in, dz, \
-        (long long)dz_bstride, Cout, gb ? 1 : 0, part, B, D, H, W, p.Qc, p.G)
+    const int n = Cout * Cin * 27;
+#define BW_LAUNCH(KERNEL, LDSF, IN_, DZ_, DZBS_, CO_, BIAS_, P_) hipLaunchKernelGGL(KERNEL, dim3((P_).T), dim3(BW_THREADS), sizeof(float) * (size_t)(LDSF), \
+        VXM_STREAM(stream), IN_, DZ_, (long long)(DZBS_), CO_, BIAS_, part, B, D, H, W, (P_).Qc, (P_).G)
+    if (swap) {
+        const BwPlan q = bw_plan(Cout, Cin, B, D, H, W);          // "input" = dz (Cout channels), "output gradient" = x (Cin channels)
+        ConvIn sin{dz, nullptr, (long long)dz_bstride, 0, Cout, 0, 0};
+        if (q.NCT == 1) BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<1>, 2 * bv_lds_floats<1>(), sin, x0, x0_bstride, Cin, 0, q);
+        else BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<2>, 2 * bv_lds_floats<2>(), sin, x0, x0_bstride, Cin, 0, q);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, (float*)nullptr, n, Cout, Cin,
+                           q.T, q.Qc, q.G, 16 * q.NCT, 1);
+        if (gb) {
+            float* cs = part + (size_t)q.nparts * ((size_t)n + Cin);
+            hipLaunchKernelGGL(k_channel_sum_partial, dim3(Cout, CS_SLICES), dim3(256), 0, VXM_STREAM(stream), dz, (long long)dz_bstride, cs, B,
+                               (size_t)D * H * W);
+            hipLaunchKernelGGL(k_channel_sum_finish, dim3(Cout), dim3(64), 0, VXM_STREAM(stream), cs, gb);
+        }
+        return vxm_check_launch("vxm_conv3d_k3_bwd_weight");
+    }
+    const BwPlan p = bw_plan(Cin, Cout, B, D, H, W);
+    ConvIn in{x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up};
     if (vec) {
-        if (p.NCT == 1) BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<1>, 2 * bv_lds_floats<1>());
-        else BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<2>, 2 * bv_lds_floats<2>());
+        if (p.NCT == 1) BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<1>, 2 * bv_lds_floats<1>(), in, dz, dz_bstride, Cout, gb ? 1 : 0, p);
+        else BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<2>, 2 * bv_lds_floats<2>(), in, dz, dz_bstride, Cout, gb ? 1 : 0, p);
     } else {
-        if (p.NCT == 1) BW_LAUNCH(k_conv3d_k3_bwd_weight_dma<1>, 2 * bw_buf_floats<1>());
-        else BW_LAUNCH(k_conv3d_k3_bwd_weight_dma<2>, 2 * bw_buf_floats<2>());
+        if (p.NCT == 1) BW_LAUNCH(k_conv3d_k3_bwd_weight_dma<1>, 2 * bw_buf_floats<1>(), in, dz, dz_bstride, Cout, gb ? 1 : 0, p);
+        else BW_LAUNCH(k_conv3d_k3_bwd_weight_dma<2>, 2 * bw_buf_floats<2>(), in, dz, dz_bstride, Cout, gb ? 1 : 0, p);
     }
 #undef BW_LAUNCH
-    const int n = Cout * Cin * 27;
     // the bias gradient rides along: its per-block partials sit behind the weight partials of every slot
     hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n + (gb ? Cout : 0), 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, gb, n, Cin, Cout,
-                       p.T, p.Qc, p.G, 16 * p.NCT);
+                       p.T, p.Qc, p.G, 16 * p.NCT, 0);
     return vxm_check_launch("vxm_conv3d_k3_bwd_weight");
 }
 
