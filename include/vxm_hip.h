@@ -86,6 +86,12 @@ int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
                       const float* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout,
                       float act_slope, const float* mask_src, int64_t mask_bstride, float mask_slope,
                       int B, int D, int H, int W, void* stream);
+/* Forward conv with 1..4 output channels (the 16 -> 3 flow conv, networks.py:211,257) on the vector ALUs: x [B,Cin,D,H,W],
+ * w [Cout,Cin,3,3,3] in the REFERENCE layout (no packing), y [B,Cout,D,H,W]; act_slope = 1: no activation.
+ * vxm_conv3d_k3_fewout_ok tells whether the operands qualify (Cout <= 4, W % 4 == 0, 16-byte aligned). */
+int vxm_conv3d_k3_fewout_ok(const float* x, int64_t x_bstride, float* y, int64_t y_bstride, int Cin, int Cout, int W);
+int vxm_conv3d_k3_fewout_fwd(const float* x, int Cin, int64_t x_bstride, const float* w, const float* bias, float* y,
+                             int64_t y_bstride, int Cout, float act_slope, int B, int D, int H, int W, void* stream);
 /* Which kernel a vxm_conv3d_k3_fwd call with these operands dispatches to (for profiling labels):
  * 100 * wide + 10 * CK + NCT, wide = 1: the 8-wave wide-load kernel (k_conv3d_k3_t8<NCT>), 0: k_conv3d_k3<CK,NCT>. */
 int vxm_conv3d_k3_fwd_variant(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,

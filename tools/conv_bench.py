@@ -87,13 +87,12 @@ def main():
         gx = torch.empty(B, cin, D, H, W, device=dev)
         gw = torch.empty_like(w)
         gb = torch.empty_like(b)
-        wp = VF.pack_weights(w, False)
         ws = VF._Workspace(dev)
         flops = 2.0 * 27 * cin * cout * B * V
 
         def fwd():
-            VF.conv_launch(x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, wp, b, y, cout * V,
-                           cout, slope, None, 0, 1.0, B, D, H, W)
+            VF.conv_forward(x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, w, b, y, cout * V,
+                            cout, slope, B, D, H, W)
 
         def bwd_data():
             VF.conv_bwd_data(dz, cout, w, gx, cin, None, 1.0, B, D, H, W)

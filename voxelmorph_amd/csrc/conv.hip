@@ -480,6 +480,108 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// forward conv with <= 4 output channels (the 16 -> 3 flow conv, networks.py:211,257)
+// ------------------------------------------------------------------------------------------
+// On the MFMA path 3 output channels occupy 3 of 16 rows.  Here the contraction runs on the vector ALUs instead:
+// a thread owns 4 consecutive W voxels x CO output channels (4 CO accumulators), a block a 4 x 8 x 32 tile; per
+// (ci, kd, kh) it reads its 6 input columns as one ds_read_b128 + one ds_read_b64 and the 3 x CO weights as LDS
+// broadcasts, and issues 12 CO FMAs.  Input chunks of 4 channels go through LDS ([4][6][10][36], halo columns at 0 / 33
+// so that the 6-column reads are 16-byte aligned), zero padding from the buffer descriptor; the weights are read in
+// the reference layout and re-ordered into LDS once per block (no pack launch).
+constexpr int FO_TD = 4, FO_TH = 8, FO_TW = 32, FO_CK = 4;
+constexpr int FO_RS = 36, FO_ROWS = (FO_TD + 2) * (FO_TH + 2), FO_PS = FO_ROWS * FO_RS;   // 60 rows, plane 2160 floats
+
+template <int CO>
+__global__ void __launch_bounds__(256) k_conv3d_k3_fewout(const float* __restrict__ x, long long x_bs, int Cin, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y, long long y_bs, float act_slope,
+                                                          int D, int H, int W) {
+    VXM_DYN_SMEM(float, smem);
+    float* const Xs = smem;                                  // [FO_CK][FO_PS]
+    float* const Wl = smem + FO_CK * FO_PS;                  // [Cin][9][3][4]: (kd,kh) x kw x co (padded to 4)
+    const int tid = threadIdx.x, tx = tid & 7, ty = (tid >> 3) & 7, tz = tid >> 6;
+    const int ntw = (W + FO_TW - 1) / FO_TW, nth = (H + FO_TH - 1) / FO_TH;
+    int t = blockIdx.x;
+    const int w0 = (t % ntw) * FO_TW; t /= ntw;
+    const int h0 = (t % nth) * FO_TH;
+    const int d0 = (t / nth) * FO_TD;
+    const int b = blockIdx.y;
+    const int V = D * H * W;
+    for (int i = tid; i < Cin * 27 * 4; i += 256) {          // Wl[(ci*9 + kdkh)*12 + kw*4 + co]
+        const int co = i & 3, kw = (i >> 2) % 3, r = i / 12, kdkh = r % 9, ci = r / 9;
+        Wl[i] = co < CO ? w[((size_t)co * Cin + ci) * 27 + kdkh * 3 + kw] : 0.0f;
+    }
+    const __amdgpu_buffer_rsrc_t rx = vxm_rsrc(x + (size_t)b * x_bs, (unsigned)Cin * (unsigned)V * 4u);
+    float acc[CO][4];
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[co][j] = 0.0f;
+
+    const int Q = (Cin + FO_CK - 1) / FO_CK;
+    for (int q = 0; q < Q; ++q) {
+        // ---- stage chunk q: 4 planes x 60 rows x (8 interior float4 + 2 halo columns)
+        for (int slot = tid; slot < FO_CK * FO_ROWS * 8; slot += 256) {
+            const int c = slot / (FO_ROWS * 8), rr = (slot / 8) % FO_ROWS, g4 = slot & 7;
+            const int cg = q * FO_CK + c;
+            const int gd = d0 - 1 + rr / (FO_TH + 2), gh = h0 - 1 + rr % (FO_TH + 2), gw = w0 + 4 * g4;
+            const bool ok = cg < Cin && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw < W;
+            const int vo = ok ? (cg * V + (gd * H + gh) * W + gw) << 2 : VXM_OOB;
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0));
+            float* dst = Xs + c * FO_PS + rr * FO_RS + 1 + 4 * g4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        for (int slot = tid; slot < FO_CK * FO_ROWS * 2; slot += 256) {
+            const int c = slot / (FO_ROWS * 2), rr = (slot >> 1) % FO_ROWS, side = slot & 1;
+            const int cg = q * FO_CK + c;
+            const int gd = d0 - 1 + rr / (FO_TH + 2), gh = h0 - 1 + rr % (FO_TH + 2), gw = side ? w0 + FO_TW : w0 - 1;
+            const bool ok = cg < Cin && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const int vo = ok ? (cg * V + (gd * H + gh) * W + gw) << 2 : VXM_OOB;
+            Xs[c * FO_PS + rr * FO_RS + (side ? FO_TW + 1 : 0)] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vo, 0, 0));
+        }
+        __syncthreads();
+        // ---- 4 channels x 9 (kd, kh) x [6 inputs, 3 x CO weights] -> 12 CO FMAs
+#pragma unroll
+        for (int c = 0; c < FO_CK; ++c) {
+            const float* wl = Wl + (size_t)(q * FO_CK + c) * 108;
+            if (q * FO_CK + c < Cin) {
+#pragma unroll
+                for (int kk = 0; kk < 9; ++kk) {
+                    const int kd = kk / 3, kh = kk % 3;
+                    const float* row = Xs + c * FO_PS + ((tz + kd) * (FO_TH + 2) + ty + kh) * FO_RS + 4 * tx;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(row);
+                    const f32x2 e = *reinterpret_cast<const f32x2*>(row + 4);
+                    const float in[6] = {a.x, a.y, a.z, a.w, e.x, e.y};
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + kk * 12 + kw * 4);       // LDS broadcast
+                        const float wc[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                        for (int co = 0; co < CO; ++co)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(in[j + kw], wc[co], acc[co][j]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int d = d0 + tz, h = h0 + ty, wq = w0 + 4 * tx;
+    if (d < D && h < H && wq < W) {                          // W % 4 == 0: the 4 voxels are in or out together
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            const float bz = bias ? bias[co] : 0.0f;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = acc[co][j] + bz;
+                o[j] = v > 0.0f ? v : v * act_slope;
+            }
+            *reinterpret_cast<f32x4*>(y + (size_t)b * y_bs + (size_t)co * V + ((size_t)d * H + h) * W + wq) = o;
+        }
+    }
+}
+
 // VXM_CONV_GENERIC=1 routes every conv launch through the generic kernels (any W / alignment; LDS-DMA backward-
 // weight), so that the parity tests can exercise them on shapes the wide-load kernels would otherwise take.
 bool bw_force_generic() {
@@ -1131,6 +1233,34 @@ int vxm_conv3d_k3_fwd_variant(const float* x0, int C0, int64_t x0_bstride, const
 int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
                                      const float* dz, int64_t dz_bstride, int Cout, int W) {
     return (bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W) ? 10 : 0) + (Cout <= 16 ? 1 : 2);     // NCT of the unswapped plan
+}
+
+int vxm_conv3d_k3_fewout_ok(const float* x, int64_t x_bstride, float* y, int64_t y_bstride, int Cin, int Cout, int W) {
+    return Cout >= 1 && Cout <= 4 && Cin >= 1 && (W & 3) == 0 && al16(x) && al16(y) && (x_bstride & 3) == 0 && (y_bstride & 3) == 0 &&
+           !bw_force_generic();
+}
+
+int vxm_conv3d_k3_fewout_fwd(const float* x, int Cin, int64_t x_bstride, const float* w, const float* bias, float* y, int64_t y_bstride,
+                             int Cout, float act_slope, int B, int D, int H, int W, void* stream) {
+    if (int e = check_conv("vxm_conv3d_k3_fewout_fwd", Cin, 0, 0, Cout, B, D, H, W)) return e;
+    VXM_REQUIRE(x && w && y, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_fewout_fwd: null pointer");
+    VXM_REQUIRE(vxm_conv3d_k3_fewout_ok(x, x_bstride, y, y_bstride, Cin, Cout, W), VXM_ERR_UNSUPPORTED,
+                "vxm_conv3d_k3_fewout_fwd: needs Cout <= 4, W %% 4 == 0 and 16-byte aligned tensors (use vxm_conv3d_k3_fwd)");
+    VXM_REQUIRE(B <= 65535 && Cin <= 512, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_fewout_fwd: B <= 65535, Cin <= 512");
+    const long long tiles = (long long)((W + FO_TW - 1) / FO_TW) * ((H + FO_TH - 1) / FO_TH) * ((D + FO_TD - 1) / FO_TD);
+    VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_fewout_fwd: too many tiles");
+    const size_t lds = sizeof(float) * ((size_t)FO_CK * FO_PS + (size_t)Cin * 108);
+    const dim3 grid((unsigned)tiles, B);
+#define FO_LAUNCH(CO_) hipLaunchKernelGGL(k_conv3d_k3_fewout<CO_>, grid, dim3(256), lds, VXM_STREAM(stream), x, (long long)x_bstride, Cin, w, bias, y, \
+        (long long)y_bstride, act_slope, D, H, W)
+    switch (Cout) {
+        case 1: FO_LAUNCH(1); break;
+        case 2: FO_LAUNCH(2); break;
+        case 3: FO_LAUNCH(3); break;
+        default: FO_LAUNCH(4); break;
+    }
+#undef FO_LAUNCH
+    return vxm_check_launch("vxm_conv3d_k3_fewout_fwd");
 }
 
 size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D, int H, int W) {

@@ -262,6 +262,16 @@ def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, ma
              cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, stream())
 
 
+def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B, D, H, W):
+    """ConvBlock / flow conv forward (networks.py:299-305, 211,257) from the reference-layout weights: the MFMA implicit
+    GEMM (weights packed per call), or the vector-ALU kernel when there are at most 4 output channels (flow conv)."""
+    if cout <= 4 and x1 is None and not up0 and _lib.lib().vxm_conv3d_k3_fewout_ok(ptr(x0), bs0, ptr(y), ybs, c0, cout, W):
+        with _prof.region("k_conv3d_k3_fewout<%d>" % cout, flops=2.0 * 27 * c0 * cout * B * D * H * W):
+            call("vxm_conv3d_k3_fewout_fwd", ptr(x0), c0, bs0, ptr(_c(w)), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W, stream())
+        return
+    conv_launch(x0, c0, bs0, up0, x1, c1, bs1, pack_weights(w, False), bias, y, ybs, cout, slope, None, 0, 1.0, B, D, H, W)
+
+
 def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W):
     """convolution_backward w.r.t. the input = the forward kernel with the flipped / transposed weights
     (networks.py:299 autograd twin), optionally multiplied by LeakyReLU'(mask) of the previous ConvBlock.
@@ -319,7 +329,7 @@ class ConvFn(torch.autograd.Function):
             raise ValueError("conv weight %s does not fit input with %d channels (3x3x3 kernels only)" % (tuple(w.shape), cin))
         V = D * H * W
         y = torch.empty((B, cout, D, H, W), dtype=x.dtype, device=x.device)
-        conv_launch(x, cin, cin * V, False, None, 0, 0, pack_weights(w, False), b, y, cout * V, cout, slope, None, 0, 1.0, B, D, H, W)
+        conv_forward(x, cin, cin * V, False, None, 0, 0, w, b, y, cout * V, cout, slope, B, D, H, W)
         ctx.save_for_backward(x, w, y)
         ctx.slope = slope
         ctx.has_bias = b is not None
@@ -468,9 +478,8 @@ class UnetFn(torch.autograd.Function):
                 s0, up0, s1 = op["src"]
                 w, b = params[2 * op["k"]], params[2 * op["k"] + 1]
                 x0, x1 = T[s0], (T[s1] if s1 is not None else None)
-                conv_launch(x0, plan.ch[s0], x0[0].numel(), up0, x1, plan.ch[s1] if s1 is not None else 0,
-                            x1[0].numel() if x1 is not None else 0, pack_weights(w, False), b, out, plan.ch[dst] * V,
-                            plan.ch[dst], op["slope"], None, 0, 1.0, B, D, H, W)
+                conv_forward(x0, plan.ch[s0], x0[0].numel(), up0, x1, plan.ch[s1] if s1 is not None else 0,
+                             x1[0].numel() if x1 is not None else 0, w, b, out, plan.ch[dst] * V, plan.ch[dst], op["slope"], B, D, H, W)
             elif op["kind"] == "pool":
                 src = T[op["src"]]
                 sD, sH, sW = src.shape[2:]
