@@ -485,10 +485,10 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
 // ------------------------------------------------------------------------------------------
 // On the MFMA path 3 output channels occupy 3 of 16 rows.  Here the contraction runs on the vector ALUs instead:
 // a thread owns 4 consecutive W voxels x CO output channels (4 CO accumulators), a block a 4 x 8 x 32 tile; per
-// (ci, kd, kh) it reads its 6 input columns as one ds_read_b128 + one ds_read_b64 and the 3 x CO weights as LDS
-// broadcasts, and issues 12 CO FMAs.  Input chunks of 4 channels go through LDS ([4][6][10][36], halo columns at 0 / 33
-// so that the 6-column reads are 16-byte aligned), zero padding from the buffer descriptor; the weights are read in
-// the reference layout and re-ordered into LDS once per block (no pack launch).
+// (ci, kd, kh) it reads its 6 input columns as one ds_read_b128 + one ds_read_b64, takes the 3 x CO weights from
+// scalar loads (wave-uniform addresses in the reference layout: SGPR operands, no pack launch, no LDS traffic), and
+// issues 12 CO FMAs.  Input chunks of 4 channels go through LDS ([4][6][10][36], halo columns at 0 / 33
+// so that the 6-column reads are 16-byte aligned), zero padding from the buffer descriptor.
 constexpr int FO_TD = 4, FO_TH = 8, FO_TW = 32, FO_CK = 4;
 constexpr int FO_RS = 36, FO_ROWS = (FO_TD + 2) * (FO_TH + 2), FO_PS = FO_ROWS * FO_RS;   // 60 rows, plane 2160 floats
 
@@ -498,7 +498,6 @@ __global__ void __launch_bounds__(256) k_conv3d_k3_fewout(const float* __restric
                                                           int D, int H, int W) {
     VXM_DYN_SMEM(float, smem);
     float* const Xs = smem;                                  // [FO_CK][FO_PS]
-    float* const Wl = smem + FO_CK * FO_PS;                  // [Cin][9][3][4]: (kd,kh) x kw x co (padded to 4)
     const int tid = threadIdx.x, tx = tid & 7, ty = (tid >> 3) & 7, tz = tid >> 6;
     const int ntw = (W + FO_TW - 1) / FO_TW, nth = (H + FO_TH - 1) / FO_TH;
     int t = blockIdx.x;
@@ -507,10 +506,6 @@ __global__ void __launch_bounds__(256) k_conv3d_k3_fewout(const float* __restric
     const int d0 = (t / nth) * FO_TD;
     const int b = blockIdx.y;
     const int V = D * H * W;
-    for (int i = tid; i < Cin * 27 * 4; i += 256) {          // Wl[(ci*9 + kdkh)*12 + kw*4 + co]
-        const int co = i & 3, kw = (i >> 2) % 3, r = i / 12, kdkh = r % 9, ci = r / 9;
-        Wl[i] = co < CO ? w[((size_t)co * Cin + ci) * 27 + kdkh * 3 + kw] : 0.0f;
-    }
     const __amdgpu_buffer_rsrc_t rx = vxm_rsrc(x + (size_t)b * x_bs, (unsigned)Cin * (unsigned)V * 4u);
     float acc[CO][4];
 #pragma unroll
@@ -543,8 +538,8 @@ __global__ void __launch_bounds__(256) k_conv3d_k3_fewout(const float* __restric
         // ---- 4 channels x 9 (kd, kh) x [6 inputs, 3 x CO weights] -> 12 CO FMAs
 #pragma unroll
         for (int c = 0; c < FO_CK; ++c) {
-            const float* wl = Wl + (size_t)(q * FO_CK + c) * 108;
-            if (q * FO_CK + c < Cin) {
+            const int ci = q * FO_CK + c;
+            if (ci < Cin) {
 #pragma unroll
                 for (int kk = 0; kk < 9; ++kk) {
                     const int kd = kk / 3, kh = kk % 3;
@@ -552,15 +547,18 @@ __global__ void __launch_bounds__(256) k_conv3d_k3_fewout(const float* __restric
                     const f32x4 a = *reinterpret_cast<const f32x4*>(row);
                     const f32x2 e = *reinterpret_cast<const f32x2*>(row + 4);
                     const float in[6] = {a.x, a.y, a.z, a.w, e.x, e.y};
+                    // the 3 x CO weights of (ci, kd, kh): wave-uniform addresses -> scalar loads, SGPR operands of the FMAs
+                    float wc[CO][3];
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + kk * 12 + kw * 4);       // LDS broadcast
-                        const float wc[4] = {wv.x, wv.y, wv.z, wv.w};
+                    for (int co = 0; co < CO; ++co)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) wc[co][kw] = w[((size_t)co * Cin + ci) * 27 + kk * 3 + kw];
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
                         for (int co = 0; co < CO; ++co)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(in[j + kw], wc[co], acc[co][j]);
-                    }
+                            for (int j = 0; j < 4; ++j) acc[co][j] = fmaf(in[j + kw], wc[co][kw], acc[co][j]);
                 }
             }
         }
@@ -1249,7 +1247,7 @@ int vxm_conv3d_k3_fewout_fwd(const float* x, int Cin, int64_t x_bstride, const f
     VXM_REQUIRE(B <= 65535 && Cin <= 512, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_fewout_fwd: B <= 65535, Cin <= 512");
     const long long tiles = (long long)((W + FO_TW - 1) / FO_TW) * ((H + FO_TH - 1) / FO_TH) * ((D + FO_TD - 1) / FO_TD);
     VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_fewout_fwd: too many tiles");
-    const size_t lds = sizeof(float) * ((size_t)FO_CK * FO_PS + (size_t)Cin * 108);
+    const size_t lds = sizeof(float) * (size_t)FO_CK * FO_PS;
     const dim3 grid((unsigned)tiles, B);
 #define FO_LAUNCH(CO_) hipLaunchKernelGGL(k_conv3d_k3_fewout<CO_>, grid, dim3(256), lds, VXM_STREAM(stream), x, (long long)x_bstride, Cin, w, bias, y, \
         (long long)y_bstride, act_slope, D, H, W)
