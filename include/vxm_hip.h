@@ -86,6 +86,18 @@ int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
                       const float* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout,
                       float act_slope, const float* mask_src, int64_t mask_bstride, float mask_slope,
                       int B, int D, int H, int W, void* stream);
+/* ConvBlock over cat([upsample2(x0), x1]) (networks.py:137-138,299-305) with the upsampled segment evaluated at LOW
+ * resolution: per output parity the 27 taps over the nearest-upsampled x0 collapse onto 2x2x2 low-resolution inputs
+ * with pre-summed weights (8 instead of 27 MACs per channel pair and voxel).  x0 [B,C0,D/2,H/2,W/2], x1 [B,C1,D,H,W]
+ * (nullable, C1 = 0), y [B,Cout,D,H,W]; weights packed by vxm_conv3d_k3_up_pack_weights from the reference layout
+ * w [Cout,C0+C1,3,3,3].  vxm_conv3d_k3_up_ok tells whether the operands qualify (otherwise vxm_conv3d_k3_fwd, x0_up=1). */
+int vxm_conv3d_k3_up_ok(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, float* y,
+                        int Cout, int B, int D, int H, int W);
+size_t vxm_conv3d_k3_up_packed_elems(int C0, int C1, int Cout);
+int vxm_conv3d_k3_up_pack_weights(const float* w, float* wpacked, int C0, int C1, int Cout, void* stream);
+int vxm_conv3d_k3_up_fwd(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
+                         const float* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope,
+                         int B, int D, int H, int W, void* stream);
 /* Forward conv with 1..4 output channels (the 16 -> 3 flow conv, networks.py:211,257) on the vector ALUs: x [B,Cin,D,H,W],
  * w [Cout,Cin,3,3,3] in the REFERENCE layout (no packing), y [B,Cout,D,H,W]; act_slope = 1: no activation.
  * vxm_conv3d_k3_fewout_ok tells whether the operands qualify (Cout <= 4, W % 4 == 0, 16-byte aligned). */

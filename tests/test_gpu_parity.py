@@ -246,6 +246,33 @@ def test_conv_block_vs_oracle(vxm, cin, cout, vol, slope):
     assert rel_l2(N(bg.grad), bo.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("c0,c1,cout,vol", [(32, 16, 32, (16, 8, 32)), (8, 0, 16, (8, 12, 16)), (6, 5, 20, (12, 8, 32)), (32, 32, 32, (8, 8, 16))])
+def test_conv_upsampled_segment_collapsed_weights(vxm, c0, c1, cout, vol):
+    """cat([upsample2(x0), x1]) conv with the upsampled segment evaluated at low resolution through per-parity collapsed
+    2x2x2 weights (k_conv3d_k3_t8u) against the plain fp64 conv over the materialised concat; borders included."""
+    import subprocess  # noqa: F401
+    from voxelmorph_amd import _lib
+    from voxelmorph_amd.torch import functional as VF
+    rng = np.random.default_rng(c0 + c1)
+    B = 2
+    x0 = rng.standard_normal((B, c0) + tuple(s // 2 for s in vol)).astype(np.float32)
+    x1 = rng.standard_normal((B, c1) + vol).astype(np.float32) if c1 else None
+    w = (rng.standard_normal((cout, c0 + c1, 3, 3, 3)) / np.sqrt(27 * (c0 + c1))).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    gx0, gx1, gw, gb = G(x0), (G(x1) if c1 else None), G(w), G(bias)
+    y = torch.empty((B, cout) + vol, device="cuda")
+    D, H, W = vol
+    V = D * H * W
+    os.environ.setdefault("VXM_CONV_WIDE_MIN_TILES", "1")          # read once per process: harmless if already loaded
+    ok = _lib.lib().vxm_conv3d_k3_up_ok(gx0.data_ptr(), c0, gx0[0].numel(), gx1.data_ptr() if c1 else None, c1, c1 * V, y.data_ptr(), cout, B, D, H, W)
+    VF.conv_forward(gx0, c0, gx0[0].numel(), True, gx1, c1, c1 * V, gw, gb, y, cout * V, cout, 0.2, B, D, H, W)
+    xin = torch.nn.functional.interpolate(torch.from_numpy(x0).double(), scale_factor=2, mode="nearest")
+    if c1:
+        xin = torch.cat([xin, torch.from_numpy(x1).double()], 1)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv3d(xin, torch.from_numpy(w).double(), torch.from_numpy(bias).double(), padding=1), 0.2)
+    assert rel_l2(N(y), ref.numpy()) < 1e-5, "collapsed path used: %s" % bool(ok)
+
+
 def test_conv_bwd_weight_bitwise_deterministic(vxm):
     """The backward-weight path has a fixed summation order: repeated launches on the same inputs must agree
     bit for bit (a race in the tile hand-over or the partial reduction would show here)."""
@@ -280,7 +307,7 @@ def test_conv_wide_forward_kernel_on_small_volumes_in_subprocess():
     env = dict(os.environ, VXM_CONV_WIDE_MIN_TILES="1")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
-                        "-k", "conv_block_vs_oracle or unet_vs_oracle or vxm_dense_golden"],
+                        "-k", "conv_block_vs_oracle or unet_vs_oracle or vxm_dense_golden or collapsed_weights"],
                        env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 

@@ -34,6 +34,11 @@ LAYERS = [
     ("rem2", (16, False, 0), 16, 0, 0.2),
     ("flow", (16, False, 0), 3, 0, 1.0),
 ]
+# synthetic single-segment layers for kernel studies (only with --only)
+EXTRA = [
+    ("up32", (32, True, 0), 32, 0, 0.2),       # pure x2-upsampled input: the collapsed-weight path alone
+    ("sk16", (16, False, 0), 32, 0, 0.2),      # the skip segment of rem0 alone
+]
 
 
 def timed(fn, iters):
@@ -69,8 +74,8 @@ def main():
     rows = []
     tot = {"fwd": 0.0, "bwd_data": 0.0, "bwd_weight": 0.0}
     totf = {"fwd": 0.0, "bwd_data": 0.0, "bwd_weight": 0.0}
-    for name, (c0, up0, c1), cout, lvl, slope in LAYERS:
-        if only and name not in only:
+    for name, (c0, up0, c1), cout, lvl, slope in LAYERS + EXTRA:
+        if (only and name not in only) or (not only and name in [e[0] for e in EXTRA]):
             continue
         D, H, W = (s >> lvl for s in shape)
         V = D * H * W

@@ -481,6 +481,316 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
 }
 
 // ------------------------------------------------------------------------------------------
+// forward kernel for cat([upsample2(x0), x1]) inputs with the upsampled segment at LOW resolution cost
+// ------------------------------------------------------------------------------------------
+// A 3x3x3 conv over a nearest-x2-upsampled tensor touches, per axis, only 2 distinct low-resolution inputs: for an
+// output coordinate o = 2m + p the taps {-1,0,+1} land on low-res indices (m-1, m, m) for p = 0 and (m, m, m+1) for
+// p = 1.  Summing the weights that share an input ("collapsed" 2x2x2 kernels, one per output parity (pd,ph,pw)):
+//     y[co, o] += sum_{ci in seg 0} sum_{j in {0,1}^3} Wc[p(o)][co,ci,j] * x0[ci, m(o) + j - 1 + p(o)]
+// does the upsampled segment with 8 instead of 27 MACs per (ci, co, voxel) -- 3.4x fewer MFMAs for 2/3 of the
+// input channels of the largest layer -- and reads x0 at its own resolution.  Border behaviour is unchanged: low-res
+// index -1 / M is exactly the zero padding of the upsampled volume.  (Weights are pre-summed, so the result differs
+// from the tap-by-tap sum by fp32 rounding only: within the conv tolerance of DESIGN.md §2.)
+// An MFMA's 16 voxel columns must share the parity class (they share the A = weight fragment): with the 8x4x16 tile of
+// k_conv3d_k3_t8 (wave = depth slice -> pd), a wave's four N-tiles are (ph, pw) in {0,1}^2, lane n holding voxel
+// (row ph + 2 (n >> 3), w = 2 (n & 7) + pw).  Segment 1 (the skip connection, full resolution) runs the regular 27-tap
+// loop on the same accumulators; its LDS rows are de-interleaved by column parity ([even cols | odd cols]) so that the
+// stride-2 voxel pattern reads consecutive words.
+constexpr int TU_RS = 24;                               // seg-1 row: [even block 12 | odd block 12]
+constexpr int TU_PS1 = (T8_TD + 2) * HH * TU_RS + 8;    // 1448 = 8 mod 32
+constexpr int TU_PSL = 6 * 4 * 16 + 8;                  // low-res plane [6][4][16] -> 392 = 8 mod 32
+constexpr int TU_CK0 = 4;                               // segment-0 channels per chunk (one k-step)
+
+template <int NCT> constexpr int tu_wc_floats() { return 8 * 8 * NCT * 64; }          // collapsed weights of a seg-0 chunk
+template <int NCT> constexpr int tu_w1_floats() { return 27 * 2 * NCT * 64; }         // packed weights of a seg-1 chunk
+template <int NCT> constexpr int tu_s0_floats() { return TU_CK0 * TU_PSL + tu_wc_floats<NCT>(); }   // one seg-0 stage (X + weights)
+template <int NCT> constexpr int tu_lds_floats() {      // two seg-0 stages (double buffered) or one seg-1 stage
+    return (8 * TU_PS1 + tu_w1_floats<NCT>()) > 2 * tu_s0_floats<NCT>() ? (8 * TU_PS1 + tu_w1_floats<NCT>()) : 2 * tu_s0_floats<NCT>();
+}
+
+template <int NCT>
+__global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8u(const float* __restrict__ x0, long long bs0, int C0, const float* __restrict__ x1,
+                                                               long long bs1, int C1, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                               float* __restrict__ y, long long y_bs, int Cout, float act_slope,
+                                                               int B, int D, int H, int W) {
+    VXM_DYN_SMEM(float, smem);
+    constexpr int WIT = (tu_wc_floats<NCT>() / 4 + T8_THREADS - 1) / T8_THREADS;       // >= the seg-1 chunk's pieces as well
+    static_assert(tu_w1_floats<NCT>() <= tu_wc_floats<NCT>(), "weight staging registers sized by the seg-0 chunk");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, n = lane & 15;
+    const int Q0 = (C0 + TU_CK0 - 1) / TU_CK0, Q1 = (C1 + 7) / 8, Q = Q0 + Q1;
+
+    const int nw = (W + TW - 1) / TW, nh = (H + TH - 1) / TH, nd = (D + T8_TD - 1) / T8_TD;
+    const int ntiles = B * nd * nh * nw;
+    int tile = blockIdx.x;
+    if (ntiles >= 64) {                              // XCD-contiguous tile numbering, as k_conv3d_k3_t8
+        const int x = tile & 7, j = tile >> 3;
+        const int lo = (int)((long long)ntiles * x / 8), hi = (int)((long long)ntiles * (x + 1) / 8);
+        tile = lo + j;
+        if (tile >= hi) return;
+    } else if (tile >= ntiles) {
+        return;
+    }
+    const int tw = tile % nw; int tq = tile / nw;
+    const int th = tq % nh; tq /= nh;
+    const int td = tq % nd; const int b = tq / nd;
+    const int d0 = td * T8_TD, h0 = th * TH, w0 = tw * TW;
+    const int g = blockIdx.y;
+
+    const int V = D * H * W;
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1, Vl = Dl * Hl * Wl;
+    const __amdgpu_buffer_rsrc_t r0 = vxm_rsrc(x0 + (size_t)b * bs0, (unsigned)C0 * (unsigned)Vl * 4u);
+    const __amdgpu_buffer_rsrc_t r1 = vxm_rsrc(C1 ? x1 + (size_t)b * bs1 : x0, (unsigned)C1 * (unsigned)V * 4u);
+
+    // ---- staging roles.  Segment 1: as k_conv3d_k3_t8 (wave w stages channel w of the chunk).  The per-lane offsets are
+    // recomputed per chunk (a few dozen VALU against >= 128 MFMAs) instead of living in 10 VGPRs: the kernel sits at the
+    // 128-register limit of 4 waves / SIMD.
+    const int lq = lane & 3, lr4 = lane >> 2, lr2 = lane >> 1, hside = lane & 1;
+    auto off_interior = [&](int j) __attribute__((always_inline)) -> int {
+        const int rr = 16 * j + lr4;
+        const int gd = d0 - 1 + rr / HH, gh = h0 - 1 + rr % HH, gw = w0 + 4 * lq;
+        const bool ok = rr < (T8_TD + 2) * HH && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw < W;
+        return ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB;
+    };
+    auto off_halo = [&](int j) __attribute__((always_inline)) -> int {
+        const int rr = 32 * j + lr2;
+        const int gd = d0 - 1 + rr / HH, gh = h0 - 1 + rr % HH, gw = hside ? w0 + TW : w0 - 1;
+        const bool ok = rr < (T8_TD + 2) * HH && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        return ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB;
+    };
+    // LDS positions of a seg-1 row piece: columns c0..c0+3 (c0 = 4 lq) -> (col + 1) = 4 lq + 1..4: the odd ones go to the odd
+    // block at [12 + 2 lq, +1], the even ones to the even block (shifted by one word) at [2 lq + 2, +1]: two aligned b64 stores
+    const int s1_odd = lr4 * TU_RS + 12 + 2 * lq, s1_even = lr4 * TU_RS + 2 * lq + 2;
+    const int s1_halo = lr2 * TU_RS + (hside ? 20 : 1);          // col 16 -> odd index 8; col -1 -> even index 0 (+1 shift)
+    // Segment 0 (low resolution): slot = tid + 512 k (< 960) -> channel c = slot / 240, (dl, hl, wl) of the [6][4][10] region
+    auto low_slot = [&](int k, int& voff, int& lds) __attribute__((always_inline)) {
+        const int slot = tid + T8_THREADS * k;
+        const int c = slot / 240, r = slot - c * 240, dl = r / 40, hl = (r % 40) / 10, wl = r % 10;
+        const int gd = (d0 >> 1) - 1 + dl, gh = (h0 >> 1) - 1 + hl, gw = (w0 >> 1) - 1 + wl;
+        const bool ok = slot < 960 && (unsigned)gd < (unsigned)Dl && (unsigned)gh < (unsigned)Hl && (unsigned)gw < (unsigned)Wl;
+        voff = ok ? (c * Vl + (gd * Hl + gh) * Wl + gw) << 2 : VXM_OOB;        // channel of the chunk in the per-lane offset
+        lds = slot < 960 ? c * TU_PSL + (dl * 4 + hl) * 16 + wl : -1;
+    };
+
+    f32x4 acc[NCT][4];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 xi[4];
+    float xh[2];
+    f32x4 wv[WIT];
+    float* const Xs = smem;
+    auto wchunk_base = [&](int q) __attribute__((always_inline)) -> size_t {       // packed layout: [g][Q0 collapsed chunks][Q1 regular chunks]
+        const size_t per_g = (size_t)Q0 * tu_wc_floats<NCT>() + (size_t)Q1 * tu_w1_floats<NCT>();
+        return (size_t)g * per_g + (q < Q0 ? (size_t)q * tu_wc_floats<NCT>() : (size_t)Q0 * tu_wc_floats<NCT>() + (size_t)(q - Q0) * tu_w1_floats<NCT>());
+    };
+    auto load_chunk = [&](int q) __attribute__((always_inline)) {
+        if (q < Q0) {                                 // low-resolution chunk: 4 channels x [6][4][10]
+            const int soff = q * TU_CK0 * Vl * 4;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                int vo, ld;
+                low_slot(k, vo, ld);
+                // channels beyond C0 in the last chunk: offset beyond num_records -> 0.0 (descriptor covers C0 planes)
+                xh[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, vo, soff, 0));
+            }
+        } else {
+            const int cg = (q - Q0) * 8 + wave;       // channel of segment 1 staged by this wave
+            if (cg < C1) {
+                const int soff = cg * V * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1, off_interior(j), soff, 0));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) xh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, off_halo(j), soff, 0));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xi[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                xh[0] = xh[1] = 0.0f;
+            }
+        }
+        const unsigned wbytes = (q < Q0 ? tu_wc_floats<NCT>() : tu_w1_floats<NCT>()) * 4u;
+        const __amdgpu_buffer_rsrc_t rw = vxm_rsrc(wp + wchunk_base(q), wbytes);
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            wv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + T8_THREADS * it) * 16, 0, 0));
+    };
+    auto store_chunk = [&](int q) __attribute__((always_inline)) {
+        float* Ws;
+        int wcount;
+        if (q < Q0) {
+            float* const X0 = smem + (q & 1) * tu_s0_floats<NCT>();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                int vo, ld;
+                low_slot(k, vo, ld);
+                if (ld >= 0) X0[ld] = xh[k];
+            }
+            Ws = X0 + TU_CK0 * TU_PSL;
+            wcount = tu_wc_floats<NCT>() / 4;
+        } else {
+            float* dst = smem + tu_w1_floats<NCT>() + wave * TU_PS1;      // seg-1 stage: [weights][X] (all operand offsets < 64 KB)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < 3 || lane < 48) {
+                    *reinterpret_cast<f32x2*>(dst + 16 * j * TU_RS + s1_odd) = (f32x2){xi[j].x, xi[j].z};
+                    *reinterpret_cast<f32x2*>(dst + 16 * j * TU_RS + s1_even) = (f32x2){xi[j].y, xi[j].w};
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                if (j < 1 || lane < 56) dst[32 * j * TU_RS + s1_halo] = xh[j];
+            Ws = smem;
+            wcount = tu_w1_floats<NCT>() / 4;
+        }
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = tid + T8_THREADS * it;
+            if (i < wcount) reinterpret_cast<f32x4*>(Ws)[i] = wv[it];
+        }
+    };
+
+    // lane parts of the B-operand addresses
+    const int pd = wave & 1;
+    const int b1base = kq * TU_PS1 + (n & 7) + 2 * TU_RS * (n >> 3) + wave * HH * TU_RS;
+    const int b0base = kq * TU_PSL + (n & 7) + 16 * (n >> 3) + ((wave >> 1) + pd) * 64;
+    const int a0base = pd * 4 * 8 * NCT * 64 + lane;
+
+    // Pipeline invariant at the top of iteration q: chunk q is in LDS, chunk q+1 (if any) is in registers.  The small seg-0
+    // stages are double buffered in LDS (the next one is stored while this one computes: one barrier per chunk); the
+    // large seg-1 stage is single buffered (store between two barriers).
+    load_chunk(0);
+    store_chunk(0);
+    if (Q > 1) load_chunk(1);
+    __syncthreads();
+    for (int q = 0; q < Q; ++q) {
+        if (q < Q0) {
+            if (q + 1 < Q0) {                       // next stage -> the other seg-0 buffer (its readers passed the last barrier)
+                store_chunk(q + 1);
+                if (q + 2 < Q) load_chunk(q + 2);
+            }
+            // ---- collapsed taps: 8 j x 4 N-tiles (ph, pw), one k-step (4 channels)
+            const float* X0 = smem + (q & 1) * tu_s0_floats<NCT>();
+            const float* Wc = X0 + TU_CK0 * TU_PSL;
+            float a[2][NCT], bb[2];
+            auto fetch = [&](int st, float (&af)[NCT], float& bf) __attribute__((always_inline)) {
+                const int j = st >> 2, nt = st & 3, ph = nt >> 1, pw = nt & 1;
+                const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) af[ct] = Wc[a0base + (((ph * 2 + pw) * 8 + j) * NCT + ct) * 64];
+                bf = X0[b0base + jd * 64 + (jh + ph) * 16 + jw + pw];
+            };
+            fetch(0, a[0], bb[0]);
+#pragma unroll
+            for (int st = 0; st < 32; ++st) {
+                if (st + 1 < 32) fetch(st + 1, a[(st + 1) & 1], bb[(st + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[ct][st & 3] = vxm_mfma16(a[st & 1][ct], bb[st & 1], acc[ct][st & 3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // ---- regular 27 taps x 2 k-steps on the de-interleaved rows
+            const float* Ws = smem;
+            const float* X1 = smem + tu_w1_floats<NCT>();
+            float a[2][NCT], bv[2][4];
+            auto fetch = [&](int st, float (&af)[NCT], float (&bf)[4]) __attribute__((always_inline)) {
+                const int t = st >> 1, s2 = st & 1;
+                const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) af[ct] = Ws[((t * 2 + s2) * NCT + ct) * 64 + lane];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int ph = nt >> 1, pw = nt & 1;
+                    const int e = (pw + kw) & 1, sh = (pw + kw) >> 1;
+                    bf[nt] = X1[b1base + s2 * 4 * TU_PS1 + (kd * HH + ph + kh) * TU_RS + (e ? 12 + sh : 1 + sh)];
+                }
+            };
+            fetch(0, a[0], bv[0]);
+#pragma unroll
+            for (int st = 0; st < 54; ++st) {
+                if (st + 1 < 54) fetch(st + 1, a[(st + 1) & 1], bv[(st + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[ct][nt] = vxm_mfma16(a[st & 1][ct], bv[st & 1][nt], acc[ct][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        if (q + 1 < Q && q + 1 >= Q0) {             // next is a seg-1 stage: it overlays everything, store it between barriers
+            store_chunk(q + 1);
+            if (q + 2 < Q) load_chunk(q + 2);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias + LeakyReLU; lane n of N-tile (ph, pw) is voxel (h0 + ph + 2 (n >> 3), w0 + 2 (n & 7) + pw)
+    const int d = d0 + wave;
+    if (d < D) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = (g * NCT + ct) * 16 + kq * 4 + j;
+                if (co >= Cout) continue;
+                const float bz = bias ? bias[co] : 0.0f;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int h = h0 + (nt >> 1) + 2 * (n >> 3), w = w0 + 2 * (n & 7) + (nt & 1);
+                    float v = acc[ct][nt][j] + bz;
+                    v = v > 0.0f ? v : v * act_slope;
+                    if (h < H && w < W) y[(size_t)b * y_bs + (size_t)co * V + ((size_t)d * H + h) * W + w] = v;
+                }
+            }
+    }
+}
+
+// packed weights of k_conv3d_k3_t8u: per output group g, Q0 collapsed chunks [par 8][j 8][NCT][64] (segment-0 channel
+// 4 q + (lane >> 4)), then Q1 regular chunks [27][2][NCT][64] (segment-1 channel 8 q + 4 s + (lane >> 4)); co = (g NCT + ct) 16 + (lane & 15).
+// Per axis the collapsed tap j of parity p sums the kernel taps {p=0: j=0 -> {0}, j=1 -> {1,2};  p=1: j=0 -> {0,1}, j=1 -> {2}}.
+__global__ void __launch_bounds__(256) k_pack_weights_up(const float* __restrict__ w, float* __restrict__ wp, int C0, int C1, int Cout, int NCT,
+                                                         size_t elems) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elems) return;
+    const int Cin = C0 + C1, Q0 = (C0 + TU_CK0 - 1) / TU_CK0, Q1 = (C1 + 7) / 8;
+    const size_t wc = (size_t)8 * 8 * NCT * 64, w1 = (size_t)27 * 2 * NCT * 64, per_g = Q0 * wc + Q1 * w1;
+    const int g = (int)(i / per_g);
+    size_t r = i - (size_t)g * per_g;
+    float v = 0.0f;
+    if (r < Q0 * wc) {
+        const int q = (int)(r / wc); r -= (size_t)q * wc;
+        const int lane = r % 64; r /= 64;
+        const int ct = r % NCT; r /= NCT;
+        const int j = r % 8; const int par = (int)(r / 8);
+        const int co = (g * NCT + ct) * 16 + (lane & 15), ci = q * TU_CK0 + (lane >> 4);
+        if (co < Cout && ci < C0) {
+            const int p[3] = {(par >> 2) & 1, (par >> 1) & 1, par & 1}, jj[3] = {(j >> 2) & 1, (j >> 1) & 1, j & 1};
+            int lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) {
+                if (p[a] == 0) { lo[a] = jj[a] ? 1 : 0; hi[a] = jj[a] ? 2 : 0; }
+                else { lo[a] = jj[a] ? 2 : 0; hi[a] = jj[a] ? 2 : 1; }
+            }
+            const float* wk = w + ((size_t)co * Cin + ci) * 27;
+            for (int kd = lo[0]; kd <= hi[0]; ++kd)
+                for (int kh = lo[1]; kh <= hi[1]; ++kh)
+                    for (int kw = lo[2]; kw <= hi[2]; ++kw) v += wk[(kd * 3 + kh) * 3 + kw];
+        }
+    } else {
+        r -= Q0 * wc;
+        const int q = (int)(r / w1); r -= (size_t)q * w1;
+        const int lane = r % 64; r /= 64;
+        const int ct = r % NCT; r /= NCT;
+        const int s2 = r % 2; const int t = (int)(r / 2);
+        const int co = (g * NCT + ct) * 16 + (lane & 15), c1 = q * 8 + 4 * s2 + (lane >> 4);
+        if (co < Cout && c1 < C1) v = w[((size_t)co * Cin + C0 + c1) * 27 + t];
+    }
+    wp[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
 // forward conv with <= 4 output channels (the 16 -> 3 flow conv, networks.py:211,257)
 // ------------------------------------------------------------------------------------------
 // On the MFMA path 3 output channels occupy 3 of 16 rows.  Here the contraction runs on the vector ALUs instead:
@@ -1231,6 +1541,58 @@ int vxm_conv3d_k3_fwd_variant(const float* x0, int C0, int64_t x0_bstride, const
 int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
                                      const float* dz, int64_t dz_bstride, int Cout, int W) {
     return (bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W) ? 10 : 0) + (Cout <= 16 ? 1 : 2);     // NCT of the unswapped plan
+}
+
+int vxm_conv3d_k3_up_ok(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, float* y,
+                        int Cout, int B, int D, int H, int W) {
+    if (C0 <= 0 || C1 < 0 || Cout <= 0 || Cout > 32 && ((Cout + 47) / 48 * 48 < (Cout + 31) / 32 * 32)) return 0;
+    const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    return (W & 3) == 0 && (D & 1) == 0 && (H & 1) == 0 && (C1 == 0 || al16(x1)) && (x1_bstride & 3) == 0 && x0 && y &&
+           (long long)C0 * (D / 2) * (H / 2) * (W / 2) < (1ll << 29) && tiles8 >= wide_min_tiles() && tiles8 < (1ll << 30) &&
+           !bw_force_generic() && (x0_bstride >= 0);
+}
+
+// 16 output channels per block: the 2-tile instance needs ~150 VGPRs (both MFMA loops + two kinds of staging registers)
+// and spills at the 128 that two 8-wave blocks per CU allow; two 1-tile blocks re-read X but do not spill.
+static int up_nct(int Cout) { (void)Cout; return 1; }
+
+size_t vxm_conv3d_k3_up_packed_elems(int C0, int C1, int Cout) {
+    if (C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
+    const int NCT = up_nct(Cout), G = (Cout + 16 * NCT - 1) / (16 * NCT);
+    const size_t Q0 = (C0 + TU_CK0 - 1) / TU_CK0, Q1 = (C1 + 7) / 8;
+    return (size_t)G * (Q0 * 8 * 8 * NCT * 64 + Q1 * 27 * 2 * NCT * 64);
+}
+
+int vxm_conv3d_k3_up_pack_weights(const float* w, float* wpacked, int C0, int C1, int Cout, void* stream) {
+    VXM_REQUIRE(w && wpacked, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_up_pack_weights: null pointer");
+    VXM_REQUIRE(C0 > 0 && C1 >= 0 && Cout > 0, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_up_pack_weights: C0=%d C1=%d Cout=%d", C0, C1, Cout);
+    const size_t elems = vxm_conv3d_k3_up_packed_elems(C0, C1, Cout);
+    hipLaunchKernelGGL(k_pack_weights_up, dim3(vxm_blocks((long long)elems, 256)), dim3(256), 0, VXM_STREAM(stream), w, wpacked, C0, C1, Cout,
+                       up_nct(Cout), elems);
+    return vxm_check_launch("vxm_conv3d_k3_up_pack_weights");
+}
+
+int vxm_conv3d_k3_up_fwd(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* wpacked,
+                         const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope, int B, int D, int H, int W, void* stream) {
+    if (int e = check_conv("vxm_conv3d_k3_up_fwd", C0, C1, 1, Cout, B, D, H, W)) return e;
+    VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_up_fwd: null pointer");
+    VXM_REQUIRE(vxm_conv3d_k3_up_ok(x0, C0, x0_bstride, x1, C1, x1_bstride, y, Cout, B, D, H, W) && al16(wpacked), VXM_ERR_UNSUPPORTED,
+                "vxm_conv3d_k3_up_fwd: operands do not qualify (see vxm_conv3d_k3_up_ok); use vxm_conv3d_k3_fwd with x0_up = 1");
+    const int NCT = up_nct(Cout), G = (Cout + 16 * NCT - 1) / (16 * NCT);
+    const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    static bool opt_in = false;
+    if (!opt_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_t8u<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_t8u<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        opt_in = true;
+    }
+    const dim3 grid((unsigned)((tiles8 + 7) / 8 * 8), G);
+#define TU_LAUNCH(NCT_) hipLaunchKernelGGL((k_conv3d_k3_t8u<NCT_>), grid, dim3(T8_THREADS), sizeof(float) * (size_t)tu_lds_floats<NCT_>(), \
+        VXM_STREAM(stream), x0, (long long)x0_bstride, C0, x1, (long long)x1_bstride, C1, wpacked, bias, y, (long long)y_bstride, Cout, act_slope, B, D, H, W)
+    if (NCT == 1) TU_LAUNCH(1);
+    else TU_LAUNCH(2);
+#undef TU_LAUNCH
+    return vxm_check_launch("vxm_conv3d_k3_up_fwd");
 }
 
 int vxm_conv3d_k3_fewout_ok(const float* x, int64_t x_bstride, float* y, int64_t y_bstride, int Cin, int Cout, int W) {

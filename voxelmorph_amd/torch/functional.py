@@ -269,6 +269,14 @@ def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B,
         with _prof.region("k_conv3d_k3_fewout<%d>" % cout, flops=2.0 * 27 * c0 * cout * B * D * H * W):
             call("vxm_conv3d_k3_fewout_fwd", ptr(x0), c0, bs0, ptr(_c(w)), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W, stream())
         return
+    if up0 and _lib.lib().vxm_conv3d_k3_up_ok(ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(y), cout, B, D, H, W):
+        # upsampled segment at low-resolution cost: collapsed 2x2x2 weights per output parity (conv.hip: k_conv3d_k3_t8u)
+        wp = torch.empty(_lib.lib().vxm_conv3d_k3_up_packed_elems(c0, c1, cout), dtype=w.dtype, device=w.device)
+        call("vxm_conv3d_k3_up_pack_weights", ptr(_c(w)), ptr(wp), c0, c1, cout, stream())
+        with _prof.region("k_conv3d_k3_t8u<1>", flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+            call("vxm_conv3d_k3_up_fwd", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs, cout, float(slope),
+                 B, D, H, W, stream())
+        return
     conv_launch(x0, c0, bs0, up0, x1, c1, bs1, pack_weights(w, False), bias, y, ybs, cout, slope, None, 0, 1.0, B, D, H, W)
 
 
