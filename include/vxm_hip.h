@@ -98,6 +98,17 @@ int vxm_conv3d_k3_up_pack_weights(const float* w, float* wpacked, int C0, int C1
 int vxm_conv3d_k3_up_fwd(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
                          const float* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope,
                          int B, int D, int H, int W, void* stream);
+/* Backward-data of the upsampled segment of such a ConvBlock, straight to the HALF-resolution gradient:
+ * gx_low[b,ci,m] = LeakyReLU'(mask_low[b,ci,m]) * sum_co sum_{delta in {-1,0,1,2}^3} Wt[delta][ci,co] dz[b,co,2m+delta]
+ * (a stride-2 4x4x4 conv with per-axis summed kernel taps = conv backward + upsample_nearest3d_backward in one pass).
+ * dz [B,Cout,D,H,W]; w [Cout,Cin,3,3,3] (reference layout; the first C0 input channels are the upsampled segment);
+ * wpacked: scratch of vxm_conv3d_k3_up_bwd_low_packed_elems(C0,Cout) floats (filled by the call); gx_low, mask_low
+ * [B,C0,D/2,H/2,W/2] (mask nullable). */
+int vxm_conv3d_k3_up_bwd_low_ok(const float* dz, int64_t dz_bstride, int C0, int Cout, int B, int D, int H, int W);
+size_t vxm_conv3d_k3_up_bwd_low_packed_elems(int C0, int Cout);
+int vxm_conv3d_k3_up_bwd_low(const float* dz, int64_t dz_bstride, int Cout, const float* w, int C0, int Cin, float* wpacked,
+                             float* gx_low, int64_t gx_bstride, const float* mask_low, int64_t mask_bstride, float mask_slope,
+                             int B, int D, int H, int W, void* stream);
 /* Forward conv with 1..4 output channels (the 16 -> 3 flow conv, networks.py:211,257) on the vector ALUs: x [B,Cin,D,H,W],
  * w [Cout,Cin,3,3,3] in the REFERENCE layout (no packing), y [B,Cout,D,H,W]; act_slope = 1: no activation.
  * vxm_conv3d_k3_fewout_ok tells whether the operands qualify (Cout <= 4, W % 4 == 0, 16-byte aligned). */

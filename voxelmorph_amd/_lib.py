@@ -33,6 +33,9 @@ SIGNATURES = {
     "vxm_conv3d_k3_up_packed_elems": [_I, _I, _I],
     "vxm_conv3d_k3_up_pack_weights": [_P, _P, _I, _I, _I, _P],
     "vxm_conv3d_k3_up_fwd": [_P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _I, _F, _I, _I, _I, _I, _P],
+    "vxm_conv3d_k3_up_bwd_low_ok": [_P, _L, _I, _I, _I, _I, _I, _I],
+    "vxm_conv3d_k3_up_bwd_low_packed_elems": [_I, _I],
+    "vxm_conv3d_k3_up_bwd_low": [_P, _L, _I, _P, _I, _I, _P, _P, _L, _P, _L, _F, _I, _I, _I, _I, _P],
     "vxm_conv3d_k3_fewout_ok": [_P, _L, _P, _L, _I, _I, _I],
     "vxm_conv3d_k3_fewout_fwd": [_P, _I, _L, _P, _P, _P, _L, _I, _F, _I, _I, _I, _I, _P],
     "vxm_conv3d_k3_fwd_variant": [_P, _I, _L, _P, _I, _L, _P, _I, _I, _I, _I, _I],
@@ -58,6 +61,7 @@ _RESTYPES = {
     "vxm_last_error_string": _c.c_char_p,
     "vxm_conv3d_k3_packed_elems": _S,
     "vxm_conv3d_k3_up_packed_elems": _S,
+    "vxm_conv3d_k3_up_bwd_low_packed_elems": _S,
     "vxm_conv3d_k3_bwd_weight_workspace_bytes": _S,
 }
 

@@ -791,6 +791,180 @@ __global__ void __launch_bounds__(256) k_pack_weights_up(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// backward-data of the upsampled segment, straight to the LOW-resolution gradient
+// ------------------------------------------------------------------------------------------
+// d L / d x0[ci, m] = sum_co sum_{delta in {-1,0,1,2}^3} Wt[delta][ci,co] * dZ[co, 2 m + delta], with, per axis,
+// Wt(-1) = w[2], Wt(0) = w[1] + w[2], Wt(1) = w[0] + w[1], Wt(2) = w[0]  (the adjoint of the collapsed forward above):
+// a stride-2, 4x4x4-tap conv from the full-resolution dZ to the half-resolution input gradient.  It replaces the
+// full-resolution backward-data of those channels (27 taps at 8x the voxels) PLUS upsample_nearest3d_backward (the
+// 2x2x2 child sum is inside the taps), and the LeakyReLU' of the decoder block is applied in the epilogue.
+// Implicit GEMM: M = 16 NCT input channels, N = 16 low-res voxels of a W row, K = 4 output channels of one tap.
+// Block = 8 waves, low-res tile 2(D) x 4(H) x 16(W) (wave = one row); chunk = 4 output channels: dZ region
+// [4][6][10][2 x 20] (rows de-interleaved by column parity, so the stride-2 columns of a tap are consecutive words)
+// + the 64 taps' weights.
+constexpr int DL_RS = 40, DL_ROWS = 6 * 10, DL_PS = DL_ROWS * DL_RS + 16;         // plane 2416 = 16 mod 32 (the two channel groups of a read hit disjoint banks)
+template <int NCT> constexpr int dl_w_floats() { return 64 * NCT * 64; }
+template <int NCT> constexpr int dl_lds_floats() { return dl_w_floats<NCT>() + 4 * DL_PS; }
+
+template <int NCT>
+__global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_dlow(const float* __restrict__ dz, long long dz_bs, int Cout, const float* __restrict__ wp,
+                                                                float* __restrict__ gx, long long gx_bs, int C0, const float* __restrict__ mask,
+                                                                long long mask_bs, float mask_slope, int B, int D, int H, int W) {
+    VXM_DYN_SMEM(float, smem);
+    constexpr int WIT = dl_w_floats<NCT>() / 4 / T8_THREADS;           // 2 NCT float4 per thread
+    float* const Ws = smem;                                           // [64 taps][NCT][64]
+    float* const Zs = smem + dl_w_floats<NCT>();                      // [4][DL_PS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, n = lane & 15;
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1, Vl = Dl * Hl * Wl, V = D * H * W;
+    const int nw = (Wl + 15) / 16, nh = (Hl + 3) / 4, nd = (Dl + 1) / 2;
+    int t = blockIdx.x;
+    const int tw = t % nw; t /= nw;
+    const int th = t % nh; t /= nh;
+    const int td = t % nd; const int b = t / nd;
+    const int d0 = td * 2, h0 = th * 4, w0 = tw * 16;                 // low-res tile origin
+    const int g = blockIdx.y;
+    const int Q = (Cout + 3) / 4;
+    const __amdgpu_buffer_rsrc_t rz = vxm_rsrc(dz + (size_t)b * dz_bs, (unsigned)Cout * (unsigned)V * 4u);
+
+    // staging roles: dZ region rows r = (dz 0..5, hy 0..9) <-> full-res (2 d0 - 1 + dz, 2 h0 - 1 + hy), columns 2 w0 - 1 .. 2 w0 + 32.
+    // interior slot = tid + 512 k (< 1920): channel c = slot / 480, row = (slot % 480) / 8, columns 4 q..4 q+3 (q = slot & 7)
+    auto zslot = [&](int k, int& voff, int& lds_odd, int& lds_even) __attribute__((always_inline)) {
+        const int slot = tid + T8_THREADS * k;
+        const int c = slot / 480, r = (slot % 480) >> 3, q = slot & 7;
+        const int gd = 2 * d0 - 1 + r / 10, gh = 2 * h0 - 1 + r % 10, gw = 2 * w0 + 4 * q;
+        const bool ok = slot < 1920 && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw < W;
+        voff = ok ? (c * V + (gd * H + gh) * W + gw) << 2 : VXM_OOB;
+        // (col + 1) = 4 q + 1..4: odd ones -> odd block [20 + 2 q, +1], even ones -> even block (shifted one word) [2 q + 2, +1]
+        lds_odd = slot < 1920 ? c * DL_PS + r * DL_RS + 20 + 2 * q : -1;
+        lds_even = c * DL_PS + r * DL_RS + 2 * q + 2;
+    };
+    auto hslot = [&](int& voff, int& lds) __attribute__((always_inline)) {        // 480 halo elements: one per thread
+        const int c = tid / 120, r = (tid % 120) >> 1, side = tid & 1;
+        const int gd = 2 * d0 - 1 + r / 10, gh = 2 * h0 - 1 + r % 10, gw = side ? 2 * w0 + 32 : 2 * w0 - 1;
+        const bool ok = tid < 480 && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        voff = ok ? (c * V + (gd * H + gh) * W + gw) << 2 : VXM_OOB;
+        lds = tid < 480 ? c * DL_PS + r * DL_RS + (side ? 20 + 16 : 1) : -1;      // col 32 -> odd index 16; col -1 -> even index 0 (+1)
+    };
+
+    f32x4 acc[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 xi[4];
+    float xh;
+    f32x4 wv[WIT];
+    auto load_chunk = [&](int q) __attribute__((always_inline)) {
+        const int soff = q * 4 * V * 4;          // channels beyond Cout in the last chunk fall outside num_records -> 0
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int vo, lo, le;
+            zslot(k, vo, lo, le);
+            xi[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, vo, soff, 0));
+        }
+        int vo, ld;
+        hslot(vo, ld);
+        xh = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rz, vo, soff, 0));
+        const __amdgpu_buffer_rsrc_t rw = vxm_rsrc(wp + ((size_t)g * Q + q) * dl_w_floats<NCT>(), dl_w_floats<NCT>() * 4u);
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            wv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + T8_THREADS * it) * 16, 0, 0));
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int vo, lo, le;
+            zslot(k, vo, lo, le);
+            if (lo >= 0) {
+                *reinterpret_cast<f32x2*>(Zs + lo) = (f32x2){xi[k].x, xi[k].z};
+                *reinterpret_cast<f32x2*>(Zs + le) = (f32x2){xi[k].y, xi[k].w};
+            }
+        }
+        int vo, ld;
+        hslot(vo, ld);
+        if (ld >= 0) Zs[ld] = xh;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) reinterpret_cast<f32x4*>(Ws)[tid + T8_THREADS * it] = wv[it];
+    };
+
+    // B operand: lane (kq = output channel of the chunk, n = low-res column): Zs[kq][row(2 dl + dd, 2 hl + dh)][parity block][n + shift]
+    const int dl = wave >> 2, hl = wave & 3;
+    const int bbase = kq * DL_PS + ((2 * dl) * 10 + 2 * hl) * DL_RS + n;
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    for (int q = 0; q < Q; ++q) {
+        if (q + 1 < Q) load_chunk(q + 1);
+        float a[2][NCT], bb[2];
+        auto fetch = [&](int tap, float (&af)[NCT], float& bf) __attribute__((always_inline)) {
+            const int ed = tap >> 4, eh = (tap >> 2) & 3, ew = tap & 3;       // delta + 1 in {0,1,2,3} per axis
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) af[ct] = Ws[(tap * NCT + ct) * 64 + lane];
+            // column 2 n + (ew - 1) -> (col + 1) = 2 n + ew: parity ew & 1, index n + (ew >> 1) (+1 word shift in the even block)
+            bf = Zs[bbase + (ed * 10 + eh) * DL_RS + ((ew & 1) ? 20 + (ew >> 1) : 1 + (ew >> 1))];
+        };
+        fetch(0, a[0], bb[0]);
+#pragma unroll
+        for (int tap = 0; tap < 64; ++tap) {
+            if (tap + 1 < 64) fetch(tap + 1, a[(tap + 1) & 1], bb[(tap + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) acc[ct] = vxm_mfma16(a[tap & 1][ct], bb[tap & 1], acc[ct]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (q + 1 < Q) {
+            __syncthreads();
+            store_chunk();
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: x LeakyReLU'(mask) (the decoder block's activation), NCDHW store at low resolution
+    const int od = d0 + dl, oh = h0 + hl, ow = w0 + n;
+    if (od < Dl && oh < Hl && ow < Wl) {
+        const size_t vox = ((size_t)od * Hl + oh) * Wl + ow;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ci = (g * NCT + ct) * 16 + kq * 4 + j;
+                if (ci >= C0) continue;
+                float v = acc[ct][j];
+                if (mask) v *= vxm_lrelu_grad(mask[(size_t)b * mask_bs + (size_t)ci * Vl + vox], mask_slope);
+                gx[(size_t)b * gx_bs + (size_t)ci * Vl + vox] = v;
+            }
+    }
+}
+
+// packed weights of k_conv3d_k3_dlow: [g][q][tap 64][NCT][64], lane -> (ci = (g NCT + ct) 16 + (lane & 15), co = 4 q + (lane >> 4));
+// tap = (ed, eh, ew), e = delta + 1; per axis the kernel taps summed: e=0 -> {2}, e=1 -> {1,2}, e=2 -> {0,1}, e=3 -> {0}.
+__global__ void __launch_bounds__(256) k_pack_weights_dlow(const float* __restrict__ w, float* __restrict__ wp, int C0, int Cin, int Cout, int NCT,
+                                                           size_t elems) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elems) return;
+    const int Q = (Cout + 3) / 4;
+    size_t r = i;
+    const int lane = r % 64; r /= 64;
+    const int ct = r % NCT; r /= NCT;
+    const int tap = r % 64; r /= 64;
+    const int q = r % Q; const int g = (int)(r / Q);
+    const int ci = (g * NCT + ct) * 16 + (lane & 15), co = 4 * q + (lane >> 4);
+    float v = 0.0f;
+    if (ci < C0 && co < Cout) {
+        const int e[3] = {tap >> 4, (tap >> 2) & 3, tap & 3};
+        int lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = e[a] == 0 ? 2 : (e[a] == 1 ? 1 : 0);
+            hi[a] = e[a] == 0 ? 2 : (e[a] == 1 ? 2 : (e[a] == 2 ? 1 : 0));
+        }
+        const float* wk = w + ((size_t)co * Cin + ci) * 27;
+        for (int kd = lo[0]; kd <= hi[0]; ++kd)
+            for (int kh = lo[1]; kh <= hi[1]; ++kh)
+                for (int kw = lo[2]; kw <= hi[2]; ++kw) v += wk[(kd * 3 + kh) * 3 + kw];
+    }
+    wp[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------
 // forward conv with <= 4 output channels (the 16 -> 3 flow conv, networks.py:211,257)
 // ------------------------------------------------------------------------------------------
 // On the MFMA path 3 output channels occupy 3 of 16 rows.  Here the contraction runs on the vector ALUs instead:
@@ -1593,6 +1767,46 @@ int vxm_conv3d_k3_up_fwd(const float* x0, int C0, int64_t x0_bstride, const floa
     else TU_LAUNCH(2);
 #undef TU_LAUNCH
     return vxm_check_launch("vxm_conv3d_k3_up_fwd");
+}
+
+static int dlow_nct(int C0) { return C0 <= 16 ? 1 : 2; }
+
+int vxm_conv3d_k3_up_bwd_low_ok(const float* dz, int64_t dz_bstride, int C0, int Cout, int B, int D, int H, int W) {
+    const long long tiles = (long long)B * ((D / 2 + 1) / 2) * ((H / 2 + 3) / 4) * ((W / 2 + 15) / 16);
+    return C0 > 0 && Cout > 0 && (W & 3) == 0 && (D & 1) == 0 && (H & 1) == 0 && al16(dz) && (dz_bstride & 3) == 0 &&
+           (long long)Cout * D * H * W < (1ll << 29) && tiles >= wide_min_tiles() && tiles < (1ll << 30) && !bw_force_generic();
+}
+
+size_t vxm_conv3d_k3_up_bwd_low_packed_elems(int C0, int Cout) {
+    if (C0 <= 0 || Cout <= 0) return 0;
+    const int NCT = dlow_nct(C0), G = (C0 + 16 * NCT - 1) / (16 * NCT), Q = (Cout + 3) / 4;
+    return (size_t)G * Q * 64 * NCT * 64;
+}
+
+int vxm_conv3d_k3_up_bwd_low(const float* dz, int64_t dz_bstride, int Cout, const float* w, int C0, int Cin, float* wpacked, float* gx_low,
+                             int64_t gx_bstride, const float* mask_low, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W,
+                             void* stream) {
+    if (int e = check_conv("vxm_conv3d_k3_up_bwd_low", C0, Cin - C0, 1, Cout, B, D, H, W)) return e;
+    VXM_REQUIRE(dz && w && wpacked && gx_low, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_up_bwd_low: null pointer");
+    VXM_REQUIRE(C0 <= Cin && vxm_conv3d_k3_up_bwd_low_ok(dz, dz_bstride, C0, Cout, B, D, H, W) && al16(wpacked), VXM_ERR_UNSUPPORTED,
+                "vxm_conv3d_k3_up_bwd_low: operands do not qualify (see vxm_conv3d_k3_up_bwd_low_ok)");
+    const int NCT = dlow_nct(C0), G = (C0 + 16 * NCT - 1) / (16 * NCT);
+    const size_t elems = vxm_conv3d_k3_up_bwd_low_packed_elems(C0, Cout);
+    hipLaunchKernelGGL(k_pack_weights_dlow, dim3(vxm_blocks((long long)elems, 256)), dim3(256), 0, VXM_STREAM(stream), w, wpacked, C0, Cin, Cout, NCT, elems);
+    static bool opt_in = false;
+    if (!opt_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_dlow<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_dlow<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        opt_in = true;
+    }
+    const long long tiles = (long long)B * ((D / 2 + 1) / 2) * ((H / 2 + 3) / 4) * ((W / 2 + 15) / 16);
+    const dim3 grid((unsigned)tiles, G);
+#define DL_LAUNCH(NCT_) hipLaunchKernelGGL((k_conv3d_k3_dlow<NCT_>), grid, dim3(T8_THREADS), sizeof(float) * (size_t)dl_lds_floats<NCT_>(), VXM_STREAM(stream), \
+        dz, (long long)dz_bstride, Cout, wpacked, gx_low, (long long)gx_bstride, C0, mask_low, (long long)mask_bstride, mask_slope, B, D, H, W)
+    if (NCT == 1) DL_LAUNCH(1);
+    else DL_LAUNCH(2);
+#undef DL_LAUNCH
+    return vxm_check_launch("vxm_conv3d_k3_up_bwd_low");
 }
 
 int vxm_conv3d_k3_fewout_ok(const float* x, int64_t x_bstride, float* y, int64_t y_bstride, int Cin, int Cout, int W) {

@@ -590,6 +590,26 @@ class UnetFn(torch.autograd.Function):
                 continue
             fuse = (not up0) and s1 is None and (not feeds_inputs) and len(plan.consumers[s0]) == 1 \
                 and plan.ops[plan.producer[s0]]["kind"] == "conv"
+            if up0 and plan.ops[plan.producer[s0]]["kind"] == "conv" and len(plan.consumers[s0]) == 1 and \
+                    _lib.lib().vxm_conv3d_k3_up_bwd_low_ok(ptr(dz), cout * V, c0, cout, B, D, H, W):
+                # upsampled segment: straight to the half-resolution gradient of the decoder block (stride-2 4x4x4 conv =
+                # conv backward + upsample_nearest3d_backward + leaky_relu_backward in one kernel, conv.hip: k_conv3d_k3_dlow)
+                pslope = plan.ops[plan.producer[s0]]["slope"]
+                lD, lH, lW = D // 2, H // 2, W // 2
+                dzl = torch.empty((B, c0, lD, lH, lW), dtype=dt, device=dev)
+                wpk = torch.empty(_lib.lib().vxm_conv3d_k3_up_bwd_low_packed_elems(c0, cout), dtype=dt, device=dev)
+                with _prof.region("k_conv3d_k3_dlow<%d>" % (1 if c0 <= 16 else 2), flops=2.0 * 27 * c0 * cout * B * V):
+                    call("vxm_conv3d_k3_up_bwd_low", ptr(dz), cout * V, cout, ptr(_c(w)), c0, cin, ptr(wpk), ptr(dzl), c0 * lD * lH * lW,
+                         ptr(T[s0]) if pslope != 1.0 else None, c0 * lD * lH * lW, float(pslope), B, D, H, W, stream())
+                DZ[s0] = dzl
+                if s1 is not None:                       # skip segment: regular backward-data of its channels only
+                    gxs = torch.empty((B, c1, D, H, W), dtype=dt, device=dev)
+                    conv_bwd_data(dz, cout, w[:, c0:].contiguous(), gxs, c1, None, 1.0, B, D, H, W)
+                    GS[s1] = (gxs, 0, c1 * V)
+                    if not any(plan.ops[m]["kind"] == "pool" for m in plan.consumers[s1]):
+                        g = GS.pop(s1)
+                        finish_conv_output(s1, g[0].view(-1)[g[1]:], g[2])
+                continue
             gx = torch.empty((B, cin, D, H, W), dtype=dt, device=dev)
             if fuse:   # dX * LeakyReLU'(y_prev) in the epilogue == DZ of the previous ConvBlock
                 pslope = plan.ops[plan.producer[s0]]["slope"]
