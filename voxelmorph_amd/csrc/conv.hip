@@ -1549,6 +1549,160 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_dma(ConvIn 
     bw_write_partial<NCT>(k, part, Cout, Cin, wave, lane, nslots, acc, bias, bsum);
 }
 
+// ---- backward-weight of the upsampled segment in collapsed form ----------------------------------------------------
+// gWc[p][j][co][ci] = sum_{o of parity p} dZ[co,o] x0[ci, (o >> 1) + j - 1 + p]  (p, j in {0,1}^3: 8 x 8 low-resolution taps
+// instead of 27 full-resolution ones: 8 instead of 27 MACs per channel pair and voxel), and afterwards
+// gW[co,ci,(kd,kh,kw)] = sum_p gWc[p][(j_pd(kd), j_ph(kh), j_pw(kw))]  with  j_0(k) = (k >= 1), j_1(k) = (k == 2).
+// Same block plan as k_conv3d_k3_bwd_weight_vec (16 waves, contiguous tile ranges, double-buffered LDS tile, one barrier
+// per tile).  Wave w owns parity p = w >> 1 and the taps j = 4 (w & 1) .. +3: its k-steps are the 8 groups of 4 voxels
+// of parity p in the 4x4x16 tile (d = pd + 2 dd, h = ph + 2 hh, w = pw + 2 (4 wh + k)), so all 16 waves work on disjoint
+// voxels of the same staged tile.  dZ rows are stored de-interleaved by column parity ([8 even | 8 odd]), x0 as its
+// [4][4][10] low-resolution neighbourhood.
+constexpr int BU_PZ = 258;                    // dZ plane [4][4][16] -> 2 mod 32
+constexpr int BU_PSL = 4 * 4 * 12 + 2;        // x0 plane [4][4][12] -> 194 = 2 mod 32
+template <int NCT> constexpr int bu_buf_floats() { return 16 * NCT * BU_PZ + BW_CKI * BU_PSL; }
+
+template <int NCT>
+__global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_up(const float* __restrict__ x0, long long bs0, int C0, const float* __restrict__ dz,
+                                                                       long long dz_bs, int Cout, float* __restrict__ part, int B, int D, int H,
+                                                                       int W, int Qc, int G) {
+    VXM_DYN_SMEM(float, smem);
+    constexpr int BUF = bu_buf_floats<NCT>();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, n = lane & 15;
+    const BwBlock k = bw_block(C0, NCT, B, D, H, W, Qc, G);
+    const int V = D * H * W;
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1, Vl = Dl * Hl * Wl;
+    const int par = wave >> 1, pd = par >> 2, ph = (par >> 1) & 1, pw = par & 1, jbase = 4 * (wave & 1);
+
+    f32x4 acc[4][NCT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging: wave w loads dZ planes NCT w + i (one dwordx4 per lane: row = lane >> 2, columns 4 (lane & 3)..+3) and the
+    // low-resolution plane of channel w (160 elements: 3 dwords per lane)
+    const int lq = lane & 3, lr4 = lane >> 2;
+    f32x4 zv[NCT];
+    float xl[3];
+    auto load_tile = [&](int tile) __attribute__((always_inline)) {
+        int sb, sd0, sh0, sw0;
+        tile_origin(tile, D, H, W, sb, sd0, sh0, sw0);
+        const __amdgpu_buffer_rsrc_t rz = vxm_rsrc(dz + (size_t)sb * dz_bs, (unsigned)Cout * (unsigned)V * 4u);
+        const __amdgpu_buffer_rsrc_t rx = vxm_rsrc(x0 + (size_t)sb * bs0, (unsigned)C0 * (unsigned)Vl * 4u);
+        const int zd = sd0 + (lr4 >> 2), zh = sh0 + (lr4 & 3), zw = sw0 + 4 * lq;
+        const int zvo = (zd < D && zh < H && zw < W) ? ((zd * H + zh) * W + zw) << 2 : VXM_OOB;
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) {
+            const int co = NCT * wave + i;
+            const bool uok = k.cog + co < Cout;
+            zv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, uok ? zvo : VXM_OOB, uok ? (k.cog + co) * V * 4 : 0, 0));
+        }
+        const int cg = k.c0 + wave;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int e = 64 * t + lane, dl = e / 40, hl = (e % 40) / 10, wl = e % 10;
+            const int gd = (sd0 >> 1) - 1 + dl, gh = (sh0 >> 1) - 1 + hl, gw = (sw0 >> 1) - 1 + wl;
+            const bool ok = e < 160 && wave < k.ckc && (unsigned)gd < (unsigned)Dl && (unsigned)gh < (unsigned)Hl && (unsigned)gw < (unsigned)Wl;
+            xl[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, ok ? ((gd * Hl + gh) * Wl + gw) << 2 : VXM_OOB, ok ? cg * Vl * 4 : 0, 0));
+        }
+    };
+    auto store_tile = [&](float* Zn, float* Xn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NCT; ++i) {            // row [8 even | 8 odd]: columns 4q, 4q+2 -> even[2q, 2q+1]; 4q+1, 4q+3 -> odd[2q, 2q+1]
+            float* zp = Zn + (NCT * wave + i) * BU_PZ + lr4 * 16 + 2 * lq;
+            *reinterpret_cast<f32x2*>(zp) = (f32x2){zv[i].x, zv[i].z};
+            *reinterpret_cast<f32x2*>(zp + 8) = (f32x2){zv[i].y, zv[i].w};
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int e = 64 * t + lane, dl = e / 40, hl = (e % 40) / 10, wl = e % 10;
+            if (e < 160) Xn[wave * BU_PSL + (dl * 4 + hl) * 12 + wl] = xl[t];
+        }
+    };
+
+    // operand addresses: A = dZ[co = n (+16 ct)][d = pd + 2 dd][h = ph + 2 hh][parity block pw][4 wh + kq]
+    //                    B = x0[ci = n][dl = dd + jd + pd][hl = hh + jh + ph][wl = 4 wh + kq + jw + pw]
+    const int abase = n * BU_PZ + (pd * 4 + ph) * 16 + pw * 8 + kq;
+    const int bbase = n * BU_PSL + (pd * 4 + ph) * 12 + pw + kq;
+    int tile = k.lo;
+    if (tile < k.hi) {
+        load_tile(tile);
+        store_tile(smem, smem + 16 * NCT * BU_PZ);
+    }
+    __syncthreads();
+    for (int iter = 0; tile < k.hi; ++tile, ++iter) {
+        const bool more = tile + 1 < k.hi;
+        if (more) load_tile(tile + 1);
+        const float* Zb = smem + (iter & 1) * BUF;
+        const float* Xb = Zb + 16 * NCT * BU_PZ;
+        float a[2][NCT], bv[2][4];
+        auto fetch = [&](int s, float (&af)[NCT], float (&bf)[4]) __attribute__((always_inline)) {
+            const int dd = s >> 2, hh = (s >> 1) & 1, wh = s & 1;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) af[ct] = Zb[abase + ct * 16 * BU_PZ + (dd * 8 + hh * 2) * 16 + 4 * wh];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // j = jbase + i (jbase in {0,4}: jd = wave & 1 is runtime-uniform, (jh, jw) = (i >> 1, i & 1) compile-time)
+                bf[i] = Xb[bbase + ((dd + (jbase >> 2)) * 4 + hh + (i >> 1)) * 12 + 4 * wh + (i & 1)];
+            }
+        };
+        fetch(0, a[0], bv[0]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (s + 1 < 8) fetch(s + 1, a[(s + 1) & 1], bv[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = vxm_mfma16(a[s & 1][ct], bv[s & 1][i], acc[i][ct]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float* Zn = smem + ((iter + 1) & 1) * BUF;
+        if (more) store_tile(Zn, Zn + 16 * NCT * BU_PZ);
+        __syncthreads();
+    }
+    // partial: part[idx][co][ci (C0)][p*8 + j]
+    float* out = part + (size_t)k.idx * ((size_t)Cout * C0 * 64);
+    const int ci = k.c0 + n;
+    if (n < k.ckc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int co = k.cog + ct * 16 + kq * 4 + j;
+                    if (co < Cout) out[((size_t)co * C0 + ci) * 64 + par * 8 + jbase + i] = acc[i][ct][j];
+                }
+    }
+}
+
+// gw[co][ci_off.. + ci][tap] = sum over the 8 parities of the reduced collapsed partial that contains `tap`
+__global__ void __launch_bounds__(256) k_reduce_partials_up(const float* __restrict__ part, float* __restrict__ gw, int C0, int Cout, int gw_cin,
+                                                            int T, int Qc, int G, int cog_size) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // (co, ci, tap)
+    if (i >= Cout * C0 * 27) return;
+    const int tap = i % 27, ci = (i / 27) % C0, co = i / (27 * C0);
+    const int cb = Qc * G, combo = ci / BW_CKI + Qc * (co / cog_size);
+    const int nparts = (T - combo + cb - 1) / cb;
+    const int k3[3] = {tap / 9, (tap / 3) % 3, tap % 3};
+    const size_t stride = (size_t)Cout * C0 * 64, base = ((size_t)co * C0 + ci) * 64;
+    float s = 0.0f;
+    for (int par = 0; par < 8; ++par) {
+        const int p3[3] = {(par >> 2) & 1, (par >> 1) & 1, par & 1};
+        int j = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) j = j * 2 + (p3[a] ? (k3[a] == 2) : (k3[a] >= 1));
+        float t = 0.0f;
+        for (int p = 0; p < nparts; ++p) t += part[(size_t)p * stride + base + par * 8 + j];
+        s += t;
+    }
+    gw[((size_t)co * gw_cin + ci) * 27 + tap] = s;
+}
+
 // gw[i] = sum_p part[p][i] (and gb[co] = sum_p part[p][n + co]) in a fixed order (deterministic): 64 outputs x 4
 // partial-slices per block, 4 independent accumulators per thread so that the (latency-bound) loads overlap.
 // Element i = (co, ci, tap) belongs to combo (ci / 16, co / cog_size), which has cnt = ceil((T - combo) / cb) slots;
@@ -1556,7 +1710,8 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_dma(ConvIn 
 // swapflip: the partials are those of the role-swapped product (see vxm_conv3d_k3_bwd_weight): element (co' = ci, ci' = co, t)
 // goes to gw[co][ci][26 - t].
 __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb,
-                                                         int n, int Cin, int Cout, int T, int Qc, int G, int cog_size, int swapflip) {
+                                                         int n, int Cin, int Cout, int T, int Qc, int G, int cog_size, int swapflip,
+                                                         int gw_cin, int ci_off) {
     __shared__ float red[4][64];
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + x;
@@ -1581,7 +1736,10 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
     if (y == 0 && i < ntot) {
         const float t = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
         if (i >= n) gb[i - n] = t;
-        else if (!swapflip) gw[i] = t;
+        else if (!swapflip) {                 // gw may be a channel sub-range [ci_off, ci_off + Cin) of a [Cout][gw_cin][27] array
+            const int co = i / (Cin * 27), r = i - co * (Cin * 27);
+            gw[((size_t)co * gw_cin + ci_off) * 27 + r] = t;
+        }
         else {
             const int cop = i / (Cin * 27), cip = (i / 27) % Cin, tap = i % 27;        // Cin = inner extent of the partial = original Cout
             gw[((size_t)cip * Cout + cop) * 27 + (26 - tap)] = t;                       // Cout = outer extent = original Cin
@@ -1846,6 +2004,11 @@ size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D,
         const size_t alt = sizeof(float) * ((size_t)q.nparts * ((size_t)Cout * Cin * 27 + Cin) + (size_t)Cout * CS_SLICES);
         if (alt > need) need = alt;
     }
+    {                                                  // collapsed product of an upsampled segment: 64 instead of 27 entries per (co, ci)
+        // nparts(C0) * C0 <= (256 / (Qc G) + 1) * 16 Qc <= 4096 / G + Cin + 16 for any split C0 <= Cin
+        const size_t alt = sizeof(float) * ((size_t)Cout * 64 * (4096 / (size_t)p.G + Cin + 16) + (size_t)Cout * CS_SLICES);
+        if (alt > need) need = alt;
+    }
     return 256 + need;
 }
 
@@ -1873,6 +2036,42 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
         lds_opt_in = true;
     }
     const int n = Cout * Cin * 27;
+    if (x0_up && vec && (D & 1) == 0 && (H & 1) == 0 && (long long)C0 * (D / 2) * (H / 2) * (W / 2) < (1ll << 29)) {
+        // upsampled segment: collapsed product (8 x 8 low-resolution taps), then the skip segment alone through the regular kernel
+        static bool up_opt_in = false;
+        if (!up_opt_in) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight_up<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_bwd_weight_up<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            up_opt_in = true;
+        }
+        const BwPlan u = bw_plan(C0, Cout, B, D, H, W);
+        if (u.NCT == 1)
+            hipLaunchKernelGGL(k_conv3d_k3_bwd_weight_up<1>, dim3(u.T), dim3(BW_THREADS), sizeof(float) * 2 * (size_t)bu_buf_floats<1>(), VXM_STREAM(stream),
+                               x0, (long long)x0_bstride, C0, dz, (long long)dz_bstride, Cout, part, B, D, H, W, u.Qc, u.G);
+        else
+            hipLaunchKernelGGL(k_conv3d_k3_bwd_weight_up<2>, dim3(u.T), dim3(BW_THREADS), sizeof(float) * 2 * (size_t)bu_buf_floats<2>(), VXM_STREAM(stream),
+                               x0, (long long)x0_bstride, C0, dz, (long long)dz_bstride, Cout, part, B, D, H, W, u.Qc, u.G);
+        hipLaunchKernelGGL(k_reduce_partials_up, dim3(vxm_blocks((long long)Cout * C0 * 27, 256)), dim3(256), 0, VXM_STREAM(stream), part, gw, C0, Cout, Cin,
+                           u.T, u.Qc, u.G, 16 * u.NCT);
+        if (C1 > 0) {
+            const BwPlan s1 = bw_plan(C1, Cout, B, D, H, W);
+            ConvIn sin{x1, nullptr, (long long)x1_bstride, 0, C1, 0, 0};
+            const int n1 = Cout * C1 * 27;
+            if (s1.NCT == 1)
+                hipLaunchKernelGGL(k_conv3d_k3_bwd_weight_vec<1>, dim3(s1.T), dim3(BW_THREADS), sizeof(float) * 2 * (size_t)bv_lds_floats<1>(), VXM_STREAM(stream),
+                                   sin, dz, (long long)dz_bstride, Cout, gb ? 1 : 0, part, B, D, H, W, s1.Qc, s1.G);
+            else
+                hipLaunchKernelGGL(k_conv3d_k3_bwd_weight_vec<2>, dim3(s1.T), dim3(BW_THREADS), sizeof(float) * 2 * (size_t)bv_lds_floats<2>(), VXM_STREAM(stream),
+                                   sin, dz, (long long)dz_bstride, Cout, gb ? 1 : 0, part, B, D, H, W, s1.Qc, s1.G);
+            hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n1 + (gb ? Cout : 0), 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, gb, n1, C1, Cout,
+                               s1.T, s1.Qc, s1.G, 16 * s1.NCT, 0, Cin, C0);
+        } else if (gb) {
+            float* cs = part + (size_t)u.nparts * (size_t)Cout * C0 * 64;
+            hipLaunchKernelGGL(k_channel_sum_partial, dim3(Cout, CS_SLICES), dim3(256), 0, VXM_STREAM(stream), dz, (long long)dz_bstride, cs, B, (size_t)D * H * W);
+            hipLaunchKernelGGL(k_channel_sum_finish, dim3(Cout), dim3(64), 0, VXM_STREAM(stream), cs, gb);
+        }
+        return vxm_check_launch("vxm_conv3d_k3_bwd_weight");
+    }
 #define BW_LAUNCH(KERNEL, LDSF, IN_, DZ_, DZBS_, CO_, BIAS_, P_) hipLaunchKernelGGL(KERNEL, dim3((P_).T), dim3(BW_THREADS), sizeof(float) * (size_t)(LDSF), \
         VXM_STREAM(stream), IN_, DZ_, (long long)(DZBS_), CO_, BIAS_, part, B, D, H, W, (P_).Qc, (P_).G)
     if (swap) {
@@ -1881,7 +2080,7 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
         if (q.NCT == 1) BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<1>, 2 * bv_lds_floats<1>(), sin, x0, x0_bstride, Cin, 0, q);
         else BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<2>, 2 * bv_lds_floats<2>(), sin, x0, x0_bstride, Cin, 0, q);
         hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, (float*)nullptr, n, Cout, Cin,
-                           q.T, q.Qc, q.G, 16 * q.NCT, 1);
+                           q.T, q.Qc, q.G, 16 * q.NCT, 1, Cin, 0);
         if (gb) {
             float* cs = part + (size_t)q.nparts * ((size_t)n + Cin);
             hipLaunchKernelGGL(k_channel_sum_partial, dim3(Cout, CS_SLICES), dim3(256), 0, VXM_STREAM(stream), dz, (long long)dz_bstride, cs, B,
@@ -1902,7 +2101,7 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
 #undef BW_LAUNCH
     // the bias gradient rides along: its per-block partials sit behind the weight partials of every slot
     hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n + (gb ? Cout : 0), 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, gb, n, Cin, Cout,
-                       p.T, p.Qc, p.G, 16 * p.NCT, 0);
+                       p.T, p.Qc, p.G, 16 * p.NCT, 0, Cin, 0);
     return vxm_check_launch("vxm_conv3d_k3_bwd_weight");
 }
 
