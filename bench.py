@@ -175,7 +175,9 @@ def main():
         ent = {"launches_per_step": st["launches"] / args.steps, "ms_per_step": st["ms"] / args.steps,
                "avg_launch_ms": st["ms"] / st["launches"]}
         if st["flops"]:
-            ent["tflops"] = st["flops"] / (st["ms"] * 1e-3) / 1e12
+            ent["tflops"] = st["flops"] / (st["ms"] * 1e-3) / 1e12                # FLOPs the kernel executes (MFMA utilisation)
+            if st.get("nominal", 0.0) > st["flops"] * 1.001:                      # collapsed-upsample kernels: reference formulation
+                ent["nominal_tflops"] = st["nominal"] / (st["ms"] * 1e-3) / 1e12
         if st["bytes"]:
             ent["gbs"] = st["bytes"] / (st["ms"] * 1e-3) / 1e9
         kernels[name] = ent

@@ -119,9 +119,10 @@ int vxm_conv3d_k3_fewout_fwd(const float* x, int Cin, int64_t x_bstride, const f
  * 100 * wide + 10 * CK + NCT, wide = 1: the 8-wave wide-load kernel (k_conv3d_k3_t8<NCT>), 0: k_conv3d_k3<CK,NCT>. */
 int vxm_conv3d_k3_fwd_variant(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
                               const float* wpacked, int Cout, int B, int D, int H, int W);
-/* Same for vxm_conv3d_k3_bwd_weight: 10 * wide + NCT (wide = 1: k_conv3d_k3_bwd_weight_vec, 0: ..._dma). */
-int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
-                                     const float* dz, int64_t dz_bstride, int Cout, int W);
+/* Same for vxm_conv3d_k3_bwd_weight: 10 * kind + NCT, kind = 0: k_conv3d_k3_bwd_weight_dma, 1: ..._vec, 2: collapsed
+ * upsampled segment (k_conv3d_k3_bwd_weight_up) + ..._vec on the skip segment. */
+int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1,
+                                     int64_t x1_bstride, const float* dz, int64_t dz_bstride, int Cout, int D, int H, int W);
 /* convolution_backward w.r.t. weight and bias: gw [Cout,C0+C1,3,3,3], gb [Cout] (nullable).
  * dz [B,Cout,D,H,W] is the gradient w.r.t. the conv output *before* the activation. */
 size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D, int H, int W);

@@ -499,13 +499,13 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
 constexpr int TU_RS = 24;                               // seg-1 row: [even block 12 | odd block 12]
 constexpr int TU_PS1 = (T8_TD + 2) * HH * TU_RS + 8;    // 1448 = 8 mod 32
 constexpr int TU_PSL = 6 * 4 * 16 + 8;                  // low-res plane [6][4][16] -> 392 = 8 mod 32
-constexpr int TU_CK0 = 4;                               // segment-0 channels per chunk (one k-step)
+constexpr int TU_CK0 = 8;                               // segment-0 channels per chunk (two k-steps)
 
-template <int NCT> constexpr int tu_wc_floats() { return 8 * 8 * NCT * 64; }          // collapsed weights of a seg-0 chunk
+template <int NCT> constexpr int tu_wc_floats() { return 8 * 8 * 2 * NCT * 64; }      // collapsed weights of a seg-0 chunk [par][j][ks][ct][64]
 template <int NCT> constexpr int tu_w1_floats() { return 27 * 2 * NCT * 64; }         // packed weights of a seg-1 chunk
-template <int NCT> constexpr int tu_s0_floats() { return TU_CK0 * TU_PSL + tu_wc_floats<NCT>(); }   // one seg-0 stage (X + weights)
-template <int NCT> constexpr int tu_lds_floats() {      // two seg-0 stages (double buffered) or one seg-1 stage
-    return (8 * TU_PS1 + tu_w1_floats<NCT>()) > 2 * tu_s0_floats<NCT>() ? (8 * TU_PS1 + tu_w1_floats<NCT>()) : 2 * tu_s0_floats<NCT>();
+template <int NCT> constexpr int tu_s0_floats() { return TU_CK0 * TU_PSL + tu_wc_floats<NCT>(); }   // seg-0 stage: [weights][X]
+template <int NCT> constexpr int tu_lds_floats() {      // the larger of the two stage kinds (single buffered; chunk q+1 waits in registers)
+    return (8 * TU_PS1 + tu_w1_floats<NCT>()) > tu_s0_floats<NCT>() ? (8 * TU_PS1 + tu_w1_floats<NCT>()) : tu_s0_floats<NCT>();
 }
 
 template <int NCT>
@@ -516,6 +516,7 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8u(const float* __
     VXM_DYN_SMEM(float, smem);
     constexpr int WIT = (tu_wc_floats<NCT>() / 4 + T8_THREADS - 1) / T8_THREADS;       // >= the seg-1 chunk's pieces as well
     static_assert(tu_w1_floats<NCT>() <= tu_wc_floats<NCT>(), "weight staging registers sized by the seg-0 chunk");
+    static_assert(NCT == 1, "the 2-tile instance does not fit 128 VGPRs (see up_nct)");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = lane >> 4, n = lane & 15;
@@ -563,14 +564,14 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8u(const float* __
     // block at [12 + 2 lq, +1], the even ones to the even block (shifted by one word) at [2 lq + 2, +1]: two aligned b64 stores
     const int s1_odd = lr4 * TU_RS + 12 + 2 * lq, s1_even = lr4 * TU_RS + 2 * lq + 2;
     const int s1_halo = lr2 * TU_RS + (hside ? 20 : 1);          // col 16 -> odd index 8; col -1 -> even index 0 (+1 shift)
-    // Segment 0 (low resolution): slot = tid + 512 k (< 960) -> channel c = slot / 240, (dl, hl, wl) of the [6][4][10] region
+    // Segment 0 (low resolution): slot = tid + 512 k (< 1920) -> channel c = slot / 240, (dl, hl, wl) of the [6][4][10] region
     auto low_slot = [&](int k, int& voff, int& lds) __attribute__((always_inline)) {
         const int slot = tid + T8_THREADS * k;
         const int c = slot / 240, r = slot - c * 240, dl = r / 40, hl = (r % 40) / 10, wl = r % 10;
         const int gd = (d0 >> 1) - 1 + dl, gh = (h0 >> 1) - 1 + hl, gw = (w0 >> 1) - 1 + wl;
-        const bool ok = slot < 960 && (unsigned)gd < (unsigned)Dl && (unsigned)gh < (unsigned)Hl && (unsigned)gw < (unsigned)Wl;
+        const bool ok = slot < 1920 && (unsigned)gd < (unsigned)Dl && (unsigned)gh < (unsigned)Hl && (unsigned)gw < (unsigned)Wl;
         voff = ok ? (c * Vl + (gd * Hl + gh) * Wl + gw) << 2 : VXM_OOB;        // channel of the chunk in the per-lane offset
-        lds = slot < 960 ? c * TU_PSL + (dl * 4 + hl) * 16 + wl : -1;
+        lds = slot < 1920 ? c * TU_PSL + (dl * 4 + hl) * 16 + wl : -1;
     };
 
     f32x4 acc[NCT][4];
@@ -579,10 +580,9 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8u(const float* __
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xi[4];
+    f32x4 xi[4];               // seg-1 interior pieces; seg-0: xi[0] carries the four low-resolution words of this thread
     float xh[2];
     f32x4 wv[WIT];
-    float* const Xs = smem;
     auto wchunk_base = [&](int q) __attribute__((always_inline)) -> size_t {       // packed layout: [g][Q0 collapsed chunks][Q1 regular chunks]
         const size_t per_g = (size_t)Q0 * tu_wc_floats<NCT>() + (size_t)Q1 * tu_w1_floats<NCT>();
         return (size_t)g * per_g + (q < Q0 ? (size_t)q * tu_wc_floats<NCT>() : (size_t)Q0 * tu_wc_floats<NCT>() + (size_t)(q - Q0) * tu_w1_floats<NCT>());
@@ -591,11 +591,11 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8u(const float* __
         if (q < Q0) {                                 // low-resolution chunk: 4 channels x [6][4][10]
             const int soff = q * TU_CK0 * Vl * 4;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 int vo, ld;
                 low_slot(k, vo, ld);
                 // channels beyond C0 in the last chunk: offset beyond num_records -> 0.0 (descriptor covers C0 planes)
-                xh[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, vo, soff, 0));
+                xi[0][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, vo, soff, 0));
             }
         } else {
             const int cg = (q - Q0) * 8 + wave;       // channel of segment 1 staged by this wave
@@ -621,14 +621,14 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8u(const float* __
         float* Ws;
         int wcount;
         if (q < Q0) {
-            float* const X0 = smem + (q & 1) * tu_s0_floats<NCT>();
+            float* const X0 = smem + tu_wc_floats<NCT>();
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < 4; ++k) {
                 int vo, ld;
                 low_slot(k, vo, ld);
-                if (ld >= 0) X0[ld] = xh[k];
+                if (ld >= 0) X0[ld] = xi[0][k];
             }
-            Ws = X0 + TU_CK0 * TU_PSL;
+            Ws = smem;
             wcount = tu_wc_floats<NCT>() / 4;
         } else {
             float* dst = smem + tu_w1_floats<NCT>() + wave * TU_PS1;      // seg-1 stage: [weights][X] (all operand offsets < 64 KB)
@@ -655,36 +655,29 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8u(const float* __
     const int pd = wave & 1;
     const int b1base = kq * TU_PS1 + (n & 7) + 2 * TU_RS * (n >> 3) + wave * HH * TU_RS;
     const int b0base = kq * TU_PSL + (n & 7) + 16 * (n >> 3) + ((wave >> 1) + pd) * 64;
-    const int a0base = pd * 4 * 8 * NCT * 64 + lane;
+    const int a0base = pd * 4 * 8 * 2 * NCT * 64 + lane;
 
-    // Pipeline invariant at the top of iteration q: chunk q is in LDS, chunk q+1 (if any) is in registers.  The small seg-0
-    // stages are double buffered in LDS (the next one is stored while this one computes: one barrier per chunk); the
-    // large seg-1 stage is single buffered (store between two barriers).
     load_chunk(0);
     store_chunk(0);
-    if (Q > 1) load_chunk(1);
     __syncthreads();
     for (int q = 0; q < Q; ++q) {
+        if (q + 1 < Q) load_chunk(q + 1);             // in flight (registers) under the MFMAs of chunk q
         if (q < Q0) {
-            if (q + 1 < Q0) {                       // next stage -> the other seg-0 buffer (its readers passed the last barrier)
-                store_chunk(q + 1);
-                if (q + 2 < Q) load_chunk(q + 2);
-            }
-            // ---- collapsed taps: 8 j x 4 N-tiles (ph, pw), one k-step (4 channels)
-            const float* X0 = smem + (q & 1) * tu_s0_floats<NCT>();
-            const float* Wc = X0 + TU_CK0 * TU_PSL;
+            // ---- collapsed taps: 8 j x 2 k-steps x 4 N-tiles (ph, pw)
+            const float* Wc = smem;
+            const float* X0 = smem + tu_wc_floats<NCT>();
             float a[2][NCT], bb[2];
             auto fetch = [&](int st, float (&af)[NCT], float& bf) __attribute__((always_inline)) {
-                const int j = st >> 2, nt = st & 3, ph = nt >> 1, pw = nt & 1;
+                const int j = st >> 3, ks = (st >> 2) & 1, nt = st & 3, ph = nt >> 1, pw = nt & 1;
                 const int jd = j >> 2, jh = (j >> 1) & 1, jw = j & 1;
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) af[ct] = Wc[a0base + (((ph * 2 + pw) * 8 + j) * NCT + ct) * 64];
-                bf = X0[b0base + jd * 64 + (jh + ph) * 16 + jw + pw];
+                for (int ct = 0; ct < NCT; ++ct) af[ct] = Wc[a0base + ((((ph * 2 + pw) * 8 + j) * 2 + ks) * NCT + ct) * 64];
+                bf = X0[b0base + ks * 4 * TU_PSL + jd * 64 + (jh + ph) * 16 + jw + pw];
             };
             fetch(0, a[0], bb[0]);
 #pragma unroll
-            for (int st = 0; st < 32; ++st) {
-                if (st + 1 < 32) fetch(st + 1, a[(st + 1) & 1], bb[(st + 1) & 1]);
+            for (int st = 0; st < 64; ++st) {
+                if (st + 1 < 64) fetch(st + 1, a[(st + 1) & 1], bb[(st + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct) acc[ct][st & 3] = vxm_mfma16(a[st & 1][ct], bb[st & 1], acc[ct][st & 3]);
@@ -719,10 +712,9 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8u(const float* __
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();
-        if (q + 1 < Q && q + 1 >= Q0) {             // next is a seg-1 stage: it overlays everything, store it between barriers
+        if (q + 1 < Q) {
+            __syncthreads();                          // every wave is done reading chunk q
             store_chunk(q + 1);
-            if (q + 2 < Q) load_chunk(q + 2);
             __syncthreads();
         }
     }
@@ -748,15 +740,15 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8u(const float* __
     }
 }
 
-// packed weights of k_conv3d_k3_t8u: per output group g, Q0 collapsed chunks [par 8][j 8][NCT][64] (segment-0 channel
-// 4 q + (lane >> 4)), then Q1 regular chunks [27][2][NCT][64] (segment-1 channel 8 q + 4 s + (lane >> 4)); co = (g NCT + ct) 16 + (lane & 15).
+// packed weights of k_conv3d_k3_t8u: per output group g, Q0 collapsed chunks [par 8][j 8][ks 2][NCT][64] (segment-0 channel
+// 8 q + 4 ks + (lane >> 4)), then Q1 regular chunks [27][2][NCT][64] (segment-1 channel 8 q + 4 s + (lane >> 4)); co = (g NCT + ct) 16 + (lane & 15).
 // Per axis the collapsed tap j of parity p sums the kernel taps {p=0: j=0 -> {0}, j=1 -> {1,2};  p=1: j=0 -> {0,1}, j=1 -> {2}}.
 __global__ void __launch_bounds__(256) k_pack_weights_up(const float* __restrict__ w, float* __restrict__ wp, int C0, int C1, int Cout, int NCT,
                                                          size_t elems) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= elems) return;
     const int Cin = C0 + C1, Q0 = (C0 + TU_CK0 - 1) / TU_CK0, Q1 = (C1 + 7) / 8;
-    const size_t wc = (size_t)8 * 8 * NCT * 64, w1 = (size_t)27 * 2 * NCT * 64, per_g = Q0 * wc + Q1 * w1;
+    const size_t wc = (size_t)8 * 8 * 2 * NCT * 64, w1 = (size_t)27 * 2 * NCT * 64, per_g = Q0 * wc + Q1 * w1;
     const int g = (int)(i / per_g);
     size_t r = i - (size_t)g * per_g;
     float v = 0.0f;
@@ -764,8 +756,9 @@ __global__ void __launch_bounds__(256) k_pack_weights_up(const float* __restrict
         const int q = (int)(r / wc); r -= (size_t)q * wc;
         const int lane = r % 64; r /= 64;
         const int ct = r % NCT; r /= NCT;
+        const int ks = r % 2; r /= 2;
         const int j = r % 8; const int par = (int)(r / 8);
-        const int co = (g * NCT + ct) * 16 + (lane & 15), ci = q * TU_CK0 + (lane >> 4);
+        const int co = (g * NCT + ct) * 16 + (lane & 15), ci = q * TU_CK0 + 4 * ks + (lane >> 4);
         if (co < Cout && ci < C0) {
             const int p[3] = {(par >> 2) & 1, (par >> 1) & 1, par & 1}, jj[3] = {(j >> 2) & 1, (j >> 1) & 1, j & 1};
             int lo[3], hi[3];
@@ -1870,9 +1863,12 @@ int vxm_conv3d_k3_fwd_variant(const float* x0, int C0, int64_t x0_bstride, const
     return (fwd_wide_ok(c, x0, x0_bstride, x1, C1, x1_bstride, wpacked, B, D, H, W) ? 100 : 0) + 10 * c.CK + c.NCT;
 }
 
-int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
-                                     const float* dz, int64_t dz_bstride, int Cout, int W) {
-    return (bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W) ? 10 : 0) + (Cout <= 16 ? 1 : 2);     // NCT of the unswapped plan
+int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
+                                     const float* dz, int64_t dz_bstride, int Cout, int D, int H, int W) {
+    const bool vec = bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W);
+    const int nct = Cout <= 16 ? 1 : 2;                 // of the unswapped plan
+    if (x0_up && vec && (D & 1) == 0 && (H & 1) == 0) return 20 + nct;      // collapsed upsampled segment (+ regular skip segment)
+    return (vec ? 10 : 0) + nct;
 }
 
 int vxm_conv3d_k3_up_ok(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, float* y,
@@ -1892,7 +1888,7 @@ size_t vxm_conv3d_k3_up_packed_elems(int C0, int C1, int Cout) {
     if (C0 <= 0 || C1 < 0 || Cout <= 0) return 0;
     const int NCT = up_nct(Cout), G = (Cout + 16 * NCT - 1) / (16 * NCT);
     const size_t Q0 = (C0 + TU_CK0 - 1) / TU_CK0, Q1 = (C1 + 7) / 8;
-    return (size_t)G * (Q0 * 8 * 8 * NCT * 64 + Q1 * 27 * 2 * NCT * 64);
+    return (size_t)G * (Q0 * 8 * 8 * 2 * NCT * 64 + Q1 * 27 * 2 * NCT * 64);
 }
 
 int vxm_conv3d_k3_up_pack_weights(const float* w, float* wpacked, int C0, int C1, int Cout, void* stream) {
@@ -1915,14 +1911,13 @@ int vxm_conv3d_k3_up_fwd(const float* x0, int C0, int64_t x0_bstride, const floa
     static bool opt_in = false;
     if (!opt_in) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_t8u<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_t8u<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         opt_in = true;
     }
     const dim3 grid((unsigned)((tiles8 + 7) / 8 * 8), G);
 #define TU_LAUNCH(NCT_) hipLaunchKernelGGL((k_conv3d_k3_t8u<NCT_>), grid, dim3(T8_THREADS), sizeof(float) * (size_t)tu_lds_floats<NCT_>(), \
         VXM_STREAM(stream), x0, (long long)x0_bstride, C0, x1, (long long)x1_bstride, C1, wpacked, bias, y, (long long)y_bstride, Cout, act_slope, B, D, H, W)
-    if (NCT == 1) TU_LAUNCH(1);
-    else TU_LAUNCH(2);
+    (void)NCT;
+    TU_LAUNCH(1);
 #undef TU_LAUNCH
     return vxm_check_launch("vxm_conv3d_k3_up_fwd");
 }
@@ -1932,7 +1927,7 @@ static int dlow_nct(int C0) { return C0 <= 16 ? 1 : 2; }
 int vxm_conv3d_k3_up_bwd_low_ok(const float* dz, int64_t dz_bstride, int C0, int Cout, int B, int D, int H, int W) {
     const long long tiles = (long long)B * ((D / 2 + 1) / 2) * ((H / 2 + 3) / 4) * ((W / 2 + 15) / 16);
     return C0 > 0 && Cout > 0 && (W & 3) == 0 && (D & 1) == 0 && (H & 1) == 0 && al16(dz) && (dz_bstride & 3) == 0 &&
-           (long long)Cout * D * H * W < (1ll << 29) && tiles >= wide_min_tiles() && tiles < (1ll << 30) && !bw_force_generic();
+           (long long)Cout * D * H * W < (1ll << 29) && tiles >= (wide_min_tiles() + 3) / 4 && tiles < (1ll << 30) && !bw_force_generic();
 }
 
 size_t vxm_conv3d_k3_up_bwd_low_packed_elems(int C0, int Cout) {

@@ -273,7 +273,8 @@ def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B,
         # upsampled segment at low-resolution cost: collapsed 2x2x2 weights per output parity (conv.hip: k_conv3d_k3_t8u)
         wp = torch.empty(_lib.lib().vxm_conv3d_k3_up_packed_elems(c0, c1, cout), dtype=w.dtype, device=w.device)
         call("vxm_conv3d_k3_up_pack_weights", ptr(_c(w)), ptr(wp), c0, c1, cout, stream())
-        with _prof.region("k_conv3d_k3_t8u<1>", flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+        with _prof.region("k_conv3d_k3_t8u<1>", flops=2.0 * (8 * c0 + 27 * c1) * cout * B * D * H * W,
+                          nominal=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
             call("vxm_conv3d_k3_up_fwd", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs, cout, float(slope),
                  B, D, H, W, stream())
         return
@@ -312,11 +313,15 @@ class _Workspace:
 def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H, W):
     need = _lib.lib().vxm_conv3d_k3_bwd_weight_workspace_bytes(c0 + c1, cout, B, D, H, W)
     buf = ws.get(need)
-    name = None
+    name, nominal = None, 2.0 * 27 * (c0 + c1) * cout * B * D * H * W
+    flops = nominal
     if _prof.ACTIVE is not None:
-        v = _lib.lib().vxm_conv3d_k3_bwd_weight_variant(ptr(x0), bs0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, W)
-        name = "k_conv3d_k3_bwd_weight_%s<%d>" % ("vec" if v >= 10 else "dma", v % 10)
-    with _prof.region(name, flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+        v = _lib.lib().vxm_conv3d_k3_bwd_weight_variant(ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, D, H, W)
+        kind = {0: "dma", 1: "vec", 2: "up+vec"}[v // 10]
+        name = "k_conv3d_k3_bwd_weight_%s<%d>" % (kind, v % 10)
+        if v // 10 == 2:
+            flops = 2.0 * (8 * c0 + 27 * c1) * cout * B * D * H * W
+    with _prof.region(name, flops=flops, nominal=nominal):
         call("vxm_conv3d_k3_bwd_weight", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W,
              cout, ptr(gw), ptr(gb), ptr(buf), buf.numel(), B, D, H, W, stream())
 
@@ -598,7 +603,8 @@ class UnetFn(torch.autograd.Function):
                 lD, lH, lW = D // 2, H // 2, W // 2
                 dzl = torch.empty((B, c0, lD, lH, lW), dtype=dt, device=dev)
                 wpk = torch.empty(_lib.lib().vxm_conv3d_k3_up_bwd_low_packed_elems(c0, cout), dtype=dt, device=dev)
-                with _prof.region("k_conv3d_k3_dlow<%d>" % (1 if c0 <= 16 else 2), flops=2.0 * 27 * c0 * cout * B * V):
+                with _prof.region("k_conv3d_k3_dlow<%d>" % (1 if c0 <= 16 else 2), flops=2.0 * 8 * c0 * cout * B * V,
+                                  nominal=2.0 * 27 * c0 * cout * B * V):
                     call("vxm_conv3d_k3_up_bwd_low", ptr(dz), cout * V, cout, ptr(_c(w)), c0, cin, ptr(wpk), ptr(dzl), c0 * lD * lH * lW,
                          ptr(T[s0]) if pslope != 1.0 else None, c0 * lD * lH * lW, float(pslope), B, D, H, W, stream())
                 DZ[s0] = dzl
