@@ -1673,25 +1673,44 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_up(const fl
     }
 }
 
-// gw[co][ci_off.. + ci][tap] = sum over the 8 parities of the reduced collapsed partial that contains `tap`
-__global__ void __launch_bounds__(256) k_reduce_partials_up(const float* __restrict__ part, float* __restrict__ gw, int C0, int Cout, int gw_cin,
-                                                            int T, int Qc, int G, int cog_size) {
+// Reduction of the collapsed partials in two coalesced steps: (1) red[e] = sum_p part[p][e] over the blocks of element e's combo
+// (e = (co, ci, par*8 + j); 64 elements x 4 partial-slices per block like k_reduce_partials), (2) gw[co][ci][tap] = sum over
+// the 8 parities of the collapsed entry that contains `tap`.
+__global__ void __launch_bounds__(256) k_reduce_partials_up_sum(const float* __restrict__ part, float* __restrict__ red, int C0, int Cout, int T,
+                                                                int Qc, int G, int cog_size) {
+    __shared__ float sm[4][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + x, n = Cout * C0 * 64;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (e < n) {
+        const int co = e / (C0 * 64), ci = (e >> 6) % C0;
+        const int cb = Qc * G, combo = ci / BW_CKI + Qc * (co / cog_size);
+        const int nparts = (T - combo + cb - 1) / cb;
+        int p = y;
+        for (; p + 4 < nparts; p += 8) {
+            s0 += part[(size_t)p * n + e];
+            s1 += part[(size_t)(p + 4) * n + e];
+        }
+        for (; p < nparts; p += 4) s0 += part[(size_t)p * n + e];
+    }
+    sm[y][x] = s0 + s1;
+    __syncthreads();
+    if (y == 0 && e < n) red[e] = (sm[0][x] + sm[1][x]) + (sm[2][x] + sm[3][x]);
+}
+__global__ void __launch_bounds__(256) k_reduce_partials_up_map(const float* __restrict__ red, float* __restrict__ gw, int C0, int Cout, int gw_cin) {
     const int i = blockIdx.x * 256 + threadIdx.x;          // (co, ci, tap)
     if (i >= Cout * C0 * 27) return;
     const int tap = i % 27, ci = (i / 27) % C0, co = i / (27 * C0);
-    const int cb = Qc * G, combo = ci / BW_CKI + Qc * (co / cog_size);
-    const int nparts = (T - combo + cb - 1) / cb;
     const int k3[3] = {tap / 9, (tap / 3) % 3, tap % 3};
-    const size_t stride = (size_t)Cout * C0 * 64, base = ((size_t)co * C0 + ci) * 64;
+    const float* r = red + ((size_t)co * C0 + ci) * 64;
     float s = 0.0f;
+#pragma unroll
     for (int par = 0; par < 8; ++par) {
         const int p3[3] = {(par >> 2) & 1, (par >> 1) & 1, par & 1};
         int j = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) j = j * 2 + (p3[a] ? (k3[a] == 2) : (k3[a] >= 1));
-        float t = 0.0f;
-        for (int p = 0; p < nparts; ++p) t += part[(size_t)p * stride + base + par * 8 + j];
-        s += t;
+        s += r[par * 8 + j];
     }
     gw[((size_t)co * gw_cin + ci) * 27 + tap] = s;
 }
@@ -2001,7 +2020,7 @@ size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D,
     }
     {                                                  // collapsed product of an upsampled segment: 64 instead of 27 entries per (co, ci)
         // nparts(C0) * C0 <= (256 / (Qc G) + 1) * 16 Qc <= 4096 / G + Cin + 16 for any split C0 <= Cin
-        const size_t alt = sizeof(float) * ((size_t)Cout * 64 * (4096 / (size_t)p.G + Cin + 16) + (size_t)Cout * CS_SLICES);
+        const size_t alt = sizeof(float) * ((size_t)Cout * 64 * (4096 / (size_t)p.G + Cin + 16) + (size_t)Cout * CS_SLICES + (size_t)Cout * Cin * 64);
         if (alt > need) need = alt;
     }
     return 256 + need;
@@ -2046,8 +2065,10 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
         else
             hipLaunchKernelGGL(k_conv3d_k3_bwd_weight_up<2>, dim3(u.T), dim3(BW_THREADS), sizeof(float) * 2 * (size_t)bu_buf_floats<2>(), VXM_STREAM(stream),
                                x0, (long long)x0_bstride, C0, dz, (long long)dz_bstride, Cout, part, B, D, H, W, u.Qc, u.G);
-        hipLaunchKernelGGL(k_reduce_partials_up, dim3(vxm_blocks((long long)Cout * C0 * 27, 256)), dim3(256), 0, VXM_STREAM(stream), part, gw, C0, Cout, Cin,
+        float* red = part + (size_t)u.nparts * (size_t)Cout * C0 * 64 + (size_t)Cout * CS_SLICES;      // behind the partials and the channel-sum scratch
+        hipLaunchKernelGGL(k_reduce_partials_up_sum, dim3(vxm_blocks((long long)Cout * C0 * 64, 64)), dim3(256), 0, VXM_STREAM(stream), part, red, C0, Cout,
                            u.T, u.Qc, u.G, 16 * u.NCT);
+        hipLaunchKernelGGL(k_reduce_partials_up_map, dim3(vxm_blocks((long long)Cout * C0 * 27, 256)), dim3(256), 0, VXM_STREAM(stream), red, gw, C0, Cout, Cin);
         if (C1 > 0) {
             const BwPlan s1 = bw_plan(C1, Cout, B, D, H, W);
             ConvIn sin{x1, nullptr, (long long)x1_bstride, 0, C1, 0, 0};
