@@ -1,0 +1,119 @@
+// Shared pieces of the conv kernels (conv_fwd.hip, conv_bwd_weight.hip): tile geometry, the virtual-concat input
+// descriptor, buffer-descriptor helpers, kernel-selection switches and argument checks.
+#ifndef VXM_CONV_COMMON_H
+#define VXM_CONV_COMMON_H
+#include <cstdlib>
+#include "vxm_common.h"
+#include "vxm_device.h"
+
+namespace {
+
+
+constexpr int TD = 4, TH = 4, TW = 16;          // output tile
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;   // haloed input tile (648 voxels)
+constexpr int HVOX = HD * HH * HW;
+
+struct ConvIn {                // virtual concat of two channel segments (see include/vxm_hip.h)
+    const float* x0; const float* x1;
+    long long bs0, bs1;
+    int C0, C1, up0;
+};
+
+__device__ __forceinline__ void tile_origin(int tile, int D, int H, int W, int& b, int& d0, int& h0, int& w0) {
+    const int nw = (W + TW - 1) / TW, nh = (H + TH - 1) / TH, nd = (D + TD - 1) / TD;
+    const int tw = tile % nw; int t = tile / nw;
+    const int th = t % nh; t /= nh;
+    const int td = t % nd; b = t / nd;
+    d0 = td * TD; h0 = th * TH; w0 = tw * TW;
+}
+
+// Row-slab gather used by both conv kernels: one wave-instruction fetches 3 haloed rows (18 floats
+// each, lanes 54..63 idle) of one (channel, depth) slab, so the channel / depth part of the address
+// is wave-uniform (SALU) and the row / column part is a per-lane constant of the tile.
+struct SlabLane {
+    int rr, wx;        // row inside the 3-row group, column inside the haloed row
+    int gh0, gw;       // global row of row-group 0 and global column of this lane (may be -1 / >= extent)
+    bool act, wok;     // lane carries data; column inside the volume
+};
+
+__device__ __forceinline__ SlabLane make_slab_lane(int lane, int h0, int w0, int W) {
+    SlabLane L;
+    L.rr = lane / HW; L.wx = lane - L.rr * HW;
+    L.act = lane < 3 * HW;
+    L.gw = w0 + L.wx - 1; L.gh0 = h0 + L.rr - 1;
+    L.wok = L.act && (unsigned)L.gw < (unsigned)W;
+    return L;
+}
+
+// Value of virtual input channel cg at depth d for this lane's (row, column).  b, cg, d, hb are
+// wave-uniform: the 64-bit base is SALU math (s_cselect, no branches), the lane contributes a 32-bit
+// offset.  The load is UNCONDITIONAL on a clamped in-bounds address and the padding zeros are applied
+// by a select afterwards: branch-free, so the unrolled loads of one chunk issue back-to-back.
+__device__ __forceinline__ float slab_load(const float* x0, const float* x1, long long bs0, long long bs1, int C0, int C1, int up0,
+                                           const SlabLane& L, int b, int cg, int d, int hb, int D, int H, int W) {
+    const bool uok = (unsigned)d < (unsigned)D && cg < C0 + C1;       // uniform validity
+    const int cgc = min(cg, C0 + C1 - 1), dc = min(max(d, 0), D - 1);
+    const bool s0 = cgc < C0;
+    const int sh = (s0 && up0) ? 1 : 0;                               // x2 nearest upsampling of segment 0
+    const float* p = s0 ? x0 + (size_t)b * bs0 : x1 + (size_t)b * bs1;
+    const int cc = s0 ? cgc : cgc - C0;
+    const int Ds = D >> sh, Hs = H >> sh, Ws = W >> sh;
+    const float* base = p + ((size_t)cc * Ds + (dc >> sh)) * Hs * Ws;
+    const int gh = L.gh0 + 3 * hb;
+    const bool ok = L.wok && (unsigned)gh < (unsigned)H;
+    // 32-bit BYTE offset (planes are < 4 GB): lets the load use the SGPR-base + 32-bit-VGPR-offset form
+    const unsigned boff = ok ? (unsigned)((gh >> sh) * Ws + (L.gw >> sh)) << 2 : 0u;
+    const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
+    return (ok && uok) ? v : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// buffer-descriptor helpers.  Tiles are zero padded through the descriptor: a lane whose offset is beyond
+// num_records loads 0.0 (and an LDS-DMA lane writes 0.0 -- probed on gfx950, tools/probe/ldsdma_probe.hip).
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int VXM_OOB = (int)0x80000000;            // voffset beyond any num_records -> the lane loads 0.0
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vxm_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void vxm_lds_dma4(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 4, voff, soff, 0, 0);      // lane l -> LDS base + 4 l
+}
+__device__ __forceinline__ void vxm_lds_dma16(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, voff, soff, 0, 0);     // lane l -> LDS base + 16 l
+}
+
+
+
+// VXM_CONV_GENERIC=1 routes every conv launch through the generic kernels (any W / alignment; LDS-DMA backward-
+// weight), so that the parity tests can exercise them on shapes the wide-load kernels would otherwise take.
+bool bw_force_generic() {
+    static const bool f = [] { const char* e = getenv("VXM_CONV_GENERIC"); return e && e[0] == '1'; }();
+    return f;
+}
+// The 8-wave forward kernel is used from this many 8x4x16 tiles up (below, its 512-voxel tiles leave CUs idle);
+// VXM_CONV_WIDE_MIN_TILES overrides the threshold so that the parity tests can run it on small volumes.
+[[maybe_unused]] long long wide_min_tiles() {
+    static const long long v = [] { const char* e = getenv("VXM_CONV_WIDE_MIN_TILES"); return e ? atoll(e) : 1024ll; }();
+    return v;
+}
+
+static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+int check_conv(const char* fn, int C0, int C1, int x0_up, int Cout, int B, int D, int H, int W) {
+    VXM_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, VXM_ERR_BAD_SHAPE,
+                "%s: bad shape B=%d C0=%d C1=%d Cout=%d D=%d H=%d W=%d", fn, B, C0, C1, Cout, D, H, W);
+    VXM_REQUIRE(!x0_up || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), VXM_ERR_BAD_SHAPE,
+                "%s: upsampled segment needs even extents, got %dx%dx%d", fn, D, H, W);
+    VXM_REQUIRE((long long)(C0 + C1 > Cout ? C0 + C1 : Cout) * D * H * W < (1ll << 29), VXM_ERR_BAD_SHAPE,
+                "%s: a tensor of one sample must stay below 2 GiB (32-bit byte offsets in the buffer descriptors)", fn);
+    return VXM_OK;
+}
+
+
+}  // namespace
+#endif

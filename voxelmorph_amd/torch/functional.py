@@ -270,7 +270,7 @@ def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B,
             call("vxm_conv3d_k3_fewout_fwd", ptr(x0), c0, bs0, ptr(_c(w)), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W, stream())
         return
     if up0 and _lib.lib().vxm_conv3d_k3_up_ok(ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(y), cout, B, D, H, W):
-        # upsampled segment at low-resolution cost: collapsed 2x2x2 weights per output parity (conv.hip: k_conv3d_k3_t8u)
+        # upsampled segment at low-resolution cost: collapsed 2x2x2 weights per output parity (conv_fwd.hip: k_conv3d_k3_t8u)
         wp = torch.empty(_lib.lib().vxm_conv3d_k3_up_packed_elems(c0, c1, cout), dtype=w.dtype, device=w.device)
         call("vxm_conv3d_k3_up_pack_weights", ptr(_c(w)), ptr(wp), c0, c1, cout, stream())
         with _prof.region("k_conv3d_k3_t8u<1>", flops=2.0 * (8 * c0 + 27 * c1) * cout * B * D * H * W,
@@ -598,7 +598,7 @@ class UnetFn(torch.autograd.Function):
             if up0 and plan.ops[plan.producer[s0]]["kind"] == "conv" and len(plan.consumers[s0]) == 1 and \
                     _lib.lib().vxm_conv3d_k3_up_bwd_low_ok(ptr(dz), cout * V, c0, cout, B, D, H, W):
                 # upsampled segment: straight to the half-resolution gradient of the decoder block (stride-2 4x4x4 conv =
-                # conv backward + upsample_nearest3d_backward + leaky_relu_backward in one kernel, conv.hip: k_conv3d_k3_dlow)
+                # conv backward + upsample_nearest3d_backward + leaky_relu_backward in one kernel, conv_fwd.hip: k_conv3d_k3_dlow)
                 pslope = plan.ops[plan.producer[s0]]["slope"]
                 lD, lH, lW = D // 2, H // 2, W // 2
                 dzl = torch.empty((B, c0, lD, lH, lW), dtype=dt, device=dev)
