@@ -182,20 +182,24 @@ __global__ void __launch_bounds__(256) k_conv3d_k3(ConvIn in, const float* __res
 //  * the MFMA loop is fully unrolled, branch-free, with the operands of step s+1 requested before the MFMAs of s.
 // X chunk in LDS: [8][10][6][20], interior columns at 2..17, halo columns at 1 / 18; plane stride 1200 = 16 mod 32.
 constexpr int T8_TD = 8;
-constexpr int T8_PS = (T8_TD + 2) * HH * BV_RS_FWD;   // 1200
 constexpr int T8_THREADS = 512;
 
-template <int NCT>
+// ROWS = H rows per wave (tile 8 x ROWS x 16).  4 is used throughout: 6 rows with a single output tile (324 instead of 216 MFMAs
+// per wave and staged chunk) measured 4 % slower, 8 rows need more than the 128 VGPRs that two blocks per CU allow.
+template <int NCT, int ROWS>
 __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const float* __restrict__ wp, const float* __restrict__ bias,
                                                               float* __restrict__ y, long long y_bs, int Cout, float act_slope,
                                                               const float* __restrict__ mask, long long mask_bs, float mask_slope,
                                                               int B, int D, int H, int W, int Q) {
     VXM_DYN_SMEM(float, smem);
     constexpr int CK = 8, KS = 2, RS = BV_RS_FWD;
+    constexpr int HR = ROWS + 2, NROW = (T8_TD + 2) * HR;                        // haloed rows per plane
+    constexpr int PS = NROW * RS + ((NROW * RS) % 32 == 16 ? 0 : 16);            // plane stride = 16 mod 32 (1200 / 1616 / 2000)
+    constexpr int NI = (NROW * 4 + 63) / 64, NHL = (NROW * 2 + 63) / 64;          // interior / halo wave-loads per plane
     constexpr int WCHUNK = 27 * KS * NCT * 64;
     constexpr int WIT = (WCHUNK / 4 + T8_THREADS - 1) / T8_THREADS;
-    float* const Xs = smem;                         // [CK][T8_PS]
-    float* const Ws = smem + CK * T8_PS;            // [27][KS][NCT][64]
+    float* const Xs = smem;                         // [CK][PS]
+    float* const Ws = smem + CK * PS;               // [27][KS][NCT][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = lane >> 4, n = lane & 15;
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
 
     // tile of this block: block b runs on XCD b % 8 (observed; speed only), XCD x takes the contiguous tile range
     // [nt x / 8, nt (x+1) / 8) so that concurrently running neighbours share halo lines and weights in one L2
-    const int nw = (W + TW - 1) / TW, nh = (H + TH - 1) / TH, nd = (D + T8_TD - 1) / T8_TD;
+    const int nw = (W + TW - 1) / TW, nh = (H + ROWS - 1) / ROWS, nd = (D + T8_TD - 1) / T8_TD;
     const int ntiles = B * nd * nh * nw;
     int tile = blockIdx.x;
     if (ntiles >= 64) {
@@ -218,7 +222,7 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
     const int tw = tile % nw; int tq = tile / nw;
     const int th = tq % nh; tq /= nh;
     const int td = tq % nd; const int b = tq / nd;
-    const int d0 = td * T8_TD, h0 = th * TH, w0 = tw * TW;
+    const int d0 = td * T8_TD, h0 = th * ROWS, w0 = tw * TW;
     const int g = blockIdx.y;                       // output-channel group of 16*NCT
 
     const int V = D * H * W;
@@ -232,33 +236,29 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
     const int lq = lane & 3, lr4 = lane >> 2, lr2 = lane >> 1, hside = lane & 1;
     const int ibase = lr4 * RS + 2 + 4 * lq;
     const int hbase = lr2 * RS + (hside ? 18 : 1);
-    int vi[4], vh[2];              // byte offsets inside a plane; for the upsampled segment: of the half-resolution source
-    int viu[4], vhu[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    // per-lane byte offsets inside a plane (for the upsampled segment: of the half-resolution source); recomputed per chunk
+    // -- a few dozen VALU against 432 MFMAs -- rather than kept in 2 (NI + NHL) registers
+    auto off_i = [&](int j, bool up) __attribute__((always_inline)) -> int {
         const int rr = 16 * j + lr4;
-        const int gd = d0 - 1 + rr / HH, gh = h0 - 1 + rr % HH, gw = w0 + 4 * lq;
-        const bool ok = rr < (T8_TD + 2) * HH && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw < W;
-        vi[j] = ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB;
-        viu[j] = ok ? (((gd >> 1) * Hs + (gh >> 1)) * Ws2 + (gw >> 1)) << 2 : VXM_OOB;
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
+        const int gd = d0 - 1 + rr / HR, gh = h0 - 1 + rr % HR, gw = w0 + 4 * lq;
+        const bool ok = rr < NROW && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw < W;
+        return !ok ? VXM_OOB : (up ? (((gd >> 1) * Hs + (gh >> 1)) * Ws2 + (gw >> 1)) << 2 : ((gd * H + gh) * W + gw) << 2);
+    };
+    auto off_h = [&](int j, bool up) __attribute__((always_inline)) -> int {
         const int rr = 32 * j + lr2;
-        const int gd = d0 - 1 + rr / HH, gh = h0 - 1 + rr % HH, gw = hside ? w0 + TW : w0 - 1;
-        const bool ok = rr < (T8_TD + 2) * HH && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-        vh[j] = ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB;
-        vhu[j] = ok ? (((gd >> 1) * Hs + (gh >> 1)) * Ws2 + (gw >> 1)) << 2 : VXM_OOB;
-    }
+        const int gd = d0 - 1 + rr / HR, gh = h0 - 1 + rr % HR, gw = hside ? w0 + TW : w0 - 1;
+        const bool ok = rr < NROW && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        return !ok ? VXM_OOB : (up ? (((gd >> 1) * Hs + (gh >> 1)) * Ws2 + (gw >> 1)) << 2 : ((gd * H + gh) * W + gw) << 2);
+    };
 
-    f32x4 acc[NCT][4];
+    f32x4 acc[NCT][ROWS];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < ROWS; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 xi[4];
-    float xh[2];
+    f32x4 xi[NI];
+    float xh[NHL];
     f32x4 wv[WIT];
     auto load_chunk = [&](int q) __attribute__((always_inline)) {
         const int cg = q * CK + wave;               // channel staged by this wave (wave-uniform)
@@ -266,25 +266,26 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
             if (cg < iC0 && iup0) {
                 const int soff = cg * V0 * 4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r0, viu[j], soff, 0));
+                for (int j = 0; j < NI; ++j) {
+                    const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r0, off_i(j, true), soff, 0));
                     xi[j] = (f32x4){t.x, t.x, t.y, t.y};
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) xh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, vhu[j], soff, 0));
+                for (int j = 0; j < NHL; ++j) xh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, off_h(j, true), soff, 0));
             } else {
                 const bool s0 = cg < iC0;
                 const __amdgpu_buffer_rsrc_t r = s0 ? r0 : r1;
                 const int soff = (s0 ? cg * V0 : (cg - iC0) * V) * 4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vi[j], soff, 0));
+                for (int j = 0; j < NI; ++j) xi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off_i(j, false), soff, 0));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) xh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vh[j], soff, 0));
+                for (int j = 0; j < NHL; ++j) xh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off_h(j, false), soff, 0));
             }
         } else {                                    // channel padding of the last chunk
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xi[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            xh[0] = xh[1] = 0.0f;
+            for (int j = 0; j < NI; ++j) xi[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NHL; ++j) xh[j] = 0.0f;
         }
         const __amdgpu_buffer_rsrc_t rw = vxm_rsrc(wp + ((size_t)g * Q + q) * WCHUNK, WCHUNK * 4u);
 #pragma unroll
@@ -292,16 +293,16 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
             wv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + T8_THREADS * it) * 16, 0, 0));
     };
     auto store_chunk = [&]() __attribute__((always_inline)) {
-        float* dst = Xs + wave * T8_PS;
+        float* dst = Xs + wave * PS;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < 3 || lane < 48) {               // 240 interior slots
+        for (int j = 0; j < NI; ++j)
+            if (64 * j + lane < NROW * 4) {         // interior slots
                 *reinterpret_cast<f32x2*>(dst + ibase + 16 * j * RS) = (f32x2){xi[j].x, xi[j].y};
                 *reinterpret_cast<f32x2*>(dst + ibase + 16 * j * RS + 2) = (f32x2){xi[j].z, xi[j].w};
             }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            if (j < 1 || lane < 56) dst[hbase + 32 * j * RS] = xh[j];       // 120 halo slots
+        for (int j = 0; j < NHL; ++j)
+            if (64 * j + lane < NROW * 2) dst[hbase + 32 * j * RS] = xh[j];     // halo slots
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
             const int i = tid + T8_THREADS * it;
@@ -309,31 +310,31 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
         }
     };
 
-    const int bbase = kq * T8_PS + wave * HH * RS + n + 1;      // + 4 s planes, + (kd, r + kh) rows, + kw
+    const int bbase = kq * PS + wave * HR * RS + n + 1;      // + 4 s planes, + (kd, r + kh) rows, + kw
     load_chunk(0);
     store_chunk();
     __syncthreads();
     for (int q = 0; q < Q; ++q) {
         if (q + 1 < Q) load_chunk(q + 1);           // in flight under the MFMAs below
         // ---- 27 taps x KS k-steps x (NCT x 4) MFMAs, operands double-buffered in registers
-        float a[2][NCT], bv[2][4];
-        auto fetch = [&](int st, float (&af)[NCT], float (&bf)[4]) __attribute__((always_inline)) {
+        float a[2][NCT], bv[2][ROWS];
+        auto fetch = [&](int st, float (&af)[NCT], float (&bf)[ROWS]) __attribute__((always_inline)) {
             const int t = st / KS, s = st % KS;
             const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) af[ct] = Ws[((t * KS + s) * NCT + ct) * 64 + lane];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bf[r] = Xs[bbase + s * 4 * T8_PS + (kd * HH + r + kh) * RS + kw];
+            for (int r = 0; r < ROWS; ++r) bf[r] = Xs[bbase + s * 4 * PS + (kd * HR + r + kh) * RS + kw];
         };
         fetch(0, a[0], bv[0]);
 #pragma unroll
         for (int st = 0; st < 27 * KS; ++st) {
             if (st + 1 < 27 * KS) fetch(st + 1, a[(st + 1) & 1], bv[(st + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);       // keep the prefetch above the MFMAs (unpinned, the scheduler hoists every read)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[ct][r] = vxm_mfma16(a[st & 1][ct], bv[st & 1][r], acc[ct][r]);
+                for (int r = 0; r < ROWS; ++r) acc[ct][r] = vxm_mfma16(a[st & 1][ct], bv[st & 1][r], acc[ct][r]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (q + 1 < Q) {
@@ -347,14 +348,14 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
     const int d = d0 + wave, w = w0 + n;
     const bool vox_ok = d < D && w < W;
     const size_t vox_off = ((size_t)min(d, D - 1) * H) * W + min(w, W - 1);
-    float bz[NCT][4], mk[NCT][4][4];
+    float bz[NCT][4], mk[NCT][4][ROWS];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bz[ct][j] = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mk[ct][j][r] = 1.0f;
+            for (int r = 0; r < ROWS; ++r) mk[ct][j][r] = 1.0f;
         }
     if (bias) {
 #pragma unroll
@@ -370,14 +371,14 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
             for (int j = 0; j < 4; ++j) {
                 const int co = min((g * NCT + ct) * 16 + kq * 4 + j, Cout - 1);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mk[ct][j][r] = mb[(size_t)co * V + (size_t)min(h0 + r, H - 1) * W];
+                for (int r = 0; r < ROWS; ++r) mk[ct][j][r] = mb[(size_t)co * V + (size_t)min(h0 + r, H - 1) * W];
             }
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mk[ct][j][r] = vxm_lrelu_grad(mk[ct][j][r], mask_slope);
+                for (int r = 0; r < ROWS; ++r) mk[ct][j][r] = vxm_lrelu_grad(mk[ct][j][r], mask_slope);
     }
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
@@ -385,7 +386,7 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
         for (int j = 0; j < 4; ++j) {
             const int co = (g * NCT + ct) * 16 + kq * 4 + j;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < ROWS; ++r) {
                 const int h = h0 + r;
                 float v = acc[ct][r][j] + bz[ct][j];
                 v = (v > 0.0f ? v : v * act_slope) * mk[ct][j][r];
@@ -984,9 +985,12 @@ ConvCfg conv_cfg(int Cin, int Cout) {
     return c;
 }
 
+// rows per wave of the 8-wave kernel
+int fwd_wide_rows(const ConvCfg& c) { (void)c; return 4; }     // 6 rows with one output tile measured 4 % slower than 4
 bool fwd_wide_ok(const ConvCfg& c, const float* x0, int64_t bs0, const float* x1, int C1, int64_t bs1, const float* wpacked,
                  int B, int D, int H, int W) {
-    const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    const int rows = fwd_wide_rows(c);
+    const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + rows - 1) / rows) * ((W + TW - 1) / TW);
     return c.CK == 8 && c.NCT <= 2 && (W & 3) == 0 && al16(x0) && (C1 == 0 || al16(x1)) && (bs0 & 3) == 0 && (bs1 & 3) == 0 &&
            al16(wpacked) && tiles8 >= wide_min_tiles() && tiles8 < (1ll << 30) && !bw_force_generic();
 }
@@ -1038,20 +1042,23 @@ int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, co
     ConvIn in{x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up};
     // large layers: the 8-wave wide-load kernel (needs 4-float groups that neither straddle row ends nor break alignment)
     {
-        const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+        const int rows = fwd_wide_rows(c);
+        const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + rows - 1) / rows) * ((W + TW - 1) / TW);
         const bool vec = fwd_wide_ok(c, x0, x0_bstride, x1, C1, x1_bstride, wpacked, B, D, H, W);
         if (vec) {
             static bool opt_in = false;
             if (!opt_in) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_t8<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_t8<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_t8<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                 opt_in = true;
             }
             const dim3 grid8((unsigned)((tiles8 + 7) / 8 * 8), c.G);
-            const size_t lds8 = sizeof(float) * ((size_t)8 * T8_PS + 27 * 2 * c.NCT * 64);
-#define LAUNCH8(NCT_) hipLaunchKernelGGL((k_conv3d_k3_t8<NCT_>), grid8, dim3(T8_THREADS), lds8, VXM_STREAM(stream), in, wpacked, bias, y, \
+            const int plane8 = (T8_TD + 2) * (rows + 2) * BV_RS_FWD, ps8 = plane8 + (plane8 % 32 == 16 ? 0 : 16);
+            const size_t lds8 = sizeof(float) * ((size_t)8 * ps8 + 27 * 2 * c.NCT * 64);
+#define LAUNCH8(NCT_, ROWS_) hipLaunchKernelGGL((k_conv3d_k3_t8<NCT_, ROWS_>), grid8, dim3(T8_THREADS), lds8, VXM_STREAM(stream), in, wpacked, bias, y, \
         (long long)y_bstride, Cout, act_slope, mask_src, (long long)mask_bstride, mask_slope, B, D, H, W, c.Q)
-            if (c.NCT == 1) LAUNCH8(1);
-            else LAUNCH8(2);
+            if (c.NCT == 1) LAUNCH8(1, 4);
+            else LAUNCH8(2, 4);
 #undef LAUNCH8
             return vxm_check_launch("vxm_conv3d_k3_fwd");
         }
