@@ -56,7 +56,8 @@ int vxm_warp3d_bwd(const float* src, const float* flow, const float* gout, float
 /* ---- VecInt.forward, layers.py:64-68: v0 = vec/2^n; v_{k+1} = v_k + warp(v_k, v_k).
  * steps: [nsteps][B,3,D,H,W]; steps[k] receives v_{k+1}; the result is steps[nsteps-1]. */
 int vxm_vecint_fwd(const float* vec, float* steps, int B, int D, int H, int W, int nsteps, void* stream);
-/* backward: gout = dL/dv_n; gvec = dL/dvec.  work: 2*B*3*D*H*W floats of scratch. */
+/* backward: gout = dL/dv_n; gvec = dL/dvec.  work: 2*B*3*D*H*W + 32 floats of scratch (two gradient buffers and the
+ * per-step counters of voxels displaced by a voxel or more, which take the atomic path). */
 int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, float* gvec, float* work,
                    int B, int D, int H, int W, int nsteps, void* stream);
 

@@ -212,6 +212,143 @@ __global__ void __launch_bounds__(256) k_vecint_step_bwd(const float* __restrict
     atomicAdd(gi + 2 * (size_t)V + p, gx * scale);
 }
 
+// ---- the same step backward as a GATHER (no atomics in the regime of scaling and squaring) ---------------------------------
+// Voxel p scatters to the 8 corners of x'(p) = p + v(p).  When every |x'_a(p) - p_a| < 1 ("near": floor(x'_a) - p_a in {-1, 0}),
+// those corners lie in the 3x3x3 neighbourhood of p, so a target q only ever receives from the 27 voxels p = q + o, o in {-1,0,1}^3:
+//   gin_c(q) = scale * [ local_c(q) + sum_o near(q+o) * w(q; x'(q+o)) * g_c(q+o) ],   w = product over axes of
+//   (1 - fr_a) if q_a == floor(x'_a), fr_a if q_a == floor(x'_a) + 1, else 0          (fr = x' - floor(x'), the forward's weights)
+// A block stages, for its 4x8x32 tile grown by one voxel, the per-voxel record {fr_z, fr_y, fr_x, g_0, g_1, g_2, code} in LDS
+// (code: near flag + the three floor offsets) -- 3 IEEE divisions per staged voxel instead of per (voxel, neighbour) -- and every
+// thread sums its 27 candidates in a fixed order (deterministic).  Voxels that are not "near" (displacement >= 1 voxel: rare
+// in VecInt, whose steps are v / 2^k) are counted and handled by a second launch that adds only their contributions with
+// atomics; when the count is zero that launch exits at once.  gin needs no zeroing.
+constexpr int VG_TD = 4, VG_TH = 8, VG_TW = 32;
+constexpr int VG_LD = VG_TD + 2, VG_LH = VG_TH + 2, VG_LW = VG_TW + 2, VG_LN = VG_LD * VG_LH * VG_LW;      // 2040 staged voxels
+
+__device__ __forceinline__ void vg_axis(float xp, int p, int S, float& fr, int& frel, bool& near) {
+    const float f = floorf(xp);
+    fr = xp - f;
+    const float rel = f - (float)p;                       // exact for the magnitudes that matter; huge values fail the test below
+    near = rel == -1.0f || rel == 0.0f;
+    frel = rel == -1.0f ? 1 : 0;                          // 1: floor = p - 1
+    (void)S;
+}
+
+__global__ void __launch_bounds__(256) k_vecint_step_bwd_gather(const float* __restrict__ in, float scale, const float* __restrict__ gout,
+                                                                float* __restrict__ gin, unsigned* __restrict__ far_count, int D, int H, int W) {
+    __shared__ float rec[6][VG_LN];
+    __shared__ int code[VG_LN];
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int ntw = (W + VG_TW - 1) / VG_TW, nth = (H + VG_TH - 1) / VG_TH;
+    int t = blockIdx.x;
+    const int w0 = (t % ntw) * VG_TW; t /= ntw;
+    const int h0 = (t % nth) * VG_TH;
+    const int d0 = (t / nth) * VG_TD;
+    const int b = blockIdx.y;
+    const int HW = H * W, V = D * HW;
+    const float* vin = in + (size_t)b * 3 * V;
+    const float* go = gout + (size_t)b * 3 * V;
+    float* gi = gin + (size_t)b * 3 * V;
+    unsigned nfar = 0;
+    for (int i = tid; i < VG_LN; i += 256) {
+        const int lx = i % VG_LW, r = i / VG_LW, ly = r % VG_LH, lz = r / VG_LH;
+        const int pz = d0 - 1 + lz, py = h0 - 1 + ly, px = w0 - 1 + lx;
+        int c = 0;
+        float fz = 0.f, fy = 0.f, fx = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if ((unsigned)pz < (unsigned)D && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
+            const int p = pz * HW + py * W + px;
+            const float v0 = vin[p] * scale, v1 = vin[V + p] * scale, v2 = vin[2 * (size_t)V + p] * scale;
+            int rz, ry, rx;
+            bool nz, ny, nx;
+            vg_axis(vxm_src_coord(pz, v0, D), pz, D, fz, rz, nz);
+            vg_axis(vxm_src_coord(py, v1, H), py, H, fy, ry, ny);
+            vg_axis(vxm_src_coord(px, v2, W), px, W, fx, rx, nx);
+            if (nz && ny && nx) {
+                c = 8 | (rz << 2) | (ry << 1) | rx;
+                g0 = go[p]; g1 = go[V + p]; g2 = go[2 * (size_t)V + p];
+            } else if (lz >= 1 && lz <= VG_TD && ly >= 1 && ly <= VG_TH && lx >= 1 && lx <= VG_TW) {
+                ++nfar;                                   // counted once, by the tile that owns the voxel
+            }
+        }
+        rec[0][i] = fz; rec[1][i] = fy; rec[2][i] = fx; rec[3][i] = g0; rec[4][i] = g1; rec[5][i] = g2;
+        code[i] = c;
+    }
+    if (nfar) atomicAdd(far_count, nfar);
+    __syncthreads();
+    const int h = h0 + ty, w = w0 + tx;
+    if (h >= H || w >= W) return;
+    for (int dd = 0; dd < VG_TD; ++dd) {
+        const int d = d0 + dd;
+        if (d >= D) break;
+        const int p = d * HW + h * W + w;
+        // ---- local part: identity + derivative through the sampling position (the 8 corners of x'(q) gathered from v itself)
+        const float v0 = vin[p] * scale, v1 = vin[V + p] * scale, v2 = vin[2 * (size_t)V + p] * scale;
+        const float g0 = go[p], g1 = go[V + p], g2 = go[2 * (size_t)V + p];
+        const Corners8 cn = corners8(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W);
+        float gz = g0, gy = g1, gx = g2;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = cn.idx[k];
+            const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
+            const float sk = cn.ok[k] ? (vin[i] * scale) * g0 + (vin[V + i] * scale) * g1 + (vin[2 * (size_t)V + i] * scale) * g2 : 0.0f;
+            gz += (dz ? sk : -sk) * (cn.wy[dy] * cn.wx[dx]);
+            gy += (dy ? sk : -sk) * (cn.wz[dz] * cn.wx[dx]);
+            gx += (dx ? sk : -sk) * (cn.wz[dz] * cn.wy[dy]);
+        }
+        // ---- gathered part: the 27 possible senders
+        const int lq = ((dd + 1) * VG_LH + ty + 1) * VG_LW + tx + 1;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+        for (int oz = -1; oz <= 1; ++oz)
+#pragma unroll
+            for (int oy = -1; oy <= 1; ++oy)
+#pragma unroll
+                for (int ox = -1; ox <= 1; ++ox) {
+                    const int i = lq + (oz * VG_LH + oy) * VG_LW + ox;
+                    const int c = code[i];
+                    // axis a: sender p = q + o, floor(x') = p - frel; q is corner 0 if -o == -frel, corner 1 if -o == 1 - frel
+                    const int rz = (c >> 2) & 1, ry = (c >> 1) & 1, rx = c & 1;
+                    const float fz = rec[0][i], fy = rec[1][i], fx = rec[2][i];
+                    const float wz = (oz == rz) ? 1.0f - fz : ((oz == rz - 1) ? fz : 0.0f);
+                    const float wy = (oy == ry) ? 1.0f - fy : ((oy == ry - 1) ? fy : 0.0f);
+                    const float wx = (ox == rx) ? 1.0f - fx : ((ox == rx - 1) ? fx : 0.0f);
+                    const float wk = (c & 8) ? (wz * wy) * wx : 0.0f;
+                    a0 += rec[3][i] * wk; a1 += rec[4][i] * wk; a2 += rec[5][i] * wk;
+                }
+        gi[p] = (gz + a0) * scale;
+        gi[V + p] = (gy + a1) * scale;
+        gi[2 * (size_t)V + p] = (gx + a2) * scale;
+    }
+}
+
+// second launch of the step: the scatter contributions of the voxels the gather skipped (displacement >= 1 voxel), by atomics
+__global__ void __launch_bounds__(256) k_vecint_step_bwd_far(const float* __restrict__ in, float scale, const float* __restrict__ gout,
+                                                             float* __restrict__ gin, const unsigned* __restrict__ far_count, int D, int H, int W) {
+    if (far_count[0] == 0) return;
+    VXM_VOXEL_INDEX(D, H, W);
+    const float* vin = in + (size_t)b * 3 * V;
+    float* gi = gin + (size_t)b * 3 * V;
+    const float v0 = vin[p] * scale, v1 = vin[V + p] * scale, v2 = vin[2 * (size_t)V + p] * scale;
+    const float xz = vxm_src_coord(d, v0, D), xy = vxm_src_coord(h, v1, H), xx = vxm_src_coord(w, v2, W);
+    float fr;
+    int rr;
+    bool nz, ny, nx;
+    vg_axis(xz, d, D, fr, rr, nz); vg_axis(xy, h, H, fr, rr, ny); vg_axis(xx, w, W, fr, rr, nx);
+    if (nz && ny && nx) return;
+    const float* go = gout + (size_t)b * 3 * V + p;
+    const float g0 = go[0], g1 = go[V], g2 = go[2 * (size_t)V];
+    const Corners8 cn = corners8(xz, xy, xx, D, H, W);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (!cn.ok[k]) continue;
+        const int i = cn.idx[k];
+        const float wk = cn.w[k] * scale;
+        atomicAdd(gi + i, g0 * wk);
+        atomicAdd(gi + V + i, g1 * wk);
+        atomicAdd(gi + 2 * (size_t)V + i, g2 * wk);
+    }
+}
+
 // ATen upsample_trilinear3d(align_corners=True) index/lambda: real = ratio*dst; i0 = (int)real;
 // i1 = i0 + (i0 < in-1); l1 = real - i0; l0 = 1 - l1.
 __device__ __forceinline__ void lin_src(int dst, float ratio, int n_in, int& i0, int& i1, float& l0, float& l1) {
@@ -427,13 +564,20 @@ int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, floa
     VXM_REQUIRE(vec && steps && gout && gvec && work, VXM_ERR_NULL_POINTER, "vxm_vecint_bwd: null pointer");
     const size_t n = (size_t)B * 3 * D * H * W;
     const dim3 grid(vxm_blocks((long long)H * W, 256), D, B);
+    const long long tiles = (long long)((W + VG_TW - 1) / VG_TW) * ((H + VG_TH - 1) / VG_TH) * ((D + VG_TD - 1) / VG_TD);
+    VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_vecint_bwd: too many tiles");
+    const dim3 grid_t((unsigned)tiles, B);
     const float scale = 1.0f / (float)(1u << nsteps);
+    // per-step counters of the voxels the gather leaves to the atomic pass live behind the two gradient buffers
+    unsigned* far = reinterpret_cast<unsigned*>(work + 2 * n);
+    (void)hipMemsetAsync(far, 0, sizeof(unsigned) * 32, VXM_STREAM(stream));
     const float* g = gout;
     for (int k = nsteps - 1; k >= 0; --k) {
         const float* in = k == 0 ? vec : steps + (size_t)(k - 1) * n;
         float* gn = k == 0 ? gvec : work + (size_t)(k & 1) * n;
-        hipMemsetAsync(gn, 0, sizeof(float) * n, VXM_STREAM(stream));
-        hipLaunchKernelGGL(k_vecint_step_bwd, grid, dim3(256), 0, VXM_STREAM(stream), in, k == 0 ? scale : 1.0f, g, gn, D, H, W);
+        const float sc = k == 0 ? scale : 1.0f;
+        hipLaunchKernelGGL(k_vecint_step_bwd_gather, grid_t, dim3(256), 0, VXM_STREAM(stream), in, sc, g, gn, far + k, D, H, W);
+        hipLaunchKernelGGL(k_vecint_step_bwd_far, grid, dim3(256), 0, VXM_STREAM(stream), in, sc, g, gn, far + k, D, H, W);
         g = gn;
     }
     return vxm_check_launch("vxm_vecint_bwd");

@@ -83,7 +83,7 @@ class VecIntFn(torch.autograd.Function):
         B, _, D, H, W = vec.shape
         gout = _c(gout)
         gvec = torch.empty_like(vec)
-        work = torch.empty((2,) + tuple(vec.shape), dtype=vec.dtype, device=vec.device)
+        work = torch.empty(2 * vec.numel() + 32, dtype=vec.dtype, device=vec.device)     # two gradient buffers + step counters
         with _prof.region("vecint_bwd", nbytes=36.0 * B * D * H * W * ctx.nsteps):
             call("vxm_vecint_bwd", ptr(vec), ptr(steps), ptr(gout), ptr(gvec), ptr(work), B, D, H, W, ctx.nsteps, stream())
         return gvec, None
