@@ -182,6 +182,34 @@ int vxm_dice_fwd(const float* yt, const float* yp, float* loss, double* acc, int
 int vxm_dice_bwd(const float* yt, const float* yp, const double* acc, const float* gloss, float* gyt,
                  float* gyp, int B, int C, int64_t V, void* stream);
 
+/* ---- 2-D (planar) variants of the same layers for [B,C,H,W] images with 2-channel flows (channel 0 = row / H
+ * displacement, channel 1 = column / W); the reference classes are N-D generic (layers.py:11-97, losses.py:15-135,
+ * networks.py:83-85).  The 3x3 convolutions of a 2-D network go through vxm_conv3d_k3_* with D = 1. */
+int vxm_warp2d_fwd(const float* src, const float* flow, float* out, int B, int C, int H, int W, int mode, void* stream);
+int vxm_warp2d_bwd(const float* src, const float* flow, const float* gout, float* gsrc /* nullable */,
+                   float* gflow /* nullable */, int B, int C, int H, int W, int mode, void* stream);
+/* steps: [nsteps][B,2,H,W]; work (backward): 2*B*2*H*W floats */
+int vxm_vecint2d_fwd(const float* vec, float* steps, int B, int H, int W, int nsteps, void* stream);
+int vxm_vecint2d_bwd(const float* vec, const float* steps, const float* gout, float* gvec, float* work,
+                     int B, int H, int W, int nsteps, void* stream);
+int vxm_resize2d_fwd(const float* x, float* out, int B, int C, int H, int W, int oH, int oW, float factor, void* stream);
+int vxm_resize2d_bwd(const float* gout, float* gx, int B, int C, int H, int W, int oH, int oW, float factor, void* stream);
+/* MaxPool2d(2) and its gradient (first arg-max of each 2x2 block) */
+int vxm_maxpool2d_fwd(const float* x, float* y, int B, int C, int H, int W, void* stream);
+int vxm_maxpool2d_bwd(const float* x, const float* gpool, float* gx, int B, int C, int H, int W, void* stream);
+/* out = cat([Upsample(2,'nearest')(x0), x1], 1) at H x W; gradient of the upsampled segment from g [B,Ctot,2H,2W] */
+int vxm_upsample2d_cat(const float* x0, int C0, const float* x1, int C1, float* out, int B, int H, int W, void* stream);
+int vxm_upsample2d_bwd(const float* g, int Ctot, float* gx0, int C0, int B, int H /* low-res */, int W, void* stream);
+/* NCC with a win x win window: sums and work are 5 (forward) / 5 and 6 (backward) planes of B*H*W floats */
+int vxm_ncc2d_fwd(const float* I, const float* J, float* loss, float* sums, float* work, double* acc,
+                  int B, int H, int W, int win, void* stream);
+int vxm_ncc2d_bwd(const float* I, const float* J, const float* sums, const float* gloss, float* gJ, float* work,
+                  int B, int H, int W, int win, void* stream);
+int vxm_gradloss2d_fwd(const float* y, float* loss, double* acc, int B, int C, int H, int W, int penalty, float mult,
+                       void* stream);
+int vxm_gradloss2d_bwd(const float* y, const float* gloss, float* gy, int B, int C, int H, int W, int penalty,
+                       float mult, void* stream);
+
 /* ---- torch.optim.Adam.step (scripts/torch/train.py:161,220) over ONE flat fp32 buffer (which is
  * also the RCCL all-reduce bucket).  g is pre-multiplied by gscale (1/world_size). */
 int vxm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

@@ -37,3 +37,8 @@ def g_network():
 @pytest.fixture(scope="session")
 def g_dice():
     return load_golden("dice_metric.npz")
+
+
+@pytest.fixture(scope="session")
+def g_planar():
+    return load_golden("planar.npz")

@@ -215,10 +215,113 @@ def gold_dice_metric():
     save("dice_metric.npz", a=a, b=b, dice=d)
 
 
+def gold_planar():
+    """2-D cases of the same classes (the reference is N-D generic): layers, losses and a small VxmDense."""
+    rng = np.random.default_rng(21)
+    img = (24, 20)
+    out = {}
+    # --- bilinear warp, C=2, flow leaving the image at the borders
+    src = rng.random((2, 2) + img).astype(np.float32)
+    flow = smooth_flow(rng, (2,) + img, amp=3.0, nd=2)
+    s, f = t(src).requires_grad_(), t(flow).requires_grad_()
+    w = L.SpatialTransformer(img)(s, f)
+    gout = rng.standard_normal(w.shape).astype(np.float32)
+    w.backward(t(gout))
+    out.update(warp_src=src, warp_flow=flow, warp_out=w.detach().numpy(), warp_gout=gout, warp_gsrc=s.grad.numpy(),
+               warp_gflow=f.grad.numpy())
+    # --- nearest warp on tie flows (bit-exact case)
+    seg = rng.integers(0, 30, size=(1, 1) + img).astype(np.float32)
+    tie = (rng.integers(-4, 5, size=(1, 2) + img) * 0.5).astype(np.float32)
+    out.update(near_seg=seg, near_flow=tie, near_out=L.SpatialTransformer(img, mode="nearest")(t(seg), t(tie)).numpy())
+    # --- VecInt 5 steps
+    vec = smooth_flow(rng, (2,) + img, amp=2.5, nd=2)
+    v = t(vec).requires_grad_()
+    iv = L.VecInt(img, 5)(v)
+    giv = rng.standard_normal(iv.shape).astype(np.float32)
+    iv.backward(t(giv))
+    out.update(vecint_in=vec, vecint_out=iv.detach().numpy(), vecint_gout=giv, vecint_gin=v.grad.numpy())
+    # --- ResizeTransform down / up
+    xr = rng.standard_normal((2, 2) + img).astype(np.float32)
+    xd = t(xr).requires_grad_()
+    down = L.ResizeTransform(2, 2)(xd)
+    gdown = rng.standard_normal(down.shape).astype(np.float32)
+    down.backward(t(gdown))
+    xu = t(xr).requires_grad_()
+    up = L.ResizeTransform(0.5, 2)(xu)
+    gup = rng.standard_normal(up.shape).astype(np.float32)
+    up.backward(t(gup))
+    out.update(resize_in=xr, resize_down=down.detach().numpy(), resize_gdown=gdown, resize_down_gin=xd.grad.numpy(),
+               resize_up=up.detach().numpy(), resize_gup=gup, resize_up_gin=xu.grad.numpy())
+    # --- losses
+    I = rng.random((2, 1) + img).astype(np.float32)
+    J = (0.6 * I + 0.4 * rng.random((2, 1) + img)).astype(np.float32)
+    with ref_loader.cuda_alias_to_cpu():
+        for tag, win in (("ncc", None), ("ncc5", [5, 5])):
+            Jt = t(J).requires_grad_()
+            ncc = LS.NCC(win=win).loss(t(I), Jt)
+            ncc.backward()
+            out[tag] = ncc.detach().numpy()
+            out[tag + "_gJ"] = Jt.grad.numpy()
+    for pen, mult in (("l1", None), ("l2", 2)):
+        fl = t(flow).requires_grad_()
+        g = LS.Grad(pen, loss_mult=mult).loss(None, fl)
+        g.backward()
+        out["grad_%s" % pen] = g.detach().numpy()
+        out["grad_%s_g" % pen] = fl.grad.numpy()
+    out.update(I=I, J=J)
+    # --- VxmDense on 32 x 48 images
+    inshape = (32, 48)
+    srcn = rng.random((2, 1) + inshape).astype(np.float32)
+    trgn = rng.random((2, 1) + inshape).astype(np.float32)
+    out.update(source=srcn, target=trgn, inshape=np.array(inshape))
+    cases = {
+        "diffeo": dict(int_steps=5, int_downsize=2, bidir=False, loss="ncc", lam=1.0),
+        "dense": dict(int_steps=0, int_downsize=2, bidir=False, loss="mse", lam=0.01),
+        "bidir": dict(int_steps=3, int_downsize=2, bidir=True, loss="mse", lam=0.01),
+    }
+    for tag, cfg in cases.items():
+        sd = orc.seeded_state_dict(inshape, seed=7, flow_std=0.2)
+        model = N.VxmDense(inshape, int_steps=cfg["int_steps"], int_downsize=cfg["int_downsize"], bidir=cfg["bidir"])
+        missing = model.load_state_dict(sd, strict=False)
+        assert all(k.endswith(".grid") for k in missing.missing_keys) and not missing.unexpected_keys, missing
+        model.train()
+        pred = model(t(srcn), t(trgn))
+        with ref_loader.cuda_alias_to_cpu():
+            img_fn = LS.NCC().loss if cfg["loss"] == "ncc" else LS.MSE().loss
+            if cfg["bidir"]:
+                imgl = 0.5 * img_fn(t(trgn), pred[0]) + 0.5 * img_fn(t(srcn), pred[1])
+            else:
+                imgl = img_fn(t(trgn), pred[0])
+            reg = LS.Grad("l2", loss_mult=cfg["int_downsize"]).loss(None, pred[-1])
+            loss = imgl + cfg["lam"] * reg
+            loss.backward()
+        out[tag + "_y_source"] = pred[0].detach().numpy()
+        if cfg["bidir"]:
+            out[tag + "_y_target"] = pred[1].detach().numpy()
+        out[tag + "_preint"] = pred[-1].detach().numpy()
+        out[tag + "_loss"] = np.array([loss.item(), imgl.item(), reg.item()])
+        names, norms = [], []
+        for k, p in model.named_parameters():
+            names.append(k)
+            norms.append(float(p.grad.double().norm()))
+            if k in KEEP_FULL:
+                out[tag + "_grad_" + k] = p.grad.numpy().copy()
+        out[tag + "_grad_names"] = np.array(names)
+        out[tag + "_grad_norms"] = np.array(norms)
+        with torch.no_grad():
+            _, pos = model(t(srcn), t(trgn), registration=True)
+        out[tag + "_pos_flow"] = pos.numpy()
+    m = N.VxmDense((16, 16))
+    out["state_keys"] = np.array(list(m.state_dict().keys()))
+    out["state_shapes"] = np.array([str(tuple(v.shape)) for v in m.state_dict().values()])
+    save("planar.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    gold_layers()
-    gold_losses()
-    gold_network()
-    gold_dice_metric()
+    only = sys.argv[1:]          # e.g. `make_golden.py planar` regenerates one file and leaves the others untouched
+    for name, fn in (("layers", gold_layers), ("losses", gold_losses), ("network", gold_network),
+                     ("dice_metric", gold_dice_metric), ("planar", gold_planar)):
+        if not only or name in only:
+            fn()

@@ -94,6 +94,26 @@ def test_api_surface_matches_reference_signatures():
     assert m0.integrate is None and m0.resize is None and m0.fullsize is None
 
 
+def test_planar_model_surface(g_planar):
+    """2-D images: same classes, reference state-dict layout ([Cout,Cin,3,3] weights, 2-channel flow conv, 2-D grids),
+    bilinear resize mode, and the no-CPU-fallback rule."""
+    m = vxm.networks.VxmDense((32, 48), int_steps=5)
+    assert [k for k in m.state_dict().keys()] == [str(k) for k in g_planar["state_keys"]]
+    shapes = {k: tuple(v.shape) for k, v in vxm.networks.VxmDense((16, 16)).state_dict().items()}
+    assert [str(shapes[str(k)]) for k in g_planar["state_keys"]] == [str(s) for s in g_planar["state_shapes"]]
+    assert m.resize.mode == "bilinear" and m.flow.weight.shape == (2, 16, 3, 3) and m.transformer.grid.shape == (1, 2, 32, 48)
+    assert m.integrate.transformer.grid.shape == (1, 2, 16, 24)
+    x = torch.zeros(1, 1, 32, 48)
+    with pytest.raises(_lib.VxmHipError):
+        m(x, x)
+    with pytest.raises(_lib.VxmHipError):
+        vxm.losses.NCC().loss(x, x)
+    with pytest.raises(_lib.VxmHipError):
+        vxm.losses.Grad("l2").loss(None, torch.zeros(1, 2, 8, 8))
+    with pytest.raises(NotImplementedError):
+        vxm.networks.Unet((32,), infeats=2)
+
+
 def test_semisupervised_seg_model_surface(tmp_path):
     """Constructor arguments / attributes of the TF reference model (tf/networks.py:293-367) on the torch-side API,
     config capture + checkpoint round trip through LoadableModel, and the no-CPU-fallback rule."""

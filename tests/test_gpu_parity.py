@@ -600,3 +600,115 @@ def test_full_size_train_step_runs_and_is_linear_in_lr(vxm):
     assert all(np.isfinite(losses)) and -1.0 <= losses[0] <= 0.0
     assert y.shape == (1, 1) + FULL and pre.shape == (1, 3, 80, 96, 112)
     assert float(opt.flat_grad.abs().sum()) > 0
+
+
+# ------------------------------------------------------------------ 2-D (planar) variants: golden fixtures from the reference
+def test_planar_layers_golden(vxm, g_planar):
+    g = g_planar
+    img = g["warp_src"].shape[2:]
+    s, f = G(g["warp_src"], True), G(g["warp_flow"], True)
+    out = vxm.layers.SpatialTransformer(img).cuda()(s, f)
+    np.testing.assert_allclose(N(out), g["warp_out"], atol=1e-5, rtol=0)
+    out.backward(G(g["warp_gout"]))
+    np.testing.assert_allclose(N(s.grad), g["warp_gsrc"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(N(f.grad), g["warp_gflow"], atol=2e-5, rtol=0)
+    near = vxm.layers.SpatialTransformer(img, mode="nearest").cuda()(G(g["near_seg"]), G(g["near_flow"]))
+    assert np.array_equal(N(near), g["near_out"])                     # label warp: bit-exact
+    v = G(g["vecint_in"], True)
+    iv = vxm.layers.VecInt(img, 5).cuda()(v)
+    np.testing.assert_allclose(N(iv), g["vecint_out"], atol=1e-4, rtol=0)
+    iv.backward(G(g["vecint_gout"]))
+    np.testing.assert_allclose(N(v.grad), g["vecint_gin"], atol=2e-4, rtol=1e-4)
+    x = G(g["resize_in"], True)
+    down = vxm.layers.ResizeTransform(2, 2)(x)
+    np.testing.assert_allclose(N(down), g["resize_down"], atol=2e-6, rtol=0)
+    down.backward(G(g["resize_gdown"]))
+    np.testing.assert_allclose(N(x.grad), g["resize_down_gin"], atol=1e-5, rtol=0)
+    x2 = G(g["resize_in"], True)
+    up = vxm.layers.ResizeTransform(0.5, 2)(x2)
+    np.testing.assert_allclose(N(up), g["resize_up"], atol=1e-5, rtol=0)        # O(10) values after the x2 rescale: a few fp32 ulps (FMA contraction)
+    up.backward(G(g["resize_gup"]))
+    np.testing.assert_allclose(N(x2.grad), g["resize_up_gin"], atol=2e-5, rtol=0)
+
+
+def test_planar_losses_golden(vxm, g_planar):
+    g = g_planar
+    for tag, win in (("ncc", None), ("ncc5", [5, 5])):
+        J = G(g["J"], True)
+        l = vxm.losses.NCC(win=win).loss(G(g["I"]), J)
+        assert abs(float(l) - float(g[tag])) < 1e-3
+        ref64 = orc.ncc_loss(torch.from_numpy(g["I"]), torch.from_numpy(g["J"]), win=win, dtype=torch.float64).item()
+        assert abs(float(l) - ref64) < 1e-5
+        l.backward()
+        assert rel_l2(N(J.grad), g[tag + "_gJ"]) < 2e-3
+    for pen, mult in (("l1", None), ("l2", 2)):
+        fl = G(g["warp_flow"], True)
+        l = vxm.losses.Grad(pen, loss_mult=mult).loss(None, fl)
+        np.testing.assert_allclose(float(l), float(g["grad_%s" % pen]), rtol=1e-5)
+        l.backward()
+        np.testing.assert_allclose(N(fl.grad), g["grad_%s_g" % pen], atol=1e-8, rtol=1e-5)
+
+
+def test_planar_unet_blocks_vs_oracle(vxm):
+    """MaxPool2d / Upsample+cat / depth-one MFMA conv against the oracle's ATen composition, forward and gradients."""
+    torch.manual_seed(7)
+    net = vxm.networks.Unet((32, 48), infeats=2).cuda()
+    sd = {"unet_model." + k: v.detach().cpu().double().requires_grad_() for k, v in net.state_dict().items()}
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 2, 32, 48)).astype(np.float32)
+    xg = G(x, True)
+    y = net(xg)
+    xo = torch.from_numpy(x).double().requires_grad_()
+    yo = orc.unet_forward(xo, sd)
+    assert rel_l2(N(y), yo.detach().numpy()) < 1e-5
+    gy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(G(gy))
+    yo.backward(torch.from_numpy(gy).double())
+    for name, p in net.named_parameters():
+        assert rel_l2(N(p.grad), sd["unet_model." + name].grad.numpy()) < 1e-4, name
+    assert rel_l2(N(xg.grad), xo.grad.numpy()) < 1e-4
+
+
+PLANAR_CASES = {
+    "diffeo": dict(int_steps=5, int_downsize=2, bidir=False, loss="ncc", lam=1.0),
+    "dense": dict(int_steps=0, int_downsize=2, bidir=False, loss="mse", lam=0.01),
+    "bidir": dict(int_steps=3, int_downsize=2, bidir=True, loss="mse", lam=0.01),
+}
+
+
+@pytest.mark.parametrize("tag", list(PLANAR_CASES))
+def test_planar_vxm_dense_golden(vxm, g_planar, tag):
+    g, cfg = g_planar, PLANAR_CASES[tag]
+    inshape = tuple(int(v) for v in g["inshape"])
+    model = vxm.networks.VxmDense(inshape, int_steps=cfg["int_steps"], int_downsize=cfg["int_downsize"], bidir=cfg["bidir"])
+    res = model.load_state_dict(orc.seeded_state_dict(inshape, seed=7, flow_std=0.2), strict=False)
+    assert all(k.endswith(".grid") for k in res.missing_keys) and not res.unexpected_keys
+    if cfg["int_steps"] > 0:
+        assert [k for k in model.state_dict().keys()] == [str(k) for k in g["state_keys"]]
+    model = model.cuda()
+    src, trg = G(g["source"]), G(g["target"])
+    pred = model(src, trg)
+    img_fn = vxm.losses.NCC().loss if cfg["loss"] == "ncc" else vxm.losses.MSE().loss
+    if cfg["bidir"]:
+        img = 0.5 * img_fn(trg, pred[0]) + 0.5 * img_fn(src, pred[1])
+        np.testing.assert_allclose(N(pred[1]), g[tag + "_y_target"], atol=2e-5, rtol=0)
+    else:
+        img = img_fn(trg, pred[0])
+    reg = vxm.losses.Grad("l2", loss_mult=cfg["int_downsize"]).loss(None, pred[-1])
+    loss = img + cfg["lam"] * reg
+    np.testing.assert_allclose(N(pred[0]), g[tag + "_y_source"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(N(pred[-1]), g[tag + "_preint"], atol=2e-5, rtol=0)
+    ref = g[tag + "_loss"]
+    assert abs(float(loss) - ref[0]) < 1e-3 * max(1.0, abs(ref[0]))
+    loss.backward()
+    params = dict(model.named_parameters())
+    tol = 2e-3 if cfg["loss"] == "ncc" else 1e-4
+    for n, r in zip([str(n) for n in g[tag + "_grad_names"]], g[tag + "_grad_norms"]):
+        got = float(params[n].grad.double().norm())
+        assert abs(got - r) <= tol * max(r, 1e-12), (n, got, r)
+    for key in g.files:
+        if key.startswith(tag + "_grad_") and key not in (tag + "_grad_names", tag + "_grad_norms"):
+            assert rel_l2(N(params[key[len(tag + "_grad_"):]].grad), g[key]) < tol, key
+    with torch.no_grad():
+        _, pos = model(src, trg, registration=True)
+    np.testing.assert_allclose(N(pos), g[tag + "_pos_flow"], atol=1e-4, rtol=0)

@@ -176,6 +176,67 @@ def test_conv_c_arbiter():
     np.testing.assert_allclose(c_oracle.conv3d_k3(x, w, b), ref, atol=2e-5)
 
 
+# ------------------------------------------------------------------ 2-D (planar) cases of the same classes
+def test_planar_layers(g_planar):
+    g = g_planar
+    s, f = T(g["warp_src"]).requires_grad_(), T(g["warp_flow"]).requires_grad_()
+    out = orc.spatial_transformer(s, f)
+    assert torch.equal(out.detach(), T(g["warp_out"]))
+    out.backward(T(g["warp_gout"]))
+    np.testing.assert_allclose(s.grad.numpy(), g["warp_gsrc"], atol=1e-6)
+    np.testing.assert_allclose(f.grad.numpy(), g["warp_gflow"], atol=1e-5)
+    np.testing.assert_allclose(orc.warp_explicit(g["warp_src"], g["warp_flow"]), g["warp_out"], atol=2e-6)
+    assert np.array_equal(orc.warp_explicit(g["near_seg"], g["near_flow"], mode="nearest"), g["near_out"])
+    v = T(g["vecint_in"]).requires_grad_()
+    iv = orc.vecint(v, 5)
+    assert torch.equal(iv.detach(), T(g["vecint_out"]))
+    iv.backward(T(g["vecint_gout"]))
+    np.testing.assert_allclose(v.grad.numpy(), g["vecint_gin"], atol=1e-5)
+    assert torch.equal(orc.resize_transform(T(g["resize_in"]), 2), T(g["resize_down"]))
+    assert torch.equal(orc.resize_transform(T(g["resize_in"]), 0.5), T(g["resize_up"]))
+    np.testing.assert_allclose(orc.resize_explicit(g["resize_in"], 2), g["resize_down"], atol=2e-6)
+    np.testing.assert_allclose(orc.resize_explicit(g["resize_in"], 0.5), g["resize_up"], atol=2e-6)
+
+
+def test_planar_losses(g_planar):
+    g = g_planar
+    I, J = T(g["I"]), T(g["J"]).requires_grad_()
+    l = orc.ncc_loss(I, J)
+    np.testing.assert_allclose(l.item(), g["ncc"], rtol=1e-6)
+    l.backward()
+    np.testing.assert_allclose(J.grad.numpy(), g["ncc_gJ"], atol=1e-7)
+    np.testing.assert_allclose(orc.ncc_loss(I, T(g["J"]), win=[5, 5]).item(), g["ncc5"], rtol=1e-6)
+    fl = T(g["warp_flow"]).requires_grad_()
+    np.testing.assert_allclose(orc.grad_loss(fl, "l1").item(), g["grad_l1"], rtol=1e-6)
+    l2 = orc.grad_loss(fl, "l2", 2)
+    np.testing.assert_allclose(l2.item(), g["grad_l2"], rtol=1e-6)
+    l2.backward()
+    np.testing.assert_allclose(fl.grad.numpy(), g["grad_l2_g"], atol=1e-8)
+
+
+@pytest.mark.parametrize("tag,kw,loss,lam", [
+    ("diffeo", dict(int_steps=5, int_downsize=2), "ncc", 1.0),
+    ("dense", dict(int_steps=0, int_downsize=2), "mse", 0.01),
+])
+def test_planar_vxm_dense(g_planar, tag, kw, loss, lam):
+    g = g_planar
+    inshape = tuple(int(v) for v in g["inshape"])
+    sd = orc.seeded_state_dict(inshape, seed=7, flow_std=0.2)
+    for v in sd.values():
+        v.requires_grad_()
+    src, trg = T(g["source"]), T(g["target"])
+    total, (img, reg, ys, pre) = orc.train_step_loss(src, trg, sd, image_loss=loss, lam=lam, **kw)
+    np.testing.assert_allclose(ys.detach().numpy(), g[tag + "_y_source"], atol=1e-6)
+    np.testing.assert_allclose(pre.detach().numpy(), g[tag + "_preint"], atol=1e-6)
+    np.testing.assert_allclose([total.item(), img.item(), reg.item()], g[tag + "_loss"], rtol=1e-5)
+    total.backward()
+    for n, ref in zip([str(n) for n in g[tag + "_grad_names"]], g[tag + "_grad_norms"]):
+        got = float(sd[n].grad.double().norm())
+        assert abs(got - ref) <= 1e-4 * max(ref, 1e-12), (n, got, ref)
+    keys = [str(k) for k in g["state_keys"] if not str(k).endswith(".grid")]
+    assert [k for k, _ in orc.state_dict_shapes((16, 16))] == keys
+
+
 @pytest.mark.skipif(not ref_loader.reference_available(), reason="reference tree not present")
 def test_live_reference_agrees():
     vxm = ref_loader.load_reference()

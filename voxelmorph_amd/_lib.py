@@ -55,6 +55,20 @@ SIGNATURES = {
     "vxm_mse_bwd": [_P, _P, _P, _P, _P, _L, _P],
     "vxm_dice_fwd": [_P, _P, _P, _P, _I, _I, _L, _P],
     "vxm_dice_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _L, _P],
+    "vxm_warp2d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vxm_warp2d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vxm_vecint2d_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "vxm_vecint2d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vxm_resize2d_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "vxm_resize2d_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "vxm_maxpool2d_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "vxm_maxpool2d_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vxm_upsample2d_cat": [_P, _I, _P, _I, _P, _I, _I, _I, _P],
+    "vxm_upsample2d_bwd": [_P, _I, _P, _I, _I, _I, _I, _P],
+    "vxm_ncc2d_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vxm_ncc2d_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vxm_gradloss2d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "vxm_gradloss2d_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "vxm_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
 }
 _RESTYPES = {

@@ -317,22 +317,24 @@ __global__ void __launch_bounds__(256) k_gradloss_fwd(const float* __restrict__ 
     block_atomic_add(sw, acc + b * 3 + 2, red);
 }
 
-__global__ void k_gradloss_finish(const double* __restrict__ acc, float* __restrict__ loss, int B, int C, int D, int H, int W, double mult) {
+// `axes` = 3 for volumes, 2 for planar images passed with D = 1 (no difference along D exists: that term is left out)
+__global__ void k_gradloss_finish(const double* __restrict__ acc, float* __restrict__ loss, int B, int C, int D, int H, int W, double mult,
+                                  int axes) {
     if (threadIdx.x || blockIdx.x) return;
     const double nd = (double)C * (D - 1) * H * W, nh = (double)C * D * (H - 1) * W, nw = (double)C * D * H * (W - 1);
     double tot = 0.0;
-    for (int b = 0; b < B; ++b) tot += mult * (acc[b * 3] / nd + acc[b * 3 + 1] / nh + acc[b * 3 + 2] / nw) / 3.0;
+    for (int b = 0; b < B; ++b) tot += mult * ((axes == 3 ? acc[b * 3] / nd : 0.0) + acc[b * 3 + 1] / nh + acc[b * 3 + 2] / nw) / (double)axes;
     loss[0] = (float)(tot / B);
 }
 
 template <int L2>
 __global__ void __launch_bounds__(256) k_gradloss_bwd(const float* __restrict__ y, const float* __restrict__ gloss, float* __restrict__ gy,
-                                                      int B, int C, int D, int H, int W, float mult) {
+                                                      int B, int C, int D, int H, int W, float mult, int axes) {
     const long long V = (long long)D * H * W, n = V * C;
     const size_t b = blockIdx.y;
     const float* yb = y + b * (size_t)n;
-    const float base = gloss[0] * mult / (3.0f * (float)B);
-    const float kd = base / ((float)C * (D - 1) * H * W), kh = base / ((float)C * D * (H - 1) * W), kw = base / ((float)C * D * H * (W - 1));
+    const float base = gloss[0] * mult / ((float)axes * (float)B);
+    const float kd = axes == 3 ? base / ((float)C * (D - 1) * H * W) : 0.0f, kh = base / ((float)C * D * (H - 1) * W), kw = base / ((float)C * D * H * (W - 1));
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const int q = (int)(i % V);
         const int w = q % W, t = q / W, h = t % H, d = t / H;
@@ -433,6 +435,22 @@ unsigned stream_blocks(long long n) {
     return (unsigned)(nb > 8192 ? 8192 : (nb < 1 ? 1 : nb));
 }
 
+// generic separable NCC passes; `sums` receives the five box sums, `work` is 5 (forward) / 6 (backward) planes of scratch
+void ncc_generic_fwd(const float* I, const float* J, float* sums, float* work, double* acc, long long BV, int D, int H, int W, int r, float n,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(k_ncc_prod_w, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, I, J, sums, BV, W, r);
+    hipLaunchKernelGGL(k_box_axis, dim3(vxm_blocks(5 * BV, 256)), dim3(256), 0, s, sums, work, 5 * BV, H, (long long)W, r);
+    hipLaunchKernelGGL(k_ncc_cc, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, work, sums, acc, BV, D, (long long)H * W, r, n);
+}
+void ncc_generic_bwd(const float* I, const float* J, const float* sums, const float* gloss, float* gJ, float* work, long long BV, int D, int H,
+                     int W, int r, float n, hipStream_t s) {
+    float* u1 = work;
+    float* u2 = work + 3 * BV;
+    hipLaunchKernelGGL(k_ncc_abc_d, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, sums, u1, BV, D, (long long)H * W, r, n);
+    hipLaunchKernelGGL(k_box_axis, dim3(vxm_blocks(3 * BV, 256)), dim3(256), 0, s, u1, u2, 3 * BV, H, (long long)W, r);
+    hipLaunchKernelGGL(k_ncc_grad_w, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, u2, I, J, gloss, gJ, BV, W, r);
+}
+
 }  // namespace
 
 extern "C" {
@@ -454,9 +472,7 @@ int vxm_ncc_fwd(const float* I, const float* J, float* loss, float* sums, float*
             default: hipLaunchKernelGGL(k_ncc_fused_fwd<4>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV); break;
         }
     } else {                                            // generic separable passes; `sums` receives the five box sums
-        hipLaunchKernelGGL(k_ncc_prod_w, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, I, J, sums, BV, W, r);
-        hipLaunchKernelGGL(k_box_axis, dim3(vxm_blocks(5 * BV, 256)), dim3(256), 0, s, sums, work, 5 * BV, H, (long long)W, r);
-        hipLaunchKernelGGL(k_ncc_cc, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, work, sums, acc, BV, D, (long long)H * W, r, (float)win * win * win);
+        ncc_generic_fwd(I, J, sums, work, acc, BV, D, H, W, r, (float)win * win * win, s);
     }
     hipLaunchKernelGGL(k_finish_mean, dim3(1), dim3(64), 0, s, acc, loss, -1.0 / (double)BV);
     return vxm_check_launch("vxm_ncc_fwd");
@@ -479,35 +495,67 @@ int vxm_ncc_bwd(const float* I, const float* J, const float* sums, const float* 
         }
         return vxm_check_launch("vxm_ncc_bwd");
     }
-    float* u1 = work;
-    float* u2 = work + 3 * BV;
-    hipLaunchKernelGGL(k_ncc_abc_d, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, sums, u1, BV, D, (long long)H * W, r, (float)win * win * win);
-    hipLaunchKernelGGL(k_box_axis, dim3(vxm_blocks(3 * BV, 256)), dim3(256), 0, s, u1, u2, 3 * BV, H, (long long)W, r);
-    hipLaunchKernelGGL(k_ncc_grad_w, dim3(vxm_blocks(BV, 256)), dim3(256), 0, s, u2, I, J, gloss, gJ, BV, W, r);
+    ncc_generic_bwd(I, J, sums, gloss, gJ, work, BV, D, H, W, r, (float)win * win * win, s);
     return vxm_check_launch("vxm_ncc_bwd");
 }
 
-int vxm_gradloss_fwd(const float* y, float* loss, double* acc, int B, int C, int D, int H, int W, int penalty, float mult, void* stream) {
-    VXM_REQUIRE(y && loss && acc, VXM_ERR_NULL_POINTER, "vxm_gradloss_fwd: null pointer");
-    VXM_REQUIRE(B > 0 && B <= 65535 && C > 0 && D > 1 && H > 1 && W > 1, VXM_ERR_BAD_SHAPE, "vxm_gradloss_fwd: bad shape");
+/* planar NCC (losses.py:15-67 with ndims = 2: win x win box filter, win_size = win^2): the separable passes with a depth of one */
+int vxm_ncc2d_fwd(const float* I, const float* J, float* loss, float* sums, float* work, double* acc, int B, int H, int W, int win, void* stream) {
+    VXM_REQUIRE(I && J && loss && sums && work && acc, VXM_ERR_NULL_POINTER, "vxm_ncc2d_fwd: null pointer");
+    VXM_REQUIRE(B > 0 && H > 0 && W > 0 && win > 0 && (win & 1), VXM_ERR_BAD_SHAPE, "vxm_ncc2d_fwd: bad shape / even window %d", win);
+    const long long BV = (long long)B * H * W;
+    hipStream_t s = VXM_STREAM(stream);
+    (void)hipMemsetAsync(acc, 0, sizeof(double), s);
+    ncc_generic_fwd(I, J, sums, work, acc, BV, 1, H, W, win / 2, (float)win * win, s);
+    hipLaunchKernelGGL(k_finish_mean, dim3(1), dim3(64), 0, s, acc, loss, -1.0 / (double)BV);
+    return vxm_check_launch("vxm_ncc2d_fwd");
+}
+
+int vxm_ncc2d_bwd(const float* I, const float* J, const float* sums, const float* gloss, float* gJ, float* work, int B, int H, int W, int win,
+                  void* stream) {
+    VXM_REQUIRE(I && J && sums && gloss && gJ && work, VXM_ERR_NULL_POINTER, "vxm_ncc2d_bwd: null pointer");
+    VXM_REQUIRE(B > 0 && H > 0 && W > 0 && win > 0 && (win & 1), VXM_ERR_BAD_SHAPE, "vxm_ncc2d_bwd: bad shape / even window %d", win);
+    ncc_generic_bwd(I, J, sums, gloss, gJ, work, (long long)B * H * W, 1, H, W, win / 2, (float)win * win, VXM_STREAM(stream));
+    return vxm_check_launch("vxm_ncc2d_bwd");
+}
+
+static int gradloss_fwd(const char* fn, const float* y, float* loss, double* acc, int B, int C, int D, int H, int W, int penalty, float mult,
+                        int axes, void* stream) {
+    VXM_REQUIRE(y && loss && acc, VXM_ERR_NULL_POINTER, "%s: null pointer", fn);
+    VXM_REQUIRE(B > 0 && B <= 65535 && C > 0 && (axes == 2 || D > 1) && H > 1 && W > 1, VXM_ERR_BAD_SHAPE, "%s: bad shape", fn);
     VXM_REQUIRE(penalty == VXM_PENALTY_L1 || penalty == VXM_PENALTY_L2, VXM_ERR_UNSUPPORTED, "penalty can only be l1 or l2. Got: %d", penalty);
     hipStream_t s = VXM_STREAM(stream);
     (void)hipMemsetAsync(acc, 0, sizeof(double) * 3 * B, s);
     const dim3 grid(reduce_blocks((long long)C * D * H * W), B);
     if (penalty == VXM_PENALTY_L2) hipLaunchKernelGGL(k_gradloss_fwd<1>, grid, dim3(256), 0, s, y, acc, C, D, H, W);
     else hipLaunchKernelGGL(k_gradloss_fwd<0>, grid, dim3(256), 0, s, y, acc, C, D, H, W);
-    hipLaunchKernelGGL(k_gradloss_finish, dim3(1), dim3(64), 0, s, acc, loss, B, C, D, H, W, (double)mult);
-    return vxm_check_launch("vxm_gradloss_fwd");
+    hipLaunchKernelGGL(k_gradloss_finish, dim3(1), dim3(64), 0, s, acc, loss, B, C, D, H, W, (double)mult, axes);
+    return vxm_check_launch(fn);
 }
 
-int vxm_gradloss_bwd(const float* y, const float* gloss, float* gy, int B, int C, int D, int H, int W, int penalty, float mult, void* stream) {
-    VXM_REQUIRE(y && gloss && gy, VXM_ERR_NULL_POINTER, "vxm_gradloss_bwd: null pointer");
-    VXM_REQUIRE(B > 0 && B <= 65535 && C > 0 && D > 1 && H > 1 && W > 1, VXM_ERR_BAD_SHAPE, "vxm_gradloss_bwd: bad shape");
+static int gradloss_bwd(const char* fn, const float* y, const float* gloss, float* gy, int B, int C, int D, int H, int W, int penalty, float mult,
+                        int axes, void* stream) {
+    VXM_REQUIRE(y && gloss && gy, VXM_ERR_NULL_POINTER, "%s: null pointer", fn);
+    VXM_REQUIRE(B > 0 && B <= 65535 && C > 0 && (axes == 2 || D > 1) && H > 1 && W > 1, VXM_ERR_BAD_SHAPE, "%s: bad shape", fn);
     VXM_REQUIRE(penalty == VXM_PENALTY_L1 || penalty == VXM_PENALTY_L2, VXM_ERR_UNSUPPORTED, "penalty can only be l1 or l2. Got: %d", penalty);
     const dim3 grid(stream_blocks((long long)C * D * H * W), B);
-    if (penalty == VXM_PENALTY_L2) hipLaunchKernelGGL(k_gradloss_bwd<1>, grid, dim3(256), 0, VXM_STREAM(stream), y, gloss, gy, B, C, D, H, W, mult);
-    else hipLaunchKernelGGL(k_gradloss_bwd<0>, grid, dim3(256), 0, VXM_STREAM(stream), y, gloss, gy, B, C, D, H, W, mult);
-    return vxm_check_launch("vxm_gradloss_bwd");
+    if (penalty == VXM_PENALTY_L2) hipLaunchKernelGGL(k_gradloss_bwd<1>, grid, dim3(256), 0, VXM_STREAM(stream), y, gloss, gy, B, C, D, H, W, mult, axes);
+    else hipLaunchKernelGGL(k_gradloss_bwd<0>, grid, dim3(256), 0, VXM_STREAM(stream), y, gloss, gy, B, C, D, H, W, mult, axes);
+    return vxm_check_launch(fn);
+}
+
+int vxm_gradloss_fwd(const float* y, float* loss, double* acc, int B, int C, int D, int H, int W, int penalty, float mult, void* stream) {
+    return gradloss_fwd("vxm_gradloss_fwd", y, loss, acc, B, C, D, H, W, penalty, mult, 3, stream);
+}
+int vxm_gradloss_bwd(const float* y, const float* gloss, float* gy, int B, int C, int D, int H, int W, int penalty, float mult, void* stream) {
+    return gradloss_bwd("vxm_gradloss_bwd", y, gloss, gy, B, C, D, H, W, penalty, mult, 3, stream);
+}
+/* planar Grad (losses.py:102-135 with ndims = 2): the same kernels over [B,C,1,H,W], two axes */
+int vxm_gradloss2d_fwd(const float* y, float* loss, double* acc, int B, int C, int H, int W, int penalty, float mult, void* stream) {
+    return gradloss_fwd("vxm_gradloss2d_fwd", y, loss, acc, B, C, 1, H, W, penalty, mult, 2, stream);
+}
+int vxm_gradloss2d_bwd(const float* y, const float* gloss, float* gy, int B, int C, int H, int W, int penalty, float mult, void* stream) {
+    return gradloss_bwd("vxm_gradloss2d_bwd", y, gloss, gy, B, C, 1, H, W, penalty, mult, 2, stream);
 }
 
 int vxm_mse_fwd(const float* a, const float* b, float* loss, double* acc, int64_t n, void* stream) {

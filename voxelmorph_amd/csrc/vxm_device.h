@@ -44,6 +44,30 @@ __device__ __forceinline__ float vxm_src_coord(int i, float f, int S) {
     return h * sm1;
 }
 
+// One axis of ATen's grid_sampler_3d corner construction: x0 = floor(x), weights (x0 + 1 - x) and (x - x0).
+// The two corner indices are clamped into the volume (so that every gather address is valid) and the in-volume
+// tests kept separately: padding_mode='zeros' is applied by zeroing the WEIGHT (forward) or the VALUE (backward)
+// of an outside corner, which leaves the in-volume terms bit-identical and needs no branches.
+struct AxisTaps { int i0, i1; float w0, w1; bool ok0, ok1; };
+__device__ __forceinline__ AxisTaps axis_corners(float x, int S) {
+    AxisTaps a;
+    const float f = floorf(x);
+    a.w1 = x - f; a.w0 = (f + 1.0f) - x;
+    const int i = (int)fminf(fmaxf(f, -2.0f), (float)S);      // clamp before the int conversion: wild coordinates stay defined
+    a.ok0 = (unsigned)i < (unsigned)S; a.ok1 = (unsigned)(i + 1) < (unsigned)S;
+    a.i0 = min(max(i, 0), S - 1); a.i1 = min(max(i + 1, 0), S - 1);
+    return a;
+}
+// ATen upsample_trilinear3d(align_corners=True) index/lambda: real = ratio*dst; i0 = (int)real;
+// i1 = i0 + (i0 < in-1); l1 = real - i0; l0 = 1 - l1.
+__device__ __forceinline__ void lin_src(int dst, float ratio, int n_in, int& i0, int& i1, float& l0, float& l1) {
+    const float r = ratio * (float)dst;
+    i0 = min((int)r, n_in - 1);
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l1 = fminf(fmaxf(r - (float)i0, 0.0f), 1.0f);
+    l0 = 1.0f - l1;
+}
+
 __device__ __forceinline__ float vxm_lrelu_grad(float y, float slope) { return y > 0.0f ? 1.0f : slope; }
 
 #endif

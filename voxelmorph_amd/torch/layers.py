@@ -1,12 +1,13 @@
 """Drop-in mirror of `voxelmorph/torch/layers.py` (reference) on the MI355X HIP kernels.
 
 Same class names, constructor signatures, attributes and buffers; `forward` dispatches to
-libvxm_hip.so through `functional.py`.  3-D volumes only in this round.
+libvxm_hip.so through `functional.py` (3-D volumes) or `planar.py` (2-D images).
 """
 import torch
 import torch.nn as nn
 
 from . import functional as VF
+from . import planar as VP
 
 
 class SpatialTransformer(nn.Module):
@@ -30,6 +31,8 @@ class SpatialTransformer(nn.Module):
         if tuple(flow.shape[2:]) != tuple(self.grid.shape[2:]):
             raise RuntimeError("flow spatial shape %s does not match the transformer size %s"
                                % (tuple(flow.shape[2:]), tuple(self.grid.shape[2:])))
+        if src.dim() == 4:
+            return VP.Warp2dFn.apply(src, flow, self.mode)
         return VF.WarpFn.apply(src, flow, self.mode)
 
 
@@ -46,6 +49,8 @@ class VecInt(nn.Module):
     def forward(self, vec):
         if self.nsteps == 0:
             return vec * self.scale          # scale == 1
+        if vec.dim() == 4:
+            return VP.VecInt2dFn.apply(vec, self.nsteps)
         return VF.VecIntFn.apply(vec, self.nsteps)
 
 
@@ -64,4 +69,6 @@ class ResizeTransform(nn.Module):
     def forward(self, x):
         if self.factor == 1:
             return x
+        if x.dim() == 4:
+            return VP.Resize2dFn.apply(x, self.factor)
         return VF.ResizeFn.apply(x, self.factor)

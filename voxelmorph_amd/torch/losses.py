@@ -3,6 +3,7 @@
 Every class keeps the reference's `loss(y_true, y_pred) -> 0-dim tensor` contract.
 """
 from . import functional as VF
+from . import planar as VP
 
 
 class NCC:
@@ -15,8 +16,11 @@ class NCC:
         ndims = len(list(y_true.size())) - 2
         assert ndims in [1, 2, 3], "volumes should be 1 to 3 dimensions. found: %d" % ndims
         win = [9] * ndims if self.win is None else list(self.win)
-        if ndims != 3 or len(set(win)) != 1 or win[0] % 2 == 0:
-            raise NotImplementedError("the MI355X NCC kernel implements cubic odd windows on 3-D volumes; got win=%s" % (win,))
+        if ndims == 1 or len(win) != ndims or len(set(win)) != 1 or win[0] % 2 == 0:
+            raise NotImplementedError("the MI355X NCC kernels implement square / cubic odd windows on 2-D / 3-D inputs; "
+                                      "got win=%s on %d-D" % (win, ndims))
+        if ndims == 2:
+            return VP.NCC2dFn.apply(y_true, y_pred, int(win[0]))
         return VF.NCCFn.apply(y_true, y_pred, int(win[0]))
 
 
@@ -44,4 +48,7 @@ class Grad:
     def loss(self, _, y_pred):
         if self.penalty != 'l1':
             assert self.penalty == 'l2', 'penalty can only be l1 or l2. Got: %s' % self.penalty
-        return VF.GradLossFn.apply(y_pred, self.penalty, 1.0 if self.loss_mult is None else float(self.loss_mult))
+        mult = 1.0 if self.loss_mult is None else float(self.loss_mult)
+        if y_pred.dim() == 4:
+            return VP.GradLoss2dFn.apply(y_pred, self.penalty, mult)
+        return VF.GradLossFn.apply(y_pred, self.penalty, mult)

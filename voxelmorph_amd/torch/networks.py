@@ -13,6 +13,7 @@ from torch.distributions.normal import Normal
 
 from . import functional as VF
 from . import layers
+from . import planar as VP
 from .modelio import LoadableModel, store_config_args
 
 
@@ -22,29 +23,31 @@ def default_unet_features():
 
 
 class _Conv3dParams(nn.Module):
-    """Weight/bias holder initialised like torch.nn.Conv3d (kaiming_uniform(a=sqrt(5)) + fan-in bias)."""
+    """Weight/bias holder initialised like torch.nn.Conv3d / Conv2d (kaiming_uniform(a=sqrt(5)) + fan-in bias)."""
 
-    def __init__(self, in_channels, out_channels):
+    def __init__(self, in_channels, out_channels, ndims=3):
         super().__init__()
-        self.in_channels, self.out_channels = in_channels, out_channels
-        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, 3, 3, 3))
+        self.in_channels, self.out_channels, self.ndims = in_channels, out_channels, ndims
+        self.weight = nn.Parameter(torch.empty((out_channels, in_channels) + (3,) * ndims))
         self.bias = nn.Parameter(torch.empty(out_channels))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
-        bound = 1 / math.sqrt(in_channels * 27)
+        bound = 1 / math.sqrt(in_channels * 3 ** ndims)
         nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x, slope=1.0):
+        if self.ndims == 2:
+            return VP.conv2d(x, self.weight, self.bias, slope)
         return VF.ConvFn.apply(x, self.weight, self.bias, slope)
 
 
 class ConvBlock(nn.Module):
-    """Conv3d(3, stride 1, pad 1) + LeakyReLU(0.2) (reference: networks.py:290-305)."""
+    """ConvNd(3, stride 1, pad 1) + LeakyReLU(0.2) (reference: networks.py:290-305)."""
 
     def __init__(self, ndims, in_channels, out_channels, stride=1):
         super().__init__()
-        if ndims != 3 or stride != 1:
-            raise NotImplementedError("the MI355X ConvBlock implements 3-D, stride-1 3x3x3 convolutions")
-        self.main = _Conv3dParams(in_channels, out_channels)
+        if ndims not in (2, 3) or stride != 1:
+            raise NotImplementedError("the MI355X ConvBlock implements 2-D / 3-D, stride-1, kernel-3 convolutions")
+        self.main = _Conv3dParams(in_channels, out_channels, ndims)
         self.activation = nn.LeakyReLU(0.2)          # attribute kept for parity; fused into the conv epilogue
 
     def forward(self, x):
@@ -62,8 +65,9 @@ class Unet(nn.Module):
         super().__init__()
         ndims = len(inshape)
         assert ndims in [1, 2, 3], 'ndims should be one of 1, 2, or 3. found: %d' % ndims
-        if ndims != 3:
-            raise NotImplementedError("the MI355X Unet implements 3-D volumes (DESIGN.md, 'next' rows)")
+        if ndims == 1:
+            raise NotImplementedError("the MI355X Unet implements 2-D images and 3-D volumes")
+        self.ndims = ndims
         self.half_res = half_res
         if nb_features is None:
             nb_features = default_unet_features()
@@ -136,7 +140,30 @@ class Unet(nn.Module):
         return self._plans[key]
 
     def forward(self, x):
+        if self.ndims == 2:
+            return self._forward_planar(x)
         return VF.UnetFn.apply(self.plan([x.shape[1]]), x, *self.conv_params())
+
+    def _forward_planar(self, x):
+        """networks.py:122-144 op by op (2-D slices are small: per-op autograd nodes instead of the fused 3-D engine)."""
+        nlev = self.nb_levels - 1
+        if any(int(d) % (1 << nlev) for d in x.shape[2:]):
+            raise ValueError("Unet: image %s must be divisible by %d (MaxPool floors and the skip concat would not "
+                             "line up, networks.py:130,138)" % (tuple(x.shape[2:]), 1 << nlev))
+        x_history = [x]
+        for convs in self.encoder:
+            for conv in convs:
+                x = conv(x)
+            x_history.append(x)
+            x = VP.MaxPool2dFn.apply(x)
+        for level, convs in enumerate(self.decoder):
+            for conv in convs:
+                x = conv(x)
+            if not self.half_res or level < (self.nb_levels - 2):
+                x = VP.UpsampleCat2dFn.apply(x, x_history.pop())
+        for conv in self.remaining:
+            x = conv(x)
+        return x
 
 
 class VxmDense(LoadableModel):
@@ -153,7 +180,8 @@ class VxmDense(LoadableModel):
         self.unet_model = Unet(inshape, infeats=(src_feats + trg_feats), nb_features=nb_unet_features,
                                nb_levels=nb_unet_levels, feat_mult=unet_feat_mult,
                                nb_conv_per_level=nb_unet_conv_per_level, half_res=unet_half_res)
-        self.flow = _Conv3dParams(self.unet_model.final_nf, ndims)
+        self.flow = _Conv3dParams(self.unet_model.final_nf, ndims, ndims)
+        self.ndims = ndims
         self.flow.weight = nn.Parameter(Normal(0, 1e-5).sample(self.flow.weight.shape))
         self.flow.bias = nn.Parameter(torch.zeros(self.flow.bias.shape))
         if use_probs:
@@ -174,9 +202,12 @@ class VxmDense(LoadableModel):
 
     def _forward_all(self, source, target):
         """(y_source, y_target, preint_flow, pos_flow, neg_flow) of networks.py:244-287 (None where not bidir)."""
-        # U-Net + flow conv as ONE fused autograd node; source/target enter as a virtual concat
-        plan = self.unet_model.plan(self._feats, extra=((self.flow.out_channels, 1.0),))
-        flow_field = VF.UnetFn.apply(plan, source, target, *self.unet_model.conv_params(), self.flow.weight, self.flow.bias)
+        if self.ndims == 2:
+            flow_field = self.flow(self.unet_model(torch.cat([source, target], dim=1)))
+        else:
+            # U-Net + flow conv as ONE fused autograd node; source/target enter as a virtual concat
+            plan = self.unet_model.plan(self._feats, extra=((self.flow.out_channels, 1.0),))
+            flow_field = VF.UnetFn.apply(plan, source, target, *self.unet_model.conv_params(), self.flow.weight, self.flow.bias)
         pos_flow = flow_field
         if self.resize:
             pos_flow = self.resize(pos_flow)
