@@ -130,7 +130,7 @@ def main():
     B = args.batch_per_gpu
     torch.manual_seed(1234)                                   # identical initial weights on every rank
     model = vxm.networks.VxmDense(shape, int_steps=args.int_steps, int_downsize=2).to(dev)
-    opt = FlatAdam(model, lr=1e-4)
+    opt = FlatAdam(model, lr=1e-4, comm=vdist.native_comm())      # VXM_COMM=rccl: direct libvxm_comm.so all-reduce
     opt.broadcast_params(0)
     torch.manual_seed(1234 + rank)                            # each rank synthesises its own volume pairs in HBM
     src = torch.rand(B, 1, *shape, device=dev)

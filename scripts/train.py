@@ -79,7 +79,7 @@ def main(argv=None):
                                       int_downsize=args.int_downsize)
     model.to(dev)
     model.train()
-    opt = FlatAdam(model, lr=args.lr)
+    opt = FlatAdam(model, lr=args.lr, comm=vdist.native_comm())
     opt.broadcast_params(0)
 
     if args.image_loss == 'ncc':

@@ -38,6 +38,22 @@ def test_library_exports_every_declared_symbol():
     assert h.vxm_conv3d_k3_bwd_weight_workspace_bytes(64, 32, 1, 8, 8, 16) > 0
 
 
+def test_comm_library_exports_declared_symbols():
+    """include/vxm_comm.h <-> libvxm_comm.so <-> voxelmorph_amd/comm.py; no collective is issued without a GPU."""
+    from voxelmorph_amd import comm
+    header = open(os.path.join(ROOT, "include", "vxm_comm.h")).read()
+    declared = set(re.findall(r"\b(vxm_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(comm.SIGNATURES), declared ^ set(comm.SIGNATURES)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", comm.LIB_PATH]).decode()
+    assert declared <= set(re.findall(r" T (vxm_[a-z0-9_]+)", out))
+    h = comm.lib()
+    assert h.vxm_comm_world() == 0
+    assert h.vxm_allreduce_sum_f32(None, 4, None) != 0 and b"not initialised" in h.vxm_comm_last_error_string()
+    assert h.vxm_comm_destroy() == 0
+    with pytest.raises(ValueError):
+        comm.NativeComm(0, 1, b"short")
+
+
 def test_kernels_are_gfx950_only():
     blob = open(_lib.LIB_PATH, "rb").read()
     archs = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))

@@ -226,6 +226,7 @@ def test_grad_mse_dice_golden(vxm, g_losses):
     (64, 32, (8, 4, 16), 0.2), (16, 3, (9, 10, 33), 1.0), (5, 7, (6, 7, 19), 0.2), (20, 40, (4, 4, 16), 0.2),
     (17, 16, (5, 7, 28), 0.2), (32, 48, (6, 9, 36), 1.0), (3, 3, (3, 3, 4), 0.2),
     (16, 3, (6, 8, 20), 1.0), (24, 2, (5, 6, 16), 0.2),        # few output channels: role-swapped backward-weight
+    (1, 16, (8, 8, 16), 0.2), (4, 20, (8, 8, 16), 0.2),        # few input channels: dense-K MFMA kernel (with VXM_CONV_WIDE_MIN_TILES=1)
 ])
 def test_conv_block_vs_oracle(vxm, cin, cout, vol, slope):
     from voxelmorph_amd.torch import functional as VF
@@ -602,6 +603,40 @@ def test_full_size_train_step_runs_and_is_linear_in_lr(vxm):
     assert float(opt.flat_grad.abs().sum()) > 0
 
 
+@pytest.mark.parametrize("c0,up0,c1,cout", [(32, False, 0, 16), (16, False, 0, 32), (32, True, 16, 32), (2, False, 0, 16), (16, False, 0, 3)])
+def test_full_size_conv_adjoint_identity(vxm, c0, up0, c1, cout):
+    """Size-independent property at 160x192x224 (where the oracle is too slow): a bias-free, activation-free convolution
+    is linear, so  <conv(x), dz> = <x, conv_bwd_data(dz)> = <w, conv_bwd_weight(x, dz)>.  One identity ties the forward,
+    backward-data and backward-weight kernels of the full-resolution layers together (the 8-wave MFMA kernels, and for
+    cat([upsample(x0), x1]) the collapsed-weight forward / backward-weight kernels)."""
+    from voxelmorph_amd.torch import functional as VF
+    D, H, W = FULL
+    V = D * H * W
+    torch.manual_seed(c0 + cout)
+    x0 = torch.randn(1, c0, D // 2, H // 2, W // 2, device="cuda") if up0 else torch.randn(1, c0, D, H, W, device="cuda")
+    x1 = torch.randn(1, c1, D, H, W, device="cuda") if c1 else None
+    cin = c0 + c1
+    w = torch.randn(cout, cin, 3, 3, 3, device="cuda") / (27 * cin) ** 0.5
+    y = torch.empty(1, cout, D, H, W, device="cuda")
+    VF.conv_forward(x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if c1 else 0, w, None, y, cout * V, cout, 1.0, 1, D, H, W)
+    dz = y + 0.5 * torch.randn_like(y)          # correlated with y: the inner products are O(|y|^2), not a random-sign sum
+    lhs = float((y.double() * dz.double()).sum())
+    gw, gb = torch.empty_like(w), torch.empty(cout, device="cuda")
+    VF.conv_bwd_weight(VF._Workspace(y.device), x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if c1 else 0, dz, cout, gw, gb, 1, D, H, W)
+    via_w = float((gw.double() * w.double()).sum())
+    scale = float(y.double().norm() * dz.double().norm())
+    assert abs(lhs - via_w) <= 1e-5 * scale, (lhs, via_w, scale)
+    np.testing.assert_allclose(N(gb), N(dz.double().sum(dim=(0, 2, 3, 4)).float()), rtol=1e-4, atol=1e-2)
+    gx = torch.empty(1, cin, D, H, W, device="cuda")
+    VF.conv_bwd_data(dz, cout, w, gx, cin, None, 1.0, 1, D, H, W)
+    if up0:      # the gradient of the upsampled segment folds back onto the half-resolution tensor (sum over the 2x2x2 children)
+        g0 = gx[:, :c0].reshape(1, c0, D // 2, 2, H // 2, 2, W // 2, 2).double().sum(dim=(3, 5, 7))
+        via_x = float((g0 * x0.double()).sum()) + float((gx[:, c0:].double() * x1.double()).sum())
+    else:
+        via_x = float((gx.double() * x0.double()).sum())
+    assert abs(lhs - via_x) <= 1e-5 * scale, (lhs, via_x, scale)
+
+
 # ------------------------------------------------------------------ 2-D (planar) variants: golden fixtures from the reference
 def test_planar_layers_golden(vxm, g_planar):
     g = g_planar
@@ -712,3 +747,31 @@ def test_planar_vxm_dense_golden(vxm, g_planar, tag):
     with torch.no_grad():
         _, pos = model(src, trg, registration=True)
     np.testing.assert_allclose(N(pos), g[tag + "_pos_flow"], atol=1e-4, rtol=0)
+
+
+def test_native_comm_world_one(vxm):
+    """libvxm_comm.so on the device: a one-rank RCCL communicator (all a 1-GPU box can host) runs the all-reduce and the
+    broadcast in place on the current stream and leaves the bucket unchanged; FlatAdam takes it as its exchange."""
+    from voxelmorph_amd.comm import NativeComm
+    from voxelmorph_amd.optim import FlatAdam
+    c = NativeComm(0, 1, NativeComm.new_unique_id())
+    try:
+        t = torch.arange(327331, dtype=torch.float32, device="cuda")
+        ref = t.clone()
+        c.all_reduce_sum(t)
+        c.broadcast(t, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(t, ref)
+        model = vxm.networks.VxmDense((16, 16, 16), int_steps=1).cuda()
+        opt = FlatAdam(model, lr=1e-4, comm=c)
+        assert opt.world == 1
+        opt.broadcast_params(0)
+        opt.flat_grad.fill_(1.0)
+        before = opt.flat_param.clone()
+        opt.step()
+        torch.cuda.synchronize()
+        assert float((before - opt.flat_param).abs().max()) > 0
+        with pytest.raises(Exception):
+            c.all_reduce_sum(torch.zeros(4))
+    finally:
+        c.destroy()

@@ -8,11 +8,19 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NI, int WIDTH>
+// RANDOM: operands are pseudo-random in [-1, 1) instead of a handful of tiny constants -- the data toggling of real
+// activations, which is what the power management reacts to
+__device__ __forceinline__ float fill_value(int i, int random) {
+    unsigned h = (unsigned)i * 2654435761u + (unsigned)blockIdx.x * 40503u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    return random ? (float)(int)(h & 0xffffff) * (1.0f / 8388608.0f) - 1.0f : (float)(i & 7) * 1e-3f;
+}
+
+template <int NI, int WIDTH, int RANDOM = 0>
 __global__ void __launch_bounds__(512) k(float* out, int iters) {
     __shared__ float s[16384];
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < 16384; i += 512) s[i] = (float)(i & 7) * 1e-3f;
+    for (int i = threadIdx.x; i < 16384; i += 512) s[i] = fill_value(i, RANDOM);
     __syncthreads();
     f32x4 acc[4];
     for (int r = 0; r < 4; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -107,6 +115,8 @@ int main() {
         run("4 x b64 per 4 MFMA (8 dw)", k<4, 2>, w, it);
         run("1 x b128 per 4 MFMA (4 dw)", k<1, 4>, w, it);
         run("2 x b128 per 4 MFMA (8 dw)", k<2, 4>, w, it);
+        run("8 x b32 per 4 MFMA, random data", k<8, 1, 1>, w, it);
+        run("2 x b128 per 4 MFMA, random data", k<2, 4, 1>, w, it);
         run("32x32x2: 2 x b32 per 2 MFMA(=4)", k32<2>, w, it);
         run("32x32x2: 4 x b32 per 2 MFMA(=4)", k32<4>, w, it);
     }

@@ -1,0 +1,91 @@
+"""ctypes binding of libvxm_comm.so (include/vxm_comm.h): the gradient all-reduce of the data-parallel step as a direct
+RCCL call on the step's HIP stream, without torch.distributed on the data path.
+
+Opt-in (`VXM_COMM=rccl`, or `FlatAdam(..., comm=NativeComm.from_torch_dist())`): the default exchange stays
+`torch.distributed.all_reduce` on the 'nccl' backend, which is the same RCCL underneath.  torch.distributed (any
+backend, gloo included) is only the rendezvous that carries rank 0's 128-byte unique id to the other ranks.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (before the CDLL: librccl / libamdhip64 resolve to the copies torch has loaded)
+
+from ._lib import VxmHipError
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvxm_comm.so")
+UNIQUE_ID_BYTES = 128
+
+_c = ctypes
+SIGNATURES = {
+    "vxm_comm_last_error_string": [],
+    "vxm_comm_unique_id": [_c.c_void_p],
+    "vxm_comm_init": [_c.c_int, _c.c_int, _c.c_void_p],
+    "vxm_comm_world": [],
+    "vxm_allreduce_sum_f32": [_c.c_void_p, _c.c_int64, _c.c_void_p],
+    "vxm_broadcast_f32": [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p],
+    "vxm_comm_destroy": [],
+}
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VxmHipError("libvxm_comm.so not found at %s -- build it with voxelmorph_amd/csrc/build.sh" % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.argtypes = args
+            fn.restype = _c.c_char_p if name == "vxm_comm_last_error_string" else _c.c_int
+        _lib = h
+    return _lib
+
+
+def _call(name, *args):
+    h = lib()
+    status = getattr(h, name)(*args)
+    if status != 0:
+        raise VxmHipError("%s failed (status %d): %s" % (name, status, h.vxm_comm_last_error_string().decode()))
+
+
+class NativeComm:
+    """One RCCL communicator per process, bound to the current HIP device."""
+
+    def __init__(self, rank, world, unique_id):
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError("unique id must be %d bytes" % UNIQUE_ID_BYTES)
+        self.rank, self.world = rank, world
+        buf = ctypes.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        _call("vxm_comm_init", rank, world, buf)
+
+    @staticmethod
+    def new_unique_id():
+        buf = ctypes.create_string_buffer(UNIQUE_ID_BYTES)
+        _call("vxm_comm_unique_id", buf)
+        return buf.raw
+
+    @classmethod
+    def from_torch_dist(cls, group=None):
+        """Rendezvous over an initialised torch.distributed group (rank 0's id is broadcast as an object)."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(rank, world, box[0])
+
+    def _check(self, t):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise VxmHipError("NativeComm: contiguous fp32 HIP tensors only, got %s %s" % (t.device, t.dtype))
+
+    def all_reduce_sum(self, t):
+        self._check(t)
+        _call("vxm_allreduce_sum_f32", t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream)
+
+    def broadcast(self, t, root=0):
+        self._check(t)
+        _call("vxm_broadcast_f32", t.data_ptr(), t.numel(), root, torch.cuda.current_stream().cuda_stream)
+
+    def destroy(self):
+        _call("vxm_comm_destroy")

@@ -19,3 +19,8 @@ done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $objs
 echo "built $(realpath $OUT)"
+# the data-parallel exchange (include/vxm_comm.h): separate library, the only one that needs RCCL
+if [ ! -f ../libvxm_comm.so ] || [ comm.cpp -nt ../libvxm_comm.so ] || [ ../../include/vxm_comm.h -nt ../libvxm_comm.so ]; then
+  hipcc -O2 -std=c++17 -fPIC -shared -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include comm.cpp -o ../libvxm_comm.so -L/opt/rocm/lib -lrccl
+fi
+echo "built $(realpath ../libvxm_comm.so)"

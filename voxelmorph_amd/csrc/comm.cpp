@@ -1,0 +1,81 @@
+// libvxm_comm.so: thin RCCL wrapper behind include/vxm_comm.h (one communicator per process, xGMI only on one node).
+#include "../../include/vxm_comm.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+ncclComm_t g_comm = nullptr;
+int g_world = 0;
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define COMM_CHECK(expr, what)                                                                          \
+    do {                                                                                                \
+        const ncclResult_t r_ = (expr);                                                                 \
+        if (r_ != ncclSuccess) return fail(100 + (int)r_, "%s: %s", what, ncclGetErrorString(r_));     \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* vxm_comm_last_error_string(void) { return g_err; }
+
+int vxm_comm_unique_id(void* out) {
+    static_assert(sizeof(ncclUniqueId) == VXM_COMM_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!out) return fail(1, "vxm_comm_unique_id: null pointer");
+    ncclUniqueId id;
+    COMM_CHECK(ncclGetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(out, &id, sizeof(id));
+    return 0;
+}
+
+int vxm_comm_init(int rank, int world, const void* unique_id) {
+    if (g_comm) return fail(2, "vxm_comm_init: communicator already initialised (one per process)");
+    if (!unique_id || world < 1 || rank < 0 || rank >= world) return fail(1, "vxm_comm_init: bad arguments rank=%d world=%d", rank, world);
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    COMM_CHECK(ncclCommInitRank(&g_comm, world, id, rank), "ncclCommInitRank");
+    g_world = world;
+    return 0;
+}
+
+int vxm_comm_world(void) { return g_world; }
+
+int vxm_allreduce_sum_f32(float* buf, int64_t n, void* stream) {
+    if (!g_comm) return fail(3, "vxm_allreduce_sum_f32: communicator not initialised");
+    if (!buf || n <= 0) return fail(1, "vxm_allreduce_sum_f32: bad buffer");
+    COMM_CHECK(ncclAllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, g_comm, reinterpret_cast<hipStream_t>(stream)), "ncclAllReduce");
+    return 0;
+}
+
+int vxm_broadcast_f32(float* buf, int64_t n, int root, void* stream) {
+    if (!g_comm) return fail(3, "vxm_broadcast_f32: communicator not initialised");
+    if (!buf || n <= 0 || root < 0 || root >= g_world) return fail(1, "vxm_broadcast_f32: bad arguments");
+    COMM_CHECK(ncclBroadcast(buf, buf, (size_t)n, ncclFloat32, root, g_comm, reinterpret_cast<hipStream_t>(stream)), "ncclBroadcast");
+    return 0;
+}
+
+int vxm_comm_destroy(void) {
+    if (!g_comm) return 0;
+    const ncclResult_t r = ncclCommDestroy(g_comm);
+    g_comm = nullptr;
+    g_world = 0;
+    if (r != ncclSuccess) return fail(100 + (int)r, "ncclCommDestroy: %s", ncclGetErrorString(r));
+    return 0;
+}
+
+}  // extern "C"

@@ -104,6 +104,61 @@ bool bw_force_generic() {
 
 static bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+// bias of the 4 output channels a lane holds per 16-channel tile (MFMA D layout)
+template <int NCT>
+__device__ __forceinline__ void conv_load_bias(float (&bz)[NCT][4], const float* __restrict__ bias, int Cout, int g, int kq) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bz[ct][j] = bias ? bias[min((g * NCT + ct) * 16 + kq * 4 + j, Cout - 1)] : 0.0f;
+}
+
+// ---- branch-free epilogue of the MFMA kernels (D layout: lane (kq, n) holds, in acc[ct][r][j], output channel
+// 16 (g NCT + ct) + 4 kq + j at voxel (d, h0 + r, w) with w = w0 + n): bias + LeakyReLU (+ the fused leaky_relu_backward
+// mask), NCDHW store.  Buffer stores / loads through descriptors whose range is exactly the tensor of the sample: the
+// lane part of the address is ONE 32-bit offset per tile (out-of-range for voxels outside the volume), channel and row
+// steps are wave-uniform scalar offsets, channels >= Cout fall off the end of the range, and the hardware drops what is out
+// of range -- no per-store branch, no 64-bit address arithmetic.  Rows beyond H are skipped by a wave-uniform test.
+template <int NCT, int ROWS>
+__device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS], float* __restrict__ yb /* y + b * y_bs */, const float (&bz)[NCT][4],
+                                                    const float* __restrict__ maskb /* mask + b * mask_bs or null */, float act_slope,
+                                                    float mask_slope, int Cout, int g, int kq, bool vox_ok, int vox /* (d H + h0) W + w */,
+                                                    int h0, int H, int W, int V) {
+    const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(yb, (unsigned)Cout * (unsigned)V * 4u);
+    const __amdgpu_buffer_rsrc_t rm = vxm_rsrc(maskb ? maskb : yb, (unsigned)Cout * (unsigned)V * 4u);
+    const int voff = vox_ok ? ((g * NCT * 16 + kq * 4) * V + vox) << 2 : VXM_OOB;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        float mk[4][ROWS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) mk[j][r] = 1.0f;
+        if (maskb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r)
+                    mk[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, voff, ((ct * 16 + j) * V + r * W) << 2, 0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) mk[j][r] = vxm_lrelu_grad(mk[j][r], mask_slope);
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            if (h0 + r < H) {                        // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[ct][r][j] + bz[ct][j];
+                    v = (v > 0.0f ? v : v * act_slope) * mk[j][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, voff, ((ct * 16 + j) * V + r * W) << 2, 0);
+                }
+            }
+        }
+    }
+}
+
 int check_conv(const char* fn, int C0, int C1, int x0_up, int Cout, int B, int D, int H, int W) {
     VXM_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, VXM_ERR_BAD_SHAPE,
                 "%s: bad shape B=%d C0=%d C1=%d Cout=%d D=%d H=%d W=%d", fn, B, C0, C1, Cout, D, H, W);

@@ -115,58 +115,13 @@ __global__ void __launch_bounds__(256) k_conv3d_k3(ConvIn in, const float* __res
         __syncthreads();
     }
 
-    // ---- epilogue: bias + LeakyReLU (+ fused leaky_relu_backward mask), NCDHW store.
-    // All bias / mask loads are issued first (clamped addresses, no branches), then the math + stores.
+    // ---- epilogue: bias + LeakyReLU (+ fused leaky_relu_backward mask), NCDHW store (branch-free buffer stores)
     const int d = d0 + wave, w = w0 + n;
-    const size_t V = (size_t)D * H * W;
-    const bool vox_ok = d < D && w < W;
-    const size_t vox_off = ((size_t)min(d, D - 1) * H) * W + min(w, W - 1);
-    float bz[NCT][4], mk[NCT][4][4];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bz[ct][j] = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mk[ct][j][r] = 1.0f;
-        }
-    if (bias) {                                   // hoisted uniform tests: the loads inside issue back-to-back
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bz[ct][j] = bias[min((g * NCT + ct) * 16 + kq * 4 + j, Cout - 1)];
-    }
-    if (mask) {
-        const float* mb = mask + (size_t)b * mask_bs + vox_off;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = min((g * NCT + ct) * 16 + kq * 4 + j, Cout - 1);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mk[ct][j][r] = mb[(size_t)co * V + (size_t)min(h0 + r, H - 1) * W];
-            }
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mk[ct][j][r] = vxm_lrelu_grad(mk[ct][j][r], mask_slope);
-    }
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int co = (g * NCT + ct) * 16 + kq * 4 + j;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int h = h0 + r;
-                float v = acc[ct][r][j] + bz[ct][j];
-                v = (v > 0.0f ? v : v * act_slope) * mk[ct][j][r];
-                if (vox_ok && h < H && co < Cout)
-                    y[(size_t)b * y_bs + (size_t)co * V + ((size_t)d * H + h) * W + w] = v;
-            }
-        }
+    const int V = D * H * W;
+    float bz[NCT][4];
+    conv_load_bias<NCT>(bz, bias, Cout, g, kq);
+    conv_epilogue_store<NCT, 4>(acc, y + (size_t)b * y_bs, bz, mask ? mask + (size_t)b * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kq,
+                                d < D && w < W, (d * H + h0) * W + w, h0, H, W, V);
 }
 
 
@@ -344,56 +299,12 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
         }
     }
 
-    // ---- epilogue: bias + LeakyReLU (+ fused leaky_relu_backward mask), NCDHW store
+    // ---- epilogue: bias + LeakyReLU (+ fused leaky_relu_backward mask), NCDHW store (branch-free buffer stores)
     const int d = d0 + wave, w = w0 + n;
-    const bool vox_ok = d < D && w < W;
-    const size_t vox_off = ((size_t)min(d, D - 1) * H) * W + min(w, W - 1);
-    float bz[NCT][4], mk[NCT][4][ROWS];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bz[ct][j] = 0.0f;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) mk[ct][j][r] = 1.0f;
-        }
-    if (bias) {
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bz[ct][j] = bias[min((g * NCT + ct) * 16 + kq * 4 + j, Cout - 1)];
-    }
-    if (mask) {
-        const float* mb = mask + (size_t)b * mask_bs + vox_off;
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = min((g * NCT + ct) * 16 + kq * 4 + j, Cout - 1);
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) mk[ct][j][r] = mb[(size_t)co * V + (size_t)min(h0 + r, H - 1) * W];
-            }
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < ROWS; ++r) mk[ct][j][r] = vxm_lrelu_grad(mk[ct][j][r], mask_slope);
-    }
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int co = (g * NCT + ct) * 16 + kq * 4 + j;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const int h = h0 + r;
-                float v = acc[ct][r][j] + bz[ct][j];
-                v = (v > 0.0f ? v : v * act_slope) * mk[ct][j][r];
-                if (vox_ok && h < H && co < Cout)
-                    y[(size_t)b * y_bs + (size_t)co * V + ((size_t)d * H + h) * W + w] = v;
-            }
-        }
+    float bz[NCT][4];
+    conv_load_bias<NCT>(bz, bias, Cout, g, kq);
+    conv_epilogue_store<NCT, ROWS>(acc, y + (size_t)b * y_bs, bz, mask ? mask + (size_t)b * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kq,
+                                   d < D && w < W, (d * H + h0) * W + w, h0, H, W, V);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -635,22 +546,24 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8u(const float* __
         }
     }
 
-    // ---- epilogue: bias + LeakyReLU; lane n of N-tile (ph, pw) is voxel (h0 + ph + 2 (n >> 3), w0 + 2 (n & 7) + pw)
-    const int d = d0 + wave;
-    if (d < D) {
+    // ---- epilogue: bias + LeakyReLU; lane n of N-tile (ph, pw) is voxel (h0 + ph + 2 (n >> 3), w0 + 2 (n & 7) + pw): the two
+    // pw tiles of a lane are neighbours along W and leave as ONE 8-byte buffer store (8 lanes = a 64-byte run); H and W
+    // are even and the tile origin is even, so both rows / both columns of a lane are inside the volume or neither is.
+    {
+        const int d = d0 + wave, h = h0 + 2 * (n >> 3), w = w0 + 2 * (n & 7);
+        const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(y + (size_t)b * y_bs, (unsigned)Cout * (unsigned)V * 4u);
+        const int voff = (d < D && h < H && w < W) ? ((g * NCT * 16 + kq * 4) * V + (d * H + h) * W + w) << 2 : VXM_OOB;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int co = (g * NCT + ct) * 16 + kq * 4 + j;
-                if (co >= Cout) continue;
-                const float bz = bias ? bias[co] : 0.0f;
+                const float bz = bias ? bias[min((g * NCT + ct) * 16 + kq * 4 + j, Cout - 1)] : 0.0f;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int h = h0 + (nt >> 1) + 2 * (n >> 3), w = w0 + 2 * (n & 7) + (nt & 1);
-                    float v = acc[ct][nt][j] + bz;
-                    v = v > 0.0f ? v : v * act_slope;
-                    if (h < H && w < W) y[(size_t)b * y_bs + (size_t)co * V + ((size_t)d * H + h) * W + w] = v;
+                for (int ph = 0; ph < 2; ++ph) {
+                    float v0 = acc[ct][2 * ph][j] + bz, v1 = acc[ct][2 * ph + 1][j] + bz;
+                    v0 = v0 > 0.0f ? v0 : v0 * act_slope;
+                    v1 = v1 > 0.0f ? v1 : v1 * act_slope;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){v0, v1}), ry, voff, ((ct * 16 + j) * V + ph * W) << 2, 0);
                 }
             }
     }
@@ -973,6 +886,176 @@ __global__ void __launch_bounds__(256) k_conv3d_k3_fewout(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// forward kernel for layers with at most 4 input channels (first encoder block: 2 -> 16; backward-data of the flow conv:
+// 3 -> 16): the reduction index K = 27 Cin is packed DENSELY into the k-steps of the MFMA (k = tap * Cin + ci), 14 / 21
+// k-steps for Cin = 2 / 3 instead of the 27 that channel chunks padded to 4 cost.  A lane's (tap, ci) changes from
+// k-step to k-step, so every lane keeps its own LDS offset per k-step in registers (the weights of a 16-channel
+// output group are loop constants of the block and sit in LDS).  These layers are HBM-bound on the output (16
+// channels written per voxel), and a tile is only 4 NS MFMAs per wave: blocks are persistent and the planes of the next
+// tile are fetched under the MFMAs of the current one into the second of two LDS buffers.
+// ------------------------------------------------------------------------------------------
+constexpr int kpack_steps(int cin) { return (27 * cin + 3) / 4; }
+constexpr int KP_ROWS = 4, KP_HR = KP_ROWS + 2, KP_NROW = (T8_TD + 2) * KP_HR;
+constexpr int KP_PS = KP_NROW * BV_RS_FWD + ((KP_NROW * BV_RS_FWD) % 32 == 16 ? 0 : 16);   // 1200 = 16 mod 32: the two channels of a half-wave (Cin = 2) sit 16 banks apart
+
+template <int CIN>
+__global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_kpack(ConvIn in, const float* __restrict__ wk, const float* __restrict__ bias,
+                                                                 float* __restrict__ y, long long y_bs, int Cout, float act_slope,
+                                                                 const float* __restrict__ mask, long long mask_bs, float mask_slope,
+                                                                 int B, int D, int H, int W) {
+    constexpr int ROWS = KP_ROWS, RS = BV_RS_FWD, HR = KP_HR, NROW = KP_NROW, PS = KP_PS, NS = kpack_steps(CIN);
+    constexpr int NI = (NROW * 4 + 63) / 64, NHL = (NROW * 2 + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float Xs2[2 * CIN * PS];      // double-buffered planes: one barrier per tile
+    __shared__ float Wl[NS * 64];                                         // A fragments of this block's 16 output channels
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, n = lane & 15;
+    const float* const ix0 = in.x0; const float* const ix1 = in.x1;
+    const int iC0 = in.C0, iC1 = in.C1;
+
+    const int nw = (W + TW - 1) / TW, nh = (H + ROWS - 1) / ROWS, nd = (D + T8_TD - 1) / T8_TD;
+    const int ntiles = B * nd * nh * nw;
+    int tile, tile_end, tile_step;
+    if (ntiles >= 64) {                             // XCD x = blockIdx.x % 8 walks its contiguous eighth of the tiles
+        const int x = blockIdx.x & 7;
+        tile_step = gridDim.x >> 3;
+        tile = (int)((long long)ntiles * x / 8) + (blockIdx.x >> 3);
+        tile_end = (int)((long long)ntiles * (x + 1) / 8);
+    } else {
+        tile = blockIdx.x; tile_end = ntiles; tile_step = gridDim.x;
+    }
+    if (tile >= tile_end) return;
+    struct Org { int b, d0, h0, w0; };
+    auto decode = [&](int t) __attribute__((always_inline)) -> Org {
+        const int tw = t % nw; int tq = t / nw;
+        const int th = tq % nh; tq /= nh;
+        return Org{tq / nd, (tq % nd) * T8_TD, th * ROWS, tw * TW};
+    };
+    Org cur = decode(tile);
+    const int g = blockIdx.y;                       // output-channel group of 16
+    const int V = D * H * W;
+
+    // per-lane k-step table: LDS offset of (ci, tap) for this lane's k = 4 s + kq; the weights of the group go to LDS once
+    int offs[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k = 4 * s + kq;
+        const bool valid = k < 27 * CIN;            // the padding k-values of the last step carry zero weights
+        const int tap = valid ? k / CIN : 0, ci = valid ? k % CIN : 0;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        offs[s] = ci * PS + (kd * HR + kh) * RS + kw + wave * HR * RS + n + 1;
+    }
+    for (int i = tid; i < NS * 64; i += T8_THREADS) Wl[i] = wk[(size_t)g * NS * 64 + i];
+    float bz[1][4];                                 // once per block, not per tile
+    conv_load_bias<1>(bz, bias, Cout, g, kq);
+
+    auto opaque = [](int v) __attribute__((always_inline)) -> int { asm volatile("" : "+v"(v)); return v; };
+    f32x4 xi[NI];
+    float xh[NHL];
+    auto load_x = [&](const Org& o) __attribute__((always_inline)) {
+        if (wave >= CIN) return;                    // wave c stages input channel c
+        const int ln = opaque(lane);                // (keeps the address arithmetic inside the tile loop: registers)
+        const bool s0 = wave < iC0;
+        const float* base = s0 ? ix0 + (size_t)o.b * in.bs0 + (size_t)wave * V : ix1 + (size_t)o.b * in.bs1 + (size_t)(wave - iC0) * V;
+        const __amdgpu_buffer_rsrc_t r = vxm_rsrc(base, (unsigned)V * 4u);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int rr = 16 * j + (ln >> 2);
+            const int gd = o.d0 - 1 + rr / HR, gh = o.h0 - 1 + rr % HR, gw = o.w0 + 4 * (ln & 3);
+            const bool ok = rr < NROW && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw < W;
+            xi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < NHL; ++j) {
+            const int rr = 32 * j + (ln >> 1);
+            const int gd = o.d0 - 1 + rr / HR, gh = o.h0 - 1 + rr % HR, gw = (ln & 1) ? o.w0 + TW : o.w0 - 1;
+            const bool ok = rr < NROW && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            xh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB, 0, 0));
+        }
+    };
+    auto store_x = [&](int buf) __attribute__((always_inline)) {
+        if (wave >= CIN) return;
+        float* dst = Xs2 + buf * (CIN * PS) + wave * PS;
+        const int ibase = (lane >> 2) * RS + 2 + 4 * (lane & 3), hbase = (lane >> 1) * RS + ((lane & 1) ? 18 : 1);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            if (64 * j + lane < NROW * 4) {
+                *reinterpret_cast<f32x2*>(dst + ibase + 16 * j * RS) = (f32x2){xi[j].x, xi[j].y};
+                *reinterpret_cast<f32x2*>(dst + ibase + 16 * j * RS + 2) = (f32x2){xi[j].z, xi[j].w};
+            }
+#pragma unroll
+        for (int j = 0; j < NHL; ++j)
+            if (64 * j + lane < NROW * 2) dst[hbase + 32 * j * RS] = xh[j];
+    };
+
+    f32x4 acc[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    load_x(cur);
+    store_x(0);
+    __syncthreads();
+    int buf = 0;
+    for (;;) {
+        const int tile_next = tile + tile_step;
+        const bool has_next = tile_next < tile_end;
+        if (has_next) load_x(decode(tile_next));    // in flight under the MFMAs below
+        const float* Xs = Xs2 + buf * (CIN * PS);
+        float bv[2][ROWS], wa[2];
+        wa[0] = Wl[lane];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) bv[0][r] = Xs[offs[0] + r * RS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s + 1 < NS) {
+                wa[(s + 1) & 1] = Wl[(s + 1) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) bv[(s + 1) & 1][r] = Xs[offs[s + 1] + r * RS];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) acc[r] = vxm_mfma16(wa[s & 1], bv[s & 1][r], acc[r]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // The next tile's planes go to the other LDS buffer BEFORE this tile's output stores are issued: vmcnt counts loads
+        // and stores alike, so waiting for the prefetch after the stores would wait for the stores' write acknowledgements.
+        if (has_next) store_x(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue: bias + LeakyReLU (+ fused leaky_relu_backward mask), NCDHW store (branch-free buffer stores)
+        {
+            const int ln = opaque(lane), ekq = ln >> 4, en = ln & 15;
+            const int d = cur.d0 + wave, w = cur.w0 + en;
+            f32x4 (&acc1)[1][ROWS] = *reinterpret_cast<f32x4 (*)[1][ROWS]>(&acc);
+            conv_epilogue_store<1, ROWS>(acc1, y + (size_t)cur.b * y_bs, bz, mask ? mask + (size_t)cur.b * mask_bs : nullptr, act_slope, mask_slope,
+                                         Cout, g, ekq, d < D && w < W, (d * H + cur.h0) * W + w, cur.h0, H, W, V);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (!has_next) break;
+        __syncthreads();                            // the other buffer is complete, and every wave is done reading this one
+        buf ^= 1;
+        tile = tile_next;
+        cur = decode(tile);
+    }
+}
+
+// w: [Cw_out][Cw_in][27] (reference layout) -> [G][NS][64]: lane (kq, n) of k-step s holds the weight of output channel
+// 16 g + n for k = 4 s + kq = tap * Cin_p + ci (zero beyond 27 Cin_p); flip = the adjoint operator (backward-data)
+__global__ void __launch_bounds__(256) k_pack_weights_kpack(const float* __restrict__ w, float* __restrict__ wk, int Cw_in, int flip, int Cin_p,
+                                                            int Cout_p, int NS, size_t elems) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elems) return;
+    const int lane = (int)(i % 64);
+    const int s = (int)((i / 64) % NS), g = (int)(i / 64 / NS);
+    const int co = g * 16 + (lane & 15), k = 4 * s + (lane >> 4);
+    float v = 0.0f;
+    if (co < Cout_p && k < 27 * Cin_p) {
+        const int tap = k / Cin_p, ci = k % Cin_p;
+        v = flip ? w[((size_t)ci * Cw_in + co) * 27 + (26 - tap)] : w[((size_t)co * Cw_in + ci) * 27 + tap];
+    }
+    wk[i] = v;
+}
+
 struct ConvCfg { int CK, NCT, Q, G; size_t elems; };
 ConvCfg conv_cfg(int Cin, int Cout) {
     ConvCfg c;
@@ -983,6 +1066,22 @@ ConvCfg conv_cfg(int Cin, int Cout) {
     c.G = (Cout + 16 * c.NCT - 1) / (16 * c.NCT);
     c.elems = (size_t)c.G * c.Q * 27 * (c.CK / 4) * c.NCT * 64;
     return c;
+}
+// layers with at most 4 input channels carry a second copy of their weights in the dense-K order of k_conv3d_k3_kpack
+size_t kpack_elems(int Cin, int Cout) { return Cin <= 4 ? (size_t)((Cout + 15) / 16) * kpack_steps(Cin) * 64 : 0; }
+int kpack_blocks() {
+    static const int n = [] {
+        const char* e = getenv("VXM_KPACK_BLOCKS");     // developer experiments
+        const int v = e ? atoi(e) : 1024;
+        return v >= 8 ? v / 8 * 8 : 1024;
+    }();
+    return n;
+}
+bool kpack_ok(int C0, int C1, int x0_up, const float* x0, int64_t bs0, const float* x1, int64_t bs1, const float* wpacked, int B, int D, int H,
+              int W) {
+    const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + KP_ROWS - 1) / KP_ROWS) * ((W + TW - 1) / TW);
+    return C0 + C1 <= 4 && !x0_up && (W & 3) == 0 && al16(x0) && (C1 == 0 || al16(x1)) && (bs0 & 3) == 0 && (bs1 & 3) == 0 &&
+           (((long long)D * H * W) & 3) == 0 && al16(wpacked) && tiles8 >= wide_min_tiles() && tiles8 < (1ll << 30) && !bw_force_generic();
 }
 
 // rows per wave of the 8-wave kernel
@@ -1020,7 +1119,7 @@ extern "C" {
 
 size_t vxm_conv3d_k3_packed_elems(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0) return 0;
-    return conv_cfg(Cin, Cout).elems;
+    return conv_cfg(Cin, Cout).elems + kpack_elems(Cin, Cout);
 }
 
 int vxm_conv3d_k3_pack_weights(const float* w, float* wpacked, int Cin, int Cout, int transpose_flip, void* stream) {
@@ -1030,6 +1129,9 @@ int vxm_conv3d_k3_pack_weights(const float* w, float* wpacked, int Cin, int Cout
     const ConvCfg c = conv_cfg(cin_p, cout_p);
     hipLaunchKernelGGL(k_pack_weights, dim3(vxm_blocks((long long)c.elems, 256)), dim3(256), 0, VXM_STREAM(stream), w, wpacked,
                        Cin, Cout, transpose_flip, cin_p, cout_p, c.CK, c.NCT, c.Q, c.elems);
+    if (const size_t ke = kpack_elems(cin_p, cout_p))
+        hipLaunchKernelGGL(k_pack_weights_kpack, dim3(vxm_blocks((long long)ke, 256)), dim3(256), 0, VXM_STREAM(stream), w, wpacked + c.elems,
+                           Cin, transpose_flip, cin_p, cout_p, kpack_steps(cin_p), ke);
     return vxm_check_launch("vxm_conv3d_k3_pack_weights");
 }
 
@@ -1040,6 +1142,22 @@ int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, co
     VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_fwd: null pointer");
     const ConvCfg c = conv_cfg(C0 + C1, Cout);
     ConvIn in{x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up};
+    if (kpack_ok(C0, C1, x0_up, x0, x0_bstride, x1, x1_bstride, wpacked, B, D, H, W)) {      // few input channels: dense-K MFMA kernel
+        const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + KP_ROWS - 1) / KP_ROWS) * ((W + TW - 1) / TW);
+        const long long nb = tiles8 < (long long)kpack_blocks() ? (tiles8 + 7) / 8 * 8 : (long long)kpack_blocks();
+        const dim3 gridk((unsigned)nb, (Cout + 15) / 16);
+        const float* wk = wpacked + c.elems;
+#define LAUNCHK(CIN_) hipLaunchKernelGGL(k_conv3d_k3_kpack<CIN_>, gridk, dim3(T8_THREADS), 0, VXM_STREAM(stream), in, wk, bias, y, (long long)y_bstride, \
+        Cout, act_slope, mask_src, (long long)mask_bstride, mask_slope, B, D, H, W)
+        switch (C0 + C1) {
+            case 1: LAUNCHK(1); break;
+            case 2: LAUNCHK(2); break;
+            case 3: LAUNCHK(3); break;
+            default: LAUNCHK(4); break;
+        }
+#undef LAUNCHK
+        return vxm_check_launch("vxm_conv3d_k3_fwd");
+    }
     // large layers: the 8-wave wide-load kernel (needs 4-float groups that neither straddle row ends nor break alignment)
     {
         const int rows = fwd_wide_rows(c);
@@ -1090,6 +1208,7 @@ int vxm_conv3d_k3_fwd_variant(const float* x0, int C0, int64_t x0_bstride, const
                               const float* wpacked, int Cout, int B, int D, int H, int W) {
     if (C0 <= 0 || C1 < 0 || Cout <= 0) return -1;
     const ConvCfg c = conv_cfg(C0 + C1, Cout);
+    if (kpack_ok(C0, C1, 0, x0, x0_bstride, x1, x1_bstride, wpacked, B, D, H, W)) return 200 + C0 + C1;
     return (fwd_wide_ok(c, x0, x0_bstride, x1, C1, x1_bstride, wpacked, B, D, H, W) ? 100 : 0) + 10 * c.CK + c.NCT;
 }
 

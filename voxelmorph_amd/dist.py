@@ -52,3 +52,12 @@ def max_over_ranks(value, device):
 def barrier():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
+
+
+def native_comm():
+    """`VXM_COMM=rccl`: a libvxm_comm.so communicator for the gradient all-reduce (None otherwise: torch.distributed's
+    'nccl' backend, the same RCCL, does it).  Needs an initialised process group for the rendezvous."""
+    if os.environ.get("VXM_COMM", "") != "rccl" or not (dist.is_available() and dist.is_initialized()):
+        return None
+    from .comm import NativeComm
+    return NativeComm.from_torch_dist()

@@ -12,7 +12,7 @@ from ._lib import call, ptr, require_device, stream
 
 
 class FlatAdam:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, direct_grads=True):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, direct_grads=True, comm=None):
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("FlatAdam: model has no trainable parameters")
@@ -26,7 +26,10 @@ class FlatAdam:
         self.step_count = 0
         self.group = process_group
         self.world = 1
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
+        self.comm = comm                       # voxelmorph_amd.comm.NativeComm: direct RCCL calls instead of torch.distributed
+        if comm is not None:
+            self.world = comm.world
+        elif torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
         off = 0
         self._views = []
@@ -44,7 +47,9 @@ class FlatAdam:
     def broadcast_params(self, src=0):
         """One-off: make every rank start from rank `src`'s weights (replaces DataParallel's per-step
         broadcast_coalesced)."""
-        if self.world > 1:
+        if self.comm is not None:
+            self.comm.broadcast(self.flat_param, src)
+        elif self.world > 1:
             torch.distributed.broadcast(self.flat_param, src, group=self.group)
 
     def zero_grad(self):
@@ -61,7 +66,9 @@ class FlatAdam:
     def reduce_grads(self):
         """The only data-path collective: SUM all-reduce of the flat gradient bucket (RCCL over xGMI when
         the backend is 'nccl'; gloo in the CPU tests).  The 1/world average is applied by the Adam kernel."""
-        if self.world > 1:
+        if self.comm is not None:
+            self.comm.all_reduce_sum(self.flat_grad)
+        elif self.world > 1:
             torch.distributed.all_reduce(self.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
 
     def step(self):

@@ -256,7 +256,8 @@ def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, ma
     name = None
     if _prof.ACTIVE is not None:          # label the region with the kernel the C ABI will dispatch to
         v = _lib.lib().vxm_conv3d_k3_fwd_variant(ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), cout, B, D, H, W)
-        name = "k_conv3d_k3_t8<%d>" % (v % 10) if v >= 100 else "k_conv3d_k3<%d,%d>" % (v // 10, v % 10)
+        name = "k_conv3d_k3_kpack<%d>" % (v - 200) if v >= 200 else (
+            "k_conv3d_k3_t8<%d>" % (v % 10) if v >= 100 else "k_conv3d_k3<%d,%d>" % (v // 10, v % 10))
     with _prof.region(name, flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_conv3d_k3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
              cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, stream())
