@@ -139,6 +139,55 @@ __device__ __forceinline__ void bw_write_partial(const BwBlock& k, float* __rest
     }
 }
 
+// K-split variant for blocks with at most 8 N-tiles (2 input channels: 4 tiles; the role-swapped 3-channel flow conv: 6):
+// instead of leaving most of the 16 waves without an N-tile, the 64 k-steps of a voxel tile are split into `ksplit` ranges
+// and wave w takes N-tile w % (16 / ksplit) over range w / (16 / ksplit); the ranges' partial sums meet in LDS at the end
+// (bw_ksplit_reduce).  LEN = 64 / ksplit k-steps; the range offset enters through boff / aoff (it is linear in the range).
+template <int NCT, int RS, int PZ>
+__device__ __forceinline__ void bw_ksteps_split(int len, bool active, bool bias, const float* Xb, const float* Zb, const int (&boff)[BW_SLOTS],
+                                                int aoff, f32x4 (&acc)[BW_SLOTS][NCT], float (&bsum)[NCT]) {
+    if (!active) return;
+    if (bias) {
+        switch (len) {
+            case 32: bw_ksteps<NCT, 1, 0, 32, RS, PZ, true>(Xb, Zb, boff, aoff, acc, bsum); break;
+            case 16: bw_ksteps<NCT, 1, 0, 16, RS, PZ, true>(Xb, Zb, boff, aoff, acc, bsum); break;
+            default: bw_ksteps<NCT, 1, 0, 8, RS, PZ, true>(Xb, Zb, boff, aoff, acc, bsum); break;
+        }
+        return;
+    }
+    switch (len) {
+        case 32: bw_ksteps<NCT, 1, 0, 32, RS, PZ, false>(Xb, Zb, boff, aoff, acc, bsum); break;
+        case 16: bw_ksteps<NCT, 1, 0, 16, RS, PZ, false>(Xb, Zb, boff, aoff, acc, bsum); break;
+        default: bw_ksteps<NCT, 1, 0, 8, RS, PZ, false>(Xb, Zb, boff, aoff, acc, bsum); break;
+    }
+}
+// sum the k-ranges of every N-tile into the range-0 wave (fixed order: deterministic); scratch = the dead tile buffers
+template <int NCT>
+__device__ __forceinline__ void bw_ksplit_reduce(float* scratch, int wave, int lane, int tp, int ksplit, f32x4 (&acc)[BW_SLOTS][NCT], float (&bsum)[NCT]) {
+    __syncthreads();                                  // every wave is done with the tile buffers
+    float* mine = scratch + wave * (NCT * 5 * 64);
+    if (wave >= tp) {
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mine[(ct * 5 + j) * 64 + lane] = acc[0][ct][j];
+            mine[(ct * 5 + 4) * 64 + lane] = bsum[ct];
+        }
+    }
+    __syncthreads();
+    if (wave < tp) {
+        for (int kp = 1; kp < ksplit; ++kp) {
+            const float* o = scratch + (wave + kp * tp) * (NCT * 5 * 64);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[0][ct][j] += o[(ct * 5 + j) * 64 + lane];
+                bsum[ct] += o[(ct * 5 + 4) * 64 + lane];
+            }
+        }
+    }
+}
+
 // ---- fast path (W % 4 == 0, 16-byte aligned tensors): register-staged tiles from wide buffer loads ------------
 // X plane in LDS: [6][6][20] with the 16 interior columns at 2..17 (8-byte aligned -> ds_write_b64), the halo
 // columns at 1 and 18; plane stride 738 = 2 mod 32 (conflict-free B-operand reads).  Per tile a wave issues 3
@@ -168,26 +217,31 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_vec(ConvIn 
     const int Hs = H >> 1, Ws = W >> 1;
     const int V0 = iup0 ? (D >> 1) * Hs * Ws : V;     // plane size of segment 0
 
-    // N-tile j of this wave (slot i): entries e = j*16 + n  ->  (tap = e / ckc, channel = e % ckc)
+    // N-tile j of this wave (slot i): entries e = j*16 + n  ->  (tap = e / ckc, channel = e % ckc).  With at most 8 N-tiles
+    // the k-steps are split instead (see bw_ksteps_split): tp N-tiles x ksplit ranges of klen k-steps.
+    const int tp = k.ntile <= 2 ? 2 : (k.ntile <= 4 ? 4 : (k.ntile <= 8 ? 8 : BW_WAVES));
+    const int ksplit = BW_WAVES / tp, klen = 64 / ksplit;
+    const int wtile = ksplit > 1 ? wave % tp : wave, kpart = ksplit > 1 ? wave / tp : 0;
+    const int rowbase = (klen * kpart) >> 2;          // first (dz, hy) row of this wave's k-range
     int boff[BW_SLOTS];
-    const int nslots = wave < k.ntile ? (k.ntile - wave + BW_WAVES - 1) / BW_WAVES : 0;     // wave-uniform
+    const int nslots = ksplit > 1 ? (wtile < k.ntile ? 1 : 0) : (wave < k.ntile ? (k.ntile - wave + BW_WAVES - 1) / BW_WAVES : 0);     // wave-uniform
 #pragma unroll
     for (int i = 0; i < BW_SLOTS; ++i) {
-        const int e = (wave + BW_WAVES * i) * 16 + n;
+        const int e = (wtile + BW_WAVES * i) * 16 + n;
         int off = 2;
         if (e < k.nent) {
             const int t = e / k.ckc, cl = e - t * k.ckc;
             off = cl * BV_PSX + ((t / 9) * HH + (t / 3) % 3) * BV_RS + t % 3 + 1;       // column = wx + kw - 1 + 2
         }
-        boff[i] = off + kq;                       // + voxel k of the MFMA B operand
+        boff[i] = off + kq + ((rowbase >> 2) * HH + (rowbase & 3)) * BV_RS;              // + voxel k of the MFMA B operand (+ k-range)
     }
-    const int aoff = n * BV_PZ + kq;              // MFMA A operand: dZ[co = n][voxel 4s + kq]
+    const int aoff = n * BV_PZ + kq + 4 * klen * kpart;      // MFMA A operand: dZ[co = n][voxel 4s + kq]
     f32x4 acc[BW_SLOTS][NCT];
 #pragma unroll
     for (int i = 0; i < BW_SLOTS; ++i)
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) acc[i][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const bool bias = want_bias && k.c0 == 0 && wave == 0;       // wave-uniform: one wave per output-channel group
+    const bool bias = want_bias && k.c0 == 0 && wtile == 0;      // wave-uniform: the wave(s) of N-tile 0 of each output-channel group
     float bsum[NCT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) bsum[ct] = 0.0f;
@@ -293,12 +347,17 @@ __global__ void __launch_bounds__(BW_THREADS) k_conv3d_k3_bwd_weight_vec(ConvIn 
         const bool more = tile + 1 < k.hi;
         if (more) load_tile(tile + 1);                 // in flight under the MFMAs below
         const float* Xb = smem + (iter & 1) * BUF;
-        bw_ksteps_n<NCT, 0, 64, BV_RS, BV_PZ>(nslots, bias, Xb, Xb + BW_CKI * BV_PSX, boff, aoff, acc, bsum);
+        if (ksplit > 1) bw_ksteps_split<NCT, BV_RS, BV_PZ>(klen, nslots > 0, bias, Xb, Xb + BW_CKI * BV_PSX, boff, aoff, acc, bsum);
+        else bw_ksteps_n<NCT, 0, 64, BV_RS, BV_PZ>(nslots, bias, Xb, Xb + BW_CKI * BV_PSX, boff, aoff, acc, bsum);
         float* Xn = smem + ((iter + 1) & 1) * BUF;     // last read before the previous barrier
         if (more) store_tile(Xn, Xn + BW_CKI * BV_PSX);
         __syncthreads();
     }
-    bw_write_partial<NCT>(k, part, Cout, Cin, wave, lane, nslots, acc, bias, bsum);
+    if (ksplit > 1) {
+        bw_ksplit_reduce<NCT>(smem, wave, lane, tp, ksplit, acc, bsum);
+        if (kpart > 0) return;
+    }
+    bw_write_partial<NCT>(k, part, Cout, Cin, wtile, lane, nslots, acc, bias && kpart == 0, bsum);
 }
 
 // ---- generic path (any W / alignment): LDS-DMA staging -------------------------------------------------------
@@ -583,12 +642,15 @@ __global__ void __launch_bounds__(256) k_reduce_partials_up_sum(const float* __r
         const int co = e / (C0 * 64), ci = (e >> 6) % C0;
         const int cb = Qc * G, combo = ci / BW_CKI + Qc * (co / cog_size);
         const int nparts = (T - combo + cb - 1) / cb;
+        // 8 independent loads in flight per thread (the partials of one element are 256 KB apart: latency, not bandwidth)
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int p = y;
-        for (; p + 4 < nparts; p += 8) {
-            s0 += part[(size_t)p * n + e];
-            s1 += part[(size_t)(p + 4) * n + e];
+        for (; p + 28 < nparts; p += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += part[(size_t)(p + 4 * u) * n + e];
         }
-        for (; p < nparts; p += 4) s0 += part[(size_t)p * n + e];
+        for (; p < nparts; p += 4) s[0] += part[(size_t)p * n + e];
+        s0 = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
     sm[y][x] = s0 + s1;
     __syncthreads();
