@@ -93,6 +93,10 @@ def hbm_traffic(kernel):
     except (OSError, ValueError):
         return None, None
     ent = ctr.get(kernel)
+    if ent is None and kernel.endswith(">"):          # region label "k<1>" vs the full template argument list "k<1, 4>"
+        stem = kernel[:-1]
+        hits = [v for k, v in ctr.items() if k.startswith(stem + ",") or k.startswith(stem + ">")]
+        ent = hits[0] if len(hits) == 1 else None
     if not ent or "FETCH_SIZE" not in ent or "WRITE_SIZE" not in ent:
         return None, None
     return (2.0 * ent["FETCH_SIZE"]["mean"] + ent["WRITE_SIZE"]["mean"]) * 1024.0, os.path.relpath(files[-1], ROOT)
