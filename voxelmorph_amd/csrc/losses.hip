@@ -134,11 +134,11 @@ __global__ void __launch_bounds__(256) k_ncc_grad_w(const float* __restrict__ u2
 // the 3-D sums of the slice R behind the front give cc, its fp64 block reduction and the three partials
 // (a, b, c) = d cc / d(J sum, J^2 sum, IJ sum) that backward box-filters.  HBM traffic: I, J once (+ L2-served halo),
 // 3 planes written -- instead of 5 planes x 3 passes.
-constexpr int NF_TH = 8, NF_TW = 32, NF_SEG = 40;     // tile, and slices per block along D
+constexpr int NF_TH = 8, NF_TW = 32, NF_SEG = 40;     // tile, and (at most) slices per block along D
 
 template <int R>
 __global__ void __launch_bounds__(256) k_ncc_fused_fwd(const float* __restrict__ I, const float* __restrict__ J, float* __restrict__ abc,
-                                                       double* __restrict__ acc, int D, int H, int W, long long BV) {
+                                                       double* __restrict__ acc, int D, int H, int W, long long BV, int seg) {
     constexpr int WIN = 2 * R + 1, PH = NF_TH + 2 * R, PW = NF_TW + 2 * R, PWP = PW + 1;
     __shared__ float P[5][PH][PWP];
     __shared__ float Rw[5][PH][NF_TW];
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256) k_ncc_fused_fwd(const float* __restrict__
     const int tid = threadIdx.x, wx = tid & 31, hy = tid >> 5;
     const int ntw = (W + NF_TW - 1) / NF_TW;
     const int w0 = (blockIdx.x % ntw) * NF_TW, h0 = (blockIdx.x / ntw) * NF_TH;
-    const int dlo = blockIdx.y * NF_SEG, dhi = min(D, dlo + NF_SEG);
+    const int dlo = blockIdx.y * seg, dhi = min(D, dlo + seg);
     const size_t HW = (size_t)H * W, vol = (size_t)blockIdx.z * D * HW;
     const float n = (float)(WIN * WIN * WIN);
     const int gh = h0 + hy, gw = w0 + wx;
@@ -223,14 +223,14 @@ __global__ void __launch_bounds__(256) k_ncc_fused_fwd(const float* __restrict__
 template <int R>
 __global__ void __launch_bounds__(256) k_ncc_fused_bwd(const float* __restrict__ I, const float* __restrict__ J, const float* __restrict__ abc,
                                                        const float* __restrict__ gloss, float* __restrict__ gJ, int D, int H, int W,
-                                                       long long BV) {
+                                                       long long BV, int seg) {
     constexpr int WIN = 2 * R + 1, PH = NF_TH + 2 * R, PW = NF_TW + 2 * R, PWP = PW + 1;
     __shared__ float P[3][PH][PWP];
     __shared__ float Rw[3][PH][NF_TW];
     const int tid = threadIdx.x, wx = tid & 31, hy = tid >> 5;
     const int ntw = (W + NF_TW - 1) / NF_TW;
     const int w0 = (blockIdx.x % ntw) * NF_TW, h0 = (blockIdx.x / ntw) * NF_TH;
-    const int dlo = blockIdx.y * NF_SEG, dhi = min(D, dlo + NF_SEG);
+    const int dlo = blockIdx.y * seg, dhi = min(D, dlo + seg);
     const size_t HW = (size_t)H * W, vol = (size_t)blockIdx.z * D * HW;
     const int gh = h0 + hy, gw = w0 + wx;
     const bool pix_ok = gh < H && gw < W;
@@ -435,6 +435,19 @@ unsigned stream_blocks(long long n) {
     return (unsigned)(nb > 8192 ? 8192 : (nb < 1 ? 1 : nb));
 }
 
+// Slices per block of the fused march: 40 (a fifth of them re-marched as warm-up halo for a 9-wide window) when that
+// still gives every CU several blocks, 20 when it does not (one 160x192x224 pair is only 168 columns x 4 segments
+// = 2.6 blocks per CU at 40).  Every output slice sums the same 2R+1 input slices in the same order whatever the
+// segment length, so the result does not depend on it.
+int ncc_segment(int B, int D, int H, int W) {
+    static const int forced = [] { const char* e = getenv("VXM_NCC_SEG"); return e ? atoi(e) : 0; }();     // developer experiments
+    if (forced > 0) return forced;
+    const long long cols = (long long)((W + NF_TW - 1) / NF_TW) * ((H + NF_TH - 1) / NF_TH) * B;
+    int seg = NF_SEG;
+    while (seg > 20 && cols * ((D + seg - 1) / seg) < 1024) seg = (seg + 1) / 2;     // measured at B = 1: 40 -> 0.39 ms, 20 -> 0.30, 14 -> 0.34, 10 -> 0.36
+    return seg;
+}
+
 // generic separable NCC passes; `sums` receives the five box sums, `work` is 5 (forward) / 6 (backward) planes of scratch
 void ncc_generic_fwd(const float* I, const float* J, float* sums, float* work, double* acc, long long BV, int D, int H, int W, int r, float n,
                      hipStream_t s) {
@@ -464,12 +477,13 @@ int vxm_ncc_fwd(const float* I, const float* J, float* loss, float* sums, float*
     hipStream_t s = VXM_STREAM(stream);
     (void)hipMemsetAsync(acc, 0, sizeof(double), s);
     if (win >= 3 && win <= 9 && B <= 65535) {          // fused march; `sums` receives the (a, b, c) planes for backward
-        const dim3 grid(((W + NF_TW - 1) / NF_TW) * ((H + NF_TH - 1) / NF_TH), (D + NF_SEG - 1) / NF_SEG, B);
+        const int seg = ncc_segment(B, D, H, W);
+        const dim3 grid(((W + NF_TW - 1) / NF_TW) * ((H + NF_TH - 1) / NF_TH), (D + seg - 1) / seg, B);
         switch (r) {
-            case 1: hipLaunchKernelGGL(k_ncc_fused_fwd<1>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV); break;
-            case 2: hipLaunchKernelGGL(k_ncc_fused_fwd<2>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV); break;
-            case 3: hipLaunchKernelGGL(k_ncc_fused_fwd<3>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV); break;
-            default: hipLaunchKernelGGL(k_ncc_fused_fwd<4>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV); break;
+            case 1: hipLaunchKernelGGL(k_ncc_fused_fwd<1>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV, seg); break;
+            case 2: hipLaunchKernelGGL(k_ncc_fused_fwd<2>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV, seg); break;
+            case 3: hipLaunchKernelGGL(k_ncc_fused_fwd<3>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV, seg); break;
+            default: hipLaunchKernelGGL(k_ncc_fused_fwd<4>, grid, dim3(256), 0, s, I, J, sums, acc, D, H, W, BV, seg); break;
         }
     } else {                                            // generic separable passes; `sums` receives the five box sums
         ncc_generic_fwd(I, J, sums, work, acc, BV, D, H, W, r, (float)win * win * win, s);
@@ -486,12 +500,13 @@ int vxm_ncc_bwd(const float* I, const float* J, const float* sums, const float* 
     const int r = win / 2;
     hipStream_t s = VXM_STREAM(stream);
     if (win >= 3 && win <= 9 && B <= 65535) {
-        const dim3 grid(((W + NF_TW - 1) / NF_TW) * ((H + NF_TH - 1) / NF_TH), (D + NF_SEG - 1) / NF_SEG, B);
+        const int seg = ncc_segment(B, D, H, W);
+        const dim3 grid(((W + NF_TW - 1) / NF_TW) * ((H + NF_TH - 1) / NF_TH), (D + seg - 1) / seg, B);
         switch (r) {
-            case 1: hipLaunchKernelGGL(k_ncc_fused_bwd<1>, grid, dim3(256), 0, s, I, J, sums, gloss, gJ, D, H, W, BV); break;
-            case 2: hipLaunchKernelGGL(k_ncc_fused_bwd<2>, grid, dim3(256), 0, s, I, J, sums, gloss, gJ, D, H, W, BV); break;
-            case 3: hipLaunchKernelGGL(k_ncc_fused_bwd<3>, grid, dim3(256), 0, s, I, J, sums, gloss, gJ, D, H, W, BV); break;
-            default: hipLaunchKernelGGL(k_ncc_fused_bwd<4>, grid, dim3(256), 0, s, I, J, sums, gloss, gJ, D, H, W, BV); break;
+            case 1: hipLaunchKernelGGL(k_ncc_fused_bwd<1>, grid, dim3(256), 0, s, I, J, sums, gloss, gJ, D, H, W, BV, seg); break;
+            case 2: hipLaunchKernelGGL(k_ncc_fused_bwd<2>, grid, dim3(256), 0, s, I, J, sums, gloss, gJ, D, H, W, BV, seg); break;
+            case 3: hipLaunchKernelGGL(k_ncc_fused_bwd<3>, grid, dim3(256), 0, s, I, J, sums, gloss, gJ, D, H, W, BV, seg); break;
+            default: hipLaunchKernelGGL(k_ncc_fused_bwd<4>, grid, dim3(256), 0, s, I, J, sums, gloss, gJ, D, H, W, BV, seg); break;
         }
         return vxm_check_launch("vxm_ncc_bwd");
     }
