@@ -5,6 +5,7 @@ calls into libvxm_hip.so on the current HIP stream.  PyTorch is used for device 
 (torch.empty through the caching allocator), streams and autograd bookkeeping only.
 """
 import math
+import os
 
 import torch
 
@@ -13,6 +14,15 @@ from .. import profiler as _prof
 from .._lib import call, ptr, require_device, stream
 
 SPLIT_48 = True     # conv_bwd_data: produce 48-channel results as 32 + 16 (module-level switch for A/B timing)
+OVERLAP_SMALL_LEVELS = os.environ.get("VXM_NO_OVERLAP", "") != "1"     # UnetFn.backward: weight gradients of the coarse levels on a second HIP stream
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
 INTERP = {"bilinear": 0, "nearest": 1}
 PENALTY = {"l1": 0, "l2": 1}
 
@@ -518,6 +528,10 @@ class UnetFn(torch.autograd.Function):
         dev, dt = gout.device, gout.dtype
         gout = _c(gout)
         ws = _Workspace(dev)
+        ws_side = _Workspace(dev)
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if OVERLAP_SMALL_LEVELS else None
+        used_side = False
         n_in = plan.n_inputs
         grads = [None] * (n_in + len(params))
         DZ = {}      # tensor id -> gradient w.r.t. the pre-activation of its producing conv
@@ -587,8 +601,20 @@ class UnetFn(torch.autograd.Function):
             gw_sink, gb_sink = getattr(w, "_vxm_grad_sink", None), getattr(b, "_vxm_grad_sink", None)
             gw = gw_sink if gw_sink is not None else torch.empty_like(w)
             gb = gb_sink if gb_sink is not None else torch.empty_like(b)
-            conv_bwd_weight(ws, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
-                            gw, gb, B, D, H, W)
+            if side is not None and plan.lvl[dst] >= 1:
+                # Below full resolution neither product fills the chip (a few hundred tiles on 256 CUs): the weight gradient
+                # of this block runs on a second stream beside the backward-data chain it does not feed.
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    conv_bwd_weight(ws_side, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
+                                    gw, gb, B, D, H, W)
+                dz.record_stream(side)          # dz is released by the main-stream chain before the side stream may be done
+                used_side = True
+            else:
+                conv_bwd_weight(ws, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
+                                gw, gb, B, D, H, W)
             grads[n_in + 2 * op["k"]] = None if gw_sink is not None else gw
             grads[n_in + 2 * op["k"] + 1] = None if gb_sink is not None else gb
             feeds_inputs = s0 < n_in
@@ -643,6 +669,8 @@ class UnetFn(torch.autograd.Function):
                 if not any(plan.ops[m]["kind"] == "pool" for m in plan.consumers[s1]):
                     g = GS.pop(s1)
                     finish_conv_output(s1, g[0].view(-1)[g[1]:], g[2])
+        if used_side:
+            main.wait_stream(side)              # gradients (and the activations the side stream read) are final past this point
         return (None,) + tuple(grads)
 
 
