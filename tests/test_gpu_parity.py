@@ -247,6 +247,36 @@ def test_conv_block_vs_oracle(vxm, cin, cout, vol, slope):
     assert rel_l2(N(bg.grad), bo.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("cin,cout,vol", [(8, 2, (8, 8, 16)), (16, 3, (8, 8, 16)), (5, 7, (6, 7, 20)), (24, 20, (8, 8, 32)), (3, 16, (8, 12, 16))])
+def test_conv_block_output_guard(vxm, cin, cout, vol):
+    """The epilogues store through buffer descriptors and let the hardware drop lanes that are out of range: channel counts that do
+    not fill the 16-channel MFMA tiles must not touch anything beyond their own channels (neighbouring channels of a larger
+    buffer, the next sample, the tail), forward and backward-data."""
+    from voxelmorph_amd.torch import functional as VF
+    D, H, W = vol
+    V = D * H * W
+    B, pad = 2, 5
+    torch.manual_seed(cin * 31 + cout)
+    x = torch.randn(B, cin, D, H, W, device="cuda")
+    w = torch.randn(cout, cin, 3, 3, 3, device="cuda") / (27 * cin) ** 0.5
+    b = torch.randn(cout, device="cuda")
+    big = torch.full((B + 1, cout + pad, D, H, W), 7.25, device="cuda")          # sentinel everywhere
+    y = big[:B, :cout]
+    VF.conv_forward(x, cin, cin * V, False, None, 0, 0, w, b, y, (cout + pad) * V, cout, 0.2, B, D, H, W)
+    assert bool((big[:B, cout:] == 7.25).all()) and bool((big[B] == 7.25).all())
+    ref = orc.conv_block(x.cpu().double(), w.cpu().double(), b.cpu().double(), 0.2)
+    assert rel_l2(N(y), ref.numpy()) < 1e-5
+    dz = torch.randn(B, cout, D, H, W, device="cuda")
+    mask = torch.randn(B, cin, D, H, W, device="cuda")
+    gfull = torch.full((B + 1, cin, D, H, W), 7.25, device="cuda")
+    VF.conv_bwd_data(dz, cout, w, gfull[:B], cin, mask, 0.2, B, D, H, W)
+    assert bool((gfull[B] == 7.25).all())
+    xr = x.cpu().double().requires_grad_()
+    torch.nn.functional.conv3d(xr, w.cpu().double(), None, padding=1).backward(dz.cpu().double())
+    want = xr.grad * torch.where(mask.cpu().double() > 0, 1.0, 0.2)
+    assert rel_l2(N(gfull[:B]), want.numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("c0,c1,cout,vol", [(32, 16, 32, (16, 8, 32)), (8, 0, 16, (8, 12, 16)), (6, 5, 20, (12, 8, 32)), (32, 32, 32, (8, 8, 16))])
 def test_conv_upsampled_segment_collapsed_weights(vxm, c0, c1, cout, vol):
     """cat([upsample2(x0), x1]) conv with the upsampled segment evaluated at low resolution through per-parity collapsed

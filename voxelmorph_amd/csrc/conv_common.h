@@ -97,8 +97,16 @@ bool bw_force_generic() {
 }
 // The 8-wave forward kernel is used from this many 8x4x16 tiles up (below, its 512-voxel tiles leave CUs idle);
 // VXM_CONV_WIDE_MIN_TILES overrides the threshold so that the parity tests can run it on small volumes.
+// Smallest tile count for which the 8-wave kernels replace the generic 4-wave kernel (measured on the default U-Net: the
+// 40x48x56 level, 210 tiles, is still faster on them; below that the generic kernel's smaller tiles win), and the same for the
+// low-resolution backward-data kernel (counted in its own tiles; it only pays from the 80x96x112 level up).
+// VXM_CONV_WIDE_MIN_TILES overrides both (the tests force every kernel onto small volumes with it).
 [[maybe_unused]] long long wide_min_tiles() {
-    static const long long v = [] { const char* e = getenv("VXM_CONV_WIDE_MIN_TILES"); return e ? atoll(e) : 1024ll; }();
+    static const long long v = [] { const char* e = getenv("VXM_CONV_WIDE_MIN_TILES"); return e ? atoll(e) : 128ll; }();
+    return v;
+}
+[[maybe_unused]] long long dlow_min_tiles() {
+    static const long long v = [] { const char* e = getenv("VXM_CONV_WIDE_MIN_TILES"); return e ? (atoll(e) + 3) / 4 : 256ll; }();
     return v;
 }
 
@@ -115,10 +123,12 @@ __device__ __forceinline__ void conv_load_bias(float (&bz)[NCT][4], const float*
 
 // ---- branch-free epilogue of the MFMA kernels (D layout: lane (kq, n) holds, in acc[ct][r][j], output channel
 // 16 (g NCT + ct) + 4 kq + j at voxel (d, h0 + r, w) with w = w0 + n): bias + LeakyReLU (+ the fused leaky_relu_backward
-// mask), NCDHW store.  Buffer stores / loads through descriptors whose range is exactly the tensor of the sample: the
-// lane part of the address is ONE 32-bit offset per tile (out-of-range for voxels outside the volume), channel and row
-// steps are wave-uniform scalar offsets, channels >= Cout fall off the end of the range, and the hardware drops what is out
-// of range -- no per-store branch, no 64-bit address arithmetic.  Rows beyond H are skipped by a wave-uniform test.
+// mask), NCDHW store.  Buffer stores / loads through a descriptor whose range is the tensor of the sample: the lane part
+// of the address is ONE 32-bit offset per tile, channel and row steps are wave-uniform scalar offsets, and a lane whose
+// voxel is outside the volume or whose channel is >= Cout gets an out-of-range offset, which the hardware drops -- no
+// per-store branch, no 64-bit address arithmetic.  (The channel test is explicit, one v_cndmask per store, and the scalar
+// offset is clamped into the tensor: the range check of a raw buffer compares the per-lane offset with num_records - soffset,
+// which must not be relied on once the scalar offset alone exceeds the range.)  Rows beyond H are skipped by a wave-uniform test.
 template <int NCT, int ROWS>
 __device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS], float* __restrict__ yb /* y + b * y_bs */, const float (&bz)[NCT][4],
                                                     const float* __restrict__ maskb /* mask + b * mask_bs or null */, float act_slope,
@@ -126,7 +136,10 @@ __device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS], flo
                                                     int h0, int H, int W, int V) {
     const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(yb, (unsigned)Cout * (unsigned)V * 4u);
     const __amdgpu_buffer_rsrc_t rm = vxm_rsrc(maskb ? maskb : yb, (unsigned)Cout * (unsigned)V * 4u);
-    const int voff = vox_ok ? ((g * NCT * 16 + kq * 4) * V + vox) << 2 : VXM_OOB;
+    const int cbase = g * NCT * 16 + kq * 4;       // first of this lane's channels; slot (ct, j) is channel cbase + 16 ct + j
+    const int nvalid = vox_ok ? Cout - cbase : 0;   // channel slots of this lane that exist (<= 0: none)
+    const int navail = Cout - g * NCT * 16;         // channel slots of the whole group (wave-uniform, >= 1)
+    const int voff = (cbase * V + vox) << 2;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         float mk[4][ROWS];
@@ -139,7 +152,8 @@ __device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS], flo
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r)
-                    mk[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, voff, ((ct * 16 + j) * V + r * W) << 2, 0));
+                    mk[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, ct * 16 + j < nvalid ? voff : VXM_OOB,
+                                                                                   (min(ct * 16 + j, navail - 1) * V + r * W) << 2, 0));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -152,7 +166,8 @@ __device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS], flo
                 for (int j = 0; j < 4; ++j) {
                     float v = acc[ct][r][j] + bz[ct][j];
                     v = (v > 0.0f ? v : v * act_slope) * mk[j][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, voff, ((ct * 16 + j) * V + r * W) << 2, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, ct * 16 + j < nvalid ? voff : VXM_OOB,
+                                                          (min(ct * 16 + j, navail - 1) * V + r * W) << 2, 0);
                 }
             }
         }

@@ -552,7 +552,10 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8u(const float* __
     {
         const int d = d0 + wave, h = h0 + 2 * (n >> 3), w = w0 + 2 * (n & 7);
         const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(y + (size_t)b * y_bs, (unsigned)Cout * (unsigned)V * 4u);
-        const int voff = (d < D && h < H && w < W) ? ((g * NCT * 16 + kq * 4) * V + (d * H + h) * W + w) << 2 : VXM_OOB;
+        const int cbase = g * NCT * 16 + kq * 4;
+        const int nvalid = (d < D && h < H && w < W) ? Cout - cbase : 0;         // existing channel slots of this lane (explicit: see conv_epilogue_store)
+        const int navail = Cout - g * NCT * 16;
+        const int voff = (cbase * V + (d * H + h) * W + w) << 2;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -563,7 +566,8 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8u(const float* __
                     float v0 = acc[ct][2 * ph][j] + bz, v1 = acc[ct][2 * ph + 1][j] + bz;
                     v0 = v0 > 0.0f ? v0 : v0 * act_slope;
                     v1 = v1 > 0.0f ? v1 : v1 * act_slope;
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){v0, v1}), ry, voff, ((ct * 16 + j) * V + ph * W) << 2, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, (f32x2){v0, v1}), ry, ct * 16 + j < nvalid ? voff : VXM_OOB,
+                                                          (min(ct * 16 + j, navail - 1) * V + ph * W) << 2, 0);
                 }
             }
     }
@@ -1268,7 +1272,7 @@ static int dlow_nct(int C0) { return C0 <= 16 ? 1 : 2; }
 int vxm_conv3d_k3_up_bwd_low_ok(const float* dz, int64_t dz_bstride, int C0, int Cout, int B, int D, int H, int W) {
     const long long tiles = (long long)B * ((D / 2 + 1) / 2) * ((H / 2 + 3) / 4) * ((W / 2 + 15) / 16);
     return C0 > 0 && Cout > 0 && (W & 3) == 0 && (D & 1) == 0 && (H & 1) == 0 && al16(dz) && (dz_bstride & 3) == 0 &&
-           (long long)Cout * D * H * W < (1ll << 29) && tiles >= (wide_min_tiles() + 3) / 4 && tiles < (1ll << 30) && !bw_force_generic();
+           (long long)Cout * D * H * W < (1ll << 29) && tiles >= dlow_min_tiles() && tiles < (1ll << 30) && !bw_force_generic();
 }
 
 size_t vxm_conv3d_k3_up_bwd_low_packed_elems(int C0, int Cout) {
