@@ -75,11 +75,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int VXM_OOB = (int)0x80000000;            // voffset beyond any num_records -> the lane loads 0.0
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t vxm_rsrc(const float* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
-}
 __device__ __forceinline__ void vxm_lds_dma4(__amdgpu_buffer_rsrc_t r, float* lds, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 4, voff, soff, 0, 0);      // lane l -> LDS base + 4 l
 }

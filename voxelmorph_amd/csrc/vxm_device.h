@@ -68,6 +68,19 @@ __device__ __forceinline__ void lin_src(int dst, float ratio, int n_in, int& i0,
     l0 = 1.0f - l1;
 }
 
+// Raw buffer descriptor over `bytes` bytes at p: loads / stores take 32-bit byte offsets (a lane part + a wave-uniform scalar
+// part) instead of 64-bit pointer arithmetic per access, and a lane whose offset is beyond the range loads 0.0 / is not stored.
+constexpr int VXM_OOB = (int)0x80000000;            // voffset beyond any num_records
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vxm_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float vxm_bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void vxm_bstore(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
 __device__ __forceinline__ float vxm_lrelu_grad(float y, float slope) { return y > 0.0f ? 1.0f : slope; }
 
 #endif

@@ -52,33 +52,40 @@ __device__ __forceinline__ Corners8 corners8(float z, float y, float x, int D, i
     const int h = p2_ / (W_), w = p2_ - h * (W_);                    \
     const int p = d * HW_ + p2_
 
+// Addressing: every plane of a sample is reached through one buffer descriptor per tensor with 32-bit byte offsets (lane part
+// 4 p or 4 idx, channel part in the wave-uniform scalar offset) -- the first version spent a quarter of its instructions on
+// 64-bit pointer arithmetic for the 8 gathers (V < 2^29 voxels per plane is checked on the host).
 template <int MODE>
 __global__ void __launch_bounds__(256) k_warp3d_fwd(const float* __restrict__ src, const float* __restrict__ flow,
                                                     float* __restrict__ out, int C, int D, int H, int W) {
     VXM_VOXEL_INDEX(D, H, W);
-    const float* fl = flow + (size_t)b * 3 * V;
-    const float z = vxm_src_coord(d, fl[p], D), y = vxm_src_coord(h, fl[V + p], H),
-                x = vxm_src_coord(w, fl[2 * (size_t)V + p], W);
+    const __amdgpu_buffer_rsrc_t rf = vxm_rsrc(flow + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
+    const int p4 = p << 2, V4 = V << 2;
+    const float z = vxm_src_coord(d, vxm_bload(rf, p4, 0), D), y = vxm_src_coord(h, vxm_bload(rf, p4, V4), H),
+                x = vxm_src_coord(w, vxm_bload(rf, p4, 2 * V4), W);
     const float* s = src + (size_t)b * C * V;
-    float* o = out + (size_t)b * C * V + p;
+    float* o = out + (size_t)b * C * V;
     if (MODE == VXM_INTERP_NEAREST) {
         const float rz = rintf(z), ry = rintf(y), rx = rintf(x);       // nearbyint: round-half-even
         const bool in = (rz >= 0.0f) & (rz <= (float)(D - 1)) & (ry >= 0.0f) & (ry <= (float)(H - 1)) &
                         (rx >= 0.0f) & (rx <= (float)(W - 1));
-        const int idx = in ? ((int)rz * H + (int)ry) * W + (int)rx : 0;
-        for (int c = 0; c < C; ++c) o[(size_t)c * V] = in ? s[(size_t)c * V + idx] : 0.0f;
+        const int idx4 = in ? (((int)rz * H + (int)ry) * W + (int)rx) << 2 : VXM_OOB;      // outside: the load returns 0.0
+        for (int c = 0; c < C; ++c) {
+            const __amdgpu_buffer_rsrc_t rs = vxm_rsrc(s + (size_t)c * V, (unsigned)V4), ro = vxm_rsrc(o + (size_t)c * V, (unsigned)V4);
+            vxm_bstore(vxm_bload(rs, idx4, 0), ro, p4, 0);
+        }
         return;
     }
     const Corners8 cn = corners8(z, y, x, D, H, W);
     for (int c = 0; c < C; ++c) {
-        const float* sc = s + (size_t)c * V;
+        const __amdgpu_buffer_rsrc_t rs = vxm_rsrc(s + (size_t)c * V, (unsigned)V4), ro = vxm_rsrc(o + (size_t)c * V, (unsigned)V4);
         float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = sc[cn.idx[k]];              // 8 independent gathers in flight
+        for (int k = 0; k < 8; ++k) v[k] = vxm_bload(rs, cn.idx[k] << 2, 0);       // 8 independent gathers in flight
         float acc = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc += v[k] * cn.w[k];
-        o[(size_t)c * V] = acc;
+        vxm_bstore(acc, ro, p4, 0);
     }
 }
 
@@ -89,22 +96,23 @@ __global__ void __launch_bounds__(256) k_warp3d_bwd(const float* __restrict__ sr
                                                     const float* __restrict__ gout, float* __restrict__ gsrc,
                                                     float* __restrict__ gflow, int C, int D, int H, int W) {
     VXM_VOXEL_INDEX(D, H, W);
-    const float* fl = flow + (size_t)b * 3 * V;
-    const float z = vxm_src_coord(d, fl[p], D), y = vxm_src_coord(h, fl[V + p], H),
-                x = vxm_src_coord(w, fl[2 * (size_t)V + p], W);
+    const __amdgpu_buffer_rsrc_t rf = vxm_rsrc(flow + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
+    const int p4 = p << 2, V4 = V << 2;
+    const float z = vxm_src_coord(d, vxm_bload(rf, p4, 0), D), y = vxm_src_coord(h, vxm_bload(rf, p4, V4), H),
+                x = vxm_src_coord(w, vxm_bload(rf, p4, 2 * V4), W);
     const float* s = src + (size_t)b * C * V;
-    const float* go = gout + (size_t)b * C * V + p;
+    const float* go = gout + (size_t)b * C * V;
     float* gs = gsrc ? gsrc + (size_t)b * C * V : nullptr;
-    float* gf = gflow ? gflow + (size_t)b * 3 * V + p : nullptr;
+    const __amdgpu_buffer_rsrc_t rg = vxm_rsrc(gflow ? gflow + (size_t)b * 3 * V : flow, gflow ? 3u * (unsigned)V * 4u : 0u);   // no gflow: every store dropped
     if (MODE == VXM_INTERP_NEAREST) {
-        if (gf) { gf[0] = 0.0f; gf[V] = 0.0f; gf[2 * (size_t)V] = 0.0f; }
+        vxm_bstore(0.0f, rg, p4, 0); vxm_bstore(0.0f, rg, p4, V4); vxm_bstore(0.0f, rg, p4, 2 * V4);
         if (gs) {
             const float rz = rintf(z), ry = rintf(y), rx = rintf(x);
             const bool in = (rz >= 0.0f) & (rz <= (float)(D - 1)) & (ry >= 0.0f) & (ry <= (float)(H - 1)) &
                             (rx >= 0.0f) & (rx <= (float)(W - 1));
             if (in) {
                 const int idx = ((int)rz * H + (int)ry) * W + (int)rx;
-                for (int c = 0; c < C; ++c) atomicAdd(gs + (size_t)c * V + idx, go[(size_t)c * V]);
+                for (int c = 0; c < C; ++c) atomicAdd(gs + (size_t)c * V + idx, go[(size_t)c * V + p]);
             }
         }
         return;
@@ -112,11 +120,11 @@ __global__ void __launch_bounds__(256) k_warp3d_bwd(const float* __restrict__ sr
     const Corners8 cn = corners8(z, y, x, D, H, W);
     float gz = 0.0f, gy = 0.0f, gx = 0.0f;
     for (int c = 0; c < C; ++c) {
-        const float g = go[(size_t)c * V];
-        const float* sc = s + (size_t)c * V;
+        const __amdgpu_buffer_rsrc_t rs = vxm_rsrc(s + (size_t)c * V, (unsigned)V4), rgo = vxm_rsrc(go + (size_t)c * V, (unsigned)V4);
+        const float g = vxm_bload(rgo, p4, 0);
         float v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = sc[cn.idx[k]];
+        for (int k = 0; k < 8; ++k) v[k] = vxm_bload(rs, cn.idx[k] << 2, 0);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
@@ -127,7 +135,7 @@ __global__ void __launch_bounds__(256) k_warp3d_bwd(const float* __restrict__ sr
             if (gs && cn.ok[k]) atomicAdd(gs + (size_t)c * V + cn.idx[k], g * cn.w[k]);
         }
     }
-    if (gf) { gf[0] = gz; gf[V] = gy; gf[2 * (size_t)V] = gx; }
+    vxm_bstore(gz, rg, p4, 0); vxm_bstore(gy, rg, p4, V4); vxm_bstore(gx, rg, p4, 2 * V4);
 }
 
 // One scaling-and-squaring step: out = v + warp(v, v), v = in * scale (scale is a power of two:
@@ -135,14 +143,16 @@ __global__ void __launch_bounds__(256) k_warp3d_bwd(const float* __restrict__ sr
 __global__ void __launch_bounds__(256) k_vecint_step_fwd(const float* __restrict__ in, float scale,
                                                          float* __restrict__ out, int D, int H, int W) {
     VXM_VOXEL_INDEX(D, H, W);
-    const float* vin = in + (size_t)b * 3 * V;
-    const float v0 = vin[p] * scale, v1 = vin[V + p] * scale, v2 = vin[2 * (size_t)V + p] * scale;
+    const __amdgpu_buffer_rsrc_t ri = vxm_rsrc(in + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
+    const __amdgpu_buffer_rsrc_t ro = vxm_rsrc(out + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
+    const int p4 = p << 2, V4 = V << 2;
+    const float v0 = vxm_bload(ri, p4, 0) * scale, v1 = vxm_bload(ri, p4, V4) * scale, v2 = vxm_bload(ri, p4, 2 * V4) * scale;
     const Corners8 cn = corners8(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W);
     float s0[8], s1[8], s2[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {                                     // 24 independent gathers in flight
-        const int i = cn.idx[k];
-        s0[k] = vin[i]; s1[k] = vin[V + i]; s2[k] = vin[2 * (size_t)V + i];
+        const int i4 = cn.idx[k] << 2;
+        s0[k] = vxm_bload(ri, i4, 0); s1[k] = vxm_bload(ri, i4, V4); s2[k] = vxm_bload(ri, i4, 2 * V4);
     }
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
 #pragma unroll
@@ -151,8 +161,7 @@ __global__ void __launch_bounds__(256) k_vecint_step_fwd(const float* __restrict
         a1 += (s1[k] * scale) * cn.w[k];
         a2 += (s2[k] * scale) * cn.w[k];
     }
-    float* o = out + (size_t)b * 3 * V + p;
-    o[0] = v0 + a0; o[V] = v1 + a1; o[2 * (size_t)V] = v2 + a2;
+    vxm_bstore(v0 + a0, ro, p4, 0); vxm_bstore(v1 + a1, ro, p4, V4); vxm_bstore(v2 + a2, ro, p4, 2 * V4);
 }
 
 // backward of one step.  With v = in*scale, out_c(p) = v_c(p) + sum_k w_k(v(p)) v_c(q_k):
@@ -479,8 +488,8 @@ __global__ void __launch_bounds__(256) k_resize3d_bwd_gather_tiled(const float* 
 int check_vol(const char* fn, int B, int C, int D, int H, int W) {
     VXM_REQUIRE(B > 0 && C > 0 && D > 1 && H > 1 && W > 1, VXM_ERR_BAD_SHAPE,
                 "%s: bad shape B=%d C=%d D=%d H=%d W=%d (3-D volumes with every extent > 1)", fn, B, C, D, H, W);
-    VXM_REQUIRE((long long)C * D * H * W < (1ll << 31) && B <= 65535 && D <= 65535, VXM_ERR_BAD_SHAPE,
-                "%s: per-sample element count must fit int32, B and D <= 65535", fn);
+    VXM_REQUIRE((long long)C * D * H * W < (1ll << 31) && (long long)D * H * W < (1ll << 28) && B <= 65535 && D <= 65535, VXM_ERR_BAD_SHAPE,
+                "%s: per-sample element count must fit int32 (32-bit byte offsets within 3 planes: fewer than 2^28 voxels), B and D <= 65535", fn);
     return VXM_OK;
 }
 
