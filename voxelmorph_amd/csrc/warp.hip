@@ -168,45 +168,8 @@ __global__ void __launch_bounds__(256) k_vecint_step_fwd(const float* __restrict
 //   d/d v_c(p)   : g_c(p)                                   (identity)
 //                  + sum_c' g_c'(p) d(sample_c')/d flow_c     (v is also the flow)
 //   d/d v_c(q_k) : g_c(p) w_k                                 (v is also the sampled source; scatter)
-// gin must be zero on entry; every contribution is an fp32 atomic (order-dependent in the last
-// bits, like ATen's grid_sampler_3d_backward + index_put(accumulate)).
-__global__ void __launch_bounds__(256) k_vecint_step_bwd(const float* __restrict__ in, float scale,
-                                                         const float* __restrict__ gout, float* __restrict__ gin,
-                                                         int D, int H, int W) {
-    VXM_VOXEL_INDEX(D, H, W);
-    const float* vin = in + (size_t)b * 3 * V;
-    const float* go = gout + (size_t)b * 3 * V + p;
-    float* gi = gin + (size_t)b * 3 * V;
-    const float v0 = vin[p] * scale, v1 = vin[V + p] * scale, v2 = vin[2 * (size_t)V + p] * scale;
-    const float g0 = go[0], g1 = go[V], g2 = go[2 * (size_t)V];
-    const Corners8 cn = corners8(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W);
-    float s0[8], s1[8], s2[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int i = cn.idx[k];
-        s0[k] = vin[i]; s1[k] = vin[V + i]; s2[k] = vin[2 * (size_t)V + i];
-    }
-    float gz = g0, gy = g1, gx = g2;                 // identity term
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int i = cn.idx[k];
-        const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
-        const float sk = cn.ok[k] ? (s0[k] * scale) * g0 + (s1[k] * scale) * g1 + (s2[k] * scale) * g2 : 0.0f;
-        gz += (dz ? sk : -sk) * (cn.wy[dy] * cn.wx[dx]);
-        gy += (dy ? sk : -sk) * (cn.wz[dz] * cn.wx[dx]);
-        gx += (dx ? sk : -sk) * (cn.wz[dz] * cn.wy[dy]);
-        if (cn.ok[k]) {
-            const float wk = cn.w[k] * scale;
-            atomicAdd(gi + i, g0 * wk);
-            atomicAdd(gi + V + i, g1 * wk);
-            atomicAdd(gi + 2 * (size_t)V + i, g2 * wk);
-        }
-    }
-    atomicAdd(gi + p, gz * scale);
-    atomicAdd(gi + V + p, gy * scale);
-    atomicAdd(gi + 2 * (size_t)V + p, gx * scale);
-}
-
+// (The first implementation scattered the last term with 27 fp32 atomics per voxel into a zeroed buffer; it was bound by the L2
+// atomic rate, 0.66 ms per pair, and is gone: see the gather below.)
 // ---- the same step backward as a GATHER (no atomics in the regime of scaling and squaring) ---------------------------------
 // Voxel p scatters to the 8 corners of x'(p) = p + v(p).  When every |x'_a(p) - p_a| < 1 ("near": floor(x'_a) - p_a in {-1, 0}),
 // those corners lie in the 3x3x3 neighbourhood of p, so a target q only ever receives from the 27 voxels p = q + o, o in {-1,0,1}^3:
@@ -241,9 +204,11 @@ __global__ void __launch_bounds__(256) k_vecint_step_bwd_gather(const float* __r
     const int d0 = (t / nth) * VG_TD;
     const int b = blockIdx.y;
     const int HW = H * W, V = D * HW;
-    const float* vin = in + (size_t)b * 3 * V;
-    const float* go = gout + (size_t)b * 3 * V;
-    float* gi = gin + (size_t)b * 3 * V;
+    // three planes per tensor behind one buffer descriptor each: 32-bit byte offsets, channel step in the scalar offset
+    const __amdgpu_buffer_rsrc_t rv = vxm_rsrc(in + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
+    const __amdgpu_buffer_rsrc_t rgo = vxm_rsrc(gout + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
+    const __amdgpu_buffer_rsrc_t rgi = vxm_rsrc(gin + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
+    const int V4 = V << 2;
     unsigned nfar = 0;
     for (int i = tid; i < VG_LN; i += 256) {
         const int lx = i % VG_LW, r = i / VG_LW, ly = r % VG_LH, lz = r / VG_LH;
@@ -251,8 +216,8 @@ __global__ void __launch_bounds__(256) k_vecint_step_bwd_gather(const float* __r
         int c = 0;
         float fz = 0.f, fy = 0.f, fx = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
         if ((unsigned)pz < (unsigned)D && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
-            const int p = pz * HW + py * W + px;
-            const float v0 = vin[p] * scale, v1 = vin[V + p] * scale, v2 = vin[2 * (size_t)V + p] * scale;
+            const int p4 = (pz * HW + py * W + px) << 2;
+            const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
             int rz, ry, rx;
             bool nz, ny, nx;
             vg_axis(vxm_src_coord(pz, v0, D), pz, D, fz, rz, nz);
@@ -260,7 +225,7 @@ __global__ void __launch_bounds__(256) k_vecint_step_bwd_gather(const float* __r
             vg_axis(vxm_src_coord(px, v2, W), px, W, fx, rx, nx);
             if (nz && ny && nx) {
                 c = 8 | (rz << 2) | (ry << 1) | rx;
-                g0 = go[p]; g1 = go[V + p]; g2 = go[2 * (size_t)V + p];
+                g0 = vxm_bload(rgo, p4, 0); g1 = vxm_bload(rgo, p4, V4); g2 = vxm_bload(rgo, p4, 2 * V4);
             } else if (lz >= 1 && lz <= VG_TD && ly >= 1 && ly <= VG_TH && lx >= 1 && lx <= VG_TW) {
                 ++nfar;                                   // counted once, by the tile that owns the voxel
             }
@@ -275,17 +240,17 @@ __global__ void __launch_bounds__(256) k_vecint_step_bwd_gather(const float* __r
     for (int dd = 0; dd < VG_TD; ++dd) {
         const int d = d0 + dd;
         if (d >= D) break;
-        const int p = d * HW + h * W + w;
+        const int p4 = (d * HW + h * W + w) << 2;
         // ---- local part: identity + derivative through the sampling position (the 8 corners of x'(q) gathered from v itself)
-        const float v0 = vin[p] * scale, v1 = vin[V + p] * scale, v2 = vin[2 * (size_t)V + p] * scale;
-        const float g0 = go[p], g1 = go[V + p], g2 = go[2 * (size_t)V + p];
+        const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
+        const float g0 = vxm_bload(rgo, p4, 0), g1 = vxm_bload(rgo, p4, V4), g2 = vxm_bload(rgo, p4, 2 * V4);
         const Corners8 cn = corners8(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W);
         float gz = g0, gy = g1, gx = g2;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int i = cn.idx[k];
+            const int i4 = cn.idx[k] << 2;
             const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
-            const float sk = cn.ok[k] ? (vin[i] * scale) * g0 + (vin[V + i] * scale) * g1 + (vin[2 * (size_t)V + i] * scale) * g2 : 0.0f;
+            const float sk = cn.ok[k] ? (vxm_bload(rv, i4, 0) * scale) * g0 + (vxm_bload(rv, i4, V4) * scale) * g1 + (vxm_bload(rv, i4, 2 * V4) * scale) * g2 : 0.0f;
             gz += (dz ? sk : -sk) * (cn.wy[dy] * cn.wx[dx]);
             gy += (dy ? sk : -sk) * (cn.wz[dz] * cn.wx[dx]);
             gx += (dx ? sk : -sk) * (cn.wz[dz] * cn.wy[dy]);
@@ -310,9 +275,9 @@ __global__ void __launch_bounds__(256) k_vecint_step_bwd_gather(const float* __r
                     const float wk = (c & 8) ? (wz * wy) * wx : 0.0f;
                     a0 += rec[3][i] * wk; a1 += rec[4][i] * wk; a2 += rec[5][i] * wk;
                 }
-        gi[p] = (gz + a0) * scale;
-        gi[V + p] = (gy + a1) * scale;
-        gi[2 * (size_t)V + p] = (gx + a2) * scale;
+        vxm_bstore((gz + a0) * scale, rgi, p4, 0);
+        vxm_bstore((gy + a1) * scale, rgi, p4, V4);
+        vxm_bstore((gx + a2) * scale, rgi, p4, 2 * V4);
     }
 }
 
