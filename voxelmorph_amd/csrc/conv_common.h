@@ -124,8 +124,9 @@ __device__ __forceinline__ void conv_load_bias(float (&bz)[NCT][4], const float*
 // per-store branch, no 64-bit address arithmetic.  (The channel test is explicit, one v_cndmask per store, and the scalar
 // offset is clamped into the tensor: the range check of a raw buffer compares the per-lane offset with num_records - soffset,
 // which must not be relied on once the scalar offset alone exceeds the range.)  Rows beyond H are skipped by a wave-uniform test.
-template <int NCT, int ROWS>
-__device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS], float* __restrict__ yb /* y + b * y_bs */, const float (&bz)[NCT][4],
+// HALVES = 16-voxel MFMA tiles side by side along W (acc index m = row * HALVES + half; needs W % (16 HALVES) == 0).
+template <int NCT, int ROWS, int HALVES = 1>
+__device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS * HALVES], float* __restrict__ yb /* y + b * y_bs */, const float (&bz)[NCT][4],
                                                     const float* __restrict__ maskb /* mask + b * mask_bs or null */, float act_slope,
                                                     float mask_slope, int Cout, int g, int kq, bool vox_ok, int vox /* (d H + h0) W + w */,
                                                     int h0, int H, int W, int V) {
@@ -137,33 +138,37 @@ __device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS], flo
     const int voff = (cbase * V + vox) << 2;
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-        float mk[4][ROWS];
+        constexpr int MT = ROWS * HALVES;
+        float mk[4][MT];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) mk[j][r] = 1.0f;
+            for (int r = 0; r < MT; ++r) mk[j][r] = 1.0f;
         if (maskb) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < ROWS; ++r)
+                for (int r = 0; r < MT; ++r)
                     mk[j][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, ct * 16 + j < nvalid ? voff : VXM_OOB,
-                                                                                   (min(ct * 16 + j, navail - 1) * V + r * W) << 2, 0));
+                                                   (min(ct * 16 + j, navail - 1) * V + (r / HALVES) * W + (r % HALVES) * 16) << 2, 0));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < ROWS; ++r) mk[j][r] = vxm_lrelu_grad(mk[j][r], mask_slope);
+                for (int r = 0; r < MT; ++r) mk[j][r] = vxm_lrelu_grad(mk[j][r], mask_slope);
         }
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
-            if (h0 + r < H) {                        // wave-uniform
+        for (int row = 0; row < ROWS; ++row) {
+            if (h0 + row < H) {                      // wave-uniform
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[ct][r][j] + bz[ct][j];
-                    v = (v > 0.0f ? v : v * act_slope) * mk[j][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, ct * 16 + j < nvalid ? voff : VXM_OOB,
-                                                          (min(ct * 16 + j, navail - 1) * V + r * W) << 2, 0);
-                }
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int half = 0; half < HALVES; ++half) {      // the halves of a row back to back: one 128-byte run per channel
+                        const int r = row * HALVES + half;
+                        float v = acc[ct][r][j] + bz[ct][j];
+                        v = (v > 0.0f ? v : v * act_slope) * mk[j][r];
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, ct * 16 + j < nvalid ? voff : VXM_OOB,
+                                                              (min(ct * 16 + j, navail - 1) * V + row * W + half * 16) << 2, 0);
+                    }
             }
         }
     }

@@ -141,16 +141,21 @@ constexpr int T8_THREADS = 512;
 
 // ROWS = H rows per wave (tile 8 x ROWS x 16).  4 is used throughout: 6 rows with a single output tile (324 instead of 216 MFMAs
 // per wave and staged chunk) measured 4 % slower, 8 rows need more than the 128 VGPRs that two blocks per CU allow.
-template <int NCT, int ROWS>
+// TWX = tile width: 16 (4 rows x 16 voxels per wave) or 32 (2 rows x 32 voxels: the output then leaves in 128-byte runs --
+// with 16-wide tiles the two halves of every 128-byte line are written by different blocks at different times, which the
+// memory system takes at 3.6 instead of 5.0 TB/s, tools/probe/store_pattern.hip).  ROWS = tile rows, MT = ROWS TWX / 16 MFMA
+// N-tiles per wave and output-channel tile.
+template <int NCT, int ROWS, int TWX = 16>
 __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const float* __restrict__ wp, const float* __restrict__ bias,
                                                               float* __restrict__ y, long long y_bs, int Cout, float act_slope,
                                                               const float* __restrict__ mask, long long mask_bs, float mask_slope,
                                                               int B, int D, int H, int W, int Q) {
     VXM_DYN_SMEM(float, smem);
-    constexpr int CK = 8, KS = 2, RS = BV_RS_FWD;
+    constexpr int CK = 8, KS = 2, RS = TWX + 4;           // rows: halo column at 1, interior at 2 .. TWX+1, halo at TWX+2
+    constexpr int HALVES = TWX / 16, MT = ROWS * HALVES, GPR = TWX / 4, RPL = 64 / GPR;      // dwordx4 groups per row, rows per wave-load
     constexpr int HR = ROWS + 2, NROW = (T8_TD + 2) * HR;                        // haloed rows per plane
     constexpr int PS = NROW * RS + ((NROW * RS) % 32 == 16 ? 0 : 16);            // plane stride = 16 mod 32 (1200 / 1616 / 2000)
-    constexpr int NI = (NROW * 4 + 63) / 64, NHL = (NROW * 2 + 63) / 64;          // interior / halo wave-loads per plane
+    constexpr int NI = (NROW * GPR + 63) / 64, NHL = (NROW * 2 + 63) / 64;        // interior / halo wave-loads per plane
     constexpr int WCHUNK = 27 * KS * NCT * 64;
     constexpr int WIT = (WCHUNK / 4 + T8_THREADS - 1) / T8_THREADS;
     float* const Xs = smem;                         // [CK][PS]
@@ -163,7 +168,7 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
 
     // tile of this block: block b runs on XCD b % 8 (observed; speed only), XCD x takes the contiguous tile range
     // [nt x / 8, nt (x+1) / 8) so that concurrently running neighbours share halo lines and weights in one L2
-    const int nw = (W + TW - 1) / TW, nh = (H + ROWS - 1) / ROWS, nd = (D + T8_TD - 1) / T8_TD;
+    const int nw = (W + TWX - 1) / TWX, nh = (H + ROWS - 1) / ROWS, nd = (D + T8_TD - 1) / T8_TD;
     const int ntiles = B * nd * nh * nw;
     int tile = blockIdx.x;
     if (ntiles >= 64) {
@@ -177,7 +182,7 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
     const int tw = tile % nw; int tq = tile / nw;
     const int th = tq % nh; tq /= nh;
     const int td = tq % nd; const int b = tq / nd;
-    const int d0 = td * T8_TD, h0 = th * ROWS, w0 = tw * TW;
+    const int d0 = td * T8_TD, h0 = th * ROWS, w0 = tw * TWX;
     const int g = blockIdx.y;                       // output-channel group of 16*NCT
 
     const int V = D * H * W;
@@ -188,29 +193,29 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
 
     // staging roles of this lane: interior slot 64 j + lane (< 240) -> row 16 j + (lane >> 2) of the [10][6] row grid,
     // columns 4 (lane & 3)..+3; halo slot 64 j + lane (< 120) -> row 32 j + (lane >> 1), side lane & 1.
-    const int lq = lane & 3, lr4 = lane >> 2, lr2 = lane >> 1, hside = lane & 1;
+    const int lq = lane % GPR, lr4 = lane / GPR, lr2 = lane >> 1, hside = lane & 1;
     const int ibase = lr4 * RS + 2 + 4 * lq;
-    const int hbase = lr2 * RS + (hside ? 18 : 1);
+    const int hbase = lr2 * RS + (hside ? TWX + 2 : 1);
     // per-lane byte offsets inside a plane (for the upsampled segment: of the half-resolution source); recomputed per chunk
     // -- a few dozen VALU against 432 MFMAs -- rather than kept in 2 (NI + NHL) registers
     auto off_i = [&](int j, bool up) __attribute__((always_inline)) -> int {
-        const int rr = 16 * j + lr4;
+        const int rr = RPL * j + lr4;
         const int gd = d0 - 1 + rr / HR, gh = h0 - 1 + rr % HR, gw = w0 + 4 * lq;
         const bool ok = rr < NROW && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw < W;
         return !ok ? VXM_OOB : (up ? (((gd >> 1) * Hs + (gh >> 1)) * Ws2 + (gw >> 1)) << 2 : ((gd * H + gh) * W + gw) << 2);
     };
     auto off_h = [&](int j, bool up) __attribute__((always_inline)) -> int {
         const int rr = 32 * j + lr2;
-        const int gd = d0 - 1 + rr / HR, gh = h0 - 1 + rr % HR, gw = hside ? w0 + TW : w0 - 1;
+        const int gd = d0 - 1 + rr / HR, gh = h0 - 1 + rr % HR, gw = hside ? w0 + TWX : w0 - 1;
         const bool ok = rr < NROW && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
         return !ok ? VXM_OOB : (up ? (((gd >> 1) * Hs + (gh >> 1)) * Ws2 + (gw >> 1)) << 2 : ((gd * H + gh) * W + gw) << 2);
     };
 
-    f32x4 acc[NCT][ROWS];
+    f32x4 acc[NCT][MT];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < MT; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 xi[NI];
     float xh[NHL];
@@ -251,9 +256,9 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
         float* dst = Xs + wave * PS;
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-            if (64 * j + lane < NROW * 4) {         // interior slots
-                *reinterpret_cast<f32x2*>(dst + ibase + 16 * j * RS) = (f32x2){xi[j].x, xi[j].y};
-                *reinterpret_cast<f32x2*>(dst + ibase + 16 * j * RS + 2) = (f32x2){xi[j].z, xi[j].w};
+            if (64 * j + lane < NROW * GPR) {       // interior slots
+                *reinterpret_cast<f32x2*>(dst + ibase + RPL * j * RS) = (f32x2){xi[j].x, xi[j].y};
+                *reinterpret_cast<f32x2*>(dst + ibase + RPL * j * RS + 2) = (f32x2){xi[j].z, xi[j].w};
             }
 #pragma unroll
         for (int j = 0; j < NHL; ++j)
@@ -272,14 +277,14 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
     for (int q = 0; q < Q; ++q) {
         if (q + 1 < Q) load_chunk(q + 1);           // in flight under the MFMAs below
         // ---- 27 taps x KS k-steps x (NCT x 4) MFMAs, operands double-buffered in registers
-        float a[2][NCT], bv[2][ROWS];
-        auto fetch = [&](int st, float (&af)[NCT], float (&bf)[ROWS]) __attribute__((always_inline)) {
+        float a[2][NCT], bv[2][MT];
+        auto fetch = [&](int st, float (&af)[NCT], float (&bf)[MT]) __attribute__((always_inline)) {
             const int t = st / KS, s = st % KS;
             const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) af[ct] = Ws[((t * KS + s) * NCT + ct) * 64 + lane];
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) bf[r] = Xs[bbase + s * 4 * PS + (kd * HR + r + kh) * RS + kw];
+            for (int r = 0; r < MT; ++r) bf[r] = Xs[bbase + s * 4 * PS + (kd * HR + r / HALVES + kh) * RS + (r % HALVES) * 16 + kw];
         };
         fetch(0, a[0], bv[0]);
 #pragma unroll
@@ -289,7 +294,7 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                for (int r = 0; r < ROWS; ++r) acc[ct][r] = vxm_mfma16(a[st & 1][ct], bv[st & 1][r], acc[ct][r]);
+                for (int r = 0; r < MT; ++r) acc[ct][r] = vxm_mfma16(a[st & 1][ct], bv[st & 1][r], acc[ct][r]);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (q + 1 < Q) {
@@ -303,7 +308,7 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_t8(ConvIn in, const
     const int d = d0 + wave, w = w0 + n;
     float bz[NCT][4];
     conv_load_bias<NCT>(bz, bias, Cout, g, kq);
-    conv_epilogue_store<NCT, ROWS>(acc, y + (size_t)b * y_bs, bz, mask ? mask + (size_t)b * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kq,
+    conv_epilogue_store<NCT, ROWS, HALVES>(acc, y + (size_t)b * y_bs, bz, mask ? mask + (size_t)b * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kq,
                                    d < D && w < W, (d * H + h0) * W + w, h0, H, W, V);
 }
 
@@ -1089,6 +1094,11 @@ bool kpack_ok(int C0, int C1, int x0_up, const float* x0, int64_t bs0, const flo
 }
 
 // rows per wave of the 8-wave kernel
+// VXM_T8_TILE32=0 keeps the 16-wide tiles everywhere (developer A/B switch)
+bool t8_tile32() {
+    static const bool on = [] { const char* e = getenv("VXM_T8_TILE32"); return !(e && e[0] == '0'); }();
+    return on;
+}
 int fwd_wide_rows(const ConvCfg& c) { (void)c; return 4; }     // 6 rows with one output tile measured 4 % slower than 4
 bool fwd_wide_ok(const ConvCfg& c, const float* x0, int64_t bs0, const float* x1, int C1, int64_t bs1, const float* wpacked,
                  int B, int D, int H, int W) {
@@ -1172,15 +1182,26 @@ int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, co
             if (!opt_in) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_t8<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_t8<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_t8<2, 2, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_t8<1, 2, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                 opt_in = true;
             }
-            const dim3 grid8((unsigned)((tiles8 + 7) / 8 * 8), c.G);
-            const int plane8 = (T8_TD + 2) * (rows + 2) * BV_RS_FWD, ps8 = plane8 + (plane8 % 32 == 16 ? 0 : 16);
+            // 32-voxel-wide tiles (8 x 2 x 32: the output leaves in 128-byte runs) when W allows, 16-wide (8 x 4 x 16) otherwise
+            const bool wide32 = (W & 31) == 0 && t8_tile32();
+            const int trows = wide32 ? 2 : rows, tw = wide32 ? 32 : TW;
+            const long long ntile = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + trows - 1) / trows) * ((W + tw - 1) / tw);
+            const dim3 grid8((unsigned)((ntile + 7) / 8 * 8), c.G);
+            const int plane8 = (T8_TD + 2) * (trows + 2) * (tw + 4), ps8 = plane8 + (plane8 % 32 == 16 ? 0 : 16);
             const size_t lds8 = sizeof(float) * ((size_t)8 * ps8 + 27 * 2 * c.NCT * 64);
-#define LAUNCH8(NCT_, ROWS_) hipLaunchKernelGGL((k_conv3d_k3_t8<NCT_, ROWS_>), grid8, dim3(T8_THREADS), lds8, VXM_STREAM(stream), in, wpacked, bias, y, \
+#define LAUNCH8(...) hipLaunchKernelGGL((k_conv3d_k3_t8<__VA_ARGS__>), grid8, dim3(T8_THREADS), lds8, VXM_STREAM(stream), in, wpacked, bias, y, \
         (long long)y_bstride, Cout, act_slope, mask_src, (long long)mask_bstride, mask_slope, B, D, H, W, c.Q)
-            if (c.NCT == 1) LAUNCH8(1, 4);
-            else LAUNCH8(2, 4);
+            if (wide32) {
+                if (c.NCT == 1) LAUNCH8(1, 2, 32);
+                else LAUNCH8(2, 2, 32);
+            } else {
+                if (c.NCT == 1) LAUNCH8(1, 4);
+                else LAUNCH8(2, 4);
+            }
 #undef LAUNCH8
             return vxm_check_launch("vxm_conv3d_k3_fwd");
         }
