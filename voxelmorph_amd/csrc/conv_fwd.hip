@@ -905,16 +905,17 @@ __global__ void __launch_bounds__(256) k_conv3d_k3_fewout(const float* __restric
 // tile are fetched under the MFMAs of the current one into the second of two LDS buffers.
 // ------------------------------------------------------------------------------------------
 constexpr int kpack_steps(int cin) { return (27 * cin + 3) / 4; }
-constexpr int KP_ROWS = 4, KP_HR = KP_ROWS + 2, KP_NROW = (T8_TD + 2) * KP_HR;
-constexpr int KP_PS = KP_NROW * BV_RS_FWD + ((KP_NROW * BV_RS_FWD) % 32 == 16 ? 0 : 16);   // 1200 = 16 mod 32: the two channels of a half-wave (Cin = 2) sit 16 banks apart
+constexpr int KP_ROWS = 4;          // tile rows of the 16-wide instance (plane stride 1200 = 16 mod 32: the two channels of a half-wave, Cin = 2, sit 16 banks apart)
 
-template <int CIN>
+// TWX: tile 8 x 4 x 16 or 8 x 2 x 32 (output in 128-byte runs when W % 32 == 0), as k_conv3d_k3_t8.
+template <int CIN, int TWX = 16>
 __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_kpack(ConvIn in, const float* __restrict__ wk, const float* __restrict__ bias,
                                                                  float* __restrict__ y, long long y_bs, int Cout, float act_slope,
                                                                  const float* __restrict__ mask, long long mask_bs, float mask_slope,
                                                                  int B, int D, int H, int W) {
-    constexpr int ROWS = KP_ROWS, RS = BV_RS_FWD, HR = KP_HR, NROW = KP_NROW, PS = KP_PS, NS = kpack_steps(CIN);
-    constexpr int NI = (NROW * 4 + 63) / 64, NHL = (NROW * 2 + 63) / 64;
+    constexpr int HALVES = TWX / 16, ROWS = 4 / HALVES, MT = ROWS * HALVES, RS = TWX + 4, HR = ROWS + 2, NROW = (T8_TD + 2) * HR;
+    constexpr int PS = NROW * RS + ((NROW * RS) % 32 == 16 ? 0 : 16), NS = kpack_steps(CIN), GPR = TWX / 4, RPL = 64 / GPR;
+    constexpr int NI = (NROW * GPR + 63) / 64, NHL = (NROW * 2 + 63) / 64;
     __shared__ __attribute__((aligned(16))) float Xs2[2 * CIN * PS];      // double-buffered planes: one barrier per tile
     __shared__ float Wl[NS * 64];                                         // A fragments of this block's 16 output channels
     const int tid = threadIdx.x, lane = tid & 63;
@@ -923,7 +924,7 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_kpack(ConvIn in, co
     const float* const ix0 = in.x0; const float* const ix1 = in.x1;
     const int iC0 = in.C0, iC1 = in.C1;
 
-    const int nw = (W + TW - 1) / TW, nh = (H + ROWS - 1) / ROWS, nd = (D + T8_TD - 1) / T8_TD;
+    const int nw = (W + TWX - 1) / TWX, nh = (H + ROWS - 1) / ROWS, nd = (D + T8_TD - 1) / T8_TD;
     const int ntiles = B * nd * nh * nw;
     int tile, tile_end, tile_step;
     if (ntiles >= 64) {                             // XCD x = blockIdx.x % 8 walks its contiguous eighth of the tiles
@@ -939,7 +940,7 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_kpack(ConvIn in, co
     auto decode = [&](int t) __attribute__((always_inline)) -> Org {
         const int tw = t % nw; int tq = t / nw;
         const int th = tq % nh; tq /= nh;
-        return Org{tq / nd, (tq % nd) * T8_TD, th * ROWS, tw * TW};
+        return Org{tq / nd, (tq % nd) * T8_TD, th * ROWS, tw * TWX};
     };
     Org cur = decode(tile);
     const int g = blockIdx.y;                       // output-channel group of 16
@@ -970,15 +971,15 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_kpack(ConvIn in, co
         const __amdgpu_buffer_rsrc_t r = vxm_rsrc(base, (unsigned)V * 4u);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int rr = 16 * j + (ln >> 2);
-            const int gd = o.d0 - 1 + rr / HR, gh = o.h0 - 1 + rr % HR, gw = o.w0 + 4 * (ln & 3);
+            const int rr = RPL * j + ln / GPR;
+            const int gd = o.d0 - 1 + rr / HR, gh = o.h0 - 1 + rr % HR, gw = o.w0 + 4 * (ln % GPR);
             const bool ok = rr < NROW && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && gw < W;
             xi[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB, 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < NHL; ++j) {
             const int rr = 32 * j + (ln >> 1);
-            const int gd = o.d0 - 1 + rr / HR, gh = o.h0 - 1 + rr % HR, gw = (ln & 1) ? o.w0 + TW : o.w0 - 1;
+            const int gd = o.d0 - 1 + rr / HR, gh = o.h0 - 1 + rr % HR, gw = (ln & 1) ? o.w0 + TWX : o.w0 - 1;
             const bool ok = rr < NROW && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
             xh[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, ok ? ((gd * H + gh) * W + gw) << 2 : VXM_OOB, 0, 0));
         }
@@ -986,21 +987,21 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_kpack(ConvIn in, co
     auto store_x = [&](int buf) __attribute__((always_inline)) {
         if (wave >= CIN) return;
         float* dst = Xs2 + buf * (CIN * PS) + wave * PS;
-        const int ibase = (lane >> 2) * RS + 2 + 4 * (lane & 3), hbase = (lane >> 1) * RS + ((lane & 1) ? 18 : 1);
+        const int ibase = (lane / GPR) * RS + 2 + 4 * (lane % GPR), hbase = (lane >> 1) * RS + ((lane & 1) ? TWX + 2 : 1);
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-            if (64 * j + lane < NROW * 4) {
-                *reinterpret_cast<f32x2*>(dst + ibase + 16 * j * RS) = (f32x2){xi[j].x, xi[j].y};
-                *reinterpret_cast<f32x2*>(dst + ibase + 16 * j * RS + 2) = (f32x2){xi[j].z, xi[j].w};
+            if (64 * j + lane < NROW * GPR) {
+                *reinterpret_cast<f32x2*>(dst + ibase + RPL * j * RS) = (f32x2){xi[j].x, xi[j].y};
+                *reinterpret_cast<f32x2*>(dst + ibase + RPL * j * RS + 2) = (f32x2){xi[j].z, xi[j].w};
             }
 #pragma unroll
         for (int j = 0; j < NHL; ++j)
             if (64 * j + lane < NROW * 2) dst[hbase + 32 * j * RS] = xh[j];
     };
 
-    f32x4 acc[ROWS];
+    f32x4 acc[MT];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < MT; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     load_x(cur);
     store_x(0);
     __syncthreads();
@@ -1010,20 +1011,20 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_kpack(ConvIn in, co
         const bool has_next = tile_next < tile_end;
         if (has_next) load_x(decode(tile_next));    // in flight under the MFMAs below
         const float* Xs = Xs2 + buf * (CIN * PS);
-        float bv[2][ROWS], wa[2];
+        float bv[2][MT], wa[2];
         wa[0] = Wl[lane];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) bv[0][r] = Xs[offs[0] + r * RS];
+        for (int r = 0; r < MT; ++r) bv[0][r] = Xs[offs[0] + (r / HALVES) * RS + (r % HALVES) * 16];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             if (s + 1 < NS) {
                 wa[(s + 1) & 1] = Wl[(s + 1) * 64 + lane];
 #pragma unroll
-                for (int r = 0; r < ROWS; ++r) bv[(s + 1) & 1][r] = Xs[offs[s + 1] + r * RS];
+                for (int r = 0; r < MT; ++r) bv[(s + 1) & 1][r] = Xs[offs[s + 1] + (r / HALVES) * RS + (r % HALVES) * 16];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) acc[r] = vxm_mfma16(wa[s & 1], bv[s & 1][r], acc[r]);
+            for (int r = 0; r < MT; ++r) acc[r] = vxm_mfma16(wa[s & 1], bv[s & 1][r], acc[r]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // The next tile's planes go to the other LDS buffer BEFORE this tile's output stores are issued: vmcnt counts loads
@@ -1034,11 +1035,11 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_kpack(ConvIn in, co
         {
             const int ln = opaque(lane), ekq = ln >> 4, en = ln & 15;
             const int d = cur.d0 + wave, w = cur.w0 + en;
-            f32x4 (&acc1)[1][ROWS] = *reinterpret_cast<f32x4 (*)[1][ROWS]>(&acc);
-            conv_epilogue_store<1, ROWS>(acc1, y + (size_t)cur.b * y_bs, bz, mask ? mask + (size_t)cur.b * mask_bs : nullptr, act_slope, mask_slope,
+            f32x4 (&acc1)[1][MT] = *reinterpret_cast<f32x4 (*)[1][MT]>(&acc);
+            conv_epilogue_store<1, ROWS, HALVES>(acc1, y + (size_t)cur.b * y_bs, bz, mask ? mask + (size_t)cur.b * mask_bs : nullptr, act_slope, mask_slope,
                                          Cout, g, ekq, d < D && w < W, (d * H + cur.h0) * W + w, cur.h0, H, W, V);
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < MT; ++r) acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         if (!has_next) break;
         __syncthreads();                            // the other buffer is complete, and every wave is done reading this one
@@ -1077,6 +1078,11 @@ ConvCfg conv_cfg(int Cin, int Cout) {
     return c;
 }
 // layers with at most 4 input channels carry a second copy of their weights in the dense-K order of k_conv3d_k3_kpack
+// VXM_T8_TILE32=0 keeps the 16-wide tiles everywhere (developer A/B switch)
+bool t8_tile32() {
+    static const bool on = [] { const char* e = getenv("VXM_T8_TILE32"); return !(e && e[0] == '0'); }();
+    return on;
+}
 size_t kpack_elems(int Cin, int Cout) { return Cin <= 4 ? (size_t)((Cout + 15) / 16) * kpack_steps(Cin) * 64 : 0; }
 int kpack_blocks() {
     static const int n = [] {
@@ -1094,11 +1100,6 @@ bool kpack_ok(int C0, int C1, int x0_up, const float* x0, int64_t bs0, const flo
 }
 
 // rows per wave of the 8-wave kernel
-// VXM_T8_TILE32=0 keeps the 16-wide tiles everywhere (developer A/B switch)
-bool t8_tile32() {
-    static const bool on = [] { const char* e = getenv("VXM_T8_TILE32"); return !(e && e[0] == '0'); }();
-    return on;
-}
 int fwd_wide_rows(const ConvCfg& c) { (void)c; return 4; }     // 6 rows with one output tile measured 4 % slower than 4
 bool fwd_wide_ok(const ConvCfg& c, const float* x0, int64_t bs0, const float* x1, int C1, int64_t bs1, const float* wpacked,
                  int B, int D, int H, int W) {
@@ -1157,17 +1158,23 @@ int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, co
     const ConvCfg c = conv_cfg(C0 + C1, Cout);
     ConvIn in{x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up};
     if (kpack_ok(C0, C1, x0_up, x0, x0_bstride, x1, x1_bstride, wpacked, B, D, H, W)) {      // few input channels: dense-K MFMA kernel
-        const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + KP_ROWS - 1) / KP_ROWS) * ((W + TW - 1) / TW);
+        const bool wide32 = (W & 31) == 0 && t8_tile32();
+        const int trows = wide32 ? 2 : KP_ROWS, tw = wide32 ? 32 : TW;
+        const long long tiles8 = (long long)B * ((D + T8_TD - 1) / T8_TD) * ((H + trows - 1) / trows) * ((W + tw - 1) / tw);
         const long long nb = tiles8 < (long long)kpack_blocks() ? (tiles8 + 7) / 8 * 8 : (long long)kpack_blocks();
         const dim3 gridk((unsigned)nb, (Cout + 15) / 16);
         const float* wk = wpacked + c.elems;
-#define LAUNCHK(CIN_) hipLaunchKernelGGL(k_conv3d_k3_kpack<CIN_>, gridk, dim3(T8_THREADS), 0, VXM_STREAM(stream), in, wk, bias, y, (long long)y_bstride, \
+#define LAUNCHK(...) hipLaunchKernelGGL((k_conv3d_k3_kpack<__VA_ARGS__>), gridk, dim3(T8_THREADS), 0, VXM_STREAM(stream), in, wk, bias, y, (long long)y_bstride, \
         Cout, act_slope, mask_src, (long long)mask_bstride, mask_slope, B, D, H, W)
-        switch (C0 + C1) {
-            case 1: LAUNCHK(1); break;
-            case 2: LAUNCHK(2); break;
-            case 3: LAUNCHK(3); break;
-            default: LAUNCHK(4); break;
+        switch ((C0 + C1) * 2 + (wide32 ? 1 : 0)) {
+            case 2: LAUNCHK(1); break;
+            case 3: LAUNCHK(1, 32); break;
+            case 4: LAUNCHK(2); break;
+            case 5: LAUNCHK(2, 32); break;
+            case 6: LAUNCHK(3); break;
+            case 7: LAUNCHK(3, 32); break;
+            case 8: LAUNCHK(4); break;
+            default: LAUNCHK(4, 32); break;
         }
 #undef LAUNCHK
         return vxm_check_launch("vxm_conv3d_k3_fwd");
