@@ -227,6 +227,7 @@ def test_grad_mse_dice_golden(vxm, g_losses):
     (17, 16, (5, 7, 28), 0.2), (32, 48, (6, 9, 36), 1.0), (3, 3, (3, 3, 4), 0.2),
     (16, 3, (6, 8, 20), 1.0), (24, 2, (5, 6, 16), 0.2),        # few output channels: role-swapped backward-weight
     (1, 16, (8, 8, 16), 0.2), (4, 20, (8, 8, 16), 0.2),        # few input channels: dense-K MFMA kernel (with VXM_CONV_WIDE_MIN_TILES=1)
+    (2, 16, (8, 8, 32), 0.2), (3, 5, (8, 4, 64), 1.0), (16, 32, (8, 4, 64), 0.2),      # W % 32 == 0: the 8 x 2 x 32 tile instances
 ])
 def test_conv_block_vs_oracle(vxm, cin, cout, vol, slope):
     from voxelmorph_amd.torch import functional as VF
