@@ -406,6 +406,34 @@ def test_unet_vs_oracle(vxm, kw):
     assert rel_l2(N(xg.grad), xo.grad.numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("src_feats,trg_feats", [(2, 1), (1, 3)])
+def test_vxm_dense_multi_feature_inputs_vs_oracle(vxm, src_feats, trg_feats):
+    """networks.py:161-162 `src_feats` / `trg_feats`: the first block reads the virtual concat of a multi-channel source and target
+    (3 / 4 input channels: the dense-K kernel with two segments), the warp moves every source channel; forward, loss and
+    parameter gradients against the oracle."""
+    inshape = (16, 32, 32)
+    torch.manual_seed(11)
+    model = vxm.networks.VxmDense(inshape, int_steps=3, int_downsize=2, src_feats=src_feats, trg_feats=trg_feats).cuda()
+    with torch.no_grad():
+        model.flow.weight.normal_(0, 0.05)
+    sd = {k: v.detach().cpu().double().requires_grad_() for k, v in model.state_dict().items() if not k.endswith(".grid")}
+    rng = np.random.default_rng(src_feats * 10 + trg_feats)
+    src = rng.random((2, src_feats) + inshape).astype(np.float32)
+    trg = rng.random((2, trg_feats) + inshape).astype(np.float32)
+    y, pre = model(G(src), G(trg))
+    yo, preo = orc.vxm_dense_forward(torch.from_numpy(src).double(), torch.from_numpy(trg).double(), sd, int_steps=3, int_downsize=2)
+    assert y.shape == (2, src_feats) + inshape
+    np.testing.assert_allclose(N(y), yo.detach().numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(N(pre), preo.detach().numpy(), atol=2e-5, rtol=0)
+    loss = (y * y).mean() + vxm.losses.Grad("l2", loss_mult=2).loss(None, pre)
+    losso = (yo * yo).mean() + orc.grad_loss(preo, "l2", 2)
+    assert abs(float(loss) - float(losso)) < 1e-5
+    loss.backward()
+    losso.backward()
+    for name, p in model.named_parameters():
+        assert rel_l2(N(p.grad), sd[name].grad.numpy()) < 2e-4, name
+
+
 # ------------------------------------------------------------------ VxmDense (golden, produced by the reference)
 CASES = {
     "diffeo": dict(int_steps=7, int_downsize=2, bidir=False, loss="ncc", lam=1.0),
