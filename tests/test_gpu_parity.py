@@ -434,6 +434,32 @@ def test_vxm_dense_multi_feature_inputs_vs_oracle(vxm, src_feats, trg_feats):
         assert rel_l2(N(p.grad), sd[name].grad.numpy()) < 2e-4, name
 
 
+@pytest.mark.parametrize("int_downsize,int_steps,half_res", [(1, 2, False), (4, 3, False), (2, 3, True)])
+def test_vxm_dense_integration_variants_vs_oracle(vxm, int_downsize, int_steps, half_res):
+    """networks.py:223-242: integration at full resolution (no resize), at quarter resolution (ResizeTransform 4 and 1/4), and with
+    `unet_half_res` (the U-Net already ends at half resolution: no down-resize, networks.py:223); forward and gradients."""
+    inshape = (32, 32, 32)
+    torch.manual_seed(5)
+    model = vxm.networks.VxmDense(inshape, int_steps=int_steps, int_downsize=int_downsize, unet_half_res=half_res).cuda()
+    with torch.no_grad():
+        model.flow.weight.normal_(0, 0.05)
+    sd = {k: v.detach().cpu().double().requires_grad_() for k, v in model.state_dict().items() if not k.endswith(".grid")}
+    rng = np.random.default_rng(int_downsize)
+    src, trg = (rng.random((1, 1) + inshape).astype(np.float32) for _ in range(2))
+    y, pre = model(G(src), G(trg))
+    yo, preo = orc.vxm_dense_forward(torch.from_numpy(src).double(), torch.from_numpy(trg).double(), sd, int_steps=int_steps,
+                                     int_downsize=int_downsize, unet_half_res=half_res)
+    assert pre.shape == preo.shape
+    np.testing.assert_allclose(N(y), yo.detach().numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(N(pre), preo.detach().numpy(), atol=2e-5, rtol=0)
+    loss = (y * y).mean() + (pre * pre).mean()
+    losso = (yo * yo).mean() + (preo * preo).mean()
+    loss.backward()
+    losso.backward()
+    for name, p in model.named_parameters():
+        assert rel_l2(N(p.grad), sd[name].grad.numpy()) < 5e-4, name      # fp32 path vs fp64 oracle through 9 blocks and the integration
+
+
 # ------------------------------------------------------------------ VxmDense (golden, produced by the reference)
 CASES = {
     "diffeo": dict(int_steps=7, int_downsize=2, bidir=False, loss="ncc", lam=1.0),
