@@ -1,21 +1,29 @@
 """Drop-in mirror of `voxelmorph/torch/layers.py` (reference) on the MI355X HIP kernels.
 
-Same class names, constructor signatures, attributes and buffers; `forward` dispatches to
-libvxm_hip.so through `functional.py` (3-D volumes) or `planar.py` (2-D images).
+Same class names, constructor signatures, attributes and buffers as the reference; `forward` dispatches to libvxm_hip.so
+through `functional.py` (3-D volumes) or `planar.py` (2-D images).  There is no CPU / ATen path behind these modules.
 """
 import torch
-import torch.nn as nn
+from torch import nn
 
 from . import functional as VF
 from . import planar as VP
 
+_LINEAR_MODE = {1: 'linear', 2: 'bilinear', 3: 'trilinear'}
+
+
+def _identity_grid(size):
+    """[1, N, *size] fp32 voxel-index grid in 'ij' order (what the reference registers as `grid`, layers.py:17-28)."""
+    axes = [torch.arange(int(s), dtype=torch.float32) for s in size]
+    return torch.stack(torch.meshgrid(*axes, indexing='ij')).unsqueeze(0)
+
 
 class SpatialTransformer(nn.Module):
-    """N-D Spatial Transformer (reference: layers.py:6-48).
+    """N-D spatial transformer (reference: layers.py:6-48): samples `src` at `identity + flow`, 'bilinear' or 'nearest'.
 
-    `grid` is kept as a registered fp32 buffer for state-dict parity (layers.py:17-28; stripped
-    by `LoadableModel.save`), but the kernel computes voxel indices in registers and never
-    reads it.
+    `grid` exists only for state-dict parity with the reference (it is in `state_dict()`, stripped by `LoadableModel.save`):
+    the kernels compute voxel indices in registers, reproduce the reference's normalise / un-normalise round trip in fp32
+    (`vxm_src_coord`) and never read the buffer.
     """
 
     def __init__(self, size, mode='bilinear'):
@@ -23,52 +31,45 @@ class SpatialTransformer(nn.Module):
         if mode not in VF.INTERP:
             raise ValueError("mode should be 'bilinear' or 'nearest', got %r" % (mode,))
         self.mode = mode
-        vectors = [torch.arange(0, s) for s in size]
-        grid = torch.stack(torch.meshgrid(*vectors, indexing='ij')).unsqueeze(0).type(torch.FloatTensor)
-        self.register_buffer('grid', grid)
+        self.register_buffer('grid', _identity_grid(size))
 
     def forward(self, src, flow):
-        if tuple(flow.shape[2:]) != tuple(self.grid.shape[2:]):
-            raise RuntimeError("flow spatial shape %s does not match the transformer size %s"
-                               % (tuple(flow.shape[2:]), tuple(self.grid.shape[2:])))
-        if src.dim() == 4:
-            return VP.Warp2dFn.apply(src, flow, self.mode)
-        return VF.WarpFn.apply(src, flow, self.mode)
+        expected = tuple(self.grid.shape[2:])
+        if tuple(flow.shape[2:]) != expected:
+            raise RuntimeError("flow spatial shape %s does not match the transformer size %s" % (tuple(flow.shape[2:]), expected))
+        warp = VP.Warp2dFn if src.dim() == 4 else VF.WarpFn
+        return warp.apply(src, flow, self.mode)
 
 
 class VecInt(nn.Module):
-    """Integrates a vector field via scaling and squaring (reference: layers.py:51-68)."""
+    """Integrates a stationary velocity field by scaling and squaring (reference: layers.py:51-68):
+    `v <- v / 2^nsteps`, then `nsteps` times `v <- v + v o (id + v)`."""
 
     def __init__(self, inshape, nsteps):
         super().__init__()
         assert nsteps >= 0, 'nsteps should be >= 0, found: %d' % nsteps
         self.nsteps = nsteps
-        self.scale = 1.0 / (2 ** self.nsteps)
-        self.transformer = SpatialTransformer(inshape)
+        self.scale = 1.0 / (2 ** nsteps)
+        self.transformer = SpatialTransformer(inshape)      # kept as a sub-module: its grid is part of the reference state dict
 
     def forward(self, vec):
         if self.nsteps == 0:
-            return vec * self.scale          # scale == 1
-        if vec.dim() == 4:
-            return VP.VecInt2dFn.apply(vec, self.nsteps)
-        return VF.VecIntFn.apply(vec, self.nsteps)
+            return vec * self.scale                          # scale == 1: nothing to integrate
+        integrate = VP.VecInt2dFn if vec.dim() == 4 else VF.VecIntFn
+        return integrate.apply(vec, self.nsteps)
 
 
 class ResizeTransform(nn.Module):
-    """Resize a transform: resample the field *and* rescale it (reference: layers.py:71-97)."""
+    """Resize a displacement field: resample by `1 / vel_resize` (linear, align_corners) AND rescale the vectors by the same
+    factor (reference: layers.py:71-97; the rescale comes after the resampling when shrinking, before it when enlarging)."""
 
     def __init__(self, vel_resize, ndims):
         super().__init__()
         self.factor = 1.0 / vel_resize
-        self.mode = 'linear'
-        if ndims == 2:
-            self.mode = 'bi' + self.mode
-        elif ndims == 3:
-            self.mode = 'tri' + self.mode
+        self.mode = _LINEAR_MODE.get(ndims, 'linear')
 
     def forward(self, x):
         if self.factor == 1:
             return x
-        if x.dim() == 4:
-            return VP.Resize2dFn.apply(x, self.factor)
-        return VF.ResizeFn.apply(x, self.factor)
+        resize = VP.Resize2dFn if x.dim() == 4 else VF.ResizeFn
+        return resize.apply(x, self.factor)

@@ -1,49 +1,56 @@
-"""Checkpoint / config plumbing with the reference's on-disk format
-(`voxelmorph/torch/modelio.py`): `torch.save({'config': ..., 'model_state': ...})`, identity-grid
-buffers stripped on save, `strict=False` on load — so files interoperate both ways."""
+"""Checkpoint / config plumbing that interoperates with the reference's files both ways.
+
+On-disk format (reference `voxelmorph/torch/modelio.py:58-77`): `torch.save({'config': <constructor arguments>,
+'model_state': <state_dict without the SpatialTransformer identity grids>})`; loading rebuilds the model from `config` and
+tolerates the missing grid buffers.  The behaviour is the reference's; the implementation here binds the constructor call
+through `inspect.signature` instead of walking the argspec by hand.
+"""
 import functools
 import inspect
 
 import torch
-import torch.nn as nn
+from torch import nn
+
+_GRID_SUFFIX = '.grid'          # buffers of SpatialTransformer: rebuilt by the constructor, never stored
 
 
-def store_config_args(func):
-    """Record every constructor argument in `self.config` (reference: modelio.py:7-35)."""
-    spec = inspect.getfullargspec(func)
+def store_config_args(init):
+    """Decorator for `__init__`: keeps the effective constructor arguments (defaults, then positionals, then keywords) in
+    `self.config`, which is all `LoadableModel.load` needs to rebuild the network (reference: modelio.py:7-35)."""
+    signature = inspect.signature(init)
+    named = [p for p in list(signature.parameters.values())[1:]
+             if p.kind in (p.POSITIONAL_OR_KEYWORD, p.KEYWORD_ONLY)]
 
-    @functools.wraps(func)
-    def wrapper(self, *args, **kwargs):
-        self.config = {}
-        if spec.defaults:
-            for name, val in zip(reversed(spec.args), reversed(spec.defaults)):
-                self.config[name] = val
-        for name, val in zip(spec.args[1:], args):
-            self.config[name] = val
-        for name, val in (kwargs or {}).items():
-            self.config[name] = val
-        return func(self, *args, **kwargs)
-    return wrapper
+    @functools.wraps(init)
+    def init_and_record(self, *args, **kwargs):
+        config = {p.name: p.default for p in named if p.default is not p.empty}
+        config.update(zip((p.name for p in named), args))
+        config.update(kwargs)                       # explicit keywords, including those swallowed by a **kwargs parameter
+        self.config = config
+        return init(self, *args, **kwargs)
+
+    return init_and_record
 
 
 class LoadableModel(nn.Module):
-    """Base class whose subclasses can be rebuilt from a checkpoint alone (reference: modelio.py:38-77)."""
+    """`nn.Module` that can be saved and re-created from a single file (reference: modelio.py:38-77).  Subclasses decorate
+    their constructor with `@store_config_args` (or set `self.config` themselves) before calling `super().__init__()`."""
 
     def __init__(self, *args, **kwargs):
-        if not hasattr(self, 'config'):
+        if getattr(self, 'config', None) is None:
             raise RuntimeError('models that inherit from LoadableModel must decorate the '
                                'constructor with @store_config_args')
         super().__init__(*args, **kwargs)
 
     def save(self, path):
-        sd = self.state_dict().copy()
-        for key in [k for k in sd.keys() if k.endswith('.grid')]:
-            sd.pop(key)
-        torch.save({'config': self.config, 'model_state': sd}, path)
+        """Write `{'config', 'model_state'}`; identity-grid buffers are left out (they depend only on the image shape)."""
+        weights = {name: tensor for name, tensor in self.state_dict().items() if not name.endswith(_GRID_SUFFIX)}
+        torch.save({'config': self.config, 'model_state': weights}, path)
 
     @classmethod
     def load(cls, path, device):
-        checkpoint = torch.load(path, map_location=torch.device(device))
-        model = cls(**checkpoint['config'])
-        model.load_state_dict(checkpoint['model_state'], strict=False)
+        """Rebuild the model from a checkpoint written by `save` (or by the reference) and map it to `device`."""
+        blob = torch.load(path, map_location=torch.device(device))
+        model = cls(**blob['config'])
+        model.load_state_dict(blob['model_state'], strict=False)      # the grids are missing by design
         return model

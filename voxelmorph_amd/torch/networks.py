@@ -54,10 +54,32 @@ class ConvBlock(nn.Module):
         return self.main(x, slope=0.2)
 
 
-class Unet(nn.Module):
-    """U-Net with the reference's feature bookkeeping (networks.py:12-144).
+def _unet_feature_plan(nb_features, nb_levels, feat_mult, nb_conv_per_level):
+    """Feature bookkeeping of the reference U-Net (networks.py:57-77) as a pure function.
 
-    Default features: encoder [16, 32, 32, 32], decoder [32, 32, 32, 32, 32, 16, 16].
+    `nb_features` is either `[encoder features, decoder features]` (decoder entries beyond the encoder's length are the extra
+    full-resolution convolutions) or an int, in which case level l has `round(nb_features * feat_mult**l)` features, every
+    level holds `nb_conv_per_level` convolutions and `nb_levels` is required.  Returns (enc, dec, final, levels)."""
+    if nb_features is None:
+        nb_features = default_unet_features()
+    if isinstance(nb_features, int):
+        if nb_levels is None:
+            raise ValueError('must provide unet nb_levels if nb_features is an integer')
+        per_level = [int(f) for f in np.round(nb_features * feat_mult ** np.arange(nb_levels))]
+        enc = [f for f in per_level[:-1] for _ in range(nb_conv_per_level)]
+        dec = [f for f in reversed(per_level) for _ in range(nb_conv_per_level)]
+    else:
+        if nb_levels is not None:
+            raise ValueError('cannot use nb_levels if nb_features is not an integer')
+        enc, dec = ([int(f) for f in group] for group in nb_features)
+    n = len(enc)
+    return enc, dec[:n], dec[n:], n // nb_conv_per_level + 1
+
+
+class Unet(nn.Module):
+    """U-Net of the reference (networks.py:12-144): per level `nb_conv_per_level` ConvBlocks, MaxPool(2) down, nearest x2 up
+    with a skip concat, then the remaining full-resolution ConvBlocks.  Default features: encoder [16, 32, 32, 32], decoder
+    [32, 32, 32, 32, 32, 16, 16].  Module tree and parameter names are the reference's (`encoder.{level}.{conv}.main.weight`, ...).
     """
 
     def __init__(self, inshape=None, infeats=None, nb_features=None, nb_levels=None, max_pool=2, feat_mult=1,
@@ -67,57 +89,39 @@ class Unet(nn.Module):
         assert ndims in [1, 2, 3], 'ndims should be one of 1, 2, or 3. found: %d' % ndims
         if ndims == 1:
             raise NotImplementedError("the MI355X Unet implements 2-D images and 3-D volumes")
-        self.ndims = ndims
-        self.half_res = half_res
-        if nb_features is None:
-            nb_features = default_unet_features()
-        if isinstance(nb_features, int):
-            if nb_levels is None:
-                raise ValueError('must provide unet nb_levels if nb_features is an integer')
-            feats = np.round(nb_features * feat_mult ** np.arange(nb_levels)).astype(int)
-            nb_features = [np.repeat(feats[:-1], nb_conv_per_level), np.repeat(np.flip(feats), nb_conv_per_level)]
-        elif nb_levels is not None:
-            raise ValueError('cannot use nb_levels if nb_features is not an integer')
-        enc_nf, dec_nf = [[int(f) for f in fs] for fs in nb_features]
-        nb_dec_convs = len(enc_nf)
-        final_convs = dec_nf[nb_dec_convs:]
-        dec_nf = dec_nf[:nb_dec_convs]
-        self.nb_levels = int(nb_dec_convs / nb_conv_per_level) + 1
-        if isinstance(max_pool, int):
-            max_pool = [max_pool] * self.nb_levels
-        if any(p != 2 for p in max_pool):
+        enc_nf, dec_nf, final_nf, self.nb_levels = _unet_feature_plan(nb_features, nb_levels, feat_mult, nb_conv_per_level)
+        pools = [max_pool] * self.nb_levels if isinstance(max_pool, int) else list(max_pool)
+        if any(p != 2 for p in pools):
             raise NotImplementedError("the MI355X Unet implements max_pool=2")
-        self.nb_conv_per_level = nb_conv_per_level
-        self._enc_nf, self._dec_nf, self._final_nf = enc_nf, dec_nf, list(final_convs)
-        self._infeats = infeats
+        self.ndims, self.half_res, self.nb_conv_per_level = ndims, half_res, nb_conv_per_level
+        self._enc_nf, self._dec_nf, self._final_nf, self._infeats = enc_nf, dec_nf, final_nf, infeats
 
-        prev_nf = infeats
-        encoder_nfs = [prev_nf]
+        def level_blocks(features, level, width):
+            """ModuleList of the ConvBlocks of one level; returns it with the channel count it ends on."""
+            blocks = nn.ModuleList()
+            for nf in features[level * nb_conv_per_level:(level + 1) * nb_conv_per_level]:
+                blocks.append(ConvBlock(ndims, width, nf))
+                width = nf
+            return blocks, width
+
+        width = infeats
+        skips = [infeats]                            # channels available for the skip concat at every resolution, coarsest last
         self.encoder = nn.ModuleList()
         for level in range(self.nb_levels - 1):
-            convs = nn.ModuleList()
-            for conv in range(nb_conv_per_level):
-                nf = enc_nf[level * nb_conv_per_level + conv]
-                convs.append(ConvBlock(ndims, prev_nf, nf))
-                prev_nf = nf
-            self.encoder.append(convs)
-            encoder_nfs.append(prev_nf)
-        encoder_nfs = encoder_nfs[::-1]
+            blocks, width = level_blocks(enc_nf, level, width)
+            self.encoder.append(blocks)
+            skips.append(width)
         self.decoder = nn.ModuleList()
         for level in range(self.nb_levels - 1):
-            convs = nn.ModuleList()
-            for conv in range(nb_conv_per_level):
-                nf = dec_nf[level * nb_conv_per_level + conv]
-                convs.append(ConvBlock(ndims, prev_nf, nf))
-                prev_nf = nf
-            self.decoder.append(convs)
-            if not half_res or level < (self.nb_levels - 2):
-                prev_nf += encoder_nfs[level]
+            blocks, width = level_blocks(dec_nf, level, width)
+            self.decoder.append(blocks)
+            if not half_res or level < self.nb_levels - 2:      # upsample + concat with the encoder output of that resolution
+                width += skips[-1 - level]
         self.remaining = nn.ModuleList()
-        for nf in final_convs:
-            self.remaining.append(ConvBlock(ndims, prev_nf, nf))
-            prev_nf = nf
-        self.final_nf = prev_nf
+        for nf in final_nf:
+            self.remaining.append(ConvBlock(ndims, width, nf))
+            width = nf
+        self.final_nf = width
         self._plans = {}
 
     def conv_params(self):
@@ -174,60 +178,60 @@ class VxmDense(LoadableModel):
     def __init__(self, inshape, nb_unet_features=None, nb_unet_levels=None, unet_feat_mult=1, nb_unet_conv_per_level=1,
                  int_steps=7, int_downsize=2, bidir=False, use_probs=False, src_feats=1, trg_feats=1, unet_half_res=False):
         super().__init__()
-        self.training = True
+        if use_probs:                                # as the reference: the probabilistic variant exists only in its TF backend
+            raise NotImplementedError('Flow variance has not been implemented in pytorch - set use_probs to False')
         ndims = len(inshape)
         assert ndims in [1, 2, 3], 'ndims should be one of 1, 2, or 3. found: %d' % ndims
-        self.unet_model = Unet(inshape, infeats=(src_feats + trg_feats), nb_features=nb_unet_features,
-                               nb_levels=nb_unet_levels, feat_mult=unet_feat_mult,
-                               nb_conv_per_level=nb_unet_conv_per_level, half_res=unet_half_res)
-        self.flow = _Conv3dParams(self.unet_model.final_nf, ndims, ndims)
-        self.ndims = ndims
-        self.flow.weight = nn.Parameter(Normal(0, 1e-5).sample(self.flow.weight.shape))
-        self.flow.bias = nn.Parameter(torch.zeros(self.flow.bias.shape))
-        if use_probs:
-            raise NotImplementedError('Flow variance has not been implemented in pytorch - set use_probs to False')
-        if not unet_half_res and int_steps > 0 and int_downsize > 1:
-            self.resize = layers.ResizeTransform(int_downsize, ndims)
-        else:
-            self.resize = None
-        if int_steps > 0 and int_downsize > 1:
-            self.fullsize = layers.ResizeTransform(1 / int_downsize, ndims)
-        else:
-            self.fullsize = None
-        self.bidir = bidir
-        down_shape = [int(dim / int_downsize) for dim in inshape]
-        self.integrate = layers.VecInt(down_shape, int_steps) if int_steps > 0 else None
-        self.transformer = layers.SpatialTransformer(inshape)
+        self.training = True                         # the reference sets the flag explicitly (networks.py:192)
+        self.ndims, self.bidir = ndims, bidir
         self._feats = (src_feats, trg_feats)
 
+        self.unet_model = Unet(inshape, infeats=src_feats + trg_feats, nb_features=nb_unet_features, nb_levels=nb_unet_levels,
+                               feat_mult=unet_feat_mult, nb_conv_per_level=nb_unet_conv_per_level, half_res=unet_half_res)
+        # flow head: ndims output channels, weights ~ N(0, 1e-5), zero bias (networks.py:210-215): training starts at the identity
+        self.flow = _Conv3dParams(self.unet_model.final_nf, ndims, ndims)
+        with torch.no_grad():
+            self.flow.weight.copy_(Normal(0, 1e-5).sample(self.flow.weight.shape))
+            self.flow.bias.zero_()
+
+        # The velocity field is integrated at 1 / int_downsize of the image resolution: shrink it first (unless the U-Net
+        # already stops at half resolution), integrate, bring the result back to full size (networks.py:223-242).
+        integrating, reduced = int_steps > 0, int_downsize > 1
+        self.resize = layers.ResizeTransform(int_downsize, ndims) if (integrating and reduced and not unet_half_res) else None
+        self.fullsize = layers.ResizeTransform(1 / int_downsize, ndims) if (integrating and reduced) else None
+        self.integrate = layers.VecInt([int(extent / int_downsize) for extent in inshape], int_steps) if integrating else None
+        self.transformer = layers.SpatialTransformer(inshape)
+
     def _forward_all(self, source, target):
-        """(y_source, y_target, preint_flow, pos_flow, neg_flow) of networks.py:244-287 (None where not bidir)."""
+        """Everything `forward` can return (reference: networks.py:244-287): (moved source, moved target or None, the field
+        the smoothness loss sees, positive displacement, negative displacement or None)."""
         if self.ndims == 2:
-            flow_field = self.flow(self.unet_model(torch.cat([source, target], dim=1)))
+            field = self.flow(self.unet_model(torch.cat([source, target], dim=1)))
         else:
-            # U-Net + flow conv as ONE fused autograd node; source/target enter as a virtual concat
+            # U-Net + flow head as ONE fused autograd node; source and target enter as a virtual concat
             plan = self.unet_model.plan(self._feats, extra=((self.flow.out_channels, 1.0),))
-            flow_field = VF.UnetFn.apply(plan, source, target, *self.unet_model.conv_params(), self.flow.weight, self.flow.bias)
-        pos_flow = flow_field
-        if self.resize:
-            pos_flow = self.resize(pos_flow)
-        preint_flow = pos_flow
-        neg_flow = -pos_flow if self.bidir else None
-        if self.integrate:
-            pos_flow = self.integrate(pos_flow)
-            neg_flow = self.integrate(neg_flow) if self.bidir else None
-            if self.fullsize:
-                pos_flow = self.fullsize(pos_flow)
-                neg_flow = self.fullsize(neg_flow) if self.bidir else None
-        y_source = self.transformer(source, pos_flow)
-        y_target = self.transformer(target, neg_flow) if self.bidir else None
-        return y_source, y_target, preint_flow, pos_flow, neg_flow
+            field = VF.UnetFn.apply(plan, source, target, *self.unet_model.conv_params(), self.flow.weight, self.flow.bias)
+        velocity = self.resize(field) if self.resize is not None else field       # what Grad regularises ("preint_flow")
+
+        def displacement(v):
+            """velocity -> full-resolution displacement: scaling and squaring, then back to the image grid"""
+            if self.integrate is not None:
+                v = self.integrate(v)
+                if self.fullsize is not None:
+                    v = self.fullsize(v)
+            return v
+
+        forward_disp = displacement(velocity)
+        backward_disp = displacement(-velocity) if self.bidir else None
+        moved_source = self.transformer(source, forward_disp)
+        moved_target = self.transformer(target, backward_disp) if self.bidir else None
+        return moved_source, moved_target, velocity, forward_disp, backward_disp
 
     def forward(self, source, target, registration=False):
-        y_source, y_target, preint_flow, pos_flow, _ = self._forward_all(source, target)
-        if not registration:
-            return (y_source, y_target, preint_flow) if self.bidir else (y_source, preint_flow)
-        return y_source, pos_flow
+        moved_source, moved_target, velocity, forward_disp, _ = self._forward_all(source, target)
+        if registration:
+            return moved_source, forward_disp
+        return (moved_source, moved_target, velocity) if self.bidir else (moved_source, velocity)
 
 
 class VxmDenseSemiSupervisedSeg(LoadableModel):
