@@ -26,27 +26,35 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
+# The reference's flags (scripts/torch/train.py:52-91) with its defaults; only --save-every is new.
+_FLAGS = [
+    # name, argparse keywords
+    ('--img-list', dict(required=True, help='text file with one training volume (npz / npy) per line')),
+    ('--img-prefix', dict(help='string put in front of every entry of --img-list')),
+    ('--img-suffix', dict(help='string appended to every entry of --img-list')),
+    ('--model-dir', dict(default='models', help='where checkpoints go [models]')),
+    ('--batch-size', dict(type=int, default=1, help='GLOBAL batch size, split evenly over the ranks [1]')),
+    ('--epochs', dict(type=int, default=1500, help='epochs to train [1500]')),
+    ('--steps-per-epoch', dict(type=int, default=100, help='optimiser steps per epoch [100]')),
+    ('--load-model', dict(help='checkpoint to start from (this package\'s or the reference\'s .pt)')),
+    ('--initial-epoch', dict(type=int, default=0, help='epoch counter to resume at [0]')),
+    ('--lr', dict(type=float, default=1e-4, help='Adam learning rate [1e-4]')),
+    ('--enc', dict(type=int, nargs='+', help='U-Net encoder features per level [16 32 32 32]')),
+    ('--dec', dict(type=int, nargs='+', help='U-Net decoder features, extra entries = full-resolution convs [32 32 32 32 32 16 16]')),
+    ('--int-steps', dict(type=int, default=7, help='scaling-and-squaring steps, 0 = no integration [7]')),
+    ('--int-downsize', dict(type=int, default=2, help='integrate the field at 1/N of the image resolution [2]')),
+    ('--bidir', dict(action='store_true', help='also warp the target onto the source and average both image losses')),
+    ('--image-loss', dict(default='mse', help="'mse' or 'ncc' [mse]")),
+    ('--lambda', dict(type=float, dest='weight', default=0.01, help='weight of the smoothness (Grad) term [0.01]')),
+    ('--save-every', dict(type=int, default=20, help='epochs between checkpoints [20, as the reference]')),
+]
+
+
 def parse(argv=None):
-    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
-    p.add_argument('--img-list', required=True, help='line-seperated list of training files')
-    p.add_argument('--img-prefix', help='optional input image file prefix')
-    p.add_argument('--img-suffix', help='optional input image file suffix')
-    p.add_argument('--model-dir', default='models', help='model output directory (default: models)')
-    p.add_argument('--batch-size', type=int, default=1, help='global batch size (default: 1)')
-    p.add_argument('--epochs', type=int, default=1500, help='number of training epochs (default: 1500)')
-    p.add_argument('--steps-per-epoch', type=int, default=100, help='steps per epoch (default: 100)')
-    p.add_argument('--load-model', help='optional model file to initialize with')
-    p.add_argument('--initial-epoch', type=int, default=0, help='initial epoch number (default: 0)')
-    p.add_argument('--lr', type=float, default=1e-4, help='learning rate (default: 1e-4)')
-    p.add_argument('--enc', type=int, nargs='+', help='list of unet encoder filters (default: 16 32 32 32)')
-    p.add_argument('--dec', type=int, nargs='+', help='list of unet decorder filters (default: 32 32 32 32 32 16 16)')
-    p.add_argument('--int-steps', type=int, default=7, help='number of integration steps (default: 7)')
-    p.add_argument('--int-downsize', type=int, default=2, help='flow downsample factor for integration (default: 2)')
-    p.add_argument('--bidir', action='store_true', help='enable bidirectional cost function')
-    p.add_argument('--image-loss', default='mse', help='image reconstruction loss - can be mse or ncc (default: mse)')
-    p.add_argument('--lambda', type=float, dest='weight', default=0.01, help='weight of deformation loss (default: 0.01)')
-    p.add_argument('--save-every', type=int, default=20, help='checkpoint period in epochs (reference: 20)')
-    return p.parse_args(argv)
+    parser = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    for flag, kw in _FLAGS:
+        parser.add_argument(flag, **kw)
+    return parser.parse_args(argv)
 
 
 def read_file_list(path, prefix=None, suffix=None):
