@@ -36,70 +36,106 @@ def parse():
     ap.add_argument("--shape", type=str, default="160,192,224")
     ap.add_argument("--int-steps", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-shape", type=str, default="160,192,112")   # half of the volume: ~6 s per CPU step on 32 threads
+    ap.add_argument("--cpu-baseline-steps", type=int, default=2)               # timed CPU steps after one warm-up, at the FULL shape
+    ap.add_argument("--cpu-threads", type=int, default=0)                      # 0: min(32, cores), see cpu_baseline()
     return ap.parse_args()
 
 
-def cpu_baseline(full_shape, sample_shape, int_steps):
-    """The oracle (CPU restatement of the reference torch path, oracle/vxm_oracle.py) timed on this host's
-    cores on a bounded sample: the SAME network/loss/optimizer on a sub-volume; throughput is scaled by the
-    voxel ratio to volume-pairs/s at the full shape.  Reported baseline, not the optimisation target."""
+def cpu_baseline(shape, int_steps, timed_steps, threads):
+    """The reference's torch path timed on this host's cores at the benchmark shape itself (SURVEY.md §8d / BASELINE.md §4):
+    B = 1, fp32, NCC(9^3) + Grad('l2', x2), Adam lr 1e-4, one warm-up + `timed_steps` timed training steps.
+
+    kind "reference": the UNMODIFIED upstream modules imported from /root/reference (oracle/ref_loader.py; NCC through the
+    `.to("cuda")` no-op shim because losses.py:29 hard-codes the device) — only where that tree exists (the build
+    container).  kind "port": the oracle's restatement of the same ATen call sequence (oracle/vxm_oracle.py) — the GPU box
+    has no /root/reference.  Reported baseline, not the optimisation target."""
     import numpy as np
+    from oracle import ref_loader
     from oracle import vxm_oracle as orc
-    # torch's intra-op pool degrades badly beyond one socket's worth of threads (256 threads on the
-    # 2x64-core bench host ran 10x slower than 8 threads elsewhere): use at most 32 and report that number
-    cores = min(32, os.cpu_count() or 1)
+    # torch's intra-op pool degrades beyond one socket's worth of threads (256 threads on the 2x64-core bench host ran
+    # 10x slower than 8 threads elsewhere): at most 32 unless told otherwise; the number used is reported as `cores`
+    cores = threads if threads > 0 else min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     rng = np.random.default_rng(1234)
-    src = torch.from_numpy(rng.random((1, 1) + sample_shape).astype(np.float32))
-    trg = torch.from_numpy(rng.random((1, 1) + sample_shape).astype(np.float32))
-    sd = orc.seeded_state_dict(sample_shape, seed=0, flow_std=1e-5)
-    params = [v.requires_grad_() for v in sd.values()]
-    opt = torch.optim.Adam(params, lr=1e-4)
+    src = torch.from_numpy(rng.random((1, 1) + shape).astype(np.float32))
+    trg = torch.from_numpy(rng.random((1, 1) + shape).astype(np.float32))
+    if ref_loader.reference_available():
+        kind = "reference"
+        ref = ref_loader.load_reference()
+        torch.manual_seed(0)
+        model = ref.networks.VxmDense(shape, int_steps=int_steps, int_downsize=2)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        ncc = ref.losses.NCC().loss
+        reg = ref.losses.Grad("l2", loss_mult=2).loss
 
-    def step():
-        opt.zero_grad()
-        loss, _ = orc.train_step_loss(src, trg, sd, "ncc", 1.0, int_steps=int_steps, int_downsize=2)
-        loss.backward()
-        opt.step()
+        def step():
+            with ref_loader.cuda_alias_to_cpu():
+                y, pre = model(src, trg)
+                loss = ncc(trg, y) + 1.0 * reg(None, pre)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+    else:
+        kind = "port"
+        sd = orc.seeded_state_dict(shape, seed=0, flow_std=1e-5)
+        params = [v.requires_grad_() for v in sd.values()]
+        opt = torch.optim.Adam(params, lr=1e-4)
+
+        def step():
+            opt.zero_grad()
+            loss, _ = orc.train_step_loss(src, trg, sd, "ncc", 1.0, int_steps=int_steps, int_downsize=2)
+            loss.backward()
+            opt.step()
 
     step()                                  # warm-up
-    t0 = time.perf_counter()
-    step()
-    dt = time.perf_counter() - t0
-    frac = float(np.prod(sample_shape)) / float(np.prod(full_shape))
+    times = []
+    for _ in range(max(1, timed_steps)):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
     return {
-        "value": frac / dt, "unit": "volume-pairs/s", "cores": cores, "kind": "port",
-        "sample": "1 warm-up + 1 timed training step (fwd+NCC+Grad+bwd+Adam) of the torch-CPU oracle on a %s "
-                  "sub-volume (%.4f of %s voxels), %.2f s/step; pairs/s scaled by the voxel ratio"
-                  % ("x".join(map(str, sample_shape)), frac, "x".join(map(str, full_shape)), dt),
+        "value": 1.0 / dt, "unit": "volume-pairs/s", "cores": cores, "kind": kind, "s_per_step": dt,
+        "sample": "1 warm-up + %d timed training step(s) (fwd+NCC+Grad+bwd+Adam) at the full %s shape, B=1, fp32, %d torch "
+                  "threads of %d host cores: %s s/step" % (len(times), "x".join(map(str, shape)), cores, os.cpu_count() or 0,
+                                                           ", ".join("%.2f" % t for t in times)),
         "cpu_model": _cpu_model(),
     }
 
 
-def hbm_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of this same command
-    (profiles/*_hbm_counters.json, written by tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc
-    passes, kernel-trace only).  Units and gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes:
-    both counters are in KiB; FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes, so the
-    read side is doubled.  Returns (bytes_per_launch or None, source)."""
+def hbm_traffic(kernel, launches_per_step):
+    """HBM bytes per launch of the region `kernel` from the committed rocprofv3 PMC summary of this same command
+    (profiles/*_hbm_counters.json, written by tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes,
+    kernel-trace only).  Units and gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes: both
+    counters are in KiB; FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes, so the read side is
+    doubled.  A region label names a kernel family ("k<1>"); its template instances ("k<1, 2, 32>", "k<1, 4, 16>") are
+    averaged weighted by their dispatch counts.  The file is REFUSED (traffic null, reason in the note) when it does not
+    describe this run: no instance of the kernel in it, or a dispatch count that is not launches_per_step x the profiled
+    steps recorded in its "_meta" entry.  Returns (bytes_per_launch or None, note)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_counters.json")))
     if not files:
-        return None, None
+        return None, "no profiles/*_hbm_counters.json"
+    rel = os.path.relpath(files[-1], ROOT)
     try:
         with open(files[-1]) as f:
             ctr = json.load(f)
     except (OSError, ValueError):
-        return None, None
-    ent = ctr.get(kernel)
-    if ent is None and kernel.endswith(">"):          # region label "k<1>" vs the full template argument list "k<1, 4>"
-        stem = kernel[:-1]
-        hits = [v for k, v in ctr.items() if k.startswith(stem + ",") or k.startswith(stem + ">")]
-        ent = hits[0] if len(hits) == 1 else None
-    if not ent or "FETCH_SIZE" not in ent or "WRITE_SIZE" not in ent:
-        return None, None
-    return (2.0 * ent["FETCH_SIZE"]["mean"] + ent["WRITE_SIZE"]["mean"]) * 1024.0, os.path.relpath(files[-1], ROOT)
+        return None, "%s unreadable" % rel
+    stem = kernel[:-1] if kernel.endswith(">") else kernel
+    hits = {k: v for k, v in ctr.items() if k == kernel or k.startswith(stem + ",") or k.startswith(stem + ">")}
+    hits = {k: v for k, v in hits.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+    if not hits:
+        return None, "%s has no counters for %s: stale profile, re-run tools/profile_bench.sh" % (rel, kernel)
+    n = sum(v["FETCH_SIZE"]["dispatches"] for v in hits.values())
+    steps = (ctr.get("_meta") or {}).get("steps_profiled")
+    if steps and abs(n - launches_per_step * steps) > 0.5:
+        return None, "%s: %d dispatches of %s in %d profiled steps, this run launches %.1f per step: stale profile" % (
+            rel, n, kernel, steps, launches_per_step)
+    tot = sum((2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * v["FETCH_SIZE"]["dispatches"] for v in hits.values())
+    return tot / n * 1024.0, "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, KiB counters; rocprofv3 --pmc of this command: %s; instances %s)" % (
+        rel, ", ".join(sorted(hits)))
 
 
 def _cpu_model():
@@ -116,11 +152,13 @@ def _cpu_model():
 def main():
     args = parse()
     from voxelmorph_amd import dist as vdist
+    # `python bench.py --gpus N` without a torchrun environment: become `python -m torch.distributed.run --nproc-per-node N
+    # ... bench.py --gpus N ...` (one rank per GPU, 127.0.0.1 rendezvous); under torchrun this returns at once
+    vdist.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:])
     rank, local, world = vdist.init_from_env()
     if args.gpus != world:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world),
-                  file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs an MI355X (HIP device); there is no CPU fallback for the product path", file=sys.stderr)
@@ -170,7 +208,7 @@ def main():
     elapsed = vdist.max_over_ranks(time.perf_counter() - t0, dev)
     profiler.uninstall()
     stats = timer.resolve()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank != 0:
         return
@@ -197,9 +235,7 @@ def main():
         roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_per_launch": ds["bytes"] / ds["launches"], "avg_launch_ms": ds["ms"] / ds["launches"]}
-    roof["traffic"], src = hbm_traffic(dom)
-    if src:
-        roof["traffic_unit"] = "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, KiB counters; rocprofv3 --pmc of this command: %s)" % src
+    roof["traffic"], roof["traffic_unit"] = hbm_traffic(dom, ds["launches"] / args.steps)
     out = {
         "metric": "volume-pairs/sec VxmDense 160x192x224 int_steps=7 NCC train",
         "value": world * B * args.steps / elapsed, "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -211,7 +247,7 @@ def main():
         "roofline": roof, "kernels": kernels, "final_loss": final_loss,
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(shape, tuple(int(s) for s in args.cpu_baseline_shape.split(",")), args.int_steps)
+        out["cpu_baseline"] = cpu_baseline(shape, args.int_steps, args.cpu_baseline_steps, args.cpu_threads)
     print(json.dumps(out))
 
 

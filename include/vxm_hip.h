@@ -161,6 +161,9 @@ int vxm_upsample2_cat(const float* x0, int C0, const float* x1, int C1, float* o
  * along D (2-D box sums through LDS, a register ring over depth) and keeps the partials (a,b,c) = d cc/d(sum J,
  * sum J^2, sum IJ) for backward in `sums` (3*B*D*H*W floats used, `work` unused).  Larger windows: separable passes;
  * `sums` keeps the five box sums (5*B*D*H*W floats) and `work` is a 5*B*D*H*W scratch. */
+/* 1 if (B, win) takes the fused march (sums: 3 planes, work unused), 0 for the separable passes (sums 5, work 5/6 planes):
+ * the ONE place that decision is made; callers allocate from it. */
+int vxm_ncc_fused(int B, int win);
 int vxm_ncc_fwd(const float* I, const float* J, float* loss, float* sums, float* work, double* acc,
                 int B, int D, int H, int W, int win, void* stream);
 /* gJ = dL/dJ (y_pred) from what vxm_ncc_fwd left in `sums` for the same (I, J, win).  work: unused for windows

@@ -1,13 +1,13 @@
 #!/usr/bin/env python
-"""Scan-to-scan VxmDense training on MI355X — the caller of the hot path, taking the command line of the reference's
+"""Scan-to-scan / scan-to-atlas VxmDense training on MI355X — the caller of the hot path, taking the command line of the reference's
 `scripts/torch/train.py` (same flag names / defaults; :52-91) and keeping its loop semantics (:184-233: weighted loss
 list, Adam lr 1e-4, a checkpoint every 20 epochs + the final one, `%04d.pt` names), with three differences that are
 the point of this package:
 
   * data parallelism is one process per GPU (launch with `python -m torch.distributed.run --nproc-per-node N
-    --master-addr 127.0.0.1 scripts/train.py ...`), each rank trains `--batch-size / N` pairs per step and the only
-    exchange is one RCCL all-reduce of the flat gradient bucket (`FlatAdam.step`), instead of `torch.nn.DataParallel`
-    (:151-154);
+    --master-addr 127.0.0.1 scripts/train.py ...`, or pass the reference's `--gpu 0,1,..`: the script then re-launches
+    itself that way on those devices), each rank trains `--batch-size / N` pairs per step and the only exchange is one
+    RCCL all-reduce of the flat gradient bucket (`FlatAdam.step`), instead of `torch.nn.DataParallel` (:151-154);
   * batches come from `voxelmorph_amd.data.PairLoader` (volumes pinned / resident in HBM, uploads on a copy stream)
     instead of numpy generators + a per-step pageable copy and permute (:199-201);
   * losses are accumulated on the device and read back once per epoch instead of three `.item()` syncs per step
@@ -26,19 +26,24 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
-# The reference's flags (scripts/torch/train.py:52-91) with its defaults; only --save-every is new.
+# The reference's flags (scripts/torch/train.py:52-91) with its defaults; only --save-every is new.  --cudnn-nondet is
+# accepted and ignored: there is no cuDNN / MIOpen algorithm choice on this path (the kernels are fixed and deterministic).
 _FLAGS = [
     # name, argparse keywords
     ('--img-list', dict(required=True, help='text file with one training volume (npz / npy) per line')),
     ('--img-prefix', dict(help='string put in front of every entry of --img-list')),
     ('--img-suffix', dict(help='string appended to every entry of --img-list')),
+    ('--atlas', dict(help='atlas volume (npz `vol` / npy): scan-to-atlas training instead of scan-to-scan')),
     ('--model-dir', dict(default='models', help='where checkpoints go [models]')),
+    ('--multichannel', dict(action='store_true', help='volumes carry a trailing feature axis [*vol, C]')),
+    ('--gpu', dict(default=None, help='device id(s), comma-separated; several ids = one rank per id [LOCAL_RANK, else 0]')),
     ('--batch-size', dict(type=int, default=1, help='GLOBAL batch size, split evenly over the ranks [1]')),
     ('--epochs', dict(type=int, default=1500, help='epochs to train [1500]')),
     ('--steps-per-epoch', dict(type=int, default=100, help='optimiser steps per epoch [100]')),
     ('--load-model', dict(help='checkpoint to start from (this package\'s or the reference\'s .pt)')),
     ('--initial-epoch', dict(type=int, default=0, help='epoch counter to resume at [0]')),
     ('--lr', dict(type=float, default=1e-4, help='Adam learning rate [1e-4]')),
+    ('--cudnn-nondet', dict(action='store_true', help='accepted for command-line compatibility; no effect here')),
     ('--enc', dict(type=int, nargs='+', help='U-Net encoder features per level [16 32 32 32]')),
     ('--dec', dict(type=int, nargs='+', help='U-Net decoder features, extra entries = full-resolution convs [32 32 32 32 32 16 16]')),
     ('--int-steps', dict(type=int, default=7, help='scaling-and-squaring steps, 0 = no integration [7]')),
@@ -70,12 +75,22 @@ def main(argv=None):
     from voxelmorph_amd import dist as vdist
     from voxelmorph_amd.optim import FlatAdam
 
+    gpus = [g for g in (args.gpu or '').split(',') if g != '']
+    if len(gpus) > 1:           # the reference's DataParallel request (train.py:123-129,151-154) = one rank per listed device
+        vdist.self_launch(len(gpus), os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), ','.join(gpus))
+    elif len(gpus) == 1 and 'LOCAL_RANK' not in os.environ:
+        os.environ['LOCAL_RANK'] = gpus[0]
     rank, local, world = vdist.init_from_env()
     files = read_file_list(args.img_list, args.img_prefix, args.img_suffix)
     assert len(files) > 0, 'Could not find any training data.'
     lo, hi = vdist.shard_range(args.batch_size, rank, world)        # asserts batch % world == 0 like train.py:128-129
     dev = torch.device('cuda', local)
-    loader = vdata.scan_to_scan(files, batch_size=hi - lo, bidir=args.bidir, device=dev, rank=rank)
+    add_feat_axis = not args.multichannel                           # train.py:101
+    if args.atlas:                                                  # train.py:103-109
+        loader = vdata.scan_to_atlas(files, args.atlas, batch_size=hi - lo, bidir=args.bidir, add_feat_axis=add_feat_axis,
+                                     device=dev, rank=rank)
+    else:
+        loader = vdata.scan_to_scan(files, batch_size=hi - lo, bidir=args.bidir, add_feat_axis=add_feat_axis, device=dev, rank=rank)
     inshape = loader.shape
 
     enc = args.enc if args.enc else [16, 32, 32, 32]
@@ -83,8 +98,10 @@ def main(argv=None):
     if args.load_model:
         model = vxm.networks.VxmDense.load(args.load_model, dev)
     else:
+        # (the reference builds the model for one feature per image even with --multichannel and then fails in its first
+        # conv for C > 1; here the channel count of the data sizes the network input)
         model = vxm.networks.VxmDense(inshape=inshape, nb_unet_features=[enc, dec], bidir=args.bidir, int_steps=args.int_steps,
-                                      int_downsize=args.int_downsize)
+                                      int_downsize=args.int_downsize, src_feats=loader.channels, trg_feats=loader.channels)
     model.to(dev)
     model.train()
     opt = FlatAdam(model, lr=args.lr, comm=vdist.native_comm())

@@ -669,23 +669,90 @@ def test_full_size_dice_of_warped_labels_matches_oracle(vxm):
     assert abs(d_gpu - d_ref) <= 1e-3
 
 
-def test_full_size_train_step_runs_and_is_linear_in_lr(vxm):
-    from voxelmorph_amd.optim import FlatAdam
-    torch.manual_seed(0)
-    model = vxm.networks.VxmDense(FULL, int_steps=7, int_downsize=2).cuda()
-    opt = FlatAdam(model, lr=1e-4)
-    src, trg = torch.rand(1, 1, *FULL, device="cuda"), torch.rand(1, 1, *FULL, device="cuda")
-    losses = []
-    for _ in range(2):
-        opt.zero_grad()
-        y, pre = model(src, trg)
-        loss = vxm.losses.NCC().loss(trg, y) + vxm.losses.Grad("l2", loss_mult=2).loss(None, pre)
-        loss.backward()
-        opt.step()
-        losses.append(float(loss))
-    assert all(np.isfinite(losses)) and -1.0 <= losses[0] <= 0.0
-    assert y.shape == (1, 1) + FULL and pre.shape == (1, 3, 80, 96, 112)
-    assert float(opt.flat_grad.abs().sum()) > 0
+def _full_size_step_vs_oracle(vxm, src, trg, seed, flow_std):
+    """One headline-config training step (VxmDense 160x192x224, int_steps=7, int_downsize=2, NCC(9^3) + Grad('l2', x2),
+    lambda 1; scripts/torch/train.py:194-223) on the HIP path against `oracle.vxm_oracle.train_step_loss` on the host cores:
+    forward tensors, loss and every parameter gradient.  Returns the GPU model and the positive full-resolution flow."""
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    sd = orc.seeded_state_dict(FULL, seed=seed, flow_std=flow_std)
+    model = vxm.networks.VxmDense(FULL, int_steps=7, int_downsize=2)
+    res = model.load_state_dict(sd, strict=False)
+    assert all(k.endswith(".grid") for k in res.missing_keys) and not res.unexpected_keys
+    model = model.cuda()
+    s, t = G(src), G(trg)
+    y, _, pre, pos, _ = model._forward_all(s, t)
+    loss = vxm.losses.NCC().loss(t, y) + vxm.losses.Grad("l2", loss_mult=2).loss(None, pre)
+    loss.backward()
+    torch.cuda.synchronize()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    ref, (_, _, ys, pres) = orc.train_step_loss(torch.from_numpy(src), torch.from_numpy(trg), sdo, "ncc", 1.0)
+    ref.backward()
+    err_y = float((y.detach().cpu() - ys.detach()).abs().max())
+    err_p = float((pre.detach().cpu() - pres.detach()).abs().max())
+    gerr = {name: rel_l2(N(p.grad), sdo[name].grad.numpy()) for name, p in model.named_parameters()}
+    worst = max(gerr, key=gerr.get)
+    print("full-size step: loss hip=%.7f oracle=%.7f | max|dy|=%.2e max|dpreint|=%.2e | worst grad rel-L2 %.2e (%s)"
+          % (float(loss), float(ref), err_y, err_p, gerr[worst], worst))
+    assert err_y <= 2e-5 and err_p <= 2e-5, (err_y, err_p)
+    assert abs(float(loss) - float(ref)) <= 1e-3
+    assert len(gerr) == 24
+    for name, e in gerr.items():
+        assert e <= 2e-3, (name, e)
+    return model, pos.detach()
+
+
+def test_full_size_train_step_vs_oracle_noise_pair(vxm):
+    """BASELINE.json configs[2] at the size the metric is quoted on, noise pairs U[0,1), flow weights
+    N(0, 0.05) so that the integrated field is a real deformation (|v| up to ~1 voxel at half resolution) rather than the
+    near-identity of the N(0, 1e-5) start."""
+    rng = np.random.default_rng(1234)
+    src = rng.random((1, 1) + FULL).astype(np.float32)
+    trg = rng.random((1, 1) + FULL).astype(np.float32)
+    _full_size_step_vs_oracle(vxm, src, trg, seed=11, flow_std=0.05)
+
+
+def _real_scan():
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_scan_u8.npz"))
+    vol = (d["vol_u8"].astype(np.float64) / 255.0).astype(np.float32)       # == test_scan.npz['vol'].astype(float32), bit for bit
+    return vol, d["seg_u8"].astype(np.float32), d["labels"]
+
+
+def _smooth_svf(shape, sigma=8.0, max_disp=5.0, seed=0):
+    """BASELINE.md §4 structured pair: Gaussian-filtered N(0,1) noise (sigma = 8 voxels) scaled to max |v| = 5 voxels."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    f = np.stack([gaussian_filter(rng.standard_normal(shape).astype(np.float32), sigma, mode="nearest") for _ in range(3)])
+    f *= max_disp / np.sqrt((f ** 2).sum(0)).max()
+    return f[None].astype(np.float32)
+
+
+def test_full_size_real_scan_step_and_label_dice_gate(vxm):
+    """The structured pair of SURVEY.md §8d / BASELINE.md §4 on the reference's real scan (data/test_scan.npz, shipped as
+    tests/golden/real_scan_u8.npz): target = the scan, source = the scan warped by a fixed smooth 5-voxel field.
+    (1) the training step against the oracle as above; (2) the accuracy gate of the north star: the label map restricted to
+    the 30 evaluated labels (data/labels.npz), nearest-warped by the network's own full-resolution flow, is BIT-EXACT
+    against the C oracle on that flow, and its Dice (py/utils.py:265-287) differs by <= 1e-3 from the Dice of the label map
+    warped by the ORACLE's flow (the two flows differ by fp32 rounding, so a handful of ties may flip)."""
+    vol, seg, labels = _real_scan()
+    assert vol.shape == FULL and len(labels) == 30
+    svf = _smooth_svf(FULL)
+    trg = vol[None, None]
+    src = c_oracle.warp3d(trg, svf, mode="bilinear")
+    model, pos = _full_size_step_vs_oracle(vxm, src, trg, seed=12, flow_std=0.05)
+    seg30 = np.where(np.isin(seg, labels), seg, 0.0).astype(np.float32)[None, None]
+    moved = N(vxm.layers.SpatialTransformer(FULL, mode="nearest").cuda()(G(seg30), pos))
+    ref_same_flow = c_oracle.warp3d(seg30, N(pos), mode="nearest")
+    assert np.array_equal(moved, ref_same_flow), "nearest label warp differs in %d voxels" % int((moved != ref_same_flow).sum())
+    assert set(np.unique(moved)) <= set(np.unique(seg30))
+    with torch.no_grad():
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items() if not k.endswith(".grid")}
+        _, pos_o = orc.vxm_dense_forward(torch.from_numpy(src), torch.from_numpy(trg), sd, registration=True)
+    ref = c_oracle.warp3d(seg30, pos_o.numpy(), mode="nearest")
+    d_hip = np.asarray(orc.dice_metric(moved[0, 0], seg30[0, 0], labels=labels))
+    d_ref = np.asarray(orc.dice_metric(ref[0, 0], seg30[0, 0], labels=labels))
+    print("real-scan label gate: mean Dice hip=%.6f oracle=%.6f, max per-label diff %.2e, flow max|d|=%.2e, label agreement %.6f"
+          % (d_hip.mean(), d_ref.mean(), np.abs(d_hip - d_ref).max(), float((pos.cpu() - pos_o).abs().max()), (moved == ref).mean()))
+    assert d_hip.shape == (30,) and np.abs(d_hip - d_ref).max() <= 1e-3
 
 
 @pytest.mark.parametrize("c0,up0,c1,cout", [(32, False, 0, 16), (16, False, 0, 32), (32, True, 16, 32), (2, False, 0, 16), (16, False, 0, 3)])
@@ -832,6 +899,153 @@ def test_planar_vxm_dense_golden(vxm, g_planar, tag):
     with torch.no_grad():
         _, pos = model(src, trg, registration=True)
     np.testing.assert_allclose(N(pos), g[tag + "_pos_flow"], atol=1e-4, rtol=0)
+
+
+def test_planar_train_step_updates_weights_through_flat_adam(vxm, g_planar):
+    """The training loop as scripts/train.py runs it (FlatAdam built first; zero_grad, backward, step) on a 2-D model: the
+    per-op 2-D network hands its parameter gradients to autograd (p.grad), not to the flat bucket; FlatAdam.step must fold
+    them in.  Weights after one step == Adam (train.py:161) applied to the reference's golden gradients."""
+    from voxelmorph_amd.optim import FlatAdam
+    g, cfg, tag = g_planar, PLANAR_CASES["dense"], "dense"
+    inshape = tuple(int(v) for v in g["inshape"])
+    model = vxm.networks.VxmDense(inshape, int_steps=cfg["int_steps"], int_downsize=cfg["int_downsize"])
+    model.load_state_dict(orc.seeded_state_dict(inshape, seed=7, flow_std=0.2), strict=False)
+    model = model.cuda()
+    opt = FlatAdam(model, lr=1e-3)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    src, trg = G(g["source"]), G(g["target"])
+    opt.zero_grad()
+    y, pre = model(src, trg)
+    loss = vxm.losses.MSE().loss(trg, y) + cfg["lam"] * vxm.losses.Grad("l2", loss_mult=2).loss(None, pre)
+    loss.backward()
+    opt.step()
+    assert float(opt.flat_grad.abs().sum()) > 0
+    for key in g.files:
+        if key.startswith(tag + "_grad_") and key not in (tag + "_grad_names", tag + "_grad_norms"):
+            name = key[len(tag + "_grad_"):]
+            gref = torch.from_numpy(g[key])
+            want, _, _ = orc.adam_step_explicit(before[name].cpu(), gref, torch.zeros_like(gref), torch.zeros_like(gref), 1, lr=1e-3)
+            got = dict(model.named_parameters())[name].detach().cpu()
+            assert not torch.equal(got, before[name].cpu()), name + " did not move"
+            # first Adam step = -lr * sign(g) where |g| >> eps: compare the update itself
+            assert rel_l2((got - before[name].cpu()).numpy(), (want - before[name].cpu()).numpy()) < 2e-3, name
+
+
+def test_flat_adam_accumulates_across_backward_calls(vxm):
+    """Two forward/backward passes before one step (gradient accumulation) on the fused 3-D engine: the first pass writes the
+    bucket directly, the second goes through autograd's p.grad; step() sees their sum."""
+    from voxelmorph_amd.optim import FlatAdam
+    inshape = (16, 32, 16)
+    rng = np.random.default_rng(5)
+    pairs = [(G(rng.random((1, 1) + inshape)), G(rng.random((1, 1) + inshape))) for _ in range(2)]
+    model = vxm.networks.VxmDense(inshape, int_steps=2)
+    model.load_state_dict(orc.seeded_state_dict(inshape, seed=2, flow_std=0.1), strict=False)
+    model = model.cuda()
+
+    def grads(batch, opt=None):
+        for a, b in batch:
+            y, pre = model(a, b)
+            (vxm.losses.MSE().loss(b, y) + 0.01 * vxm.losses.Grad("l2", loss_mult=2).loss(None, pre)).backward()
+
+    grads(pairs[:1])
+    g0 = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    model.zero_grad(set_to_none=True)
+    grads(pairs[1:])
+    g1 = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    model.zero_grad(set_to_none=True)
+    opt = FlatAdam(model, lr=1e-4)
+    opt.zero_grad()
+    grads(pairs)
+    opt.load_grads_from_params()
+    assert rel_l2(N(opt.flat_grad), N(g0 + g1)) < 1e-6
+    # an optimiser step between a forward and its backward is an error, not silently wrong gradients
+    opt.zero_grad()
+    y, pre = model(*pairs[0])
+    opt.step()
+    with pytest.raises(RuntimeError, match="modified in place"):
+        vxm.losses.MSE().loss(pairs[0][1], y).backward()
+
+
+def test_atlas_and_semisupervised_loaders(vxm, tmp_path):
+    """generators.py:110-143 / :146-194 tuple contracts on the device loaders (resident and streaming)."""
+    from voxelmorph_amd import data as vdata
+    rng = np.random.default_rng(2)
+    shape = (8, 12, 16)
+    vols = [rng.random(shape) for _ in range(4)]
+    segs = [rng.integers(0, 6, size=shape).astype(np.float64) for _ in range(4)]
+    atlas = rng.random(shape)
+    refv = np.stack(vols).astype(np.float32)
+    for resident_bytes in (1 << 30, 0):
+        ld = vdata.scan_to_atlas(vols, atlas[None, ..., None], batch_size=2, bidir=True, device="cuda", resident_bytes=resident_bytes)
+        (scan, atl), (o0, o1, z) = next(ld)
+        assert scan.shape == (2, 1) + shape and atl.shape == scan.shape and o0 is atl and o1 is scan
+        assert np.array_equal(N(atl)[1, 0], atlas.astype(np.float32)) and z.shape == (2, 3) + shape and float(z.abs().max()) == 0
+        assert all(any(np.array_equal(N(scan)[b, 0], refv[i]) for i in range(4)) for b in range(2))
+        ld = vdata.scan_to_atlas(vols, atlas, batch_size=2, segs=segs, no_warp=True, device="cuda", resident_bytes=resident_bytes)
+        (scan, atl), (seg,) = next(ld)
+        for b in range(2):          # the segmentation handed out belongs to the scan drawn
+            i = [k for k in range(4) if np.array_equal(N(scan)[b, 0], refv[k])][0]
+            assert np.array_equal(N(seg)[b, 0], segs[i].astype(np.float32))
+        labels = np.array([1, 3, 5])
+        ld = vdata.semisupervised(vols, segs, labels, device="cuda", resident_bytes=resident_bytes)
+        (sv, tv, ss), (tv2, z, ts) = next(ld)
+        assert sv.shape == (1, 1) + shape and ss.shape == (1, 3, 4, 6, 8) and ts.shape == ss.shape and tv2 is tv
+        i = [k for k in range(4) if np.array_equal(N(sv)[0, 0], refv[k])][0]
+        want = np.stack([(segs[i] == lab) for lab in labels])[:, ::2, ::2, ::2].astype(np.float32)      # split_seg, :161-165
+        assert np.array_equal(N(ss)[0], want)
+    np.savez(tmp_path / "atlas.npz", vol=atlas, seg=segs[0])
+    ld = vdata.semisupervised(vols, segs, labels, atlas_file=str(tmp_path / "atlas.npz"), device="cuda")
+    (sv, tv, ss), (tv2, z, ts) = next(ld)
+    assert np.array_equal(N(tv)[0, 0], atlas.astype(np.float32))
+    assert np.array_equal(N(ts)[0], np.stack([(segs[0] == lab) for lab in labels])[:, ::2, ::2, ::2].astype(np.float32))
+    mc = [rng.random(shape + (2,)) for _ in range(3)]                       # multichannel volumes [*vol, C] (train.py:101)
+    (a, b), _ = next(vdata.scan_to_scan(mc, batch_size=2, add_feat_axis=False, device="cuda"))
+    assert a.shape == (2, 2) + shape and any(np.array_equal(N(a)[0], np.moveaxis(m, -1, 0).astype(np.float32)) for m in mc)
+
+
+def test_train_cli_atlas_multichannel_and_semisupervised(vxm, tmp_path):
+    """scripts/train.py --atlas / --multichannel / --gpu / --cudnn-nondet (scripts/torch/train.py:56,59,63,72) and
+    scripts/train_semisupervised_seg.py (flags of scripts/tf/train_semisupervised_seg.py:41-79): a 2-epoch run each."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(4)
+    base = rng.random((32, 32, 32)).astype(np.float32)
+    names, stems = [], []
+    for i in range(3):
+        v = np.roll(base, shift=i, axis=1)
+        lab = (np.roll(base, shift=i, axis=1) * 4).astype(np.int32).astype(np.float32)
+        np.savez(tmp_path / ("s%d_img.npz" % i), vol=v)
+        np.savez(tmp_path / ("s%d_seg.npz" % i), vol=lab)
+        np.savez(tmp_path / ("m%d.npz" % i), vol=np.stack([v, 1 - v], -1))
+        names.append(str(tmp_path / ("s%d_img.npz" % i)))
+        stems.append(str(tmp_path / ("s%d" % i)))
+    np.savez(tmp_path / "atlas.npz", vol=base, seg=(base * 4).astype(np.int32).astype(np.float32))
+    np.save(tmp_path / "labels.npy", np.array([1, 2, 3]))
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    (tmp_path / "mlist.txt").write_text("\n".join(str(tmp_path / ("m%d.npz" % i)) for i in range(3)) + "\n")
+    (tmp_path / "stems.txt").write_text("\n".join(stems) + "\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(script, *argv):
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", script)] + list(argv) + ["--epochs", "2", "--steps-per-epoch", "3"],
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        losses = [float(ln.split("loss:")[1].split()[0]) for ln in r.stdout.splitlines() if "loss:" in ln]
+        assert len(losses) == 2 and all(np.isfinite(losses))
+        return r
+
+    run("train.py", "--img-list", str(tmp_path / "list.txt"), "--atlas", str(tmp_path / "atlas.npz"), "--model-dir", str(tmp_path / "ma"),
+        "--gpu", "0", "--cudnn-nondet", "--bidir", "--image-loss", "ncc", "--lambda", "1")
+    ck = torch.load(tmp_path / "ma" / "0002.pt", map_location="cpu")
+    assert ck["config"]["bidir"] is True
+    run("train.py", "--img-list", str(tmp_path / "mlist.txt"), "--multichannel", "--model-dir", str(tmp_path / "mm"))
+    ck = torch.load(tmp_path / "mm" / "0002.pt", map_location="cpu")
+    assert ck["config"]["src_feats"] == 2 and ck["model_state"]["unet_model.encoder.0.0.main.weight"].shape[1] == 4
+    for extra in ([], ["--atlas", str(tmp_path / "atlas.npz")]):
+        run("train_semisupervised_seg.py", "--img-list", str(tmp_path / "stems.txt"), "--img-suffix", "_img.npz", "--seg-suffix", "_seg.npz",
+            "--labels", str(tmp_path / "labels.npy"), "--model-dir", str(tmp_path / "ms"), "--image-loss", "ncc", *extra)
+    ck = torch.load(tmp_path / "ms" / "0002.pt", map_location="cpu")
+    assert ck["config"]["nb_labels"] == 3 and (tmp_path / "ms" / "0000.pt").exists()
 
 
 def test_native_comm_world_one(vxm):

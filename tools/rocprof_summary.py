@@ -53,6 +53,9 @@ def pmc(roots, out):
                 c[0] += 1
                 c[1] += float(r["Counter_Value"])
     res = collections.OrderedDict()
+    steps = os.environ.get("VXM_PROFILED_STEPS")
+    if steps:                  # bench steps + warm-up steps of the profiled command: bench.py checks dispatch counts against it
+        res["_meta"] = {"steps_profiled": int(steps)}
     for k, ctrs in agg.items():
         res[k] = {c: {"dispatches": v[0], "mean": v[1] / v[0]} for c, v in ctrs.items()}
     with open(out, "w") as f:

@@ -47,6 +47,7 @@ SIGNATURES = {
     "vxm_maxpool2_bwd": [_P, _L, _P, _P, _L, _P, _F, _I, _I, _I, _I, _I, _P],
     "vxm_upsample2_bwd": [_P, _L, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     "vxm_upsample2_cat": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
+    "vxm_ncc_fused": [_I, _I],
     "vxm_ncc_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vxm_ncc_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vxm_gradloss_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],

@@ -1,8 +1,8 @@
 """ctypes binding of libvxm_comm.so (include/vxm_comm.h): the gradient all-reduce of the data-parallel step as a direct
 RCCL call on the step's HIP stream, without torch.distributed on the data path.
 
-Opt-in (`VXM_COMM=rccl`, or `FlatAdam(..., comm=NativeComm.from_torch_dist())`): the default exchange stays
-`torch.distributed.all_reduce` on the 'nccl' backend, which is the same RCCL underneath.  torch.distributed (any
+This is the exchange of every multi-rank HIP job (`voxelmorph_amd.dist.native_comm()`; `VXM_COMM=torch` opts out to
+`torch.distributed.all_reduce` on the 'nccl' backend, which is the same RCCL underneath).  torch.distributed (any
 backend, gloo included) is only the rendezvous that carries rank 0's 128-byte unique id to the other ranks.
 """
 import ctypes
@@ -74,6 +74,29 @@ class NativeComm:
         box = [cls.new_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0, group=group)
         return cls(rank, world, box[0])
+
+    @classmethod
+    def try_from_torch_dist(cls, group=None):
+        """`from_torch_dist`, agreed on by all ranks: if the communicator cannot be created on ANY rank (e.g. two ranks on
+        one GPU, which RCCL refuses), every rank drops it and returns None, so that the job continues on
+        torch.distributed's RCCL instead of hanging in a half-initialised collective."""
+        import torch.distributed as dist
+        comm, err = None, ""
+        try:
+            comm = cls.from_torch_dist(group)
+        except (VxmHipError, OSError, AttributeError) as exc:
+            err = str(exc)
+        flags = [None] * dist.get_world_size(group)
+        dist.all_gather_object(flags, comm is not None, group=group)
+        if all(flags):
+            return comm
+        if comm is not None:
+            comm.destroy()
+        if dist.get_rank(group) == 0:
+            import sys
+            print("voxelmorph_amd: libvxm_comm.so communicator unavailable on %d of %d ranks (%s); gradient all-reduce through "
+                  "torch.distributed (same RCCL)" % (flags.count(False), len(flags), err or "see other ranks"), file=sys.stderr)
+        return None
 
     def _check(self, t):
         if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):

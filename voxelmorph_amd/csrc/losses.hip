@@ -468,6 +468,9 @@ void ncc_generic_bwd(const float* I, const float* J, const float* sums, const fl
 
 extern "C" {
 
+/* 1 when vxm_ncc_fwd / vxm_ncc_bwd take the fused march for (B, win): callers size `sums` / `work` from this */
+int vxm_ncc_fused(int B, int win) { return (win >= 3 && win <= 9 && B > 0 && B <= 65535) ? 1 : 0; }
+
 int vxm_ncc_fwd(const float* I, const float* J, float* loss, float* sums, float* work, double* acc, int B, int D, int H, int W, int win,
                 void* stream) {
     VXM_REQUIRE(I && J && loss && sums && work && acc, VXM_ERR_NULL_POINTER, "vxm_ncc_fwd: null pointer");
@@ -476,7 +479,7 @@ int vxm_ncc_fwd(const float* I, const float* J, float* loss, float* sums, float*
     const int r = win / 2;
     hipStream_t s = VXM_STREAM(stream);
     (void)hipMemsetAsync(acc, 0, sizeof(double), s);
-    if (win >= 3 && win <= 9 && B <= 65535) {          // fused march; `sums` receives the (a, b, c) planes for backward
+    if (vxm_ncc_fused(B, win)) {          // fused march; `sums` receives the (a, b, c) planes for backward
         const int seg = ncc_segment(B, D, H, W);
         const dim3 grid(((W + NF_TW - 1) / NF_TW) * ((H + NF_TH - 1) / NF_TH), (D + seg - 1) / seg, B);
         switch (r) {
@@ -499,7 +502,7 @@ int vxm_ncc_bwd(const float* I, const float* J, const float* sums, const float* 
     const long long V = (long long)D * H * W, BV = V * B;
     const int r = win / 2;
     hipStream_t s = VXM_STREAM(stream);
-    if (win >= 3 && win <= 9 && B <= 65535) {
+    if (vxm_ncc_fused(B, win)) {
         const int seg = ncc_segment(B, D, H, W);
         const dim3 grid(((W + NF_TW - 1) / NF_TW) * ((H + NF_TH - 1) / NF_TH), (D + seg - 1) / seg, B);
         switch (r) {

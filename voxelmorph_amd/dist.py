@@ -32,6 +32,28 @@ def init_from_env(backend=None):
     return rank, local, world
 
 
+def self_launch(nproc, script, argv, visible_devices=None):
+    """Replace this process by `python -m torch.distributed.run --nnodes=1 --nproc-per-node nproc ... script argv` (one rank per
+    GPU of this node, rendezvous on 127.0.0.1 and a free port) when it was started WITHOUT a torchrun environment but asked
+    for nproc > 1 ranks (`bench.py --gpus N`, `train.py --gpu 0,1,..`).  Returns normally when nothing has to be done."""
+    if nproc <= 1 or "RANK" in os.environ or "LOCAL_RANK" in os.environ:
+        return
+    import socket
+    import sys
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL across processes needs it on this driver
+    if visible_devices:
+        env["HIP_VISIBLE_DEVICES"] = visible_devices
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def shard_range(global_batch, rank, world):
     """[start, stop) of this rank's samples; the reference's divisibility assert (train.py:128-129)."""
     assert global_batch % world == 0, \
@@ -55,9 +77,14 @@ def barrier():
 
 
 def native_comm():
-    """`VXM_COMM=rccl`: a libvxm_comm.so communicator for the gradient all-reduce (None otherwise: torch.distributed's
-    'nccl' backend, the same RCCL, does it).  Needs an initialised process group for the rendezvous."""
-    if os.environ.get("VXM_COMM", "") != "rccl" or not (dist.is_available() and dist.is_initialized()):
+    """The gradient exchange of a multi-rank run: a `libvxm_comm.so` communicator (include/vxm_comm.h — RCCL behind the C ABI,
+    SURVEY.md §8b) whenever the job has more than one rank on HIP devices; torch.distributed is then only the rendezvous
+    for the 128-byte unique id.  `VXM_COMM=torch` keeps `torch.distributed.all_reduce` (the same RCCL through torch's 'nccl'
+    backend; also what the gloo CPU tests use); `VXM_COMM=rccl` forces the native communicator for a one-rank job too."""
+    mode = os.environ.get("VXM_COMM", "")
+    if mode == "torch" or not (dist.is_available() and dist.is_initialized()):
+        return None
+    if dist.get_backend() != "nccl" or (dist.get_world_size() == 1 and mode != "rccl"):
         return None
     from .comm import NativeComm
-    return NativeComm.from_torch_dist()
+    return NativeComm.try_from_torch_dist()

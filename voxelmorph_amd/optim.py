@@ -41,6 +41,7 @@ class FlatAdam:
             self._views.append(gview)
             # the fused U-Net backward writes parameter gradients straight into the bucket
             p._vxm_grad_sink = gview if direct_grads else None
+            p._vxm_sink_written = False
             off += n
         self.direct = direct_grads
 
@@ -56,12 +57,17 @@ class FlatAdam:
         self.flat_grad.zero_()
         for p in self.params:
             p.grad = None
+            p._vxm_sink_written = False
 
     def load_grads_from_params(self):
-        """Gather autograd-produced `p.grad` tensors into the flat bucket (non-direct mode / tests)."""
+        """Fold autograd-produced `p.grad` tensors into the flat bucket.  The fused 3-D engine (UnetFn.backward) writes its
+        parameter gradients straight into the bucket; every other producer — the per-op 2-D network (planar.conv2d ->
+        ConvFn), a standalone ConvBlock, any torch op on a parameter — hands them to autograd, which accumulates them in
+        `p.grad`.  Both contributions are summed here; `p.grad` is then released so a second call cannot add it twice."""
         for p, g in zip(self.params, self._views):
             if p.grad is not None and p.grad.data_ptr() != g.data_ptr():
-                g.copy_(p.grad)
+                g.add_(p.grad)
+                p.grad = None
 
     def reduce_grads(self):
         """The only data-path collective: SUM all-reduce of the flat gradient bucket (RCCL over xGMI when
@@ -72,11 +78,13 @@ class FlatAdam:
             torch.distributed.all_reduce(self.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
 
     def step(self):
-        if not self.direct:
-            self.load_grads_from_params()
+        self.load_grads_from_params()
         self.reduce_grads()
         require_device(self.flat_param)            # the update itself is a HIP kernel: no CPU fallback
         self.step_count += 1
         call("vxm_adam_step", ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
              float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count,
              1.0 / self.world, stream())
+        # the kernel wrote the parameters behind autograd's back: bump their version counters so that a backward pass over
+        # a graph recorded BEFORE this step fails loudly (UnetFn checks them) instead of using the new weights
+        torch.autograd.graph.increment_version(tuple(self.params))

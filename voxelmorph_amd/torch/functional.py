@@ -140,7 +140,7 @@ class NCCFn(torch.autograd.Function):
             raise ValueError("NCC: expected two [B,1,D,H,W] tensors (the reference's box filter has one "
                              "input channel, losses.py:29), got %s / %s" % (tuple(I.shape), tuple(J.shape)))
         loss = torch.empty((), dtype=I.dtype, device=I.device)
-        fused = 3 <= win <= 9          # vxm_ncc_fwd: windows up to 9 take the fused march and keep (a, b, c), 3 planes
+        fused = bool(_lib.lib().vxm_ncc_fused(B, win))    # the C side decides (window AND batch): fused march keeps (a, b, c), 3 planes
         sums = torch.empty((3 if fused else 5, B, D, H, W), dtype=I.dtype, device=I.device)
         work = torch.empty((1,) if fused else (5, B, D, H, W), dtype=I.dtype, device=I.device)
         acc = torch.empty(1, dtype=torch.float64, device=I.device)
@@ -306,6 +306,15 @@ def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W):
         ws = w if (lo, hi) == (0, cin) else w[:, lo:hi].contiguous()
         conv_launch(dz, cout, cout * V, False, None, 0, 0, pack_weights(ws, True), None, gx[:, lo:hi], cin * V, hi - lo, 1.0,
                     mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W)
+
+
+def _claim_sink(p):
+    """The optimiser's flat-bucket view of parameter p if it has not been written since the last zero_grad()."""
+    sink = getattr(p, "_vxm_grad_sink", None)
+    if sink is None or getattr(p, "_vxm_sink_written", False):
+        return None
+    p._vxm_sink_written = True
+    return sink
 
 
 class _Workspace:
@@ -518,12 +527,22 @@ class UnetFn(torch.autograd.Function):
         out = T.pop(plan.out)
         ctx.save_for_backward(out)
         ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B = plan, T, params, shape3, B
+        # activations and parameters are held as plain attributes (the returned tensor alone goes through
+        # save_for_backward, see above), so autograd's version-counter check is done by hand in backward
+        ctx.versions = [t._version for t in params] + [t._version for t in T.values()]
         return out
 
     @staticmethod
     def backward(ctx, gout):
         plan, params, shape3, B = ctx.plan, ctx.params, ctx.shape3, ctx.B
+        if ctx.T is None:
+            raise RuntimeError("UnetFn: backward a second time: the saved activations were released by the first pass "
+                               "(a retained graph is not supported by the fused engine)")
         T = dict(ctx.T)
+        if [t._version for t in params] + [t._version for t in T.values()] != ctx.versions:
+            raise RuntimeError("UnetFn: a parameter or a saved activation was modified in place between forward and "
+                               "backward (e.g. an optimizer step before loss.backward()); gradients would be wrong")
+        ctx.T = None                # released with this pass, not when the graph node dies
         T[plan.out] = ctx.saved_tensors[0]
         dev, dt = gout.device, gout.dtype
         gout = _c(gout)
@@ -531,7 +550,6 @@ class UnetFn(torch.autograd.Function):
         ws_side = _Workspace(dev)
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if OVERLAP_SMALL_LEVELS else None
-        used_side = False
         n_in = plan.n_inputs
         grads = [None] * (n_in + len(params))
         DZ = {}      # tensor id -> gradient w.r.t. the pre-activation of its producing conv
@@ -558,119 +576,128 @@ class UnetFn(torch.autograd.Function):
         else:
             GCAT = gout
 
-        for n in range(len(plan.ops) - 1, -1, -1):
-            op = plan.ops[n]
-            dst = op["dst"]
-            D, H, W = _dims(shape3, plan.lvl[dst])
-            V = D * H * W
-            if op["kind"] == "cat":
-                s0, _, s1 = op["src"]
+        try:
+            for n in range(len(plan.ops) - 1, -1, -1):
+                op = plan.ops[n]
+                dst = op["dst"]
+                D, H, W = _dims(shape3, plan.lvl[dst])
+                V = D * H * W
+                if op["kind"] == "cat":
+                    s0, _, s1 = op["src"]
+                    c0 = plan.ch[s0]
+                    GC[s0] = (GCAT, GCAT[0].numel())
+                    GS[s1] = (GCAT, c0 * V, GCAT[0].numel())
+                    _resolve_decoder(plan, T, DZ, GC, s0, B, shape3, dt, dev)
+                    continue
+                if op["kind"] == "pool":
+                    src = op["src"]
+                    sD, sH, sW = _dims(shape3, plan.lvl[src])
+                    C = plan.ch[src]
+                    dz = torch.empty((B, C, sD, sH, sW), dtype=dt, device=dev)
+                    gs = GS.get(src)
+                    prod = plan.ops[plan.producer[src]] if src in plan.producer else None
+                    slope = prod["slope"] if prod is not None and prod["kind"] == "conv" else 1.0
+                    gskip = None
+                    gs_bs = 0
+                    if gs is not None:
+                        gskip = gs[0].view(-1)[gs[1]:]
+                        gs_bs = gs[2]
+                    call("vxm_maxpool2_bwd", ptr(T[src]), T[src][0].numel(), ptr(GP[dst]), ptr(gskip), gs_bs, ptr(dz),
+                         float(slope), B, C, sD, sH, sW, stream())
+                    DZ[src] = dz
+                    continue
+                # ---- conv
+                s0, up0, s1 = op["src"]
+                w, b = params[2 * op["k"]], params[2 * op["k"] + 1]
+                cout = plan.ch[dst]
                 c0 = plan.ch[s0]
-                GC[s0] = (GCAT, GCAT[0].numel())
-                GS[s1] = (GCAT, c0 * V, GCAT[0].numel())
-                _resolve_decoder(plan, T, DZ, GC, s0, B, shape3, dt, dev)
-                continue
-            if op["kind"] == "pool":
-                src = op["src"]
-                sD, sH, sW = _dims(shape3, plan.lvl[src])
-                C = plan.ch[src]
-                dz = torch.empty((B, C, sD, sH, sW), dtype=dt, device=dev)
-                gs = GS.get(src)
-                prod = plan.ops[plan.producer[src]] if src in plan.producer else None
-                slope = prod["slope"] if prod is not None and prod["kind"] == "conv" else 1.0
-                gskip = None
-                gs_bs = 0
-                if gs is not None:
-                    gskip = gs[0].view(-1)[gs[1]:]
-                    gs_bs = gs[2]
-                call("vxm_maxpool2_bwd", ptr(T[src]), T[src][0].numel(), ptr(GP[dst]), ptr(gskip), gs_bs, ptr(dz),
-                     float(slope), B, C, sD, sH, sW, stream())
-                DZ[src] = dz
-                continue
-            # ---- conv
-            s0, up0, s1 = op["src"]
-            w, b = params[2 * op["k"]], params[2 * op["k"] + 1]
-            cout = plan.ch[dst]
-            c0 = plan.ch[s0]
-            c1 = plan.ch[s1] if s1 is not None else 0
-            cin = c0 + c1
-            dz = DZ.pop(dst)
-            x0, x1 = T[s0], (T[s1] if s1 is not None else None)
-            # parameter gradients go straight into the optimiser's flat bucket when one is attached
-            # (voxelmorph_amd.optim.FlatAdam): no per-tensor accumulate / copy launches
-            gw_sink, gb_sink = getattr(w, "_vxm_grad_sink", None), getattr(b, "_vxm_grad_sink", None)
-            gw = gw_sink if gw_sink is not None else torch.empty_like(w)
-            gb = gb_sink if gb_sink is not None else torch.empty_like(b)
-            if side is not None and plan.lvl[dst] >= 1:
-                # Below full resolution neither product fills the chip (a few hundred tiles on 256 CUs): the weight gradient
-                # of this block runs on a second stream beside the backward-data chain it does not feed.
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-                with torch.cuda.stream(side):
-                    conv_bwd_weight(ws_side, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
+                c1 = plan.ch[s1] if s1 is not None else 0
+                cin = c0 + c1
+                dz = DZ.pop(dst)
+                x0, x1 = T[s0], (T[s1] if s1 is not None else None)
+                # parameter gradients go straight into the optimiser's flat bucket when one is attached
+                # (voxelmorph_amd.optim.FlatAdam): no per-tensor accumulate / copy launches
+                # The kernel OVERWRITES its destination: only the first gradient of a parameter since zero_grad() may land in
+                # the bucket; later ones (a second backward / a model called twice before one backward) go through autograd's
+                # accumulation into p.grad, which FlatAdam.step() folds into the bucket.
+                gw_sink, gb_sink = _claim_sink(w), _claim_sink(b)
+                gw = gw_sink if gw_sink is not None else torch.empty_like(w)
+                gb = gb_sink if gb_sink is not None else torch.empty_like(b)
+                if side is not None and plan.lvl[dst] >= 1:
+                    # Below full resolution neither product fills the chip (a few hundred tiles on 256 CUs): the weight gradient
+                    # of this block runs on a second stream beside the backward-data chain it does not feed.
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        conv_bwd_weight(ws_side, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
+                                        gw, gb, B, D, H, W)
+                    dz.record_stream(side)          # dz is released by the main-stream chain before the side stream may be done
+                    for g, sink in ((gw, gw_sink), (gb, gb_sink)):
+                        if sink is None:            # allocated on the main stream, written on the side stream
+                            g.record_stream(side)
+                else:
+                    conv_bwd_weight(ws, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
                                     gw, gb, B, D, H, W)
-                dz.record_stream(side)          # dz is released by the main-stream chain before the side stream may be done
-                used_side = True
-            else:
-                conv_bwd_weight(ws, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
-                                gw, gb, B, D, H, W)
-            grads[n_in + 2 * op["k"]] = None if gw_sink is not None else gw
-            grads[n_in + 2 * op["k"] + 1] = None if gb_sink is not None else gb
-            feeds_inputs = s0 < n_in
-            if feeds_inputs and not any(ctx.needs_input_grad[1 + i] for i in range(n_in)):
-                continue
-            fuse = (not up0) and s1 is None and (not feeds_inputs) and len(plan.consumers[s0]) == 1 \
-                and plan.ops[plan.producer[s0]]["kind"] == "conv"
-            if up0 and plan.ops[plan.producer[s0]]["kind"] == "conv" and len(plan.consumers[s0]) == 1 and \
-                    _lib.lib().vxm_conv3d_k3_up_bwd_low_ok(ptr(dz), cout * V, c0, cout, B, D, H, W):
-                # upsampled segment: straight to the half-resolution gradient of the decoder block (stride-2 4x4x4 conv =
-                # conv backward + upsample_nearest3d_backward + leaky_relu_backward in one kernel, conv_fwd.hip: k_conv3d_k3_dlow)
-                pslope = plan.ops[plan.producer[s0]]["slope"]
-                lD, lH, lW = D // 2, H // 2, W // 2
-                dzl = torch.empty((B, c0, lD, lH, lW), dtype=dt, device=dev)
-                wpk = torch.empty(_lib.lib().vxm_conv3d_k3_up_bwd_low_packed_elems(c0, cout), dtype=dt, device=dev)
-                with _prof.region("k_conv3d_k3_dlow<%d>" % (1 if c0 <= 16 else 2), flops=2.0 * 8 * c0 * cout * B * V,
-                                  nominal=2.0 * 27 * c0 * cout * B * V):
-                    call("vxm_conv3d_k3_up_bwd_low", ptr(dz), cout * V, cout, ptr(_c(w)), c0, cin, ptr(wpk), ptr(dzl), c0 * lD * lH * lW,
-                         ptr(T[s0]) if pslope != 1.0 else None, c0 * lD * lH * lW, float(pslope), B, D, H, W, stream())
-                DZ[s0] = dzl
-                if s1 is not None:                       # skip segment: regular backward-data of its channels only
-                    gxs = torch.empty((B, c1, D, H, W), dtype=dt, device=dev)
-                    conv_bwd_data(dz, cout, w[:, c0:].contiguous(), gxs, c1, None, 1.0, B, D, H, W)
-                    GS[s1] = (gxs, 0, c1 * V)
+                grads[n_in + 2 * op["k"]] = None if gw_sink is not None else gw
+                grads[n_in + 2 * op["k"] + 1] = None if gb_sink is not None else gb
+                feeds_inputs = s0 < n_in
+                if feeds_inputs and not any(ctx.needs_input_grad[1 + i] for i in range(n_in)):
+                    continue
+                fuse = (not up0) and s1 is None and (not feeds_inputs) and len(plan.consumers[s0]) == 1 \
+                    and plan.ops[plan.producer[s0]]["kind"] == "conv"
+                if up0 and plan.ops[plan.producer[s0]]["kind"] == "conv" and len(plan.consumers[s0]) == 1 and \
+                        _lib.lib().vxm_conv3d_k3_up_bwd_low_ok(ptr(dz), cout * V, c0, cout, B, D, H, W):
+                    # upsampled segment: straight to the half-resolution gradient of the decoder block (stride-2 4x4x4 conv =
+                    # conv backward + upsample_nearest3d_backward + leaky_relu_backward in one kernel, conv_fwd.hip: k_conv3d_k3_dlow)
+                    pslope = plan.ops[plan.producer[s0]]["slope"]
+                    lD, lH, lW = D // 2, H // 2, W // 2
+                    dzl = torch.empty((B, c0, lD, lH, lW), dtype=dt, device=dev)
+                    wpk = torch.empty(_lib.lib().vxm_conv3d_k3_up_bwd_low_packed_elems(c0, cout), dtype=dt, device=dev)
+                    with _prof.region("k_conv3d_k3_dlow<%d>" % (1 if c0 <= 16 else 2), flops=2.0 * 8 * c0 * cout * B * V,
+                                      nominal=2.0 * 27 * c0 * cout * B * V):
+                        call("vxm_conv3d_k3_up_bwd_low", ptr(dz), cout * V, cout, ptr(_c(w)), c0, cin, ptr(wpk), ptr(dzl), c0 * lD * lH * lW,
+                             ptr(T[s0]) if pslope != 1.0 else None, c0 * lD * lH * lW, float(pslope), B, D, H, W, stream())
+                    DZ[s0] = dzl
+                    if s1 is not None:                       # skip segment: regular backward-data of its channels only
+                        gxs = torch.empty((B, c1, D, H, W), dtype=dt, device=dev)
+                        conv_bwd_data(dz, cout, w[:, c0:].contiguous(), gxs, c1, None, 1.0, B, D, H, W)
+                        GS[s1] = (gxs, 0, c1 * V)
+                        if not any(plan.ops[m]["kind"] == "pool" for m in plan.consumers[s1]):
+                            g = GS.pop(s1)
+                            finish_conv_output(s1, g[0].view(-1)[g[1]:], g[2])
+                    continue
+                gx = torch.empty((B, cin, D, H, W), dtype=dt, device=dev)
+                if fuse:   # dX * LeakyReLU'(y_prev) in the epilogue == DZ of the previous ConvBlock
+                    pslope = plan.ops[plan.producer[s0]]["slope"]
+                    conv_bwd_data(dz, cout, w, gx, cin, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W)
+                    DZ[s0] = gx
+                    continue
+                conv_bwd_data(dz, cout, w, gx, cin, None, 1.0, B, D, H, W)
+                if feeds_inputs:
+                    for i, sid in enumerate([s0] + ([s1] if s1 is not None else [])):
+                        lo = 0 if i == 0 else c0
+                        grads[sid] = gx[:, lo:lo + plan.ch[sid]]
+                    continue
+                if up0:
+                    GC[s0] = (gx, cin * V)
+                    _resolve_decoder(plan, T, DZ, GC, s0, B, shape3, dt, dev)
+                else:
+                    prod = plan.ops[plan.producer[s0]]
+                    if prod["kind"] == "pool":
+                        GP[s0] = gx if s1 is None else gx[:, :c0].contiguous()
+                    else:      # conv output with several consumers (not produced by the reference topologies)
+                        finish_conv_output(s0, gx, cin * V)
+                if s1 is not None:
+                    GS[s1] = (gx, c0 * V, cin * V)
                     if not any(plan.ops[m]["kind"] == "pool" for m in plan.consumers[s1]):
                         g = GS.pop(s1)
                         finish_conv_output(s1, g[0].view(-1)[g[1]:], g[2])
-                continue
-            gx = torch.empty((B, cin, D, H, W), dtype=dt, device=dev)
-            if fuse:   # dX * LeakyReLU'(y_prev) in the epilogue == DZ of the previous ConvBlock
-                pslope = plan.ops[plan.producer[s0]]["slope"]
-                conv_bwd_data(dz, cout, w, gx, cin, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W)
-                DZ[s0] = gx
-                continue
-            conv_bwd_data(dz, cout, w, gx, cin, None, 1.0, B, D, H, W)
-            if feeds_inputs:
-                for i, sid in enumerate([s0] + ([s1] if s1 is not None else [])):
-                    lo = 0 if i == 0 else c0
-                    grads[sid] = gx[:, lo:lo + plan.ch[sid]]
-                continue
-            if up0:
-                GC[s0] = (gx, cin * V)
-                _resolve_decoder(plan, T, DZ, GC, s0, B, shape3, dt, dev)
-            else:
-                prod = plan.ops[plan.producer[s0]]
-                if prod["kind"] == "pool":
-                    GP[s0] = gx if s1 is None else gx[:, :c0].contiguous()
-                else:      # conv output with several consumers (not produced by the reference topologies)
-                    finish_conv_output(s0, gx, cin * V)
-            if s1 is not None:
-                GS[s1] = (gx, c0 * V, cin * V)
-                if not any(plan.ops[m]["kind"] == "pool" for m in plan.consumers[s1]):
-                    g = GS.pop(s1)
-                    finish_conv_output(s1, g[0].view(-1)[g[1]:], g[2])
-        if used_side:
-            main.wait_stream(side)              # gradients (and the activations the side stream read) are final past this point
+        finally:
+            # also on an exception half-way: later main-stream work (zero_grad, Adam on the bucket) must not race with
+            # side-stream launches that are still writing parameter gradients
+            if side is not None:
+                main.wait_stream(side)          # gradients (and the activations the side stream read) are final past this point
         return (None,) + tuple(grads)
 
 
