@@ -292,3 +292,16 @@ def test_data_parallel_equivalence_gloo_world2(tmp_path):
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def test_bench_gpus_n_self_launches_one_rank_per_gpu():
+    """`python bench.py --gpus 2` with no torchrun environment (how the scaling driver invokes it) re-launches itself under
+    torch.distributed.run with two ranks on a 127.0.0.1 rendezvous; on this GPU-less host both ranks get past the process-group
+    initialisation (gloo) and the world-size check, then stop at the explicit no-fallback message."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert out.stderr.count("bench.py needs an MI355X") == 2, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "WORLD_SIZE" not in out.stderr.split("bench.py needs an MI355X")[0][-300:]
