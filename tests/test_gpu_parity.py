@@ -693,7 +693,11 @@ def _full_size_step_vs_oracle(vxm, src, trg, seed, flow_std):
     worst = max(gerr, key=gerr.get)
     print("full-size step: loss hip=%.7f oracle=%.7f | max|dy|=%.2e max|dpreint|=%.2e | worst grad rel-L2 %.2e (%s)"
           % (float(loss), float(ref), err_y, err_p, gerr[worst], worst))
-    assert err_y <= 2e-5 and err_p <= 2e-5, (err_y, err_p)
+    # preint_flow is a conv output (<= 2e-5 abs).  y_source is an image sampled at (voxel + integrated flow): the stated
+    # tolerance of the integrated flows is 1e-4 abs (fp32 scaling and squaring drifts 3.9e-5 against fp64 after 7
+    # steps) and a U[0,1) noise image changes by O(1) per voxel, so the moved image inherits that bound, not the 1e-5 of a
+    # single warp on identical flows.
+    assert err_p <= 2e-5 and err_y <= 1e-4, (err_y, err_p)
     assert abs(float(loss) - float(ref)) <= 1e-3
     assert len(gerr) == 24
     for name, e in gerr.items():

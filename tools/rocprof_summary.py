@@ -58,6 +58,11 @@ def pmc(roots, out):
         res["_meta"] = {"steps_profiled": int(steps)}
     for k, ctrs in agg.items():
         res[k] = {c: {"dispatches": v[0], "mean": v[1] / v[0]} for c, v in ctrs.items()}
+    for k, v in res.items():
+        # MFMA-pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs (= 32 cycles x SQ_INSTS_MFMA for
+        # v_mfma_f32_16x16x4_f32), GRBM_GUI_ACTIVE over the 8 XCDs (checked against kernel duration x 2.4 GHz)
+        if k != "_meta" and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"]["mean"] > 0:
+            v["mfma_util"] = v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0 / (v["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print("wrote", out, len(res), "kernels")
