@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 MFMA dense peak (never the 2:1-sparsity headline)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -34,14 +35,17 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=1)
     ap.add_argument("--shape", type=str, default="160,192,224")
-    ap.add_argument("--int-steps", type=int, default=7)
+    ap.add_argument("--int-steps", type=int, default=None)
+    ap.add_argument("--config", choices=["diffeo_fp32", "dense_bf16"], default="diffeo_fp32",
+                    help="diffeo_fp32 = BASELINE.json configs[2], the headline metric (default); dense_bf16 = configs[1]: int_steps=0, "
+                         "MSE + 0.01 Grad, bf16 activations / fp32 accumulate under torch.autocast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=2)               # timed CPU steps after one warm-up, at the FULL shape
     ap.add_argument("--cpu-threads", type=int, default=0)                      # 0: min(32, cores), see cpu_baseline()
     return ap.parse_args()
 
 
-def cpu_baseline(shape, int_steps, timed_steps, threads):
+def cpu_baseline(shape, int_steps, timed_steps, threads, image_loss="ncc", lam=1.0):
     """The reference's torch path timed on this host's cores at the benchmark shape itself (SURVEY.md §8d / BASELINE.md §4):
     B = 1, fp32, NCC(9^3) + Grad('l2', x2), Adam lr 1e-4, one warm-up + `timed_steps` timed training steps.
 
@@ -66,13 +70,13 @@ def cpu_baseline(shape, int_steps, timed_steps, threads):
         model = ref.networks.VxmDense(shape, int_steps=int_steps, int_downsize=2)
         model.train()
         opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-        ncc = ref.losses.NCC().loss
+        ncc = ref.losses.NCC().loss if image_loss == "ncc" else ref.losses.MSE().loss
         reg = ref.losses.Grad("l2", loss_mult=2).loss
 
         def step():
             with ref_loader.cuda_alias_to_cpu():
                 y, pre = model(src, trg)
-                loss = ncc(trg, y) + 1.0 * reg(None, pre)
+                loss = ncc(trg, y) + lam * reg(None, pre)
             opt.zero_grad()
             loss.backward()
             opt.step()
@@ -84,7 +88,7 @@ def cpu_baseline(shape, int_steps, timed_steps, threads):
 
         def step():
             opt.zero_grad()
-            loss, _ = orc.train_step_loss(src, trg, sd, "ncc", 1.0, int_steps=int_steps, int_downsize=2)
+            loss, _ = orc.train_step_loss(src, trg, sd, image_loss, lam, int_steps=int_steps, int_downsize=2)
             loss.backward()
             opt.step()
 
@@ -97,14 +101,14 @@ def cpu_baseline(shape, int_steps, timed_steps, threads):
     dt = sum(times) / len(times)
     return {
         "value": 1.0 / dt, "unit": "volume-pairs/s", "cores": cores, "kind": kind, "s_per_step": dt,
-        "sample": "1 warm-up + %d timed training step(s) (fwd+NCC+Grad+bwd+Adam) at the full %s shape, B=1, fp32, %d torch "
-                  "threads of %d host cores: %s s/step" % (len(times), "x".join(map(str, shape)), cores, os.cpu_count() or 0,
-                                                           ", ".join("%.2f" % t for t in times)),
+        "sample": "1 warm-up + %d timed training step(s) (fwd+%s+Grad+bwd+Adam, int_steps=%d) at the full %s shape, B=1, fp32, %d torch "
+                  "threads of %d host cores: %s s/step" % (len(times), image_loss.upper(), int_steps, "x".join(map(str, shape)), cores,
+                                                           os.cpu_count() or 0, ", ".join("%.2f" % t for t in times)),
         "cpu_model": _cpu_model(),
     }
 
 
-def hbm_traffic(kernel, launches_per_step):
+def hbm_traffic(kernel, launches_per_step, suffix=""):
     """HBM bytes per launch of the region `kernel` from the committed rocprofv3 PMC summary of this same command
     (profiles/*_hbm_counters.json, written by tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes,
     kernel-trace only).  Units and gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes: both
@@ -114,17 +118,18 @@ def hbm_traffic(kernel, launches_per_step):
     describe this run: no instance of the kernel in it, or a dispatch count that is not launches_per_step x the profiled
     steps recorded in its "_meta" entry.  Returns (bytes_per_launch or None, note)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_counters.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_counters%s.json" % suffix)))
     if not files:
-        return None, "no profiles/*_hbm_counters.json"
+        return None, "no profiles/*_hbm_counters%s.json" % suffix
     rel = os.path.relpath(files[-1], ROOT)
     try:
         with open(files[-1]) as f:
             ctr = json.load(f)
     except (OSError, ValueError):
         return None, "%s unreadable" % rel
-    stem = kernel[:-1] if kernel.endswith(">") else kernel
-    hits = {k: v for k, v in ctr.items() if k == kernel or k.startswith(stem + ",") or k.startswith(stem + ">")}
+    kernel_ns = kernel.replace(" ", "")
+    stem = kernel_ns[:-1] if kernel_ns.endswith(">") else kernel_ns
+    hits = {k: v for k, v in ctr.items() if k.replace(" ", "") == kernel_ns or k.replace(" ", "").startswith(stem + ",")}
     hits = {k: v for k, v in hits.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
     if not hits:
         return None, "%s has no counters for %s: stale profile, re-run tools/profile_bench.sh" % (rel, kernel)
@@ -170,6 +175,10 @@ def main():
     dev = torch.device("cuda", local)
     shape = tuple(int(s) for s in args.shape.split(","))
     B = args.batch_per_gpu
+    bf16 = args.config == "dense_bf16"
+    if args.int_steps is None:
+        args.int_steps = 0 if bf16 else 7
+    lam = 0.01 if bf16 else 1.0                               # README.md:70: lambda 0.01 with MSE, 1 with NCC
     torch.manual_seed(1234)                                   # identical initial weights on every rank
     model = vxm.networks.VxmDense(shape, int_steps=args.int_steps, int_downsize=2).to(dev)
     opt = FlatAdam(model, lr=1e-4, comm=vdist.native_comm())      # VXM_COMM=rccl: direct libvxm_comm.so all-reduce
@@ -177,13 +186,14 @@ def main():
     torch.manual_seed(1234 + rank)                            # each rank synthesises its own volume pairs in HBM
     src = torch.rand(B, 1, *shape, device=dev)
     trg = torch.rand(B, 1, *shape, device=dev)
-    ncc = vxm.losses.NCC().loss
+    ncc = vxm.losses.MSE().loss if bf16 else vxm.losses.NCC().loss
     reg = vxm.losses.Grad("l2", loss_mult=2).loss
 
     def step():
         opt.zero_grad()
-        y, pre = model(src, trg)
-        loss = ncc(trg, y) + 1.0 * reg(None, pre)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):      # bf16: blocked-bf16 activations between the convs
+            y, pre = model(src, trg)
+            loss = ncc(trg, y) + lam * reg(None, pre)
         loss.backward()
         opt.step()                                            # all-reduce (world>1) + fused Adam
         return loss
@@ -226,28 +236,37 @@ def main():
     dom = max(stats, key=lambda k: stats[k]["ms"])
     ds = stats[dom]
     if ds["flops"]:
-        ach = ds["flops"] / (ds["ms"] * 1e-3) / 1e12
-        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                "algorithmic_per_launch": ds["flops"] / ds["launches"], "avg_launch_ms": ds["ms"] / ds["launches"]}
+        # fp32 kernels: FLOPs executed (= the reference formulation's, except the collapsed-upsample kernels, which execute fewer);
+        # bf16 kernels: the reference formulation's FLOPs (they EXECUTE more: zero-padded channels and K slots are not work)
+        is_bf = dom.startswith("k_bf16")
+        alg = ds["nominal"] if is_bf else ds["flops"]
+        peak = BF16_MFMA_PEAK_TFLOPS if is_bf else FP32_MFMA_PEAK_TFLOPS
+        ach = alg / (ds["ms"] * 1e-3) / 1e12
+        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": ach / peak, "traffic": None,
+                "algorithmic_per_launch": alg / ds["launches"], "avg_launch_ms": ds["ms"] / ds["launches"]}
     else:
         ach = ds["bytes"] / (ds["ms"] * 1e-3) / 1e9
         roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_per_launch": ds["bytes"] / ds["launches"], "avg_launch_ms": ds["ms"] / ds["launches"]}
-    roof["traffic"], roof["traffic_unit"] = hbm_traffic(dom, ds["launches"] / args.steps)
+    roof["traffic"], roof["traffic_unit"] = hbm_traffic(dom, ds["launches"] / args.steps, "_bf16" if bf16 else "")
     out = {
-        "metric": "volume-pairs/sec VxmDense 160x192x224 int_steps=7 NCC train",
+        "metric": "volume-pairs/sec VxmDense 160x192x224 int_steps=0 MSE train (bf16 activations)" if bf16
+                  else "volume-pairs/sec VxmDense 160x192x224 int_steps=7 NCC train",
         "value": world * B * args.steps / elapsed, "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "VxmDense 3D %s, int_steps=%d diffeomorphic (int_downsize=2), NCC(9^3)+Grad(l2,x2), fp32, Adam "
-                               "lr 1e-4, %d pair(s)/GPU (BASELINE.json configs[2])" % ("x".join(map(str, shape)), args.int_steps, B),
+        "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+        "config": {"workload": ("VxmDense 3D %s, int_steps=%d (CVPR dense), MSE + 0.01 Grad(l2,x2), bf16 activations / fp32 accumulate, "
+                                "fp32 master weights, Adam lr 1e-4, %d pair(s)/GPU (BASELINE.json configs[1])" if bf16 else
+                                "VxmDense 3D %s, int_steps=%d diffeomorphic (int_downsize=2), NCC(9^3)+Grad(l2,x2), fp32, Adam "
+                                "lr 1e-4, %d pair(s)/GPU (BASELINE.json configs[2])") % ("x".join(map(str, shape)), args.int_steps, B),
                    "global_batch": world * B, "parallelism": "dp%d" % world},
         "roofline": roof, "kernels": kernels, "final_loss": final_loss,
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(shape, args.int_steps, args.cpu_baseline_steps, args.cpu_threads)
+        out["cpu_baseline"] = cpu_baseline(shape, args.int_steps, args.cpu_baseline_steps, args.cpu_threads,
+                                           "mse" if bf16 else "ncc", lam)
     print(json.dumps(out))
 
 

@@ -218,6 +218,44 @@ int vxm_gradloss2d_bwd(const float* y, const float* gloss, float* gy, int B, int
 int vxm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float gscale, void* stream);
 
+/* ---- bf16 activations / fp32 accumulate path of the U-Net (BASELINE.json configs[1]); csrc/conv_bf16.hip.
+ * What torch.autocast(bfloat16) over ConvBlock / flow conv / MaxPool3d / Upsample + cat (networks.py:83-85,130,137-138,211,257,
+ * 290-305) would dispatch to MIOpen.  Activations and their gradients are CHANNEL-BLOCKED bf16 tensors
+ * [B][C/8][D][H][W][8] (contiguous, C a multiple of 16, 16-byte aligned; passed as void*); weights, biases and parameter
+ * gradients stay fp32 in the reference layout [Cout][Cin][3][3][3]. */
+/* planar fp32 [B][C0 (+C1)][V] -> blocked bf16 with Cblk >= C0 + C1 channels (the rest zero); and back (first C channels). */
+int vxm_bf16_to_blocked(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, void* out,
+                        int Cblk, int B, int64_t V, void* stream);
+int vxm_bf16_from_blocked(const void* x, int Cblk, float* out, int C, int B, int64_t V, void* stream);
+/* weights of an operator with InC inputs / OutC outputs in MFMA fragment order, rounded to bf16.  Forward: inputs = the
+ * input-channel range [ci_lo, ci_lo + ci_n) of w, outputs = Cw_out.  transpose_flip: the adjoint onto that range
+ * (backward-data): inputs = Cw_out, outputs = ci_n. */
+size_t vxm_bf16_conv_packed_bytes(int InC, int OutC);
+int vxm_bf16_conv_pack_weights(const float* w, int Cw_in, int Cw_out, int ci_lo, int ci_n, int transpose_flip, void* wpacked,
+                               void* stream);
+/* conv3d(k3,p1) over the virtual concat [x0 (optionally nearest-x2 upsampled) | x1] + bias + LeakyReLU(leaky_slope).
+ * out_planar_f32 = 0: y blocked bf16 with Cout (multiple of 16) channels, optionally multiplied by LeakyReLU'(mask)
+ * (mask: blocked, Cout channels; the fused leaky_relu_backward of backward-data).  out_planar_f32 = 1: y fp32
+ * [B][Cout <= 4][D][H][W] (the flow head).  Backward-data = this entry point with transpose_flip-packed weights. */
+int vxm_bf16_conv_fwd(const void* x0, int C0, int x0_up, const void* x1, int C1, const void* wpacked, const float* bias, void* y,
+                      int Cout, int out_planar_f32, float leaky_slope, const void* mask, float mask_slope,
+                      int B, int D, int H, int W, void* stream);
+/* gw[Cout_w][Cin_w][27], gb[Cout_w] (nullable) fp32 from the blocked input (virtual concat, C0 + C1 >= Cin_w channels) and the
+ * blocked gradient dz (Cdz = 16 or 32 >= Cout_w channels).  Deterministic (fixed-order partial sums in `work`). */
+size_t vxm_bf16_conv_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D, int H, int W);
+int vxm_bf16_conv_bwd_weight(const void* x0, int C0, int x0_up, const void* x1, int C1, const void* dz, int Cdz, float* gw,
+                             int Cin_w, int Cout_w, float* gb, void* work, size_t work_bytes, int B, int D, int H, int W,
+                             void* stream);
+/* MaxPool3d(2) forward; its backward fused with the skip-branch gradient (nullable) and LeakyReLU'(x); Upsample(2) backward
+ * fused with LeakyReLU'(y) (y nullable); plain leaky_relu_backward.  All on blocked tensors; D, H, W = input (full) extents,
+ * Dl.. = low-resolution extents. */
+int vxm_bf16_maxpool2_fwd(const void* x, void* y, int B, int C, int D, int H, int W, void* stream);
+int vxm_bf16_maxpool2_bwd(const void* x, const void* gpool, const void* gskip, void* dz, float slope, int B, int C,
+                          int D, int H, int W, void* stream);
+int vxm_bf16_upsample2_bwd(const void* g, const void* y, void* dz, float slope, int B, int C, int Dl, int Hl, int Wl,
+                           void* stream);
+int vxm_bf16_lrelu_bwd(const void* g, const void* y, void* dz, float slope, int64_t n_elems, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -177,8 +177,61 @@ def unet_plan(nb_features=None, nb_levels=None, feat_mult=1, nb_conv_per_level=1
     return enc_nf, dec_nf[:n_dec], dec_nf[n_dec:], int(n_dec / nb_conv_per_level) + 1
 
 
+# ---- emulation of bf16 activations / fp32 accumulate (BASELINE.json configs[1]).  Not reference code: the reference has no
+# reduced-precision path; this restates what `torch.autocast(bfloat16)` over networks.py:290-305 means arithmetically
+# (operands rounded to bf16, products accumulated in fp32 or better, results rounded once) so that the HIP bf16 engine
+# can be checked at its own rounding points instead of only against the fp32 result.
+_BF16 = [False]
+
+
+class bf16_activations:
+    """Context: conv_block / the flow conv round their input, weights and output activation to bf16 (forward) and the
+    gradients w.r.t. their pre-activation and their input to bf16 (backward); biases, accumulation and parameter gradients
+    keep the dtype of the surrounding computation."""
+
+    def __enter__(self):
+        self.prev = _BF16[0]
+        _BF16[0] = True
+
+    def __exit__(self, *exc):
+        _BF16[0] = self.prev
+
+
+def _rbf(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _RoundFwd(torch.autograd.Function):            # round forward, straight-through backward
+    @staticmethod
+    def forward(ctx, x):
+        return _rbf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):            # identity forward, the gradient is rounded
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rbf(g)
+
+
+def conv_bf16(x, w, b, slope=0.2, round_out=True):
+    conv = getattr(F, "conv%dd" % (x.dim() - 2))
+    z = conv(_RoundFwd.apply(_RoundBwd.apply(x)), _RoundFwd.apply(w), b, stride=1, padding=1)
+    a = F.leaky_relu(_RoundBwd.apply(z), slope) if slope != 1.0 else _RoundBwd.apply(z)
+    return _RoundFwd.apply(a) if round_out else a
+
+
 def conv_block(x, w, b, slope=0.2):
     """`ConvBlock.forward` networks.py:302-305 (k3, stride 1, pad 1, LeakyReLU 0.2)."""
+    if _BF16[0]:
+        return conv_bf16(x, w, b, slope)
     conv = getattr(F, "conv%dd" % (x.dim() - 2))
     return F.leaky_relu(conv(x, w, b, stride=1, padding=1), slope)
 
@@ -215,7 +268,10 @@ def vxm_dense_forward(source, target, sd, int_steps=7, int_downsize=2, bidir=Fal
     nd = source.dim() - 2
     x = unet_forward(torch.cat([source, target], dim=1), sd, half_res=unet_half_res, **unet_kwargs)
     conv = getattr(F, "conv%dd" % nd)
-    pos = conv(x, sd["flow.weight"], sd["flow.bias"], padding=1)       # :257
+    if _BF16[0]:
+        pos = conv_bf16(x, sd["flow.weight"], sd["flow.bias"], slope=1.0, round_out=False)    # the field itself stays fp32
+    else:
+        pos = conv(x, sd["flow.weight"], sd["flow.bias"], padding=1)   # :257
     if (not unet_half_res) and int_steps > 0 and int_downsize > 1:    # :223,:261
         pos = resize_transform(pos, int_downsize)
     preint = pos                                                       # :264

@@ -1,0 +1,303 @@
+"""bf16-activation path (BASELINE.json configs[1]) through the C ABI against the oracle.  Run on the MI355X box: `pytest -m gpu`.
+
+Two references per case:
+  * the oracle with the SAME rounding points (`oracle.vxm_oracle.bf16_activations`: operands rounded to bf16, accumulation in
+    fp64, one rounding of the result) — the kernels may differ from it only by fp32-vs-fp64 accumulation, i.e. by an
+    occasional flip of the final bf16 rounding (1 bf16 ulp = 2^-8 relative on single elements, ~1e-3 rel-L2);
+  * the plain fp32 oracle — the stated tolerance of SURVEY.md §8c for bf16 mode: conv activations rel-L2 <= 1e-2.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vxm_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vxm():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    import voxelmorph_amd
+    from voxelmorph_amd import _lib
+    _lib.lib()
+    return voxelmorph_amd
+
+
+def G(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def N(t):
+    return t.detach().float().cpu().numpy()
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def rbf(a):
+    return torch.from_numpy(np.asarray(a, np.float32)).to(torch.bfloat16).to(torch.float64)
+
+
+def to_blocked(x, cblk=None):
+    """planar fp32 cuda [B,C,D,H,W] -> blocked bf16 [B,cblk/8,D,H,W,8] through the C ABI."""
+    from voxelmorph_amd._lib import call, ptr, stream
+    B, C = x.shape[:2]
+    dims = tuple(x.shape[2:])
+    cblk = cblk or (C + 15) // 16 * 16
+    out = torch.empty((B, cblk // 8) + dims + (8,), dtype=torch.bfloat16, device=x.device)
+    call("vxm_bf16_to_blocked", ptr(x), C, x[0].numel(), None, 0, 0, ptr(out), cblk, B, int(np.prod(dims)), stream())
+    return out
+
+
+def from_blocked(xb, C):
+    from voxelmorph_amd._lib import call, ptr, stream
+    B = xb.shape[0]
+    dims = tuple(xb.shape[2:5])
+    out = torch.empty((B, C) + dims, dtype=torch.float32, device=xb.device)
+    call("vxm_bf16_from_blocked", ptr(xb), xb.shape[1] * 8, ptr(out), C, B, int(np.prod(dims)), stream())
+    return out
+
+
+def test_blocked_layout_roundtrip(vxm):
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 19, 4, 6, 10)).astype(np.float32)
+    xb = to_blocked(G(x), 32)
+    assert xb.shape == (2, 4, 4, 6, 10, 8) and xb.dtype == torch.bfloat16
+    ref = torch.from_numpy(x).to(torch.bfloat16)                                       # torch's RNE conversion
+    got = xb.cpu().permute(0, 1, 5, 2, 3, 4).reshape(2, 32, 4, 6, 10)
+    assert torch.equal(got[:, :19], ref) and float(got[:, 19:].abs().max()) == 0.0
+    assert torch.equal(from_blocked(xb, 19).cpu(), ref.float())
+
+
+CONV_CASES = [
+    # c0, up0, c1, cout, vol, slope
+    (16, False, 0, 16, (8, 8, 16), 0.2),
+    (16, False, 0, 32, (10, 6, 20), 0.2),          # ragged tiles: D, H, W not multiples of the 8 x 4 x 16 tile
+    (32, False, 0, 16, (8, 12, 16), 0.2),
+    (32, True, 16, 32, (16, 8, 32), 0.2),           # cat([upsample(x0), x1])
+    (32, True, 32, 32, (8, 8, 16), 0.2),
+    (32, False, 0, 32, (2, 4, 6), 1.0),             # coarsest level, no activation
+    (16, False, 0, 3, (9, 7, 18), 1.0),             # flow head: planar fp32 output
+]
+
+
+def _conv_ref(x0, up0, x1, w, b, slope):
+    x = torch.from_numpy(x0).double()
+    x = rbf(x0)
+    if up0:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    if x1 is not None:
+        x = torch.cat([x, rbf(x1)], 1)
+    z = F.conv3d(x, rbf(w), torch.from_numpy(b).double(), padding=1)
+    return F.leaky_relu(z, slope) if slope != 1.0 else z
+
+
+@pytest.mark.parametrize("c0,up0,c1,cout,vol,slope", CONV_CASES)
+def test_bf16_conv_forward_and_mask_vs_oracle(vxm, c0, up0, c1, cout, vol, slope):
+    from voxelmorph_amd.torch import functional_bf16 as VB
+    rng = np.random.default_rng(c0 + 3 * c1 + cout)
+    B = 2
+    D, H, W = vol
+    lo = tuple(s // 2 for s in vol)
+    x0 = rng.standard_normal((B, c0) + (lo if up0 else vol)).astype(np.float32)
+    x1 = rng.standard_normal((B, c1) + vol).astype(np.float32) if c1 else None
+    w = (rng.standard_normal((cout, c0 + c1, 3, 3, 3)) / np.sqrt(27 * (c0 + c1))).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    ref = _conv_ref(x0, up0, x1, w, b, slope)
+    planar = cout <= 4
+    wg = G(w)
+    wp = VB.pack_weights(wg, 0, c0 + c1, False)
+    x0b, x1b = to_blocked(G(x0)), (to_blocked(G(x1)) if c1 else None)
+    if planar:
+        y = torch.full((B, cout, D, H, W), float("nan"), device="cuda")
+        VB.conv(x0b, c0, up0, x1b, c1, wp, G(b), y, cout, True, slope, None, 1.0, B, D, H, W)
+        assert rel_l2(N(y), ref.numpy()) < 1e-5           # fp32 accumulation of exact bf16 products, no output rounding
+        return
+    yb = VB._blocked(B, cout, vol, "cuda")
+    VB.conv(x0b, c0, up0, x1b, c1, wp, G(b), yb, cout, False, slope, None, 1.0, B, D, H, W)
+    got = N(from_blocked(yb, cout))
+    want = ref.to(torch.bfloat16).double().numpy()
+    assert rel_l2(got, want) < 2e-3
+    assert np.abs(got - want).max() <= 2.0 ** -7 * np.abs(want).max()                 # single elements: at most a rounding flip
+    assert rel_l2(got, ref.numpy()) < 4e-3                                            # vs the unrounded result: bf16 resolution
+    # the fused leaky_relu_backward mask of backward-data: y * LeakyReLU'(mask)
+    m = rng.standard_normal((B, cout) + vol).astype(np.float32)
+    VB.conv(x0b, c0, up0, x1b, c1, wp, G(b), yb, cout, False, slope, to_blocked(G(m)), 0.2, B, D, H, W)
+    mk = np.where(rbf(m).numpy() > 0, 1.0, 0.2)
+    assert rel_l2(N(from_blocked(yb, cout)), (ref.numpy() * mk)) < 4e-3
+
+
+@pytest.mark.parametrize("c0,up0,c1,cout,vol", [(16, False, 0, 16, (8, 8, 32)), (32, True, 16, 32, (12, 10, 36)), (16, False, 0, 3, (6, 16, 40)),
+                                                (32, False, 0, 32, (2, 2, 2)), (2, False, 0, 16, (8, 8, 16))])
+def test_bf16_conv_backward_data_and_weight_vs_oracle(vxm, c0, up0, c1, cout, vol):
+    """gW, gb from blocked x / dz, and the adjoint (backward-data) per input segment, against autograd of the fp64 conv on the
+    bf16-rounded operands.  (2 -> 16: the first layer, whose blocked input carries 14 zero channels; 16 -> 3: the flow head,
+    whose blocked gradient carries 13.)"""
+    from voxelmorph_amd.torch import functional_bf16 as VB
+    from voxelmorph_amd.torch.functional import _Workspace
+    rng = np.random.default_rng(7 * c0 + cout)
+    B = 2
+    D, H, W = vol
+    lo = tuple(s // 2 for s in vol)
+    x0 = rng.standard_normal((B, c0) + (lo if up0 else vol)).astype(np.float32)
+    x1 = rng.standard_normal((B, c1) + vol).astype(np.float32) if c1 else None
+    w = (rng.standard_normal((cout, c0 + c1, 3, 3, 3)) / np.sqrt(27 * (c0 + c1))).astype(np.float32)
+    dz = rng.standard_normal((B, cout) + vol).astype(np.float32)
+    X0 = rbf(x0).requires_grad_()
+    X1 = rbf(x1).requires_grad_() if c1 else None
+    Wt = rbf(w).requires_grad_()
+    x = F.interpolate(X0, scale_factor=2, mode="nearest") if up0 else X0
+    if c1:
+        x = torch.cat([x, X1], 1)
+    bias = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x, Wt, bias, padding=1).backward(rbf(dz))
+    c0p, cdz = (c0 + 15) // 16 * 16, (cout + 15) // 16 * 16
+    x0b, x1b, dzb = to_blocked(G(x0)), (to_blocked(G(x1)) if c1 else None), to_blocked(G(dz))
+    gw = torch.full((cout, c0 + c1, 3, 3, 3), float("nan"), device="cuda")
+    gb = torch.full((cout,), float("nan"), device="cuda")
+    VB.conv_bwd_weight(_Workspace(torch.device("cuda")), x0b, c0p, up0, x1b, c1, dzb, cdz, gw, gb, B, D, H, W)
+    assert rel_l2(N(gw), Wt.grad.numpy()) < 1e-5
+    assert rel_l2(N(gb), bias.grad.numpy()) < 1e-5
+    gw2 = torch.empty_like(gw)
+    VB.conv_bwd_weight(_Workspace(torch.device("cuda")), x0b, c0p, up0, x1b, c1, dzb, cdz, gw2, gb, B, D, H, W)
+    assert torch.equal(gw, gw2)                                                        # fixed-order partial sums
+    wg = G(w)
+    for lo_c, n_c, ref in ((0, c0, X0.grad), (c0, c1, X1.grad if c1 else None)):
+        if not n_c:
+            continue
+        npad = (n_c + 15) // 16 * 16
+        gx = VB._blocked(B, npad, vol, "cuda")
+        VB.conv(dzb, cdz, False, None, 0, VB.pack_weights(wg, lo_c, n_c, True), None, gx, npad, False, 1.0, None, 1.0, B, D, H, W)
+        got = from_blocked(gx, n_c).double().cpu()
+        if up0 and lo_c == 0:               # gradient of the upsampled segment: sum over the 2x2x2 children (fp64 here; the
+            got = got.reshape(B, n_c, lo[0], 2, lo[1], 2, lo[2], 2).sum(dim=(3, 5, 7))          # kernel under test comes next)
+            assert rel_l2(got.numpy(), ref.numpy()) < 4e-3
+            dzl = VB._blocked(B, n_c, lo, "cuda")
+            from voxelmorph_amd._lib import call, ptr, stream
+            call("vxm_bf16_upsample2_bwd", ptr(gx), None, ptr(dzl), 1.0, B, n_c, lo[0], lo[1], lo[2], stream())
+            assert rel_l2(N(from_blocked(dzl, n_c)), got.numpy()) < 4e-3
+        else:
+            assert rel_l2(got.numpy(), ref.numpy()) < 4e-3
+
+
+def test_bf16_pool_kernels_vs_oracle(vxm):
+    from voxelmorph_amd._lib import call, ptr, stream
+    from voxelmorph_amd.torch import functional_bf16 as VB
+    rng = np.random.default_rng(3)
+    B, C, vol = 2, 16, (4, 6, 8)
+    lo = tuple(s // 2 for s in vol)
+    x = rng.integers(-3, 4, size=(B, C) + vol).astype(np.float32)       # small integers: many ties inside the 2x2x2 blocks
+    gp = rng.standard_normal((B, C) + lo).astype(np.float32)
+    gs = rng.standard_normal((B, C) + vol).astype(np.float32)
+    xb = to_blocked(G(x))
+    yb = VB._blocked(B, C, lo, "cuda")
+    call("vxm_bf16_maxpool2_fwd", ptr(xb), ptr(yb), B, C, *vol, stream())
+    X = torch.from_numpy(x).double().requires_grad_()
+    P = F.max_pool3d(X, 2)
+    assert np.array_equal(N(from_blocked(yb, C)), P.detach().numpy())
+    P.backward(rbf(gp))
+    want = (X.grad + rbf(gs)) * torch.where(X.detach() > 0, 1.0, 0.2)       # first arg-max routing (ATen) + skip add + LeakyReLU'
+    dz = VB._blocked(B, C, vol, "cuda")
+    call("vxm_bf16_maxpool2_bwd", ptr(xb), ptr(to_blocked(G(gp))), ptr(to_blocked(G(gs))), ptr(dz), 0.2, B, C, *vol, stream())
+    assert rel_l2(N(from_blocked(dz, C)), want.numpy()) < 3e-3
+    call("vxm_bf16_maxpool2_bwd", ptr(xb), ptr(to_blocked(G(gp))), None, ptr(dz), 1.0, B, C, *vol, stream())
+    assert np.array_equal(N(from_blocked(dz, C)), X.grad.to(torch.bfloat16).double().numpy())
+
+
+def _dense_step(vxm, model, src, trg, lam=0.01):
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y, flow = model(src, trg)
+        loss = vxm.losses.MSE().loss(trg, y) + lam * vxm.losses.Grad("l2", loss_mult=2).loss(None, flow)
+    loss.backward()
+    return y, flow, loss
+
+
+@pytest.mark.parametrize("inshape,kw", [((32, 48, 32), {}), ((32, 32, 64), dict(nb_unet_features=[[16, 32], [32, 32, 16]]))])
+def test_vxm_dense_bf16_vs_emulated_and_fp32_oracle(vxm, inshape, kw):
+    """BASELINE.json configs[1] wiring at a small size: VxmDense(int_steps=0) under torch.autocast(bfloat16), MSE + 0.01 Grad."""
+    rng = np.random.default_rng(11)
+    src = rng.random((2, 1) + inshape).astype(np.float32)
+    trg = rng.random((2, 1) + inshape).astype(np.float32)
+    okw = dict(nb_features=kw["nb_unet_features"]) if kw else {}
+    sd = orc.seeded_state_dict(inshape, seed=4, flow_std=0.05, **okw)
+    model = vxm.networks.VxmDense(inshape, int_steps=0, **kw)
+    model.load_state_dict(sd, strict=False)
+    model = model.cuda()
+    y, flow, loss = _dense_step(vxm, model, G(src), G(trg))
+    assert flow.dtype == torch.float32 and flow.shape == (2, 3) + inshape and y.dtype == torch.float32
+    res = {}
+    for tag, emulate in (("emulated", True), ("fp32", False)):
+        sdo = {k: v.clone().double().requires_grad_() for k, v in sd.items()}
+        S, T = torch.from_numpy(src).double(), torch.from_numpy(trg).double()
+        if emulate:
+            with orc.bf16_activations():
+                ref, (_, _, ys, fl) = orc.train_step_loss(S, T, sdo, "mse", 0.01, int_steps=0, **okw)
+        else:
+            ref, (_, _, ys, fl) = orc.train_step_loss(S, T, sdo, "mse", 0.01, int_steps=0, **okw)
+        ref.backward()
+        gerr = {n: rel_l2(N(p.grad), sdo[n].grad.numpy()) for n, p in model.named_parameters()}
+        res[tag] = (rel_l2(N(flow), fl.detach().numpy()), abs(float(loss) - float(ref)), max(gerr.values()), gerr)
+        print("%s: flow rel-L2 %.2e, |dloss| %.2e, worst grad rel-L2 %.2e (%s)" % (tag, res[tag][0], res[tag][1], res[tag][2],
+                                                                                 max(gerr, key=gerr.get)))
+    assert res["emulated"][0] < 5e-3 and res["emulated"][1] < 1e-5 and res["emulated"][2] < 3e-2
+    assert res["fp32"][0] < 1e-2 and res["fp32"][1] < 1e-4                           # bf16 conv activations rel-L2 <= 1e-2
+    for n, e in res["fp32"][3].items():
+        assert e < 0.15, (n, e)                                                       # bf16 gradients against fp32 ones (coarse levels: few voxels)
+
+
+def test_vxm_dense_bf16_engine_is_selected_by_autocast_only(vxm):
+    from voxelmorph_amd.torch import functional_bf16 as VB
+    assert not VB.enabled()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert VB.enabled()
+    with torch.autocast("cuda", dtype=torch.float16):
+        assert not VB.enabled()
+    VB.set_activation_dtype("bf16")
+    try:
+        assert VB.enabled()
+    finally:
+        VB.set_activation_dtype(None)
+    model = vxm.networks.VxmDense((16, 16, 16), int_steps=0, nb_unet_features=[[4, 8], [8, 8, 4]]).cuda()
+    x = torch.rand(1, 1, 16, 16, 16, device="cuda")
+    with torch.autocast("cuda", dtype=torch.bfloat16), pytest.raises(Exception, match="multiples of 16"):
+        model(x, x)
+
+
+def test_full_size_dense_bf16_step_vs_oracle(vxm):
+    """BASELINE.json configs[1] at the size it is quoted on: VxmDense 160x192x224, int_steps=0, MSE + 0.01 Grad('l2', x2), bf16
+    activations; one training step against the oracle with the same rounding points (host cores, fp32 accumulation there)."""
+    from voxelmorph_amd.optim import FlatAdam
+    FULL = (160, 192, 224)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    rng = np.random.default_rng(99)
+    src = rng.random((1, 1) + FULL).astype(np.float32)
+    trg = rng.random((1, 1) + FULL).astype(np.float32)
+    sd = orc.seeded_state_dict(FULL, seed=13, flow_std=0.02)
+    model = vxm.networks.VxmDense(FULL, int_steps=0)
+    model.load_state_dict(sd, strict=False)
+    model = model.cuda()
+    opt = FlatAdam(model, lr=1e-4)
+    opt.zero_grad()
+    y, flow, loss = _dense_step(vxm, model, G(src), G(trg))
+    grads = {n: g.clone() for (n, _), g in zip(model.named_parameters(), opt._views)}
+    opt.step()
+    torch.cuda.synchronize()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    with orc.bf16_activations():
+        ref, (_, _, ys, fl) = orc.train_step_loss(torch.from_numpy(src), torch.from_numpy(trg), sdo, "mse", 0.01, int_steps=0)
+    ref.backward()
+    e_flow = rel_l2(N(flow), fl.detach().numpy())
+    gerr = {n: rel_l2(N(g), sdo[n].grad.numpy()) for n, g in grads.items()}
+    worst = max(gerr, key=gerr.get)
+    print("full-size bf16 dense step: loss hip=%.7f oracle=%.7f | flow rel-L2 %.2e | max|dy| %.2e | worst grad rel-L2 %.2e (%s)"
+          % (float(loss), float(ref), e_flow, float((y.detach().cpu() - ys.detach()).abs().max()), gerr[worst], worst))
+    assert e_flow < 1e-2 and abs(float(loss) - float(ref)) < 1e-4
+    for n, e in gerr.items():
+        assert e < 3e-2, (n, e)

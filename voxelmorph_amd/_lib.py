@@ -70,6 +70,17 @@ SIGNATURES = {
     "vxm_ncc2d_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vxm_gradloss2d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "vxm_gradloss2d_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "vxm_bf16_to_blocked": [_P, _I, _L, _P, _I, _L, _P, _I, _I, _L, _P],
+    "vxm_bf16_from_blocked": [_P, _I, _P, _I, _I, _L, _P],
+    "vxm_bf16_conv_packed_bytes": [_I, _I],
+    "vxm_bf16_conv_pack_weights": [_P, _I, _I, _I, _I, _I, _P, _P],
+    "vxm_bf16_conv_fwd": [_P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _F, _P, _F, _I, _I, _I, _I, _P],
+    "vxm_bf16_conv_bwd_weight_workspace_bytes": [_I, _I, _I, _I, _I, _I],
+    "vxm_bf16_conv_bwd_weight": [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _S, _I, _I, _I, _I, _P],
+    "vxm_bf16_maxpool2_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "vxm_bf16_maxpool2_bwd": [_P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
+    "vxm_bf16_upsample2_bwd": [_P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
+    "vxm_bf16_lrelu_bwd": [_P, _P, _P, _F, _L, _P],
     "vxm_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
 }
 _RESTYPES = {
@@ -78,6 +89,8 @@ _RESTYPES = {
     "vxm_conv3d_k3_up_packed_elems": _S,
     "vxm_conv3d_k3_up_bwd_low_packed_elems": _S,
     "vxm_conv3d_k3_bwd_weight_workspace_bytes": _S,
+    "vxm_bf16_conv_packed_bytes": _S,
+    "vxm_bf16_conv_bwd_weight_workspace_bytes": _S,
 }
 
 _lib = None

@@ -12,6 +12,7 @@ import torch.nn as nn
 from torch.distributions.normal import Normal
 
 from . import functional as VF
+from . import functional_bf16 as VB
 from . import layers
 from . import planar as VP
 from .modelio import LoadableModel, store_config_args
@@ -146,7 +147,8 @@ class Unet(nn.Module):
     def forward(self, x):
         if self.ndims == 2:
             return self._forward_planar(x)
-        return VF.UnetFn.apply(self.plan([x.shape[1]]), x, *self.conv_params())
+        engine = VB.UnetBf16Fn if VB.enabled() else VF.UnetFn       # torch.autocast(bfloat16): blocked-bf16 activations
+        return engine.apply(self.plan([x.shape[1]]), x, *self.conv_params())
 
     def _forward_planar(self, x):
         """networks.py:122-144 op by op (2-D slices are small: per-op autograd nodes instead of the fused 3-D engine)."""
@@ -210,7 +212,10 @@ class VxmDense(LoadableModel):
         else:
             # U-Net + flow head as ONE fused autograd node; source and target enter as a virtual concat
             plan = self.unet_model.plan(self._feats, extra=((self.flow.out_channels, 1.0),))
-            field = VF.UnetFn.apply(plan, source, target, *self.unet_model.conv_params(), self.flow.weight, self.flow.bias)
+            # under torch.autocast(bfloat16) the activations between the convolutions are blocked bf16 (functional_bf16.py);
+            # the field that leaves the flow head, and everything that consumes it, stays fp32
+            engine = VB.UnetBf16Fn if VB.enabled() else VF.UnetFn
+            field = engine.apply(plan, source, target, *self.unet_model.conv_params(), self.flow.weight, self.flow.bias)
         velocity = self.resize(field) if self.resize is not None else field       # what Grad regularises ("preint_flow")
 
         def displacement(v):
