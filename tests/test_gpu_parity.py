@@ -669,10 +669,15 @@ def test_full_size_dice_of_warped_labels_matches_oracle(vxm):
     assert abs(d_gpu - d_ref) <= 1e-3
 
 
-def _full_size_step_vs_oracle(vxm, src, trg, seed, flow_std):
+def _full_size_step_vs_oracle(vxm, src, trg, seed, flow_std, fp64_ncc_arbiter=False):
     """One headline-config training step (VxmDense 160x192x224, int_steps=7, int_downsize=2, NCC(9^3) + Grad('l2', x2),
     lambda 1; scripts/torch/train.py:194-223) on the HIP path against `oracle.vxm_oracle.train_step_loss` on the host cores:
-    forward tensors, loss and every parameter gradient.  Returns the GPU model and the positive full-resolution flow."""
+    forward tensors, loss and every parameter gradient.  Returns the GPU model and the positive full-resolution flow.
+
+    fp64_ncc_arbiter: the reference's fp32 NCC formula cancels catastrophically where the image is locally flat (SURVEY.md §7;
+    a real scan is, noise is not), so two fp32 evaluations of it in different summation orders differ by more than either differs
+    from the exact value.  The gradients are then judged against the oracle with the NCC term evaluated in fp64 (same fp32
+    network), and the HIP path must be at least as close to it as the reference-order fp32 evaluation is (factor 2 of slack)."""
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     sd = orc.seeded_state_dict(FULL, seed=seed, flow_std=flow_std)
     model = vxm.networks.VxmDense(FULL, int_steps=7, int_downsize=2)
@@ -685,13 +690,15 @@ def _full_size_step_vs_oracle(vxm, src, trg, seed, flow_std):
     loss.backward()
     torch.cuda.synchronize()
     sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
-    ref, (_, _, ys, pres) = orc.train_step_loss(torch.from_numpy(src), torch.from_numpy(trg), sdo, "ncc", 1.0)
-    ref.backward()
+    names, params = list(sdo), list(sdo.values())
+    ts = torch.from_numpy(trg)
+    ref, (_, reg, ys, pres) = orc.train_step_loss(torch.from_numpy(src), ts, sdo, "ncc", 1.0)
+    g32 = dict(zip(names, torch.autograd.grad(ref, params, retain_graph=fp64_ncc_arbiter)))
     err_y = float((y.detach().cpu() - ys.detach()).abs().max())
     err_p = float((pre.detach().cpu() - pres.detach()).abs().max())
-    gerr = {name: rel_l2(N(p.grad), sdo[name].grad.numpy()) for name, p in model.named_parameters()}
+    gerr = {name: rel_l2(N(p.grad), g32[name].numpy()) for name, p in model.named_parameters()}
     worst = max(gerr, key=gerr.get)
-    print("full-size step: loss hip=%.7f oracle=%.7f | max|dy|=%.2e max|dpreint|=%.2e | worst grad rel-L2 %.2e (%s)"
+    print("full-size step: loss hip=%.7f oracle=%.7f | max|dy|=%.2e max|dpreint|=%.2e | worst grad rel-L2 vs fp32 oracle %.2e (%s)"
           % (float(loss), float(ref), err_y, err_p, gerr[worst], worst))
     # preint_flow is a conv output (<= 2e-5 abs).  y_source is an image sampled at (voxel + integrated flow): the stated
     # tolerance of the integrated flows is 1e-4 abs (fp32 scaling and squaring drifts 3.9e-5 against fp64 after 7
@@ -700,8 +707,17 @@ def _full_size_step_vs_oracle(vxm, src, trg, seed, flow_std):
     assert err_p <= 2e-5 and err_y <= 1e-4, (err_y, err_p)
     assert abs(float(loss) - float(ref)) <= 1e-3
     assert len(gerr) == 24
-    for name, e in gerr.items():
-        assert e <= 2e-3, (name, e)
+    if not fp64_ncc_arbiter:
+        for name, e in gerr.items():
+            assert e <= 2e-3, (name, e)
+    else:
+        ref64 = orc.ncc_loss(ts, ys, dtype=torch.float64).float() + reg
+        g64 = dict(zip(names, torch.autograd.grad(ref64, params)))
+        assert abs(float(loss) - float(ref64)) <= 1e-3
+        for name, p in model.named_parameters():
+            e_hip, e_ref = rel_l2(N(p.grad), g64[name].numpy()), rel_l2(g32[name].numpy(), g64[name].numpy())
+            print("  %-40s vs fp64-NCC arbiter: hip %.2e, fp32 oracle %.2e" % (name, e_hip, e_ref))
+            assert e_hip <= max(2e-3, 2.0 * e_ref), (name, e_hip, e_ref)
     return model, pos.detach()
 
 
@@ -742,7 +758,7 @@ def test_full_size_real_scan_step_and_label_dice_gate(vxm):
     svf = _smooth_svf(FULL)
     trg = vol[None, None]
     src = c_oracle.warp3d(trg, svf, mode="bilinear")
-    model, pos = _full_size_step_vs_oracle(vxm, src, trg, seed=12, flow_std=0.05)
+    model, pos = _full_size_step_vs_oracle(vxm, src, trg, seed=12, flow_std=0.05, fp64_ncc_arbiter=True)
     seg30 = np.where(np.isin(seg, labels), seg, 0.0).astype(np.float32)[None, None]
     moved = N(vxm.layers.SpatialTransformer(FULL, mode="nearest").cuda()(G(seg30), pos))
     ref_same_flow = c_oracle.warp3d(seg30, N(pos), mode="nearest")

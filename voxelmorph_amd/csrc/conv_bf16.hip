@@ -400,7 +400,8 @@ __device__ __forceinline__ u32x2 bf_tr_read(const char* lds_base, int byte_off) 
     return __builtin_bit_cast(u32x2, v);
 }
 
-template <int NCO>
+// STAGE: 0 = plain staging loop (few registers), 1 = every load of the tile in flight before the first LDS write
+template <int NCO, int STAGE>
 __global__ void __launch_bounds__(BWB_THREADS, 3) k_bf16_conv_bwd_weight(BfIn in, const void* __restrict__ dz, float* __restrict__ part,
                                                                          int B, int D, int H, int W, int NBLK) {
     VXM_DYN_SMEM(char, smem);
@@ -441,26 +442,41 @@ __global__ void __launch_bounds__(BWB_THREADS, 3) k_bf16_conv_bwd_weight(BfIn in
         const int d0 = td * BWB_TD, h0 = th * BWB_TH, w0 = tw * BWB_TW;
         const __amdgpu_buffer_rsrc_t rx = bf_rsrc(static_cast<const char*>(s0 ? in.x0 : in.x1) + (size_t)b * CBs * Vs * 16, (unsigned)CBs * (unsigned)Vs * 16u);
         const __amdgpu_buffer_rsrc_t rz = bf_rsrc(static_cast<const char*>(dz) + (size_t)b * CBz * V * 16, (unsigned)CBz * (unsigned)V * 16u);
-        __syncthreads();                                        // every wave is done with the previous tile
-        constexpr int NX = (BWB_TD + 2) * (BWB_TH + 2) * BWB_XW * 2;
-        for (int i = tid; i < NX; i += BWB_THREADS) {
+        constexpr int NX = (BWB_TD + 2) * (BWB_TH + 2) * BWB_XW * 2, NXI = (NX + BWB_THREADS - 1) / BWB_THREADS;
+        constexpr int NZ = BWB_TD * BWB_TH * BWB_TW * 2, NZI = (NZ * NCO + BWB_THREADS - 1) / BWB_THREADS;
+        auto x_load = [&](int i) __attribute__((always_inline)) -> u32x4 {
             const int cb = i & 1, v = i >> 1;
             const int hd = v / ((BWB_TH + 2) * BWB_XW), r2 = v - hd * (BWB_TH + 2) * BWB_XW, hh = r2 / BWB_XW, hw = r2 - hh * BWB_XW;
             const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-            const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const bool ok = i < NX && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
             const int vox = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
-            *reinterpret_cast<u32x4*>(Xs + i * 16) =
-                __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vox << 4 : VXM_OOB, (cbg + cb) * Vs * 16, 0));
-        }
-        constexpr int NZ = BWB_TD * BWB_TH * BWB_TW * 2;
-        for (int i = tid; i < NZ * NCO; i += BWB_THREADS) {
+            return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vox << 4 : VXM_OOB, (cbg + cb) * Vs * 16, 0));
+        };
+        auto z_load = [&](int i) __attribute__((always_inline)) -> u32x4 {
             const int co = i / NZ, r = i - co * NZ;
             const int cb = r & 1, v = r >> 1;
             const int zd = v / (BWB_TH * BWB_TW), r2 = v - zd * BWB_TH * BWB_TW, zh = r2 / BWB_TW, zw = r2 - zh * BWB_TW;
             const int gd = d0 + zd, gh = h0 + zh, gw = w0 + zw;
-            const bool ok = gd < D && gh < H && gw < W;
-            *reinterpret_cast<u32x4*>(Zs + i * 16) =
-                __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, ok ? ((gd * H + gh) * W + gw) << 4 : VXM_OOB, (2 * co + cb) * V * 16, 0));
+            const bool ok = i < NZ * NCO && gd < D && gh < H && gw < W;
+            return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, ok ? ((gd * H + gh) * W + gw) << 4 : VXM_OOB, (2 * co + cb) * V * 16, 0));
+        };
+        if constexpr (STAGE == 0) {
+            __syncthreads();                                    // every wave is done with the previous tile
+            for (int i = tid; i < NX; i += BWB_THREADS) *reinterpret_cast<u32x4*>(Xs + i * 16) = x_load(i);
+            for (int i = tid; i < NZ * NCO; i += BWB_THREADS) *reinterpret_cast<u32x4*>(Zs + i * 16) = z_load(i);
+        } else {
+            u32x4 xv[NXI], zv[NZI];
+#pragma unroll
+            for (int j = 0; j < NXI; ++j) xv[j] = x_load(tid + BWB_THREADS * j);
+#pragma unroll
+            for (int j = 0; j < NZI; ++j) zv[j] = z_load(tid + BWB_THREADS * j);
+            __syncthreads();                                    // every wave is done with the previous tile
+#pragma unroll
+            for (int j = 0; j < NXI; ++j)
+                if (tid + BWB_THREADS * j < NX) *reinterpret_cast<u32x4*>(Xs + (tid + BWB_THREADS * j) * 16) = xv[j];
+#pragma unroll
+            for (int j = 0; j < NZI; ++j)
+                if (tid + BWB_THREADS * j < NZ * NCO) *reinterpret_cast<u32x4*>(Zs + (tid + BWB_THREADS * j) * 16) = zv[j];
         }
         __syncthreads();
 
@@ -661,14 +677,17 @@ int vxm_bf16_conv_bwd_weight(const void* x0, int C0, int x0_up, const void* x1, 
     const BfIn in = {x0, x1, C0 / 8, C1 / 8, x0_up ? 1 : 0};
     hipStream_t s = VXM_STREAM(stream);
     float* part = static_cast<float*>(work);
+    static const int stage = [] { const char* e = getenv("VXM_BF16_BWDW_STAGE"); return e ? atoi(e) : -1; }();     // developer A/B switch
+    auto launch = [&](auto kern, int lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(kern, dim3(NBLK, Q), dim3(BWB_THREADS), lds, s, in, dz, part, B, D, H, W, NBLK);
+    };
     if (NCO == 1) {
-        static const bool a1 = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf16_conv_bwd_weight<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bwb_lds_bytes(1)); return true; }();
-        (void)a1;
-        hipLaunchKernelGGL(k_bf16_conv_bwd_weight<1>, dim3(NBLK, Q), dim3(BWB_THREADS), bwb_lds_bytes(1), s, in, dz, part, B, D, H, W, NBLK);
+        if (stage == 0) launch(k_bf16_conv_bwd_weight<1, 0>, bwb_lds_bytes(1));
+        else launch(k_bf16_conv_bwd_weight<1, 1>, bwb_lds_bytes(1));
     } else {
-        static const bool a2 = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf16_conv_bwd_weight<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bwb_lds_bytes(2)); return true; }();
-        (void)a2;
-        hipLaunchKernelGGL(k_bf16_conv_bwd_weight<2>, dim3(NBLK, Q), dim3(BWB_THREADS), bwb_lds_bytes(2), s, in, dz, part, B, D, H, W, NBLK);
+        if (stage == 1) launch(k_bf16_conv_bwd_weight<2, 1>, bwb_lds_bytes(2));
+        else launch(k_bf16_conv_bwd_weight<2, 0>, bwb_lds_bytes(2));
     }
     const int n = 16 * NCO * 16 * Q * 28;
     hipLaunchKernelGGL(k_bf16_reduce_partials, dim3(vxm_blocks(n, 256)), dim3(256), 0, s, part, gw, gb, Cin_w, Cout_w, Q, NCO, NBLK);
