@@ -382,15 +382,23 @@ __global__ void __launch_bounds__(256) k_bf16_lrelu_bwd(const u32x4* __restrict_
 // ------------------------------------------------------------------------------------------
 // M = 16 output channels (A = dZ^T), N = 16 input channels (B = X), K = 32 voxels of a W row.  Block = 6 waves = (depth slice
 // of a 2 x 8 x 32 voxel tile) x (kd); a wave keeps the 9 (kh, kw) taps x NCO output-channel tiles of its kd in registers
-// (36 NCO accumulator VGPRs) over its whole tile range and slides over the 10 haloed X rows: the three kw-shifted B fragments
-// of a row serve kh = 0, 1, 2 with the A fragments of output rows r, r-1, r-2.  One block owns one 16-input-channel chunk of
-// the virtual concat and a contiguous tile range; partials are written once and summed in a fixed order (deterministic).
+// (36 NCO accumulator VGPRs) over ALL its tiles and slides over the 10 haloed X rows: the three kw-shifted B fragments of a
+// row serve kh = 0, 1, 2 with the A fragments of output rows r, r-1, r-2.
+// HBM-bound (X and dZ are streamed once per 16-input-channel chunk), so the kernel is built around the stream:
+//  * one persistent block per CU walks DOWN THE DEPTH of a (b, th, tw) column: consecutive tiles share two of their four
+//    haloed X planes, which stay in a 6-slot LDS ring -- a tile fetches 2 new planes (x 1.33 halo amplification from H / W
+//    only, instead of x 2.66);
+//  * the loads of tile t+1 (2 X planes + the dZ tile, 7-10 dwordx4 per lane) are in flight in registers under the MFMAs of
+//    tile t and written to LDS afterwards (ring slots / the other dZ buffer): one barrier per tile;
+//  * a block owns one chunk and a contiguous range of (column, depth segment) tasks; its accumulators are written once, as
+//    partials that k_bf16_reduce_partials sums in a fixed order (deterministic).
 constexpr int BWB_WAVES = 6, BWB_THREADS = 64 * BWB_WAVES;
 constexpr int BWB_TD = 2, BWB_TH = 8, BWB_TW = 32;
 constexpr int BWB_XW = BWB_TW + 2;                                                 // haloed row, voxels
-constexpr int BWB_XBYTES = (BWB_TD + 2) * (BWB_TH + 2) * BWB_XW * 32;              // [hd][hh][hw][16 ci]
-constexpr int BWB_ZBYTES = BWB_TD * BWB_TH * BWB_TW * 32;                          // per output-channel tile: [ds][row][w][16 co]
-constexpr int bwb_lds_bytes(int nco) { return BWB_XBYTES + nco * BWB_ZBYTES; }
+constexpr int BWB_PLANE = (BWB_TH + 2) * BWB_XW * 32;                              // one haloed X plane: [hh][hw][16 ci], bytes
+constexpr int BWB_RING = 6;
+constexpr int BWB_ZBYTES = BWB_TD * BWB_TH * BWB_TW * 32;                          // dZ tile per output-channel tile: [ds][row][w][16 co]
+constexpr int bwb_lds_bytes(int nco) { return BWB_RING * BWB_PLANE + 2 * nco * BWB_ZBYTES; }
 
 // transposing read of a [voxel][16 channel] bf16 tile (32-byte rows): the lane pattern supplies, per 16-lane group, the
 // 16 8-byte pieces of 4 consecutive voxels; lane (n, kg) receives channel n of voxels 4 kg .. 4 kg + 3 (tools/probe/tr16_probe.hip)
@@ -400,20 +408,20 @@ __device__ __forceinline__ u32x2 bf_tr_read(const char* lds_base, int byte_off) 
     return __builtin_bit_cast(u32x2, v);
 }
 
-// STAGE: 0 = plain staging loop (few registers), 1 = every load of the tile in flight before the first LDS write
-template <int NCO, int STAGE>
-__global__ void __launch_bounds__(BWB_THREADS, 3) k_bf16_conv_bwd_weight(BfIn in, const void* __restrict__ dz, float* __restrict__ part,
-                                                                         int B, int D, int H, int W, int NBLK) {
+struct BwbTasks { int ncol, nseg, seg_len, nd, nh, nw; };       // tasks = (column (b, th, tw), depth segment), seg_len tiles each
+
+template <int NCO>
+__global__ void __launch_bounds__(BWB_THREADS, 1) k_bf16_conv_bwd_weight(BfIn in, const void* __restrict__ dz, float* __restrict__ part,
+                                                                         int D, int H, int W, int NBLK, BwbTasks tk) {
     VXM_DYN_SMEM(char, smem);
-    char* const Xs = smem;
-    char* const Zs = smem + BWB_XBYTES;
+    char* const Xs = smem;                                       // ring of 6 haloed planes
+    char* const Zs = smem + BWB_RING * BWB_PLANE;                // [2 buffers][NCO][ZBYTES]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ds = wave / 3, kd = wave - 3 * ds;
     const int q = blockIdx.y;                                    // 16-channel chunk of the virtual concat
-    const int nw = (W + BWB_TW - 1) / BWB_TW, nh = (H + BWB_TH - 1) / BWB_TH, nd = (D + BWB_TD - 1) / BWB_TD;
-    const int ntiles = B * nd * nh * nw;
-    const int t_lo = (int)((long long)ntiles * blockIdx.x / NBLK), t_hi = (int)((long long)ntiles * (blockIdx.x + 1) / NBLK);
+    const int ntask = tk.ncol * tk.nseg;
+    const int k_lo = (int)((long long)ntask * blockIdx.x / NBLK), k_hi = (int)((long long)ntask * (blockIdx.x + 1) / NBLK);
 
     const int V = D * H * W;
     const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
@@ -421,7 +429,7 @@ __global__ void __launch_bounds__(BWB_THREADS, 3) k_bf16_conv_bwd_weight(BfIn in
     const bool up = s0 && in.up0;
     const int Vs = up ? Dl * Hl * Wl : V;
     const int CBs = s0 ? in.CB0 : in.CB1, cbg = s0 ? 2 * q : 2 * q - in.CB0;
-    const int CBz = 2 * NCO;
+    constexpr int CBz = 2 * NCO;
 
     f32x4 acc[3][3][NCO], accb[NCO];
 #pragma unroll
@@ -435,81 +443,117 @@ __global__ void __launch_bounds__(BWB_THREADS, 3) k_bf16_conv_bwd_weight(BfIn in
     const int lp = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;     // lane pattern of the transposing read
     const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};       // bf16 1.0 x 8: B operand of the bias sum
 
-    for (int tile = t_lo; tile < t_hi; ++tile) {
-        const int tw = tile % nw; int tq = tile / nw;
-        const int th = tq % nh; tq /= nh;
-        const int td = tq % nd; const int b = tq / nd;
-        const int d0 = td * BWB_TD, h0 = th * BWB_TH, w0 = tw * BWB_TW;
+    constexpr int NXP = 2 * (BWB_TH + 2) * BWB_XW * 2, NXI = (NXP + BWB_THREADS - 1) / BWB_THREADS;        // two planes
+    constexpr int NZ = BWB_TD * BWB_TH * BWB_TW * 2, NZI = (NZ * NCO + BWB_THREADS - 1) / BWB_THREADS;
+    u32x4 xv[NXI], zv[NZI];
+
+    for (int task = k_lo; task < k_hi; ++task) {
+        const int col = task / tk.nseg, seg = task - col * tk.nseg;
+        const int tw = col % tk.nw; int cq = col / tk.nw;
+        const int th = cq % tk.nh; const int b = cq / tk.nh;
+        const int td0 = seg * tk.seg_len, ntile = min(tk.seg_len, tk.nd - td0);
+        const int dbase = td0 * BWB_TD, h0 = th * BWB_TH, w0 = tw * BWB_TW;
         const __amdgpu_buffer_rsrc_t rx = bf_rsrc(static_cast<const char*>(s0 ? in.x0 : in.x1) + (size_t)b * CBs * Vs * 16, (unsigned)CBs * (unsigned)Vs * 16u);
         const __amdgpu_buffer_rsrc_t rz = bf_rsrc(static_cast<const char*>(dz) + (size_t)b * CBz * V * 16, (unsigned)CBz * (unsigned)V * 16u);
-        constexpr int NX = (BWB_TD + 2) * (BWB_TH + 2) * BWB_XW * 2, NXI = (NX + BWB_THREADS - 1) / BWB_THREADS;
-        constexpr int NZ = BWB_TD * BWB_TH * BWB_TW * 2, NZI = (NZ * NCO + BWB_THREADS - 1) / BWB_THREADS;
-        auto x_load = [&](int i) __attribute__((always_inline)) -> u32x4 {
-            const int cb = i & 1, v = i >> 1;
-            const int hd = v / ((BWB_TH + 2) * BWB_XW), r2 = v - hd * (BWB_TH + 2) * BWB_XW, hh = r2 / BWB_XW, hw = r2 - hh * BWB_XW;
-            const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-            const bool ok = i < NX && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-            const int vox = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
-            return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vox << 4 : VXM_OOB, (cbg + cb) * Vs * 16, 0));
+
+        // planes p0, p0 + 1 of this task (plane p = global depth dbase - 1 + p) -> registers / -> ring slots p % 6
+        auto load_planes = [&](int p0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NXI; ++j) {
+                const int i = tid + BWB_THREADS * j;
+                const int cb = i & 1, v = i >> 1;
+                const int pl = v / ((BWB_TH + 2) * BWB_XW), r2 = v - pl * (BWB_TH + 2) * BWB_XW, hh = r2 / BWB_XW, hw = r2 - hh * BWB_XW;
+                const int gd = dbase - 1 + p0 + pl, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+                const bool ok = i < NXP && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+                const int vox = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
+                xv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vox << 4 : VXM_OOB, (cbg + cb) * Vs * 16, 0));
+            }
         };
-        auto z_load = [&](int i) __attribute__((always_inline)) -> u32x4 {
-            const int co = i / NZ, r = i - co * NZ;
-            const int cb = r & 1, v = r >> 1;
-            const int zd = v / (BWB_TH * BWB_TW), r2 = v - zd * BWB_TH * BWB_TW, zh = r2 / BWB_TW, zw = r2 - zh * BWB_TW;
-            const int gd = d0 + zd, gh = h0 + zh, gw = w0 + zw;
-            const bool ok = i < NZ * NCO && gd < D && gh < H && gw < W;
-            return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, ok ? ((gd * H + gh) * W + gw) << 4 : VXM_OOB, (2 * co + cb) * V * 16, 0));
+        auto store_planes = [&](int p0) __attribute__((always_inline)) {
+            const int sl0 = p0 % BWB_RING, sl1 = (p0 + 1) % BWB_RING;
+#pragma unroll
+            for (int j = 0; j < NXI; ++j) {
+                const int i = tid + BWB_THREADS * j;
+                if (i < NXP) {
+                    const int pl = i / ((BWB_TH + 2) * BWB_XW * 2), r = i - pl * (BWB_TH + 2) * BWB_XW * 2;
+                    *reinterpret_cast<u32x4*>(Xs + (pl ? sl1 : sl0) * BWB_PLANE + r * 16) = xv[j];
+                }
+            }
         };
-        if constexpr (STAGE == 0) {
-            __syncthreads();                                    // every wave is done with the previous tile
-            for (int i = tid; i < NX; i += BWB_THREADS) *reinterpret_cast<u32x4*>(Xs + i * 16) = x_load(i);
-            for (int i = tid; i < NZ * NCO; i += BWB_THREADS) *reinterpret_cast<u32x4*>(Zs + i * 16) = z_load(i);
-        } else {
-            u32x4 xv[NXI], zv[NZI];
+        auto load_z = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NXI; ++j) xv[j] = x_load(tid + BWB_THREADS * j);
+            for (int j = 0; j < NZI; ++j) {
+                const int i = tid + BWB_THREADS * j;
+                const int co = i / NZ, r = i - co * NZ;
+                const int cb = r & 1, v = r >> 1;
+                const int zd = v / (BWB_TH * BWB_TW), r2 = v - zd * BWB_TH * BWB_TW, zh = r2 / BWB_TW, zw = r2 - zh * BWB_TW;
+                const int gd = dbase + t * BWB_TD + zd, gh = h0 + zh, gw = w0 + zw;
+                const bool ok = i < NZ * NCO && gd < D && gh < H && gw < W;
+                zv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, ok ? ((gd * H + gh) * W + gw) << 4 : VXM_OOB, (2 * co + cb) * V * 16, 0));
+            }
+        };
+        auto store_z = [&](int t) __attribute__((always_inline)) {
+            char* const zb = Zs + (t & 1) * NCO * BWB_ZBYTES;
 #pragma unroll
-            for (int j = 0; j < NZI; ++j) zv[j] = z_load(tid + BWB_THREADS * j);
-            __syncthreads();                                    // every wave is done with the previous tile
-#pragma unroll
-            for (int j = 0; j < NXI; ++j)
-                if (tid + BWB_THREADS * j < NX) *reinterpret_cast<u32x4*>(Xs + (tid + BWB_THREADS * j) * 16) = xv[j];
-#pragma unroll
-            for (int j = 0; j < NZI; ++j)
-                if (tid + BWB_THREADS * j < NZ * NCO) *reinterpret_cast<u32x4*>(Zs + (tid + BWB_THREADS * j) * 16) = zv[j];
-        }
+            for (int j = 0; j < NZI; ++j) {
+                const int i = tid + BWB_THREADS * j;
+                if (i < NZ * NCO) *reinterpret_cast<u32x4*>(zb + i * 16) = zv[j];
+            }
+        };
+
+        __syncthreads();                                        // every wave is done with the previous task
+        load_planes(0);
+        load_z(0);
+        store_planes(0);
+        load_planes(2);
+        store_z(0);
+        store_planes(2);
         __syncthreads();
 
-        // ---- slide over the haloed rows of X plane ds + kd
-        u32x4 az[3][NCO];                                      // A fragments (dZ) of output rows hr, hr - 1, hr - 2 (ring index row % 3)
+        for (int t = 0; t < ntile; ++t) {
+            const bool more = t + 1 < ntile;                     // wave-uniform
+            const char* const xp = Xs + ((2 * t + ds + kd) % BWB_RING) * BWB_PLANE;
+            const char* const zp = Zs + (t & 1) * NCO * BWB_ZBYTES;
+            // haloed rows [r0, r1) of X plane 2 t + ds + kd: per row three kw-shifted B fragments; the A fragments (dZ rows
+            // hr, hr - 1, hr - 2) are re-read per use -- LDS has the headroom, the register file has not
+            auto rows = [&](int r0, int r1) __attribute__((always_inline)) {
 #pragma unroll
-        for (int hr = 0; hr < BWB_TH + 2; ++hr) {
-            if (hr < BWB_TH) {
+                for (int hr = r0; hr < r1; ++hr) {
+                    u32x4 bx[3];
 #pragma unroll
-                for (int co = 0; co < NCO; ++co) {
-                    const int zb = co * BWB_ZBYTES + ((ds * BWB_TH + hr) * BWB_TW) * 32 + lp;
-                    const u32x2 lo = bf_tr_read(Zs, zb), hi = bf_tr_read(Zs, zb + 16 * 32);
-                    az[hr % 3][co] = (u32x4){lo.x, lo.y, hi.x, hi.y};
-                    if (kd == 0) accb[co] = bf_mfma(az[hr % 3][co], ones, accb[co]);
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int xb = (hr * BWB_XW + kw) * 32 + lp;
+                        const u32x2 lo = bf_tr_read(xp, xb), hi = bf_tr_read(xp, xb + 16 * 32);
+                        bx[kw] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+                    }
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const int row = hr - kh;
+                        if (row >= 0 && row < BWB_TH) {
+#pragma unroll
+                            for (int co = 0; co < NCO; ++co) {
+                                const int zb = co * BWB_ZBYTES + ((ds * BWB_TH + row) * BWB_TW) * 32 + lp;
+                                const u32x2 lo = bf_tr_read(zp, zb), hi = bf_tr_read(zp, zb + 16 * 32);
+                                const u32x4 az = {lo.x, lo.y, hi.x, hi.y};
+                                if (kh == 0 && kd == 0) accb[co] = bf_mfma(az, ones, accb[co]);
+#pragma unroll
+                                for (int kw = 0; kw < 3; ++kw) acc[kh][kw][co] = bf_mfma(az, bx[kw], acc[kh][kw][co]);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);         // keep the operand reads of row hr + 1 behind this row (register budget)
                 }
-            }
-            u32x4 bx[3];
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int xb = (((ds + kd) * (BWB_TH + 2) + hr) * BWB_XW + kw) * 32 + lp;
-                const u32x2 lo = bf_tr_read(Xs, xb), hi = bf_tr_read(Xs, xb + 16 * 32);
-                bx[kw] = (u32x4){lo.x, lo.y, hi.x, hi.y};
-            }
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int row = hr - kh;
-                if (row >= 0 && row < BWB_TH) {
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                        for (int co = 0; co < NCO; ++co) acc[kh][kw][co] = bf_mfma(az[row % 3][co], bx[kw], acc[kh][kw][co]);
-                }
-            }
+            };
+            // the loads of tile t + 1 are in flight under the MFMAs: its X planes under the first half of the rows, its dZ
+            // tile under the second (written to ring slots / the dZ buffer last read by tile t - 1)
+            if (more) load_planes(2 * t + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            rows(0, (BWB_TH + 2) / 2);
+            if (more) { store_planes(2 * t + 4); load_z(t + 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            rows((BWB_TH + 2) / 2, BWB_TH + 2);
+            if (more) store_z(t + 1);
+            __syncthreads();
         }
     }
 
@@ -588,15 +632,29 @@ void bf_launch_conv(const BfIn& in, const void* wp, const float* bias, void* y, 
                        static_cast<const u32x4*>(wp), bias, y, Cout, slope, mask, mask_slope, B, D, H, W, Q);
 }
 
-int bwb_blocks(long long ntiles, int Q) {
+int bwb_cus() {
     static const int cus = [] {
         int dev = 0; hipDeviceProp_t p;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
         return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     }();
-    long long n = (2ll * cus + Q - 1) / Q;                     // two blocks per CU over all chunks
-    if (n > ntiles) n = ntiles;
-    return (int)(n < 1 ? 1 : n);
+    return cus;
+}
+// one persistent block per CU over all chunks; columns are cut into depth segments until there are ~4 tasks per block
+// (a segment start re-fetches two planes: 1 / seg_len overhead)
+BwbTasks bwb_tasks(int Q, int B, int D, int H, int W, int& NBLK) {
+    BwbTasks tk;
+    tk.nd = (D + BWB_TD - 1) / BWB_TD; tk.nh = (H + BWB_TH - 1) / BWB_TH; tk.nw = (W + BWB_TW - 1) / BWB_TW;
+    tk.ncol = B * tk.nh * tk.nw;
+    const int nb = bwb_cus() / Q > 0 ? bwb_cus() / Q : 1;
+    int nseg = (4 * nb + tk.ncol - 1) / tk.ncol;
+    if (nseg > tk.nd) nseg = tk.nd;
+    if (nseg < 1) nseg = 1;
+    tk.seg_len = (tk.nd + nseg - 1) / nseg;
+    tk.nseg = (tk.nd + tk.seg_len - 1) / tk.seg_len;
+    const long long ntask = (long long)tk.ncol * tk.nseg;
+    NBLK = (int)(nb < ntask ? nb : ntask);
+    return tk;
 }
 
 }  // namespace
@@ -658,8 +716,9 @@ int vxm_bf16_conv_fwd(const void* x0, int C0, int x0_up, const void* x1, int C1,
 size_t vxm_bf16_conv_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D, int H, int W) {
     if (Cin <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     const int Q = (Cin + 15) / 16, NCO = (Cout + 15) / 16;
-    const long long ntiles = (long long)B * ((D + BWB_TD - 1) / BWB_TD) * ((H + BWB_TH - 1) / BWB_TH) * ((W + BWB_TW - 1) / BWB_TW);
-    return (size_t)bwb_blocks(ntiles, Q) * Q * BWB_TD * 28 * (16 * NCO) * 16 * sizeof(float);
+    int NBLK = 1;
+    (void)bwb_tasks(Q, B, D, H, W, NBLK);
+    return (size_t)NBLK * Q * BWB_TD * 28 * (16 * NCO) * 16 * sizeof(float);
 }
 
 int vxm_bf16_conv_bwd_weight(const void* x0, int C0, int x0_up, const void* x1, int C1, const void* dz, int Cdz, float* gw, int Cin_w, int Cout_w,
@@ -670,25 +729,19 @@ int vxm_bf16_conv_bwd_weight(const void* x0, int C0, int x0_up, const void* x1, 
                 "vxm_bf16_conv_bwd_weight: dz carries %d channels (16 or 32), weight is [%d][%d]", Cdz, Cout_w, Cin_w);
     VXM_REQUIRE(bf_al16(x0) && bf_al16(x1) && bf_al16(dz), VXM_ERR_BAD_SHAPE, "vxm_bf16_conv_bwd_weight: 16-byte alignment");
     const int Q = (C0 + C1) / 16, NCO = Cdz / 16;
-    const long long ntiles = (long long)B * ((D + BWB_TD - 1) / BWB_TD) * ((H + BWB_TH - 1) / BWB_TH) * ((W + BWB_TW - 1) / BWB_TW);
-    const int NBLK = bwb_blocks(ntiles, Q);
+    int NBLK = 1;
+    const BwbTasks tk = bwb_tasks(Q, B, D, H, W, NBLK);
     VXM_REQUIRE(work_bytes >= (size_t)NBLK * Q * BWB_TD * 28 * (16 * NCO) * 16 * sizeof(float), VXM_ERR_BAD_SHAPE,
                 "vxm_bf16_conv_bwd_weight: workspace too small");
     const BfIn in = {x0, x1, C0 / 8, C1 / 8, x0_up ? 1 : 0};
     hipStream_t s = VXM_STREAM(stream);
     float* part = static_cast<float*>(work);
-    static const int stage = [] { const char* e = getenv("VXM_BF16_BWDW_STAGE"); return e ? atoi(e) : -1; }();     // developer A/B switch
     auto launch = [&](auto kern, int lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(kern, dim3(NBLK, Q), dim3(BWB_THREADS), lds, s, in, dz, part, B, D, H, W, NBLK);
+        hipLaunchKernelGGL(kern, dim3(NBLK, Q), dim3(BWB_THREADS), lds, s, in, dz, part, D, H, W, NBLK, tk);
     };
-    if (NCO == 1) {
-        if (stage == 0) launch(k_bf16_conv_bwd_weight<1, 0>, bwb_lds_bytes(1));
-        else launch(k_bf16_conv_bwd_weight<1, 1>, bwb_lds_bytes(1));
-    } else {
-        if (stage == 1) launch(k_bf16_conv_bwd_weight<2, 1>, bwb_lds_bytes(2));
-        else launch(k_bf16_conv_bwd_weight<2, 0>, bwb_lds_bytes(2));
-    }
+    if (NCO == 1) launch(k_bf16_conv_bwd_weight<1>, bwb_lds_bytes(1));
+    else launch(k_bf16_conv_bwd_weight<2>, bwb_lds_bytes(2));
     const int n = 16 * NCO * 16 * Q * 28;
     hipLaunchKernelGGL(k_bf16_reduce_partials, dim3(vxm_blocks(n, 256)), dim3(256), 0, s, part, gw, gb, Cin_w, Cout_w, Q, NCO, NBLK);
     return vxm_check_launch("vxm_bf16_conv_bwd_weight");
