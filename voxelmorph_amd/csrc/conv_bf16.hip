@@ -392,7 +392,8 @@ __global__ void __launch_bounds__(256) k_bf16_lrelu_bwd(const u32x4* __restrict_
 //    tile t and written to LDS afterwards (ring slots / the other dZ buffer): one barrier per tile;
 //  * a block owns one chunk and a contiguous range of (column, depth segment) tasks; its accumulators are written once, as
 //    partials that k_bf16_reduce_partials sums in a fixed order (deterministic).
-constexpr int BWB_WAVES = 6, BWB_THREADS = 64 * BWB_WAVES;
+constexpr int BWB_WAVES = 6;                                                       // per output-channel tile: (depth slice, kd)
+constexpr int bwb_threads(int nco) { return 64 * BWB_WAVES * nco; }
 constexpr int BWB_TD = 2, BWB_TH = 8, BWB_TW = 32;
 constexpr int BWB_XW = BWB_TW + 2;                                                 // haloed row, voxels
 constexpr int BWB_PLANE = (BWB_TH + 2) * BWB_XW * 32;                              // one haloed X plane: [hh][hw][16 ci], bytes
@@ -411,14 +412,16 @@ __device__ __forceinline__ u32x2 bf_tr_read(const char* lds_base, int byte_off) 
 struct BwbTasks { int ncol, nseg, seg_len, nd, nh, nw; };       // tasks = (column (b, th, tw), depth segment), seg_len tiles each
 
 template <int NCO>
-__global__ void __launch_bounds__(BWB_THREADS, 1) k_bf16_conv_bwd_weight(BfIn in, const void* __restrict__ dz, float* __restrict__ part,
+__global__ void __launch_bounds__(bwb_threads(NCO), 1) k_bf16_conv_bwd_weight(BfIn in, const void* __restrict__ dz, float* __restrict__ part,
                                                                          int D, int H, int W, int NBLK, BwbTasks tk) {
     VXM_DYN_SMEM(char, smem);
     char* const Xs = smem;                                       // ring of 6 haloed planes
     char* const Zs = smem + BWB_RING * BWB_PLANE;                // [2 buffers][NCO][ZBYTES]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ds = wave / 3, kd = wave - 3 * ds;
+    constexpr int BWB_THREADS = bwb_threads(NCO);
+    const int cow = wave / BWB_WAVES, w6 = wave - BWB_WAVES * cow;    // this wave's output-channel tile, (depth slice, kd)
+    const int ds = w6 / 3, kd = w6 - 3 * ds;
     const int q = blockIdx.y;                                    // 16-channel chunk of the virtual concat
     const int ntask = tk.ncol * tk.nseg;
     const int k_lo = (int)((long long)ntask * blockIdx.x / NBLK), k_hi = (int)((long long)ntask * (blockIdx.x + 1) / NBLK);
@@ -431,15 +434,11 @@ __global__ void __launch_bounds__(BWB_THREADS, 1) k_bf16_conv_bwd_weight(BfIn in
     const int CBs = s0 ? in.CB0 : in.CB1, cbg = s0 ? 2 * q : 2 * q - in.CB0;
     constexpr int CBz = 2 * NCO;
 
-    f32x4 acc[3][3][NCO], accb[NCO];
+    f32x4 acc[3][3], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) {
-        accb[co] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) acc[kh][kw][co] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+        for (int kw = 0; kw < 3; ++kw) acc[kh][kw] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lp = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;     // lane pattern of the transposing read
     const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};       // bf16 1.0 x 8: B operand of the bias sum
 
@@ -513,46 +512,36 @@ __global__ void __launch_bounds__(BWB_THREADS, 1) k_bf16_conv_bwd_weight(BfIn in
         for (int t = 0; t < ntile; ++t) {
             const bool more = t + 1 < ntile;                     // wave-uniform
             const char* const xp = Xs + ((2 * t + ds + kd) % BWB_RING) * BWB_PLANE;
-            const char* const zp = Zs + (t & 1) * NCO * BWB_ZBYTES;
-            // haloed rows [r0, r1) of X plane 2 t + ds + kd: per row three kw-shifted B fragments; the A fragments (dZ rows
-            // hr, hr - 1, hr - 2) are re-read per use -- LDS has the headroom, the register file has not
-            auto rows = [&](int r0, int r1) __attribute__((always_inline)) {
+            const char* const zp = Zs + ((t & 1) * NCO + cow) * BWB_ZBYTES;
+            // the loads of tile t + 1 (2 X planes + the dZ tile) are in flight under the MFMAs of tile t
+            if (more) { load_planes(2 * t + 4); load_z(t + 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            // haloed rows of X plane 2 t + ds + kd: per row three kw-shifted B fragments; the A fragments (dZ rows hr, hr - 1,
+            // hr - 2 of this wave's output-channel tile) are re-read per use -- LDS has the headroom
 #pragma unroll
-                for (int hr = r0; hr < r1; ++hr) {
-                    u32x4 bx[3];
+            for (int hr = 0; hr < BWB_TH + 2; ++hr) {
+                u32x4 bx[3];
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) {
-                        const int xb = (hr * BWB_XW + kw) * 32 + lp;
-                        const u32x2 lo = bf_tr_read(xp, xb), hi = bf_tr_read(xp, xb + 16 * 32);
-                        bx[kw] = (u32x4){lo.x, lo.y, hi.x, hi.y};
-                    }
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh) {
-                        const int row = hr - kh;
-                        if (row >= 0 && row < BWB_TH) {
-#pragma unroll
-                            for (int co = 0; co < NCO; ++co) {
-                                const int zb = co * BWB_ZBYTES + ((ds * BWB_TH + row) * BWB_TW) * 32 + lp;
-                                const u32x2 lo = bf_tr_read(zp, zb), hi = bf_tr_read(zp, zb + 16 * 32);
-                                const u32x4 az = {lo.x, lo.y, hi.x, hi.y};
-                                if (kh == 0 && kd == 0) accb[co] = bf_mfma(az, ones, accb[co]);
-#pragma unroll
-                                for (int kw = 0; kw < 3; ++kw) acc[kh][kw][co] = bf_mfma(az, bx[kw], acc[kh][kw][co]);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);         // keep the operand reads of row hr + 1 behind this row (register budget)
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int xb = (hr * BWB_XW + kw) * 32 + lp;
+                    const u32x2 lo = bf_tr_read(xp, xb), hi = bf_tr_read(xp, xb + 16 * 32);
+                    bx[kw] = (u32x4){lo.x, lo.y, hi.x, hi.y};
                 }
-            };
-            // the loads of tile t + 1 are in flight under the MFMAs: its X planes under the first half of the rows, its dZ
-            // tile under the second (written to ring slots / the dZ buffer last read by tile t - 1)
-            if (more) load_planes(2 * t + 4);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int row = hr - kh;
+                    if (row >= 0 && row < BWB_TH) {
+                        const int zb = ((ds * BWB_TH + row) * BWB_TW) * 32 + lp;
+                        const u32x2 lo = bf_tr_read(zp, zb), hi = bf_tr_read(zp, zb + 16 * 32);
+                        const u32x4 az = {lo.x, lo.y, hi.x, hi.y};
+                        if (kh == 0 && kd == 0) accb = bf_mfma(az, ones, accb);
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) acc[kh][kw] = bf_mfma(az, bx[kw], acc[kh][kw]);
+                    }
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
-            rows(0, (BWB_TH + 2) / 2);
-            if (more) { store_planes(2 * t + 4); load_z(t + 1); }
-            __builtin_amdgcn_sched_barrier(0);
-            rows((BWB_TH + 2) / 2, BWB_TH + 2);
-            if (more) store_z(t + 1);
+            if (more) { store_planes(2 * t + 4); store_z(t + 1); }   // ring slots / dZ buffer last read by tile t - 1
             __syncthreads();
         }
     }
@@ -560,18 +549,15 @@ __global__ void __launch_bounds__(BWB_THREADS, 1) k_bf16_conv_bwd_weight(BfIn in
     // ---- partials: part[blk][q][ds][tap 0..27][co 16 NCO][ci 16]; D layout: lane (kg, n) holds co = 4 kg + r, ci = n
     float* const pp = part + ((((size_t)blockIdx.x * gridDim.y + q) * BWB_TD + ds) * 28) * (16 * NCO) * 16;
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) {
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
+            for (int r = 0; r < 4; ++r)
+                pp[((size_t)(kd * 9 + kh * 3 + kw) * (16 * NCO) + cow * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[kh][kw][r];
+    if (kd == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    pp[((size_t)(kd * 9 + kh * 3 + kw) * (16 * NCO) + co * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[kh][kw][co][r];
-        if (kd == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pp[((size_t)27 * (16 * NCO) + co * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = accb[co][r];
-        }
+        for (int r = 0; r < 4; ++r) pp[((size_t)27 * (16 * NCO) + cow * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = accb[r];
     }
 }
 
@@ -738,7 +724,7 @@ int vxm_bf16_conv_bwd_weight(const void* x0, int C0, int x0_up, const void* x1, 
     float* part = static_cast<float*>(work);
     auto launch = [&](auto kern, int lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(kern, dim3(NBLK, Q), dim3(BWB_THREADS), lds, s, in, dz, part, D, H, W, NBLK, tk);
+        hipLaunchKernelGGL(kern, dim3(NBLK, Q), dim3(bwb_threads(NCO)), lds, s, in, dz, part, D, H, W, NBLK, tk);
     };
     if (NCO == 1) launch(k_bf16_conv_bwd_weight<1>, bwb_lds_bytes(1));
     else launch(k_bf16_conv_bwd_weight<2>, bwb_lds_bytes(2));
