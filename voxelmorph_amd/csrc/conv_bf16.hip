@@ -442,9 +442,14 @@ __global__ void __launch_bounds__(bwb_threads(NCO), 1) k_bf16_conv_bwd_weight(Bf
     const int lp = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;     // lane pattern of the transposing read
     const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};       // bf16 1.0 x 8: B operand of the bias sum
 
-    constexpr int NXP = 2 * (BWB_TH + 2) * BWB_XW * 2, NXI = (NXP + BWB_THREADS - 1) / BWB_THREADS;        // two planes
+    // staging roles of a thread, fixed for the whole kernel: slot i = tid + THREADS j of one haloed X plane ([hh][hw][cb], 16 bytes)
+    // and of the dZ tile ([co][zd][zh][zw][cb]).  Per (column) task the lane offsets are rebuilt once -- H / W validity does not
+    // change down a column -- and per tile only the wave-uniform depth offset moves: a few VALU per load instead of ~40.
+    constexpr int NXP = (BWB_TH + 2) * BWB_XW * 2, NXI = (NXP + BWB_THREADS - 1) / BWB_THREADS;             // one plane
     constexpr int NZ = BWB_TD * BWB_TH * BWB_TW * 2, NZI = (NZ * NCO + BWB_THREADS - 1) / BWB_THREADS;
-    u32x4 xv[NXI], zv[NZI];
+    u32x4 xv[2][NXI], zv[NZI];
+    int xoff[NXI], zoff[NZI];                                    // byte offsets inside a depth slice of the tensor (VXM_OOB: padding)
+    const int HWs = up ? Hl * Wl : H * W;                        // voxels per depth slice of the X source
 
     for (int task = k_lo; task < k_hi; ++task) {
         const int col = task / tk.nseg, seg = task - col * tk.nseg;
@@ -454,50 +459,59 @@ __global__ void __launch_bounds__(bwb_threads(NCO), 1) k_bf16_conv_bwd_weight(Bf
         const int dbase = td0 * BWB_TD, h0 = th * BWB_TH, w0 = tw * BWB_TW;
         const __amdgpu_buffer_rsrc_t rx = bf_rsrc(static_cast<const char*>(s0 ? in.x0 : in.x1) + (size_t)b * CBs * Vs * 16, (unsigned)CBs * (unsigned)Vs * 16u);
         const __amdgpu_buffer_rsrc_t rz = bf_rsrc(static_cast<const char*>(dz) + (size_t)b * CBz * V * 16, (unsigned)CBz * (unsigned)V * 16u);
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) {
+            const int i = tid + BWB_THREADS * j;
+            const int cb = i & 1, v = i >> 1, hh = v / BWB_XW, hw = v - hh * BWB_XW;
+            const int gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+            const bool ok = i < NXP && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            xoff[j] = !ok ? VXM_OOB : ((cbg + cb) * Vs + (up ? (gh >> 1) * Wl + (gw >> 1) : gh * W + gw)) << 4;
+        }
+#pragma unroll
+        for (int j = 0; j < NZI; ++j) {
+            const int i = tid + BWB_THREADS * j;
+            const int co = i / NZ, r = i - co * NZ;
+            const int cb = r & 1, v = r >> 1;
+            const int zd = v / (BWB_TH * BWB_TW), r2 = v - zd * BWB_TH * BWB_TW, zh = r2 / BWB_TW, zw = r2 - zh * BWB_TW;
+            const bool ok = i < NZ * NCO && h0 + zh < H && w0 + zw < W;
+            // depth validity: the tile's second slice (zd = 1) may lie beyond D -- folded in per tile through `zlast`
+            zoff[j] = !ok ? VXM_OOB : (((2 * co + cb) * V + (zd * H + h0 + zh) * W + w0 + zw) << 4) | zd;      // bit 0: depth slice of the slot
+        }
 
         // planes p0, p0 + 1 of this task (plane p = global depth dbase - 1 + p) -> registers / -> ring slots p % 6
         auto load_planes = [&](int p0) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NXI; ++j) {
-                const int i = tid + BWB_THREADS * j;
-                const int cb = i & 1, v = i >> 1;
-                const int pl = v / ((BWB_TH + 2) * BWB_XW), r2 = v - pl * (BWB_TH + 2) * BWB_XW, hh = r2 / BWB_XW, hw = r2 - hh * BWB_XW;
-                const int gd = dbase - 1 + p0 + pl, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-                const bool ok = i < NXP && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-                const int vox = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
-                xv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? vox << 4 : VXM_OOB, (cbg + cb) * Vs * 16, 0));
+            for (int pl = 0; pl < 2; ++pl) {
+                const int gd = dbase - 1 + p0 + pl;                 // wave-uniform
+                const bool dok = (unsigned)gd < (unsigned)D;
+                const int soff = dok ? ((up ? gd >> 1 : gd) * HWs) << 4 : 0;
+#pragma unroll
+                for (int j = 0; j < NXI; ++j)
+                    xv[pl][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, dok ? xoff[j] : VXM_OOB, soff, 0));
             }
         };
         auto store_planes = [&](int p0) __attribute__((always_inline)) {
-            const int sl0 = p0 % BWB_RING, sl1 = (p0 + 1) % BWB_RING;
 #pragma unroll
-            for (int j = 0; j < NXI; ++j) {
-                const int i = tid + BWB_THREADS * j;
-                if (i < NXP) {
-                    const int pl = i / ((BWB_TH + 2) * BWB_XW * 2), r = i - pl * (BWB_TH + 2) * BWB_XW * 2;
-                    *reinterpret_cast<u32x4*>(Xs + (pl ? sl1 : sl0) * BWB_PLANE + r * 16) = xv[j];
-                }
+            for (int pl = 0; pl < 2; ++pl) {
+                char* const dst = Xs + ((p0 + pl) % BWB_RING) * BWB_PLANE;
+#pragma unroll
+                for (int j = 0; j < NXI; ++j)
+                    if (tid + BWB_THREADS * j < NXP) *reinterpret_cast<u32x4*>(dst + (tid + BWB_THREADS * j) * 16) = xv[pl][j];
             }
         };
         auto load_z = [&](int t) __attribute__((always_inline)) {
+            const int gd = dbase + t * BWB_TD;                      // first depth slice of the tile (always < D)
+            const bool zlast = gd + 1 < D;
+            const int soff = (gd * H * W) << 4;
 #pragma unroll
-            for (int j = 0; j < NZI; ++j) {
-                const int i = tid + BWB_THREADS * j;
-                const int co = i / NZ, r = i - co * NZ;
-                const int cb = r & 1, v = r >> 1;
-                const int zd = v / (BWB_TH * BWB_TW), r2 = v - zd * BWB_TH * BWB_TW, zh = r2 / BWB_TW, zw = r2 - zh * BWB_TW;
-                const int gd = dbase + t * BWB_TD + zd, gh = h0 + zh, gw = w0 + zw;
-                const bool ok = i < NZ * NCO && gd < D && gh < H && gw < W;
-                zv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, ok ? ((gd * H + gh) * W + gw) << 4 : VXM_OOB, (2 * co + cb) * V * 16, 0));
-            }
+            for (int j = 0; j < NZI; ++j)
+                zv[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, ((zoff[j] & 1) && !zlast) ? VXM_OOB : (zoff[j] & ~15), soff, 0));
         };
         auto store_z = [&](int t) __attribute__((always_inline)) {
             char* const zb = Zs + (t & 1) * NCO * BWB_ZBYTES;
 #pragma unroll
-            for (int j = 0; j < NZI; ++j) {
-                const int i = tid + BWB_THREADS * j;
-                if (i < NZ * NCO) *reinterpret_cast<u32x4*>(zb + i * 16) = zv[j];
-            }
+            for (int j = 0; j < NZI; ++j)
+                if (tid + BWB_THREADS * j < NZ * NCO) *reinterpret_cast<u32x4*>(zb + (tid + BWB_THREADS * j) * 16) = zv[j];
         };
 
         __syncthreads();                                        // every wave is done with the previous task
