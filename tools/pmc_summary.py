@@ -7,6 +7,9 @@ import glob
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rocprof_summary import short as _short  # noqa: E402
+
 root = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 agg = collections.OrderedDict()
@@ -16,8 +19,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), r
         name = r["Kernel_Name"]
         if flt and flt not in name:
             continue
-        short = name.split("(")[0].split("::")[-1][:48]
-        key = (short, r["Grid_Size"], r["Dispatch_Id"])
+        short = _short(name)[:60]
         agg.setdefault((short, r["Grid_Size"]), collections.OrderedDict()).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 for (short, grid), ctrs in agg.items():
     print("%s grid=%s" % (short, grid))
@@ -30,7 +32,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursi
         name = r["Kernel_Name"]
         if flt and flt not in name:
             continue
-        short = name.split("(")[0].split("::")[-1][:48]
+        short = _short(name)[:60]
         dur.setdefault((short, r["Grid_Size"]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     for (short, grid), v in dur.items():
         print("%s grid=%s  n=%d  avg %.1f us  min %.1f us" % (short, grid, len(v), sum(v) / len(v), min(v)))
