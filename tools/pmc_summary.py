@@ -25,6 +25,8 @@ for (short, grid), ctrs in agg.items():
     print("%s grid=%s" % (short, grid))
     for c, vals in ctrs.items():
         print("    %-40s n=%d mean=%.4g" % (c, len(vals), sum(vals) / len(vals)))
+        if os.environ.get("PMC_PER_DISPATCH") and c in ("FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES"):
+            print("        per dispatch: " + " ".join("%.4g" % v for v in vals))
 # kernel durations from the kernel trace, if present
 for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True))[:1]:
     dur = collections.OrderedDict()
@@ -33,6 +35,6 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursi
         if flt and flt not in name:
             continue
         short = _short(name)[:60]
-        dur.setdefault((short, r["Grid_Size"]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        dur.setdefault((short, r.get("Grid_Size", r.get("Grid_Size_X", "?"))), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     for (short, grid), v in dur.items():
         print("%s grid=%s  n=%d  avg %.1f us  min %.1f us" % (short, grid, len(v), sum(v) / len(v), min(v)))

@@ -47,12 +47,14 @@ constexpr int bf_lds_bytes(int nct, int rows) { return 2 * bf_cbs(rows) + bf_wch
 
 // OUT: 0 = blocked bf16 (bias + LeakyReLU, optional LeakyReLU' mask of the previous block = fused leaky_relu_backward),
 //      1 = planar fp32 [B][Cout<=4][D][H][W] (the flow head: bias only)
-// Persistent blocks (two per CU) walk a contiguous range of 8 x ROWS x 16 tiles; the sequence of (tile, 16-channel chunk)
+// Persistent blocks (16 -> 16 channel tiles: two per CU, 128 VGPRs; 32 output channels: ONE per CU with 8 x 8 x 16 tiles, 64
+// accumulator VGPRs and a 256-VGPR budget -- with 4 rows and two blocks per CU the kernel spilled into scratch inside the stage
+// loop, which cost more HBM traffic than the tile itself) walk a contiguous range of 8 x ROWS x 16 tiles; the sequence of (tile, 16-channel chunk)
 // stages is software-pipelined: the global loads of stage s + 1 (haloed tile of the chunk, its packed weights) are in flight in
 // registers under the MFMAs of stage s and reach LDS between two barriers.  A thread stages the same (row, column) of every
 // haloed plane, so its lane offset is computed once per tile and the (block, depth) part of the address is wave-uniform.
 template <int NCT, int ROWS, int OUT>
-__global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
+__global__ void __launch_bounds__(BF_THREADS, NCT == 2 ? 2 : 4) k_bf16_conv(BfIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                           void* __restrict__ y, int Cout, float act_slope, const void* __restrict__ mask,
                                                           float mask_slope, int B, int D, int H, int W, int Q, int NBX) {
     VXM_DYN_SMEM(u32x4, smem);
@@ -690,8 +692,8 @@ void bf_launch_conv(const BfIn& in, const void* wp, const float* bias, void* y, 
     const int Q = (in.CB0 + in.CB1) / 2;
     const long long ntiles = (long long)B * ((D + BF_TD - 1) / BF_TD) * ((H + ROWS - 1) / ROWS) * ((W + 15) / 16);
     const int G = (Cout + 16 * NCT - 1) / (16 * NCT);
-    // two resident blocks per CU, each walking ~4+ tiles (a shorter walk only when there are few tiles)
-    long long nbx = 2ll * bwb_cus() / G;
+    // resident blocks per CU (see the kernel), each walking ~4+ tiles (a shorter walk only when there are few tiles)
+    long long nbx = (NCT == 2 ? 1ll : 2ll) * bwb_cus() / G;
     if (nbx > ntiles) nbx = ntiles;
     if (nbx >= 8) nbx = nbx / 8 * 8;
     if (nbx < 1) nbx = 1;
@@ -776,7 +778,7 @@ int vxm_bf16_conv_fwd(const void* x0, int C0, int x0_up, const void* x1, int C1,
     hipStream_t s = VXM_STREAM(stream);
     if (out_planar_f32) bf_launch_conv<1, 8, 1>(in, wpacked, bias, y, Cout, leaky_slope, nullptr, 1.0f, B, D, H, W, s);
     else if (bf_nct(Cout) == 1) bf_launch_conv<1, 8, 0>(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
-    else bf_launch_conv<2, 4, 0>(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
+    else bf_launch_conv<2, 8, 0>(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
     return vxm_check_launch("vxm_bf16_conv_fwd");
 }
 
