@@ -47,91 +47,44 @@ constexpr int bf_lds_bytes(int nct, int rows) { return 2 * bf_cbs(rows) + bf_wch
 
 // OUT: 0 = blocked bf16 (bias + LeakyReLU, optional LeakyReLU' mask of the previous block = fused leaky_relu_backward),
 //      1 = planar fp32 [B][Cout<=4][D][H][W] (the flow head: bias only)
-// Persistent blocks (16 -> 16 channel tiles: two per CU, 128 VGPRs; 32 output channels: ONE per CU with 8 x 8 x 16 tiles, 64
-// accumulator VGPRs and a 256-VGPR budget -- with 4 rows and two blocks per CU the kernel spilled into scratch inside the stage
-// loop, which cost more HBM traffic than the tile itself) walk a contiguous range of 8 x ROWS x 16 tiles; the sequence of (tile, 16-channel chunk)
-// stages is software-pipelined: the global loads of stage s + 1 (haloed tile of the chunk, its packed weights) are in flight in
-// registers under the MFMAs of stage s and reach LDS between two barriers.  A thread stages the same (row, column) of every
-// haloed plane, so its lane offset is computed once per tile and the (block, depth) part of the address is wave-uniform.
 template <int NCT, int ROWS, int OUT>
-__global__ void __launch_bounds__(BF_THREADS, NCT == 2 ? 2 : 4) k_bf16_conv(BfIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
+__global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                           void* __restrict__ y, int Cout, float act_slope, const void* __restrict__ mask,
-                                                          float mask_slope, int B, int D, int H, int W, int Q, int NBX) {
+                                                          float mask_slope, int B, int D, int H, int W, int Q) {
     VXM_DYN_SMEM(u32x4, smem);
     constexpr int HR = ROWS + 2, CBS = bf_cbs(ROWS) / 16, PLANE = HR * BF_HWV;     // in 16-byte words
-    constexpr int PG = BF_THREADS / PLANE, NPL = (BF_TD + 2 + PG - 1) / PG;         // planes staged per pass, passes per block of 8 channels
+    constexpr int NSLOT = 2 * (BF_TD + 2) * PLANE, NI = (NSLOT + BF_THREADS - 1) / BF_THREADS;
     constexpr int WCH = bf_wchunk(NCT), WIT = (WCH + BF_THREADS - 1) / BF_THREADS;
     u32x4* const Xs = smem;                 // [2][CBS]: [cb][hd][hr][hw]
     u32x4* const Ws = smem + 2 * CBS;       // [5][3][NCT][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = lane >> 4, n = lane & 15;
-    const int g = blockIdx.y;
 
-    // tile range of this block: block b runs on XCD b % 8 (observed; speed only); the blocks of one XCD take neighbouring ranges
+    // tile of this block: block b runs on XCD b % 8 (observed; speed only), XCD x takes a contiguous tile range
     const int nw = (W + 15) / 16, nh = (H + ROWS - 1) / ROWS, nd = (D + BF_TD - 1) / BF_TD;
     const int ntiles = B * nd * nh * nw;
-    const int lb = (NBX & 7) == 0 ? (int)(blockIdx.x & 7) * (NBX >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int t_lo = (int)((long long)ntiles * lb / NBX), t_hi = (int)((long long)ntiles * (lb + 1) / NBX);
-    if (t_lo >= t_hi) return;
+    int tile = blockIdx.x;
+    if (ntiles >= 64) {
+        const int x = tile & 7, j = tile >> 3;
+        const int lo = (int)((long long)ntiles * x / 8), hi = (int)((long long)ntiles * (x + 1) / 8);
+        tile = lo + j;
+        if (tile >= hi) return;
+    } else if (tile >= ntiles) {
+        return;
+    }
+    const int tw = tile % nw; int tq = tile / nw;
+    const int th = tq % nh; tq /= nh;
+    const int td = tq % nd; const int b = tq / nd;
+    const int d0 = td * BF_TD, h0 = th * ROWS, w0 = tw * 16;
+    const int g = blockIdx.y;
 
-    const int V = D * H * W, HWf = H * W;
+    const int V = D * H * W;
     const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
     const int V0 = in.up0 ? Dl * Hl * Wl : V;
-
-    // staging role: plane group sp (planes sp, sp + PG, ...), slot sr = (row, column) inside a haloed plane
-    const int sp = tid / PLANE, sr = tid - sp * PLANE, shh = sr / BF_HWV, shw = sr - shh * BF_HWV;
-    const bool sact = sp < PG;
-
-    struct Tile { int b, d0, h0, w0; };
-    auto decode = [&](int tile) __attribute__((always_inline)) -> Tile {
-        const int tw = tile % nw; int tq = tile / nw;
-        const int th = tq % nh; tq /= nh;
-        const int td = tq % nd;
-        return Tile{tq / nd, td * BF_TD, th * ROWS, tw * 16};
-    };
-
-    u32x4 xv[2 * NPL], wv[WIT];
-    // loads of stage (tile T, chunk q) -> registers
-    auto load_stage = [&](const Tile& T, int q, bool with_w) __attribute__((always_inline)) {
-        const bool s0 = 2 * q < in.CB0;
-        const bool up = s0 && in.up0;
-        const int CBs = s0 ? in.CB0 : in.CB1, cbg = s0 ? 2 * q : 2 * q - in.CB0;
-        const int Vs = up ? V0 : V, HWs = up ? Hl * Wl : HWf;
-        const __amdgpu_buffer_rsrc_t r = bf_rsrc(static_cast<const char*>(s0 ? in.x0 : in.x1) + (size_t)T.b * CBs * Vs * 16, (unsigned)CBs * (unsigned)Vs * 16u);
-        const int gh = T.h0 - 1 + shh, gw = T.w0 - 1 + shw;
-        const bool ok = sact && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-        const int voff = !ok ? VXM_OOB : (up ? (gh >> 1) * Wl + (gw >> 1) : gh * W + gw) << 4;
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) {
-                const int hd = sp + PG * k;                   // per-thread plane; its validity is folded into the lane offset
-                const int gd = T.d0 - 1 + hd;
-                const bool dok = hd < BF_TD + 2 && (unsigned)gd < (unsigned)D;
-                const int gds = dok ? (up ? gd >> 1 : gd) : 0;
-                xv[cb * NPL + k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, dok ? voff + ((gds * HWs) << 4) : VXM_OOB, (cbg + cb) * Vs * 16, 0));
-            }
-        if (with_w) {
-            const __amdgpu_buffer_rsrc_t rw = bf_rsrc(wp + ((size_t)g * Q + q) * WCH, WCH * 16u);
-#pragma unroll
-            for (int it = 0; it < WIT; ++it) wv[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + BF_THREADS * it) * 16, 0, 0));
-        }
-    };
-    auto store_stage = [&](bool with_w) __attribute__((always_inline)) {
-        if (sact) {
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int k = 0; k < NPL; ++k)
-                    if (sp + PG * k < BF_TD + 2) Xs[cb * CBS + (sp + PG * k) * PLANE + sr] = xv[cb * NPL + k];
-        }
-        if (with_w) {
-#pragma unroll
-            for (int it = 0; it < WIT; ++it)
-                if (tid + BF_THREADS * it < WCH) Ws[tid + BF_THREADS * it] = wv[it];
-        }
-    };
+    const __amdgpu_buffer_rsrc_t r0 = bf_rsrc(static_cast<const char*>(in.x0) + (size_t)b * in.CB0 * V0 * 16, (unsigned)in.CB0 * (unsigned)V0 * 16u);
+    const __amdgpu_buffer_rsrc_t r1 = bf_rsrc(in.CB1 ? static_cast<const char*>(in.x1) + (size_t)b * in.CB1 * V * 16 : in.x0,
+                                              (unsigned)in.CB1 * (unsigned)V * 16u);
 
     f32x4 acc[NCT][ROWS];
 #pragma unroll
@@ -148,108 +101,109 @@ __global__ void __launch_bounds__(BF_THREADS, NCT == 2 ? 2 : 4) k_bf16_conv(BfIn
         xoff[s] = cb * CBS + (wave + kd) * PLANE + kw + n;
     }
 
-    Tile cur = decode(t_lo);
-    load_stage(cur, 0, true);
-    store_stage(true);
-    __syncthreads();
-    for (int tile = t_lo; tile < t_hi; ++tile) {
-        Tile nxt = cur;
-        for (int q = 0; q < Q; ++q) {
-            const bool last_q = q + 1 == Q;
-            const bool more = !last_q || tile + 1 < t_hi;      // wave-uniform: a stage follows
-            const bool next_w = Q > 1;                          // a single chunk: its weights stay in LDS for every tile
-            if (more) {
-                if (last_q) nxt = decode(tile + 1);
-                load_stage(last_q ? nxt : cur, last_q ? 0 : q + 1, next_w);     // in flight under the MFMAs below
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- 5 K-steps x (ROWS + 2) haloed rows: one B read per row, up to 3 NCT MFMAs per read
+    for (int q = 0; q < Q; ++q) {
+        // ---- stage chunk q: 2 blocks x haloed tile, 16 bytes per slot, zero padding through the buffer descriptor
+        const bool s0 = 2 * q < in.CB0;
+        const bool up = s0 && in.up0;
+        const __amdgpu_buffer_rsrc_t r = s0 ? r0 : r1;
+        const int cbg = s0 ? 2 * q : 2 * q - in.CB0;
+        const int Vs = up ? V0 : V;
+        if (q) __syncthreads();                         // every wave is done reading chunk q - 1
 #pragma unroll
-            for (int s = 0; s < BF_STEPS; ++s) {
-                u32x4 a[3][NCT];
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) a[kh][ct] = Ws[((s * 3 + kh) * NCT + ct) * 64 + lane];
-#pragma unroll
-                for (int hr = 0; hr < HR; ++hr) {
-                    const u32x4 bf = Xs[xoff[s] + hr * BF_HWV];
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh) {
-                        const int row = hr - kh;
-                        if (row >= 0 && row < ROWS) {
-#pragma unroll
-                            for (int ct = 0; ct < NCT; ++ct) acc[ct][row] = bf_mfma(a[kh][ct], bf, acc[ct][row]);
-                        }
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (last_q) {
-                // ---- epilogue of the tile.  D layout: lane (kg, n) holds output channels 16 ct + 4 kg + j (j = 0..3) of voxel
-                // (d, h0 + row, w0 + n).
-                const int d = cur.d0 + wave, w = cur.w0 + n, h0 = cur.h0, b = cur.b;
-                const bool vok = d < D && w < W;
-                if constexpr (OUT == 1) {
-                    float* const yp = static_cast<float*>(y) + (size_t)b * Cout * V;
-                    if (kg == 0 && vok) {
-#pragma unroll
-                        for (int row = 0; row < ROWS; ++row)
-                            if (h0 + row < H) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    if (j < Cout) {
-                                        float v = acc[0][row][j] + (bias ? bias[j] : 0.0f);
-                                        v = v > 0.0f ? v : v * act_slope;
-                                        yp[(size_t)j * V + (d * H + h0 + row) * W + w] = v;
-                                    }
-                            }
-                    }
-                } else {
-                    const int CBo = Cout >> 3;
-                    const __amdgpu_buffer_rsrc_t ry = bf_rsrc(static_cast<char*>(y) + (size_t)b * CBo * V * 16, (unsigned)CBo * (unsigned)V * 16u);
-                    const __amdgpu_buffer_rsrc_t rm = bf_rsrc(mask ? static_cast<const char*>(mask) + (size_t)b * CBo * V * 16 : y, (unsigned)CBo * (unsigned)V * 16u);
-#pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) {
-                        const int co = (g * NCT + ct) * 16 + 4 * kg;           // first of this lane's 4 channels
-                        const int pb = co >> 3;                                // its 8-channel block
-                        const bool cok = vok && pb < CBo;
-                        float bz[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) bz[j] = (bias && co + j < Cout) ? bias[co + j] : 0.0f;
-#pragma unroll
-                        for (int row = 0; row < ROWS; ++row) {
-                            if (h0 + row < H) {                                // wave-uniform
-                                const int voff = cok ? (((pb * D + d) * H + h0 + row) * W + w) * 16 + (kg & 1) * 8 : VXM_OOB;
-                                float v[4];
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    v[j] = acc[ct][row][j] + bz[j];
-                                    v[j] = v[j] > 0.0f ? v[j] : v[j] * act_slope;
-                                }
-                                if (mask) {
-                                    const u32x2 m = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, voff, 0, 0));
-                                    v[0] *= vxm_lrelu_grad(bf_lo(m.x), mask_slope); v[1] *= vxm_lrelu_grad(bf_hi(m.x), mask_slope);
-                                    v[2] *= vxm_lrelu_grad(bf_lo(m.y), mask_slope); v[3] *= vxm_lrelu_grad(bf_hi(m.y), mask_slope);
-                                }
-                                const u32x2 o = {bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3])};
-                                __builtin_amdgcn_raw_buffer_store_b64(o, ry, voff, 0, 0);
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                    for (int r = 0; r < ROWS; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            if (more) {
-                __syncthreads();                            // every wave is done reading this stage
-                store_stage(next_w);
-                __syncthreads();
+        for (int j = 0; j < NI; ++j) {
+            const int i = tid + BF_THREADS * j;
+            if (i < NSLOT) {
+                const int cb = i / ((BF_TD + 2) * PLANE), rem = i - cb * (BF_TD + 2) * PLANE;
+                const int hd = rem / PLANE, r2 = rem - hd * PLANE, hh = r2 / BF_HWV, hw = r2 - hh * BF_HWV;
+                const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+                const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+                const int vox = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
+                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? vox << 4 : VXM_OOB, (cbg + cb) * Vs * 16, 0));
+                Xs[cb * CBS + rem] = v;
             }
         }
-        cur = nxt;
+        const __amdgpu_buffer_rsrc_t rw = bf_rsrc(wp + ((size_t)g * Q + q) * WCH, WCH * 16u);
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = tid + BF_THREADS * it;
+            if (i < WCH) Ws[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, i * 16, 0, 0));
+        }
+        __syncthreads();
+
+        // ---- 5 K-steps x (ROWS + 2) haloed rows: one B read per row, up to 3 NCT MFMAs per read
+#pragma unroll
+        for (int s = 0; s < BF_STEPS; ++s) {
+            u32x4 a[3][NCT];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) a[kh][ct] = Ws[((s * 3 + kh) * NCT + ct) * 64 + lane];
+#pragma unroll
+            for (int hr = 0; hr < HR; ++hr) {
+                const u32x4 bf = Xs[xoff[s] + hr * BF_HWV];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int row = hr - kh;
+                    if (row >= 0 && row < ROWS) {
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) acc[ct][row] = bf_mfma(a[kh][ct], bf, acc[ct][row]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue.  D layout: lane (kg, n) holds output channels 16 ct + 4 kg + j (j = 0..3) of voxel (d, h0 + row, w0 + n).
+    const int d = d0 + wave, w = w0 + n;
+    const bool vok = d < D && w < W;
+    if constexpr (OUT == 1) {
+        float* const yp = static_cast<float*>(y) + (size_t)b * Cout * V;
+        if (kg == 0 && vok) {
+#pragma unroll
+            for (int row = 0; row < ROWS; ++row)
+                if (h0 + row < H) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < Cout) {
+                            float v = acc[0][row][j] + (bias ? bias[j] : 0.0f);
+                            v = v > 0.0f ? v : v * act_slope;
+                            yp[(size_t)j * V + (d * H + h0 + row) * W + w] = v;
+                        }
+                }
+        }
+        return;
+    } else {
+    const int CBo = Cout >> 3;
+    const __amdgpu_buffer_rsrc_t ry = bf_rsrc(static_cast<char*>(y) + (size_t)b * CBo * V * 16, (unsigned)CBo * (unsigned)V * 16u);
+    const __amdgpu_buffer_rsrc_t rm = bf_rsrc(mask ? static_cast<const char*>(mask) + (size_t)b * CBo * V * 16 : y, (unsigned)CBo * (unsigned)V * 16u);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const int co = (g * NCT + ct) * 16 + 4 * kg;           // first of this lane's 4 channels
+        const int pb = co >> 3;                                // its 8-channel block
+        const bool cok = vok && pb < CBo;
+        float bz[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bz[j] = (bias && co + j < Cout) ? bias[co + j] : 0.0f;
+#pragma unroll
+        for (int row = 0; row < ROWS; ++row) {
+            if (h0 + row < H) {                                // wave-uniform
+                const int voff = cok ? (((pb * D + d) * H + h0 + row) * W + w) * 16 + (kg & 1) * 8 : VXM_OOB;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = acc[ct][row][j] + bz[j];
+                    v[j] = v[j] > 0.0f ? v[j] : v[j] * act_slope;
+                }
+                if (mask) {
+                    const u32x2 m = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, voff, 0, 0));
+                    v[0] *= vxm_lrelu_grad(bf_lo(m.x), mask_slope); v[1] *= vxm_lrelu_grad(bf_hi(m.x), mask_slope);
+                    v[2] *= vxm_lrelu_grad(bf_lo(m.y), mask_slope); v[3] *= vxm_lrelu_grad(bf_hi(m.y), mask_slope);
+                }
+                const u32x2 o = {bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3])};
+                __builtin_amdgcn_raw_buffer_store_b64(o, ry, voff, 0, 0);
+            }
+        }
+    }
     }
 }
 
@@ -679,7 +633,6 @@ int bf_check(const char* fn, int C0, int C1, int up0, int Cout, int B, int D, in
 int bf_nct(int OutC) { return OutC <= 16 ? 1 : 2; }
 bool bf_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-int bwb_cus();
 template <int NCT, int ROWS, int OUT>
 void bf_launch_conv(const BfIn& in, const void* wp, const float* bias, void* y, int Cout, float slope, const void* mask, float mask_slope,
                     int B, int D, int H, int W, hipStream_t s) {
@@ -691,14 +644,10 @@ void bf_launch_conv(const BfIn& in, const void* wp, const float* bias, void* y, 
     (void)attr;
     const int Q = (in.CB0 + in.CB1) / 2;
     const long long ntiles = (long long)B * ((D + BF_TD - 1) / BF_TD) * ((H + ROWS - 1) / ROWS) * ((W + 15) / 16);
+    const unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
     const int G = (Cout + 16 * NCT - 1) / (16 * NCT);
-    // resident blocks per CU (see the kernel), each walking ~4+ tiles (a shorter walk only when there are few tiles)
-    long long nbx = (NCT == 2 ? 1ll : 2ll) * bwb_cus() / G;
-    if (nbx > ntiles) nbx = ntiles;
-    if (nbx >= 8) nbx = nbx / 8 * 8;
-    if (nbx < 1) nbx = 1;
-    hipLaunchKernelGGL((k_bf16_conv<NCT, ROWS, OUT>), dim3((unsigned)nbx, G), dim3(BF_THREADS), bf_lds_bytes(NCT, ROWS), s, in,
-                       static_cast<const u32x4*>(wp), bias, y, Cout, slope, mask, mask_slope, B, D, H, W, Q, (int)nbx);
+    hipLaunchKernelGGL((k_bf16_conv<NCT, ROWS, OUT>), dim3(gx, G), dim3(BF_THREADS), bf_lds_bytes(NCT, ROWS), s, in,
+                       static_cast<const u32x4*>(wp), bias, y, Cout, slope, mask, mask_slope, B, D, H, W, Q);
 }
 
 int bwb_cus() {
@@ -778,7 +727,7 @@ int vxm_bf16_conv_fwd(const void* x0, int C0, int x0_up, const void* x1, int C1,
     hipStream_t s = VXM_STREAM(stream);
     if (out_planar_f32) bf_launch_conv<1, 8, 1>(in, wpacked, bias, y, Cout, leaky_slope, nullptr, 1.0f, B, D, H, W, s);
     else if (bf_nct(Cout) == 1) bf_launch_conv<1, 8, 0>(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
-    else bf_launch_conv<2, 8, 0>(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
+    else bf_launch_conv<2, 4, 0>(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
     return vxm_check_launch("vxm_bf16_conv_fwd");
 }
 

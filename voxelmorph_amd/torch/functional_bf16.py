@@ -60,7 +60,7 @@ def pack_weights(w, ci_lo, ci_n, flip):
 
 def conv(x0, c0, up0, x1, c1, wp, bias, y, cout, planar, slope, mask, mask_slope, B, D, H, W):
     nct = 1 if (planar or cout <= 16) else 2
-    with _prof.region("k_bf16_conv<%d,8,%d>" % (nct, 1 if planar else 0),
+    with _prof.region("k_bf16_conv<%d,%d,%d>" % (nct, 4 if nct == 2 else 8, 1 if planar else 0),
                       flops=2.0 * 27 * (c0 + c1) * (16 * nct * ((cout + 16 * nct - 1) // (16 * nct))) * B * D * H * W,
                       nominal=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_bf16_conv_fwd", ptr(x0), c0, 1 if up0 else 0, ptr(x1), c1, ptr(wp), ptr(bias), ptr(y), cout, 1 if planar else 0,
