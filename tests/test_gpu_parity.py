@@ -1098,3 +1098,49 @@ def test_native_comm_world_one(vxm):
             c.all_reduce_sum(torch.zeros(4))
     finally:
         c.destroy()
+
+
+_COMM_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from voxelmorph_amd.comm import NativeComm
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(0)                                   # both ranks on the one GPU of this box
+dist.init_process_group("gloo", rank=rank, world_size=world)   # rendezvous only: carries the 128-byte unique id
+comm = NativeComm.try_from_torch_dist()
+if comm is None:
+    print("rank", rank, "native communicator refused (two ranks on one device): fell back together")
+else:
+    t = torch.full((327331,), float(rank + 1), device="cuda")
+    comm.all_reduce_sum(t)
+    torch.cuda.synchronize()
+    assert float(t.min()) == float(t.max()) == 3.0
+    b = torch.full((16,), float(rank), device="cuda")
+    comm.broadcast(b, 1)
+    torch.cuda.synchronize()
+    assert float(b.max()) == 1.0
+    comm.destroy()
+    print("rank", rank, "native all-reduce over", world, "ranks ok")
+dist.barrier()
+"""
+
+
+def test_native_comm_two_ranks_agree(vxm, tmp_path):
+    """libvxm_comm.so beyond one rank, as far as a 1-GPU box allows: two processes create the communicator through
+    `NativeComm.try_from_torch_dist` (what `dist.native_comm()` uses for every multi-rank job).  Either RCCL accepts two ranks
+    on one device and the SUM all-reduce / broadcast of the 1.31 MB bucket are checked, or it refuses and BOTH ranks drop the
+    communicator together (the job would continue on torch.distributed) -- never a hang, never a split decision."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(tmp_path, "comm_worker.py")
+    with open(script, "w") as f:
+        f.write(_COMM_WORKER % dict(root=root))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29553", script], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    ok, refused = out.stdout.count("ranks ok"), out.stdout.count("fell back together")
+    print(out.stdout.strip().splitlines()[-2:])
+    assert (ok, refused) in ((2, 0), (0, 2)), out.stdout[-2000:]
