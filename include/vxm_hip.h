@@ -82,6 +82,10 @@ size_t vxm_conv3d_k3_packed_elems(int Cin, int Cout);
  * (backward-data) operator, i.e. w'[ci][co][t] = w[co][ci][26-t], packed as a Cout->Cin conv. */
 int vxm_conv3d_k3_pack_weights(const float* w, float* wpacked, int Cin, int Cout, int transpose_flip,
                                void* stream);
+/* the same for the input-channel sub-range [ci_lo, ci_lo + ci_n) of w (row stride Cw_in): the operator on those inputs, or with
+ * transpose_flip its adjoint onto them (backward-data of one segment of a concatenated input) -- no sliced copy of w needed */
+int vxm_conv3d_k3_pack_weights_range(const float* w, float* wpacked, int Cw_in, int Cout, int ci_lo, int ci_n, int transpose_flip,
+                                     void* stream);
 int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
                       const float* x1, int C1, int64_t x1_bstride,
                       const float* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout,

@@ -28,6 +28,7 @@ SIGNATURES = {
     "vxm_resize3d_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "vxm_conv3d_k3_packed_elems": [_I, _I],
     "vxm_conv3d_k3_pack_weights": [_P, _P, _I, _I, _I, _P],
+    "vxm_conv3d_k3_pack_weights_range": [_P, _P, _I, _I, _I, _I, _I, _P],
     "vxm_conv3d_k3_fwd": [_P, _I, _L, _I, _P, _I, _L, _P, _P, _P, _L, _I, _F, _P, _L, _F, _I, _I, _I, _I, _P],
     "vxm_conv3d_k3_up_ok": [_P, _I, _L, _P, _I, _L, _P, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_up_packed_elems": [_I, _I, _I],

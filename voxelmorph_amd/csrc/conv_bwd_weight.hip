@@ -680,32 +680,35 @@ __global__ void __launch_bounds__(256) k_reduce_partials_up_map(const float* __r
 // the bias partials live in the chunk-0 combos.
 // swapflip: the partials are those of the role-swapped product (see vxm_conv3d_k3_bwd_weight): element (co' = ci, ci' = co, t)
 // goes to gw[co][ci][26 - t].
-__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb,
-                                                         int n, int Cin, int Cout, int T, int Qc, int G, int cog_size, int swapflip,
-                                                         int gw_cin, int ci_off) {
-    __shared__ float red[4][64];
+__global__ void __launch_bounds__(1024) k_reduce_partials(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb,
+                                                          int n, int Cin, int Cout, int T, int Qc, int G, int cog_size, int swapflip,
+                                                          int gw_cin, int ci_off) {
+    // 64 outputs x 16 slices of the partials per block, 8 loads in flight per thread (the partials of one element are a whole
+    // partial-array apart: latency, not bandwidth); slices combined in a fixed tree (deterministic)
+    __shared__ float red[16][64];
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + x;
     const int ntot = n + (gb ? Cout : 0);
     const size_t stride = (size_t)n + Cout;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    float acc = 0.0f;
     if (i < ntot) {
         const int co = i < n ? i / (Cin * 27) : i - n, ci = i < n ? (i / 27) % Cin : 0;
         const int cb = Qc * G, combo = ci / BW_CKI + Qc * (co / cog_size);
         const int nparts = (T - combo + cb - 1) / cb;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int p = y;
-        for (; p + 12 < nparts; p += 16) {
-            s0 += part[(size_t)p * stride + i];
-            s1 += part[(size_t)(p + 4) * stride + i];
-            s2 += part[(size_t)(p + 8) * stride + i];
-            s3 += part[(size_t)(p + 12) * stride + i];
+        for (; p + 16 * 7 < nparts; p += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += part[(size_t)(p + 16 * u) * stride + i];
         }
-        for (; p < nparts; p += 4) s0 += part[(size_t)p * stride + i];
+        for (; p < nparts; p += 16) s[0] += part[(size_t)p * stride + i];
+        acc = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
-    red[y][x] = (s0 + s1) + (s2 + s3);
+    red[y][x] = acc;
     __syncthreads();
     if (y == 0 && i < ntot) {
-        const float t = (red[0][x] + red[1][x]) + (red[2][x] + red[3][x]);
+        const float t = (((red[0][x] + red[1][x]) + (red[2][x] + red[3][x])) + ((red[4][x] + red[5][x]) + (red[6][x] + red[7][x]))) +
+                        (((red[8][x] + red[9][x]) + (red[10][x] + red[11][x])) + ((red[12][x] + red[13][x]) + (red[14][x] + red[15][x])));
         if (i >= n) gb[i - n] = t;
         else if (!swapflip) {                 // gw may be a channel sub-range [ci_off, ci_off + Cin) of a [Cout][gw_cin][27] array
             const int co = i / (Cin * 27), r = i - co * (Cin * 27);
@@ -837,7 +840,7 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
             else
                 hipLaunchKernelGGL(k_conv3d_k3_bwd_weight_vec<2>, dim3(s1.T), dim3(BW_THREADS), sizeof(float) * 2 * (size_t)bv_lds_floats<2>(), VXM_STREAM(stream),
                                    sin, dz, (long long)dz_bstride, Cout, gb ? 1 : 0, part, B, D, H, W, s1.Qc, s1.G);
-            hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n1 + (gb ? Cout : 0), 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, gb, n1, C1, Cout,
+            hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n1 + (gb ? Cout : 0), 64)), dim3(1024), 0, VXM_STREAM(stream), part, gw, gb, n1, C1, Cout,
                                s1.T, s1.Qc, s1.G, 16 * s1.NCT, 0, Cin, C0);
         } else if (gb) {
             float* cs = part + (size_t)u.nparts * (size_t)Cout * C0 * 64;
@@ -853,7 +856,7 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
         ConvIn sin{dz, nullptr, (long long)dz_bstride, 0, Cout, 0, 0};
         if (q.NCT == 1) BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<1>, 2 * bv_lds_floats<1>(), sin, x0, x0_bstride, Cin, 0, q);
         else BW_LAUNCH(k_conv3d_k3_bwd_weight_vec<2>, 2 * bv_lds_floats<2>(), sin, x0, x0_bstride, Cin, 0, q);
-        hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, (float*)nullptr, n, Cout, Cin,
+        hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(1024), 0, VXM_STREAM(stream), part, gw, (float*)nullptr, n, Cout, Cin,
                            q.T, q.Qc, q.G, 16 * q.NCT, 1, Cin, 0);
         if (gb) {
             float* cs = part + (size_t)q.nparts * ((size_t)n + Cin);
@@ -874,7 +877,7 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
     }
 #undef BW_LAUNCH
     // the bias gradient rides along: its per-block partials sit behind the weight partials of every slot
-    hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n + (gb ? Cout : 0), 64)), dim3(256), 0, VXM_STREAM(stream), part, gw, gb, n, Cin, Cout,
+    hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n + (gb ? Cout : 0), 64)), dim3(1024), 0, VXM_STREAM(stream), part, gw, gb, n, Cin, Cout,
                        p.T, p.Qc, p.G, 16 * p.NCT, 0, Cin, 0);
     return vxm_check_launch("vxm_conv3d_k3_bwd_weight");
 }

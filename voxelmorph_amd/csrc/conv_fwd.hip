@@ -1051,7 +1051,7 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_kpack(ConvIn in, co
 
 // w: [Cw_out][Cw_in][27] (reference layout) -> [G][NS][64]: lane (kq, n) of k-step s holds the weight of output channel
 // 16 g + n for k = 4 s + kq = tap * Cin_p + ci (zero beyond 27 Cin_p); flip = the adjoint operator (backward-data)
-__global__ void __launch_bounds__(256) k_pack_weights_kpack(const float* __restrict__ w, float* __restrict__ wk, int Cw_in, int flip, int Cin_p,
+__global__ void __launch_bounds__(256) k_pack_weights_kpack(const float* __restrict__ w, float* __restrict__ wk, int Cw_in, int ci_lo, int flip, int Cin_p,
                                                             int Cout_p, int NS, size_t elems) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= elems) return;
@@ -1061,7 +1061,7 @@ __global__ void __launch_bounds__(256) k_pack_weights_kpack(const float* __restr
     float v = 0.0f;
     if (co < Cout_p && k < 27 * Cin_p) {
         const int tap = k / Cin_p, ci = k % Cin_p;
-        v = flip ? w[((size_t)ci * Cw_in + co) * 27 + (26 - tap)] : w[((size_t)co * Cw_in + ci) * 27 + tap];
+        v = flip ? w[((size_t)ci * Cw_in + ci_lo + co) * 27 + (26 - tap)] : w[((size_t)co * Cw_in + ci_lo + ci) * 27 + tap];
     }
     wk[i] = v;
 }
@@ -1110,7 +1110,7 @@ bool fwd_wide_ok(const ConvCfg& c, const float* x0, int64_t bs0, const float* x1
 }
 
 // w: [Cw_out][Cw_in][27] (reference layout).  Packed operator has Cin_p inputs / Cout_p outputs.
-__global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, float* __restrict__ wp, int Cw_in, int Cw_out,
+__global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, float* __restrict__ wp, int Cw_in, int ci_lo,
                                                       int flip, int Cin_p, int Cout_p, int CK, int NCT, int Q, size_t elems) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= elems) return;
@@ -1124,7 +1124,7 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
     const int co = (g * NCT + ct) * 16 + (lane & 15);
     const int ci = q * CK + 4 * s + (lane >> 4);
     float v = 0.0f;
-    if (co < Cout_p && ci < Cin_p) v = flip ? w[((size_t)ci * Cw_in + co) * 27 + (26 - t)] : w[((size_t)co * Cw_in + ci) * 27 + t];
+    if (co < Cout_p && ci < Cin_p) v = flip ? w[((size_t)ci * Cw_in + ci_lo + co) * 27 + (26 - t)] : w[((size_t)co * Cw_in + ci_lo + ci) * 27 + t];
     wp[i] = v;
 }
 
@@ -1137,17 +1137,22 @@ size_t vxm_conv3d_k3_packed_elems(int Cin, int Cout) {
     return conv_cfg(Cin, Cout).elems + kpack_elems(Cin, Cout);
 }
 
-int vxm_conv3d_k3_pack_weights(const float* w, float* wpacked, int Cin, int Cout, int transpose_flip, void* stream) {
+int vxm_conv3d_k3_pack_weights_range(const float* w, float* wpacked, int Cw_in, int Cout, int ci_lo, int ci_n, int transpose_flip, void* stream) {
     VXM_REQUIRE(w && wpacked, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_pack_weights: null pointer");
-    VXM_REQUIRE(Cin > 0 && Cout > 0, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_pack_weights: Cin=%d Cout=%d", Cin, Cout);
-    const int cin_p = transpose_flip ? Cout : Cin, cout_p = transpose_flip ? Cin : Cout;
+    VXM_REQUIRE(Cw_in > 0 && Cout > 0 && ci_lo >= 0 && ci_n > 0 && ci_lo + ci_n <= Cw_in, VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_pack_weights: channel range [%d, %d) of %d, Cout=%d", ci_lo, ci_lo + ci_n, Cw_in, Cout);
+    const int cin_p = transpose_flip ? Cout : ci_n, cout_p = transpose_flip ? ci_n : Cout;
     const ConvCfg c = conv_cfg(cin_p, cout_p);
     hipLaunchKernelGGL(k_pack_weights, dim3(vxm_blocks((long long)c.elems, 256)), dim3(256), 0, VXM_STREAM(stream), w, wpacked,
-                       Cin, Cout, transpose_flip, cin_p, cout_p, c.CK, c.NCT, c.Q, c.elems);
+                       Cw_in, ci_lo, transpose_flip, cin_p, cout_p, c.CK, c.NCT, c.Q, c.elems);
     if (const size_t ke = kpack_elems(cin_p, cout_p))
         hipLaunchKernelGGL(k_pack_weights_kpack, dim3(vxm_blocks((long long)ke, 256)), dim3(256), 0, VXM_STREAM(stream), w, wpacked + c.elems,
-                           Cin, transpose_flip, cin_p, cout_p, kpack_steps(cin_p), ke);
+                           Cw_in, ci_lo, transpose_flip, cin_p, cout_p, kpack_steps(cin_p), ke);
     return vxm_check_launch("vxm_conv3d_k3_pack_weights");
+}
+
+int vxm_conv3d_k3_pack_weights(const float* w, float* wpacked, int Cin, int Cout, int transpose_flip, void* stream) {
+    return vxm_conv3d_k3_pack_weights_range(w, wpacked, Cin, Cout, 0, Cin, transpose_flip, stream);
 }
 
 int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,

@@ -192,11 +192,15 @@ __device__ __forceinline__ void vg_axis(float xp, int p, int S, float& fr, int& 
     (void)S;
 }
 
-__global__ void __launch_bounds__(256) k_vecint_step_bwd_gather(const float* __restrict__ in, float scale, const float* __restrict__ gout,
-                                                                float* __restrict__ gin, unsigned* __restrict__ far_count, int D, int H, int W) {
-    __shared__ float rec[6][VG_LN];
-    __shared__ int code[VG_LN];
-    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+// One thread per voxel of the 4 x 8 x 32 tile (1024-thread blocks: 16-32 waves per CU hide the latency chain load -> corners ->
+// 24 gathers -> 54 LDS reads that a 4-voxel-per-thread loop exposed); the staged record is two 16-byte words per voxel,
+// {fr_z, fr_y, fr_x, code} and {g_0, g_1, g_2, -}, so a candidate costs 2 ds_read_b128 (conflict-free: consecutive lanes read
+// consecutive words) instead of 7 ds_read_b32.
+__global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __restrict__ in, float scale, const float* __restrict__ gout,
+                                                                 float* __restrict__ gin, unsigned* __restrict__ far_count, int D, int H, int W) {
+    __shared__ f32x4 recF[VG_LN];
+    __shared__ f32x4 recG[VG_LN];
+    const int tid = threadIdx.x, tx = tid & 31, ty = (tid >> 5) & 7, dd = tid >> 8;
     const int ntw = (W + VG_TW - 1) / VG_TW, nth = (H + VG_TH - 1) / VG_TH;
     int t = blockIdx.x;
     const int w0 = (t % ntw) * VG_TW; t /= ntw;
@@ -210,75 +214,76 @@ __global__ void __launch_bounds__(256) k_vecint_step_bwd_gather(const float* __r
     const __amdgpu_buffer_rsrc_t rgi = vxm_rsrc(gin + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
     const int V4 = V << 2;
     unsigned nfar = 0;
-    for (int i = tid; i < VG_LN; i += 256) {
-        const int lx = i % VG_LW, r = i / VG_LW, ly = r % VG_LH, lz = r / VG_LH;
-        const int pz = d0 - 1 + lz, py = h0 - 1 + ly, px = w0 - 1 + lx;
-        int c = 0;
-        float fz = 0.f, fy = 0.f, fx = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
-        if ((unsigned)pz < (unsigned)D && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
-            const int p4 = (pz * HW + py * W + px) << 2;
-            const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
-            int rz, ry, rx;
-            bool nz, ny, nx;
-            vg_axis(vxm_src_coord(pz, v0, D), pz, D, fz, rz, nz);
-            vg_axis(vxm_src_coord(py, v1, H), py, H, fy, ry, ny);
-            vg_axis(vxm_src_coord(px, v2, W), px, W, fx, rx, nx);
-            if (nz && ny && nx) {
-                c = 8 | (rz << 2) | (ry << 1) | rx;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 1024 * k;
+        if (i < VG_LN) {
+            const int lx = i % VG_LW, r = i / VG_LW, ly = r % VG_LH, lz = r / VG_LH;
+            const int pz = d0 - 1 + lz, py = h0 - 1 + ly, px = w0 - 1 + lx;
+            int c = 0;
+            float fz = 0.f, fy = 0.f, fx = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if ((unsigned)pz < (unsigned)D && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
+                const int p4 = (pz * HW + py * W + px) << 2;
+                const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
                 g0 = vxm_bload(rgo, p4, 0); g1 = vxm_bload(rgo, p4, V4); g2 = vxm_bload(rgo, p4, 2 * V4);
-            } else if (lz >= 1 && lz <= VG_TD && ly >= 1 && ly <= VG_TH && lx >= 1 && lx <= VG_TW) {
-                ++nfar;                                   // counted once, by the tile that owns the voxel
+                int rz, ry, rx;
+                bool nz, ny, nx;
+                vg_axis(vxm_src_coord(pz, v0, D), pz, D, fz, rz, nz);
+                vg_axis(vxm_src_coord(py, v1, H), py, H, fy, ry, ny);
+                vg_axis(vxm_src_coord(px, v2, W), px, W, fx, rx, nx);
+                if (nz && ny && nx) {
+                    c = 8 | (rz << 2) | (ry << 1) | rx;
+                } else if (lz >= 1 && lz <= VG_TD && ly >= 1 && ly <= VG_TH && lx >= 1 && lx <= VG_TW) {
+                    ++nfar;                               // counted once, by the tile that owns the voxel
+                }
             }
+            recF[i] = (f32x4){fz, fy, fx, __int_as_float(c)};
+            recG[i] = (f32x4){g0, g1, g2, 0.0f};
         }
-        rec[0][i] = fz; rec[1][i] = fy; rec[2][i] = fx; rec[3][i] = g0; rec[4][i] = g1; rec[5][i] = g2;
-        code[i] = c;
     }
     if (nfar) atomicAdd(far_count, nfar);
     __syncthreads();
-    const int h = h0 + ty, w = w0 + tx;
-    if (h >= H || w >= W) return;
-    for (int dd = 0; dd < VG_TD; ++dd) {
-        const int d = d0 + dd;
-        if (d >= D) break;
-        const int p4 = (d * HW + h * W + w) << 2;
-        // ---- local part: identity + derivative through the sampling position (the 8 corners of x'(q) gathered from v itself)
-        const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
-        const float g0 = vxm_bload(rgo, p4, 0), g1 = vxm_bload(rgo, p4, V4), g2 = vxm_bload(rgo, p4, 2 * V4);
-        const Corners8 cn = corners8(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W);
-        float gz = g0, gy = g1, gx = g2;
+    const int h = h0 + ty, w = w0 + tx, d = d0 + dd;
+    if (h >= H || w >= W || d >= D) return;
+    const int p4 = (d * HW + h * W + w) << 2;
+    // ---- local part: identity + derivative through the sampling position (the 8 corners of x'(q) gathered from v itself)
+    const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
+    const int lq = ((dd + 1) * VG_LH + ty + 1) * VG_LW + tx + 1;
+    const f32x4 gq = recG[lq];
+    const float g0 = gq.x, g1 = gq.y, g2 = gq.z;                    // the voxel's own upstream gradient (staged for every in-volume voxel)
+    const Corners8 cn = corners8(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W);
+    float gz = g0, gy = g1, gx = g2;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int i4 = cn.idx[k] << 2;
-            const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
-            const float sk = cn.ok[k] ? (vxm_bload(rv, i4, 0) * scale) * g0 + (vxm_bload(rv, i4, V4) * scale) * g1 + (vxm_bload(rv, i4, 2 * V4) * scale) * g2 : 0.0f;
-            gz += (dz ? sk : -sk) * (cn.wy[dy] * cn.wx[dx]);
-            gy += (dy ? sk : -sk) * (cn.wz[dz] * cn.wx[dx]);
-            gx += (dx ? sk : -sk) * (cn.wz[dz] * cn.wy[dy]);
-        }
-        // ---- gathered part: the 27 possible senders
-        const int lq = ((dd + 1) * VG_LH + ty + 1) * VG_LW + tx + 1;
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-#pragma unroll
-        for (int oz = -1; oz <= 1; ++oz)
-#pragma unroll
-            for (int oy = -1; oy <= 1; ++oy)
-#pragma unroll
-                for (int ox = -1; ox <= 1; ++ox) {
-                    const int i = lq + (oz * VG_LH + oy) * VG_LW + ox;
-                    const int c = code[i];
-                    // axis a: sender p = q + o, floor(x') = p - frel; q is corner 0 if -o == -frel, corner 1 if -o == 1 - frel
-                    const int rz = (c >> 2) & 1, ry = (c >> 1) & 1, rx = c & 1;
-                    const float fz = rec[0][i], fy = rec[1][i], fx = rec[2][i];
-                    const float wz = (oz == rz) ? 1.0f - fz : ((oz == rz - 1) ? fz : 0.0f);
-                    const float wy = (oy == ry) ? 1.0f - fy : ((oy == ry - 1) ? fy : 0.0f);
-                    const float wx = (ox == rx) ? 1.0f - fx : ((ox == rx - 1) ? fx : 0.0f);
-                    const float wk = (c & 8) ? (wz * wy) * wx : 0.0f;
-                    a0 += rec[3][i] * wk; a1 += rec[4][i] * wk; a2 += rec[5][i] * wk;
-                }
-        vxm_bstore((gz + a0) * scale, rgi, p4, 0);
-        vxm_bstore((gy + a1) * scale, rgi, p4, V4);
-        vxm_bstore((gx + a2) * scale, rgi, p4, 2 * V4);
+    for (int k = 0; k < 8; ++k) {
+        const int i4 = cn.idx[k] << 2;
+        const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
+        const float sk = cn.ok[k] ? (vxm_bload(rv, i4, 0) * scale) * g0 + (vxm_bload(rv, i4, V4) * scale) * g1 + (vxm_bload(rv, i4, 2 * V4) * scale) * g2 : 0.0f;
+        gz += (dz ? sk : -sk) * (cn.wy[dy] * cn.wx[dx]);
+        gy += (dy ? sk : -sk) * (cn.wz[dz] * cn.wx[dx]);
+        gx += (dx ? sk : -sk) * (cn.wz[dz] * cn.wy[dy]);
     }
+    // ---- gathered part: the 27 possible senders
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+    for (int oz = -1; oz <= 1; ++oz)
+#pragma unroll
+        for (int oy = -1; oy <= 1; ++oy)
+#pragma unroll
+            for (int ox = -1; ox <= 1; ++ox) {
+                const int i = lq + (oz * VG_LH + oy) * VG_LW + ox;
+                const f32x4 rf = recF[i], rg = recG[i];
+                const int c = __float_as_int(rf.w);
+                // axis a: sender p = q + o, floor(x') = p - frel; q is corner 0 if -o == -frel, corner 1 if -o == 1 - frel
+                const int rz = (c >> 2) & 1, ry = (c >> 1) & 1, rx = c & 1;
+                const float wz = (oz == rz) ? 1.0f - rf.x : ((oz == rz - 1) ? rf.x : 0.0f);
+                const float wy = (oy == ry) ? 1.0f - rf.y : ((oy == ry - 1) ? rf.y : 0.0f);
+                const float wx = (ox == rx) ? 1.0f - rf.z : ((ox == rx - 1) ? rf.z : 0.0f);
+                const float wk = (c & 8) ? (wz * wy) * wx : 0.0f;
+                a0 += rg.x * wk; a1 += rg.y * wk; a2 += rg.z * wk;
+            }
+    vxm_bstore((gz + a0) * scale, rgi, p4, 0);
+    vxm_bstore((gy + a1) * scale, rgi, p4, V4);
+    vxm_bstore((gx + a2) * scale, rgi, p4, 2 * V4);
 }
 
 // second launch of the step: the scatter contributions of the voxels the gather skipped (displacement >= 1 voxel), by atomics
@@ -450,6 +455,99 @@ __global__ void __launch_bounds__(256) k_resize3d_bwd_gather_tiled(const float* 
     }
 }
 
+// ---- adjoint of an UP-sampling resize (ratio < 1: every input voxel receives from 4-5 outputs per axis, 64-125 terms in the
+// gather above) as three separable 1-D passes through LDS: the forward weight is a product of per-axis weights, so
+//   gx[d,h,w] = sum_od wD[d][od] sum_oh wH[h][oh] sum_ow wW[w][ow] g[od,oh,ow].
+// A block owns a 4 x 8 x 16 tile of inputs, loads the (<= 14 x 22 x 38) block of output gradients its taps can touch once,
+// and contracts W, then H, then D (7 candidate taps per axis from axis_taps(), zeros included): ~5x fewer FMAs, each gradient
+// read once per tile instead of once per receiving voxel.  Deterministic.  A tile whose tap span does not fit the LDS block
+// (ratios below ~0.47) takes the direct gather.
+constexpr int RB_D = 4, RB_H = 8, RB_W = 16, RB_N = RB_W + RB_H + RB_D;
+constexpr int RB_SD = 14, RB_SH = 22, RB_SW = 38;
+
+__global__ void __launch_bounds__(256) k_resize3d_bwd_sep(const float* __restrict__ gout, float* __restrict__ gx, int D, int H, int W, int oD,
+                                                          int oH, int oW, float rd, float rh, float rw, float scale) {
+    VXM_DYN_SMEM(float, smem);                          // 66.5 KB: beyond the static limit
+    float* const b0 = smem;                             // [RB_SD][RB_SH][RB_SW] output gradients; later [RB_SD][RB_H][RB_W]
+    float* const b1 = b0 + RB_SD * RB_SH * RB_SW;       // [RB_SD][RB_SH][RB_W]
+    float (*const sw)[RS_KC + 1] = reinterpret_cast<float (*)[RS_KC + 1]>(b1 + RB_SD * RB_SH * RB_W);
+    int* const solo = reinterpret_cast<int*>(b1 + RB_SD * RB_SH * RB_W + RB_N * (RS_KC + 1));
+    const int tw = (W + RB_W - 1) / RB_W, th = (H + RB_H - 1) / RB_H;
+    int t = blockIdx.x;
+    const int w0 = (t % tw) * RB_W; t /= tw;
+    const int h0 = (t % th) * RB_H;
+    const int d0 = (t / th) * RB_D;
+    const int tid = threadIdx.x;
+    if (tid < RB_N) {
+        const int ax = tid < RB_W ? 2 : (tid < RB_W + RB_H ? 1 : 0);
+        const int i = ax == 2 ? w0 + tid : (ax == 1 ? h0 + tid - RB_W : d0 + tid - RB_W - RB_H);
+        const int n_in = ax == 2 ? W : (ax == 1 ? H : D), n_out = ax == 2 ? oW : (ax == 1 ? oH : oD);
+        int olo;
+        float wt[RS_KC];
+        axis_taps(min(i, n_in - 1), ax == 2 ? rw : (ax == 1 ? rh : rd), n_in, n_out, olo, wt);
+#pragma unroll
+        for (int k = 0; k < RS_KC; ++k) sw[tid][k] = i < n_in ? wt[k] : 0.0f;
+        solo[tid] = olo;
+    }
+    __syncthreads();
+    const int bw = solo[0], bh = solo[RB_W], bd = solo[RB_W + RB_H];           // olo is non-decreasing along an axis
+    const bool fits = solo[RB_W - 1] + RS_KC - bw <= RB_SW && solo[RB_W + RB_H - 1] + RS_KC - bh <= RB_SH && solo[RB_N - 1] + RS_KC - bd <= RB_SD;
+    const size_t bc = blockIdx.y;
+    const float* g = gout + bc * (size_t)oD * oH * oW;
+    float* o = gx + bc * (size_t)D * H * W;
+    if (!fits) {                                            // block-uniform: direct gather for this tile
+        for (int idx = tid; idx < RB_D * RB_H * RB_W; idx += 256) {
+            const int tx = idx % RB_W, ty = (idx / RB_W) % RB_H, dd = idx / (RB_W * RB_H);
+            const int w = w0 + tx, h = h0 + ty, d = d0 + dd;
+            if (w >= W || h >= H || d >= D) continue;
+            float acc = 0.0f;
+            for (int a = 0; a < RS_KC; ++a)
+                for (int e = 0; e < RS_KC; ++e)
+                    for (int c = 0; c < RS_KC; ++c) {
+                        const float wt = sw[RB_W + RB_H + dd][a] * sw[RB_W + ty][e] * sw[tx][c];
+                        if (wt != 0.0f)
+                            acc += wt * g[((size_t)(solo[RB_W + RB_H + dd] + a) * oH + (solo[RB_W + ty] + e)) * oW + solo[tx] + c];
+                    }
+            o[((size_t)d * H + h) * W + w] = acc * scale;
+        }
+        return;
+    }
+    for (int idx = tid; idx < RB_SD * RB_SH * RB_SW; idx += 256) {
+        const int c = idx % RB_SW, e = (idx / RB_SW) % RB_SH, a = idx / (RB_SW * RB_SH);
+        const int od = bd + a, oh = bh + e, ow = bw + c;
+        b0[idx] = (od < oD && oh < oH && ow < oW) ? g[((size_t)od * oH + oh) * oW + ow] : 0.0f;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < RB_SD * RB_SH * RB_W; idx += 256) {            // contract W
+        const int tx = idx % RB_W, row = idx / RB_W;
+        const float* src = b0 + row * RB_SW + (solo[tx] - bw);
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < RS_KC; ++c) acc += sw[tx][c] * src[c];
+        b1[idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < RB_SD * RB_H * RB_W; idx += 256) {             // contract H -> b0 reused as [RB_SD][RB_H][RB_W]
+        const int tx = idx % RB_W, ty = (idx / RB_W) % RB_H, a = idx / (RB_W * RB_H);
+        const float* src = b1 + (a * RB_SH + (solo[RB_W + ty] - bh)) * RB_W + tx;
+        float acc = 0.0f;
+#pragma unroll
+        for (int e = 0; e < RS_KC; ++e) acc += sw[RB_W + ty][e] * src[e * RB_W];
+        b0[idx] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < RB_D * RB_H * RB_W; idx += 256) {              // contract D
+        const int tx = idx % RB_W, ty = (idx / RB_W) % RB_H, dd = idx / (RB_W * RB_H);
+        const int w = w0 + tx, h = h0 + ty, d = d0 + dd;
+        if (w >= W || h >= H || d >= D) continue;
+        const float* src = b0 + ((solo[RB_W + RB_H + dd] - bd) * RB_H + ty) * RB_W + tx;
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < RS_KC; ++a) acc += sw[RB_W + RB_H + dd][a] * src[a * RB_H * RB_W];
+        o[((size_t)d * H + h) * W + w] = acc * scale;
+    }
+}
+
 int check_vol(const char* fn, int B, int C, int D, int H, int W) {
     VXM_REQUIRE(B > 0 && C > 0 && D > 1 && H > 1 && W > 1, VXM_ERR_BAD_SHAPE,
                 "%s: bad shape B=%d C=%d D=%d H=%d W=%d (3-D volumes with every extent > 1)", fn, B, C, D, H, W);
@@ -526,7 +624,7 @@ int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, floa
         const float* in = k == 0 ? vec : steps + (size_t)(k - 1) * n;
         float* gn = k == 0 ? gvec : work + (size_t)(k & 1) * n;
         const float sc = k == 0 ? scale : 1.0f;
-        hipLaunchKernelGGL(k_vecint_step_bwd_gather, grid_t, dim3(256), 0, VXM_STREAM(stream), in, sc, g, gn, far + k, D, H, W);
+        hipLaunchKernelGGL(k_vecint_step_bwd_gather, grid_t, dim3(1024), 0, VXM_STREAM(stream), in, sc, g, gn, far + k, D, H, W);
         hipLaunchKernelGGL(k_vecint_step_bwd_far, grid, dim3(256), 0, VXM_STREAM(stream), in, sc, g, gn, far + k, D, H, W);
         g = gn;
     }
@@ -561,7 +659,19 @@ int vxm_resize3d_bwd(const float* gout, float* gx, int B, int C, int D, int H, i
     const float rd = oD > 1 ? (float)(D - 1) / (float)(oD - 1) : 0.0f, rh = oH > 1 ? (float)(H - 1) / (float)(oH - 1) : 0.0f,
                 rw = oW > 1 ? (float)(W - 1) / (float)(oW - 1) : 0.0f;
     const float rmin = fminf(oD > 1 ? rd : 1.0f, fminf(oH > 1 ? rh : 1.0f, oW > 1 ? rw : 1.0f));
-    if (rmin > 0.4f) {       // floor(2/ratio) + 3 <= RS_KC: every contributing output is among the candidates
+    const float rmax = fmaxf(rd, fmaxf(rh, rw));
+    if (rmin > 0.4f && rmax < 0.75f) {      // up-sampling by ~2: separable passes through LDS
+        const long long tiles = (long long)((W + RB_W - 1) / RB_W) * ((H + RB_H - 1) / RB_H) * ((D + RB_D - 1) / RB_D);
+        VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_resize3d_bwd: too many tiles");
+        constexpr int lds = (RB_SD * RB_SH * RB_SW + RB_SD * RB_SH * RB_W + RB_N * (RS_KC + 1) + RB_N) * 4;
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_resize3d_bwd_sep), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            return true;
+        }();
+        (void)attr;
+        hipLaunchKernelGGL(k_resize3d_bwd_sep, dim3((unsigned)tiles, B * C), dim3(256), lds, VXM_STREAM(stream),
+                           gout, gx, D, H, W, oD, oH, oW, rd, rh, rw, factor);
+    } else if (rmin > 0.4f) {       // floor(2/ratio) + 3 <= RS_KC: every contributing output is among the candidates
         const long long tiles = (long long)((W + RT_W - 1) / RT_W) * ((H + RT_H - 1) / RT_H) * ((D + RT_D - 1) / RT_D);
         VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_resize3d_bwd: too many tiles");
         hipLaunchKernelGGL(k_resize3d_bwd_gather_tiled, dim3((unsigned)tiles, B * C), dim3(256), 0, VXM_STREAM(stream),

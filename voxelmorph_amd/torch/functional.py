@@ -253,12 +253,14 @@ class DiceFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- conv helpers
-def pack_weights(w, flip):
-    """[Cout,Cin,3,3,3] -> MFMA A-fragment order (forward operator, or its adjoint if flip)."""
+def pack_weights(w, flip, lo=0, hi=None):
+    """[Cout,Cin,3,3,3] -> MFMA A-fragment order of the operator on the input channels [lo, hi) (forward), or of its adjoint
+    onto them (flip: backward-data of that segment); the channel range is read in place, no sliced copy of w."""
     cout, cin = w.shape[:2]
-    n = _lib.lib().vxm_conv3d_k3_packed_elems(cout if flip else cin, cin if flip else cout)
+    hi = cin if hi is None else hi
+    n = _lib.lib().vxm_conv3d_k3_packed_elems(cout if flip else hi - lo, hi - lo if flip else cout)
     wp = torch.empty(n, dtype=w.dtype, device=w.device)
-    call("vxm_conv3d_k3_pack_weights", ptr(_c(w)), ptr(wp), cin, cout, 1 if flip else 0, stream())
+    call("vxm_conv3d_k3_pack_weights_range", ptr(_c(w)), ptr(wp), cin, cout, lo, hi - lo, 1 if flip else 0, stream())
     return wp
 
 
@@ -292,7 +294,7 @@ def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B,
     conv_launch(x0, c0, bs0, up0, x1, c1, bs1, pack_weights(w, False), bias, y, ybs, cout, slope, None, 0, 1.0, B, D, H, W)
 
 
-def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W):
+def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W, w_lo=0):
     """convolution_backward w.r.t. the input = the forward kernel with the flipped / transposed weights
     (networks.py:299 autograd twin), optionally multiplied by LeakyReLU'(mask) of the previous ConvBlock.
     A 48-channel result (16 mod 32) is produced as 32 + 16 channels: two launches of the 8-wave kernel's 2- and
@@ -302,9 +304,8 @@ def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W):
         bounds = list(range(0, cin - 16, 32)) + [cin - 16, cin]
     else:
         bounds = [0, cin]
-    for lo, hi in zip(bounds[:-1], bounds[1:]):
-        ws = w if (lo, hi) == (0, cin) else w[:, lo:hi].contiguous()
-        conv_launch(dz, cout, cout * V, False, None, 0, 0, pack_weights(ws, True), None, gx[:, lo:hi], cin * V, hi - lo, 1.0,
+    for lo, hi in zip(bounds[:-1], bounds[1:]):         # w_lo: gx covers the input channels [w_lo, w_lo + cin) of w
+        conv_launch(dz, cout, cout * V, False, None, 0, 0, pack_weights(w, True, w_lo + lo, w_lo + hi), None, gx[:, lo:hi], cin * V, hi - lo, 1.0,
                     mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W)
 
 
@@ -661,7 +662,7 @@ class UnetFn(torch.autograd.Function):
                     DZ[s0] = dzl
                     if s1 is not None:                       # skip segment: regular backward-data of its channels only
                         gxs = torch.empty((B, c1, D, H, W), dtype=dt, device=dev)
-                        conv_bwd_data(dz, cout, w[:, c0:].contiguous(), gxs, c1, None, 1.0, B, D, H, W)
+                        conv_bwd_data(dz, cout, w, gxs, c1, None, 1.0, B, D, H, W, w_lo=c0)
                         GS[s1] = (gxs, 0, c1 * V)
                         if not any(plan.ops[m]["kind"] == "pool" for m in plan.consumers[s1]):
                             g = GS.pop(s1)
