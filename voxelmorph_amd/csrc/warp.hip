@@ -512,10 +512,27 @@ __global__ void __launch_bounds__(256) k_resize3d_bwd_sep(const float* __restric
         }
         return;
     }
-    for (int idx = tid; idx < RB_SD * RB_SH * RB_SW; idx += 256) {
-        const int c = idx % RB_SW, e = (idx / RB_SW) % RB_SH, a = idx / (RB_SW * RB_SH);
-        const int od = bd + a, oh = bh + e, ow = bw + c;
-        b0[idx] = (od < oD && oh < oH && ow < oW) ? g[((size_t)od * oH + oh) * oW + ow] : 0.0f;
+    // rows of RB_SW gradients: thread -> (row slot, column); 8 loads in flight per thread before the LDS writes
+    {
+        constexpr int NROW = RB_SD * RB_SH, RPP = 256 / 64;            // 4 rows per pass: 64 lanes cover one 38-wide row (lanes >= 38 idle)
+        const int c = tid & 63, rsub = tid >> 6;
+        const __amdgpu_buffer_rsrc_t rg = vxm_rsrc(g, (unsigned)oD * (unsigned)oH * (unsigned)oW * 4u);
+        const bool cok = c < RB_SW && bw + c < oW;
+        for (int r0 = 0; r0 < NROW; r0 += RPP * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = r0 + RPP * u + rsub;                   // wave-uniform
+                const int a = row / RB_SH, e = row - a * RB_SH;
+                const bool ok = cok && row < NROW && bd + a < oD && bh + e < oH;
+                v[u] = vxm_bload(rg, ok ? (((bd + a) * oH + bh + e) * oW + bw + c) << 2 : VXM_OOB, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = r0 + RPP * u + rsub;
+                if (c < RB_SW && row < NROW) b0[row * RB_SW + c] = v[u];
+            }
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < RB_SD * RB_SH * RB_W; idx += 256) {            // contract W
