@@ -738,11 +738,16 @@ def _real_scan():
 
 
 def _smooth_svf(shape, sigma=8.0, max_disp=5.0, seed=0):
-    """BASELINE.md §4 structured pair: Gaussian-filtered N(0,1) noise (sigma = 8 voxels) scaled to max |v| = 5 voxels."""
+    """BASELINE.md §4 structured pair: Gaussian-filtered N(0,1) noise (sigma = 8 voxels) scaled to max |v| = 5 voxels.  (The raw
+    maximum of the filtered field is a boundary artefact at one corner, 18x its mean; the scale is set by the 99.9th percentile
+    of |v| and the few longer vectors are shortened to 5 voxels, which leaves a field with |v| ~ 1.5 voxels on average.)"""
     from scipy.ndimage import gaussian_filter
     rng = np.random.default_rng(seed)
-    f = np.stack([gaussian_filter(rng.standard_normal(shape).astype(np.float32), sigma, mode="nearest") for _ in range(3)])
-    f *= max_disp / np.sqrt((f ** 2).sum(0)).max()
+    f = np.stack([gaussian_filter(rng.standard_normal(shape), sigma, mode="nearest") for _ in range(3)])
+    mag = np.sqrt((f ** 2).sum(0))
+    f *= max_disp / np.percentile(mag, 99.9)
+    mag = np.sqrt((f ** 2).sum(0))
+    f *= np.minimum(1.0, max_disp / np.maximum(mag, 1e-12))
     return f[None].astype(np.float32)
 
 
@@ -775,7 +780,7 @@ def test_full_size_real_scan_step_and_label_dice_gate(vxm):
     d_ref = np.asarray(orc.dice_metric(ref[0, 0], seg30[0, 0], labels=labels))
     print("real-scan label gate: mean Dice hip=%.6f oracle=%.6f, max per-label diff %.2e, flow max|d|=%.2e, label agreement %.6f"
           % (d_hip.mean(), d_ref.mean(), np.abs(d_hip - d_ref).max(), float((pos.cpu() - pos_o).abs().max()), (moved == ref).mean()))
-    assert 0.2 < d_hip.mean() < 0.98            # a real deformation: the structures moved, and still overlap
+    assert 0.2 < d_hip.mean() < 0.99            # a real deformation: the structures moved, and still overlap
     assert d_hip.shape == (30,) and np.abs(d_hip - d_ref).max() <= 1e-3
 
 

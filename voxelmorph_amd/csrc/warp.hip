@@ -463,9 +463,9 @@ __global__ void __launch_bounds__(256) k_resize3d_bwd_gather_tiled(const float* 
 // read once per tile instead of once per receiving voxel.  Deterministic.  A tile whose tap span does not fit the LDS block
 // (ratios below ~0.47) takes the direct gather.
 constexpr int RB_D = 4, RB_H = 8, RB_W = 16, RB_N = RB_W + RB_H + RB_D;
-constexpr int RB_SD = 14, RB_SH = 22, RB_SW = 38;
+constexpr int RB_SD = 14, RB_SH = 22, RB_SW = 38, RB_THREADS = 1024;
 
-__global__ void __launch_bounds__(256) k_resize3d_bwd_sep(const float* __restrict__ gout, float* __restrict__ gx, int D, int H, int W, int oD,
+__global__ void __launch_bounds__(RB_THREADS) k_resize3d_bwd_sep(const float* __restrict__ gout, float* __restrict__ gx, int D, int H, int W, int oD,
                                                           int oH, int oW, float rd, float rh, float rw, float scale) {
     VXM_DYN_SMEM(float, smem);                          // 66.5 KB: beyond the static limit
     float* const b0 = smem;                             // [RB_SD][RB_SH][RB_SW] output gradients; later [RB_SD][RB_H][RB_W]
@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(256) k_resize3d_bwd_sep(const float* __restric
     const float* g = gout + bc * (size_t)oD * oH * oW;
     float* o = gx + bc * (size_t)D * H * W;
     if (!fits) {                                            // block-uniform: direct gather for this tile
-        for (int idx = tid; idx < RB_D * RB_H * RB_W; idx += 256) {
+        for (int idx = tid; idx < RB_D * RB_H * RB_W; idx += RB_THREADS) {
             const int tx = idx % RB_W, ty = (idx / RB_W) % RB_H, dd = idx / (RB_W * RB_H);
             const int w = w0 + tx, h = h0 + ty, d = d0 + dd;
             if (w >= W || h >= H || d >= D) continue;
@@ -512,30 +512,28 @@ __global__ void __launch_bounds__(256) k_resize3d_bwd_sep(const float* __restric
         }
         return;
     }
-    // rows of RB_SW gradients: thread -> (row slot, column); 8 loads in flight per thread before the LDS writes
+    // rows of RB_SW gradients: thread -> (row slot, column)
     {
-        constexpr int NROW = RB_SD * RB_SH, RPP = 256 / 64;            // 4 rows per pass: 64 lanes cover one 38-wide row (lanes >= 38 idle)
+        constexpr int NROW = RB_SD * RB_SH, RPP = RB_THREADS / 64, NL = (NROW + RPP - 1) / RPP;   // 16 rows per pass: 64 lanes cover one 38-wide row
         const int c = tid & 63, rsub = tid >> 6;
         const __amdgpu_buffer_rsrc_t rg = vxm_rsrc(g, (unsigned)oD * (unsigned)oH * (unsigned)oW * 4u);
         const bool cok = c < RB_SW && bw + c < oW;
-        for (int r0 = 0; r0 < NROW; r0 += RPP * 8) {
-            float v[8];
+        float v[NL];                                                   // every load of the tile in flight before the first LDS write
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int row = r0 + RPP * u + rsub;                   // wave-uniform
-                const int a = row / RB_SH, e = row - a * RB_SH;
-                const bool ok = cok && row < NROW && bd + a < oD && bh + e < oH;
-                v[u] = vxm_bload(rg, ok ? (((bd + a) * oH + bh + e) * oW + bw + c) << 2 : VXM_OOB, 0);
-            }
+        for (int u = 0; u < NL; ++u) {
+            const int row = RPP * u + rsub;                            // wave-uniform
+            const int a = row / RB_SH, e = row - a * RB_SH;
+            const bool ok = cok && row < NROW && bd + a < oD && bh + e < oH;
+            v[u] = vxm_bload(rg, ok ? (((bd + a) * oH + bh + e) * oW + bw + c) << 2 : VXM_OOB, 0);
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int row = r0 + RPP * u + rsub;
-                if (c < RB_SW && row < NROW) b0[row * RB_SW + c] = v[u];
-            }
+        for (int u = 0; u < NL; ++u) {
+            const int row = RPP * u + rsub;
+            if (c < RB_SW && row < NROW) b0[row * RB_SW + c] = v[u];
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < RB_SD * RB_SH * RB_W; idx += 256) {            // contract W
+    for (int idx = tid; idx < RB_SD * RB_SH * RB_W; idx += RB_THREADS) {            // contract W
         const int tx = idx % RB_W, row = idx / RB_W;
         const float* src = b0 + row * RB_SW + (solo[tx] - bw);
         float acc = 0.0f;
@@ -544,7 +542,7 @@ __global__ void __launch_bounds__(256) k_resize3d_bwd_sep(const float* __restric
         b1[idx] = acc;
     }
     __syncthreads();
-    for (int idx = tid; idx < RB_SD * RB_H * RB_W; idx += 256) {             // contract H -> b0 reused as [RB_SD][RB_H][RB_W]
+    for (int idx = tid; idx < RB_SD * RB_H * RB_W; idx += RB_THREADS) {             // contract H -> b0 reused as [RB_SD][RB_H][RB_W]
         const int tx = idx % RB_W, ty = (idx / RB_W) % RB_H, a = idx / (RB_W * RB_H);
         const float* src = b1 + (a * RB_SH + (solo[RB_W + ty] - bh)) * RB_W + tx;
         float acc = 0.0f;
@@ -553,7 +551,7 @@ __global__ void __launch_bounds__(256) k_resize3d_bwd_sep(const float* __restric
         b0[idx] = acc;
     }
     __syncthreads();
-    for (int idx = tid; idx < RB_D * RB_H * RB_W; idx += 256) {              // contract D
+    for (int idx = tid; idx < RB_D * RB_H * RB_W; idx += RB_THREADS) {              // contract D
         const int tx = idx % RB_W, ty = (idx / RB_W) % RB_H, dd = idx / (RB_W * RB_H);
         const int w = w0 + tx, h = h0 + ty, d = d0 + dd;
         if (w >= W || h >= H || d >= D) continue;
@@ -686,7 +684,7 @@ int vxm_resize3d_bwd(const float* gout, float* gx, int B, int C, int D, int H, i
             return true;
         }();
         (void)attr;
-        hipLaunchKernelGGL(k_resize3d_bwd_sep, dim3((unsigned)tiles, B * C), dim3(256), lds, VXM_STREAM(stream),
+        hipLaunchKernelGGL(k_resize3d_bwd_sep, dim3((unsigned)tiles, B * C), dim3(RB_THREADS), lds, VXM_STREAM(stream),
                            gout, gx, D, H, W, oD, oH, oW, rd, rh, rw, factor);
     } else if (rmin > 0.4f) {       // floor(2/ratio) + 3 <= RS_KC: every contributing output is among the candidates
         const long long tiles = (long long)((W + RT_W - 1) / RT_W) * ((H + RT_H - 1) / RT_H) * ((D + RT_D - 1) / RT_D);
