@@ -15,6 +15,7 @@ from .._lib import call, ptr, require_device, stream
 
 SPLIT_48 = True     # conv_bwd_data: produce 48-channel results as 32 + 16 (module-level switch for A/B timing)
 OVERLAP_SMALL_LEVELS = os.environ.get("VXM_NO_OVERLAP", "") != "1"     # UnetFn.backward: weight gradients of the coarse levels on a second HIP stream
+OVERLAP_MIN_LEVEL = int(os.environ.get("VXM_OVERLAP_MIN_LEVEL", "1"))   # first U-Net level whose weight gradients go to the second stream
 _SIDE_STREAMS = {}
 
 
@@ -624,7 +625,7 @@ class UnetFn(torch.autograd.Function):
                 gw_sink, gb_sink = _claim_sink(w), _claim_sink(b)
                 gw = gw_sink if gw_sink is not None else torch.empty_like(w)
                 gb = gb_sink if gb_sink is not None else torch.empty_like(b)
-                if side is not None and plan.lvl[dst] >= 1:
+                if side is not None and plan.lvl[dst] >= OVERLAP_MIN_LEVEL:
                     # Below full resolution neither product fills the chip (a few hundred tiles on 256 CUs): the weight gradient
                     # of this block runs on a second stream beside the backward-data chain it does not feed.
                     ev = torch.cuda.Event()
