@@ -766,11 +766,7 @@ int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int C0, int64_t x0_bstride
                                      const float* dz, int64_t dz_bstride, int Cout, int D, int H, int W) {
     const bool vec = bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W);
     const int nct = Cout <= 16 ? 1 : 2;                 // of the unswapped plan
-    if (x0_up && vec && (D & 1) == 0 && (H & 1) == 0)      // collapsed upsampled segment + skip segment (row-sliding: 40, 16-wave kernel: 20)
-        return (C1 > 0 && vxm_bw_rs_ok(x1, x1_bstride, C1, dz, dz_bstride, Cout, 1, D, H, W) ? 40 : 20) + nct;
-    if (vec && !x0_up && Cout > 4 && vxm_bw_rs_ok(x0, x0_bstride, C0, dz, dz_bstride, Cout, 1, D, H, W) &&
-        (C1 == 0 || vxm_bw_rs_ok(x1, x1_bstride, C1, dz, dz_bstride, Cout, 1, D, H, W)))
-        return 30 + nct;
+    if (x0_up && vec && (D & 1) == 0 && (H & 1) == 0) return 20 + nct;      // collapsed upsampled segment (+ regular skip segment)
     return (vec ? 10 : 0) + nct;
 }
 
@@ -787,14 +783,6 @@ size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D,
         // nparts(C0) * C0 <= (256 / (Qc G) + 1) * 16 Qc <= 4096 / G + Cin + 16 for any split C0 <= Cin
         const size_t alt = sizeof(float) * ((size_t)Cout * 64 * (4096 / (size_t)p.G + Cin + 16) + (size_t)Cout * CS_SLICES + (size_t)Cout * Cin * 64);
         if (alt > need) need = alt;
-    }
-    {                                                  // row-sliding kernel: per-(block, depth slice) partials of any 16-multiple segment,
-        size_t rs = 0;                                 // placed behind the collapsed product's buffers when it takes the skip segment
-        for (int c = 16; c <= Cin; c += 16) {
-            const size_t f = vxm_bw_rs_workspace_floats(c, Cout, B, D, H, W);
-            if (f > rs) rs = f;
-        }
-        if (Cout % 16 == 0 && Cout <= 32 && rs) need += sizeof(float) * rs;
     }
     return 256 + need;
 }
@@ -842,11 +830,7 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
         hipLaunchKernelGGL(k_reduce_partials_up_sum, dim3(vxm_blocks((long long)Cout * C0 * 64, 64)), dim3(256), 0, VXM_STREAM(stream), part, red, C0, Cout,
                            u.T, u.Qc, u.G, 16 * u.NCT);
         hipLaunchKernelGGL(k_reduce_partials_up_map, dim3(vxm_blocks((long long)Cout * C0 * 27, 256)), dim3(256), 0, VXM_STREAM(stream), red, gw, C0, Cout, Cin);
-        if (C1 > 0 && vxm_bw_rs_ok(x1, x1_bstride, C1, dz, dz_bstride, Cout, B, D, H, W)) {
-            // skip segment on the row-sliding kernel; its partials go behind everything the collapsed product uses
-            float* rs_work = red + (size_t)Cout * C0 * 64;
-            vxm_bw_rs_launch(x1, x1_bstride, C1, dz, dz_bstride, Cout, gw, Cin, C0, gb, rs_work, B, D, H, W, VXM_STREAM(stream));
-        } else if (C1 > 0) {
+        if (C1 > 0) {
             const BwPlan s1 = bw_plan(C1, Cout, B, D, H, W);
             ConvIn sin{x1, nullptr, (long long)x1_bstride, 0, C1, 0, 0};
             const int n1 = Cout * C1 * 27;
@@ -880,13 +864,6 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
                                (size_t)D * H * W);
             hipLaunchKernelGGL(k_channel_sum_finish, dim3(Cout), dim3(64), 0, VXM_STREAM(stream), cs, gb);
         }
-        return vxm_check_launch("vxm_conv3d_k3_bwd_weight");
-    }
-    if (vec && !x0_up && vxm_bw_rs_ok(x0, x0_bstride, C0, dz, dz_bstride, Cout, B, D, H, W) &&
-        (C1 == 0 || vxm_bw_rs_ok(x1, x1_bstride, C1, dz, dz_bstride, Cout, B, D, H, W))) {
-        // full-resolution segments with 16-channel multiples on both sides: row-sliding kernel, one launch per segment
-        vxm_bw_rs_launch(x0, x0_bstride, C0, dz, dz_bstride, Cout, gw, Cin, 0, gb, part, B, D, H, W, VXM_STREAM(stream));
-        if (C1 > 0) vxm_bw_rs_launch(x1, x1_bstride, C1, dz, dz_bstride, Cout, gw, Cin, C0, nullptr, part, B, D, H, W, VXM_STREAM(stream));
         return vxm_check_launch("vxm_conv3d_k3_bwd_weight");
     }
     const BwPlan p = bw_plan(Cin, Cout, B, D, H, W);

@@ -174,14 +174,6 @@ __device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS * HAL
     }
 }
 
-}  // namespace
-// row-sliding backward-weight kernel of full-resolution 16-channel-multiple segments (conv_bwd_weight_rs.hip)
-bool vxm_bw_rs_ok(const float* x, int64_t x_bs, int Cseg, const float* dz, int64_t dz_bs, int Cout, int B, int D, int H, int W);
-size_t vxm_bw_rs_workspace_floats(int Cseg, int Cout, int B, int D, int H, int W);
-void vxm_bw_rs_launch(const float* x, int64_t x_bs, int Cseg, const float* dz, int64_t dz_bs, int Cout, float* gw, int gw_cin, int ci_off, float* gb,
-                      float* work, int B, int D, int H, int W, hipStream_t s);
-namespace {
-
 int check_conv(const char* fn, int C0, int C1, int x0_up, int Cout, int B, int D, int H, int W) {
     VXM_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, VXM_ERR_BAD_SHAPE,
                 "%s: bad shape B=%d C0=%d C1=%d Cout=%d D=%d H=%d W=%d", fn, B, C0, C1, Cout, D, H, W);
