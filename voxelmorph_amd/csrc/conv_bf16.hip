@@ -61,28 +61,21 @@ __global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = lane >> 4, n = lane & 15;
 
-    // tile of this block.  Block b runs on XCD b % 8 (observed; speed only); XCD x takes a contiguous range of BRICKS of 4 x 4 x 4
-    // tiles, and the 64 blocks an XCD runs side by side are one brick: their haloed tiles overlap inside a 34 x 34 x 66-voxel
-    // neighbourhood (2.5 MB for 16 bf16 channels) that the XCD's 4 MB L2 holds, instead of every block re-fetching its halo
-    // (x 1.76 - 2.1 of the input) from the fabric -- these layers are traffic-bound.
+    // tile of this block: block b runs on XCD b % 8 (observed; speed only), XCD x takes a contiguous tile range
     const int nw = (W + 15) / 16, nh = (H + ROWS - 1) / ROWS, nd = (D + BF_TD - 1) / BF_TD;
-    const int bw = (nw + 3) >> 2, bh = (nh + 3) >> 2, bd = (nd + 3) >> 2;
-    const int nbrick = B * bd * bh * bw;
-    int slot = blockIdx.x;                                 // 64 slots per brick
-    if (nbrick >= 8) {
-        const int x = slot & 7, j = slot >> 3;
-        const int lo = (int)((long long)nbrick * x / 8), hi = (int)((long long)nbrick * (x + 1) / 8);
-        if (j >= (hi - lo) * 64) return;                   // grid is rounded up to 8 x the largest per-XCD share
-        slot = lo * 64 + j;
-    } else if (slot >= nbrick * 64) {
+    const int ntiles = B * nd * nh * nw;
+    int tile = blockIdx.x;
+    if (ntiles >= 64) {
+        const int x = tile & 7, j = tile >> 3;
+        const int lo = (int)((long long)ntiles * x / 8), hi = (int)((long long)ntiles * (x + 1) / 8);
+        tile = lo + j;
+        if (tile >= hi) return;
+    } else if (tile >= ntiles) {
         return;
     }
-    const int brick = slot >> 6, inb = slot & 63;
-    const int kw_ = brick % bw; int bq = brick / bw;
-    const int kh_ = bq % bh; bq /= bh;
-    const int kd_ = bq % bd; const int b = bq / bd;
-    const int tw = kw_ * 4 + (inb & 3), th = kh_ * 4 + ((inb >> 2) & 3), td = kd_ * 4 + (inb >> 4);
-    if (tw >= nw || th >= nh || td >= nd) return;          // partial bricks at the far faces
+    const int tw = tile % nw; int tq = tile / nw;
+    const int th = tq % nh; tq /= nh;
+    const int td = tq % nd; const int b = tq / nd;
     const int d0 = td * BF_TD, h0 = th * ROWS, w0 = tw * 16;
     const int g = blockIdx.y;
 
@@ -650,8 +643,8 @@ void bf_launch_conv(const BfIn& in, const void* wp, const float* bias, void* y, 
     }();
     (void)attr;
     const int Q = (in.CB0 + in.CB1) / 2;
-    const long long nbrick = (long long)B * (((D + BF_TD - 1) / BF_TD + 3) / 4) * (((H + ROWS - 1) / ROWS + 3) / 4) * (((W + 15) / 16 + 3) / 4);
-    const unsigned gx = nbrick >= 8 ? (unsigned)(8 * ((nbrick + 7) / 8) * 64) : (unsigned)(nbrick * 64);
+    const long long ntiles = (long long)B * ((D + BF_TD - 1) / BF_TD) * ((H + ROWS - 1) / ROWS) * ((W + 15) / 16);
+    const unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
     const int G = (Cout + 16 * NCT - 1) / (16 * NCT);
     hipLaunchKernelGGL((k_bf16_conv<NCT, ROWS, OUT>), dim3(gx, G), dim3(BF_THREADS), bf_lds_bytes(NCT, ROWS), s, in,
                        static_cast<const u32x4*>(wp), bias, y, Cout, slope, mask, mask_slope, B, D, H, W, Q);
