@@ -76,6 +76,54 @@ __global__ void __launch_bounds__(256) k_maxpool2_bwd(const float* __restrict__ 
 
 // The volume may have odd extents (MaxPool floors): voxels outside the pooled region get only the
 // skip gradient.  Handled by a second tiny kernel over the uncovered border.
+// The same for two W-neighbouring pooled voxels per thread: every row piece is one aligned 16-byte access (W % 4 == 0, 16-byte
+// aligned tensors), i.e. 1 KB per wave instruction instead of 64 strided 4-byte words -- the kernel is pure HBM traffic
+// (1.37 GB per pair at full resolution).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__global__ void __launch_bounds__(256) k_maxpool2_bwd_v4(const float* __restrict__ x, long long x_bs, const float* __restrict__ gpool,
+                                                         const float* __restrict__ gskip, long long gs_bs, float* __restrict__ dz,
+                                                         float slope, int C, int D, int H, int W) {
+    const int D2 = D >> 1, H2 = H >> 1, W4 = W >> 2;
+    const long long n = (long long)D2 * H2 * W4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * C) return;
+    const size_t b = blockIdx.y;
+    const int c = (int)(i / n);
+    const int q = (int)(i - (long long)c * n);
+    const int w4 = q % W4, t = q / W4, h = t % H2, d = t / H2;
+    const size_t off = ((size_t)c * D + 2 * d) * H * W + (size_t)(2 * h) * W + 4 * w4;
+    const size_t V = (size_t)D * H * W;
+    f32x4v xv[4], gs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t o = off + (size_t)(r >> 1) * H * W + (size_t)(r & 1) * W;
+        xv[r] = *reinterpret_cast<const f32x4v*>(x + b * x_bs + o);
+        gs[r] = gskip ? *reinterpret_cast<const f32x4v*>(gskip + b * gs_bs + o) : (f32x4v){0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x2v gp = *reinterpret_cast<const f32x2v*>(gpool + b * (size_t)C * (V >> 3) + ((size_t)c * D2 + d) * H2 * (W >> 1) + (size_t)h * (W >> 1) + 2 * w4);
+    f32x4v out[4];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {              // the two pooled voxels: columns 2 half, 2 half + 1 of the row pieces
+        float m = xv[0][2 * half];
+        int arg = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {                   // ATen scan order (d, h, w): first maximum wins, NaN propagates
+            const float v = xv[k >> 1][2 * half + (k & 1)];
+            if (v > m || v != v) { m = v; arg = k; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = xv[k >> 1][2 * half + (k & 1)];
+            const float g = (k == arg ? gp[half] : 0.0f) + gs[k >> 1][2 * half + (k & 1)];
+            out[k >> 1][2 * half + (k & 1)] = g * vxm_lrelu_grad(v, slope);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<f32x4v*>(dz + b * (size_t)C * V + off + (size_t)(r >> 1) * H * W + (size_t)(r & 1) * W) = out[r];
+}
+
 __global__ void __launch_bounds__(256) k_maxpool2_bwd_border(const float* __restrict__ x, long long x_bs, const float* __restrict__ gskip,
                                                              long long gs_bs, float* __restrict__ dz, float slope, int C, int D, int H, int W) {
     const long long V = (long long)D * H * W;
@@ -156,8 +204,14 @@ int vxm_maxpool2_bwd(const float* x, int64_t x_bstride, const float* gpool, cons
     VXM_REQUIRE(x && gpool && dz, VXM_ERR_NULL_POINTER, "vxm_maxpool2_bwd: null pointer");
     VXM_REQUIRE(B > 0 && B <= 65535 && C > 0 && D >= 2 && H >= 2 && W >= 2, VXM_ERR_BAD_SHAPE, "vxm_maxpool2_bwd: bad shape %dx%dx%d", D, H, W);
     const long long n = (long long)C * (D / 2) * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(k_maxpool2_bwd, dim3(vxm_blocks(n, 256), B), dim3(256), 0, VXM_STREAM(stream), x, (long long)x_bstride, gpool, gskip,
-                       (long long)gskip_bstride, dz, slope, C, D, H, W);
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if ((W & 3) == 0 && !((D | H) & 1) && a16(x) && a16(gskip) && a16(dz) && (reinterpret_cast<uintptr_t>(gpool) & 7) == 0 && (x_bstride & 3) == 0 &&
+        (gskip_bstride & 3) == 0)
+        hipLaunchKernelGGL(k_maxpool2_bwd_v4, dim3(vxm_blocks(n / 2, 256), B), dim3(256), 0, VXM_STREAM(stream), x, (long long)x_bstride, gpool, gskip,
+                           (long long)gskip_bstride, dz, slope, C, D, H, W);
+    else
+        hipLaunchKernelGGL(k_maxpool2_bwd, dim3(vxm_blocks(n, 256), B), dim3(256), 0, VXM_STREAM(stream), x, (long long)x_bstride, gpool, gskip,
+                           (long long)gskip_bstride, dz, slope, C, D, H, W);
     if ((D | H | W) & 1)
         hipLaunchKernelGGL(k_maxpool2_bwd_border, dim3(vxm_blocks((long long)C * D * H * W, 256), B), dim3(256), 0, VXM_STREAM(stream), x,
                            (long long)x_bstride, gskip, (long long)gskip_bstride, dz, slope, C, D, H, W);
