@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Register a moving volume to a fixed one with a trained VxmDense on MI355X — the command line of the reference's
-`scripts/torch/register.py` (:49-58: --moving --fixed --moved --model --warp); reference checkpoints load unchanged
+`scripts/torch/register.py` (:49-58: --moving --fixed --moved --model --warp -g/--gpu --multichannel); reference checkpoints load unchanged
 (`LoadableModel.load`, modelio.py:69-77).  npz / npy in and out (the reference's NIfTI I/O needs nibabel, absent
 here); `--seg` additionally warps a label map with the bit-exact nearest-neighbour transformer, and `--jacobian`
 reports the fraction of voxels with a non-positive Jacobian determinant of the deformation (py/utils.py:473-516)."""
@@ -45,6 +45,7 @@ def main(argv=None):
     p.add_argument('--moved-seg', help='output filename of the warped label map')
     p.add_argument('--jacobian', action='store_true', help='print the fraction of non-positive Jacobian determinants')
     p.add_argument('-g', '--gpu', default='0', help='GPU number (this path has no CPU fallback)')
+    p.add_argument('--multichannel', action='store_true', help='volumes carry a trailing feature axis [*vol, C]')
     args = p.parse_args(argv)
 
     import voxelmorph_amd as vxm
@@ -52,16 +53,19 @@ def main(argv=None):
     dev = torch.device('cuda', int(args.gpu))
     torch.cuda.set_device(dev)
 
-    def load(path):
-        return torch.from_numpy(np.ascontiguousarray(vdata.load_volfile(path), dtype=np.float32))[None, None].to(dev)
+    def load(path, multichannel=False):
+        """[*vol] (or [*vol, C] with --multichannel, register.py:69-72) -> [1, C, *vol] fp32 on the device"""
+        vol = np.asarray(vdata.load_volfile(path))
+        vol = np.moveaxis(vol, -1, 0) if multichannel else vol[None]
+        return torch.from_numpy(np.ascontiguousarray(vol, dtype=np.float32))[None].to(dev)
 
-    moving, fixed = load(args.moving), load(args.fixed)
+    moving, fixed = load(args.moving, args.multichannel), load(args.fixed, args.multichannel)
     model = vxm.networks.VxmDense.load(args.model, dev)
     model.to(dev)
     model.eval()
     with torch.no_grad():
         moved, warp = model(moving, fixed, registration=True)
-        save_vol(moved.cpu().numpy().squeeze(), args.moved)
+        save_vol((moved[0].permute(1, 2, 3, 0) if args.multichannel else moved).cpu().numpy().squeeze(), args.moved)
         if args.warp:
             save_vol(warp.cpu().numpy().squeeze(), args.warp)
         if args.seg:
