@@ -1070,6 +1070,11 @@ def test_train_cli_atlas_multichannel_and_semisupervised(vxm, tmp_path):
     run("train.py", "--img-list", str(tmp_path / "mlist.txt"), "--multichannel", "--model-dir", str(tmp_path / "mm"))
     ck = torch.load(tmp_path / "mm" / "0002.pt", map_location="cpu")
     assert ck["config"]["src_feats"] == 2 and ck["model_state"]["unet_model.encoder.0.0.main.weight"].shape[1] == 4
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "register.py"), "--moving", str(tmp_path / "m0.npz"), "--fixed",
+                        str(tmp_path / "m1.npz"), "--moved", str(tmp_path / "mmoved.npz"), "--model", str(tmp_path / "mm" / "0002.pt"),
+                        "--multichannel", "-g", "0"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert np.load(tmp_path / "mmoved.npz")["vol"].shape == (32, 32, 32, 2)            # register.py:69-72: [*vol, C] in and out
     for extra in ([], ["--atlas", str(tmp_path / "atlas.npz")]):
         run("train_semisupervised_seg.py", "--img-list", str(tmp_path / "stems.txt"), "--img-suffix", "_img.npz", "--seg-suffix", "_seg.npz",
             "--labels", str(tmp_path / "labels.npy"), "--model-dir", str(tmp_path / "ms"), "--image-loss", "ncc", *extra)
