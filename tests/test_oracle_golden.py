@@ -249,3 +249,16 @@ def test_live_reference_agrees():
     with ref_loader.cuda_alias_to_cpu():
         a = vxm.losses.NCC().loss(src, src * 0.5 + 0.1)
     assert torch.equal(a, orc.ncc_loss(src, src * 0.5 + 0.1))
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="reference tree not present")
+def test_reference_one_dimensional_path_is_not_runnable():
+    """Why 1-D is not a row of this build: the reference's torch backend accepts ndims = 1 in its asserts (networks.py:51,196,
+    layers.py:79-83) but cannot execute it -- SpatialTransformer passes a 3-D tensor to grid_sample (layers.py:41-48 permutes
+    only 2-D / 3-D grids), which ATen rejects."""
+    vxm = ref_loader.load_reference()
+    x = torch.rand(1, 1, 64)
+    with pytest.raises(RuntimeError, match="grid_sampler"):
+        vxm.layers.SpatialTransformer((64,))(x, torch.zeros(1, 1, 64))
+    with pytest.raises(RuntimeError, match="grid_sampler"):
+        vxm.networks.VxmDense((64,), int_steps=0)(x, x)
