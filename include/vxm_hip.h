@@ -174,7 +174,9 @@ int vxm_ncc_fwd(const float* I, const float* J, float* loss, float* sums, float*
  * 3..9, else 6*B*D*H*W floats. */
 int vxm_ncc_bwd(const float* I, const float* J, const float* sums, const float* gloss, float* gJ,
                 float* work, int B, int D, int H, int W, int win, void* stream);
-/* Grad.loss, losses.py:102-135.  mult = loss_mult (1 if None).  acc: 3*B doubles. */
+/* Grad.loss, losses.py:102-135.  mult = loss_mult (1 if None).  acc: 3 * B * VXM_GRAD_SLOTS doubles (per-axis sums, spread over
+ * slots so that the blocks' fp64 atomics do not serialise on three addresses). */
+#define VXM_GRAD_SLOTS 32
 int vxm_gradloss_fwd(const float* y, float* loss, double* acc, int B, int C, int D, int H, int W,
                      int penalty, float mult, void* stream);
 int vxm_gradloss_bwd(const float* y, const float* gloss, float* gy, int B, int C, int D, int H, int W,

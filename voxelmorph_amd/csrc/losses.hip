@@ -321,9 +321,12 @@ __global__ void __launch_bounds__(256) k_gradloss_fwd(const float* __restrict__ 
         }
         sd += (double)fd; sh += (double)fh; sw += (double)fw;
     }
-    block_atomic_add(sd, acc + b * 3 + 0, red);
-    block_atomic_add(sh, acc + b * 3 + 1, red);
-    block_atomic_add(sw, acc + b * 3 + 2, red);
+    // VXM_GRAD_SLOTS copies of every sum: blocks spread their fp64 atomics over the slots (the L2 serialises same-address
+    // atomics), k_gradloss_finish adds the slots up -- which is what lets the grid have thousands of blocks
+    const int slot = blockIdx.x % VXM_GRAD_SLOTS;
+    block_atomic_add(sd, acc + ((b * 3 + 0) * VXM_GRAD_SLOTS + slot), red);
+    block_atomic_add(sh, acc + ((b * 3 + 1) * VXM_GRAD_SLOTS + slot), red);
+    block_atomic_add(sw, acc + ((b * 3 + 2) * VXM_GRAD_SLOTS + slot), red);
 }
 
 // `axes` = 3 for volumes, 2 for planar images passed with D = 1 (no difference along D exists: that term is left out)
@@ -332,7 +335,12 @@ __global__ void k_gradloss_finish(const double* __restrict__ acc, float* __restr
     if (threadIdx.x || blockIdx.x) return;
     const double nd = (double)C * (D - 1) * H * W, nh = (double)C * D * (H - 1) * W, nw = (double)C * D * H * (W - 1);
     double tot = 0.0;
-    for (int b = 0; b < B; ++b) tot += mult * ((axes == 3 ? acc[b * 3] / nd : 0.0) + acc[b * 3 + 1] / nh + acc[b * 3 + 2] / nw) / (double)axes;
+    for (int b = 0; b < B; ++b) {
+        double a[3] = {0.0, 0.0, 0.0};
+        for (int k = 0; k < 3; ++k)
+            for (int s = 0; s < VXM_GRAD_SLOTS; ++s) a[k] += acc[(b * 3 + k) * VXM_GRAD_SLOTS + s];
+        tot += mult * ((axes == 3 ? a[0] / nd : 0.0) + a[1] / nh + a[2] / nw) / (double)axes;
+    }
     loss[0] = (float)(tot / B);
 }
 
@@ -557,8 +565,9 @@ static int gradloss_fwd(const char* fn, const float* y, float* loss, double* acc
     VXM_REQUIRE(B > 0 && B <= 65535 && C > 0 && (axes == 2 || D > 1) && H > 1 && W > 1, VXM_ERR_BAD_SHAPE, "%s: bad shape", fn);
     VXM_REQUIRE(penalty == VXM_PENALTY_L1 || penalty == VXM_PENALTY_L2, VXM_ERR_UNSUPPORTED, "penalty can only be l1 or l2. Got: %d", penalty);
     hipStream_t s = VXM_STREAM(stream);
-    (void)hipMemsetAsync(acc, 0, sizeof(double) * 3 * B, s);
-    const dim3 grid(reduce_blocks((long long)C * D * H * W), B);          // few fat blocks: they end in fp64 atomics
+    (void)hipMemsetAsync(acc, 0, sizeof(double) * 3 * B * VXM_GRAD_SLOTS, s);
+    const long long rows4 = ((long long)C * D * H + 3) / 4;
+    const dim3 grid((unsigned)(rows4 > 8192 ? 8192 : rows4), B);          // 4 rows per block and pass; atomics spread over the slots
     if (penalty == VXM_PENALTY_L2) hipLaunchKernelGGL(k_gradloss_fwd<1>, grid, dim3(256), 0, s, y, acc, C, D, H, W);
     else hipLaunchKernelGGL(k_gradloss_fwd<0>, grid, dim3(256), 0, s, y, acc, C, D, H, W);
     hipLaunchKernelGGL(k_gradloss_finish, dim3(1), dim3(64), 0, s, acc, loss, B, C, D, H, W, (double)mult, axes);

@@ -148,7 +148,7 @@ class GradLoss2dFn(torch.autograd.Function):
         y = _c(y)
         B, C, H, W = y.shape
         loss = torch.empty((), dtype=y.dtype, device=y.device)
-        acc = torch.empty(3 * B, dtype=torch.float64, device=y.device)
+        acc = torch.empty(3 * B * 32, dtype=torch.float64, device=y.device)      # 3 * B * VXM_GRAD_SLOTS (include/vxm_hip.h)
         call("vxm_gradloss2d_fwd", ptr(y), ptr(loss), ptr(acc), B, C, H, W, PENALTY[penalty], float(mult), stream())
         ctx.save_for_backward(y)
         ctx.args = (penalty, float(mult))
