@@ -252,6 +252,33 @@ def test_vxm_dense_bf16_vs_emulated_and_fp32_oracle(vxm, inshape, kw):
         assert e < 0.15, (n, e)                                                       # bf16 gradients against fp32 ones (coarse levels: few voxels)
 
 
+def test_bare_unet_bf16_vs_emulated_oracle(vxm):
+    """`Unet.forward` alone under autocast (one input tensor, the last activation handed back as fp32 NCDHW), forward and
+    gradients of the parameters and of the input, against the oracle with the same rounding points."""
+    inshape = (16, 32, 32)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((2, 2) + inshape).astype(np.float32)
+    sd = {k: v for k, v in orc.seeded_state_dict(inshape, seed=9).items() if k.startswith("unet_model.")}
+    net = vxm.networks.Unet(inshape, infeats=2)
+    net.load_state_dict({k[len("unet_model."):]: v for k, v in sd.items()})
+    net = net.cuda()
+    xg = G(x).requires_grad_()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = net(xg)
+    assert y.dtype == torch.float32 and y.shape == (2, 16) + inshape
+    gout = rng.standard_normal(y.shape).astype(np.float32)
+    y.backward(G(gout))
+    sdo = {k: v.clone().double().requires_grad_() for k, v in sd.items()}
+    xo = torch.from_numpy(x).double().requires_grad_()
+    with orc.bf16_activations():
+        yo = orc.unet_forward(xo, sdo)
+    yo.backward(rbf(gout))
+    assert rel_l2(N(y), yo.detach().numpy()) < 5e-3
+    assert rel_l2(N(xg.grad), xo.grad.numpy()) < 2e-2
+    for name, p in net.named_parameters():
+        assert rel_l2(N(p.grad), sdo["unet_model." + name].grad.numpy()) < 3e-2, name
+
+
 def test_vxm_dense_bf16_engine_is_selected_by_autocast_only(vxm):
     from voxelmorph_amd.torch import functional_bf16 as VB
     assert not VB.enabled()
