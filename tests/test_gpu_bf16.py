@@ -255,7 +255,7 @@ def test_vxm_dense_bf16_vs_emulated_and_fp32_oracle(vxm, inshape, kw):
 def test_bare_unet_bf16_vs_emulated_oracle(vxm):
     """`Unet.forward` alone under autocast (one input tensor, the last activation handed back as fp32 NCDHW), forward and
     gradients of the parameters and of the input, against the oracle with the same rounding points."""
-    inshape = (16, 32, 32)
+    inshape = (32, 32, 32)
     rng = np.random.default_rng(8)
     x = rng.standard_normal((2, 2) + inshape).astype(np.float32)
     sd = {k: v for k, v in orc.seeded_state_dict(inshape, seed=9).items() if k.startswith("unet_model.")}
@@ -266,7 +266,9 @@ def test_bare_unet_bf16_vs_emulated_oracle(vxm):
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = net(xg)
     assert y.dtype == torch.float32 and y.shape == (2, 16) + inshape
-    gout = rng.standard_normal(y.shape).astype(np.float32)
+    # a cotangent with a non-zero mean: with a white-noise one every parameter gradient is a cancelling sum over the voxels
+    # (condition ~ sqrt(#voxels)) and the two bf16 evaluations differ by 2-3 %, each 7-14 % from the fp64 one — measured, DESIGN.md §2
+    gout = (rng.standard_normal(y.shape) + 1.0).astype(np.float32)
     y.backward(G(gout))
     sdo = {k: v.clone().double().requires_grad_() for k, v in sd.items()}
     xo = torch.from_numpy(x).double().requires_grad_()
@@ -274,9 +276,12 @@ def test_bare_unet_bf16_vs_emulated_oracle(vxm):
         yo = orc.unet_forward(xo, sdo)
     yo.backward(rbf(gout))
     assert rel_l2(N(y), yo.detach().numpy()) < 5e-3
-    assert rel_l2(N(xg.grad), xo.grad.numpy()) < 2e-2
-    for name, p in net.named_parameters():
-        assert rel_l2(N(p.grad), sdo["unet_model." + name].grad.numpy()) < 3e-2, name
+    # d/dx: the first layer's dz is stored once more in bf16 after the pooled and the skip contribution are added (the oracle adds
+    # the two rounded contributions in fp64); dx is a 432-term signed sum of it, so that 2^-9 shows up ~20x larger
+    assert rel_l2(N(xg.grad), xo.grad.numpy()) < 3e-2
+    gerr = {n: rel_l2(N(p.grad), sdo["unet_model." + n].grad.numpy()) for n, p in net.named_parameters()}
+    print("bare Unet bf16: worst grad rel-L2 %.2e (%s)" % (max(gerr.values()), max(gerr, key=gerr.get)), sorted(gerr.items(), key=lambda kv: -kv[1])[:4])
+    assert max(gerr.values()) < 6e-3, gerr
 
 
 def test_vxm_dense_bf16_engine_is_selected_by_autocast_only(vxm):
