@@ -220,6 +220,24 @@ def test_grad_mse_dice_golden(vxm, g_losses):
     np.testing.assert_allclose(N(yp.grad), g_losses["dice_g"], atol=1e-9, rtol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 40, 48, 56), (1, 3, 7, 9, 12), (2, 3, 5, 6, 260), (1, 3, 6, 5, 11), (1, 2, 1, 9, 16)])
+@pytest.mark.parametrize("pen", ["l1", "l2"])
+def test_grad_loss_kernel_variants_vs_oracle(vxm, shape, pen):
+    """Both Grad kernels (16-byte loads when W % 4 == 0 — incl. W > 256, where a wave walks a row in two pieces — and the
+    scalar one otherwise), volumes and a planar field (D = 1), value and gradient against the fp64 oracle."""
+    rng = np.random.default_rng(sum(shape))
+    planar = shape[2] == 1
+    f = rng.standard_normal(shape).astype(np.float32)
+    fg = G(f[:, :, 0] if planar else f, True)
+    l = vxm.losses.Grad(pen, loss_mult=2).loss(None, fg)
+    l.backward()
+    fo = torch.from_numpy(f[:, :, 0] if planar else f).double().requires_grad_()
+    lo = orc.grad_loss(fo, pen, 2)
+    lo.backward()
+    assert abs(float(l.detach()) - float(lo.detach())) <= 1e-6 * abs(float(lo.detach()))
+    assert rel_l2(N(fg.grad), fo.grad.numpy()) < 1e-6
+
+
 # ------------------------------------------------------------------ conv / pool / U-Net
 @pytest.mark.parametrize("cin,cout,vol,slope", [
     (2, 16, (8, 8, 16), 0.2), (16, 32, (8, 12, 16), 0.2), (32, 32, (5, 6, 7), 0.2), (48, 32, (4, 8, 32), 0.2),
