@@ -239,6 +239,14 @@ int vxm_bf16_from_blocked(const void* x, int Cblk, float* out, int C, int B, int
 size_t vxm_bf16_conv_packed_bytes(int InC, int OutC);
 int vxm_bf16_conv_pack_weights(const float* w, int Cw_in, int Cw_out, int ci_lo, int ci_n, int transpose_flip, void* wpacked,
                                void* stream);
+/* the same for n_jobs operators in one launch (the job table is host memory, read before the call returns): what a training step
+ * uses after every optimiser step, when all the packed copies of a network are stale at once */
+typedef struct VxmBf16PackJob {
+    const float* w;
+    void* wpacked;
+    int Cw_in, Cw_out, ci_lo, ci_n, transpose_flip;
+} VxmBf16PackJob;
+int vxm_bf16_conv_pack_weights_batch(const VxmBf16PackJob* jobs, int n_jobs, void* stream);
 /* conv3d(k3,p1) over the virtual concat [x0 (optionally nearest-x2 upsampled) | x1] + bias + LeakyReLU(leaky_slope).
  * out_planar_f32 = 0: y blocked bf16 with Cout (multiple of 16) channels, optionally multiplied by LeakyReLU'(mask)
  * (mask: blocked, Cout channels; the fused leaky_relu_backward of backward-data).  out_planar_f32 = 1: y fp32

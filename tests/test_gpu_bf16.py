@@ -252,6 +252,45 @@ def test_vxm_dense_bf16_vs_emulated_and_fp32_oracle(vxm, inshape, kw):
         assert e < 0.15, (n, e)                                                       # bf16 gradients against fp32 ones (coarse levels: few voxels)
 
 
+def test_batched_weight_packing_equals_per_operator_packing(vxm):
+    """`vxm_bf16_conv_pack_weights_batch` (one launch for a whole network; > 48 jobs: more than one kernel-argument table) writes
+    the same bytes as the per-operator entry point, and `prepack` fills the cache `pack_weights` reads."""
+    import ctypes
+    from voxelmorph_amd import _lib
+    from voxelmorph_amd._lib import call, stream
+    from voxelmorph_amd.torch import functional_bf16 as VB
+    rng = np.random.default_rng(3)
+    ws = [G(rng.standard_normal(sh).astype(np.float32)) for sh in [(16, 2, 3, 3, 3), (32, 16, 3, 3, 3), (32, 48, 3, 3, 3), (3, 16, 3, 3, 3)]]
+    specs = []
+    for w in ws:
+        cin = w.shape[1]
+        specs += [(w, 0, cin, False), (w, 0, cin, True)]
+        if cin == 48:
+            specs += [(w, 0, 32, True), (w, 32, 16, True)]
+    specs = specs * 6                                                     # 60 jobs
+    singles = []
+    for w, lo, n, flip in specs:
+        cout, cin = w.shape[:2]
+        inc, outc = (cout, n) if flip else (n, cout)
+        wp = torch.zeros(_lib.lib().vxm_bf16_conv_packed_bytes(inc, outc), dtype=torch.uint8, device="cuda")
+        call("vxm_bf16_conv_pack_weights", w.data_ptr(), cin, cout, lo, n, 1 if flip else 0, wp.data_ptr(), stream())
+        singles.append(wp)
+    outs = [torch.full_like(x, 0xAB) for x in singles]
+    table = (_lib.Bf16PackJob * len(specs))()
+    for j, ((w, lo, n, flip), o) in enumerate(zip(specs, outs)):
+        table[j] = _lib.Bf16PackJob(w.data_ptr(), o.data_ptr(), w.shape[1], w.shape[0], lo, n, 1 if flip else 0)
+    call("vxm_bf16_conv_pack_weights_batch", ctypes.cast(table, ctypes.c_void_p), len(specs), stream())
+    for a, b in zip(singles, outs):
+        assert torch.equal(a, b)
+    table[3].ci_n = 99
+    with pytest.raises(Exception, match="channel range"):
+        call("vxm_bf16_conv_pack_weights_batch", ctypes.cast(table, ctypes.c_void_p), len(specs), stream())
+    VB.prepack(specs[:10])
+    for (w, lo, n, flip), ref in zip(specs[:10], singles):
+        ver, wp = w._vxm_bf16_packs[(lo, n, flip)]
+        assert ver == w._version and torch.equal(wp, ref) and VB.pack_weights(w, lo, n, flip) is wp
+
+
 def test_bare_unet_bf16_vs_emulated_oracle(vxm):
     """`Unet.forward` alone under autocast (one input tensor, the last activation handed back as fp32 NCDHW), forward and
     gradients of the parameters and of the input, against the oracle with the same rounding points."""

@@ -16,6 +16,13 @@ LIB_PATH = os.path.join(_HERE, "libvxm_hip.so")
 _c = ctypes
 _P, _I, _L, _F, _S = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_size_t
 
+
+class Bf16PackJob(_c.Structure):
+    """`VxmBf16PackJob` of include/vxm_hip.h"""
+    _fields_ = [("w", _c.c_void_p), ("wpacked", _c.c_void_p), ("Cw_in", _c.c_int), ("Cw_out", _c.c_int), ("ci_lo", _c.c_int),
+                ("ci_n", _c.c_int), ("transpose_flip", _c.c_int)]
+
+
 # name -> argtypes (return type is int unless listed in _RESTYPES); mirrors include/vxm_hip.h
 SIGNATURES = {
     "vxm_version": [],
@@ -75,6 +82,7 @@ SIGNATURES = {
     "vxm_bf16_from_blocked": [_P, _I, _P, _I, _I, _L, _P],
     "vxm_bf16_conv_packed_bytes": [_I, _I],
     "vxm_bf16_conv_pack_weights": [_P, _I, _I, _I, _I, _I, _P, _P],
+    "vxm_bf16_conv_pack_weights_batch": [_P, _I, _P],
     "vxm_bf16_conv_fwd": [_P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _F, _P, _F, _I, _I, _I, _I, _P],
     "vxm_bf16_conv_bwd_weight_workspace_bytes": [_I, _I, _I, _I, _I, _I],
     "vxm_bf16_conv_bwd_weight": [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _S, _I, _I, _I, _I, _P],

@@ -212,10 +212,8 @@ __global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x
 // Operator: y[o] = sum_i Wop[o][i][tap] x[i];  forward Wop[o][i][t] = w[o][ci_lo + i][t] (InC = ci_n inputs, OutC = Cw_out);
 // flip (backward-data onto the input-channel range [ci_lo, ci_lo + ci_n)): Wop[o][i][t] = w[i][ci_lo + o][26 - t]
 // (InC = Cw_out inputs, OutC = ci_n).
-__global__ void __launch_bounds__(256) k_bf16_pack_weights(const float* __restrict__ w, u32x4* __restrict__ wp, int Cw_in, int ci_lo, int flip,
-                                                           int InC, int OutC, int NCT, int Q, size_t words) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= words) return;
+__device__ __forceinline__ void bf_pack_word(const float* __restrict__ w, u32x4* __restrict__ wp, size_t i, int Cw_in, int ci_lo, int flip, int InC,
+                                             int OutC, int NCT, int Q) {
     size_t r = i;
     const int lane = r % 64; r /= 64;
     const int ct = r % NCT; r /= NCT;
@@ -234,6 +232,33 @@ __global__ void __launch_bounds__(256) k_bf16_pack_weights(const float* __restri
         }
     }
     wp[i] = (u32x4){bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3]), bf_pack2(v[4], v[5]), bf_pack2(v[6], v[7])};
+}
+
+__global__ void __launch_bounds__(256) k_bf16_pack_weights(const float* __restrict__ w, u32x4* __restrict__ wp, int Cw_in, int ci_lo, int flip,
+                                                           int InC, int OutC, int NCT, int Q, size_t words) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < words) bf_pack_word(w, wp, i, Cw_in, ci_lo, flip, InC, OutC, NCT, Q);
+}
+
+// All the operators of a network in ONE launch (a training step re-packs ~27 operators after every optimiser step: 27 launches of
+// ~4 us each were 2 % of the bf16 step).  The job table travels in the kernel arguments; a block finds its job by a scan.
+#define BF_PACK_JOBS 48
+struct BfPackJob {
+    const float* w;
+    u32x4* wp;
+    int Cw_in, ci_lo, flip, InC, OutC, NCT, Q;
+    unsigned first_block, words;
+};
+struct BfPackBatch {
+    BfPackJob job[BF_PACK_JOBS];
+    int n;
+};
+__global__ void __launch_bounds__(256) k_bf16_pack_weights_batch(const BfPackBatch batch) {
+    int j = 0;
+    while (j + 1 < batch.n && blockIdx.x >= batch.job[j + 1].first_block) ++j;          // block-uniform
+    const BfPackJob& jb = batch.job[j];
+    const size_t i = (size_t)(blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+    if (i < jb.words) bf_pack_word(jb.w, jb.wp, i, jb.Cw_in, jb.ci_lo, jb.flip, jb.InC, jb.OutC, jb.NCT, jb.Q);
 }
 
 // planar fp32 [B][C0 (+ C1)][V] -> blocked bf16 [B][CB][V][8], channels beyond C0 + C1 zero.  One thread per (block, voxel).
@@ -714,6 +739,32 @@ int vxm_bf16_conv_pack_weights(const float* w, int Cw_in, int Cw_out, int ci_lo,
     hipLaunchKernelGGL(k_bf16_pack_weights, dim3(vxm_blocks((long long)words, 256)), dim3(256), 0, VXM_STREAM(stream), w, static_cast<u32x4*>(wpacked),
                        Cw_in, ci_lo, transpose_flip, InC, OutC, NCT, Q, words);
     return vxm_check_launch("vxm_bf16_conv_pack_weights");
+}
+
+int vxm_bf16_conv_pack_weights_batch(const VxmBf16PackJob* jobs, int n_jobs, void* stream) {
+    VXM_REQUIRE(n_jobs >= 0 && (jobs || n_jobs == 0), VXM_ERR_NULL_POINTER, "vxm_bf16_conv_pack_weights_batch: null job table");
+    for (int j = 0; j < n_jobs; ++j) {
+        const VxmBf16PackJob& a = jobs[j];
+        VXM_REQUIRE(a.w && a.wpacked, VXM_ERR_NULL_POINTER, "vxm_bf16_conv_pack_weights_batch: job %d: null pointer", j);
+        VXM_REQUIRE(a.Cw_in > 0 && a.Cw_out > 0 && a.ci_lo >= 0 && a.ci_n > 0 && a.ci_lo + a.ci_n <= a.Cw_in, VXM_ERR_BAD_SHAPE,
+                    "vxm_bf16_conv_pack_weights_batch: job %d: channel range [%d, %d) of %d", j, a.ci_lo, a.ci_lo + a.ci_n, a.Cw_in);
+        VXM_REQUIRE(bf_al16(a.wpacked), VXM_ERR_BAD_SHAPE, "vxm_bf16_conv_pack_weights_batch: job %d: 16-byte alignment", j);
+    }
+    for (int j0 = 0; j0 < n_jobs; j0 += BF_PACK_JOBS) {
+        BfPackBatch batch;
+        batch.n = n_jobs - j0 < BF_PACK_JOBS ? n_jobs - j0 : BF_PACK_JOBS;
+        unsigned blocks = 0;
+        for (int j = 0; j < batch.n; ++j) {
+            const VxmBf16PackJob& a = jobs[j0 + j];
+            const int InC = a.transpose_flip ? a.Cw_out : a.ci_n, OutC = a.transpose_flip ? a.ci_n : a.Cw_out;
+            const size_t words = vxm_bf16_conv_packed_bytes(InC, OutC) / 16;
+            batch.job[j] = {a.w, static_cast<u32x4*>(a.wpacked), a.Cw_in, a.ci_lo, a.transpose_flip ? 1 : 0, InC, OutC, bf_nct(OutC), (InC + 15) / 16,
+                            blocks, (unsigned)words};
+            blocks += (unsigned)((words + 255) / 256);
+        }
+        hipLaunchKernelGGL(k_bf16_pack_weights_batch, dim3(blocks), dim3(256), 0, VXM_STREAM(stream), batch);
+    }
+    return vxm_check_launch("vxm_bf16_conv_pack_weights_batch");
 }
 
 int vxm_bf16_conv_fwd(const void* x0, int C0, int x0_up, const void* x1, int C1, const void* wpacked, const float* bias, void* y, int Cout,

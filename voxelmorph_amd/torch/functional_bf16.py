@@ -10,6 +10,8 @@ It is selected the way a torch user asks for it: `with torch.autocast('cuda', dt
 (or `voxelmorph_amd.torch.functional_bf16.set_activation_dtype('bf16')` process-wide).  Replaces what autocast would send to
 MIOpen for `ConvBlock` / flow conv / MaxPool3d / Upsample + cat (voxelmorph/torch/networks.py:83-85,122-144,211,257,290-305).
 """
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -56,6 +58,54 @@ def pack_weights(w, ci_lo, ci_n, flip):
     call("vxm_bf16_conv_pack_weights", ptr(_c(w)), cin, cout, ci_lo, ci_n, 1 if flip else 0, ptr(wp), stream())
     cache[key] = (w._version, wp)
     return wp
+
+
+def prepack(jobs):
+    """Pack every stale operator of `jobs` = [(w, ci_lo, ci_n, flip), ...] in ONE launch (`vxm_bf16_conv_pack_weights_batch`); the
+    per-layer `pack_weights` calls of the step then hit the cache.  After an optimiser step all ~27 packed copies of a VxmDense
+    U-Net are stale at once."""
+    stale = []
+    for w, ci_lo, ci_n, flip in jobs:
+        cache = w.__dict__.setdefault("_vxm_bf16_packs", {})
+        key = (ci_lo, ci_n, bool(flip))
+        hit = cache.get(key)
+        if hit is not None and hit[0] == w._version and hit[1].device == w.device:
+            continue
+        cout, cin = w.shape[:2]
+        inc, outc = (cout, ci_n) if flip else (ci_n, cout)
+        nbytes = _lib.lib().vxm_bf16_conv_packed_bytes(inc, outc)
+        wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else \
+            torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        stale.append((_c(w), cin, cout, ci_lo, ci_n, bool(flip), wp, cache, key, w._version))
+    if not stale:
+        return
+    table = (_lib.Bf16PackJob * len(stale))()
+    for j, (w, cin, cout, ci_lo, ci_n, flip, wp, _, _, _) in enumerate(stale):
+        table[j] = _lib.Bf16PackJob(w.data_ptr(), wp.data_ptr(), cin, cout, ci_lo, ci_n, 1 if flip else 0)
+    call("vxm_bf16_conv_pack_weights_batch", ctypes.cast(table, ctypes.c_void_p), len(stale), stream())
+    for _, _, _, _, _, _, wp, cache, key, ver in stale:
+        cache[key] = (ver, wp)
+
+
+def _pack_jobs(plan, params, cin0, with_backward, input_grads):
+    """the operators one pass over `plan` uses: the forward one of every conv and, for a training step, its adjoints per segment"""
+    jobs = []
+    for op in plan.ops:
+        if op["kind"] != "conv":
+            continue
+        w = params[2 * op["k"]]
+        jobs.append((w, 0, w.shape[1], False))
+        if not with_backward:
+            continue
+        s0, _, s1 = op["src"]
+        if s0 < plan.n_inputs:
+            if input_grads:
+                jobs.append((w, 0, cin0, True))
+            continue
+        jobs.append((w, 0, plan.ch[s0], True))
+        if s1 is not None:
+            jobs.append((w, plan.ch[s0], plan.ch[s1], True))
+    return jobs
 
 
 def conv(x0, c0, up0, x1, c1, wp, bias, y, cout, planar, slope, mask, mask_slope, B, D, H, W):
@@ -108,6 +158,7 @@ class UnetBf16Fn(torch.autograd.Function):
         x1 = inputs[1] if len(inputs) == 2 else None
         call("vxm_bf16_to_blocked", ptr(inputs[0]), plan.ch[0], inputs[0][0].numel(), ptr(x1), plan.ch[1] if x1 is not None else 0,
              x1[0].numel() if x1 is not None else 0, ptr(xin), _pad16(cin0), B, V, stream())
+        prepack(_pack_jobs(plan, params, cin0, any(ctx.needs_input_grad[1:]), any(ctx.needs_input_grad[1:1 + plan.n_inputs])))
         T = {}                  # tensor id -> blocked bf16 activation (ids of the inputs map to `xin`)
         out = None
         last = len(plan.ops) - 1
