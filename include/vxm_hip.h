@@ -254,6 +254,12 @@ int vxm_bf16_conv_pack_weights_batch(const VxmBf16PackJob* jobs, int n_jobs, voi
 int vxm_bf16_conv_fwd(const void* x0, int C0, int x0_up, const void* x1, int C1, const void* wpacked, const float* bias, void* y,
                       int Cout, int out_planar_f32, float leaky_slope, const void* mask, float mask_slope,
                       int B, int D, int H, int W, void* stream);
+/* backward-data onto a nearest-x2 UPSAMPLED segment in one kernel (replaces vxm_bf16_conv_fwd at full resolution followed by
+ * vxm_bf16_upsample2_bwd; same rounding points): dz blocked [B][Cdz/8][D][H][W][8], wpacked = the transpose_flip pack of the segment's
+ * channel range, dx_low blocked [B][Cout/8][D/2][H/2][W/2][8] = (sum over the 2x2x2 children of the adjoint conv) * LeakyReLU'(mask_low)
+ * (mask_low: blocked, low resolution, or NULL).  D, H, W even. */
+int vxm_bf16_conv_bwd_data_up(const void* dz, int Cdz, const void* wpacked, void* dx_low, int Cout, const void* mask_low, float mask_slope,
+                              int B, int D, int H, int W, void* stream);
 /* gw[Cout_w][Cin_w][27], gb[Cout_w] (nullable) fp32 from the blocked input (virtual concat, C0 + C1 >= Cin_w channels) and the
  * blocked gradient dz (Cdz = 16 or 32 >= Cout_w channels).  Deterministic (fixed-order partial sums in `work`). */
 size_t vxm_bf16_conv_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D, int H, int W);

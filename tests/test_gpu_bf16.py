@@ -79,7 +79,7 @@ def test_blocked_layout_roundtrip(vxm):
 CONV_CASES = [
     # c0, up0, c1, cout, vol, slope
     (16, False, 0, 16, (8, 8, 16), 0.2),
-    (16, False, 0, 32, (10, 6, 20), 0.2),          # ragged tiles: D, H, W not multiples of the 8 x 4 x 16 tile
+    (16, False, 0, 32, (10, 6, 20), 0.2),          # ragged tiles: D, H, W not multiples of the 8 x 6 x 16 (or 8 x 8 x 16) tile
     (32, False, 0, 16, (8, 12, 16), 0.2),
     (32, True, 16, 32, (16, 8, 32), 0.2),           # cat([upsample(x0), x1])
     (32, True, 32, 32, (8, 8, 16), 0.2),
@@ -250,6 +250,36 @@ def test_vxm_dense_bf16_vs_emulated_and_fp32_oracle(vxm, inshape, kw):
     assert res["fp32"][0] < 1e-2 and res["fp32"][1] < 1e-4                           # bf16 conv activations rel-L2 <= 1e-2
     for n, e in res["fp32"][3].items():
         assert e < 0.15, (n, e)                                                       # bf16 gradients against fp32 ones (coarse levels: few voxels)
+
+
+@pytest.mark.parametrize("cdz,cup,vol,masked", [(32, 32, (12, 6, 20), True), (32, 16, (8, 8, 16), True), (16, 32, (18, 10, 36), False),
+                                                 (32, 32, (2, 2, 2), True)])
+def test_fused_upsampled_segment_backward_data_equals_the_two_kernel_form(vxm, cdz, cup, vol, masked):
+    """`vxm_bf16_conv_bwd_data_up` (adjoint conv + adjoint of nearest-x2 upsampling + leaky_relu_backward, one kernel, nothing
+    written at full resolution) against `vxm_bf16_conv_fwd` followed by `vxm_bf16_upsample2_bwd`: same rounding points (every
+    full-resolution value rounded to bf16 before the 2x2x2 sum), so the results may differ only by the order of an fp32 sum of
+    eight bf16 numbers."""
+    from voxelmorph_amd._lib import call, ptr, stream
+    from voxelmorph_amd.torch import functional_bf16 as VB
+    rng = np.random.default_rng(cdz + cup + vol[0])
+    B = 2
+    D, H, W = vol
+    low = (D // 2, H // 2, W // 2)
+    w = G((rng.standard_normal((cdz, cup + 16, 3, 3, 3)) / np.sqrt(27 * cdz)).astype(np.float32))      # Conv3d(cup + 16 -> cdz): segment 0 = upsampled
+    dz = to_blocked(G(rng.standard_normal((B, cdz) + vol).astype(np.float32)))
+    ylow = to_blocked(G(rng.standard_normal((B, cup) + low).astype(np.float32)))
+    wp = VB.pack_weights(w, 0, cup, True)
+    gfull = VB._blocked(B, cup, vol, "cuda")
+    VB.conv(dz, cdz, False, None, 0, wp, None, gfull, cup, False, 1.0, None, 1.0, B, D, H, W)
+    want = VB._blocked(B, cup, low, "cuda")
+    call("vxm_bf16_upsample2_bwd", ptr(gfull), ptr(ylow) if masked else None, ptr(want), 0.2, B, cup, *low, stream())
+    got = torch.full_like(want, float("nan"))
+    call("vxm_bf16_conv_bwd_data_up", ptr(dz), cdz, ptr(wp), ptr(got), cup, ptr(ylow) if masked else None, 0.2, B, D, H, W, stream())
+    a, b = got.float().cpu().numpy(), want.float().cpu().numpy()
+    assert np.isfinite(a).all()
+    assert (a == b).mean() > 0.995 and np.abs(a - b).max() <= 2.0 ** -7 * np.abs(b).max()
+    with pytest.raises(Exception, match="even extents"):
+        call("vxm_bf16_conv_bwd_data_up", ptr(dz), cdz, ptr(wp), ptr(got), cup, None, 0.2, B, D, H, W - 1, stream())
 
 
 def test_batched_weight_packing_equals_per_operator_packing(vxm):

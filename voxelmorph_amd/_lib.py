@@ -84,6 +84,7 @@ SIGNATURES = {
     "vxm_bf16_conv_pack_weights": [_P, _I, _I, _I, _I, _I, _P, _P],
     "vxm_bf16_conv_pack_weights_batch": [_P, _I, _P],
     "vxm_bf16_conv_fwd": [_P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _F, _P, _F, _I, _I, _I, _I, _P],
+    "vxm_bf16_conv_bwd_data_up": [_P, _I, _P, _P, _I, _P, _F, _I, _I, _I, _I, _P],
     "vxm_bf16_conv_bwd_weight_workspace_bytes": [_I, _I, _I, _I, _I, _I],
     "vxm_bf16_conv_bwd_weight": [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _P, _P, _S, _I, _I, _I, _I, _P],
     "vxm_bf16_maxpool2_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],

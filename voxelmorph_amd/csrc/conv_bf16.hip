@@ -47,6 +47,8 @@ constexpr int bf_lds_bytes(int nct, int rows) { return 2 * bf_cbs(rows) + bf_wch
 
 // OUT: 0 = blocked bf16 (bias + LeakyReLU, optional LeakyReLU' mask of the previous block = fused leaky_relu_backward),
 //      1 = planar fp32 [B][Cout<=4][D][H][W] (the flow head: bias only)
+//      2 = blocked bf16 at HALF resolution: the sum over each voxel's 2 x 2 x 2 children (adjoint of nearest-x2 upsampling; no bias /
+//          activation; optional LeakyReLU' mask of the low-resolution block) -- backward-data onto an upsampled segment
 template <int NCT, int ROWS, int OUT>
 __global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                           void* __restrict__ y, int Cout, float act_slope, const void* __restrict__ mask,
@@ -170,6 +172,55 @@ __global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x
                             yp[(size_t)j * V + (d * H + h0 + row) * W + w] = v;
                         }
                 }
+        }
+        return;
+    } else if constexpr (OUT == 2) {
+        // the adjoint of nearest-x2 upsampling fused in: every voxel's result is rounded to bf16 (the value the unfused pair of
+        // kernels stored), the 2 x 2 x 2 children are added in fp32 -- h pairs in registers, w pairs across lanes n ^ 1, d pairs
+        // across waves through LDS -- and the sum, times LeakyReLU'(mask) of the LOW-resolution block, is stored at low resolution.
+        __syncthreads();                                        // every wave is done reading Xs
+        f32x4* const ex = reinterpret_cast<f32x4*>(Xs);         // [4 odd waves][NCT][ROWS / 2][64]
+        f32x4 sum[NCT][ROWS / 2];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int hp = 0; hp < ROWS / 2; ++hp) {
+                const f32x4 a0 = acc[ct][2 * hp], a1 = acc[ct][2 * hp + 1];
+                const unsigned p0 = bf_pack2(a0[0], a0[1]), p1 = bf_pack2(a0[2], a0[3]), p2 = bf_pack2(a1[0], a1[1]), p3 = bf_pack2(a1[2], a1[3]);
+                f32x4 t = {bf_lo(p0) + bf_lo(p2), bf_hi(p0) + bf_hi(p2), bf_lo(p1) + bf_lo(p3), bf_hi(p1) + bf_hi(p3)};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] += __shfl_xor(t[j], 1);
+                sum[ct][hp] = t;
+                if (wave & 1) ex[(((wave >> 1) * NCT + ct) * (ROWS / 2) + hp) * 64 + lane] = t;
+            }
+        __syncthreads();
+        if ((wave & 1) || (n & 1)) return;
+        const int Vl = Dl * Hl * Wl, CBo = Cout >> 3;
+        const int dl = (d0 + wave) >> 1, wl = (w0 + n) >> 1;
+        const __amdgpu_buffer_rsrc_t ry = bf_rsrc(static_cast<char*>(y) + (size_t)b * CBo * Vl * 16, (unsigned)CBo * (unsigned)Vl * 16u);
+        const __amdgpu_buffer_rsrc_t rm = bf_rsrc(mask ? static_cast<const char*>(mask) + (size_t)b * CBo * Vl * 16 : y, (unsigned)CBo * (unsigned)Vl * 16u);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const int co = (g * NCT + ct) * 16 + 4 * kg, pb = co >> 3;
+            const bool cok = dl < Dl && wl < Wl && pb < CBo;
+#pragma unroll
+            for (int hp = 0; hp < ROWS / 2; ++hp) {
+                const int hl = (h0 >> 1) + hp;
+                if (hl < Hl) {                                  // wave-uniform
+                    const f32x4 o = ex[(((wave >> 1) * NCT + ct) * (ROWS / 2) + hp) * 64 + lane];
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = sum[ct][hp][j] + o[j];
+                    const int voff = cok ? (((pb * Dl + dl) * Hl + hl) * Wl + wl) * 16 + (kg & 1) * 8 : VXM_OOB;
+                    if (mask) {
+                        const u32x2 m = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, voff, 0, 0));
+                        v[0] *= vxm_lrelu_grad(bf_lo(m.x), mask_slope); v[1] *= vxm_lrelu_grad(bf_hi(m.x), mask_slope);
+                        v[2] *= vxm_lrelu_grad(bf_lo(m.y), mask_slope); v[3] *= vxm_lrelu_grad(bf_hi(m.y), mask_slope);
+                    }
+                    const u32x2 st = {bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(st, ry, voff, 0, 0);
+                }
+            }
         }
         return;
     } else {
@@ -778,8 +829,21 @@ int vxm_bf16_conv_fwd(const void* x0, int C0, int x0_up, const void* x1, int C1,
     hipStream_t s = VXM_STREAM(stream);
     if (out_planar_f32) bf_launch_conv<1, 8, 1>(in, wpacked, bias, y, Cout, leaky_slope, nullptr, 1.0f, B, D, H, W, s);
     else if (bf_nct(Cout) == 1) bf_launch_conv<1, 8, 0>(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
-    else bf_launch_conv<2, 4, 0>(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
+    else bf_launch_conv<2, 6, 0>(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
     return vxm_check_launch("vxm_bf16_conv_fwd");
+}
+
+int vxm_bf16_conv_bwd_data_up(const void* dz, int Cdz, const void* wpacked, void* dx_low, int Cout, const void* mask_low, float mask_slope, int B,
+                              int D, int H, int W, void* stream) {
+    VXM_REQUIRE(dz && wpacked && dx_low, VXM_ERR_NULL_POINTER, "vxm_bf16_conv_bwd_data_up: null pointer");
+    if (int e = bf_check("vxm_bf16_conv_bwd_data_up", Cdz, 0, 1, Cout, B, D, H, W)) return e;
+    VXM_REQUIRE(Cout % 16 == 0, VXM_ERR_BAD_SHAPE, "vxm_bf16_conv_bwd_data_up: %d output channels (multiples of 16)", Cout);
+    VXM_REQUIRE(bf_al16(dz) && bf_al16(wpacked) && bf_al16(dx_low) && bf_al16(mask_low), VXM_ERR_BAD_SHAPE, "vxm_bf16_conv_bwd_data_up: 16-byte alignment");
+    const BfIn in = {dz, nullptr, Cdz / 8, 0, 0};
+    hipStream_t s = VXM_STREAM(stream);
+    if (bf_nct(Cout) == 1) bf_launch_conv<1, 8, 2>(in, wpacked, nullptr, dx_low, Cout, 1.0f, mask_low, mask_slope, B, D, H, W, s);
+    else bf_launch_conv<2, 6, 2>(in, wpacked, nullptr, dx_low, Cout, 1.0f, mask_low, mask_slope, B, D, H, W, s);
+    return vxm_check_launch("vxm_bf16_conv_bwd_data_up");
 }
 
 size_t vxm_bf16_conv_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D, int H, int W) {

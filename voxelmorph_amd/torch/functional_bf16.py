@@ -110,7 +110,7 @@ def _pack_jobs(plan, params, cin0, with_backward, input_grads):
 
 def conv(x0, c0, up0, x1, c1, wp, bias, y, cout, planar, slope, mask, mask_slope, B, D, H, W):
     nct = 1 if (planar or cout <= 16) else 2
-    with _prof.region("k_bf16_conv<%d,%d,%d>" % (nct, 4 if nct == 2 else 8, 1 if planar else 0),
+    with _prof.region("k_bf16_conv<%d,%d,%d>" % (nct, 6 if nct == 2 else 8, 1 if planar else 0),
                       flops=2.0 * 27 * (c0 + c1) * (16 * nct * ((cout + 16 * nct - 1) // (16 * nct))) * B * D * H * W,
                       nominal=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_bf16_conv_fwd", ptr(x0), c0, 1 if up0 else 0, ptr(x1), c1, ptr(wp), ptr(bias), ptr(y), cout, 1 if planar else 0,
@@ -280,13 +280,16 @@ class UnetBf16Fn(torch.autograd.Function):
             single = len(plan.consumers[s0]) == 1
             if up0:
                 lD, lH, lW = D // 2, H // 2, W // 2
-                gfull = _blocked(B, c0r, (D, H, W), dev)
-                conv(dz, cdz, False, None, 0, pack_weights(w, 0, c0r, True), None, gfull, c0r, False, 1.0, None, 1.0, B, D, H, W)
-                dzl = _blocked(B, c0r, (lD, lH, lW), dev)
                 if prod0["kind"] != "conv" or not single:
                     raise NotImplementedError("bf16 engine: upsampled tensors come from a decoder ConvBlock with one consumer")
-                call("vxm_bf16_upsample2_bwd", ptr(gfull), ptr(T[s0]) if prod0["slope"] != 1.0 else None, ptr(dzl), float(prod0["slope"]),
-                     B, c0r, lD, lH, lW, stream())
+                dzl = _blocked(B, c0r, (lD, lH, lW), dev)
+                # adjoint conv + adjoint of the upsampling + leaky_relu_backward of the producer in one kernel: the full-resolution
+                # gradient of the upsampled segment (440 MB at the top level) is never written
+                nct = 1 if c0r <= 16 else 2
+                with _prof.region("k_bf16_conv<%d,%d,2>" % (nct, 6 if nct == 2 else 8), flops=2.0 * 27 * cdz * c0r * B * D * H * W,
+                                  nominal=2.0 * 27 * cdz * c0r * B * D * H * W):
+                    call("vxm_bf16_conv_bwd_data_up", ptr(dz), cdz, ptr(pack_weights(w, 0, c0r, True)), ptr(dzl), c0r,
+                         ptr(T[s0]) if prod0["slope"] != 1.0 else None, float(prod0["slope"]), B, D, H, W, stream())
                 DZ[s0] = dzl
             elif prod0["kind"] == "conv" and single:
                 gx = _blocked(B, c0r, (D, H, W), dev)
