@@ -235,10 +235,16 @@ __global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x
         float bz[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bz[j] = (bias && co + j < Cout) ? bias[co + j] : 0.0f;
+        // rows in pairs: the lane groups kg and kg ^ 1 hold the two halves of an 8-channel block; v_permlane16_swap (gfx950; lane
+        // pattern probed in tools/probe/permlane_swap_probe.hip) hands the even group the other half of row 2 rp and the odd group
+        // the other half of row 2 rp + 1, so that every lane stores ONE full 16-byte word (half the store instructions: the
+        // epilogue was 8 % store issue + 12 % store traffic of these launches, measured with the stores dropped)
 #pragma unroll
-        for (int row = 0; row < ROWS; ++row) {
-            if (h0 + row < H) {                                // wave-uniform
-                const int voff = cok ? (((pb * D + d) * H + h0 + row) * W + w) * 16 + (kg & 1) * 8 : VXM_OOB;
+        for (int rp = 0; rp < ROWS / 2; ++rp) {
+            unsigned pk[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int row = 2 * rp + e;
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -246,13 +252,19 @@ __global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x
                     v[j] = v[j] > 0.0f ? v[j] : v[j] * act_slope;
                 }
                 if (mask) {
-                    const u32x2 m = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, voff, 0, 0));
+                    const int moff = (cok && h0 + row < H) ? (((pb * D + d) * H + h0 + row) * W + w) * 16 + (kg & 1) * 8 : VXM_OOB;
+                    const u32x2 m = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, moff, 0, 0));
                     v[0] *= vxm_lrelu_grad(bf_lo(m.x), mask_slope); v[1] *= vxm_lrelu_grad(bf_hi(m.x), mask_slope);
                     v[2] *= vxm_lrelu_grad(bf_lo(m.y), mask_slope); v[3] *= vxm_lrelu_grad(bf_hi(m.y), mask_slope);
                 }
-                const u32x2 o = {bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3])};
-                __builtin_amdgcn_raw_buffer_store_b64(o, ry, voff, 0, 0);
+                pk[e][0] = bf_pack2(v[0], v[1]);
+                pk[e][1] = bf_pack2(v[2], v[3]);
             }
+            const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+            const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+            const int hrow = h0 + 2 * rp + (kg & 1);
+            const int voff = (cok && hrow < H) ? (((pb * D + d) * H + hrow) * W + w) * 16 : VXM_OOB;
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){s0.x, s1.x, s0.y, s1.y}, ry, voff, 0, 0);
         }
     }
     }
