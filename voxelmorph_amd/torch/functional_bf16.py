@@ -110,9 +110,12 @@ def _pack_jobs(plan, params, cin0, with_backward, input_grads):
 
 def conv(x0, c0, up0, x1, c1, wp, bias, y, cout, planar, slope, mask, mask_slope, B, D, H, W):
     nct = 1 if (planar or cout <= 16) else 2
+    V = B * D * H * W
+    # algorithmic bytes: every operand element read once (the upsampled segment at its own resolution), every result written once
+    nbytes = 2.0 * (c0 * (V // 8 if up0 else V) + c1 * V) + (4.0 if planar else 2.0) * cout * V + (2.0 * cout * V if mask is not None else 0.0)
     with _prof.region("k_bf16_conv<%d,%d,%d>" % (nct, 6 if nct == 2 else 8, 1 if planar else 0),
                       flops=2.0 * 27 * (c0 + c1) * (16 * nct * ((cout + 16 * nct - 1) // (16 * nct))) * B * D * H * W,
-                      nominal=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+                      nbytes=nbytes, nominal=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_bf16_conv_fwd", ptr(x0), c0, 1 if up0 else 0, ptr(x1), c1, ptr(wp), ptr(bias), ptr(y), cout, 1 if planar else 0,
              float(slope), ptr(mask), float(mask_slope), B, D, H, W, stream())
 
@@ -287,7 +290,7 @@ class UnetBf16Fn(torch.autograd.Function):
                 # gradient of the upsampled segment (440 MB at the top level) is never written
                 nct = 1 if c0r <= 16 else 2
                 with _prof.region("k_bf16_conv<%d,%d,2>" % (nct, 6 if nct == 2 else 8), flops=2.0 * 27 * cdz * c0r * B * D * H * W,
-                                  nominal=2.0 * 27 * cdz * c0r * B * D * H * W):
+                                  nbytes=2.0 * B * D * H * W * (cdz + c0r / 4.0), nominal=2.0 * 27 * cdz * c0r * B * D * H * W):
                     call("vxm_bf16_conv_bwd_data_up", ptr(dz), cdz, ptr(pack_weights(w, 0, c0r, True)), ptr(dzl), c0r,
                          ptr(T[s0]) if prod0["slope"] != 1.0 else None, float(prod0["slope"]), B, D, H, W, stream())
                 DZ[s0] = dzl
