@@ -144,6 +144,33 @@ def hbm_traffic(kernel, launches_per_step, suffix=""):
         rel, ", ".join(sorted(hits)))
 
 
+def binding_roofline(name, st):
+    """`roofline` of one kernel region from its totals over the timed steps (`st`: launches, ms, flops, nominal, bytes).
+    fp32 kernels are priced on the FLOPs they execute (= the reference formulation's, except the collapsed-upsample kernels, which
+    execute fewer), bf16 kernels on the reference formulation's FLOPs (they EXECUTE more: zero-padded channels and K slots are not
+    work).  A kernel with both a FLOP and a byte count is priced against the roofline that BINDS it, the one with the larger minimum
+    time: a 16-channel bf16 layer moves 64 B per voxel (8 ns per M voxel at 8 TB/s) for 13.8 kFLOP (5.5 ns at 2.5 PFLOP/s) -- an
+    HBM kernel that happens to use the MFMA; its MFMA fraction is kept as `mfma_frac`."""
+    sec = st["ms"] * 1e-3
+    per = {"avg_launch_ms": st["ms"] / st["launches"], "traffic": None}
+    hbm = None
+    if st["bytes"]:
+        ach_b = st["bytes"] / sec / 1e9
+        hbm = dict(per, kernel=name, bound="hbm", achieved=ach_b, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach_b / HBM_PEAK_GBS,
+                   algorithmic_per_launch=st["bytes"] / st["launches"])
+    if not st["flops"]:
+        return hbm or dict(per, kernel=name, bound="hbm", achieved=0.0, peak=HBM_PEAK_GBS, unit="GB/s", frac=0.0, algorithmic_per_launch=0.0)
+    is_bf = name.startswith("k_bf16")
+    alg = st["nominal"] if is_bf else st["flops"]
+    peak = BF16_MFMA_PEAK_TFLOPS if is_bf else FP32_MFMA_PEAK_TFLOPS
+    ach = alg / sec / 1e12
+    if hbm is not None and st["bytes"] / (HBM_PEAK_GBS * 1e9) > alg / (peak * 1e12):
+        hbm["mfma_frac"] = ach / peak
+        return hbm
+    return dict(per, kernel=name, bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
+                algorithmic_per_launch=alg / st["launches"])
+
+
 def _cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -237,27 +264,7 @@ def main():
         kernels[name] = ent
     dom = max(stats, key=lambda k: stats[k]["ms"])
     ds = stats[dom]
-    if ds["flops"]:
-        # fp32 kernels: FLOPs executed (= the reference formulation's, except the collapsed-upsample kernels, which execute fewer);
-        # bf16 kernels: the reference formulation's FLOPs (they EXECUTE more: zero-padded channels and K slots are not work)
-        is_bf = dom.startswith("k_bf16")
-        alg = ds["nominal"] if is_bf else ds["flops"]
-        peak = BF16_MFMA_PEAK_TFLOPS if is_bf else FP32_MFMA_PEAK_TFLOPS
-        ach = alg / (ds["ms"] * 1e-3) / 1e12
-        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": None,
-                "algorithmic_per_launch": alg / ds["launches"], "avg_launch_ms": ds["ms"] / ds["launches"]}
-        # the roofline that binds a kernel is the one with the LARGER minimum time: a 16-channel bf16 layer moves 64 B per voxel
-        # (8 ns per M voxel at 8 TB/s) for 13.8 kFLOP (5.5 ns at 2.5 PFLOP/s) -- it is an HBM kernel that happens to use the MFMA
-        if ds["bytes"] and ds["bytes"] / (HBM_PEAK_GBS * 1e9) > alg / (peak * 1e12):
-            ach_b = ds["bytes"] / (ds["ms"] * 1e-3) / 1e9
-            roof.update({"bound": "hbm", "achieved": ach_b, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS,
-                         "algorithmic_per_launch": ds["bytes"] / ds["launches"], "mfma_frac": ach / peak})
-    else:
-        ach = ds["bytes"] / (ds["ms"] * 1e-3) / 1e9
-        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_per_launch": ds["bytes"] / ds["launches"], "avg_launch_ms": ds["ms"] / ds["launches"]}
+    roof = binding_roofline(dom, ds)
     roof["traffic"], roof["traffic_unit"] = hbm_traffic(dom, ds["launches"] / args.steps, "_bf16" if bf16 else "")
     out = {
         "metric": "volume-pairs/sec VxmDense 160x192x224 int_steps=0 MSE train (bf16 activations)" if dense

@@ -305,3 +305,22 @@ def test_bench_gpus_n_self_launches_one_rank_per_gpu():
     assert out.returncode != 0
     assert out.stderr.count("bench.py needs an MI355X") == 2, out.stdout[-2000:] + out.stderr[-3000:]
     assert "WORLD_SIZE" not in out.stderr.split("bench.py needs an MI355X")[0][-300:]
+
+
+def test_bench_reports_the_roofline_that_binds_the_kernel():
+    """bench.py prices a kernel against the roofline with the larger minimum time: the fp32 conv (119 GFLOP, 0.88 GB per launch) is an
+    MFMA kernel; a 16-channel bf16 layer (0.095 TFLOP, 0.44 GB) is an HBM kernel whose MFMA fraction is kept beside; a 32-channel bf16
+    layer (0.38 TFLOP, 0.88 GB) is an MFMA kernel again; byte-only kernels (the warps) stay HBM."""
+    sys.path.insert(0, ROOT)
+    import bench
+    t8 = bench.binding_roofline("k_conv3d_k3_t8<1>", dict(launches=10, ms=9.7, flops=10 * 118.9e9, nominal=10 * 118.9e9, bytes=0.0))
+    assert t8["bound"] == "mfma" and t8["unit"] == "TFLOP/s" and abs(t8["frac"] - 122.6 / 157.3) < 1e-2 and t8["peak"] == bench.FP32_MFMA_PEAK_TFLOPS
+    a = bench.binding_roofline("k_bf16_conv<1,8,0>", dict(launches=2, ms=0.36, flops=2 * 0.12e12, nominal=2 * 0.095e12, bytes=2 * 0.44e9))
+    assert a["bound"] == "hbm" and a["peak"] == bench.HBM_PEAK_GBS and abs(a["achieved"] - 2444.4) < 1.0
+    assert abs(a["mfma_frac"] - (0.19e12 / 0.36e-3 / 1e12) / bench.BF16_MFMA_PEAK_TFLOPS) < 1e-9 and a["algorithmic_per_launch"] == 0.44e9
+    b = bench.binding_roofline("k_bf16_conv<2,6,0>", dict(launches=1, ms=0.44, flops=0.40e12, nominal=0.38e12, bytes=0.88e9))
+    assert b["bound"] == "mfma" and abs(b["achieved"] - 0.38e12 / 0.44e-3 / 1e12) < 1e-6 and "mfma_frac" not in b
+    w = bench.binding_roofline("warp3d_fwd", dict(launches=4, ms=0.2, flops=0.0, nominal=0.0, bytes=4 * 0.14e9))
+    assert w["bound"] == "hbm" and abs(w["frac"] - 2800.0 / 8000.0) < 1e-9
+    for r in (t8, a, b, w):
+        assert r["traffic"] is None and r["avg_launch_ms"] > 0
