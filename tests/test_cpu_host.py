@@ -324,3 +324,25 @@ def test_bench_reports_the_roofline_that_binds_the_kernel():
     assert w["bound"] == "hbm" and abs(w["frac"] - 2800.0 / 8000.0) < 1e-9
     for r in (t8, a, b, w):
         assert r["traffic"] is None and r["avg_launch_ms"] > 0
+
+
+def test_bf16_engine_enumerates_the_weight_operators_of_a_step():
+    """`functional_bf16._pack_jobs`: what one pass over the default VxmDense plan packs in its single launch — the forward operator of
+    each of the 12 convolutions; for a training step also the adjoint per input segment (two for the decoder layers that read
+    cat([upsample(x), skip]), none for the first layer unless the inputs want gradients)."""
+    from voxelmorph_amd.torch import functional_bf16 as VB
+    m = vxm.networks.VxmDense((32, 32, 32), int_steps=0)
+    plan = m.unet_model.plan(m._feats, extra=((m.flow.out_channels, 1.0),))
+    params = list(m.unet_model.conv_params()) + [m.flow.weight, m.flow.bias]
+    fwd = VB._pack_jobs(plan, params, 2, False, False)
+    assert [(tuple(w.shape[:2]), lo, n, flip) for w, lo, n, flip in fwd] == [
+        ((16, 2), 0, 2, False), ((32, 16), 0, 16, False), ((32, 32), 0, 32, False), ((32, 32), 0, 32, False), ((32, 32), 0, 32, False),
+        ((32, 64), 0, 64, False), ((32, 64), 0, 64, False), ((32, 64), 0, 64, False), ((32, 48), 0, 48, False), ((16, 32), 0, 32, False),
+        ((16, 16), 0, 16, False), ((3, 16), 0, 16, False)]
+    train = VB._pack_jobs(plan, params, 2, True, False)
+    assert len(train) == 27 and [j for j in train if not j[3]] == fwd
+    adj = [(tuple(w.shape[:2]), lo, n) for w, lo, n, flip in train if flip]
+    assert ((32, 48), 0, 32) in adj and ((32, 48), 32, 16) in adj and adj.count(((32, 64), 0, 32)) == 3 and adj.count(((32, 64), 32, 32)) == 3
+    assert not any(sh == (16, 2) for sh, _, _ in adj)
+    with_inputs = VB._pack_jobs(plan, params, 2, True, True)
+    assert len(with_inputs) == 28 and ((16, 2), 0, 2) in [(tuple(w.shape[:2]), lo, n) for w, lo, n, flip in with_inputs if flip]
