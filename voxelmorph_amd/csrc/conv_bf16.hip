@@ -270,192 +270,6 @@ __global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x
     }
 }
 
-// ---- persistent, double-buffered form of k_bf16_conv<NCT, ROWS, 0>.  One 8-wave block per CU walks its XCD's tile range; the haloed
-// tile of the NEXT (tile, chunk) item and its weights travel HBM/L2 -> LDS by LDS-DMA (16 bytes per lane, no VGPRs, zero padding through
-// the descriptor) into the other half of the LDS while this item multiplies: one barrier per item, no ds_write phase, and the
-// epilogue stores of a tile overlap the loads of the next.  (Measured: every launch of the one-tile-per-block kernel spends 54 % of
-// its wave-cycles parked in staging waits / barriers with the matrix pipe 42 % busy.)
-template <int NCT, int ROWS, int RESW>
-__global__ void __launch_bounds__(BF_THREADS, 2) k_bf16_conv_p(BfIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
-                                                            void* __restrict__ y, int Cout, float act_slope, const void* __restrict__ mask,
-                                                            float mask_slope, int B, int D, int H, int W, int Q) {
-    VXM_DYN_SMEM(u32x4, smem);
-    constexpr int HR = ROWS + 2, CBS = bf_cbs(ROWS) / 16, PLANE = HR * BF_HWV;
-    constexpr int NCBS = (BF_TD + 2) * PLANE, NIB = (NCBS + BF_THREADS - 1) / BF_THREADS;          // slots of one 8-channel block, DMA rounds for them
-    constexpr int WCH = bf_wchunk(NCT), WIT = (WCH + BF_THREADS - 1) / BF_THREADS;
-    // LDS, in 16-byte words.  RESW = 1: [Q chunks of weights, resident for the whole launch][tile buffer 0][tile buffer 1];
-    // RESW = 0 (the weights of the layer do not fit beside two tiles): two buffers of [tile][weights of its chunk]
-    constexpr int XW = 2 * CBS, BUFW = XW + (RESW ? 0 : WCH);
-    u32x4* const bufs = smem + (RESW ? Q * WCH : 0);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = lane >> 4, n = lane & 15;
-    const int g = blockIdx.y;
-
-    const int nw = (W + 15) / 16, nh = (H + ROWS - 1) / ROWS, nd = (D + BF_TD - 1) / BF_TD;
-    const int ntiles = B * nd * nh * nw;
-    const int xcd = blockIdx.x & 7, nper = gridDim.x >> 3;
-    const int lo = (int)((long long)ntiles * xcd / 8), hi = (int)((long long)ntiles * (xcd + 1) / 8);
-    int t = lo + (blockIdx.x >> 3);
-    if (t >= hi) return;
-
-    const int V = D * H * W;
-    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
-    const int V0 = in.up0 ? Dl * Hl * Wl : V;
-
-    // this thread's staging slots inside one 8-channel block, as halo coordinates (the same for both blocks and every item)
-    int sl[NIB];
-#pragma unroll
-    for (int j = 0; j < NIB; ++j) {
-        const int rem = tid + BF_THREADS * j;
-        const int hd = rem / PLANE, r2 = rem - hd * PLANE, hh = r2 / BF_HWV, hw = r2 - hh * BF_HWV;
-        sl[j] = (hd << 16) | (hh << 8) | hw;
-    }
-    int xoff[BF_STEPS];
-#pragma unroll
-    for (int s = 0; s < BF_STEPS; ++s) {
-        const int u = 4 * s + kg, uu = u < 18 ? u : 0;
-        const int kdkw = uu >> 1, cb = uu & 1, kd = kdkw / 3, kw = kdkw - 3 * kd;
-        xoff[s] = cb * CBS + (wave + kd) * PLANE + kw + n;
-    }
-
-    auto issue = [&](int tile, int q, int bi) {                  // LDS-DMA of item (tile, q) into buffer bi
-        const int tw = tile % nw; int tq = tile / nw;
-        const int th = tq % nh; tq /= nh;
-        const int td = tq % nd; const int b = tq / nd;
-        const int d0 = td * BF_TD, h0 = th * ROWS, w0 = tw * 16;
-        const bool s0 = 2 * q < in.CB0;
-        const bool up = s0 && in.up0;
-        const int cbg = s0 ? 2 * q : 2 * q - in.CB0;
-        const int Vs = up ? V0 : V;
-        const __amdgpu_buffer_rsrc_t r = s0 ? bf_rsrc(static_cast<const char*>(in.x0) + (size_t)b * in.CB0 * V0 * 16, (unsigned)in.CB0 * (unsigned)V0 * 16u)
-                                            : bf_rsrc(static_cast<const char*>(in.x1) + (size_t)b * in.CB1 * V * 16, (unsigned)in.CB1 * (unsigned)V * 16u);
-        u32x4* const dst = bufs + bi * BUFW;
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int j = 0; j < NIB; ++j) {
-                if (tid + BF_THREADS * j < NCBS) {
-                    const int gd = d0 - 1 + (sl[j] >> 16), gh = h0 - 1 + ((sl[j] >> 8) & 255), gw = w0 - 1 + (sl[j] & 255);
-                    const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-                    const int vox = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
-                    vxm_lds_dma16(r, reinterpret_cast<float*>(dst + cb * CBS + wave * 64 + BF_THREADS * j), ok ? vox << 4 : VXM_OOB, (cbg + cb) * Vs * 16);
-                }
-            }
-        if constexpr (!RESW) {
-            const __amdgpu_buffer_rsrc_t rw = bf_rsrc(wp + ((size_t)g * Q + q) * WCH, WCH * 16u);
-#pragma unroll
-            for (int it = 0; it < WIT; ++it)
-                if (tid + BF_THREADS * it < WCH)
-                    vxm_lds_dma16(rw, reinterpret_cast<float*>(dst + XW + wave * 64 + BF_THREADS * it), (tid + BF_THREADS * it) * 16, 0);
-        }
-    };
-
-    if constexpr (RESW) {                                        // all the weights of this channel group, once
-        const __amdgpu_buffer_rsrc_t rw = bf_rsrc(wp + (size_t)g * Q * WCH, (unsigned)Q * WCH * 16u);
-        for (int i0 = 0; i0 < Q * WCH; i0 += BF_THREADS)
-            if (i0 + tid < Q * WCH) vxm_lds_dma16(rw, reinterpret_cast<float*>(smem + i0 + wave * 64), (i0 + tid) * 16, 0);
-    }
-    int cur = 0;
-    issue(t, 0, 0);
-    while (true) {
-        f32x4 acc[NCT][ROWS];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < Q; ++q) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my share of this item has landed (and my stores of the last tile left)
-            __syncthreads();                                      // everyone's has; everyone is done reading the other buffer
-            const int nq = q + 1 < Q ? q + 1 : 0, nt = q + 1 < Q ? t : t + nper;
-            if (nt < hi) issue(nt, nq, cur ^ 1);
-            const u32x4* const Xs = bufs + cur * BUFW;
-            const u32x4* const Ws = RESW ? smem + q * WCH : Xs + XW;
-            // software-pipelined K loop (two waves per SIMD here: nobody else covers an LDS latency): B fragments BF_LOOK row-groups
-            // ahead in a rolling window, the weight fragments of the next step loaded in place after their last row of this step
-            constexpr int NG = BF_STEPS * HR, BF_LOOK = 3;
-            u32x4 a[3][NCT], bq[BF_LOOK + 1];
-#pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) a[kh][ct] = Ws[(kh * NCT + ct) * 64 + lane];
-#pragma unroll
-            for (int gi = 0; gi < BF_LOOK; ++gi) bq[gi] = Xs[xoff[gi / HR] + (gi % HR) * BF_HWV];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int gi = 0; gi < NG; ++gi) {
-                const int s = gi / HR, hr = gi % HR;
-                if (gi + BF_LOOK < NG) bq[(gi + BF_LOOK) % (BF_LOOK + 1)] = Xs[xoff[(gi + BF_LOOK) / HR] + ((gi + BF_LOOK) % HR) * BF_HWV];
-                const u32x4 bf = bq[gi % (BF_LOOK + 1)];
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) {
-                    const int row = hr - kh;
-                    if (row >= 0 && row < ROWS) {
-#pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) acc[ct][row] = bf_mfma(a[kh][ct], bf, acc[ct][row]);
-                    }
-                }
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-                    if (hr == ROWS - 1 + kh && s + 1 < BF_STEPS) {
-#pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) a[kh][ct] = Ws[(((s + 1) * 3 + kh) * NCT + ct) * 64 + lane];
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            cur ^= 1;
-        }
-        // ---- epilogue of tile t (as k_bf16_conv, OUT = 0)
-        {
-            const int tw = t % nw; int tq = t / nw;
-            const int th = tq % nh; tq /= nh;
-            const int td = tq % nd; const int b = tq / nd;
-            const int d = td * BF_TD + wave, h0 = th * ROWS, w = tw * 16 + n;
-            const bool vok = d < D && w < W;
-            const int CBo = Cout >> 3;
-            const __amdgpu_buffer_rsrc_t ry = bf_rsrc(static_cast<char*>(y) + (size_t)b * CBo * V * 16, (unsigned)CBo * (unsigned)V * 16u);
-            const __amdgpu_buffer_rsrc_t rm = bf_rsrc(mask ? static_cast<const char*>(mask) + (size_t)b * CBo * V * 16 : y, (unsigned)CBo * (unsigned)V * 16u);
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const int co = (g * NCT + ct) * 16 + 4 * kg, pb = co >> 3;
-                const bool cok = vok && pb < CBo;
-                float bz[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bz[j] = (bias && co + j < Cout) ? bias[co + j] : 0.0f;
-#pragma unroll
-                for (int rp = 0; rp < ROWS / 2; ++rp) {
-                    unsigned pk[2][2];
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int row = 2 * rp + e;
-                        float v[4];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            v[j] = acc[ct][row][j] + bz[j];
-                            v[j] = v[j] > 0.0f ? v[j] : v[j] * act_slope;
-                        }
-                        if (mask) {
-                            const int moff = (cok && h0 + row < H) ? (((pb * D + d) * H + h0 + row) * W + w) * 16 + (kg & 1) * 8 : VXM_OOB;
-                            const u32x2 m = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, moff, 0, 0));
-                            v[0] *= vxm_lrelu_grad(bf_lo(m.x), mask_slope); v[1] *= vxm_lrelu_grad(bf_hi(m.x), mask_slope);
-                            v[2] *= vxm_lrelu_grad(bf_lo(m.y), mask_slope); v[3] *= vxm_lrelu_grad(bf_hi(m.y), mask_slope);
-                        }
-                        pk[e][0] = bf_pack2(v[0], v[1]);
-                        pk[e][1] = bf_pack2(v[2], v[3]);
-                    }
-                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-                    const int hrow = h0 + 2 * rp + (kg & 1);
-                    const int voff = (cok && hrow < H) ? (((pb * D + d) * H + hrow) * W + w) * 16 : VXM_OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){s0.x, s1.x, s0.y, s1.y}, ry, voff, 0, 0);
-                }
-            }
-        }
-        t += nper;
-        if (t >= hi) break;
-    }
-}
-
 // w: [Cw_out][Cw_in][27] fp32 (reference layout) -> bf16 [G][Q][5][3][NCT][64 lanes][8]: lane (kg, m) of K-step s / row tap kh holds,
 // for output channel 16 (g NCT + ct) + m, the 8 input channels of unit u = 4 s + kg (kd, kw, block) of chunk q.
 // Operator: y[o] = sum_i Wop[o][i][tap] x[i];  forward Wop[o][i][t] = w[o][ci_lo + i][t] (InC = ci_n inputs, OutC = Cw_out);
@@ -938,38 +752,6 @@ void bf_launch_conv(const BfIn& in, const void* wp, const float* bias, void* y, 
                        static_cast<const u32x4*>(wp), bias, y, Cout, slope, mask, mask_slope, B, D, H, W, Q);
 }
 
-bool bf_conv_persistent() {
-    static const bool f = [] { const char* e = getenv("VXM_BF16_CONV_P"); return e && e[0] == '1'; }();
-    return f;
-}
-int bwb_cus();
-template <int NCT, int ROWS, int RESW>
-void bf_launch_conv_p(const BfIn& in, const void* wp, const float* bias, void* y, int Cout, float slope, const void* mask, float mask_slope,
-                      int B, int D, int H, int W, hipStream_t s) {
-    const int Q = (in.CB0 + in.CB1) / 2;
-    const int lds = RESW ? Q * bf_wchunk(NCT) * 16 + 4 * bf_cbs(ROWS) : 2 * (2 * bf_cbs(ROWS) + bf_wchunk(NCT) * 16);
-    static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf16_conv_p<NCT, ROWS, RESW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return true;
-    }();
-    (void)attr;
-    const long long ntiles = (long long)B * ((D + BF_TD - 1) / BF_TD) * ((H + ROWS - 1) / ROWS) * ((W + 15) / 16);
-    const int G = (Cout + 16 * NCT - 1) / (16 * NCT);
-    long long per = (ntiles + 7) / 8;                           // blocks per XCD: one per CU (per channel group), at most one per tile
-    const long long cap = bwb_cus() / 8 / G > 0 ? bwb_cus() / 8 / G : 1;
-    if (per > cap) per = cap;
-    hipLaunchKernelGGL((k_bf16_conv_p<NCT, ROWS, RESW>), dim3((unsigned)(8 * per), G), dim3(BF_THREADS), lds, s, in, static_cast<const u32x4*>(wp),
-                       bias, y, Cout, slope, mask, mask_slope, B, D, H, W, Q);
-}
-// the persistent kernel for 32 output channels: weights resident when they fit beside two 8 x 6 x 16 tiles (Q <= 2) or two 8 x 4 x 16 tiles (Q = 3)
-void bf_launch_conv_p2(const BfIn& in, const void* wp, const float* bias, void* y, int Cout, float slope, const void* mask, float mask_slope,
-                       int B, int D, int H, int W, hipStream_t s) {
-    const int Q = (in.CB0 + in.CB1) / 2, wbytes = Q * bf_wchunk(2) * 16;
-    if (wbytes + 4 * bf_cbs(6) <= 160 * 1024) bf_launch_conv_p<2, 6, 1>(in, wp, bias, y, Cout, slope, mask, mask_slope, B, D, H, W, s);
-    else if (wbytes + 4 * bf_cbs(4) <= 160 * 1024) bf_launch_conv_p<2, 4, 1>(in, wp, bias, y, Cout, slope, mask, mask_slope, B, D, H, W, s);
-    else bf_launch_conv_p<2, 6, 0>(in, wp, bias, y, Cout, slope, mask, mask_slope, B, D, H, W, s);
-}
-
 int bwb_cus() {
     static const int cus = [] {
         int dev = 0; hipDeviceProp_t p;
@@ -1073,7 +855,6 @@ int vxm_bf16_conv_fwd(const void* x0, int C0, int x0_up, const void* x1, int C1,
     hipStream_t s = VXM_STREAM(stream);
     if (out_planar_f32) bf_launch_conv<1, 8, 1>(in, wpacked, bias, y, Cout, leaky_slope, nullptr, 1.0f, B, D, H, W, s);
     else if (bf_nct(Cout) == 1) bf_launch_conv<1, 8, 0>(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
-    else if (bf_conv_persistent()) bf_launch_conv_p2(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
     else bf_launch_conv<2, 6, 0>(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
     return vxm_check_launch("vxm_bf16_conv_fwd");
 }
