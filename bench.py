@@ -36,11 +36,12 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=1)
     ap.add_argument("--shape", type=str, default="160,192,224")
     ap.add_argument("--int-steps", type=int, default=None)
-    ap.add_argument("--config", choices=["diffeo_fp32", "dense_bf16", "diffeo_bf16"], default="diffeo_fp32",
+    ap.add_argument("--config", choices=["diffeo_fp32", "dense_bf16", "diffeo_bf16", "semisup_fp32"], default="diffeo_fp32",
                     help="diffeo_fp32 = BASELINE.json configs[2], the headline metric (default); dense_bf16 = configs[1]: int_steps=0, "
                          "MSE + 0.01 Grad, bf16 activations / fp32 accumulate under torch.autocast; diffeo_bf16 = the headline network "
                          "and losses with bf16 activations (an extra, labelled line: NOT the headline metric, which is fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true")                 # only the headline (profiling runs)
     ap.add_argument("--cpu-baseline-steps", type=int, default=2)               # timed CPU steps after one warm-up, at the FULL shape
     ap.add_argument("--cpu-threads", type=int, default=0)                      # 0: min(32, cores), see cpu_baseline()
     return ap.parse_args()
@@ -135,6 +136,9 @@ def hbm_traffic(kernel, launches_per_step, suffix=""):
     if not hits:
         return None, "%s has no counters for %s: stale profile, re-run tools/profile_bench.sh" % (rel, kernel)
     n = sum(v["FETCH_SIZE"]["dispatches"] for v in hits.values())
+    sha = (ctr.get("_meta") or {}).get("csrc_sha")
+    if sha != csrc_sha():
+        return None, "%s was collected on kernel sources %s, this tree is %s: stale profile, re-run tools/profile_bench.sh" % (rel, sha, csrc_sha())
     steps = (ctr.get("_meta") or {}).get("steps_profiled")
     if steps and abs(n - launches_per_step * steps) > 0.5:
         return None, "%s: %d dispatches of %s in %d profiled steps, this run launches %.1f per step: stale profile" % (
@@ -182,12 +186,160 @@ def _cpu_model():
     return "unknown"
 
 
+def csrc_sha():
+    """Identity of the kernel sources (voxelmorph_amd/buildinfo.py): written into profiles/*_counters.json `_meta` by
+    tools/rocprof_summary.py, compared in hbm_traffic() so that counters collected on OTHER kernel sources are refused."""
+    sys.path.insert(0, os.path.join(ROOT, "voxelmorph_amd"))
+    try:
+        import buildinfo                      # by path: no torch / library import needed for a hash
+    finally:
+        sys.path.pop(0)
+    return buildinfo.csrc_sha()
+
+
+class Workload:
+    """One benchmark configuration: model + optimiser + synthetic batch resident in HBM + the training step."""
+
+    def __init__(self, vxm, vdist, name, shape, B, dev, rank, int_steps=None, comm=None):
+        from voxelmorph_amd.optim import FlatAdam
+        self.name, self.B, self.shape = name, B, shape
+        self.bf16 = name in ("dense_bf16", "diffeo_bf16")
+        self.dense = name == "dense_bf16"
+        self.semi = name == "semisup_fp32"
+        self.int_steps = (0 if self.dense else 7) if int_steps is None else int_steps
+        self.lam = 0.01 if self.dense else 1.0                    # README.md:70: lambda 0.01 with MSE, 1 with NCC
+        torch.manual_seed(1234)                                   # identical initial weights on every rank
+        if self.semi:                                             # BASELINE.json configs[4]: 30 one-hot labels at half resolution, Dice weight 0.01
+            self.model = vxm.networks.VxmDenseSemiSupervisedSeg(shape, 30, int_steps=self.int_steps, int_downsize=2).to(dev)
+        else:
+            self.model = vxm.networks.VxmDense(shape, int_steps=self.int_steps, int_downsize=2).to(dev)
+        self.opt = FlatAdam(self.model, lr=1e-4, comm=comm)
+        self.opt.broadcast_params(0)
+        torch.manual_seed(1234 + rank)                            # each rank synthesises its own volume pairs in HBM
+        self.src = torch.rand(B, 1, *shape, device=dev)
+        self.trg = torch.rand(B, 1, *shape, device=dev)
+        if self.semi:
+            half = tuple(s // 2 for s in shape)
+            lab = torch.randint(0, 31, (2, B) + half, device=dev)                  # 0 = background (not among the 30 labels)
+            one = lambda l: torch.stack([(l == k) for k in range(1, 31)], 1).float().contiguous()
+            self.seg_src, self.seg_trg = one(lab[0]), one(lab[1])
+            self.dice = vxm.losses.Dice().loss
+        self.img = vxm.losses.MSE().loss if self.dense else vxm.losses.NCC().loss
+        self.reg = vxm.losses.Grad("l2", loss_mult=2).loss
+
+    def step(self):
+        self.opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):      # bf16: blocked-bf16 activations between the convs
+            if self.semi:
+                y, pre, yseg = self.model(self.src, self.trg, self.seg_src)
+                loss = self.img(self.trg, y) + self.lam * self.reg(None, pre) + 0.01 * self.dice(self.seg_trg, yseg)
+            else:
+                y, pre = self.model(self.src, self.trg)
+                loss = self.img(self.trg, y) + self.lam * self.reg(None, pre)
+        loss.backward()
+        self.opt.step()                                            # all-reduce (world>1) + fused Adam
+        return loss
+
+    def describe(self):
+        sh = "x".join(map(str, self.shape))
+        if self.dense:
+            return ("VxmDense 3D %s, int_steps=%d (CVPR dense), MSE + 0.01 Grad(l2,x2), bf16 activations / fp32 accumulate, fp32 master "
+                    "weights, Adam lr 1e-4, %d pair(s)/GPU (BASELINE.json configs[1])" % (sh, self.int_steps, self.B))
+        if self.bf16:
+            return ("VxmDense 3D %s, int_steps=%d diffeomorphic (int_downsize=2), NCC(9^3)+Grad(l2,x2), bf16 activations / fp32 accumulate "
+                    "in the U-Net (everything else fp32), Adam lr 1e-4, %d pair(s)/GPU" % (sh, self.int_steps, self.B))
+        if self.semi:
+            return ("VxmDenseSemiSupervisedSeg 3D %s, int_steps=%d, 30 one-hot labels at half resolution, NCC(9^3)+Grad(l2,x2)+0.01 Dice, "
+                    "fp32, Adam lr 1e-4, %d pair(s)/GPU (BASELINE.json configs[4], per-GPU step)" % (sh, self.int_steps, self.B))
+        return ("VxmDense 3D %s, int_steps=%d diffeomorphic (int_downsize=2), NCC(9^3)+Grad(l2,x2), fp32, Adam lr 1e-4, %d pair(s)/GPU "
+                "(BASELINE.json configs[2])" % (sh, self.int_steps, self.B))
+
+
+def timed_steps(wl, steps, vdist, dev, timer=None):
+    """EXACTLY `steps` steps between barrier + synchronize on both sides; MAX over ranks.  timer: bracket every C-ABI launch
+    with HIP events on the launch stream (per-kernel pass); None: nothing but the steps is inside the region (the `value` pass)."""
+    from voxelmorph_amd import profiler
+    if timer is not None:
+        profiler.install(timer)
+    vdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = wl.step()
+    torch.cuda.synchronize()
+    vdist.barrier()
+    elapsed = vdist.max_over_ranks(time.perf_counter() - t0, dev)
+    if timer is not None:
+        profiler.uninstall()
+    return elapsed, float(loss.detach())
+
+
+def kernel_table(stats, steps):
+    kernels = {}
+    for name, st in stats.items():
+        ent = {"launches_per_step": st["launches"] / steps, "ms_per_step": st["ms"] / steps, "avg_launch_ms": st["ms"] / st["launches"]}
+        if st["flops"]:
+            ent["tflops"] = st["flops"] / (st["ms"] * 1e-3) / 1e12                # FLOPs the kernel executes (MFMA utilisation)
+            if st.get("nominal", 0.0) > st["flops"] * 1.001:                      # collapsed-upsample kernels: reference formulation
+                ent["nominal_tflops"] = st["nominal"] / (st["ms"] * 1e-3) / 1e12
+        if st["bytes"]:
+            ent["gbs"] = st["bytes"] / (st["ms"] * 1e-3) / 1e9
+        kernels[name] = ent
+    return kernels
+
+
+def comm_evidence(opt, dev):
+    """What a multi-rank run leaves behind about its exchange (the scaling run is the driver's, not the builder's): which library
+    carries the all-reduce, how many ranks its communicator spans, and the median of 20 timed all-reduces of the 1.31 MB bucket."""
+    import statistics
+    ev = {"backend": "libvxm_comm" if opt.comm is not None else "torch.distributed(nccl)", "ranks_seen": opt.world,
+          "bucket_bytes": 4 * opt.n}
+    if opt.comm is not None:
+        from voxelmorph_amd import comm as vcomm
+        ev["ranks_seen"] = int(vcomm.lib().vxm_comm_world())
+        ev["rccl_version"] = vcomm.rccl_version()
+    buf = torch.zeros_like(opt.flat_grad)
+    times = []
+    for i in range(25):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if opt.comm is not None:
+            opt.comm.all_reduce_sum(buf)
+        else:
+            torch.distributed.all_reduce(buf, group=opt.group)
+        torch.cuda.synchronize()
+        if i >= 5:
+            times.append((time.perf_counter() - t0) * 1e6)
+    ev["allreduce_us"] = statistics.median(times)
+    ev["transport"] = _transport_note()
+    return ev
+
+
+def _transport_note():
+    """How the ranks are wired, from what this process can see without a debug re-run: NCCL_DEBUG=INFO lines RCCL wrote to the
+    file named by NCCL_DEBUG_FILE (bench.py sets both for multi-rank runs), reduced to the channel / transport lines."""
+    path = os.environ.get("NCCL_DEBUG_FILE", "")
+    path = path.replace("%h", os.uname().nodename).replace("%p", str(os.getpid()))
+    try:
+        with open(path) as f:
+            lines = [l.strip() for l in f if (" via " in l or "Connected all" in l or "xGMI" in l.upper() or "XGMI" in l)]
+    except OSError:
+        return "no RCCL debug file"
+    kinds = sorted({l.split(" via ", 1)[1].split()[0] for l in lines if " via " in l})
+    return {"via": kinds, "sample": lines[:3]}
+
+
 def main():
     args = parse()
     from voxelmorph_amd import dist as vdist
     # `python bench.py --gpus N` without a torchrun environment: become `python -m torch.distributed.run --nproc-per-node N
     # ... bench.py --gpus N ...` (one rank per GPU, 127.0.0.1 rendezvous); under torchrun this returns at once
     vdist.self_launch(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # transport evidence of the multi-rank run (comm_evidence): RCCL's INFO lines of the init phase go to a per-process file
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/vxm_rccl_%h_%p.log")
     rank, local, world = vdist.init_from_env()
     if args.gpus != world:
         if rank == 0:
@@ -198,74 +350,73 @@ def main():
         sys.exit(2)
     import voxelmorph_amd as vxm
     from voxelmorph_amd import profiler
-    from voxelmorph_amd.optim import FlatAdam
+    from voxelmorph_amd.torch import functional as VF
 
     dev = torch.device("cuda", local)
     shape = tuple(int(s) for s in args.shape.split(","))
     B = args.batch_per_gpu
-    bf16 = args.config in ("dense_bf16", "diffeo_bf16")
-    dense = args.config == "dense_bf16"
-    if args.int_steps is None:
-        args.int_steps = 0 if dense else 7
-    lam = 0.01 if dense else 1.0                              # README.md:70: lambda 0.01 with MSE, 1 with NCC
-    torch.manual_seed(1234)                                   # identical initial weights on every rank
-    model = vxm.networks.VxmDense(shape, int_steps=args.int_steps, int_downsize=2).to(dev)
-    opt = FlatAdam(model, lr=1e-4, comm=vdist.native_comm())      # VXM_COMM=rccl: direct libvxm_comm.so all-reduce
-    opt.broadcast_params(0)
-    torch.manual_seed(1234 + rank)                            # each rank synthesises its own volume pairs in HBM
-    src = torch.rand(B, 1, *shape, device=dev)
-    trg = torch.rand(B, 1, *shape, device=dev)
-    ncc = vxm.losses.MSE().loss if dense else vxm.losses.NCC().loss
-    reg = vxm.losses.Grad("l2", loss_mult=2).loss
-
-    def step():
-        opt.zero_grad()
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):      # bf16: blocked-bf16 activations between the convs
-            y, pre = model(src, trg)
-            loss = ncc(trg, y) + lam * reg(None, pre)
-        loss.backward()
-        opt.step()                                            # all-reduce (world>1) + fused Adam
-        return loss
+    # a multi-rank HIP job whose native communicator cannot be built fails HERE, loudly, unless VXM_COMM=torch was asked for
+    comm = vdist.native_comm(required=world > 1 and os.environ.get("VXM_COMM", "") != "torch")
+    wl = Workload(vxm, vdist, args.config, shape, B, dev, rank, args.int_steps, comm)
+    args.int_steps = wl.int_steps
+    bf16, dense = wl.bf16, wl.dense
 
     for _ in range(args.warmup):
-        step()
+        wl.step()
     # Python's cyclic GC would otherwise run its first full (generation-2) collection somewhere inside the timed
     # region: a one-off ~40 ms host stall (measured) that stops kernel submission.  Collect now and move the survivors
     # to the permanent generation; the GC stays enabled (a training loop does the same after its first steps).
     import gc
     gc.collect()
     gc.freeze()
+    # pass 1 -- `value`: the K timed steps and nothing else (no event bracketing; the full-resolution weight-gradient launches may
+    # share the chip with the backward-data chain on the second stream, VXM_OVERLAP_MIN_LEVEL=0 unless the environment says otherwise)
+    keep = VF.OVERLAP_MIN_LEVEL
+    if "VXM_OVERLAP_MIN_LEVEL" not in os.environ:
+        VF.OVERLAP_MIN_LEVEL = 0
+    elapsed, final_loss = timed_steps(wl, args.steps, vdist, dev)
+    VF.OVERLAP_MIN_LEVEL = keep
+    # pass 2 -- per-kernel table and `roofline`: every C-ABI launch bracketed by HIP events on the launch stream, the dominant
+    # launches serialised (one kernel on the chip at a time, so that a launch's duration is its own)
     timer = profiler.KernelTimer()
-    profiler.install(timer)
-    vdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    vdist.barrier()
-    elapsed = vdist.max_over_ranks(time.perf_counter() - t0, dev)
-    profiler.uninstall()
+    ksteps = min(args.steps, 10)
+    elapsed_k, _ = timed_steps(wl, ksteps, vdist, dev, timer)
     stats = timer.resolve()
-    final_loss = float(loss.detach())
+    comm_ev = comm_evidence(wl.opt, dev) if world > 1 else None
+
+    extra = {}
+    if world == 1 and args.config == "diffeo_fp32" and not args.no_extra_configs:
+        # the other BASELINE.json configs that fit one GPU, a few steps each, in the SAME line (labelled; none of them is `value`)
+        del wl
+        torch.cuda.empty_cache()
+        for key, name, eb, esteps in (("dense_bf16", "dense_bf16", 1, 8), ("diffeo_fp32_4_pairs_per_gpu", "diffeo_fp32", 4, 4),
+                                      ("semisup_fp32", "semisup_fp32", 1, 8)):
+            try:
+                w2 = Workload(vxm, vdist, name, shape, eb, dev, rank)
+                for _ in range(2):
+                    w2.step()
+                t2, l2 = timed_steps(w2, esteps, vdist, dev)
+                tm = profiler.KernelTimer()
+                timed_steps(w2, 2, vdist, dev, tm)
+                st2 = tm.resolve()
+                d2 = max(st2, key=lambda k: st2[k]["ms"])
+                extra[key] = {"value": eb * esteps / t2, "unit": "volume-pairs/s", "ms_per_step": 1e3 * t2 / esteps, "steps": esteps,
+                              "dtype": "bf16" if w2.bf16 else "f32", "workload": w2.describe(), "final_loss": l2,
+                              "roofline": binding_roofline(d2, st2[d2])}
+                del w2
+                torch.cuda.empty_cache()
+            except Exception as exc:                       # an extra line must never take the headline down with it
+                extra[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     if rank != 0:
         return
-    kernels = {}
-    for name, st in stats.items():
-        ent = {"launches_per_step": st["launches"] / args.steps, "ms_per_step": st["ms"] / args.steps,
-               "avg_launch_ms": st["ms"] / st["launches"]}
-        if st["flops"]:
-            ent["tflops"] = st["flops"] / (st["ms"] * 1e-3) / 1e12                # FLOPs the kernel executes (MFMA utilisation)
-            if st.get("nominal", 0.0) > st["flops"] * 1.001:                      # collapsed-upsample kernels: reference formulation
-                ent["nominal_tflops"] = st["nominal"] / (st["ms"] * 1e-3) / 1e12
-        if st["bytes"]:
-            ent["gbs"] = st["bytes"] / (st["ms"] * 1e-3) / 1e9
-        kernels[name] = ent
+    kernels = kernel_table(stats, ksteps)
     dom = max(stats, key=lambda k: stats[k]["ms"])
     ds = stats[dom]
     roof = binding_roofline(dom, ds)
-    roof["traffic"], roof["traffic_unit"] = hbm_traffic(dom, ds["launches"] / args.steps, "_bf16" if bf16 else "")
+    roof["traffic"], roof["traffic_unit"] = hbm_traffic(dom, ds["launches"] / ksteps, "_bf16" if bf16 else "")
+    roof["measured_in"] = "per-kernel pass: %d steps with HIP-event bracketing, %.3f ms/step (the `value` pass runs un-instrumented)" % (
+        ksteps, 1e3 * elapsed_k / ksteps)
     out = {
         "metric": "volume-pairs/sec VxmDense 160x192x224 int_steps=0 MSE train (bf16 activations)" if dense
                   else ("volume-pairs/sec VxmDense 160x192x224 int_steps=7 NCC train (bf16 activations; not the fp32 headline)" if bf16
@@ -273,19 +424,25 @@ def main():
         "value": world * B * args.steps / elapsed, "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-        "config": {"workload": ("VxmDense 3D %s, int_steps=%d (CVPR dense), MSE + 0.01 Grad(l2,x2), bf16 activations / fp32 accumulate, "
-                                "fp32 master weights, Adam lr 1e-4, %d pair(s)/GPU (BASELINE.json configs[1])" if dense else
-                                "VxmDense 3D %s, int_steps=%d diffeomorphic (int_downsize=2), NCC(9^3)+Grad(l2,x2), bf16 activations / fp32 "
-                                "accumulate in the U-Net (everything else fp32), Adam lr 1e-4, %d pair(s)/GPU" if bf16 else
-                                "VxmDense 3D %s, int_steps=%d diffeomorphic (int_downsize=2), NCC(9^3)+Grad(l2,x2), fp32, Adam "
-                                "lr 1e-4, %d pair(s)/GPU (BASELINE.json configs[2])") % ("x".join(map(str, shape)), args.int_steps, B),
-                   "global_batch": world * B, "parallelism": "dp%d" % world},
+        "config": {"workload": wl_desc(args, shape, B), "global_batch": world * B, "parallelism": "dp%d" % world,
+                   "fp32_engine": VF.fp32_engine_note()},
         "roofline": roof, "kernels": kernels, "final_loss": final_loss,
     }
+    if comm_ev is not None:
+        out["comm"] = comm_ev
+    if extra:
+        out["extra_configs"] = extra
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(shape, args.int_steps, args.cpu_baseline_steps, args.cpu_threads,
-                                           "mse" if dense else "ncc", lam)
+                                           "mse" if dense else "ncc", 0.01 if dense else 1.0)
     print(json.dumps(out))
+
+
+def wl_desc(args, shape, B):
+    w = Workload.__new__(Workload)
+    w.name, w.B, w.shape, w.int_steps = args.config, B, shape, args.int_steps
+    w.bf16, w.dense, w.semi = args.config in ("dense_bf16", "diffeo_bf16"), args.config == "dense_bf16", args.config == "semisup_fp32"
+    return w.describe()
 
 
 if __name__ == "__main__":

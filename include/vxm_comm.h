@@ -18,9 +18,11 @@ const char* vxm_comm_last_error_string(void);
 /* rank 0 creates the rendezvous token (ncclGetUniqueId) and hands its 128 bytes to the other ranks out of band
  * (the torchrun store, a file, MPI ...) */
 int vxm_comm_unique_id(void* out /* VXM_COMM_UNIQUE_ID_BYTES */);
-/* collective over all ranks: binds the communicator to the CURRENT HIP device of the calling process */
+/* collective over all ranks: binds the communicator to the CURRENT HIP device of the calling process.  Bounded: if the other ranks
+ * do not join within VXM_COMM_INIT_TIMEOUT_S seconds (default 180) it returns status 5 instead of blocking for ever. */
 int vxm_comm_init(int rank, int world, const void* unique_id);
-int vxm_comm_world(void);                      /* 0 before init */
+int vxm_comm_world(void);                      /* ranks of the communicator (ncclCommCount at init); 0 before init */
+int vxm_comm_rccl_version(void);               /* ncclGetVersion code of the RCCL the library resolved to (e.g. 22606); 0 on failure */
 /* in-place SUM all-reduce / broadcast of n floats on `stream` (asynchronous, ordered with the kernels on that stream) */
 int vxm_allreduce_sum_f32(float* buf, int64_t n, void* stream);
 int vxm_broadcast_f32(float* buf, int64_t n, int root, void* stream);

@@ -40,7 +40,7 @@ typedef enum {
 enum { VXM_INTERP_LINEAR = 0, VXM_INTERP_NEAREST = 1 };   /* SpatialTransformer mode, layers.py:11 */
 enum { VXM_PENALTY_L1 = 0, VXM_PENALTY_L2 = 1 };          /* Grad penalty, losses.py:98 */
 
-int vxm_version(void);
+int vxm_version(void);                 /* 10000 major + 100 minor + patch of this ABI: 300 = 0.3.0 (round 3) */
 const char* vxm_last_error_string(void);
 
 /* ---- SpatialTransformer.forward, layers.py:30-48 (add + normalise + permute + index +
@@ -275,6 +275,31 @@ int vxm_bf16_maxpool2_bwd(const void* x, const void* gpool, const void* gskip, v
 int vxm_bf16_upsample2_bwd(const void* g, const void* y, void* dz, float slope, int B, int C, int Dl, int Hl, int Wl,
                            void* stream);
 int vxm_bf16_lrelu_bwd(const void* g, const void* y, void* dz, float slope, int64_t n_elems, void* stream);
+
+/* ---- fp32 convolutions on the bf16 matrix pipe ("bf16x3" split, csrc/conv_s3.hip).
+ * Same operator, operands and layouts as vxm_conv3d_k3_fwd (ConvBlock networks.py:299-305 forward, and convolution_backward
+ * w.r.t. the input with transpose_flip-packed weights): planar fp32 NCDHW in and out, virtual concat [x0 (optionally nearest-x2
+ * upsampled) | x1], bias + LeakyReLU(act_slope) (+ LeakyReLU'(mask_src) = fused leaky_relu_backward).  Every fp32 operand is
+ * split into three bf16 pieces (exactly: x = h + m + l up to 2^-24 |x|) while it is staged, and a product is accumulated in fp32
+ * from its six leading piece products on v_mfma_f32_16x16x32_bf16: fp32-level accuracy (same rel-L2 <= 1e-5 gate against an fp64
+ * evaluation as the fp32-MFMA kernels), 2.67x the matrix-pipe rate.  C0, C1 multiples of 8.
+ * vxm_conv3d_k3_s3_ok: 1 when the split kernel takes a launch of this shape (otherwise use vxm_conv3d_k3_fwd). */
+int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W);
+int vxm_conv3d_k3_s3_variant(int Cout);                     /* 10 * NCT + CB of the kernel instance (profiling labels) */
+/* packed, pre-split weights of one operator: seg0 / seg1 = input channels of the two segments of the virtual concat it reads */
+size_t vxm_conv3d_k3_s3_packed_bytes(int seg0, int seg1, int OutC);
+typedef struct VxmS3PackJob {
+    const float* w;                                         /* [Cw_out][Cw_in][3][3][3], reference layout */
+    void* wpacked;                                          /* vxm_conv3d_k3_s3_packed_bytes(seg0, InC - seg0, OutC) bytes, 16-byte aligned */
+    int Cw_in, Cw_out, ci_lo, ci_n, transpose_flip;         /* as vxm_bf16_conv_pack_weights: forward operator on input channels
+                                                             * [ci_lo, ci_lo + ci_n) (InC = ci_n, OutC = Cw_out), or its adjoint onto them
+                                                             * (transpose_flip: InC = Cw_out, OutC = ci_n) */
+    int seg0;                                               /* operator input channels that belong to segment 0 (InC for one tensor) */
+} VxmS3PackJob;
+int vxm_conv3d_k3_s3_pack_weights_batch(const VxmS3PackJob* jobs, int n_jobs, void* stream);
+int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
+                         const void* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope,
+                         const float* mask_src, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -263,8 +263,9 @@ def unet_forward(x, sd, prefix="unet_model.", nb_features=None, nb_levels=None, 
 
 
 def vxm_dense_forward(source, target, sd, int_steps=7, int_downsize=2, bidir=False,
-                      registration=False, unet_half_res=False, **unet_kwargs):
-    """`VxmDense.forward` networks.py:244-287."""
+                      registration=False, unet_half_res=False, return_all=False, **unet_kwargs):
+    """`VxmDense.forward` networks.py:244-287.  return_all: (y_source, y_target, preint_flow, pos_flow) of ONE evaluation (what
+    the semi-supervised composition needs: the training outputs AND the positive flow)."""
     nd = source.dim() - 2
     x = unet_forward(torch.cat([source, target], dim=1), sd, half_res=unet_half_res, **unet_kwargs)
     conv = getattr(F, "conv%dd" % nd)
@@ -284,6 +285,8 @@ def vxm_dense_forward(source, target, sd, int_steps=7, int_downsize=2, bidir=Fal
             neg = resize_transform(neg, 1 / int_downsize) if bidir else None
     y_source = spatial_transformer(source, pos)                        # :280
     y_target = spatial_transformer(target, neg) if bidir else None
+    if return_all:
+        return y_source, y_target, preint, pos
     if not registration:
         return (y_source, y_target, preint) if bidir else (y_source, preint)
     return y_source, pos
@@ -294,8 +297,8 @@ def vxm_semisupervised_forward(source, target, seg_src, sd, seg_resolution=2, in
     layers of the path: seg_flow = RescaleTransform(1/seg_resolution)(pos_flow) (tf/networks.py:336-337) is
     `ResizeTransform(seg_resolution)` (torch/layers.py:76-97); the down-sampled one-hot source segmentation is warped
     with a linear SpatialTransformer (tf/networks.py:338-339).  Returns (y_source, preint_flow, y_seg_src, pos_flow)."""
-    y_source, preint = vxm_dense_forward(source, target, sd, int_steps=int_steps, int_downsize=int_downsize, **unet_kwargs)
-    _, pos = vxm_dense_forward(source, target, sd, int_steps=int_steps, int_downsize=int_downsize, registration=True, **unet_kwargs)
+    y_source, _, preint, pos = vxm_dense_forward(source, target, sd, int_steps=int_steps, int_downsize=int_downsize, return_all=True,
+                                                 **unet_kwargs)
     seg_flow = resize_transform(pos, seg_resolution)
     return y_source, preint, spatial_transformer(seg_src, seg_flow), pos
 

@@ -519,13 +519,18 @@ def test_vxm_dense_golden(vxm, g_network, tag):
     norms = g_network[tag + "_grad_norms"]
     params = dict(model.named_parameters())
     tol = 2e-3 if cfg["loss"] == "ncc" else 1e-4      # NCC's fp32 formula is ill-conditioned
+    worst_n = worst_g = 0.0
     for n, r in zip(names, norms):
         got = float(params[n].grad.double().norm())
+        worst_n = max(worst_n, abs(got - r) / max(r, 1e-12))
         assert abs(got - r) <= tol * max(r, 1e-12), (n, got, r)
     for key in g_network.files:
         if key.startswith(tag + "_grad_") and key not in (tag + "_grad_names", tag + "_grad_norms"):
             pname = key[len(tag + "_grad_"):]
-            assert rel_l2(N(params[pname].grad), g_network[key]) < tol, pname
+            e = rel_l2(N(params[pname].grad), g_network[key])
+            worst_g = max(worst_g, e)
+            assert e < tol, (pname, e)
+    print("golden %s: worst gradient-norm error %.2e, worst gradient rel-L2 %.2e (tol %.0e)" % (tag, worst_n, worst_g, tol))
     with torch.no_grad():
         _, pos = model(src, trg, registration=True)
     np.testing.assert_allclose(N(pos), g_network[tag + "_pos_flow"], atol=1e-4, rtol=0)
@@ -707,6 +712,7 @@ def _full_size_step_vs_oracle(vxm, src, trg, seed, flow_std, fp64_ncc_arbiter=Fa
     loss = vxm.losses.NCC().loss(t, y) + vxm.losses.Grad("l2", loss_mult=2).loss(None, pre)
     loss.backward()
     torch.cuda.synchronize()
+    assert tuple(y.shape) == tuple(src.shape) and tuple(pre.shape) == (src.shape[0], 3) + tuple(d // 2 for d in FULL)
     sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
     names, params = list(sdo), list(sdo.values())
     ts = torch.from_numpy(trg)
@@ -722,12 +728,13 @@ def _full_size_step_vs_oracle(vxm, src, trg, seed, flow_std, fp64_ncc_arbiter=Fa
     # tolerance of the integrated flows is 1e-4 abs (fp32 scaling and squaring drifts 3.9e-5 against fp64 after 7
     # steps) and a U[0,1) noise image changes by O(1) per voxel, so the moved image inherits that bound, not the 1e-5 of a
     # single warp on identical flows.
-    assert err_p <= 2e-5 and err_y <= 1e-4, (err_y, err_p)
+    # measured (round 2, native fp32 engine): err_y 6e-6 .. 3e-5, err_p <= 1e-7, worst gradient 1.8e-5 on the noise pair
+    assert err_p <= 2e-5 and err_y <= 5e-5, (err_y, err_p)
     assert abs(float(loss) - float(ref)) <= 1e-3
     assert len(gerr) == 24
     if not fp64_ncc_arbiter:
         for name, e in gerr.items():
-            assert e <= 2e-3, (name, e)
+            assert e <= 1e-4, (name, e)                  # the stated parameter-gradient tolerance (module docstring)
     else:
         ref64 = orc.ncc_loss(ts, ys, dtype=torch.float64).float() + reg
         g64 = dict(zip(names, torch.autograd.grad(ref64, params)))
@@ -735,7 +742,7 @@ def _full_size_step_vs_oracle(vxm, src, trg, seed, flow_std, fp64_ncc_arbiter=Fa
         for name, p in model.named_parameters():
             e_hip, e_ref = rel_l2(N(p.grad), g64[name].numpy()), rel_l2(g32[name].numpy(), g64[name].numpy())
             print("  %-40s vs fp64-NCC arbiter: hip %.2e, fp32 oracle %.2e" % (name, e_hip, e_ref))
-            assert e_hip <= max(2e-3, 2.0 * e_ref), (name, e_hip, e_ref)
+            assert e_hip <= max(3e-4, 2.0 * e_ref), (name, e_hip, e_ref)       # measured 1.0e-5 .. 1.4e-4
     return model, pos.detach()
 
 
@@ -747,6 +754,16 @@ def test_full_size_train_step_vs_oracle_noise_pair(vxm):
     src = rng.random((1, 1) + FULL).astype(np.float32)
     trg = rng.random((1, 1) + FULL).astype(np.float32)
     _full_size_step_vs_oracle(vxm, src, trg, seed=11, flow_std=0.05)
+
+
+def test_full_size_train_step_batch_of_two_vs_oracle(vxm):
+    """The same step with TWO pairs in the batch (scripts/torch/train.py:128-129,200-220: the per-GPU batch of BASELINE
+    configs[3] is > 1): batch strides, 32-bit buffer offsets of the second sample and the batch mean of both losses at the
+    size the metric is quoted on -- forward tensors, loss and all 24 parameter gradients against the oracle."""
+    rng = np.random.default_rng(4321)
+    src = rng.random((2, 1) + FULL).astype(np.float32)
+    trg = rng.random((2, 1) + FULL).astype(np.float32)
+    _full_size_step_vs_oracle(vxm, src, trg, seed=13, flow_std=0.05)
 
 
 def _real_scan():
@@ -834,6 +851,117 @@ def test_full_size_conv_adjoint_identity(vxm, c0, up0, c1, cout):
     else:
         via_x = float((gx.double() * x0.double()).sum())
     assert abs(lhs - via_x) <= 1e-5 * scale, (lhs, via_x, scale)
+
+
+@pytest.mark.parametrize("c0,up0,c1,cout", [(32, False, 0, 16), (16, False, 0, 16), (16, False, 0, 32), (32, True, 16, 32), (2, False, 0, 16),
+                                            (16, False, 0, 3)])
+def test_full_size_conv_adjoint_identity_four_pairs(vxm, c0, up0, c1, cout):
+    """The adjoint identity of every full-resolution conv product at the per-GPU load of BASELINE configs[3] (4 pairs per GPU,
+    scripts/torch/train.py:128-129): B = 4 at 160x192x224.  Checked PER SAMPLE -- a kernel that mixed up batch strides would
+    still satisfy the identity summed over the batch -- plus bit-equality of sample 0 with the B = 1 launch (forward), so the
+    later samples are tied to an already-verified one through linearity."""
+    from voxelmorph_amd.torch import functional as VF
+    D, H, W = FULL
+    V, B = D * H * W, 4
+    torch.manual_seed(100 + c0 + cout)
+    lo = (D // 2, H // 2, W // 2)
+    x0 = torch.randn(B, c0, *(lo if up0 else FULL), device="cuda")
+    x1 = torch.randn(B, c1, D, H, W, device="cuda") if c1 else None
+    cin = c0 + c1
+    w = torch.randn(cout, cin, 3, 3, 3, device="cuda") / (27 * cin) ** 0.5
+    y = torch.empty(B, cout, D, H, W, device="cuda")
+    VF.conv_forward(x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if c1 else 0, w, None, y, cout * V, cout, 1.0, B, D, H, W)
+    y1 = torch.empty(1, cout, D, H, W, device="cuda")
+    VF.conv_forward(x0[:1], c0, x0[0].numel(), up0, x1[:1] if c1 else None, c1, x1[0].numel() if c1 else 0, w, None, y1, cout * V, cout, 1.0, 1, D, H, W)
+    assert torch.equal(y[:1], y1)
+    del y1
+    dz = y + 0.5 * torch.randn_like(y)
+    lhs = (y.double() * dz.double()).sum(dim=(1, 2, 3, 4))
+    scale = y.double().flatten(1).norm(dim=1) * dz.double().flatten(1).norm(dim=1)
+    gx = torch.empty(B, cin, D, H, W, device="cuda")
+    VF.conv_bwd_data(dz, cout, w, gx, cin, None, 1.0, B, D, H, W)
+    if up0:
+        g0 = gx[:, :c0].reshape(B, c0, D // 2, 2, H // 2, 2, W // 2, 2).double().sum(dim=(3, 5, 7))
+        via_x = (g0 * x0.double()).sum(dim=(1, 2, 3, 4)) + (gx[:, c0:].double() * x1.double()).sum(dim=(1, 2, 3, 4))
+        del g0
+    else:
+        via_x = (gx.double() * x0.double()).sum(dim=(1, 2, 3, 4))
+    del gx
+    assert bool(((lhs - via_x).abs() <= 1e-5 * scale).all()), (lhs, via_x, scale)
+    # the weight gradient sums over the batch: per-sample identity through one-sample launches on views of the batch
+    ws = VF._Workspace(y.device)
+    gsum = torch.zeros_like(w, dtype=torch.float64)
+    for b in range(B):
+        gw, gb = torch.empty_like(w), torch.empty(cout, device="cuda")
+        VF.conv_bwd_weight(ws, x0[b:b + 1], c0, x0[0].numel(), up0, x1[b:b + 1] if c1 else None, c1, x1[0].numel() if c1 else 0, dz[b:b + 1], cout,
+                           gw, gb, 1, D, H, W)
+        via_w = float((gw.double() * w.double()).sum())
+        assert abs(float(lhs[b]) - via_w) <= 1e-5 * float(scale[b]), (b, float(lhs[b]), via_w)
+        gsum += gw.double()
+    gw, gb = torch.empty_like(w), torch.empty(cout, device="cuda")
+    VF.conv_bwd_weight(ws, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if c1 else 0, dz, cout, gw, gb, B, D, H, W)
+    assert rel_l2(N(gw), gsum.cpu().numpy()) <= 1e-5
+    np.testing.assert_allclose(N(gb), N(dz.double().sum(dim=(0, 2, 3, 4)).float()), rtol=1e-4, atol=4e-2)
+
+
+def test_semisupervised_config5_shape_vs_oracle(vxm):
+    """BASELINE.json configs[4] AT ITS SHAPE: VxmDenseSemiSupervisedSeg 160x192x224 with the 30 evaluated
+    labels one-hot at half resolution [1, 30, 80, 96, 112], losses [NCC, Grad('l2', x2), Dice] weighted [1, 1, 0.01]
+    (voxelmorph/tf/networks.py:287-388, scripts/tf/train_semisupervised_seg.py:117-140) on the structured pair built from the
+    reference's real scan: forward tensors, loss and every parameter gradient against the oracle composition; then the
+    evaluation protocol of scripts/tf/test.py:80-112 -- nearest warp of the full-resolution label map (bit-exact against the C
+    oracle on the same flow) and py/utils.py:265-287 Dice against the oracle's."""
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    vol, seg, labels = _real_scan()
+    nb = len(labels)
+    assert nb == 30
+    svf = _smooth_svf(FULL)
+    trg = vol[None, None]
+    src = c_oracle.warp3d(trg, svf, mode="bilinear")
+    seg30 = np.where(np.isin(seg, labels), seg, 0.0).astype(np.float32)
+    seg_moving = c_oracle.warp3d(seg30[None, None], svf, mode="nearest")[0, 0]
+    half = tuple(slice(None, None, 2) for _ in range(3))                       # generators.py:161-165: seg[::2, ::2, ::2] split into one-hot labels
+    onehot = lambda lab: np.stack([(lab[half] == l) for l in labels], 0).astype(np.float32)[None]
+    seg_src, seg_trg = onehot(seg_moving), onehot(seg30)
+    assert seg_src.shape == (1, 30, 80, 96, 112)
+    sd = orc.seeded_state_dict(FULL, seed=14, flow_std=0.05)
+    model = vxm.networks.VxmDenseSemiSupervisedSeg(FULL, nb, int_steps=7, int_downsize=2)
+    res = model.vxm_model.load_state_dict(sd, strict=False)
+    assert all(k.endswith(".grid") for k in res.missing_keys) and not res.unexpected_keys
+    model = model.cuda()
+    y, pre, yseg = model(G(src), G(trg), G(seg_src))
+    l_dice = vxm.losses.Dice().loss(G(seg_trg), yseg)
+    loss = vxm.losses.NCC().loss(G(trg), y) + vxm.losses.Grad("l2", loss_mult=2).loss(None, pre) + 0.01 * l_dice
+    loss.backward()
+    torch.cuda.synchronize()
+    sdo = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    names, params = list(sdo), list(sdo.values())
+    ts, tt = torch.from_numpy(src), torch.from_numpy(trg)
+    yo, preo, ysego, poso = orc.vxm_semisupervised_forward(ts, tt, torch.from_numpy(seg_src), sdo)
+    reg_o, dice_o = orc.grad_loss(preo, "l2", 2), orc.dice_loss(torch.from_numpy(seg_trg), ysego)
+    # the image term against the fp64-NCC arbiter: the reference's fp32 NCC formula loses its digits on a real scan (see above)
+    ref64 = orc.ncc_loss(tt, yo, dtype=torch.float64).float() + reg_o + 0.01 * dice_o
+    g64 = dict(zip(names, torch.autograd.grad(ref64, params)))
+    err_seg = float((yseg.detach().cpu() - ysego.detach()).abs().max())
+    print("config-5 step: loss hip=%.7f oracle=%.7f | dice term hip=%.6f oracle=%.6f | max|d warped seg|=%.2e"
+          % (float(loss), float(ref64), float(l_dice), float(dice_o), err_seg))
+    assert tuple(yseg.shape) == (1, 30, 80, 96, 112)
+    assert err_seg <= 1e-4 and abs(float(l_dice) - float(dice_o)) <= 1e-5 and abs(float(loss) - float(ref64)) <= 1e-3
+    for name, p in model.vxm_model.named_parameters():
+        e = rel_l2(N(p.grad), g64[name].numpy())
+        print("  %-40s vs fp64-NCC arbiter: hip %.2e" % (name, e))
+        assert e <= 3e-4, (name, e)
+    # evaluation: nearest warp of the full-resolution moving label map with the predicted flow
+    moved = N(model.apply_transform(G(src), G(trg), G(seg_moving[None, None]), interp_method="nearest"))
+    with torch.no_grad():
+        flow_hip = model.register(G(src), G(trg))
+    ref_same_flow = c_oracle.warp3d(seg_moving[None, None], N(flow_hip), mode="nearest")
+    assert np.array_equal(moved, ref_same_flow), "nearest label warp differs in %d voxels" % int((moved != ref_same_flow).sum())
+    ref = c_oracle.warp3d(seg_moving[None, None], poso.detach().numpy(), mode="nearest")
+    d_hip = np.asarray(orc.dice_metric(moved[0, 0], seg30, labels=labels))
+    d_ref = np.asarray(orc.dice_metric(ref[0, 0], seg30, labels=labels))
+    print("config-5 evaluation: mean Dice hip=%.6f oracle=%.6f, max per-label diff %.2e" % (d_hip.mean(), d_ref.mean(), np.abs(d_hip - d_ref).max()))
+    assert d_hip.shape == (30,) and np.abs(d_hip - d_ref).max() <= 1e-3
 
 
 # ------------------------------------------------------------------ 2-D (planar) variants: golden fixtures from the reference
@@ -1098,6 +1226,35 @@ def test_train_cli_atlas_multichannel_and_semisupervised(vxm, tmp_path):
             "--labels", str(tmp_path / "labels.npy"), "--model-dir", str(tmp_path / "ms"), "--image-loss", "ncc", *extra)
     ck = torch.load(tmp_path / "ms" / "0002.pt", map_location="cpu")
     assert ck["config"]["nb_labels"] == 3 and (tmp_path / "ms" / "0000.pt").exists()
+
+
+def test_inference_mode_and_flat_adam_zero_grad_contract(vxm):
+    """(1) torch.inference_mode(): inference tensors carry no version counter -- the fused engines must not read one (fp32 and
+    bf16 engine, parameters created inside inference_mode included).  (2) FlatAdam.step() without FlatAdam.zero_grad() since the
+    previous step raises instead of adding new gradients onto the old, already reduced ones."""
+    from voxelmorph_amd.optim import FlatAdam
+    inshape = (16, 16, 16)
+    src, trg = torch.rand(1, 1, *inshape, device="cuda"), torch.rand(1, 1, *inshape, device="cuda")
+    model = vxm.networks.VxmDense(inshape, int_steps=2).cuda()
+    with torch.no_grad():
+        want, _ = model(src, trg, registration=True)
+    with torch.inference_mode():
+        got, _ = model(src, trg, registration=True)
+        m2 = vxm.networks.VxmDense(inshape, int_steps=2).cuda()            # parameters that are inference tensors themselves
+        m2(src, trg, registration=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            m2(src, trg, registration=True)
+    assert torch.equal(got, want)
+    opt = FlatAdam(model, lr=1e-4)
+    for it in range(2):
+        opt.zero_grad()
+        y, pre = model(src, trg)
+        (vxm.losses.MSE().loss(trg, y) + 0.01 * vxm.losses.Grad("l2", loss_mult=2).loss(None, pre)).backward()
+        opt.step()
+    y, pre = model(src, trg)
+    vxm.losses.MSE().loss(trg, y).backward()
+    with pytest.raises(RuntimeError, match="zero_grad"):
+        opt.step()
 
 
 def test_native_comm_world_one(vxm):

@@ -8,9 +8,10 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 STEPS=4; WARM=2
-export VXM_PROFILED_STEPS=$((STEPS + WARM))
+# bench.py runs warm-up + the timed pass + the per-kernel pass (min(steps, 10) more steps): all of them are dispatches the profiler sees
+export VXM_PROFILED_STEPS=$((STEPS + WARM + (STEPS < 10 ? STEPS : 10)))
 SUF=${VXM_PROFILE_SUFFIX:-}
-ARGS="--steps $STEPS --warmup $WARM --no-cpu-baseline $*"
+ARGS="--steps $STEPS --warmup $WARM --no-cpu-baseline --no-extra-configs $*"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py $ARGS > $OUT/bench_stats.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python bench.py $ARGS > $OUT/bench_fetch.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python bench.py $ARGS > $OUT/bench_write.log 2>&1

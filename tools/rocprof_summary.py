@@ -55,7 +55,9 @@ def pmc(roots, out):
     res = collections.OrderedDict()
     steps = os.environ.get("VXM_PROFILED_STEPS")
     if steps:                  # bench steps + warm-up steps of the profiled command: bench.py checks dispatch counts against it
-        res["_meta"] = {"steps_profiled": int(steps)}
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "voxelmorph_amd"))
+        import buildinfo                # kernel sources these counters belong to: bench.py refuses them for any other tree
+        res["_meta"] = {"steps_profiled": int(steps), "csrc_sha": buildinfo.csrc_sha()}
     for k, ctrs in agg.items():
         res[k] = {c: {"dispatches": v[0], "mean": v[1] / v[0]} for c, v in ctrs.items()}
     for k, v in res.items():

@@ -1,0 +1,110 @@
+#!/usr/bin/env python
+"""Developer microbenchmark (not a test, not the product): the forward / backward-data conv products of the full-resolution layers
+of the default VxmDense U-Net at 160x192x224 on the split-fp32 kernel (csrc/conv_s3.hip) and on the exact-fp32 MFMA kernels
+(csrc/conv_fwd.hip), timed with HIP events; fp32-equivalent TFLOP/s, and the difference between the two results.
+
+    [VXM_S3_CB=2] [VXM_S3_NCT=1] python tools/s3_bench.py [--iters 5] [--shape 160,192,224] [--batch 1]
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# name, c0, up0, c1, cout, level, flip (operator = adjoint of a layer with `c0` outputs... see below), mask
+# forward operators: x [c0 (+c1)] -> cout.  backward-data operators are forward launches with flipped packs: dz [c0] -> cout.
+OPS = [
+    ("rem1 fwd      32->16", 32, False, 0, 16, 0, False),
+    ("rem2 fwd      16->16", 16, False, 0, 16, 0, False),
+    ("rem2 bwd-data 16->16", 16, False, 0, 16, 0, True),
+    ("rem1 bwd-data 16->32", 16, False, 0, 32, 0, True),
+    ("rem0 bwd-skip 32->16", 32, False, 0, 16, 0, True),
+    ("enc1 fwd      16->32 (L1)", 16, False, 0, 32, 1, False),
+    ("enc1 bwd-data 32->16 (L1)", 32, False, 0, 16, 1, True),
+    ("rem0 fwd 32^+16->32", 32, True, 16, 32, 0, False),
+    ("dec3 fwd 32^+32->32 (L1)", 32, True, 32, 32, 1, False),
+]
+
+
+def timed(fn, iters):
+    fn()
+    fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--shape", type=str, default="160,192,224")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--json", type=str, default="")
+    args = ap.parse_args()
+    from voxelmorph_amd import _lib
+    from voxelmorph_amd.torch import functional as VF
+    shape = tuple(int(s) for s in args.shape.split(","))
+    B = args.batch
+    torch.manual_seed(0)
+    rows = []
+    print("instance for 16 / 32 output channels: %d / %d (10 NCT + CB)" % (_lib.lib().vxm_conv3d_k3_s3_variant(16), _lib.lib().vxm_conv3d_k3_s3_variant(32)))
+    for name, c0, up0, c1, cout, lvl, flip in OPS:
+        if args.only and args.only not in name:
+            continue
+        D, H, W = (s >> lvl for s in shape)
+        V = D * H * W
+        x0 = torch.randn(B, c0, *((D // 2, H // 2, W // 2) if up0 else (D, H, W)), device="cuda")
+        x1 = torch.randn(B, c1, D, H, W, device="cuda") if c1 else None
+        cin = c0 + c1
+        # a weight tensor whose operator on (cin -> cout) is what we time: forward reads w[cout][cin], the adjoint reads w[cin][cout]
+        w = torch.randn(*((cin, cout) if flip else (cout, cin)), 3, 3, 3, device="cuda") / (27 * cin) ** 0.5
+        bias = None if flip else torch.randn(cout, device="cuda")
+        mask = torch.randn(B, cout, D, H, W, device="cuda") if flip else None
+        y_s3 = torch.empty(B, cout, D, H, W, device="cuda")
+        y_nat = torch.empty_like(y_s3)
+        slope = 1.0 if flip else 0.2
+        wp_s3 = VF.s3_pack(w, flip, 0, cout if flip else cin, cin if flip else c0)
+
+        def run_s3():
+            VF.s3_launch(x0, c0, x0[0].numel(), up0, x1, c1, c1 * V, wp_s3, bias, y_s3, cout * V, cout, slope, mask, cout * V, 0.2, B, D, H, W)
+
+        if up0 and not flip:
+            keep = VF.FP32_ENGINE
+            VF.FP32_ENGINE = "native"
+
+            def run_nat():
+                VF.conv_forward(x0, c0, x0[0].numel(), True, x1, c1, c1 * V, w, bias, y_nat, cout * V, cout, slope, B, D, H, W)
+        else:
+            wp_nat = VF.pack_weights(w, flip, 0, cout if flip else cin)
+
+            def run_nat():
+                VF.conv_launch(x0, c0, x0[0].numel(), up0, x1, c1, c1 * V, wp_nat, bias, y_nat, cout * V, cout, slope, mask, cout * V, 0.2, B, D, H, W)
+        ok = bool(_lib.lib().vxm_conv3d_k3_s3_ok(c0, c1, cout, B, D, H, W))
+        t_s3 = timed(run_s3, args.iters)
+        t_nat = timed(run_nat, args.iters)
+        if up0 and not flip:
+            VF.FP32_ENGINE = keep
+        gf = 2.0 * 27 * cin * cout * B * V / 1e9
+        diff = float((y_s3.double() - y_nat.double()).norm() / y_nat.double().norm())
+        row = dict(op=name, gflop=gf, s3_ms=t_s3, s3_tflops=gf / t_s3, native_ms=t_nat, native_tflops=gf / t_nat, rel_l2_s3_vs_native=diff, s3_eligible=ok)
+        rows.append(row)
+        print("%-28s %7.1f GFLOP | split %.3f ms = %6.1f TF-eq | fp32-MFMA %.3f ms = %6.1f TF | x%.2f | rel-L2(split, fp32) %.2e"
+              % (name, gf, t_s3, gf / t_s3, t_nat, gf / t_nat, t_nat / t_s3, diff), flush=True)
+        del x0, x1, y_s3, y_nat, mask
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(rows, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

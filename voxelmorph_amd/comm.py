@@ -22,6 +22,7 @@ SIGNATURES = {
     "vxm_comm_unique_id": [_c.c_void_p],
     "vxm_comm_init": [_c.c_int, _c.c_int, _c.c_void_p],
     "vxm_comm_world": [],
+    "vxm_comm_rccl_version": [],
     "vxm_allreduce_sum_f32": [_c.c_void_p, _c.c_int64, _c.c_void_p],
     "vxm_broadcast_f32": [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p],
     "vxm_comm_destroy": [],
@@ -41,6 +42,10 @@ def lib():
             fn.restype = _c.c_char_p if name == "vxm_comm_last_error_string" else _c.c_int
         _lib = h
     return _lib
+
+
+def rccl_version():
+    return int(lib().vxm_comm_rccl_version())
 
 
 def _call(name, *args):
@@ -81,21 +86,54 @@ class NativeComm:
         one GPU, which RCCL refuses), every rank drops it and returns None, so that the job continues on
         torch.distributed's RCCL instead of hanging in a half-initialised collective."""
         import torch.distributed as dist
-        comm, err = None, ""
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def agree(ok):
+            flags = [None] * world
+            dist.all_gather_object(flags, bool(ok), group=group)
+            return flags
+
+        def report(flags, err, what):
+            if rank == 0:
+                import sys
+                print("voxelmorph_amd: libvxm_comm.so %s on %d of %d ranks (%s); gradient all-reduce through "
+                      "torch.distributed (same RCCL)" % (what, flags.count(False), len(flags), err or "see other ranks"), file=sys.stderr)
+
+        # round 1: can every rank load the library at all?  Agreed on BEFORE any rank enters the unique-id broadcast: a rank
+        # that failed here must not leave the others waiting in a collective it never joins.
+        err = ""
         try:
-            comm = cls.from_torch_dist(group)
+            lib()
         except (VxmHipError, OSError, AttributeError) as exc:
             err = str(exc)
-        flags = [None] * dist.get_world_size(group)
-        dist.all_gather_object(flags, comm is not None, group=group)
+        flags = agree(not err)
+        if not all(flags):
+            report(flags, err, "cannot be loaded")
+            return None
+        # round 2: rank 0's unique id travels as an (id | error) object, so a failure to create it is seen by every rank
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.new_unique_id()
+            except VxmHipError as exc:
+                box[0] = exc
+        dist.broadcast_object_list(box, src=0, group=group)
+        if not isinstance(box[0], (bytes, bytearray)):
+            report([False] * world, str(box[0]), "unique id unavailable")
+            return None
+        # round 3: the communicator itself (ncclCommInitRank is collective inside RCCL; it fails on all ranks or on none in
+        # the cases seen -- two ranks on one device --, and the agreement below covers a split decision)
+        comm = None
+        try:
+            comm = cls(rank, world, box[0])
+        except (VxmHipError, OSError) as exc:
+            err = str(exc)
+        flags = agree(comm is not None)
         if all(flags):
             return comm
         if comm is not None:
             comm.destroy()
-        if dist.get_rank(group) == 0:
-            import sys
-            print("voxelmorph_amd: libvxm_comm.so communicator unavailable on %d of %d ranks (%s); gradient all-reduce through "
-                  "torch.distributed (same RCCL)" % (flags.count(False), len(flags), err or "see other ranks"), file=sys.stderr)
+        report(flags, err, "communicator unavailable")
         return None
 
     def _check(self, t):

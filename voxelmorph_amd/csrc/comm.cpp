@@ -4,9 +4,15 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 namespace {
 
@@ -48,9 +54,35 @@ int vxm_comm_init(int rank, int world, const void* unique_id) {
     if (!unique_id || world < 1 || rank < 0 || rank >= world) return fail(1, "vxm_comm_init: bad arguments rank=%d world=%d", rank, world);
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
-    COMM_CHECK(ncclCommInitRank(&g_comm, world, id, rank), "ncclCommInitRank");
-    g_world = world;
+    // ncclCommInitRank blocks until EVERY rank has joined: a rank that died before it (or never calls it) would leave the others
+    // waiting for ever.  It runs on a helper thread bound to the caller's device; the caller waits at most
+    // VXM_COMM_INIT_TIMEOUT_S seconds (default 180) and then reports an error instead of hanging (the helper is abandoned).
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(4, "vxm_comm_init: no current HIP device");
+    struct Shared { std::mutex m; std::condition_variable cv; bool done = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr; };
+    auto sh = std::make_shared<Shared>();
+    std::thread([sh, dev, world, id, rank] {
+        ncclComm_t c = nullptr;
+        ncclResult_t r = hipSetDevice(dev) == hipSuccess ? ncclCommInitRank(&c, world, id, rank) : ncclUnhandledCudaError;
+        std::lock_guard<std::mutex> lk(sh->m);
+        sh->res = r; sh->comm = c; sh->done = true;
+        sh->cv.notify_all();
+    }).detach();
+    const char* e = getenv("VXM_COMM_INIT_TIMEOUT_S");
+    const long secs = e && atol(e) > 0 ? atol(e) : 180;
+    std::unique_lock<std::mutex> lk(sh->m);
+    if (!sh->cv.wait_for(lk, std::chrono::seconds(secs), [&] { return sh->done; }))
+        return fail(5, "vxm_comm_init: ncclCommInitRank did not complete within %ld s (rank %d of %d): a rank is missing", secs, rank, world);
+    if (sh->res != ncclSuccess) return fail(100 + (int)sh->res, "ncclCommInitRank: %s", ncclGetErrorString(sh->res));
+    g_comm = sh->comm;
+    int n = 0;
+    g_world = ncclCommCount(g_comm, &n) == ncclSuccess ? n : world;     // what RCCL itself says the communicator spans
     return 0;
+}
+
+int vxm_comm_rccl_version(void) {
+    int v = 0;
+    return ncclGetVersion(&v) == ncclSuccess ? v : 0;
 }
 
 int vxm_comm_world(void) { return g_world; }

@@ -1,0 +1,398 @@
+// fp32 convolutions of the VxmDense U-Net on the bf16 matrix pipe: the three-way bf16 split ("bf16x3").
+//
+// Replaces, for the plain (not collapsed-upsample) full-resolution layers, the fp32-MFMA kernels of conv_fwd.hip:
+//   voxelmorph/torch/networks.py:299-305  ConvBlock = Conv3d(k3,s1,p1) + LeakyReLU(0.2)   (forward)
+//   and its autograd twin convolution_backward w.r.t. the input (+ leaky_relu_backward of the previous block).
+//
+// Arithmetic.  Every fp32 operand is written as the exact sum of three bf16 pieces, x = h + m + l (+ a remainder below 2^-24 |x|):
+//     h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m)          (the two subtractions are exact in fp32)
+// and a product x w is accumulated in fp32 from the six piece products whose magnitude is above 2^-24 |x w|:
+//     x w  ~=  h_x h_w + h_x m_w + m_x h_w + h_x l_w + l_x h_w + m_x m_w           (dropped: m l, l m, l l  <=  2^-25 |x w|)
+// Each piece product is exact in the MFMA (8 x 8 significand bits), the accumulation is the fp32 accumulation of
+// v_mfma_f32_16x16x32_bf16.  The result is an fp32 convolution to within a few fp32 ulps of the exact dot product (measured
+// against an fp64 evaluation by the same gate as the fp32-MFMA kernels: rel-L2 <= 1e-5, tests/test_gpu_s3.py), on a pipe that does
+// 8192 MACs in 16 cycles instead of 1024 in 32: six instructions replace sixteen.
+//
+// Layout.  HBM tensors stay planar fp32 NCDHW (the C ABI and every other kernel are unchanged); a block splits its haloed
+// input tile while staging it: LDS holds, per piece, channel-blocked bf16 [8-channel block][hd][hr][hw][8] -- the 8 channels of
+// a voxel are one 16-byte word, one lane's share of a K = 32 MFMA operand.  Weights are split when they are packed.
+//
+// Implicit GEMM (as conv_bf16.hip): M = 16 output channels, N = 16 voxels of a W row, K = 32 = four units of 8 input channels,
+// unit = (kd, kw, 8-channel block); the kh tap is walked by SLIDING over the haloed rows: the three B pieces of haloed row r
+// serve output rows r, r-1, r-2 with the weight fragments of kh = 0, 1, 2 (3 LDS reads feed up to 18 NCT MFMAs).
+// Block = 8 waves, output tile 8(D) x ROWS(H) x 16(W), wave = depth slice; chunk = CB 8-channel blocks of one segment of the
+// virtual concat [x0 (optionally through a nearest x2 upsampling gather) | x1].
+#include "conv_common.h"
+
+namespace {
+
+typedef __bf16 s3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 s3_bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 s3_mfma(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s3_bf16x8, a), __builtin_bit_cast(s3_bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned s3_pack2(float lo, float hi) {            // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, s3_bf16x2));
+}
+__device__ __forceinline__ float s3_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float s3_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// (x0, x1) -> the three packed bf16 pairs (h, m, l); both remainders are exact fp32 differences
+__device__ __forceinline__ void s3_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+#pragma clang fp contract(off)
+    h = s3_pack2(x0, x1);
+    const float r0 = x0 - s3_lo(h), r1 = x1 - s3_hi(h);
+    m = s3_pack2(r0, r1);
+    const float q0 = r0 - s3_lo(m), q1 = r1 - s3_hi(m);
+    l = s3_pack2(q0, q1);
+}
+
+constexpr int S3_TD = 8, S3_THREADS = 512, S3_HWV = 18;
+
+template <int NCT, int ROWS, int CB>
+struct S3Cfg {
+    static constexpr int HR = ROWS + 2, PLANE = HR * S3_HWV, SLOTS = (S3_TD + 2) * PLANE;     // 16-byte words of one (piece, block)
+    static constexpr int NU = 9 * CB, NS = (NU + 3) / 4;                                      // units / K-steps of a chunk
+    static constexpr int XW = 3 * CB * SLOTS;                                                 // [piece][cb][slot]
+    static constexpr int WCH = NS * 9 * NCT * 64;                                             // [s][kh][piece][ct][lane]
+    static constexpr int LDS_BYTES = (XW + WCH) * 16;
+    static constexpr int NI = (CB * SLOTS + S3_THREADS - 1) / S3_THREADS;                     // staging slots per thread
+    static constexpr int WIT = (WCH + S3_THREADS - 1) / S3_THREADS;
+    static constexpr int MIN_WAVES = LDS_BYTES <= 80 * 1024 ? 4 : 2;                          // two blocks per CU when the LDS allows it
+};
+
+// wp: [G][Q][NS][kh 3][piece 3][NCT][64 lanes] 16-byte words (k_s3_pack_weights).  Q0 chunks cover segment 0, Q - Q0 segment 1.
+template <int NCT, int ROWS, int CB>
+__global__ void __launch_bounds__(S3_THREADS, (S3Cfg<NCT, ROWS, CB>::MIN_WAVES))
+k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout,
+          float act_slope, const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W, int Q0, int Q) {
+    using C = S3Cfg<NCT, ROWS, CB>;
+    VXM_DYN_SMEM(u32x4, smem);
+    constexpr int HR = C::HR, PLANE = C::PLANE, SLOTS = C::SLOTS, NS = C::NS, NI = C::NI, WCH = C::WCH, WIT = C::WIT;
+    u32x4* const Xs = smem;                 // [3][CB][SLOTS]
+    u32x4* const Ws = smem + C::XW;         // [NS][3][3][NCT][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = lane >> 4, n = lane & 15;
+
+    // tile of this block: block b runs on XCD b % 8 (observed; speed only), XCD x takes a contiguous tile range
+    const int nw = (W + 15) / 16, nh = (H + ROWS - 1) / ROWS, nd = (D + S3_TD - 1) / S3_TD;
+    const int ntiles = B * nd * nh * nw;
+    int tile = blockIdx.x;
+    if (ntiles >= 64) {
+        const int x = tile & 7, j = tile >> 3;
+        const int lo = (int)((long long)ntiles * x / 8), hi = (int)((long long)ntiles * (x + 1) / 8);
+        tile = lo + j;
+        if (tile >= hi) return;
+    } else if (tile >= ntiles) {
+        return;
+    }
+    const int tw = tile % nw; int tq = tile / nw;
+    const int th = tq % nh; tq /= nh;
+    const int td = tq % nd; const int b = tq / nd;
+    const int d0 = td * S3_TD, h0 = th * ROWS, w0 = tw * 16;
+    const int g = blockIdx.y;
+
+    const int V = D * H * W;
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
+    const int V0 = in.up0 ? Dl * Hl * Wl : V;
+    const __amdgpu_buffer_rsrc_t r0 = vxm_rsrc(in.x0 + (size_t)b * in.bs0, (unsigned)in.C0 * (unsigned)V0 * 4u);
+    const __amdgpu_buffer_rsrc_t r1 = vxm_rsrc(in.C1 ? in.x1 + (size_t)b * in.bs1 : in.x0, (unsigned)in.C1 * (unsigned)V * 4u);
+
+    // staging roles of this thread, fixed for the block: slot i = tid + 512 j = (cb, hd, hh, hw) of the haloed tile; element
+    // offsets of its voxel in a full-resolution plane set / in the half-resolution source of an upsampled segment (-1: padding)
+    int sfull[NI], shalf[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int i = tid + S3_THREADS * j;
+        const int rem = i % SLOTS;
+        const int hd = rem / PLANE, r2 = rem - hd * PLANE, hh = r2 / S3_HWV, hw = r2 - hh * S3_HWV;
+        const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+        const bool ok = i < CB * SLOTS && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        sfull[j] = ok ? (gd * H + gh) * W + gw : -1;
+        shalf[j] = ok ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : -1;
+    }
+
+    f32x4 acc[NCT][ROWS];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane LDS word offset of the unit this lane group reads in K-step s: unit u = 4 s + kg = CB (3 kd + kw) + cb
+    int xoff[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int u = 4 * s + kg, uu = u < C::NU ? u : 0;     // units beyond NU carry zero weights: any valid address
+        const int kdkw = uu / CB, cb = uu - kdkw * CB, kd = kdkw / 3, kw = kdkw - 3 * kd;
+        xoff[s] = cb * SLOTS + (wave + kd) * PLANE + kw + n;
+    }
+
+    float xr[NI][8];                                         // chunk q + 1 in flight under the MFMAs of chunk q
+    int voffs[NI];                                           // its per-lane offsets: kept live across the MFMA phase (see keep_offsets)
+    auto load_chunk = [&](int q) __attribute__((always_inline)) {
+        const bool s0 = q < Q0;                               // wave-uniform
+        const bool up = s0 && in.up0;
+        const __amdgpu_buffer_rsrc_t r = s0 ? r0 : r1;
+        const int Cseg = s0 ? in.C0 : in.C1, cbg = (s0 ? q : q - Q0) * CB, Vs = up ? V0 : V;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int cb = (tid + S3_THREADS * j) / SLOTS;
+            const int sv = up ? shalf[j] : sfull[j];
+            const bool ok = sv >= 0 && (cbg + cb) * 8 < Cseg && q < Q;  // segments carry multiples of 8 channels; q == Q: nothing to fetch
+            voffs[j] = ok ? ((cbg + cb) * 8 * Vs + sv) << 2 : VXM_OOB;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xr[j][e] = vxm_bload(r, voffs[j], (e * Vs) << 2);
+        }
+    };
+    // The address VGPR of a buffer load that is still in flight must not be reused: the compiler otherwise hands it to the first
+    // ds_read of the MFMA phase and protects that write with `s_waitcnt vmcnt(0)` -- i.e. waits for the whole prefetch right after
+    // issuing it (seen in the ISA).  Keeping the offsets formally live until the MFMA phase is over costs NI registers.
+    auto keep_offsets = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(voffs[j]));
+    };
+    auto store_chunk = [&](int q) __attribute__((always_inline)) {
+        // the chunk's packed weights: requested first, written to LDS after the split arithmetic below has covered their latency
+        u32x4 wv[WIT];
+        const __amdgpu_buffer_rsrc_t rw = vxm_rsrc(reinterpret_cast<const float*>(wp + ((size_t)g * Q + q) * WCH), WCH * 16u);
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            wv[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + S3_THREADS * it) * 16, 0, 0));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int i = tid + S3_THREADS * j;
+            unsigned pk[3][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s3_split2(xr[j][2 * e], xr[j][2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+            if (i < CB * SLOTS) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) Xs[p * CB * SLOTS + i] = (u32x4){pk[p][0], pk[p][1], pk[p][2], pk[p][3]};
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = tid + S3_THREADS * it;
+            if (i < WCH) Ws[i] = wv[it];
+        }
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int q = 0; q < Q; ++q) {
+        // unconditional (past the last chunk every lane is out of range and nothing is fetched): a branch around the prefetch makes
+        // the compiler wait for it at the join, right after it was issued (s_waitcnt vmcnt(0) in front of the first MFMA, seen in the ISA)
+        load_chunk(q + 1);
+        // ---- NS K-steps x (ROWS + 2) haloed rows: three B pieces per row, up to 3 kh x NCT x 6 piece products per read set
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            u32x4 a[3][3][NCT];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) a[kh][p][ct] = Ws[(((s * 3 + kh) * 3 + p) * NCT + ct) * 64 + lane];
+#pragma unroll
+            for (int hr = 0; hr < HR; ++hr) {
+                u32x4 bf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[p] = Xs[p * CB * SLOTS + xoff[s] + hr * S3_HWV];
+                // piece products, small terms first; consecutive MFMAs go to different accumulators (rows hr, hr-1, hr-2)
+                constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};       // (m,m) (l,h) (h,l) (m,h) (h,m) (h,h)
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const int row = hr - kh;
+                        if (row >= 0 && row < ROWS) {
+#pragma unroll
+                            for (int ct = 0; ct < NCT; ++ct) acc[ct][row] = s3_mfma(a[kh][PA[t]][ct], bf[PB[t]], acc[ct][row]);
+                        }
+                    }
+            }
+        }
+        if (q + 1 < Q) {
+            keep_offsets();
+            __syncthreads();                        // every wave is done reading chunk q
+            store_chunk(q + 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: the D layout of the bf16 MFMA is the fp32 one's (lane (kg, n): channels 4 kg + j of voxel column n):
+    // bias + LeakyReLU (+ fused leaky_relu_backward mask), planar fp32 store, shared with the fp32-MFMA kernels
+    const int d = d0 + wave, w = w0 + n;
+    float bz[NCT][4];
+    conv_load_bias<NCT>(bz, bias, Cout, g, kg);
+    conv_epilogue_store<NCT, ROWS, 1>(acc, y + (size_t)b * y_bs, bz, mask ? mask + (size_t)b * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
+                                      d < D && w < W, (d * H + h0) * W + w, h0, H, W, V);
+}
+
+// w: [Cw_out][Cw_in][27] fp32 (reference layout) -> [G][Q][NS][kh][piece][NCT][64 lanes][8 bf16]: lane (kg, m) of K-step s / row
+// tap kh / piece p holds, for output channel 16 (g NCT + ct) + m, piece p of the weights of unit u = 4 s + kg = CB (3 kd + kw) + cb.
+// Operator: y[o] = sum_i Wop[o][i][tap] x[i] over the virtual input channels i (segment 0: [0, seg0), segment 1: the rest);
+// chunk q < Q0 holds segment-0 channels 8 CB q + 8 cb + e, chunk q >= Q0 segment-1 channels seg0 + 8 CB (q - Q0) + 8 cb + e.
+// forward: Wop[o][i][t] = w[o][ci_lo + i][t]; flip (backward-data onto input channels [ci_lo, ci_lo + OutC)): Wop[o][i][t] = w[i][ci_lo + o][26 - t].
+struct S3PackJob {
+    const float* w; u32x4* wp;
+    int Cw_in, ci_lo, flip, InC, seg0, OutC, NCT, CB, Q0, Q;
+    unsigned first_block, words;
+};
+__device__ __forceinline__ void s3_pack_word(const S3PackJob& jb, size_t i) {
+    const int NS = (9 * jb.CB + 3) / 4;
+    size_t r = i;
+    const int lane = r % 64; r /= 64;
+    const int ct = r % jb.NCT; r /= jb.NCT;
+    const int p = r % 3; r /= 3;
+    const int kh = r % 3; r /= 3;
+    const int s = r % NS; r /= NS;
+    const int q = r % jb.Q; const int g = (int)(r / jb.Q);
+    const int kg = lane >> 4, m = lane & 15, u = 4 * s + kg;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int o = (g * jb.NCT + ct) * 16 + m;
+    if (u < 9 * jb.CB && o < jb.OutC) {
+        const int kdkw = u / jb.CB, cb = u % jb.CB, kd = kdkw / 3, kw = kdkw % 3, tap = kd * 9 + kh * 3 + kw;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool s0 = q < jb.Q0;
+            const int cl = (s0 ? q : q - jb.Q0) * 8 * jb.CB + cb * 8 + e;          // channel inside its segment
+            const int ci = s0 ? cl : jb.seg0 + cl;
+            if (cl < (s0 ? jb.seg0 : jb.InC - jb.seg0))
+                v[e] = jb.flip ? jb.w[((size_t)ci * jb.Cw_in + jb.ci_lo + o) * 27 + (26 - tap)] : jb.w[((size_t)o * jb.Cw_in + jb.ci_lo + ci) * 27 + tap];
+        }
+    }
+    unsigned pk[3][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s3_split2(v[2 * e], v[2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+    jb.wp[i] = (u32x4){pk[p][0], pk[p][1], pk[p][2], pk[p][3]};
+}
+
+// Every stale operator of a step in one launch; the job table travels in the kernel arguments, a block finds its job by a scan.
+#define S3_PACK_JOBS 40
+struct S3PackBatch {
+    S3PackJob job[S3_PACK_JOBS];
+    int n;
+};
+__global__ void __launch_bounds__(256) k_s3_pack_weights(const S3PackBatch batch) {
+    int j = 0;
+    while (j + 1 < batch.n && blockIdx.x >= batch.job[j + 1].first_block) ++j;          // block-uniform
+    const S3PackJob& jb = batch.job[j];
+    const size_t i = (size_t)(blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+    if (i < jb.words) s3_pack_word(jb, i);
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------
+// Kernel instance of an operator with OutC output channels.  VXM_S3_CB=2 stages 16-channel chunks (5 K-steps, 90 % of the K slots
+// used, one block per CU) instead of 8-channel ones (3 K-steps, 75 %, two blocks per CU); VXM_S3_NCT=1 runs 32-channel operators as
+// two 16-channel groups.  The packed layout depends on both, so they are read once per process.
+struct S3Variant { int NCT, CB; };
+S3Variant s3_variant(int OutC) {
+    static const int cb = [] { const char* e = getenv("VXM_S3_CB"); return e && e[0] == '2' ? 2 : 1; }();
+    static const int nct_max = [] { const char* e = getenv("VXM_S3_NCT"); return e && e[0] == '1' ? 1 : 2; }();
+    S3Variant v;
+    v.CB = cb;
+    v.NCT = (OutC > 16 && nct_max == 2 && cb == 1) ? 2 : 1;      // (NCT 2, CB 2) does not fit the LDS
+    return v;
+}
+long long s3_min_tiles() {
+    static const long long v = [] { const char* e = getenv("VXM_S3_MIN_TILES"); return e ? atoll(e) : 1024ll; }();
+    return v;
+}
+int s3_chunks(int C, int CB) { return (C + 8 * CB - 1) / (8 * CB); }
+size_t s3_packed_words(int seg0, int seg1, int OutC) {
+    const S3Variant v = s3_variant(OutC);
+    const int Q = s3_chunks(seg0, v.CB) + s3_chunks(seg1, v.CB), G = (OutC + 16 * v.NCT - 1) / (16 * v.NCT), NS = (9 * v.CB + 3) / 4;
+    return (size_t)G * Q * NS * 9 * v.NCT * 64;
+}
+
+template <int NCT, int ROWS, int CB>
+void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, long long y_bs, int Cout, float slope, const float* mask,
+               long long mask_bs, float mask_slope, int B, int D, int H, int W, hipStream_t s) {
+    using C = S3Cfg<NCT, ROWS, CB>;
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_conv<NCT, ROWS, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        return true;
+    }();
+    (void)attr;
+    const int Q0 = s3_chunks(in.C0, CB), Q = Q0 + s3_chunks(in.C1, CB);
+    const long long ntiles = (long long)B * ((D + S3_TD - 1) / S3_TD) * ((H + ROWS - 1) / ROWS) * ((W + 15) / 16);
+    const unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
+    const int G = (Cout + 16 * NCT - 1) / (16 * NCT);
+    hipLaunchKernelGGL((k_s3_conv<NCT, ROWS, CB>), dim3(gx, G), dim3(S3_THREADS), C::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
+                       Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W) {
+    if (C0 <= 0 || C1 < 0 || Cout < 8 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (C0 % 8 || C1 % 8) return 0;
+    if (s3_variant(Cout).CB == 2 && C1 > 0 && C0 % 16) return 0;          // a chunk lies inside one segment
+    if ((long long)(C0 + C1 > Cout ? C0 + C1 : Cout) * D * H * W >= (1ll << 29)) return 0;
+    const long long ntiles = (long long)B * ((D + S3_TD - 1) / S3_TD) * ((H + 3) / 4) * ((W + 15) / 16);
+    return ntiles >= s3_min_tiles() ? 1 : 0;
+}
+
+int vxm_conv3d_k3_s3_variant(int Cout) {
+    const S3Variant v = s3_variant(Cout);
+    return 10 * v.NCT + v.CB;
+}
+
+size_t vxm_conv3d_k3_s3_packed_bytes(int seg0, int seg1, int OutC) {
+    if (seg0 <= 0 || seg1 < 0 || OutC <= 0) return 0;
+    return s3_packed_words(seg0, seg1, OutC) * 16;
+}
+
+int vxm_conv3d_k3_s3_pack_weights_batch(const VxmS3PackJob* jobs, int n_jobs, void* stream) {
+    VXM_REQUIRE(n_jobs >= 0 && (jobs || n_jobs == 0), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3_pack_weights_batch: null job table");
+    for (int j = 0; j < n_jobs; ++j) {
+        const VxmS3PackJob& a = jobs[j];
+        VXM_REQUIRE(a.w && a.wpacked, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3_pack_weights_batch: job %d: null pointer", j);
+        VXM_REQUIRE(a.Cw_in > 0 && a.Cw_out > 0 && a.ci_lo >= 0 && a.ci_n > 0 && a.ci_lo + a.ci_n <= a.Cw_in, VXM_ERR_BAD_SHAPE,
+                    "vxm_conv3d_k3_s3_pack_weights_batch: job %d: channel range [%d, %d) of %d", j, a.ci_lo, a.ci_lo + a.ci_n, a.Cw_in);
+        const int InC = a.transpose_flip ? a.Cw_out : a.ci_n;
+        VXM_REQUIRE(a.seg0 > 0 && a.seg0 <= InC && (reinterpret_cast<uintptr_t>(a.wpacked) & 15) == 0, VXM_ERR_BAD_SHAPE,
+                    "vxm_conv3d_k3_s3_pack_weights_batch: job %d: segment split %d of %d input channels / alignment", j, a.seg0, InC);
+    }
+    for (int j0 = 0; j0 < n_jobs; j0 += S3_PACK_JOBS) {
+        S3PackBatch batch;
+        batch.n = n_jobs - j0 < S3_PACK_JOBS ? n_jobs - j0 : S3_PACK_JOBS;
+        unsigned blocks = 0;
+        for (int j = 0; j < batch.n; ++j) {
+            const VxmS3PackJob& a = jobs[j0 + j];
+            const int InC = a.transpose_flip ? a.Cw_out : a.ci_n, OutC = a.transpose_flip ? a.ci_n : a.Cw_out;
+            const S3Variant v = s3_variant(OutC);
+            const int Q0 = s3_chunks(a.seg0, v.CB), Q = Q0 + s3_chunks(InC - a.seg0, v.CB);
+            const size_t words = s3_packed_words(a.seg0, InC - a.seg0, OutC);
+            batch.job[j] = {a.w, static_cast<u32x4*>(a.wpacked), a.Cw_in, a.ci_lo, a.transpose_flip ? 1 : 0, InC, a.seg0, OutC, v.NCT, v.CB, Q0, Q,
+                            blocks, (unsigned)words};
+            blocks += (unsigned)((words + 255) / 256);
+        }
+        hipLaunchKernelGGL(k_s3_pack_weights, dim3(blocks), dim3(256), 0, VXM_STREAM(stream), batch);
+    }
+    return vxm_check_launch("vxm_conv3d_k3_s3_pack_weights_batch");
+}
+
+int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride, const void* wpacked,
+                         const float* bias, float* y, int64_t y_bstride, int Cout, float leaky_slope, const float* mask, int64_t mask_bstride,
+                         float mask_slope, int B, int D, int H, int W, void* stream) {
+    VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3_fwd: null pointer");
+    if (int e = check_conv("vxm_conv3d_k3_s3_fwd", C0, C1, x0_up, Cout, B, D, H, W)) return e;
+    VXM_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_fwd: segments carry multiples of 8 channels, got %d + %d", C0, C1);
+    const S3Variant v = s3_variant(Cout);
+    VXM_REQUIRE(!(v.CB == 2 && C1 > 0 && C0 % 16), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_fwd: 16-channel chunks need C0 %% 16 == 0 beside a second segment");
+    VXM_REQUIRE((reinterpret_cast<uintptr_t>(wpacked) & 15) == 0, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_fwd: packed weights must be 16-byte aligned");
+    const ConvIn in = {x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up ? 1 : 0};
+    hipStream_t s = VXM_STREAM(stream);
+    if (v.NCT == 2) s3_launch<2, 4, 1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
+    else if (v.CB == 2) s3_launch<1, 4, 2>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
+    else s3_launch<1, 4, 1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
+    return vxm_check_launch("vxm_conv3d_k3_s3_fwd");
+}
+
+}  // extern "C"

@@ -76,15 +76,23 @@ def barrier():
         dist.barrier()
 
 
-def native_comm():
+def native_comm(required=False):
     """The gradient exchange of a multi-rank run: a `libvxm_comm.so` communicator (include/vxm_comm.h — RCCL behind the C ABI,
     SURVEY.md §8b) whenever the job has more than one rank on HIP devices; torch.distributed is then only the rendezvous
     for the 128-byte unique id.  `VXM_COMM=torch` keeps `torch.distributed.all_reduce` (the same RCCL through torch's 'nccl'
-    backend; also what the gloo CPU tests use); `VXM_COMM=rccl` forces the native communicator for a one-rank job too."""
+    backend; also what the gloo CPU tests use); `VXM_COMM=rccl` forces the native communicator for a one-rank job too.
+    required: raise (on every rank) instead of returning None when the communicator cannot be built -- bench.py asks for that, so a
+    scaling run never silently measures a different exchange than the one it reports."""
     mode = os.environ.get("VXM_COMM", "")
     if mode == "torch" or not (dist.is_available() and dist.is_initialized()):
         return None
     if dist.get_backend() != "nccl" or (dist.get_world_size() == 1 and mode != "rccl"):
         return None
     from .comm import NativeComm
-    return NativeComm.try_from_torch_dist()
+    comm = NativeComm.try_from_torch_dist()
+    if comm is None and required:
+        # every rank took the same decision (try_from_torch_dist agrees on it), so every rank raises: no half-dead job
+        raise RuntimeError("voxelmorph_amd: the libvxm_comm.so RCCL communicator could not be built for this %d-rank job (reason on rank 0's "
+                           "stderr); set VXM_COMM=torch to run the gradient all-reduce through torch.distributed instead"
+                           % dist.get_world_size())
+    return comm

@@ -52,9 +52,18 @@ class FlatAdam:
             self.comm.broadcast(self.flat_param, src)
         elif self.world > 1:
             torch.distributed.broadcast(self.flat_param, src, group=self.group)
+        self._params_rewritten()
+
+    def _params_rewritten(self):
+        """The flat buffer was written behind autograd's back (collective / kernel): bump the parameters' version counters (a
+        graph recorded before must fail loudly) and invalidate the packed bf16 operators cached per parameter."""
+        torch.autograd.graph.increment_version(tuple(self.params))
+        from .torch.functional_bf16 import invalidate_packs
+        invalidate_packs(self.params)
 
     def zero_grad(self):
         self.flat_grad.zero_()
+        self._stale = False
         for p in self.params:
             p.grad = None
             p._vxm_sink_written = False
@@ -78,6 +87,12 @@ class FlatAdam:
             torch.distributed.all_reduce(self.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
 
     def step(self):
+        if getattr(self, "_stale", False):
+            # the bucket still holds the previous step's (already all-reduced) gradients: a loop that calls model.zero_grad()
+            # or nothing at all would silently add the new gradients on top of them
+            raise RuntimeError("FlatAdam.step(): no FlatAdam.zero_grad() since the previous step -- the flat gradient bucket is "
+                               "only cleared (and the fused backward only allowed to write it again) by the optimiser's own "
+                               "zero_grad(); model.zero_grad() is not sufficient")
         self.load_grads_from_params()
         self.reduce_grads()
         require_device(self.flat_param)            # the update itself is a HIP kernel: no CPU fallback
@@ -88,3 +103,4 @@ class FlatAdam:
         # the kernel wrote the parameters behind autograd's back: bump their version counters so that a backward pass over
         # a graph recorded BEFORE this step fails loudly (UnetFn checks them) instead of using the new weights
         torch.autograd.graph.increment_version(tuple(self.params))
+        self._stale = True

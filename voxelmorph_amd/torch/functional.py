@@ -16,7 +16,21 @@ from .._lib import call, ptr, require_device, stream
 SPLIT_48 = True     # conv_bwd_data: produce 48-channel results as 32 + 16 (module-level switch for A/B timing)
 OVERLAP_SMALL_LEVELS = os.environ.get("VXM_NO_OVERLAP", "") != "1"     # UnetFn.backward: weight gradients of the coarse levels on a second HIP stream
 OVERLAP_MIN_LEVEL = int(os.environ.get("VXM_OVERLAP_MIN_LEVEL", "1"))   # first U-Net level whose weight gradients go to the second stream
+# fp32 engine of the 3-D convolutions: "split" = the plain full-resolution layers run on the bf16 matrix pipe with every fp32 operand
+# split into three bf16 pieces (csrc/conv_s3.hip: fp32-level accuracy, 2.67x the pipe rate); "native" = v_mfma_f32_16x16x4_f32
+# everywhere (csrc/conv_fwd.hip).  VXM_S3_UP=1 also sends cat([upsample(x0), x1]) layers through the split kernel (nominal FLOPs,
+# gather through the upsampling) instead of the collapsed-weight fp32 kernel.
+FP32_ENGINE = os.environ.get("VXM_FP32_ENGINE", "split")
+S3_UP = os.environ.get("VXM_S3_UP", "") == "1"
 _SIDE_STREAMS = {}
+
+
+def fp32_engine_note():
+    if FP32_ENGINE != "split":
+        return "native: v_mfma_f32_16x16x4_f32 for every conv product"
+    return ("split: forward / backward-data of the plain full-resolution layers as 3 x bf16 pieces per fp32 operand, 6 piece products on "
+            "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-level accuracy, parity-gated); every other conv product on "
+            "v_mfma_f32_16x16x4_f32")
 
 
 def _side_stream(dev):
@@ -265,6 +279,60 @@ def pack_weights(w, flip, lo=0, hi=None):
     return wp
 
 
+def _pack_ver(t):
+    """cache key of a packed copy of weight tensor t: its version counter + the generation bumped by writers that bypass it"""
+    from .functional_bf16 import _ver
+    return _ver(t)
+
+
+def s3_route(c0, up0, c1, cout, B, D, H, W):
+    """does this conv launch (forward operator over the virtual concat, or an adjoint as a forward) go to the split kernel?"""
+    if FP32_ENGINE != "split" or (up0 and not S3_UP):
+        return False
+    return bool(_lib.lib().vxm_conv3d_k3_s3_ok(c0, c1, cout, B, D, H, W))
+
+
+def s3_prepack(jobs):
+    """Pack every stale split operator of `jobs` = [(w, lo, hi, flip, seg0), ...] in ONE launch (vxm_conv3d_k3_s3_pack_weights_batch).
+    The packed, pre-split copies are cached on the weight tensor until its version moves (once per optimiser step)."""
+    import ctypes
+    stale = []
+    for w, lo, hi, flip, seg0 in jobs:
+        cache = w.__dict__.setdefault("_vxm_s3_packs", {})
+        key = (lo, hi, bool(flip), seg0)
+        hit = cache.get(key)
+        if hit is not None and hit[0] == _pack_ver(w) and hit[1].device == w.device:
+            continue
+        if any(k is cache and kk == key for (_, _, _, _, _, _, _, _, k, kk, _) in stale):
+            continue
+        cout, cin = w.shape[:2]
+        inc, outc = (cout, hi - lo) if flip else (hi - lo, cout)
+        nbytes = _lib.lib().vxm_conv3d_k3_s3_packed_bytes(seg0, inc - seg0, outc)
+        wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else \
+            torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        stale.append((_c(w), cin, cout, lo, hi - lo, bool(flip), seg0, wp, cache, key, _pack_ver(w)))
+    if not stale:
+        return
+    table = (_lib.S3PackJob * len(stale))()
+    for j, (w, cin, cout, lo, n, flip, seg0, wp, _, _, _) in enumerate(stale):
+        table[j] = _lib.S3PackJob(w.data_ptr(), wp.data_ptr(), cin, cout, lo, n, 1 if flip else 0, seg0)
+    call("vxm_conv3d_k3_s3_pack_weights_batch", ctypes.cast(table, ctypes.c_void_p), len(stale), stream())
+    for _, _, _, _, _, _, _, wp, cache, key, ver in stale:
+        cache[key] = (ver, wp)
+
+
+def s3_pack(w, flip, lo, hi, seg0):
+    s3_prepack([(w, lo, hi, flip, seg0)])
+    return w.__dict__["_vxm_s3_packs"][(lo, hi, bool(flip), seg0)][1]
+
+
+def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
+    v = _lib.lib().vxm_conv3d_k3_s3_variant(cout)
+    with _prof.region("k_s3_conv<%d,%d>" % (v // 10, v % 10), flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+        call("vxm_conv3d_k3_s3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
+             cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, stream())
+
+
 def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
     name = None
     if _prof.ACTIVE is not None:          # label the region with the kernel the C ABI will dispatch to
@@ -282,6 +350,9 @@ def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B,
     if cout <= 4 and x1 is None and not up0 and _lib.lib().vxm_conv3d_k3_fewout_ok(ptr(x0), bs0, ptr(y), ybs, c0, cout, W):
         with _prof.region("k_conv3d_k3_fewout<%d>" % cout, flops=2.0 * 27 * c0 * cout * B * D * H * W):
             call("vxm_conv3d_k3_fewout_fwd", ptr(x0), c0, bs0, ptr(_c(w)), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W, stream())
+        return
+    if s3_route(c0, up0, c1, cout, B, D, H, W):
+        s3_launch(x0, c0, bs0, up0, x1, c1, bs1, s3_pack(w, False, 0, c0 + c1, c0), bias, y, ybs, cout, slope, None, 0, 1.0, B, D, H, W)
         return
     if up0 and _lib.lib().vxm_conv3d_k3_up_ok(ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(y), cout, B, D, H, W):
         # upsampled segment at low-resolution cost: collapsed 2x2x2 weights per output parity (conv_fwd.hip: k_conv3d_k3_t8u)
@@ -301,13 +372,20 @@ def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W, w_lo=0):
     A 48-channel result (16 mod 32) is produced as 32 + 16 channels: two launches of the 8-wave kernel's 2- and
     1-tile instances beat one launch of the 3-tile instance (which only exists in the 4-wave kernel)."""
     V = D * H * W
-    if cin > 32 and cin % 32 == 16 and SPLIT_48:
-        bounds = list(range(0, cin - 16, 32)) + [cin - 16, cin]
-    else:
-        bounds = [0, cin]
+    bounds = _bwd_bounds(cin)
     for lo, hi in zip(bounds[:-1], bounds[1:]):         # w_lo: gx covers the input channels [w_lo, w_lo + cin) of w
+        if s3_route(cout, False, 0, hi - lo, B, D, H, W):
+            s3_launch(dz, cout, cout * V, False, None, 0, 0, s3_pack(w, True, w_lo + lo, w_lo + hi, cout), None, gx[:, lo:hi], cin * V, hi - lo,
+                      1.0, mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W)
+            continue
         conv_launch(dz, cout, cout * V, False, None, 0, 0, pack_weights(w, True, w_lo + lo, w_lo + hi), None, gx[:, lo:hi], cin * V, hi - lo, 1.0,
                     mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W)
+
+
+def _versions(tensors):
+    """Version counters for the hand-made in-place-modification check of the fused engines (None for inference tensors,
+    which have none: reading `._version` of a tensor made under torch.inference_mode() raises)."""
+    return [None if t.is_inference() else t._version for t in tensors]
 
 
 def _claim_sink(p):
@@ -479,6 +557,41 @@ def _dims(shape3, lvl):
     return tuple(s >> lvl for s in shape3)
 
 
+def _bwd_bounds(cin):
+    if cin > 32 and cin % 32 == 16 and SPLIT_48:
+        return list(range(0, cin - 16, 32)) + [cin - 16, cin]
+    return [0, cin]
+
+
+def _s3_jobs(plan, params, B, shape3, with_backward, input_grads):
+    """The split-kernel operators one pass over `plan` will ask for (forward operator of every eligible conv; for a training step
+    the adjoints `conv_bwd_data` launches), so that they are packed in ONE launch.  A job listed here and not used costs a few
+    microseconds; one not listed is packed on demand."""
+    jobs = []
+    for op in plan.ops:
+        if op["kind"] != "conv":
+            continue
+        s0, up0, s1 = op["src"]
+        w = params[2 * op["k"]]
+        cout, c0 = plan.ch[op["dst"]], plan.ch[s0]
+        c1 = plan.ch[s1] if s1 is not None else 0
+        if s0 < plan.n_inputs:
+            c0, c1 = sum(plan.ch[i] for i in range(plan.n_inputs)), 0 if plan.n_inputs == 1 else plan.ch[1]
+            c0 -= c1
+        D, H, W = _dims(shape3, plan.lvl[op["dst"]])
+        if cout > 4 and s3_route(c0, up0, c1, cout, B, D, H, W):
+            jobs.append((w, 0, c0 + c1, False, c0))
+        if not with_backward or (s0 < plan.n_inputs and not input_grads):
+            continue
+        ranges = [(c0, c1)] if (up0 and s1 is not None) else ([] if up0 else [(0, c0 + c1)])     # (first channel, count) handed to conv_bwd_data
+        for w_lo, cin in ranges:
+            bounds = _bwd_bounds(cin)
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                if s3_route(cout, False, 0, hi - lo, B, D, H, W):
+                    jobs.append((w, w_lo + lo, w_lo + hi, True, cout))
+    return jobs
+
+
 class UnetFn(torch.autograd.Function):
     """Whole U-Net (+ trailing convs) forward/backward on the HIP kernels: 12 MFMA conv launches,
     4 pool launches forward; backward = per conv one bwd-data launch (the forward kernel with the
@@ -504,6 +617,8 @@ class UnetFn(torch.autograd.Function):
         for i, t in T.items():
             if t.shape[1] != plan.ch[i] or t.shape[0] != B or tuple(t.shape[2:]) != shape3:
                 raise ValueError("Unet: input %d has shape %s, expected [%d,%d,%s]" % (i, tuple(t.shape), B, plan.ch[i], shape3))
+        if FP32_ENGINE == "split":
+            s3_prepack(_s3_jobs(plan, params, B, shape3, any(ctx.needs_input_grad[1:]), any(ctx.needs_input_grad[1:1 + plan.n_inputs])))
         for op in plan.ops:
             dst = op["dst"]
             D, H, W = _dims(shape3, plan.lvl[dst])
@@ -531,7 +646,8 @@ class UnetFn(torch.autograd.Function):
         ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B = plan, T, params, shape3, B
         # activations and parameters are held as plain attributes (the returned tensor alone goes through
         # save_for_backward, see above), so autograd's version-counter check is done by hand in backward
-        ctx.versions = [t._version for t in params] + [t._version for t in T.values()]
+        # (inference tensors -- torch.inference_mode() -- carry no version counter and can never reach backward)
+        ctx.versions = _versions(list(params) + list(T.values()))
         return out
 
     @staticmethod
@@ -541,7 +657,7 @@ class UnetFn(torch.autograd.Function):
             raise RuntimeError("UnetFn: backward a second time: the saved activations were released by the first pass "
                                "(a retained graph is not supported by the fused engine)")
         T = dict(ctx.T)
-        if [t._version for t in params] + [t._version for t in T.values()] != ctx.versions:
+        if _versions(list(params) + list(T.values())) != ctx.versions:
             raise RuntimeError("UnetFn: a parameter or a saved activation was modified in place between forward and "
                                "backward (e.g. an optimizer step before loss.backward()); gradients would be wrong")
         ctx.T = None                # released with this pass, not when the graph node dies

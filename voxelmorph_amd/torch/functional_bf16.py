@@ -36,6 +36,22 @@ def enabled():
     return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
 
+def _ver(t):
+    """Version counter of a parameter for the packed-weight cache and the hand-made in-place check.  Inference tensors (a model
+    built or loaded under torch.inference_mode()) have none: they cannot be modified in place by autograd-visible code either, so
+    the cache key is their storage address + a generation number bumped by `invalidate_packs`."""
+    if t.is_inference():
+        return ("inference", t.data_ptr(), t.__dict__.get("_vxm_pack_gen", 0))
+    return (t._version, t.__dict__.get("_vxm_pack_gen", 0))
+
+
+def invalidate_packs(params):
+    """Writers that change parameter VALUES without bumping the version counter (`.data` writes, collectives into the flat
+    buffer: FlatAdam.broadcast_params) call this so that the cached bf16 operators are re-packed."""
+    for p in params:
+        p.__dict__["_vxm_pack_gen"] = p.__dict__.get("_vxm_pack_gen", 0) + 1
+
+
 def _blocked(B, C, dims, dev):
     return torch.empty((B, C // 8) + tuple(dims) + (8,), dtype=torch.bfloat16, device=dev)
 
@@ -50,13 +66,13 @@ def pack_weights(w, ci_lo, ci_n, flip):
     cache = w.__dict__.setdefault("_vxm_bf16_packs", {})
     key = (ci_lo, ci_n, bool(flip))
     hit = cache.get(key)
-    if hit is not None and hit[0] == w._version and hit[1].device == w.device:
+    if hit is not None and hit[0] == _ver(w) and hit[1].device == w.device:
         return hit[1]
     cout, cin = w.shape[:2]
     inc, outc = (cout, ci_n) if flip else (ci_n, cout)
     wp = torch.empty(_lib.lib().vxm_bf16_conv_packed_bytes(inc, outc), dtype=torch.uint8, device=w.device)
     call("vxm_bf16_conv_pack_weights", ptr(_c(w)), cin, cout, ci_lo, ci_n, 1 if flip else 0, ptr(wp), stream())
-    cache[key] = (w._version, wp)
+    cache[key] = (_ver(w), wp)
     return wp
 
 
@@ -69,14 +85,14 @@ def prepack(jobs):
         cache = w.__dict__.setdefault("_vxm_bf16_packs", {})
         key = (ci_lo, ci_n, bool(flip))
         hit = cache.get(key)
-        if hit is not None and hit[0] == w._version and hit[1].device == w.device:
+        if hit is not None and hit[0] == _ver(w) and hit[1].device == w.device:
             continue
         cout, cin = w.shape[:2]
         inc, outc = (cout, ci_n) if flip else (ci_n, cout)
         nbytes = _lib.lib().vxm_bf16_conv_packed_bytes(inc, outc)
         wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else \
             torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-        stale.append((_c(w), cin, cout, ci_lo, ci_n, bool(flip), wp, cache, key, w._version))
+        stale.append((_c(w), cin, cout, ci_lo, ci_n, bool(flip), wp, cache, key, _ver(w)))
     if not stale:
         return
     table = (_lib.Bf16PackJob * len(stale))()
@@ -155,6 +171,13 @@ class UnetBf16Fn(torch.autograd.Function):
                 raise ValueError("Unet: input %d has shape %s, expected [%d,%d,%s]" % (i, tuple(t.shape), B, plan.ch[i], shape3))
         if len(inputs) > 2:
             raise NotImplementedError("bf16 engine: one or two input tensors")
+        if any(ctx.needs_input_grad[1:]):
+            # vxm_bf16_conv_bwd_weight holds the taps of at most 32 output channels in a wave's accumulators: refuse HERE, before
+            # any gradient sink of the optimiser has been claimed, not half-way through loss.backward()
+            wide = [c for (_, c, _) in plan.convs if c > 32]
+            if wide:
+                raise NotImplementedError("bf16 engine: training needs ConvBlocks of at most 32 output features (got %s); "
+                                          "run this network on the fp32 engine (no autocast)" % wide)
         V = shape3[0] * shape3[1] * shape3[2]
         cin0 = sum(plan.ch[i] for i in range(plan.n_inputs))
         xin = _blocked(B, _pad16(cin0), shape3, dev)             # virtual concat of the inputs, blocked, zero-padded to 16 channels
@@ -202,7 +225,7 @@ class UnetBf16Fn(torch.autograd.Function):
             out = torch.empty((B, plan.ch[plan.out], D, H, W), dtype=torch.float32, device=dev)
             call("vxm_bf16_from_blocked", ptr(T[plan.out]), plan.ch[plan.out], ptr(out), plan.ch[plan.out], B, D * H * W, stream())
         ctx.plan, ctx.T, ctx.xin, ctx.params, ctx.shape3, ctx.B, ctx.cin0 = plan, T, xin, params, shape3, B, cin0
-        ctx.versions = [t._version for t in params]
+        ctx.versions = [_ver(t) for t in params]
         return out
 
     @staticmethod
@@ -210,7 +233,7 @@ class UnetBf16Fn(torch.autograd.Function):
         plan, params, shape3, B, xin, cin0 = ctx.plan, ctx.params, ctx.shape3, ctx.B, ctx.xin, ctx.cin0
         if ctx.T is None:
             raise RuntimeError("UnetBf16Fn: backward a second time: the saved activations were released by the first pass")
-        if [t._version for t in params] != ctx.versions:
+        if [_ver(t) for t in params] != ctx.versions:
             raise RuntimeError("UnetBf16Fn: a parameter was modified in place between forward and backward "
                                "(e.g. an optimizer step before loss.backward()); gradients would be wrong")
         T, ctx.T, ctx.xin = ctx.T, None, None
