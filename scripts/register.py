@@ -24,14 +24,19 @@ def save_vol(arr, path):
         raise ValueError('unknown filetype for %s (npz / npy here; NIfTI needs nibabel)' % path)
 
 
-def nonpositive_jacobian_fraction(disp):
-    """disp [3, D, H, W] in voxels: det(I + grad disp) by central differences (py/utils.py:473-516), on the device."""
+def jacobian_determinant(disp):
+    """disp [3, D, H, W] in voxels -> det(I + grad disp) [D, H, W] with np.gradient's differences (central inside, one-sided at
+    the borders), the cofactor expansion of py/utils.py:473-516; runs where the tensor lives."""
     g = [torch.gradient(disp[a], dim=(0, 1, 2)) for a in range(3)]
     J = torch.stack([torch.stack(list(g[a]), 0) for a in range(3)], 0)          # [3(a), 3(axis), D, H, W]
-    J = J + torch.eye(3, device=disp.device)[:, :, None, None, None]
-    det = (J[0, 0] * (J[1, 1] * J[2, 2] - J[1, 2] * J[2, 1]) - J[0, 1] * (J[1, 0] * J[2, 2] - J[1, 2] * J[2, 0])
-           + J[0, 2] * (J[1, 0] * J[2, 1] - J[1, 1] * J[2, 0]))
-    return float((det <= 0).float().mean())
+    J = J + torch.eye(3, device=disp.device, dtype=disp.dtype)[:, :, None, None, None]
+    return (J[0, 0] * (J[1, 1] * J[2, 2] - J[1, 2] * J[2, 1]) - J[0, 1] * (J[1, 0] * J[2, 2] - J[1, 2] * J[2, 0])
+            + J[0, 2] * (J[1, 0] * J[2, 1] - J[1, 1] * J[2, 0]))
+
+
+def nonpositive_jacobian_fraction(disp):
+    """fraction of voxels where the deformation folds (det <= 0)"""
+    return float((jacobian_determinant(disp) <= 0).float().mean())
 
 
 def main(argv=None):

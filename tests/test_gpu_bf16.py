@@ -318,7 +318,7 @@ def test_batched_weight_packing_equals_per_operator_packing(vxm):
     VB.prepack(specs[:10])
     for (w, lo, n, flip), ref in zip(specs[:10], singles):
         ver, wp = w._vxm_bf16_packs[(lo, n, flip)]
-        assert ver == w._version and torch.equal(wp, ref) and VB.pack_weights(w, lo, n, flip) is wp
+        assert ver == VB._ver(w) and ver[0] == w._version and torch.equal(wp, ref) and VB.pack_weights(w, lo, n, flip) is wp
 
 
 def test_bare_unet_bf16_vs_emulated_oracle(vxm):

@@ -1178,6 +1178,37 @@ def test_atlas_and_semisupervised_loaders(vxm, tmp_path):
     assert a.shape == (2, 2) + shape and any(np.array_equal(N(a)[0], np.moveaxis(m, -1, 0).astype(np.float32)) for m in mc)
 
 
+def test_device_loaders_against_reference_generator_fixture(vxm, tmp_path):
+    """The device loaders against what the UNMODIFIED reference generators yield on the same inputs
+    (tests/golden/generators.npz, written by tests/golden/make_generators_golden.py from voxelmorph/generators.py:71-194; pinned to
+    the live reference by tests/test_cpu_contracts.py): same tuple structure, and every tensor equals the reference array after the
+    one documented transform -- `[B, *vol, C]` float64 -> `[B, C, *vol]` float32 (scripts/torch/train.py:199-201 does the same
+    cast + permute on the device every step)."""
+    from voxelmorph_amd import data as vdata
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "generators.npz"))
+    vol, seg, atlas_vol, atlas_seg, labels = g["vol"], g["seg"], g["atlas_vol"], g["atlas_seg"], g["labels"]
+    np.savez(tmp_path / "atlas.npz", vol=atlas_vol, seg=atlas_seg)
+    atlas = atlas_vol[np.newaxis, ..., np.newaxis]
+    runs = {
+        "s2s": vdata.scan_to_scan([vol], batch_size=2, device="cuda"),
+        "s2s_bidir": vdata.scan_to_scan([vol], bidir=True, batch_size=1, device="cuda"),
+        "s2s_nowarp": vdata.scan_to_scan([vol], no_warp=True, batch_size=1, device="cuda"),
+        "s2a": vdata.scan_to_atlas([vol], atlas, batch_size=2, device="cuda"),
+        "s2a_bidir": vdata.scan_to_atlas([vol], atlas, bidir=True, batch_size=1, device="cuda"),
+        "s2a_segs": vdata.scan_to_atlas([vol], atlas, batch_size=1, segs=[seg], device="cuda"),
+        "semi": vdata.semisupervised([vol], [seg], list(labels), device="cuda"),
+        "semi_atlas": vdata.semisupervised([vol], [seg], list(labels), atlas_file=str(tmp_path / "atlas.npz"), device="cuda"),
+    }
+    for tag, loader in runs.items():
+        invols, outvols = next(loader)
+        assert [len(invols), len(outvols)] == list(g[tag + "_n"]), tag
+        for kind, got in (("in", invols), ("out", outvols)):
+            for i, t in enumerate(got):
+                want = np.moveaxis(g["%s_%s%d" % (tag, kind, i)], -1, 1).astype(np.float32)
+                assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), (tag, kind, i)
+                assert tuple(t.shape) == want.shape and np.array_equal(N(t), want), (tag, kind, i)
+
+
 def test_train_cli_atlas_multichannel_and_semisupervised(vxm, tmp_path):
     """scripts/train.py --atlas / --multichannel / --gpu / --cudnn-nondet (scripts/torch/train.py:56,59,63,72) and
     scripts/train_semisupervised_seg.py (flags of scripts/tf/train_semisupervised_seg.py:41-79): a 2-epoch run each."""
