@@ -300,6 +300,15 @@ int vxm_conv3d_k3_s3_pack_weights_batch(const VxmS3PackJob* jobs, int n_jobs, vo
 int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
                          const void* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope,
                          const float* mask_src, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, void* stream);
+/* convolution_backward w.r.t. weight and bias (autograd twin of networks.py:299) of ONE full-resolution tensor x [B,C,D,H,W] on the
+ * same split arithmetic (contraction over voxels, K = 32 voxels of a W row per MFMA): gw[co][ci_off + ci][tap] for ci < C inside a
+ * [Cout][gw_cin][3][3][3] array (the channel sub-range a segment of a virtual concat owns), gb[Cout] (nullable).  C, Cout multiples
+ * of 16.  Deterministic (fixed-order partial sums in `work`).  _ok: 1 when the split kernel takes a launch of this shape. */
+int vxm_conv3d_k3_s3_bwd_weight_ok(int C, int Cout, int B, int D, int H, int W);
+size_t vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(int C, int Cout, int B, int D, int H, int W);
+int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw,
+                                int gw_cin, int ci_off, float* gb, void* work, size_t work_bytes, int B, int D, int H, int W,
+                                void* stream);
 
 #ifdef __cplusplus
 }

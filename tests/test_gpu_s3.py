@@ -136,6 +136,33 @@ def test_s3_scale_invariance_and_small_magnitudes(VF):
     assert bool((z == 0).all())
 
 
+@pytest.mark.parametrize("c,cout,vol,B", [(16, 16, (4, 8, 32), 2), (32, 16, (5, 7, 40), 2), (16, 32, (6, 4, 64), 1), (48, 32, (3, 9, 33), 2)])
+def test_s3_backward_weight_vs_fp64(VF, c, cout, vol, B):
+    """vxm_conv3d_k3_s3_bwd_weight directly: weight and bias gradient against fp64 autograd, partial tiles in every direction, a
+    destination that is a channel sub-range of a wider weight array (nothing else written), and bit-wise run-to-run determinism."""
+    D, H, W = vol
+    V = D * H * W
+    torch.manual_seed(300 + c + cout)
+    x = torch.randn(B, c, D, H, W, device="cuda")
+    dz = torch.randn(B, cout, D, H, W, device="cuda")
+    pad = 16
+    gw = torch.full((cout, c + pad, 3, 3, 3), 7.25, device="cuda")
+    gb = torch.empty(cout, device="cuda")
+    ws = VF._Workspace(x.device)
+    VF.s3_bwd_weight(ws, x, c, c * V, dz, cout, gw, c + pad, pad, gb, B, D, H, W)
+    assert bool((gw[:, :pad] == 7.25).all())
+    wr = torch.zeros(cout, c, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    br = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv3d(x.cpu().double(), wr, br, padding=1).backward(dz.cpu().double())
+    e_w, e_b = rel_l2(gw[:, pad:].cpu().numpy(), wr.grad.numpy()), rel_l2(gb.cpu().numpy(), br.grad.numpy())
+    print("s3 backward-weight (%d -> %d, %s, B=%d): rel-L2 vs fp64 gw %.2e gb %.2e" % (c, cout, "x".join(map(str, vol)), B, e_w, e_b))
+    assert e_w <= 3e-6 and e_b <= 3e-6, (e_w, e_b)          # fp32 accumulation over B V voxels (measured ~3e-7)
+    gw2 = torch.full_like(gw, 7.25)
+    gb2 = torch.empty_like(gb)
+    VF.s3_bwd_weight(ws, x, c, c * V, dz, cout, gw2, c + pad, pad, gb2, B, D, H, W)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+
+
 def _rerun(env_extra, select, files=("tests/test_gpu_s3.py",), timeout=900):
     env = dict(os.environ, **env_extra)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu"] + [os.path.join(ROOT, f) for f in files] + ["-k", select],

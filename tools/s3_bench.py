@@ -101,6 +101,34 @@ def main():
         print("%-28s %7.1f GFLOP | split %.3f ms = %6.1f TF-eq | fp32-MFMA %.3f ms = %6.1f TF | x%.2f | rel-L2(split, fp32) %.2e"
               % (name, gf, t_s3, gf / t_s3, t_nat, gf / t_nat, t_nat / t_s3, diff), flush=True)
         del x0, x1, y_s3, y_nat, mask
+    # backward-weight of the plain full-resolution tensors: split kernel vs the fp32-MFMA kernels
+    for name, c, cout, lvl in (("rem1 bwd-weight 32->16", 32, 16, 0), ("rem2 bwd-weight 16->16", 16, 16, 0), ("rem0-skip bwd-weight 16->32", 16, 32, 0),
+                               ("enc1 bwd-weight 16->32 (L1)", 16, 32, 1), ("dec3-skip bwd-weight 32->32 (L1)", 32, 32, 1)):
+        if args.only and args.only not in name:
+            continue
+        D, H, W = (s >> lvl for s in shape)
+        V = D * H * W
+        x = torch.randn(B, c, D, H, W, device="cuda")
+        dz = torch.randn(B, cout, D, H, W, device="cuda")
+        gw_s, gb_s = torch.empty(cout, c, 3, 3, 3, device="cuda"), torch.empty(cout, device="cuda")
+        gw_n, gb_n = torch.empty_like(gw_s), torch.empty_like(gb_s)
+        ws = VF._Workspace(x.device)
+        keep = VF.FP32_ENGINE
+
+        def run_s3():
+            VF.s3_bwd_weight(ws, x, c, c * V, dz, cout, gw_s, c, 0, gb_s, B, D, H, W)
+
+        def run_nat():
+            VF.FP32_ENGINE = "native"
+            VF.conv_bwd_weight(ws, x, c, c * V, False, None, 0, 0, dz, cout, gw_n, gb_n, B, D, H, W)
+            VF.FP32_ENGINE = keep
+        t_s3, t_nat = timed(run_s3, args.iters), timed(run_nat, args.iters)
+        gf = 2.0 * 27 * c * cout * B * V / 1e9
+        diff = float((gw_s.double() - gw_n.double()).norm() / gw_n.double().norm())
+        rows.append(dict(op=name, gflop=gf, s3_ms=t_s3, s3_tflops=gf / t_s3, native_ms=t_nat, native_tflops=gf / t_nat, rel_l2_s3_vs_native=diff))
+        print("%-34s %7.1f GFLOP | split %.3f ms = %6.1f TF-eq | fp32-MFMA %.3f ms = %6.1f TF | x%.2f | rel-L2(split, fp32) %.2e"
+              % (name, gf, t_s3, gf / t_s3, t_nat, gf / t_nat, t_nat / t_s3, diff), flush=True)
+        del x, dz
     if args.json:
         with open(args.json, "w") as f:
             json.dump(rows, f, indent=1)

@@ -102,6 +102,9 @@ SIGNATURES = {
     "vxm_conv3d_k3_s3_packed_bytes": [_I, _I, _I],
     "vxm_conv3d_k3_s3_pack_weights_batch": [_P, _I, _P],
     "vxm_conv3d_k3_s3_fwd": [_P, _I, _L, _I, _P, _I, _L, _P, _P, _P, _L, _I, _F, _P, _L, _F, _I, _I, _I, _I, _P],
+    "vxm_conv3d_k3_s3_bwd_weight_ok": [_I, _I, _I, _I, _I, _I],
+    "vxm_conv3d_k3_s3_bwd_weight_workspace_bytes": [_I, _I, _I, _I, _I, _I],
+    "vxm_conv3d_k3_s3_bwd_weight": [_P, _I, _L, _P, _L, _I, _P, _I, _I, _P, _P, _S, _I, _I, _I, _I, _P],
     "vxm_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
 }
 _RESTYPES = {
@@ -112,6 +115,7 @@ _RESTYPES = {
     "vxm_conv3d_k3_bwd_weight_workspace_bytes": _S,
     "vxm_bf16_conv_packed_bytes": _S,
     "vxm_conv3d_k3_s3_packed_bytes": _S,
+    "vxm_conv3d_k3_s3_bwd_weight_workspace_bytes": _S,
     "vxm_bf16_conv_bwd_weight_workspace_bytes": _S,
 }
 

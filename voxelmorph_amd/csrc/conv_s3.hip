@@ -316,6 +316,327 @@ __global__ void __launch_bounds__(256) k_s3_pack_weights(const S3PackBatch batch
     if (i < jb.words) s3_pack_word(jb, i);
 }
 
+// ------------------------------------------------------------------------------------------
+// backward-weight on the bf16 pipe: gW[co][ci][tap] = sum_v dZ[co][v] X[ci][v + tap - 1],  gb[co] = sum_v dZ[co][v]
+// ------------------------------------------------------------------------------------------
+// Replaces convolution_backward w.r.t. weight and bias (autograd twin of networks.py:299) for plain full-resolution tensors.
+// The contraction runs over VOXELS: M = 16 output channels (A = dZ^T), N = 16 input channels (B = X), K = 32 voxels of a W row,
+// so no K slot is ever padding.  Both operands are split into three bf16 pieces while they are staged from planar fp32 into
+// [voxel][16 channel] LDS tiles (32-byte rows), and read with the transposing LDS read of gfx950 (ds_read_b64_tr_b16: a lane
+// receives 4 consecutive voxels of one channel; lane pattern probed in tools/probe/tr16_probe.hip) -- the structure of
+// k_bf16_conv_bwd_weight (conv_bf16.hip), with six piece products per (A, B) fragment pair.
+// Block = 12 waves = (row half) x (depth slice of a 2 x 4 x 32 voxel tile) x (kd) for ONE 16-output-channel tile and ONE
+// 16-input-channel chunk; a wave keeps the 9 (kh, kw) taps of its kd in 36 accumulator VGPRs over ALL its tiles and slides over
+// the 4 haloed X rows of its two output rows (three kw-shifted B fragment sets per row serve kh = 0, 1, 2; the dZ fragment sets
+// of its two rows stay in registers).  (The first version had 6 waves, four rows each: 1.5 waves per SIMD, two SIMDs with twice
+// the work of the others -- matrix pipe 31 % busy, measured.)  One persistent block per CU walks down the depth of a (b, th, tw) column: consecutive tiles share two of their
+// four haloed X planes in a 6-slot LDS ring, the raw fp32 loads of tile t + 1 are in flight in registers under the MFMAs of tile
+// t.  LDS: 3 pieces x (6 planes x 6 x 34 voxels + 2 x 4 x 32 voxels) x 32 B = 142,080 B (three pieces leave no room for a second
+// dZ buffer: two barriers per tile).  Partials per block, summed in a fixed order by k_s3_reduce_partials (deterministic).
+constexpr int SW_WAVES = 12, SW_THREADS = 64 * SW_WAVES, SW_NSL = 4;     // waves = (row half, depth slice, kd); partial slices = (depth slice, row half)
+constexpr int SW_TD = 2, SW_TH = 4, SW_TW = 32, SW_XW = SW_TW + 2, SW_HR = SW_TH + 2, SW_RING = 6;
+constexpr int SW_PLANE = SW_HR * SW_XW * 32;                  // bytes of one haloed X plane of one piece: [hh][hw][16 ci]
+constexpr int SW_XPIECE = SW_RING * SW_PLANE;
+constexpr int SW_ZPIECE = SW_TD * SW_TH * SW_TW * 32;         // dZ tile of one piece: [ds][row][w][16 co]
+constexpr int SW_LDS_BYTES = 3 * (SW_XPIECE + SW_ZPIECE);
+
+__device__ __forceinline__ u32x2 s3_tr_read(const char* lds_base, int byte_off) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)(lds_base + byte_off));
+    return __builtin_bit_cast(u32x2, v);
+}
+
+struct SwTasks { int ncol, nseg, seg_len, nd, nh, nw; };       // tasks = (column (b, th, tw), depth segment), seg_len tiles each
+
+// x: [B][C][D][H][W] fp32 (batch stride x_bs), dz: [B][Cdz][D][H][W] fp32; grid = NBLK x NCOMBO, combo = (16-channel chunk q of x, 16-channel tile of dz)
+__global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __restrict__ x, long long x_bs, int C, const float* __restrict__ dz,
+                                                              long long dz_bs, int Cdz, float* __restrict__ part, int D, int H, int W, int NBLK,
+                                                              int NCO, SwTasks tk) {
+    VXM_DYN_SMEM(char, smem);
+    char* const Xs = smem;                                       // [3 pieces][6 ring planes][SW_PLANE]
+    char* const Zs = smem + 3 * SW_XPIECE;                       // [3 pieces][SW_ZPIECE]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rh = wave / 6, w6 = wave - 6 * rh, ds = w6 / 3, kd = w6 - 3 * ds;      // rows 2 rh, 2 rh + 1 of depth slice ds, taps kd
+    // block -> (task range bx, combo).  The combos of one bx read the same X / dZ tiles at the same pace: their workgroup ids are
+    // 8 apart so that they share one XCD's L2 (as k_bf16_conv_bwd_weight)
+    const int NCOMBO = gridDim.x / NBLK, xmain = NBLK & ~7;
+    int bx, combo;
+    if ((int)blockIdx.x < xmain * NCOMBO) {
+        const int j = blockIdx.x >> 3;
+        combo = j % NCOMBO;
+        bx = (j / NCOMBO) * 8 + (blockIdx.x & 7);
+    } else {
+        const int r = blockIdx.x - xmain * NCOMBO;
+        bx = xmain + r / NCOMBO;
+        combo = r % NCOMBO;
+    }
+    const int q = combo / NCO, cot = combo - q * NCO;
+    const int ntask = tk.ncol * tk.nseg;
+    const int k_lo = (int)((long long)ntask * bx / NBLK), k_hi = (int)((long long)ntask * (bx + 1) / NBLK);
+    const int V = D * H * W, HW = H * W;
+
+    f32x4 acc[3][3], accb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kh][kw] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lp = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;     // lane pattern of the transposing read
+    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};       // bf16 1.0 x 8: B operand of the bias sum
+
+    // staging roles of a thread, fixed for the kernel: slot i = tid + THREADS j = (voxel, 8-channel half) of one haloed X plane / of
+    // the dZ tile; a slot is 8 planar fp32 loads (one per channel), split into three 16-byte words
+    constexpr int NXP = SW_HR * SW_XW * 2, NXI = (NXP + SW_THREADS - 1) / SW_THREADS;
+    constexpr int NZ = SW_TD * SW_TH * SW_TW * 2, NZI = (NZ + SW_THREADS - 1) / SW_THREADS;
+    float xr[2][NXI][8], zr[NZI][8];
+    int xoff[NXI], zoff[NZI];                                    // byte offsets inside a depth slice of the tensor (VXM_OOB: padding)
+    int xv[2][NXI], zv[NZI];                                     // the offsets the in-flight loads were issued with (kept live, see keep_offsets)
+
+    for (int task = k_lo; task < k_hi; ++task) {
+        const int col = task / tk.nseg, seg = task - col * tk.nseg;
+        const int tw = col % tk.nw; int cq = col / tk.nw;
+        const int th = cq % tk.nh; const int b = cq / tk.nh;
+        const int td0 = seg * tk.seg_len, ntile = min(tk.seg_len, tk.nd - td0);
+        const int dbase = td0 * SW_TD, h0 = th * SW_TH, w0 = tw * SW_TW;
+        const __amdgpu_buffer_rsrc_t rx = vxm_rsrc(x + (size_t)b * x_bs, (unsigned)C * (unsigned)V * 4u);
+        const __amdgpu_buffer_rsrc_t rz = vxm_rsrc(dz + (size_t)b * dz_bs, (unsigned)Cdz * (unsigned)V * 4u);
+#pragma unroll
+        for (int j = 0; j < NXI; ++j) {
+            const int i = tid + SW_THREADS * j;
+            const int cb = i & 1, v = i >> 1, hh = v / SW_XW, hw = v - hh * SW_XW;
+            const int gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+            const bool ok = i < NXP && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && q * 16 + cb * 8 < C;
+            xoff[j] = !ok ? VXM_OOB : ((q * 16 + cb * 8) * V + gh * W + gw) << 2;
+        }
+#pragma unroll
+        for (int j = 0; j < NZI; ++j) {
+            const int i = tid + SW_THREADS * j;
+            const int cb = i & 1, v = i >> 1;
+            const int zd = v / (SW_TH * SW_TW), r2 = v - zd * SW_TH * SW_TW, zh = r2 / SW_TW, zw = r2 - zh * SW_TW;
+            const bool ok = i < NZ && h0 + zh < H && w0 + zw < W && cot * 16 + cb * 8 < Cdz;
+            // depth validity: the tile's second slice (zd = 1) may lie beyond D -- folded in per tile through `zlast`
+            zoff[j] = !ok ? VXM_OOB : ((((cot * 16 + cb * 8) * V + (zd * H + h0 + zh) * W + w0 + zw) << 2) | zd);      // bit 0: depth slice of the slot
+        }
+
+        // planes p0, p0 + 1 of this task (plane p = global depth dbase - 1 + p) -> registers / -> ring slots p % 6
+        auto load_planes = [&](int p0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const int gd = dbase - 1 + p0 + pl;                 // wave-uniform
+                const bool dok = (unsigned)gd < (unsigned)D;
+                const int soff = dok ? (gd * HW) << 2 : 0;
+                // branch-free: a plane outside the volume ORs the out-of-range bit into every lane offset.  (Written as a select on the
+                // wave-uniform `dok`, the compiler branches around the loads, and the joins behind those branches make it wait for
+                // the prefetch -- s_waitcnt vmcnt -- at the START of the MFMA phase: seen in the ISA.)
+                int bad = dok ? 0 : VXM_OOB;
+                asm volatile("" : "+v"(bad));
+#pragma unroll
+                for (int j = 0; j < NXI; ++j) {
+                    xv[pl][j] = xoff[j] | bad;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xr[pl][j][e] = vxm_bload(rx, xv[pl][j], soff + ((e * V) << 2));
+                }
+            }
+        };
+        auto store_planes = [&](int p0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                char* const dst = Xs + ((p0 + pl) % SW_RING) * SW_PLANE;
+#pragma unroll
+                for (int j = 0; j < NXI; ++j) {
+                    unsigned pk[3][4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s3_split2(xr[pl][j][2 * e], xr[pl][j][2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+                    if (tid + SW_THREADS * j < NXP) {
+#pragma unroll
+                        for (int p = 0; p < 3; ++p)
+                            *reinterpret_cast<u32x4*>(dst + p * SW_XPIECE + (tid + SW_THREADS * j) * 16) = (u32x4){pk[p][0], pk[p][1], pk[p][2], pk[p][3]};
+                    }
+                }
+            }
+        };
+        auto load_z = [&](int t) __attribute__((always_inline)) {
+            const int gd = dbase + t * SW_TD;                      // first depth slice of the tile (always < D)
+            int nolast = gd + 1 < D ? 0 : 1;                      // the tile's second depth slice lies beyond the volume
+            asm volatile("" : "+v"(nolast));
+            const int soff = (gd * HW) << 2;
+#pragma unroll
+            for (int j = 0; j < NZI; ++j) {
+                zv[j] = (zoff[j] & ~3) | ((zoff[j] & nolast) << 31);                // branch-free, as load_planes
+#pragma unroll
+                for (int e = 0; e < 8; ++e) zr[j][e] = vxm_bload(rz, zv[j], soff + ((e * V) << 2));
+            }
+        };
+        auto store_z = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NZI; ++j) {
+                unsigned pk[3][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s3_split2(zr[j][2 * e], zr[j][2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+                if (tid + SW_THREADS * j < NZ) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        *reinterpret_cast<u32x4*>(Zs + p * SW_ZPIECE + (tid + SW_THREADS * j) * 16) = (u32x4){pk[p][0], pk[p][1], pk[p][2], pk[p][3]};
+                }
+            }
+        };
+
+        __syncthreads();                                        // every wave is done with the previous task
+        load_planes(0);
+        load_z(0);
+        store_planes(0);
+        load_planes(2);
+        store_z();
+        store_planes(2);
+        __syncthreads();
+
+        for (int t = 0; t < ntile; ++t) {
+            const bool more = t + 1 < ntile;                     // wave-uniform
+            const char* const xp = Xs + ((2 * t + ds + kd) % SW_RING) * SW_PLANE;
+            // the raw loads of tile t + 1 (2 X planes + the dZ tile) are in flight under the MFMAs of tile t; unconditional: past
+            // the last tile the planes lie beyond this task's depth range and are simply not stored
+            load_planes(2 * t + 4);
+            load_z(more ? t + 1 : t);
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 az[2][3];                                      // dZ fragment sets (3 pieces) of this wave's two output rows
+#pragma unroll
+            for (int hl = 0; hl < 4; ++hl) {                     // haloed rows 2 rh + hl serve output rows 2 rh + hl - kh
+                const int hr = 2 * rh + hl;                      // wave-uniform
+                u32x4 bxf[3][3];                                 // [kw][piece]
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const int xb = p * SW_XPIECE + (hr * SW_XW + kw) * 32 + lp;
+                        const u32x2 lo = s3_tr_read(xp, xb), hi = s3_tr_read(xp, xb + 16 * 32);
+                        bxf[kw][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+                    }
+                if (hl < 2) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const int zb = p * SW_ZPIECE + ((ds * SW_TH + hr) * SW_TW) * 32 + lp;
+                        const u32x2 lo = s3_tr_read(Zs, zb), hi = s3_tr_read(Zs, zb + 16 * 32);
+                        az[hl][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+                    }
+                    if (kd == 0) {                               // wave-uniform: bias gradient = sum of the three pieces against ones
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) accb = s3_mfma(az[hl][p], ones, accb);
+                    }
+                }
+                constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};       // (m,m) (l,h) (h,l) (m,h) (h,m) (h,h)
+#pragma unroll
+                for (int tp = 0; tp < 6; ++tp)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const int rl = hl - kh;                  // local output row
+                        if (rl >= 0 && rl < 2) {
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw) acc[kh][kw] = s3_mfma(az[rl][PA[tp]], bxf[kw][PB[tp]], acc[kh][kw]);
+                        }
+                    }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the address registers of the loads in flight stay live until here: reused earlier, the compiler guards every reuse
+            // with s_waitcnt vmcnt(..), i.e. waits for the prefetch at the start of the MFMA phase (seen in the ISA)
+#pragma unroll
+            for (int j = 0; j < NXI; ++j) asm volatile("" ::"v"(xv[0][j]), "v"(xv[1][j]));
+#pragma unroll
+            for (int j = 0; j < NZI; ++j) asm volatile("" ::"v"(zv[j]));
+            __syncthreads();                                     // every wave is done reading tile t (X ring slots of t - 1 and the dZ tile are free)
+            if (more) {
+                store_planes(2 * t + 4);
+                store_z();
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- partials: part[bx][q][slice = 2 ds + rh][tap 0..27][co 16 NCO][ci 16]; D layout: lane (kg, n) holds co = 4 kg + r, ci = n
+    const int Q = NCOMBO / NCO;
+    float* const pp = part + ((((size_t)bx * Q + q) * SW_NSL + 2 * ds + rh) * 28) * (16 * NCO) * 16;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                pp[((size_t)(kd * 9 + kh * 3 + kw) * (16 * NCO) + cot * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[kh][kw][r];
+    if (kd == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pp[((size_t)27 * (16 * NCO) + cot * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = accb[r];
+    }
+}
+
+// gw[co][ci_off + ci][tap] (row length gw_cin) = sum over the (block, depth slice) partials in a fixed order; gb[co] from tap slot 27
+// of chunk 0 (every chunk carries the same bias sum).  Block = 64 consecutive outputs x 16 slices, 8 loads in flight per thread,
+// slices combined through LDS in a fixed tree (deterministic) -- the reducer of conv_bf16.hip with a channel sub-range destination.
+__global__ void __launch_bounds__(1024) k_s3_reduce_partials(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb, int C,
+                                                             int Cout, int gw_cin, int ci_off, int Q, int NCO, int NBLK) {
+    __shared__ float sm[16][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const int CoP = 16 * NCO, per_q = 28 * CoP * 16, n = Q * per_q;
+    const int e = blockIdx.x * 64 + x;
+    float tot = 0.0f;
+    if (e < n) {
+        const int q = e / per_q, r = e - q * per_q;
+        const size_t stride_blk = (size_t)Q * SW_NSL * per_q;
+        const float* p = part + (size_t)q * SW_NSL * per_q + r;      // + blk * stride_blk + slice * per_q
+        const int K = SW_NSL * NBLK;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = y;
+        for (; k + 16 * 7 < K; k += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int kk = k + 16 * u;
+                s[u] += p[(size_t)(kk / SW_NSL) * stride_blk + (size_t)(kk % SW_NSL) * per_q];
+            }
+        }
+        for (; k < K; k += 16) s[0] += p[(size_t)(k / SW_NSL) * stride_blk + (size_t)(k % SW_NSL) * per_q];
+        tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    }
+    sm[y][x] = tot;
+    __syncthreads();
+    if (y == 0 && e < n) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = sm[u][x];
+        const float sum = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                          (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+        const int q = e / per_q, r = e - q * per_q;
+        const int tap = r / (CoP * 16), co = (r / 16) % CoP, ci = q * 16 + (r & 15);
+        if (tap < 27) {
+            if (co < Cout && ci < C) gw[((size_t)co * gw_cin + ci_off + ci) * 27 + tap] = sum;
+        } else if (gb != nullptr && q == 0 && (r & 15) == 0 && co < Cout) {
+            gb[co] = sum;
+        }
+    }
+}
+
+int sw_cus() {
+    static const int cus = [] {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+        return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }();
+    return cus;
+}
+// one persistent block per CU over all combos; columns are cut into depth segments until there are ~4 tasks per block
+SwTasks sw_tasks(int ncombo, int B, int D, int H, int W, int& NBLK) {
+    SwTasks tk;
+    tk.nd = (D + SW_TD - 1) / SW_TD; tk.nh = (H + SW_TH - 1) / SW_TH; tk.nw = (W + SW_TW - 1) / SW_TW;
+    tk.ncol = B * tk.nh * tk.nw;
+    const int nb = sw_cus() / ncombo > 0 ? sw_cus() / ncombo : 1;
+    int nseg = (4 * nb + tk.ncol - 1) / tk.ncol;
+    if (nseg > tk.nd) nseg = tk.nd;
+    if (nseg < 1) nseg = 1;
+    tk.seg_len = (tk.nd + nseg - 1) / nseg;
+    tk.nseg = (tk.nd + tk.seg_len - 1) / tk.seg_len;
+    const long long ntask = (long long)tk.ncol * tk.nseg;
+    NBLK = (int)(nb < ntask ? nb : ntask);
+    return tk;
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------
 // Kernel instance of an operator with OutC output channels.  VXM_S3_CB=2 stages 16-channel chunks (5 K-steps, 90 % of the K slots
 // used, one block per CU) instead of 8-channel ones (3 K-steps, 75 %, two blocks per CU); VXM_S3_NCT=1 runs 32-channel operators as
@@ -346,6 +667,11 @@ void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, lo
     using C = S3Cfg<NCT, ROWS, CB>;
     static const bool attr = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_conv<NCT, ROWS, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (getenv("VXM_S3_DEBUG")) {             // developer switch: what the runtime says about co-residency
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_s3_conv<NCT, ROWS, CB>, S3_THREADS, C::LDS_BYTES);
+            fprintf(stderr, "k_s3_conv<%d,%d,%d>: %d bytes of LDS, %d block(s) per CU\n", NCT, ROWS, CB, C::LDS_BYTES, nb);
+        }
         return true;
     }();
     (void)attr;
@@ -425,6 +751,50 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
     else if (v.CB == 2) s3_launch<1, 4, 2>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
     else s3_launch<1, 4, 1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
     return vxm_check_launch("vxm_conv3d_k3_s3_fwd");
+}
+
+int vxm_conv3d_k3_s3_bwd_weight_ok(int C, int Cout, int B, int D, int H, int W) {
+    if (C <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (C % 16 || Cout % 16 || Cout < 16) return 0;
+    if ((C / 16) * (Cout / 16) > sw_cus()) return 0;
+    if ((long long)(C > Cout ? C : Cout) * D * H * W >= (1ll << 29)) return 0;
+    const long long ntiles = (long long)B * ((D + S3_TD - 1) / S3_TD) * ((H + 3) / 4) * ((W + 15) / 16);
+    return ntiles >= s3_min_tiles() ? 1 : 0;
+}
+
+size_t vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(int C, int Cout, int B, int D, int H, int W) {
+    if (C <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const int Q = (C + 15) / 16, NCO = (Cout + 15) / 16;
+    int NBLK = 1;
+    (void)sw_tasks(Q * NCO, B, D, H, W, NBLK);
+    return (size_t)NBLK * Q * SW_NSL * 28 * (16 * NCO) * 16 * sizeof(float);
+}
+
+int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw, int gw_cin,
+                                int ci_off, float* gb, void* work, size_t work_bytes, int B, int D, int H, int W, void* stream) {
+    VXM_REQUIRE(x && dz && gw && work, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3_bwd_weight: null pointer");
+    if (int e = check_conv("vxm_conv3d_k3_s3_bwd_weight", C, 0, 0, Cout, B, D, H, W)) return e;
+    VXM_REQUIRE(C % 16 == 0 && Cout % 16 == 0 && ci_off >= 0 && ci_off + C <= gw_cin, VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3_bwd_weight: %d input / %d output channels (multiples of 16), destination channels [%d, %d) of %d", C, Cout, ci_off,
+                ci_off + C, gw_cin);
+    const int Q = C / 16, NCO = Cout / 16;
+    VXM_REQUIRE(Q * NCO <= sw_cus(), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_bwd_weight: %d x %d channel tiles exceed the compute units", Q, NCO);
+    int NBLK = 1;
+    const SwTasks tk = sw_tasks(Q * NCO, B, D, H, W, NBLK);
+    VXM_REQUIRE(work_bytes >= (size_t)NBLK * Q * SW_NSL * 28 * (16 * NCO) * 16 * sizeof(float), VXM_ERR_WORKSPACE,
+                "vxm_conv3d_k3_s3_bwd_weight: workspace too small");
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS_BYTES);
+        return true;
+    }();
+    (void)attr;
+    hipStream_t s = VXM_STREAM(stream);
+    float* part = static_cast<float*>(work);
+    hipLaunchKernelGGL(k_s3_bwd_weight, dim3(NBLK * Q * NCO), dim3(SW_THREADS), SW_LDS_BYTES, s, x, (long long)x_bstride, C, dz, (long long)dz_bstride,
+                       Cout, part, D, H, W, NBLK, NCO, tk);
+    const int n = 16 * NCO * 16 * Q * 28;
+    hipLaunchKernelGGL(k_s3_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(1024), 0, s, part, gw, gb, C, Cout, gw_cin, ci_off, Q, NCO, NBLK);
+    return vxm_check_launch("vxm_conv3d_k3_s3_bwd_weight");
 }
 
 }  // extern "C"

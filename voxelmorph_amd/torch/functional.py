@@ -410,7 +410,19 @@ class _Workspace:
         return self.buf
 
 
+def s3_bwd_weight(ws, x, c, bs, dz, cout, gw, gw_cin, ci_off, gb, B, D, H, W):
+    """weight / bias gradient of one full-resolution tensor on the split kernel (vxm_conv3d_k3_s3_bwd_weight)"""
+    need = _lib.lib().vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(c, cout, B, D, H, W)
+    buf = ws.get(need)
+    with _prof.region("k_s3_bwd_weight", flops=2.0 * 27 * c * cout * B * D * H * W):
+        call("vxm_conv3d_k3_s3_bwd_weight", ptr(x), c, bs, ptr(dz), cout * D * H * W, cout, ptr(gw), gw_cin, ci_off, ptr(gb), ptr(buf), buf.numel(),
+             B, D, H, W, stream())
+
+
 def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H, W):
+    if FP32_ENGINE == "split" and not up0 and x1 is None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c0, cout, B, D, H, W):
+        s3_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, c0, 0, gb, B, D, H, W)
+        return
     need = _lib.lib().vxm_conv3d_k3_bwd_weight_workspace_bytes(c0 + c1, cout, B, D, H, W)
     buf = ws.get(need)
     name, nominal = None, 2.0 * 27 * (c0 + c1) * cout * B * D * H * W
