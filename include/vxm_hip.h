@@ -128,6 +128,12 @@ int vxm_conv3d_k3_fwd_variant(const float* x0, int C0, int64_t x0_bstride, const
  * upsampled segment (k_conv3d_k3_bwd_weight_up) + ..._vec on the skip segment. */
 int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1,
                                      int64_t x1_bstride, const float* dz, int64_t dz_bstride, int Cout, int D, int H, int W);
+/* Only the UPSAMPLED segment's share of that gradient, gw[:, 0:C0, :] inside the [Cout][C0+C1][27] array (collapsed low-resolution
+ * product), when vxm_conv3d_k3_bwd_weight_variant(...) / 10 == 2; the caller computes the skip segment's share and the bias gradient
+ * itself (vxm_conv3d_k3_s3_bwd_weight with ci_off = C0).  x1 is only inspected for alignment. */
+int vxm_conv3d_k3_bwd_weight_up_segment(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
+                                        const float* dz, int64_t dz_bstride, int Cout, float* gw, void* workspace,
+                                        size_t workspace_bytes, int B, int D, int H, int W, void* stream);
 /* convolution_backward w.r.t. weight and bias: gw [Cout,C0+C1,3,3,3], gb [Cout] (nullable).
  * dz [B,Cout,D,H,W] is the gradient w.r.t. the conv output *before* the activation. */
 size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D, int H, int W);

@@ -228,12 +228,50 @@ def conv_bf16(x, w, b, slope=0.2, round_out=True):
     return _RoundFwd.apply(a) if round_out else a
 
 
+# Conditioning probe (tests only): the network is piecewise linear; a pre-activation within rounding of zero, or two entries of a
+# pooling window within rounding of each other, makes LeakyReLU' / the arg-max -- and with them every upstream gradient -- depend on
+# the LAST BITS of the forward pass.  No two fp32 evaluations (different summation orders) agree on such a sample, so a parity test
+# has to know when it is looking at one.  `with conditioning() as m:` records, over every ConvBlock / pooling of a forward pass,
+# the smallest |pre-activation| and the smallest top-2 gap of a pooling window, each relative to the rms of its tensor.
+_MARGIN = [None]
+
+
+class conditioning:
+    def __enter__(self):
+        self.margins = {"lrelu": float("inf"), "pool": float("inf")}
+        _MARGIN[0] = self.margins
+        return self.margins
+
+    def __exit__(self, *exc):
+        _MARGIN[0] = None
+        return False
+
+
+def _note_margin(kind, values, ref):
+    if _MARGIN[0] is not None:
+        rms = float(ref.detach().double().pow(2).mean().sqrt())
+        _MARGIN[0][kind] = min(_MARGIN[0][kind], float(values.detach().double().abs().min()) / max(rms, 1e-30))
+
+
 def conv_block(x, w, b, slope=0.2):
     """`ConvBlock.forward` networks.py:302-305 (k3, stride 1, pad 1, LeakyReLU 0.2)."""
     if _BF16[0]:
         return conv_bf16(x, w, b, slope)
     conv = getattr(F, "conv%dd" % (x.dim() - 2))
-    return F.leaky_relu(conv(x, w, b, stride=1, padding=1), slope)
+    z = conv(x, w, b, stride=1, padding=1)
+    _note_margin("lrelu", z, z)
+    return F.leaky_relu(z, slope)
+
+
+def _pool_margin(x, nd):
+    if _MARGIN[0] is None:
+        return
+    xd = x.detach()
+    for a in range(nd):                      # windows as a trailing axis of 2^nd entries
+        xd = xd.unflatten(2 + a + a, (xd.shape[2 + a + a] // 2, 2))
+    win = xd.permute([0, 1] + [2 + 2 * a for a in range(nd)] + [3 + 2 * a for a in range(nd)]).flatten(2 + nd)
+    top = win.topk(2, dim=-1).values
+    _note_margin("pool", top[..., 0] - top[..., 1], x)
 
 
 def unet_forward(x, sd, prefix="unet_model.", nb_features=None, nb_levels=None, feat_mult=1,
@@ -248,6 +286,7 @@ def unet_forward(x, sd, prefix="unet_model.", nb_features=None, nb_levels=None, 
             k = "%sencoder.%d.%d.main." % (prefix, lvl, c)
             x = conv_block(x, sd[k + "weight"], sd[k + "bias"])
         hist.append(x)
+        _pool_margin(x, nd)
         x = pool(x, 2)
     for lvl in range(levels - 1):                                      # :133-138
         for c in range(nb_conv_per_level):

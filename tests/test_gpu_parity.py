@@ -400,28 +400,40 @@ def test_maxpool_ties_first_index(vxm):
                                 dict(half_res=True), dict(nb_features=[[8, 8], [8, 8]])])
 def test_unet_vs_oracle(vxm, kw):
     inshape = (16, 16, 32)
-    # seeded weights: with unseeded ones the test is flaky by construction -- now and then a pre-activation lands within
-    # fp32 rounding of 0, LeakyReLU' differs between the fp32 path and the fp64 oracle at that voxel, and at the deepest
-    # levels (a few hundred activations) one such flip moves a parameter gradient by more than the tolerance
-    torch.manual_seed(20240607)
-    net = vxm.networks.Unet(inshape, infeats=2, **kw).cuda()
-    sd = {("unet_model." + k): v for k, v in net.state_dict().items()}
-    rng = np.random.default_rng(4)
-    x = rng.standard_normal((2, 2) + inshape).astype(np.float32)
-    xg = G(x, True)
-    y = net(xg)
-    sdo = {k: v.detach().cpu().double().requires_grad_() for k, v in sd.items()}
-    xo = torch.from_numpy(x).double().requires_grad_()
-    okw = {k: v for k, v in kw.items()}
-    yo = orc.unet_forward(xo, sdo, **okw)
-    assert y.shape == yo.shape and y.shape[1] == net.final_nf
-    assert rel_l2(N(y), yo.detach().numpy()) < 1e-5
-    gy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
-    y.backward(G(gy))
-    yo.backward(torch.from_numpy(gy).double())
-    for name, p in net.named_parameters():
-        assert rel_l2(N(p.grad), sdo["unet_model." + name].grad.numpy()) < 1e-4, name
-    assert rel_l2(N(xg.grad), xo.grad.numpy()) < 1e-4
+    # Seeded weights, and a conditioning check: the network is piecewise linear, so when a pre-activation lands within fp32 rounding
+    # of 0 (or two entries of a pooling window within rounding of each other) LeakyReLU' / the arg-max differ between ANY two
+    # evaluations with different summation orders -- the fp32 path and the fp64 oracle, or the fp32-MFMA and the split kernels -- and
+    # at the deepest levels (a few hundred activations) one such flip moves a gradient by more than the tolerance.  A seed whose
+    # smallest margin (oracle.conditioning) is inside that rounding is not a parity sample; the next seed is taken instead, and at
+    # least one well-conditioned seed must exist and pass.
+    checked = 0
+    for seed in (20240607, 20240608, 20240609, 20240610):
+        torch.manual_seed(seed)
+        net = vxm.networks.Unet(inshape, infeats=2, **kw).cuda()
+        sd = {("unet_model." + k): v for k, v in net.state_dict().items()}
+        rng = np.random.default_rng(4)
+        x = rng.standard_normal((2, 2) + inshape).astype(np.float32)
+        sdo = {k: v.detach().cpu().double().requires_grad_() for k, v in sd.items()}
+        xo = torch.from_numpy(x).double().requires_grad_()
+        okw = {k: v for k, v in kw.items()}
+        with orc.conditioning() as margins:
+            yo = orc.unet_forward(xo, sdo, **okw)
+        if min(margins.values()) < 1e-6:          # fp32 conv outputs differ from fp64 by 1e-7 .. 3e-7 of their rms (measured, both engines)
+            print("seed %d: smallest margins %s -- inside fp32 rounding, not a parity sample" % (seed, margins))
+            continue
+        checked += 1
+        xg = G(x, True)
+        y = net(xg)
+        assert y.shape == yo.shape and y.shape[1] == net.final_nf
+        assert rel_l2(N(y), yo.detach().numpy()) < 1e-5
+        gy = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+        y.backward(G(gy))
+        yo.backward(torch.from_numpy(gy).double())
+        for name, p in net.named_parameters():
+            assert rel_l2(N(p.grad), sdo["unet_model." + name].grad.numpy()) < 1e-4, (seed, name)
+        assert rel_l2(N(xg.grad), xo.grad.numpy()) < 1e-4, seed
+        break
+    assert checked >= 1, "no well-conditioned seed among the four"
 
 
 @pytest.mark.parametrize("src_feats,trg_feats", [(2, 1), (1, 3)])

@@ -56,6 +56,7 @@ SIGNATURES = {
     "vxm_conv3d_k3_bwd_weight_variant": [_P, _I, _L, _I, _P, _I, _L, _P, _L, _I, _I, _I, _I],
     "vxm_conv3d_k3_bwd_weight_workspace_bytes": [_I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_bwd_weight": [_P, _I, _L, _I, _P, _I, _L, _P, _L, _I, _P, _P, _P, _S, _I, _I, _I, _I, _P],
+    "vxm_conv3d_k3_bwd_weight_up_segment": [_P, _I, _L, _P, _I, _L, _P, _L, _I, _P, _P, _S, _I, _I, _I, _I, _P],
     "vxm_lrelu_bwd": [_P, _L, _P, _L, _P, _L, _F, _I, _I, _L, _P],
     "vxm_maxpool2_fwd": [_P, _L, _P, _I, _I, _I, _I, _I, _P],
     "vxm_maxpool2_bwd": [_P, _L, _P, _P, _L, _P, _F, _I, _I, _I, _I, _I, _P],

@@ -787,9 +787,9 @@ size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D,
     return 256 + need;
 }
 
-int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
-                             const float* dz, int64_t dz_bstride, int Cout, float* gw, float* gb, void* workspace,
-                             size_t workspace_bytes, int B, int D, int H, int W, void* stream) {
+static int bwd_weight_impl(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
+                           const float* dz, int64_t dz_bstride, int Cout, float* gw, float* gb, void* workspace,
+                           size_t workspace_bytes, int B, int D, int H, int W, void* stream, bool seg0_only) {
     if (int e = check_conv("vxm_conv3d_k3_bwd_weight", C0, C1, x0_up, Cout, B, D, H, W)) return e;
     VXM_REQUIRE(x0 && dz && gw && workspace && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_bwd_weight: null pointer");
     const int Cin = C0 + C1;
@@ -830,6 +830,7 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
         hipLaunchKernelGGL(k_reduce_partials_up_sum, dim3(vxm_blocks((long long)Cout * C0 * 64, 64)), dim3(256), 0, VXM_STREAM(stream), part, red, C0, Cout,
                            u.T, u.Qc, u.G, 16 * u.NCT);
         hipLaunchKernelGGL(k_reduce_partials_up_map, dim3(vxm_blocks((long long)Cout * C0 * 27, 256)), dim3(256), 0, VXM_STREAM(stream), red, gw, C0, Cout, Cin);
+        if (seg0_only) return vxm_check_launch("vxm_conv3d_k3_bwd_weight_up_segment");      // the caller owns the skip segment and the bias
         if (C1 > 0) {
             const BwPlan s1 = bw_plan(C1, Cout, B, D, H, W);
             ConvIn sin{x1, nullptr, (long long)x1_bstride, 0, C1, 0, 0};
@@ -880,6 +881,23 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
     hipLaunchKernelGGL(k_reduce_partials, dim3(vxm_blocks(n + (gb ? Cout : 0), 64)), dim3(1024), 0, VXM_STREAM(stream), part, gw, gb, n, Cin, Cout,
                        p.T, p.Qc, p.G, 16 * p.NCT, 0, Cin, 0);
     return vxm_check_launch("vxm_conv3d_k3_bwd_weight");
+}
+
+int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
+                             const float* dz, int64_t dz_bstride, int Cout, float* gw, float* gb, void* workspace,
+                             size_t workspace_bytes, int B, int D, int H, int W, void* stream) {
+    return bwd_weight_impl(x0, C0, x0_bstride, x0_up, x1, C1, x1_bstride, dz, dz_bstride, Cout, gw, gb, workspace, workspace_bytes, B, D, H, W, stream,
+                           false);
+}
+
+int vxm_conv3d_k3_bwd_weight_up_segment(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* dz,
+                                        int64_t dz_bstride, int Cout, float* gw, void* workspace, size_t workspace_bytes, int B, int D, int H,
+                                        int W, void* stream) {
+    VXM_REQUIRE(vxm_conv3d_k3_bwd_weight_variant(x0, C0, x0_bstride, 1, x1, C1, x1_bstride, dz, dz_bstride, Cout, D, H, W) / 10 == 2 &&
+                    (long long)C0 * (D / 2) * (H / 2) * (W / 2) < (1ll << 29),
+                VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_bwd_weight_up_segment: operands do not qualify for the collapsed kernel (use vxm_conv3d_k3_bwd_weight)");
+    return bwd_weight_impl(x0, C0, x0_bstride, 1, x1, C1, x1_bstride, dz, dz_bstride, Cout, gw, nullptr, workspace, workspace_bytes, B, D, H, W, stream,
+                           true);
 }
 
 }  // extern "C"

@@ -192,14 +192,25 @@ __device__ __forceinline__ void vg_axis(float xp, int p, int S, float& fr, int& 
     (void)S;
 }
 
-// One thread per voxel of the 4 x 8 x 32 tile (1024-thread blocks: 16-32 waves per CU hide the latency chain load -> corners ->
-// 24 gathers -> 54 LDS reads that a 4-voxel-per-thread loop exposed); the staged record is two 16-byte words per voxel,
-// {fr_z, fr_y, fr_x, code} and {g_0, g_1, g_2, -}, so a candidate costs 2 ds_read_b128 (conflict-free: consecutive lanes read
-// consecutive words) instead of 7 ds_read_b32.
+// One thread per voxel of the 4 x 8 x 32 tile (1024-thread blocks, two per CU: 32 waves hide the latency chain load -> corners ->
+// 24 gathers -> LDS reads that a 4-voxel-per-thread loop exposed).  The staged record of a sender is SIX floats: per axis one
+// value E_a = fr_a with the floor code in its SIGN BIT (negative: floor(x'_a) = p_a - 1; -0.0 is a valid value), and its gradient
+// with the "near" test folded in (a sender that is not near stages g = 0: its scatter belongs to the atomic pass) -- 24 bytes per
+// voxel (one ds_read_b128 + one ds_read_b64 per candidate, 49 KB of LDS per block).  The sender's weight towards the target at
+// offset o is rebuilt per candidate from E_a with the offset known at compile time: o = +1: floor code 1 ? 1 - fr : 0;  o = 0:
+// code ? fr : 1 - fr;  o = -1: code ? 0 : fr  (~10 vector instructions per candidate; the first gather unpacked a code word and
+// compared it against every offset, ~24 per candidate, and a version with all nine weights precomputed in 48-byte records needed
+// 96 KB of LDS, one block per CU, and was SLOWER, 39 vs 30 us per step: the step is bound by latency, i.e. by resident waves).
+typedef float vg_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float vg_weight(float e, int o) {
+    const bool r = (__float_as_uint(e) >> 31) != 0u;              // floor code: 1 <=> floor(x') = p - 1
+    const float a = fabsf(e);
+    return o > 0 ? (r ? 1.0f - a : 0.0f) : (o == 0 ? (r ? a : 1.0f - a) : (r ? 0.0f : a));
+}
 __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __restrict__ in, float scale, const float* __restrict__ gout,
                                                                  float* __restrict__ gin, unsigned* __restrict__ far_count, int D, int H, int W) {
-    __shared__ f32x4 recF[VG_LN];
-    __shared__ f32x4 recG[VG_LN];
+    __shared__ f32x4 recA[VG_LN];                                 // {E_z, E_y, E_x, g_0 (0 when not near)}
+    __shared__ vg_f32x2 recB[VG_LN];                                 // {g_1, g_2}
     const int tid = threadIdx.x, tx = tid & 31, ty = (tid >> 5) & 7, dd = tid >> 8;
     const int ntw = (W + VG_TW - 1) / VG_TW, nth = (H + VG_TH - 1) / VG_TH;
     int t = blockIdx.x;
@@ -220,25 +231,25 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __
         if (i < VG_LN) {
             const int lx = i % VG_LW, r = i / VG_LW, ly = r % VG_LH, lz = r / VG_LH;
             const int pz = d0 - 1 + lz, py = h0 - 1 + ly, px = w0 - 1 + lx;
-            int c = 0;
-            float fz = 0.f, fy = 0.f, fx = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            float ez = 0.f, ey = 0.f, ex = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
             if ((unsigned)pz < (unsigned)D && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
                 const int p4 = (pz * HW + py * W + px) << 2;
                 const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
-                g0 = vxm_bload(rgo, p4, 0); g1 = vxm_bload(rgo, p4, V4); g2 = vxm_bload(rgo, p4, 2 * V4);
+                float fz, fy, fx;
                 int rz, ry, rx;
                 bool nz, ny, nx;
                 vg_axis(vxm_src_coord(pz, v0, D), pz, D, fz, rz, nz);
                 vg_axis(vxm_src_coord(py, v1, H), py, H, fy, ry, ny);
                 vg_axis(vxm_src_coord(px, v2, W), px, W, fx, rx, nx);
                 if (nz && ny && nx) {
-                    c = 8 | (rz << 2) | (ry << 1) | rx;
+                    g0 = vxm_bload(rgo, p4, 0); g1 = vxm_bload(rgo, p4, V4); g2 = vxm_bload(rgo, p4, 2 * V4);
+                    ez = rz ? -fz : fz; ey = ry ? -fy : fy; ex = rx ? -fx : fx;          // fr >= 0: the sign bit is free (-0.0 when fr == 0)
                 } else if (lz >= 1 && lz <= VG_TD && ly >= 1 && ly <= VG_TH && lx >= 1 && lx <= VG_TW) {
                     ++nfar;                               // counted once, by the tile that owns the voxel
                 }
             }
-            recF[i] = (f32x4){fz, fy, fx, __int_as_float(c)};
-            recG[i] = (f32x4){g0, g1, g2, 0.0f};
+            recA[i] = (f32x4){ez, ey, ex, g0};
+            recB[i] = (vg_f32x2){g1, g2};
         }
     }
     if (nfar) atomicAdd(far_count, nfar);
@@ -248,9 +259,8 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __
     const int p4 = (d * HW + h * W + w) << 2;
     // ---- local part: identity + derivative through the sampling position (the 8 corners of x'(q) gathered from v itself)
     const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
+    const float g0 = vxm_bload(rgo, p4, 0), g1 = vxm_bload(rgo, p4, V4), g2 = vxm_bload(rgo, p4, 2 * V4);     // the voxel's own upstream gradient
     const int lq = ((dd + 1) * VG_LH + ty + 1) * VG_LW + tx + 1;
-    const f32x4 gq = recG[lq];
-    const float g0 = gq.x, g1 = gq.y, g2 = gq.z;                    // the voxel's own upstream gradient (staged for every in-volume voxel)
     const Corners8 cn = corners8(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W);
     float gz = g0, gy = g1, gx = g2;
 #pragma unroll
@@ -262,7 +272,7 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __
         gy += (dy ? sk : -sk) * (cn.wz[dz] * cn.wx[dx]);
         gx += (dx ? sk : -sk) * (cn.wz[dz] * cn.wy[dy]);
     }
-    // ---- gathered part: the 27 possible senders
+    // ---- gathered part: the 27 possible senders, fixed order (deterministic)
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
 #pragma unroll
     for (int oz = -1; oz <= 1; ++oz)
@@ -271,15 +281,11 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __
 #pragma unroll
             for (int ox = -1; ox <= 1; ++ox) {
                 const int i = lq + (oz * VG_LH + oy) * VG_LW + ox;
-                const f32x4 rf = recF[i], rg = recG[i];
-                const int c = __float_as_int(rf.w);
-                // axis a: sender p = q + o, floor(x') = p - frel; q is corner 0 if -o == -frel, corner 1 if -o == 1 - frel
-                const int rz = (c >> 2) & 1, ry = (c >> 1) & 1, rx = c & 1;
-                const float wz = (oz == rz) ? 1.0f - rf.x : ((oz == rz - 1) ? rf.x : 0.0f);
-                const float wy = (oy == ry) ? 1.0f - rf.y : ((oy == ry - 1) ? rf.y : 0.0f);
-                const float wx = (ox == rx) ? 1.0f - rf.z : ((ox == rx - 1) ? rf.z : 0.0f);
-                const float wk = (c & 8) ? (wz * wy) * wx : 0.0f;
-                a0 += rg.x * wk; a1 += rg.y * wk; a2 += rg.z * wk;
+                const f32x4 ra = recA[i];
+                const vg_f32x2 rb = recB[i];
+                // sender p = q + o: q is corner 0 of x'(p) along axis a if o_a == frel_a, corner 1 if o_a == frel_a - 1
+                const float wk = (vg_weight(ra.x, oz) * vg_weight(ra.y, oy)) * vg_weight(ra.z, ox);
+                a0 += ra.w * wk; a1 += rb.x * wk; a2 += rb.y * wk;
             }
     vxm_bstore((gz + a0) * scale, rgi, p4, 0);
     vxm_bstore((gy + a1) * scale, rgi, p4, V4);
@@ -287,10 +293,10 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __
 }
 
 // second launch of the step: the scatter contributions of the voxels the gather skipped (displacement >= 1 voxel), by atomics
-__global__ void __launch_bounds__(256) k_vecint_step_bwd_far(const float* __restrict__ in, float scale, const float* __restrict__ gout,
-                                                             float* __restrict__ gin, const unsigned* __restrict__ far_count, int D, int H, int W) {
-    if (far_count[0] == 0) return;
-    VXM_VOXEL_INDEX(D, H, W);
+__device__ __forceinline__ void vecint_far_voxel(const float* __restrict__ in, float scale, const float* __restrict__ gout, float* __restrict__ gin,
+                                                      int b, int p, int D, int H, int W) {
+    const int HWf = H * W, V = D * HWf;
+    const int d = p / HWf, r = p - d * HWf, h = r / W, w = r - h * W;
     const float* vin = in + (size_t)b * 3 * V;
     float* gi = gin + (size_t)b * 3 * V;
     const float v0 = vin[p] * scale, v1 = vin[V + p] * scale, v2 = vin[2 * (size_t)V + p] * scale;
@@ -312,6 +318,14 @@ __global__ void __launch_bounds__(256) k_vecint_step_bwd_far(const float* __rest
         atomicAdd(gi + V + i, g1 * wk);
         atomicAdd(gi + 2 * (size_t)V + i, g2 * wk);
     }
+}
+// A SMALL persistent grid (the common case is count == 0: 256 blocks exit at once instead of several thousand, 5.7 -> ~2 us per step)
+__global__ void __launch_bounds__(256) k_vecint_step_bwd_far(const float* __restrict__ in, float scale, const float* __restrict__ gout,
+                                                             float* __restrict__ gin, const unsigned* __restrict__ far_count, int B, int D, int H, int W) {
+    if (far_count[0] == 0) return;
+    const int HWf = H * W, V = D * HWf;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < (long long)B * V; idx += (long long)gridDim.x * 256)
+        vecint_far_voxel(in, scale, gout, gin, (int)(idx / V), (int)(idx % V), D, H, W);
 }
 
 // adjoint of the trilinear resize as a scatter (gx zeroed by the caller); only used for very large upsampling factors
@@ -626,7 +640,6 @@ int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, floa
     VXM_REQUIRE(nsteps >= 1 && nsteps < 31, VXM_ERR_BAD_SHAPE, "vxm_vecint_bwd: nsteps should be >= 1, found: %d", nsteps);
     VXM_REQUIRE(vec && steps && gout && gvec && work, VXM_ERR_NULL_POINTER, "vxm_vecint_bwd: null pointer");
     const size_t n = (size_t)B * 3 * D * H * W;
-    const dim3 grid(vxm_blocks((long long)H * W, 256), D, B);
     const long long tiles = (long long)((W + VG_TW - 1) / VG_TW) * ((H + VG_TH - 1) / VG_TH) * ((D + VG_TD - 1) / VG_TD);
     VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_vecint_bwd: too many tiles");
     const dim3 grid_t((unsigned)tiles, B);
@@ -640,7 +653,7 @@ int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, floa
         float* gn = k == 0 ? gvec : work + (size_t)(k & 1) * n;
         const float sc = k == 0 ? scale : 1.0f;
         hipLaunchKernelGGL(k_vecint_step_bwd_gather, grid_t, dim3(1024), 0, VXM_STREAM(stream), in, sc, g, gn, far + k, D, H, W);
-        hipLaunchKernelGGL(k_vecint_step_bwd_far, grid, dim3(256), 0, VXM_STREAM(stream), in, sc, g, gn, far + k, D, H, W);
+        hipLaunchKernelGGL(k_vecint_step_bwd_far, dim3(256), dim3(256), 0, VXM_STREAM(stream), in, sc, g, gn, far + k, B, D, H, W);
         g = gn;
     }
     return vxm_check_launch("vxm_vecint_bwd");

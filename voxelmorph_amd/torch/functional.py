@@ -423,6 +423,18 @@ def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H
     if FP32_ENGINE == "split" and not up0 and x1 is None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c0, cout, B, D, H, W):
         s3_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, c0, 0, gb, B, D, H, W)
         return
+    if FP32_ENGINE == "split" and up0 and x1 is not None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c1, cout, B, D, H, W) and \
+            _lib.lib().vxm_conv3d_k3_bwd_weight_variant(ptr(x0), c0, bs0, 1, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, D, H, W) // 10 == 2:
+        # cat([upsample(x0), x1]): the upsampled segment through the collapsed fp32-MFMA kernel, the full-resolution skip segment (and the
+        # bias gradient) on the split kernel, each into its channel range of gw
+        need = _lib.lib().vxm_conv3d_k3_bwd_weight_workspace_bytes(c0 + c1, cout, B, D, H, W)
+        buf = ws.get(need)
+        with _prof.region("k_conv3d_k3_bwd_weight_up<%d>" % (1 if cout <= 16 else 2), flops=2.0 * 8 * c0 * cout * B * D * H * W,
+                          nominal=2.0 * 27 * c0 * cout * B * D * H * W):
+            call("vxm_conv3d_k3_bwd_weight_up_segment", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, ptr(gw), ptr(buf),
+                 buf.numel(), B, D, H, W, stream())
+        s3_bwd_weight(ws, x1, c1, bs1, dz, cout, gw, c0 + c1, c0, gb, B, D, H, W)
+        return
     need = _lib.lib().vxm_conv3d_k3_bwd_weight_workspace_bytes(c0 + c1, cout, B, D, H, W)
     buf = ws.get(need)
     name, nominal = None, 2.0 * 27 * (c0 + c1) * cout * B * D * H * W
