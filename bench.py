@@ -165,14 +165,21 @@ def binding_roofline(name, st):
     if not st["flops"]:
         return hbm or dict(per, kernel=name, bound="hbm", achieved=0.0, peak=HBM_PEAK_GBS, unit="GB/s", frac=0.0, algorithmic_per_launch=0.0)
     is_bf = name.startswith("k_bf16")
+    is_split = name.startswith("k_s3_")
     alg = st["nominal"] if is_bf else st["flops"]
-    peak = BF16_MFMA_PEAK_TFLOPS if is_bf else FP32_MFMA_PEAK_TFLOPS
+    # split-fp32 kernels (csrc/conv_s3.hip) run on the bf16 pipe, six v_mfma_f32_16x16x32_bf16 per fp32-equivalent MAC block: their
+    # ceiling in fp32-equivalent FLOPs is the dense bf16 peak / 6 -- NOT the fp32-MFMA peak, which they can (and do) exceed
+    peak = BF16_MFMA_PEAK_TFLOPS if is_bf else (BF16_MFMA_PEAK_TFLOPS / 6.0 if is_split else FP32_MFMA_PEAK_TFLOPS)
     ach = alg / sec / 1e12
     if hbm is not None and st["bytes"] / (HBM_PEAK_GBS * 1e9) > alg / (peak * 1e12):
         hbm["mfma_frac"] = ach / peak
         return hbm
-    return dict(per, kernel=name, bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
-                algorithmic_per_launch=alg / st["launches"])
+    out = dict(per, kernel=name, bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, algorithmic_per_launch=alg / st["launches"])
+    if is_split:
+        out["peak_note"] = ("fp32-equivalent FLOPs of a kernel that executes 6 bf16 MFMAs per fp32 MAC block: peak = 2500 / 6 TFLOP/s; the same rate "
+                            "is %.2f x the fp32-MFMA peak (157.3)" % (ach / FP32_MFMA_PEAK_TFLOPS))
+        out["bf16_pipe_tflops"] = 6.0 * ach
+    return out
 
 
 def _cpu_model():

@@ -19,7 +19,9 @@
 //
 // Implicit GEMM (as conv_bf16.hip): M = 16 output channels, N = 16 voxels of a W row, K = 32 = four units of 8 input channels,
 // unit = (kd, kw, 8-channel block); the kh tap is walked by SLIDING over the haloed rows: the three B pieces of haloed row r
-// serve output rows r, r-1, r-2 with the weight fragments of kh = 0, 1, 2 (3 LDS reads feed up to 18 NCT MFMAs).
+// serve output rows r, r-1, r-2 with the weight fragments of kh = 0, 1, 2 (3 LDS reads feed up to 18 NCT MFMAs).  With 8-channel
+// chunks eight of the nine (kd, kw) units fill two sliding K-steps and the ninth is multiplied in a "row-tap" step whose four
+// lane groups hold its three kh taps: 27 of 28 K slots carry data (s3_unit below).
 // Block = 8 waves, output tile 8(D) x ROWS(H) x 16(W), wave = depth slice; chunk = CB 8-channel blocks of one segment of the
 // virtual concat [x0 (optionally through a nearest x2 upsampling gather) | x1].
 #include "conv_common.h"
@@ -56,7 +58,11 @@ constexpr int S3_TD = 8, S3_THREADS = 512, S3_HWV = 18;
 // must share kw and differ in the depth plane / channel block only, and plane / block strides are padded to multiples of 16 words
 // (the first layout, units in (kd, kw) order with unpadded strides, cost 8 instead of 4 LDS cycles per read).
 //   CB = 2: pairs are the two channel blocks of one (kd, kw): unit u = 4 s + kg = 2 (3 kd + kw) + cb, 18 units in 5 steps.
-//   CB = 1: s0: (0,0) (1,0) | (0,1) (1,1);  s1: (0,2) (1,2) | (2,0) -;  s2: (2,1) - | (2,2) -   ("-": zero weights, the partner's address)
+//   CB = 1: 9 units do not fill K-steps of 4 (the first version used three sliding steps, 9 of 12 slots: a quarter of all MFMAs
+//   multiplied zeros, on a pipe that is power-limited -- see DESIGN.md).  Now 27 of 28 slots: two SLIDING steps
+//       s0: (0,0) (1,0) | (0,1) (1,1)      s1: (0,2) (1,2) | (2,0) (2,1)      (the last pair is 1 word apart: 6 instead of 4 LDS cycles)
+//   and the remaining unit (kd, kw) = (2, 2) in one ROW-TAP step per output row: lane group kg multiplies tap kh = kg of haloed row
+//   r + kg (kg = 3: zero weights, kg 2's address) -- 7 instead of 9 MFMA sets per output row and 8-channel chunk.
 struct S3Unit { int kd, kw, cb, valid; };
 __host__ __device__ constexpr S3Unit s3_unit(int CB, int s, int kg) {
     if (CB == 2) {
@@ -64,8 +70,7 @@ __host__ __device__ constexpr S3Unit s3_unit(int CB, int s, int kg) {
         return S3Unit{p / 3, p % 3, u & 1, v};
     }
     if (s == 0) return S3Unit{kg & 1, kg >> 1, 0, 1};
-    if (s == 1) return kg < 2 ? S3Unit{kg, 2, 0, 1} : S3Unit{2, 0, 0, kg == 2};
-    return S3Unit{2, kg < 2 ? 1 : 2, 0, (kg & 1) == 0};
+    return kg < 2 ? S3Unit{kg, 2, 0, 1} : S3Unit{2, kg - 2, 0, 1};       // s == 1 (CB = 1 has two sliding steps)
 }
 
 template <int NCT, int ROWS, int CB>
@@ -73,16 +78,17 @@ struct S3Cfg {
     static constexpr int HR = ROWS + 2, PLANE_USED = HR * S3_HWV;
     static constexpr int PLANE = (PLANE_USED + 15) / 16 * 16, SLOTS = (S3_TD + 2) * PLANE;    // 16-byte words of one (piece, block); strides = 0 mod 16
     static constexpr int NSLOT = CB * (S3_TD + 2) * PLANE_USED;                               // haloed voxels x blocks to stage
-    static constexpr int NU = 9 * CB, NS = (NU + 3) / 4;                                      // units / K-steps of a chunk
+    static constexpr int NS = CB == 2 ? 5 : 2;                                                // sliding K-steps of a chunk
+    static constexpr int RT = CB == 2 ? 0 : 1;                                                // row-tap steps (CB = 1: unit (2, 2))
     static constexpr int XW = 3 * CB * SLOTS;                                                 // [piece][cb][slot]
-    static constexpr int WCH = NS * 9 * NCT * 64;                                             // [s][kh][piece][ct][lane]
+    static constexpr int WCH = (NS * 9 + RT * 3) * NCT * 64;                                  // [s][kh][piece][ct][lane], then [piece][ct][lane] of the row-tap step
     static constexpr int LDS_BYTES = (XW + WCH) * 16;
     static constexpr int NI = (NSLOT + S3_THREADS - 1) / S3_THREADS;                          // staging slots per thread
     static constexpr int WIT = (WCH + S3_THREADS - 1) / S3_THREADS;
     static constexpr int MIN_WAVES = LDS_BYTES <= 80 * 1024 ? 4 : 2;                          // two blocks per CU when the LDS allows it
 };
 
-// wp: [G][Q][NS][kh 3][piece 3][NCT][64 lanes] 16-byte words (k_s3_pack_weights).  Q0 chunks cover segment 0, Q - Q0 segment 1.
+// wp: [G][Q]{[NS][kh 3][piece 3][NCT][64 lanes], [RT][piece 3][NCT][64 lanes]} 16-byte words (k_s3_pack_weights).  Q0 chunks cover segment 0.
 template <int NCT, int ROWS, int CB>
 __global__ void __launch_bounds__(S3_THREADS, (S3Cfg<NCT, ROWS, CB>::MIN_WAVES))
 k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout,
@@ -149,6 +155,8 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
         const S3Unit u = kg == 0 ? u0 : kg == 1 ? u1 : kg == 2 ? u2 : u3;
         xoff[s] = u.cb * SLOTS + (wave + u.kd) * PLANE + u.kw + n;
     }
+    // row-tap step (CB = 1): lane group kg reads tap (kd, kh, kw) = (2, kg, 2) of output row r at haloed row r + kg; kg = 3 mirrors kg 2
+    const int xoff_rt = (wave + 2) * PLANE + (kg < 3 ? kg : 2) * S3_HWV + 2 + n;
 
     float xr[NI][8];                                         // chunk q + 1 in flight under the MFMAs of chunk q
     int voffs[NI];                                           // its per-lane offsets: kept live across the MFMA phase (see keep_offsets)
@@ -245,6 +253,28 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (C::RT) {
+            u32x4 a[3][NCT], bf[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[0][p] = Xs[p * CB * SLOTS + xoff_rt];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) a[p][ct] = Ws[((NS * 9 + p) * NCT + ct) * 64 + lane];
+#pragma unroll
+            for (int row = 0; row < ROWS; ++row) {
+                if (row + 1 < ROWS) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bf[(row + 1) & 1][p] = Xs[p * CB * SLOTS + xoff_rt + (row + 1) * S3_HWV];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) acc[ct][row] = s3_mfma(a[PA[t]][ct], bf[row & 1][PB[t]], acc[ct][row]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         if (q + 1 < Q) {
             keep_offsets();
             __syncthreads();                        // every wave is done reading chunk q
@@ -262,8 +292,9 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
                                       d < D && w < W, (d * H + h0) * W + w, h0, H, W, V);
 }
 
-// w: [Cw_out][Cw_in][27] fp32 (reference layout) -> [G][Q][NS][kh][piece][NCT][64 lanes][8 bf16]: lane (kg, m) of K-step s / row
-// tap kh / piece p holds, for output channel 16 (g NCT + ct) + m, piece p of the weights of unit u = 4 s + kg = CB (3 kd + kw) + cb.
+// w: [Cw_out][Cw_in][27] fp32 (reference layout) -> [G][Q]{[NS][kh][piece][NCT][64 lanes], [RT][piece][NCT][64 lanes]} x 8 bf16: lane (kg, m) of
+// sliding step s / row tap kh / piece p holds, for output channel 16 (g NCT + ct) + m, piece p of the weights of unit s3_unit(CB, s, kg);
+// lane (kg, m) of the row-tap step those of tap (kd, kh, kw) = (2, kg, 2) (kg = 3: zeros).
 // Operator: y[o] = sum_i Wop[o][i][tap] x[i] over the virtual input channels i (segment 0: [0, seg0), segment 1: the rest);
 // chunk q < Q0 holds segment-0 channels 8 CB q + 8 cb + e, chunk q >= Q0 segment-1 channels seg0 + 8 CB (q - Q0) + 8 cb + e.
 // forward: Wop[o][i][t] = w[o][ci_lo + i][t]; flip (backward-data onto input channels [ci_lo, ci_lo + OutC)): Wop[o][i][t] = w[i][ci_lo + o][26 - t].
@@ -273,20 +304,29 @@ struct S3PackJob {
     unsigned first_block, words;
 };
 __device__ __forceinline__ void s3_pack_word(const S3PackJob& jb, size_t i) {
-    const int NS = (9 * jb.CB + 3) / 4;
+    const int NS = jb.CB == 2 ? 5 : 2, RT = jb.CB == 2 ? 0 : 1;
+    const int per_chunk = (NS * 9 + RT * 3) * jb.NCT * 64;
     size_t r = i;
-    const int lane = r % 64; r /= 64;
-    const int ct = r % jb.NCT; r /= jb.NCT;
-    const int p = r % 3; r /= 3;
-    const int kh = r % 3; r /= 3;
-    const int s = r % NS; r /= NS;
+    const int wi = (int)(r % per_chunk); r /= per_chunk;       // word inside the chunk
     const int q = r % jb.Q; const int g = (int)(r / jb.Q);
+    const int lane = wi % 64;
+    int t2 = wi / 64;
+    const int ct = t2 % jb.NCT; t2 /= jb.NCT;                   // t2: (s, kh, piece) of a sliding step, or NS * 9 + piece of the row-tap step
     const int kg = lane >> 4, m = lane & 15;
+    int p, tap, cb;
+    bool valid;
+    if (t2 < NS * 9) {
+        p = t2 % 3;
+        const int kh = (t2 / 3) % 3, st = t2 / 9;
+        const S3Unit un = s3_unit(jb.CB, st, kg);
+        valid = un.valid != 0; cb = un.cb; tap = un.kd * 9 + kh * 3 + un.kw;
+    } else {
+        p = t2 - NS * 9;
+        valid = kg < 3; cb = 0; tap = 2 * 9 + kg * 3 + 2;       // (kd, kh, kw) = (2, kg, 2)
+    }
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int o = (g * jb.NCT + ct) * 16 + m;
-    const S3Unit un = s3_unit(jb.CB, s, kg);
-    if (un.valid && o < jb.OutC) {
-        const int cb = un.cb, tap = un.kd * 9 + kh * 3 + un.kw;
+    if (valid && o < jb.OutC) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const bool s0 = q < jb.Q0;
@@ -657,8 +697,9 @@ long long s3_min_tiles() {
 int s3_chunks(int C, int CB) { return (C + 8 * CB - 1) / (8 * CB); }
 size_t s3_packed_words(int seg0, int seg1, int OutC) {
     const S3Variant v = s3_variant(OutC);
-    const int Q = s3_chunks(seg0, v.CB) + s3_chunks(seg1, v.CB), G = (OutC + 16 * v.NCT - 1) / (16 * v.NCT), NS = (9 * v.CB + 3) / 4;
-    return (size_t)G * Q * NS * 9 * v.NCT * 64;
+    const int Q = s3_chunks(seg0, v.CB) + s3_chunks(seg1, v.CB), G = (OutC + 16 * v.NCT - 1) / (16 * v.NCT);
+    const int NS = v.CB == 2 ? 5 : 2, RT = v.CB == 2 ? 0 : 1;
+    return (size_t)G * Q * (NS * 9 + RT * 3) * v.NCT * 64;
 }
 
 template <int NCT, int ROWS, int CB>
@@ -747,6 +788,8 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
     VXM_REQUIRE((reinterpret_cast<uintptr_t>(wpacked) & 15) == 0, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_fwd: packed weights must be 16-byte aligned");
     const ConvIn in = {x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up ? 1 : 0};
     hipStream_t s = VXM_STREAM(stream);
+    // (32-channel operators on 8 x 2 x 16 tiles -- 81 KB of LDS, two blocks per CU instead of one -- were measured: 32 spilled registers
+    // at the 128-VGPR limit of four waves per SIMD and 2.56 instead of 2.02 ms per step on these launches; not kept)
     if (v.NCT == 2) s3_launch<2, 4, 1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
     else if (v.CB == 2) s3_launch<1, 4, 2>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
     else s3_launch<1, 4, 1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
