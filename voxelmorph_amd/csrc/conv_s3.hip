@@ -479,23 +479,32 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
                 }
             }
         };
-        auto store_planes = [&](int p0) __attribute__((always_inline)) {
+        // split (registers only) and write (LDS) are separate steps: a wave splits the tile it prefetched right after ITS OWN MFMA loop,
+        // while the waves it shares the SIMD with are still multiplying, and only the LDS writes wait for the barrier
+        unsigned xk[2][NXI][3][4], zk[NZI][3][4];
+        auto split_planes = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int j = 0; j < NXI; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s3_split2(xr[pl][j][2 * e], xr[pl][j][2 * e + 1], xk[pl][j][0][e], xk[pl][j][1][e], xk[pl][j][2][e]);
+        };
+        auto write_planes = [&](int p0) __attribute__((always_inline)) {
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
                 char* const dst = Xs + ((p0 + pl) % SW_RING) * SW_PLANE;
 #pragma unroll
-                for (int j = 0; j < NXI; ++j) {
-                    unsigned pk[3][4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) s3_split2(xr[pl][j][2 * e], xr[pl][j][2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+                for (int j = 0; j < NXI; ++j)
                     if (tid + SW_THREADS * j < NXP) {
 #pragma unroll
                         for (int p = 0; p < 3; ++p)
-                            *reinterpret_cast<u32x4*>(dst + p * SW_XPIECE + (tid + SW_THREADS * j) * 16) = (u32x4){pk[p][0], pk[p][1], pk[p][2], pk[p][3]};
+                            *reinterpret_cast<u32x4*>(dst + p * SW_XPIECE + (tid + SW_THREADS * j) * 16) =
+                                (u32x4){xk[pl][j][p][0], xk[pl][j][p][1], xk[pl][j][p][2], xk[pl][j][p][3]};
                     }
-                }
             }
         };
+        auto store_planes = [&](int p0) __attribute__((always_inline)) { split_planes(); write_planes(p0); };
         auto load_z = [&](int t) __attribute__((always_inline)) {
             const int gd = dbase + t * SW_TD;                      // first depth slice of the tile (always < D)
             int nolast = gd + 1 < D ? 0 : 1;                      // the tile's second depth slice lies beyond the volume
@@ -508,19 +517,22 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
                 for (int e = 0; e < 8; ++e) zr[j][e] = vxm_bload(rz, zv[j], soff + ((e * V) << 2));
             }
         };
-        auto store_z = [&]() __attribute__((always_inline)) {
+        auto split_z = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NZI; ++j) {
-                unsigned pk[3][4];
+            for (int j = 0; j < NZI; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s3_split2(zr[j][2 * e], zr[j][2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+                for (int e = 0; e < 4; ++e) s3_split2(zr[j][2 * e], zr[j][2 * e + 1], zk[j][0][e], zk[j][1][e], zk[j][2][e]);
+        };
+        auto write_z = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NZI; ++j)
                 if (tid + SW_THREADS * j < NZ) {
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
-                        *reinterpret_cast<u32x4*>(Zs + p * SW_ZPIECE + (tid + SW_THREADS * j) * 16) = (u32x4){pk[p][0], pk[p][1], pk[p][2], pk[p][3]};
+                        *reinterpret_cast<u32x4*>(Zs + p * SW_ZPIECE + (tid + SW_THREADS * j) * 16) = (u32x4){zk[j][p][0], zk[j][p][1], zk[j][p][2], zk[j][p][3]};
                 }
-            }
         };
+        auto store_z = [&]() __attribute__((always_inline)) { split_z(); write_z(); };
 
         __syncthreads();                                        // every wave is done with the previous task
         load_planes(0);
@@ -583,10 +595,12 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
             for (int j = 0; j < NXI; ++j) asm volatile("" ::"v"(xv[0][j]), "v"(xv[1][j]));
 #pragma unroll
             for (int j = 0; j < NZI; ++j) asm volatile("" ::"v"(zv[j]));
+            split_planes();                                      // before the barrier: overlaps the other waves' MFMAs
+            split_z();
             __syncthreads();                                     // every wave is done reading tile t (X ring slots of t - 1 and the dZ tile are free)
             if (more) {
-                store_planes(2 * t + 4);
-                store_z();
+                write_planes(2 * t + 4);
+                write_z();
             }
             __syncthreads();
         }
