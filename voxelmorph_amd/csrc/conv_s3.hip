@@ -417,11 +417,11 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
     const int k_lo = (int)((long long)ntask * bx / NBLK), k_hi = (int)((long long)ntask * (bx + 1) / NBLK);
     const int V = D * H * W, HW = H * W;
 
-    f32x4 acc[3][3], accb = {0.f, 0.f, 0.f, 0.f};
+    f32x4 tot[3][3], totb = {0.f, 0.f, 0.f, 0.f};               // running totals (vector-ALU sums of the per-tile MFMA chains)
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) acc[kh][kw] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kw = 0; kw < 3; ++kw) tot[kh][kw] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lp = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;     // lane pattern of the transposing read
     const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};       // bf16 1.0 x 8: B operand of the bias sum
 
@@ -551,19 +551,15 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
             load_planes(2 * t + 4);
             load_z(more ? t + 1 : t);
             __builtin_amdgcn_sched_barrier(0);
+            // The fp32 accumulation of the bf16 MFMA TRUNCATES (tools/bw_accuracy.py: a chain of ~10^4 MFMAs into one accumulator drifts,
+            // 1.5e-5 against 4e-6 for the fp32 MFMA on cancelling sums).  So an MFMA chain lives for ONE tile -- it starts from zero and is
+            // at most 12 links long -- and is then added to the running totals by the vector ALU (round to nearest, unbiased).
             u32x4 az[2][3];                                      // dZ fragment sets (3 pieces) of this wave's two output rows
+            f32x4 acc[3][3], accb = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int hl = 0; hl < 4; ++hl) {                     // haloed rows 2 rh + hl serve output rows 2 rh + hl - kh
                 const int hr = 2 * rh + hl;                      // wave-uniform
-                u32x4 bxf[3][3];                                 // [kw][piece]
-#pragma unroll
-                for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        const int xb = p * SW_XPIECE + (hr * SW_XW + kw) * 32 + lp;
-                        const u32x2 lo = s3_tr_read(xp, xb), hi = s3_tr_read(xp, xb + 16 * 32);
-                        bxf[kw][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
-                    }
                 if (hl < 2) {
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
@@ -578,16 +574,29 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
                 }
                 constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};       // (m,m) (l,h) (h,l) (m,h) (h,m) (h,h)
 #pragma unroll
-                for (int tp = 0; tp < 6; ++tp)
+                for (int kw = 0; kw < 3; ++kw) {                 // one kw-shifted B fragment set at a time (12 instead of 36 registers)
+                    u32x4 bxf[3];
 #pragma unroll
-                    for (int kh = 0; kh < 3; ++kh) {
-                        const int rl = hl - kh;                  // local output row
-                        if (rl >= 0 && rl < 2) {
-#pragma unroll
-                            for (int kw = 0; kw < 3; ++kw) acc[kh][kw] = s3_mfma(az[rl][PA[tp]], bxf[kw][PB[tp]], acc[kh][kw]);
-                        }
+                    for (int p = 0; p < 3; ++p) {
+                        const int xb = p * SW_XPIECE + (hr * SW_XW + kw) * 32 + lp;
+                        const u32x2 lo = s3_tr_read(xp, xb), hi = s3_tr_read(xp, xb + 16 * 32);
+                        bxf[p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
                     }
+#pragma unroll
+                    for (int tp = 0; tp < 6; ++tp)
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh) {
+                            const int rl = hl - kh;              // local output row
+                            if (rl >= 0 && rl < 2)               // the first link of a tile's chain (output row 0, first product) starts from zero
+                                acc[kh][kw] = s3_mfma(az[rl][PA[tp]], bxf[PB[tp]], (rl == 0 && tp == 0) ? zero4 : acc[kh][kw]);
+                        }
+                }
             }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) tot[kh][kw] += acc[kh][kw];
+            totb += accb;
             __builtin_amdgcn_sched_barrier(0);
             // the address registers of the loads in flight stay live until here: reused earlier, the compiler guards every reuse
             // with s_waitcnt vmcnt(..), i.e. waits for the prefetch at the start of the MFMA phase (seen in the ISA)
@@ -615,10 +624,10 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                pp[((size_t)(kd * 9 + kh * 3 + kw) * (16 * NCO) + cot * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[kh][kw][r];
+                pp[((size_t)(kd * 9 + kh * 3 + kw) * (16 * NCO) + cot * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = tot[kh][kw][r];
     if (kd == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pp[((size_t)27 * (16 * NCO) + cot * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = accb[r];
+        for (int r = 0; r < 4; ++r) pp[((size_t)27 * (16 * NCO) + cot * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = totb[r];
     }
 }
 
