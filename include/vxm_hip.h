@@ -125,7 +125,8 @@ int vxm_conv3d_k3_fewout_fwd(const float* x, int Cin, int64_t x_bstride, const f
 int vxm_conv3d_k3_fwd_variant(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
                               const float* wpacked, int Cout, int B, int D, int H, int W);
 /* Same for vxm_conv3d_k3_bwd_weight: 10 * kind + NCT, kind = 0: k_conv3d_k3_bwd_weight_dma, 1: ..._vec, 2: collapsed
- * upsampled segment (k_conv3d_k3_bwd_weight_up) + ..._vec on the skip segment. */
+ * upsampled segment (k_conv3d_k3_bwd_weight_up) + ..._vec on the skip segment, 3: k_fewch_bwd_weight (1-3 channels on one side:
+ * first block, flow conv). */
 int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1,
                                      int64_t x1_bstride, const float* dz, int64_t dz_bstride, int Cout, int D, int H, int W);
 /* Only the UPSAMPLED segment's share of that gradient, gw[:, 0:C0, :] inside the [Cout][C0+C1][27] array (collapsed low-resolution

@@ -743,6 +743,195 @@ __global__ void __launch_bounds__(64) k_channel_sum_finish(const float* __restri
     if (threadIdx.x == 0) gb[blockIdx.x] = s;
 }
 
+// ------------------------------------------------------------------------------------------
+// backward-weight of the layers with 1-3 channels on one side (first block 2 -> 16, flow conv 16 -> 3)
+// ------------------------------------------------------------------------------------------
+// 2 % of the conv FLOPs, but in the general kernel above (16 waves per 4 x 4 x 16 tile, ~300 instructions of per-tile address
+// arithmetic against a few dozen MFMAs) they took 0.75 ms per step at 40 TFLOP/s.  Here: R[m][(c, tap)] = sum_v P[m][v] S[c][v + off(tap)]
+// with P the 16-channel tensor (A operand, M = 16, halo-free), S the tensor with cs <= 3 channels -- its 27 cs shifted copies are the
+// N columns (NT = ceil(27 cs / 16) N-tiles), K = 4 voxels of a W row per v_mfma_f32_16x16x4_f32 (exact fp32).
+//   first block (x has 2 channels: virtual concat of two 1-channel tensors):  P = dz, S = x, off(tap) = tap - 1,     gw[co = m][ci = c][tap]
+//   flow conv (dz has 3 channels):                                            P = x,  S = dz, off(tap) = 1 - tap,   gw[co = c][ci = m][tap]
+// plus, for the first case, the bias gradient as one more column against a plane of ones.  Persistent blocks of 4 waves walk
+// 1 x 8 x 64 voxel tiles: the 16 P planes of a tile (dwordx4 loads, 32 KB) and the haloed S planes sit in LDS (plane stride 514 = 2 mod 32:
+// the A reads of a half-wave hit 32 distinct banks), the next tile is in flight in registers, a wave owns two rows and walks them in 16
+// K-steps of NT MFMAs with immediate offsets; per-block partials, reduced in a fixed order by k_fewch_reduce (deterministic).
+constexpr int FC_TH = 8, FC_TW = 64, FC_THREADS = 256;
+constexpr int FC_PSTRIDE = FC_TH * FC_TW + 2;                 // floats per P plane in LDS
+constexpr int FC_SW = FC_TW + 4, FC_SPLANE = 3 * (FC_TH + 2) * FC_SW;     // haloed S rows hold w0 - 1 .. w0 + 64 (+ padding); planes of one channel
+constexpr int fc_lds_floats(int cs) { return 16 * FC_PSTRIDE + (cs + 1) * FC_SPLANE; }      // + one plane set of ones (bias column)
+
+struct FcIn {
+    const float* P; long long p_bs;            // [B][16][D][H][W]
+    const float* S0; long long s0_bs; int cs0;  // small operand: virtual concat of S0 (cs0 channels) and S1 (cs - cs0 channels)
+    const float* S1; long long s1_bs;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(FC_THREADS, 2) k_fewch_bwd_weight(FcIn in, int cs, int flip, int with_ones, float* __restrict__ part, int B, int D,
+                                                                 int H, int W) {
+    VXM_DYN_SMEM(float, smem);
+    float* const Ps = smem;                                  // [16][FC_PSTRIDE]: [row][w]
+    float* const Ss = smem + 16 * FC_PSTRIDE;                // [cs + 1][3][FC_TH + 2][FC_SW], the last "channel" is all ones
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, idx = lane & 15;
+    const int nw = (W + FC_TW - 1) / FC_TW, nh = (H + FC_TH - 1) / FC_TH;
+    const int ntiles = B * D * nh * nw;
+    const int V = D * H * W, HW = H * W;
+
+    // column n = c * 27 + tap of N-tile nt -> LDS offset of S[c] shifted by the tap (haloed coordinates 0..2 per axis); columns
+    // beyond 27 cs: the ones plane at tap (1, 1, 1) for column 27 cs (bias gradient), any valid address otherwise (dropped by the reducer)
+    int sbase[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + idx;
+        int c = n / 27, tap = n - c * 27;
+        if (n >= 27 * cs) { c = cs; tap = 13; }
+        int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        if (flip && n < 27 * cs) { kd = 2 - kd; kh = 2 - kh; kw = 2 - kw; }
+        sbase[nt] = c * FC_SPLANE + (kd * (FC_TH + 2) + kh) * FC_SW + kw + kq;
+    }
+    for (int i = tid; i < FC_SPLANE; i += FC_THREADS) Ss[cs * FC_SPLANE + i] = 1.0f;      // written once: no tile touches it
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging roles, fixed per thread.  P: 16 planes x 8 rows x 16 float4: thread -> (plane tid >> 7, row, float4), 8 loads two planes apart
+    // (the plane step is a wave-uniform scalar offset); S: one haloed plane is 10 x 66 floats = 3 slots per thread, the same three slots
+    // for every (channel, depth plane) of the region, which again only moves the scalar offset.
+    constexpr int NPV = 8, NSK = 3, NSV = 3 * 3 * NSK;          // cs <= 3 channels x 3 depth planes x 3 slots
+    f32x4 pv[NPV];
+    float sv[NSV];
+    const int pm0 = tid >> 7, prow = (tid >> 4) & 7, pw4 = tid & 15;
+    const int pdst = pm0 * FC_PSTRIDE + prow * FC_TW + 4 * pw4;
+    int spr[NSK], spw[NSK];
+#pragma unroll
+    for (int k = 0; k < NSK; ++k) {
+        const int e = tid + FC_THREADS * k;
+        spr[k] = e / (FC_TW + 2); spw[k] = e - spr[k] * (FC_TW + 2);          // spr >= FC_TH + 2: no slot
+    }
+    auto tile_coords = [&](int t, int& b, int& d, int& h0, int& w0) __attribute__((always_inline)) {
+        const int tw = t % nw; int q = t / nw;
+        const int th = q % nh; q /= nh;
+        d = q % D; b = q / D;
+        h0 = th * FC_TH; w0 = tw * FC_TW;
+    };
+    auto load_tile = [&](int t) __attribute__((always_inline)) {
+        int b, d, h0, w0;
+        tile_coords(t < ntiles ? t : 0, b, d, h0, w0);
+        int dead = t < ntiles ? 0 : VXM_OOB;                     // past the last tile: every lane out of range (branch-free)
+        asm volatile("" : "+v"(dead));
+        const __amdgpu_buffer_rsrc_t rp = vxm_rsrc(in.P + (size_t)b * in.p_bs, 16u * (unsigned)V * 4u);
+        const int gh = h0 + prow, gw = w0 + 4 * pw4;
+        const int pvoff = ((gh < H && gw < W) ? (pm0 * V + d * HW + gh * W + gw) << 2 : VXM_OOB) | dead;   // W % 4 == 0: a float4 is inside or outside the row
+#pragma unroll
+        for (int j = 0; j < NPV; ++j) pv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, pvoff, (2 * j * V) << 2, 0));
+        const __amdgpu_buffer_rsrc_t r0 = vxm_rsrc(in.S0 + (size_t)b * in.s0_bs, (unsigned)in.cs0 * (unsigned)V * 4u);
+        const __amdgpu_buffer_rsrc_t r1 = vxm_rsrc(cs > in.cs0 ? in.S1 + (size_t)b * in.s1_bs : in.S0, (unsigned)(cs > in.cs0 ? cs - in.cs0 : in.cs0) * (unsigned)V * 4u);
+        int svoff[NSK];
+#pragma unroll
+        for (int k = 0; k < NSK; ++k) {
+            const int sh = h0 - 1 + spr[k], sw = w0 - 1 + spw[k];
+            const bool ok = spr[k] < FC_TH + 2 && (unsigned)sh < (unsigned)H && (unsigned)sw < (unsigned)W;
+            svoff[k] = (ok ? (sh * W + sw) << 2 : VXM_OOB) | dead;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int pd = 0; pd < 3; ++pd) {
+                const int gd = d - 1 + pd;                       // wave-uniform
+                const bool first = c < in.cs0;
+                const __amdgpu_buffer_rsrc_t r = first ? r0 : r1;
+                const int cc = first ? c : c - in.cs0;
+                int bad = (c < cs && (unsigned)gd < (unsigned)D) ? 0 : VXM_OOB;
+                asm volatile("" : "+v"(bad));
+                const int soff = (c < cs && (unsigned)gd < (unsigned)D) ? (cc * V + gd * HW) << 2 : 0;
+#pragma unroll
+                for (int k = 0; k < NSK; ++k) sv[(c * 3 + pd) * NSK + k] = vxm_bload(r, svoff[k] | bad, soff);
+            }
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NPV; ++j) {
+            float* dst = Ps + pdst + 2 * j * FC_PSTRIDE;         // 8-byte aligned (plane stride even)
+            *reinterpret_cast<f32x2*>(dst) = (f32x2){pv[j].x, pv[j].y};
+            *reinterpret_cast<f32x2*>(dst + 2) = (f32x2){pv[j].z, pv[j].w};
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int pd = 0; pd < 3; ++pd)
+#pragma unroll
+                for (int k = 0; k < NSK; ++k)
+                    if (c < cs && spr[k] < FC_TH + 2) Ss[c * FC_SPLANE + (pd * (FC_TH + 2) + spr[k]) * FC_SW + spw[k]] = sv[(c * 3 + pd) * NSK + k];
+    };
+
+    int t = blockIdx.x;
+    load_tile(t);
+    store_tile();
+    __syncthreads();
+    for (; t < ntiles; t += gridDim.x) {
+        load_tile(t + gridDim.x);                                // unconditional (past the end every lane is out of range)
+        const int abase = idx * FC_PSTRIDE + kq;
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * wave + rr;
+#pragma unroll 4                                                 // (fully unrolled, the compiler hoists all 16 x (NT + 1) LDS reads: 256 VGPRs and spills)
+            for (int j = 0; j < FC_TW / 4; ++j) {
+                const float a = Ps[abase + row * FC_TW + 4 * j];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = vxm_mfma16(a, Ss[sbase[nt] + row * FC_SW + 4 * j], acc[nt]);
+            }
+        }
+        __syncthreads();                                        // every wave is done reading this tile
+        if (t + (int)gridDim.x < ntiles) store_tile();
+        __syncthreads();
+    }
+    (void)with_ones;
+    // ---- partials: part[block][16 m][NT * 16 columns]; the four waves of a block are summed through LDS in a fixed order
+    float* const red = smem;                                   // [4][16][NT * 16]
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * kq + r) * (NT * 16) + nt * 16 + idx] = acc[nt][r];
+    __syncthreads();
+    for (int i = tid; i < 16 * NT * 16; i += FC_THREADS)
+        part[(size_t)blockIdx.x * (16 * NT * 16) + i] = (red[i] + red[16 * NT * 16 + i]) + (red[2 * 16 * NT * 16 + i] + red[3 * 16 * NT * 16 + i]);
+}
+
+// gw / gb from the per-block partials (fixed order: 16 slices of the blocks, then a tree)
+__global__ void __launch_bounds__(256) k_fewch_reduce(const float* __restrict__ part, int nblocks, int ncols, int cs, int flip, int Cw_in,
+                                                      float* __restrict__ gw, float* __restrict__ gb) {
+    __shared__ float sm[16][17];
+    const int e = blockIdx.x * 16 + (threadIdx.x & 15), y = threadIdx.x >> 4;       // element (m, col) of the 16 x ncols result; slice y of 16
+    float s = 0.0f;
+    if (e < 16 * ncols)
+        for (int k = y; k < nblocks; k += 16) s += part[(size_t)k * (16 * ncols) + e];
+    sm[y][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (y == 0 && e < 16 * ncols) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = sm[u][threadIdx.x & 15];
+        const float sum = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) + (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+        const int m = e / ncols, n = e - m * ncols;
+        if (n < 27 * cs) {
+            const int c = n / 27, tap = n - c * 27;
+            if (!flip) gw[((size_t)m * Cw_in + c) * 27 + tap] = sum;            // P = dz: m = co, c = ci
+            else gw[((size_t)c * Cw_in + m) * 27 + tap] = sum;                  // P = x:  m = ci, c = co
+        } else if (n == 27 * cs && gb != nullptr && !flip) {
+            gb[m] = sum;                                                        // ones column: sum_v dz[co][v]
+        }
+    }
+}
+
+bool fewch_enabled() {
+    static const bool on = [] { const char* e = getenv("VXM_FEWCH"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 struct BwPlan { int NCT, Qc, G, T, nparts; };
 BwPlan bw_plan(int Cin, int Cout, int B, int D, int H, int W) {
     BwPlan p;
@@ -766,6 +955,7 @@ int vxm_conv3d_k3_bwd_weight_variant(const float* x0, int C0, int64_t x0_bstride
                                      const float* dz, int64_t dz_bstride, int Cout, int D, int H, int W) {
     const bool vec = bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W);
     const int nct = Cout <= 16 ? 1 : 2;                 // of the unswapped plan
+    if (vec && fewch_enabled() && !x0_up && ((Cout == 16 && C0 + C1 <= 3) || (Cout <= 3 && C0 == 16 && C1 == 0))) return 30 + nct;    // k_fewch_bwd_weight
     if (x0_up && vec && (D & 1) == 0 && (H & 1) == 0) return 20 + nct;      // collapsed upsampled segment (+ regular skip segment)
     return (vec ? 10 : 0) + nct;
 }
@@ -784,6 +974,10 @@ size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D,
         const size_t alt = sizeof(float) * ((size_t)Cout * 64 * (4096 / (size_t)p.G + Cin + 16) + (size_t)Cout * CS_SLICES + (size_t)Cout * Cin * 64);
         if (alt > need) need = alt;
     }
+    {                                                  // few-channel kernel: 512 block partials of 16 x 96 (+ channel-sum scratch)
+        const size_t alt = sizeof(float) * ((size_t)512 * 16 * 96 + (size_t)Cout * CS_SLICES);
+        if ((Cin <= 3 || Cout <= 3) && alt > need) need = alt;
+    }
     return 256 + need;
 }
 
@@ -801,6 +995,38 @@ static int bwd_weight_impl(const float* x0, int C0, int64_t x0_bstride, int x0_u
     // workspace: per-block partials [nparts][Cout*Cin*27 + (Cout | Cin)] (+ channel-sum scratch when swapped)
     uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
     float* part = reinterpret_cast<float*>(base);
+    // layers with 1-3 channels on one side: the dedicated persistent kernel (k_fewch_bwd_weight)
+    const bool few_in = vec && fewch_enabled() && !x0_up && Cout == 16 && Cin <= 3 && !seg0_only;           // first block: P = dz, S = x
+    const bool few_out = vec && fewch_enabled() && !x0_up && Cout <= 3 && C0 == 16 && C1 == 0 && !seg0_only;  // flow conv: P = x, S = dz
+    if (few_in || few_out) {
+        const int cs = few_in ? Cin : Cout;
+        const int NT = (27 * cs + (few_in && gb ? 1 : 0) + 15) / 16;
+        FcIn fin;
+        if (few_in) fin = FcIn{dz, (long long)dz_bstride, x0, (long long)x0_bstride, C0, x1, (long long)x1_bstride};
+        else fin = FcIn{x0, (long long)x0_bstride, dz, (long long)dz_bstride, Cout, nullptr, 0};
+        const long long ntiles = (long long)B * D * ((H + FC_TH - 1) / FC_TH) * ((W + FC_TW - 1) / FC_TW);
+        const int nblk = (int)(ntiles < 512 ? ntiles : 512);
+        const size_t lds = sizeof(float) * (size_t)fc_lds_floats(cs);
+        static bool fc_opt_in = false;
+        if (!fc_opt_in) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            fc_opt_in = true;
+        }
+#define FC_LAUNCH(NT_) hipLaunchKernelGGL(k_fewch_bwd_weight<NT_>, dim3(nblk), dim3(FC_THREADS), lds, VXM_STREAM(stream), fin, cs, few_out ? 1 : 0, 1, part, B, D, H, W)
+        if (NT <= 2) FC_LAUNCH(2); else if (NT <= 4) FC_LAUNCH(4); else FC_LAUNCH(6);
+#undef FC_LAUNCH
+        const int ncols = (NT <= 2 ? 2 : (NT <= 4 ? 4 : 6)) * 16;
+        hipLaunchKernelGGL(k_fewch_reduce, dim3((16 * ncols + 15) / 16), dim3(256), 0, VXM_STREAM(stream), part, nblk, ncols, cs, few_out ? 1 : 0, Cin, gw,
+                           few_in ? gb : nullptr);
+        if (few_out && gb) {
+            float* cs_ws = part + (size_t)nblk * 16 * ncols;
+            hipLaunchKernelGGL(k_channel_sum_partial, dim3(Cout, CS_SLICES), dim3(256), 0, VXM_STREAM(stream), dz, (long long)dz_bstride, cs_ws, B, (size_t)D * H * W);
+            hipLaunchKernelGGL(k_channel_sum_finish, dim3(Cout), dim3(64), 0, VXM_STREAM(stream), cs_ws, gb);
+        }
+        return vxm_check_launch("vxm_conv3d_k3_bwd_weight");
+    }
     // up to 161 KB of dynamic LDS (> the 64 KB default cap): opt in once per kernel
     static bool lds_opt_in = false;
     if (!lds_opt_in) {

@@ -441,8 +441,8 @@ def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H
     flops = nominal
     if _prof.ACTIVE is not None:
         v = _lib.lib().vxm_conv3d_k3_bwd_weight_variant(ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, D, H, W)
-        kind = {0: "dma", 1: "vec", 2: "up+vec"}[v // 10]
-        name = "k_conv3d_k3_bwd_weight_%s<%d>" % (kind, v % 10)
+        kind = {0: "dma", 1: "vec", 2: "up+vec", 3: "fewch"}[v // 10]
+        name = "k_fewch_bwd_weight" if v // 10 == 3 else "k_conv3d_k3_bwd_weight_%s<%d>" % (kind, v % 10)
         if v // 10 == 2:
             flops = 2.0 * (8 * c0 + 27 * c1) * cout * B * D * H * W
     with _prof.region(name, flops=flops, nominal=nominal):
