@@ -306,15 +306,16 @@ def comm_evidence(opt, dev):
         ev["ranks_seen"] = int(vcomm.lib().vxm_comm_world())
         ev["rccl_version"] = vcomm.rccl_version()
     buf = torch.zeros_like(opt.flat_grad)
+    sync = torch.cuda.synchronize if buf.is_cuda else (lambda: None)         # (the CPU test drives this over gloo)
     times = []
     for i in range(25):
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         if opt.comm is not None:
             opt.comm.all_reduce_sum(buf)
         else:
             torch.distributed.all_reduce(buf, group=opt.group)
-        torch.cuda.synchronize()
+        sync()
         if i >= 5:
             times.append((time.perf_counter() - t0) * 1e6)
     ev["allreduce_us"] = statistics.median(times)

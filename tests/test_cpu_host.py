@@ -294,6 +294,48 @@ def test_data_parallel_equivalence_gloo_world2(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+_COMM_WORKER = """
+import os, sys, json, types
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+import bench
+from voxelmorph_amd import comm as vcomm, dist as vdist
+# (1) the evidence a multi-rank bench line carries about its exchange, over a stand-in optimiser on the gloo group
+opt = types.SimpleNamespace(comm=None, world=dist.get_world_size(), n=327331, group=None, flat_grad=torch.zeros(327331))
+ev = bench.comm_evidence(opt, torch.device("cpu"))
+assert ev["backend"].startswith("torch.distributed") and ev["ranks_seen"] == 2 and ev["bucket_bytes"] == 4 * 327331 and ev["allreduce_us"] > 0
+assert "transport" in ev
+# (2) a rank that cannot LOAD libvxm_comm.so: every rank must come back with None (no rank left waiting in the unique-id broadcast)
+if dist.get_rank() == 1:
+    vcomm.LIB_PATH = "/nonexistent/libvxm_comm.so"
+    vcomm._lib = None
+got = vcomm.NativeComm.try_from_torch_dist()
+assert got is None, got
+# (3) required=True turns that into an error on EVERY rank (bench.py: never a silently different exchange) -- native_comm() itself only
+# engages on the nccl backend, so the rule is checked on its decision function
+os.environ["VXM_COMM"] = ""
+assert vdist.native_comm(required=True) is None          # gloo: not a HIP job, nothing required
+dist.barrier()
+print("ok")
+"""
+
+
+def test_comm_evidence_and_library_agreement_gloo_world2(tmp_path):
+    """bench.py's `comm` object over a 2-rank gloo group (fields and types the scaling run will leave behind), and the three-round
+    agreement of `NativeComm.try_from_torch_dist`: one rank without the library -> both ranks fall back together, nobody hangs."""
+    script = os.path.join(tmp_path, "comm_worker.py")
+    with open(script, "w") as f:
+        f.write(_COMM_WORKER % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29543", script],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert out.stdout.count("ok") == 2
+    assert "cannot be loaded on 1 of 2 ranks" in out.stderr
+
+
 def test_bench_gpus_n_self_launches_one_rank_per_gpu():
     """`python bench.py --gpus 2` with no torchrun environment (how the scaling driver invokes it) re-launches itself under
     torch.distributed.run with two ranks on a 127.0.0.1 rendezvous; on this GPU-less host both ranks get past the process-group
@@ -324,6 +366,31 @@ def test_bench_reports_the_roofline_that_binds_the_kernel():
     assert w["bound"] == "hbm" and abs(w["frac"] - 2800.0 / 8000.0) < 1e-9
     for r in (t8, a, b, w):
         assert r["traffic"] is None and r["avg_launch_ms"] > 0
+    # split-fp32 kernels run on the bf16 pipe with six MFMAs per fp32 MAC block: priced against 2500 / 6, not against the fp32-MFMA peak
+    sp = bench.binding_roofline("k_s3_conv<1,4,1>", dict(launches=5, ms=2.94, flops=594.5e9, nominal=594.5e9, bytes=0.0))
+    assert sp["bound"] == "mfma" and abs(sp["peak"] - 2500.0 / 6.0) < 1e-9 and abs(sp["achieved"] - 202.2) < 0.1 and abs(sp["frac"] - 202.2 / 416.67) < 1e-3
+    assert abs(sp["bf16_pipe_tflops"] - 6 * sp["achieved"]) < 1e-9 and "1.29 x the fp32-MFMA peak" in sp["peak_note"]
+
+
+def test_split_engine_enumerates_its_operators(monkeypatch):
+    """`functional._s3_jobs`: the operators of the default VxmDense plan that one batched launch packs for the split kernels when the
+    two finest levels qualify (stand-in for the C-side shape test: levels 0 and 1, channel counts in multiples of 8): forward operators of
+    the plain layers, and for a training step the adjoints `conv_bwd_data` will ask for -- per segment, 48-channel results as 32 + 16."""
+    from voxelmorph_amd.torch import functional as VF
+    m = vxm.networks.VxmDense((160, 192, 224), int_steps=0)
+    plan = m.unet_model.plan(m._feats, extra=((m.flow.out_channels, 1.0),))
+    params = list(m.unet_model.conv_params()) + [m.flow.weight, m.flow.bias]
+    monkeypatch.setattr(VF, "FP32_ENGINE", "split")
+    monkeypatch.setattr(VF, "S3_UP", False)
+    monkeypatch.setattr(VF, "s3_route", lambda c0, up0, c1, cout, B, D, H, W: (not up0) and c0 % 8 == 0 and c1 % 8 == 0 and cout >= 8 and D >= 80)
+    fwd = [(tuple(w.shape[:2]), lo, hi, flip, seg0) for w, lo, hi, flip, seg0 in VF._s3_jobs(plan, params, 1, (160, 192, 224), False, False)]
+    assert fwd == [((32, 16), 0, 16, False, 16), ((16, 32), 0, 32, False, 32), ((16, 16), 0, 16, False, 16)]          # enc1, rem1, rem2
+    train = [(tuple(w.shape[:2]), lo, hi, flip, seg0) for w, lo, hi, flip, seg0 in VF._s3_jobs(plan, params, 1, (160, 192, 224), True, False)]
+    adj = [j for j in train if j[3]]
+    assert ((32, 16), 0, 16, True, 32) in adj and ((16, 32), 0, 32, True, 16) in adj and ((16, 16), 0, 16, True, 16) in adj
+    assert ((32, 48), 32, 48, True, 32) in adj and ((32, 64), 32, 64, True, 32) in adj              # skip segments of rem0 and dec3
+    assert ((3, 16), 0, 16, True, 3) not in adj                                                      # 3 channels: not a split operand
+    assert [j for j in train if not j[3]] == fwd
 
 
 def test_bf16_engine_enumerates_the_weight_operators_of_a_step():

@@ -323,6 +323,34 @@ def test_conv_upsampled_segment_collapsed_weights(vxm, c0, c1, cout, vol):
     assert rel_l2(N(y), ref.numpy()) < 1e-5, "collapsed path used: %s" % bool(ok)
 
 
+@pytest.mark.parametrize("c0,c1,cout,vol", [(1, 1, 16, (3, 9, 68)), (2, 0, 16, (5, 7, 20)), (2, 1, 16, (4, 8, 64)), (16, 0, 3, (3, 9, 68)), (16, 0, 2, (5, 17, 132)),
+                                            (16, 0, 1, (4, 8, 64))])
+def test_few_channel_backward_weight_kernel(vxm, c0, c1, cout, vol):
+    """`k_fewch_bwd_weight` (first block: 1-3 input channels as a virtual concat of two tensors; flow conv: 1-3 output channels): weight
+    and bias gradient against fp64 autograd with two samples, rows that do not fill the 8-row tiles, more than one 64-column tile with a
+    partial last one, and the general kernel (VXM_FEWCH is read once per process, so the comparison partner here is fp64 only)."""
+    from voxelmorph_amd import _lib
+    from voxelmorph_amd.torch import functional as VF
+    D, H, W = vol
+    V, B, cin = D * H * W, 2, c0 + c1
+    torch.manual_seed(17 * cin + cout)
+    x0 = torch.randn(B, c0, D, H, W, device="cuda")
+    x1 = torch.randn(B, c1, D, H, W, device="cuda") if c1 else None
+    dz = torch.randn(B, cout, D, H, W, device="cuda")
+    v = _lib.lib().vxm_conv3d_k3_bwd_weight_variant(x0.data_ptr(), c0, c0 * V, 0, x1.data_ptr() if c1 else None, c1, c1 * V, dz.data_ptr(), cout * V, cout, D, H, W)
+    assert v // 10 == 3, "the dedicated kernel should take this shape (variant %d)" % v
+    gw, gb = torch.full((cout, cin, 3, 3, 3), 7.25, device="cuda"), torch.full((cout,), 7.25, device="cuda")
+    VF.conv_bwd_weight(VF._Workspace(x0.device), x0, c0, c0 * V, False, x1, c1, c1 * V, dz, cout, gw, gb, B, D, H, W)
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    wr = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    br = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv3d(xin.cpu().double(), wr, br, padding=1).backward(dz.cpu().double())
+    assert rel_l2(N(gw), wr.grad.numpy()) < 1e-5 and rel_l2(N(gb), br.grad.numpy()) < 1e-5
+    gw2, gb2 = torch.empty_like(gw), torch.empty_like(gb)
+    VF.conv_bwd_weight(VF._Workspace(x0.device), x0, c0, c0 * V, False, x1, c1, c1 * V, dz, cout, gw2, gb2, B, D, H, W)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)           # fixed summation order
+
+
 def test_conv_bwd_weight_bitwise_deterministic(vxm):
     """The backward-weight path has a fixed summation order: repeated launches on the same inputs must agree
     bit for bit (a race in the tile hand-over or the partial reduction would show here)."""
