@@ -398,12 +398,20 @@ def main():
         del wl
         torch.cuda.empty_cache()
         for key, name, eb, esteps in (("dense_bf16", "dense_bf16", 1, 8), ("diffeo_fp32_4_pairs_per_gpu", "diffeo_fp32", 4, 4),
-                                      ("semisup_fp32", "semisup_fp32", 1, 8)):
+                                      ("semisup_fp32", "semisup_fp32", 1, 8), ("diffeo_fp32_native_engine", "diffeo_fp32", 1, 8)):
+            engine = VF.FP32_ENGINE
             try:
+                if key == "diffeo_fp32_native_engine":     # the headline workload on the exact-fp32 MFMA kernels of rounds 1-2, for comparison
+                    if engine == "native":
+                        continue
+                    VF.FP32_ENGINE = "native"
                 w2 = Workload(vxm, vdist, name, shape, eb, dev, rank)
                 for _ in range(2):
                     w2.step()
+                if "VXM_OVERLAP_MIN_LEVEL" not in os.environ:
+                    VF.OVERLAP_MIN_LEVEL = 0                 # as the headline's value pass
                 t2, l2 = timed_steps(w2, esteps, vdist, dev)
+                VF.OVERLAP_MIN_LEVEL = keep
                 tm = profiler.KernelTimer()
                 timed_steps(w2, 2, vdist, dev, tm)
                 st2 = tm.resolve()
@@ -415,6 +423,9 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as exc:                       # an extra line must never take the headline down with it
                 extra[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            finally:
+                VF.FP32_ENGINE = engine
+                VF.OVERLAP_MIN_LEVEL = keep
 
     if rank != 0:
         return
