@@ -811,8 +811,9 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
     VXM_REQUIRE((reinterpret_cast<uintptr_t>(wpacked) & 15) == 0, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_fwd: packed weights must be 16-byte aligned");
     const ConvIn in = {x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up ? 1 : 0};
     hipStream_t s = VXM_STREAM(stream);
-    // (32-channel operators on 8 x 2 x 16 tiles -- 81 KB of LDS, two blocks per CU instead of one -- were measured: 32 spilled registers
-    // at the 128-VGPR limit of four waves per SIMD and 2.56 instead of 2.02 ms per step on these launches; not kept)
+    // (32-channel operators with two blocks per CU were measured twice and not kept: on 8 x 2 x 16 tiles -- 81 KB of LDS -- 32 spilled registers
+    // at the 128-VGPR limit of four waves per SIMD, 2.56 instead of 2.02 ms per step on these launches; as two passes of the 16-channel
+    // instance over one staged chunk -- weights of one pass in LDS at a time -- 41 spilled registers, rem1 backward-data 1.49 instead of 1.39 ms)
     if (v.NCT == 2) s3_launch<2, 4, 1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
     else if (v.CB == 2) s3_launch<1, 4, 2>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
     else s3_launch<1, 4, 1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);

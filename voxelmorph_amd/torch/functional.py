@@ -15,7 +15,10 @@ from .._lib import call, ptr, require_device, stream
 
 SPLIT_48 = True     # conv_bwd_data: produce 48-channel results as 32 + 16 (module-level switch for A/B timing)
 OVERLAP_SMALL_LEVELS = os.environ.get("VXM_NO_OVERLAP", "") != "1"     # UnetFn.backward: weight gradients of the coarse levels on a second HIP stream
-OVERLAP_MIN_LEVEL = int(os.environ.get("VXM_OVERLAP_MIN_LEVEL", "1"))   # first U-Net level whose weight gradients go to the second stream
+# first U-Net level whose weight gradients go to the second stream.  0 (default since round 3): all of them -- the tails of the big
+# full-resolution launches fill with each other's blocks (-1.6 % per step, measured); 1 keeps the full-resolution launches serialised, which
+# is what bench.py's per-kernel pass sets so that a launch's duration is its own.
+OVERLAP_MIN_LEVEL = int(os.environ.get("VXM_OVERLAP_MIN_LEVEL", "0"))
 # fp32 engine of the 3-D convolutions: "split" = the plain full-resolution layers run on the bf16 matrix pipe with every fp32 operand
 # split into three bf16 pieces (csrc/conv_s3.hip: fp32-level accuracy, 2.67x the pipe rate); "native" = v_mfma_f32_16x16x4_f32
 # everywhere (csrc/conv_fwd.hip).  VXM_S3_UP=1 also sends cat([upsample(x0), x1]) layers through the split kernel (nominal FLOPs,
@@ -287,7 +290,12 @@ def _pack_ver(t):
 
 def s3_route(c0, up0, c1, cout, B, D, H, W):
     """does this conv launch (forward operator over the virtual concat, or an adjoint as a forward) go to the split kernel?"""
-    if FP32_ENGINE != "split" or (up0 and not S3_UP):
+    if FP32_ENGINE != "split":
+        return False
+    # cat([upsample(x0), x1]): through the upsampling gather the split kernel executes the nominal FLOPs, the fp32 kernel 8 / 27 of the
+    # upsampled segment's -- measured, the split kernel wins when the skip segment is at least as wide as the upsampled one (dec3 at L1:
+    # 0.42 vs 0.53 ms) and ties when it is half as wide (rem0: 2.60 vs 2.56 ms: stays on the collapsed kernel); VXM_S3_UP=1 forces it
+    if up0 and not (S3_UP or c1 >= c0):
         return False
     return bool(_lib.lib().vxm_conv3d_k3_s3_ok(c0, c1, cout, B, D, H, W))
 
