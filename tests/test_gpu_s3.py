@@ -136,7 +136,7 @@ def test_s3_scale_invariance_and_small_magnitudes(VF):
     assert bool((z == 0).all())
 
 
-@pytest.mark.parametrize("c,cout,vol,B", [(16, 16, (4, 8, 32), 2), (32, 16, (5, 7, 40), 2), (16, 32, (6, 4, 64), 1), (48, 32, (3, 9, 33), 2)])
+@pytest.mark.parametrize("c,cout,vol,B", [(16, 16, (4, 8, 32), 2), (32, 16, (5, 7, 40), 2), (16, 32, (6, 4, 64), 1), (48, 32, (3, 9, 34), 2)])
 def test_s3_backward_weight_vs_fp64(VF, c, cout, vol, B):
     """vxm_conv3d_k3_s3_bwd_weight directly: weight and bias gradient against fp64 autograd, partial tiles in every direction, a
     destination that is a channel sub-range of a wider weight array (nothing else written), and bit-wise run-to-run determinism."""
@@ -161,6 +161,18 @@ def test_s3_backward_weight_vs_fp64(VF, c, cout, vol, B):
     gb2 = torch.empty_like(gb)
     VF.s3_bwd_weight(ws, x, c, c * V, dz, cout, gw2, c + pad, pad, gb2, B, D, H, W)
     assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+
+
+def test_s3_backward_weight_refuses_odd_width(VF):
+    """the staging of k_s3_bwd_weight loads W-neighbouring voxel pairs: an odd W is not eligible (the dispatcher keeps the fp32-MFMA kernel)
+    and a direct launch is a shape error, not a wrong gradient"""
+    from voxelmorph_amd import _lib
+    assert _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(16, 16, 4, 64, 64, 66) == 1
+    assert _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(16, 16, 4, 64, 64, 65) == 0
+    x = torch.randn(1, 16, 4, 8, 33, device="cuda")
+    gw, gb = torch.empty(16, 16, 3, 3, 3, device="cuda"), torch.empty(16, device="cuda")
+    with pytest.raises(Exception, match="even"):
+        VF.s3_bwd_weight(VF._Workspace(x.device), x, 16, x[0].numel(), x, 16, gw, 16, 0, gb, 1, 4, 8, 33)
 
 
 def _rerun(env_extra, select, files=("tests/test_gpu_s3.py",), timeout=900):

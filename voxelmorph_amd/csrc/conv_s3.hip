@@ -425,13 +425,25 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
     const int lp = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;     // lane pattern of the transposing read
     const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};       // bf16 1.0 x 8: B operand of the bias sum
 
-    // staging roles of a thread, fixed for the kernel: slot i = tid + THREADS j = (voxel, 8-channel half) of one haloed X plane / of
-    // the dZ tile; a slot is 8 planar fp32 loads (one per channel), split into three 16-byte words
-    constexpr int NXP = SW_HR * SW_XW * 2, NXI = (NXP + SW_THREADS - 1) / SW_THREADS;
-    constexpr int NZ = SW_TD * SW_TH * SW_TW * 2, NZI = (NZ + SW_THREADS - 1) / SW_THREADS;
-    float xr[2][NXI][8], zr[NZI][8];
-    int xoff[NXI], zoff[NZI];                                    // byte offsets inside a depth slice of the tensor (VXM_OOB: padding)
-    int xv[2][NXI], zv[NZI];                                     // the offsets the in-flight loads were issued with (kept live, see keep_offsets)
+    // Staging roles of a thread, fixed for the kernel.  A slot is (PAIR of W-neighbouring voxels, 8-channel half): 8 planar fp32 dwordx2 loads
+    // (one per channel), split into 2 x 3 16-byte words.  Pairs start at even w (W is even, tiles start at multiples of 32), so a pair is inside
+    // the volume or outside it as a whole: the haloed row w0 - 1 .. w0 + 32 is covered by the 18 pairs from w0 - 2, whose first and last voxel
+    // are dropped at the LDS write.  A tile stages 2 haloed X planes (2 x 6 rows x 18 pairs x 2 halves = 432 slots) and the dZ tile (2 x 4
+    // rows x 16 pairs x 2 = 256 slots) on 768 threads in ONE round: waves 0 .. 6 stage X, waves 7 .. 10 dZ (wave-uniform roles: one
+    // descriptor per wave).  What bounded the first versions was the NUMBER of vector-memory instructions -- one dword per lane and channel,
+    // 192 wave-loads per tile: with the loads removed the kernel ran 1.40 -> 0.95 ms (rem1), with split + LDS writes removed only
+    // 1.51 -> 1.40 -- hence pairs: half the instructions for the same bytes.
+    constexpr int SW_XPAIRS = SW_XW / 2 + 1, NXS = SW_HR * SW_XPAIRS * 2, NZS = SW_TD * SW_TH * (SW_TW / 2) * 2;    // 18, 216 per plane, 256
+    static_assert(SW_XW % 2 == 0 && 2 * NXS <= 7 * 64 && NZS == 4 * 64 && SW_WAVES >= 11, "slot plan");
+    const int s_role = wave <= 6 ? 1 : (wave <= 10 ? 2 : 0);                             // 1 = X pair, 2 = dZ pair, 0 = none (wave-uniform)
+    const int s_i = s_role == 1 ? tid : tid - 7 * 64;                                    // X: slot of the plane pair (>= 2 NXS: idle lane); dZ: slot of the tile
+    const int x_pl = s_i >= NXS ? 1 : 0, x_r = s_i - x_pl * NXS;                         // X role: plane of the pair, slot inside the plane
+    const int z_ds = wave >= 9 ? 1 : 0;                                                  // dZ role: depth slice of the tile (wave-uniform)
+    float ra[8], rb[8];                                          // first / second voxel of the pair, 8 channels
+    unsigned ka[3][4], kb[3][4];
+    int off0 = VXM_OOB, ldst = 0;                                // per task: byte offset inside a depth slice; LDS byte offset of the first voxel's word inside
+                                                                 // a plane / the dZ tile, | 1: drop the first voxel, | 2: drop the second
+    int vk;                                                      // the offset the in-flight loads were issued with (kept live until the MFMA phase is over)
 
     for (int task = k_lo; task < k_hi; ++task) {
         const int col = task / tk.nseg, seg = task - col * tk.nseg;
@@ -441,106 +453,76 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
         const int dbase = td0 * SW_TD, h0 = th * SW_TH, w0 = tw * SW_TW;
         const __amdgpu_buffer_rsrc_t rx = vxm_rsrc(x + (size_t)b * x_bs, (unsigned)C * (unsigned)V * 4u);
         const __amdgpu_buffer_rsrc_t rz = vxm_rsrc(dz + (size_t)b * dz_bs, (unsigned)Cdz * (unsigned)V * 4u);
-#pragma unroll
-        for (int j = 0; j < NXI; ++j) {
-            const int i = tid + SW_THREADS * j;
-            const int cb = i & 1, v = i >> 1, hh = v / SW_XW, hw = v - hh * SW_XW;
-            const int gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-            const bool ok = i < NXP && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && q * 16 + cb * 8 < C;
-            xoff[j] = !ok ? VXM_OOB : ((q * 16 + cb * 8) * V + gh * W + gw) << 2;
-        }
-#pragma unroll
-        for (int j = 0; j < NZI; ++j) {
-            const int i = tid + SW_THREADS * j;
-            const int cb = i & 1, v = i >> 1;
-            const int zd = v / (SW_TH * SW_TW), r2 = v - zd * SW_TH * SW_TW, zh = r2 / SW_TW, zw = r2 - zh * SW_TW;
-            const bool ok = i < NZ && h0 + zh < H && w0 + zw < W && cot * 16 + cb * 8 < Cdz;
-            // depth validity: the tile's second slice (zd = 1) may lie beyond D -- folded in per tile through `zlast`
-            zoff[j] = !ok ? VXM_OOB : ((((cot * 16 + cb * 8) * V + (zd * H + h0 + zh) * W + w0 + zw) << 2) | zd);      // bit 0: depth slice of the slot
+        if (s_role == 1) {
+            const int cb = x_r & 1, pr = x_r >> 1, hh = pr / SW_XPAIRS, pp = pr - hh * SW_XPAIRS;
+            const int gh = h0 - 1 + hh, gw = w0 - 2 + 2 * pp;
+            const bool live = s_i < 2 * NXS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && q * 16 + cb * 8 < C;
+            off0 = live ? ((q * 16 + cb * 8) * V + gh * W + gw) << 2 : VXM_OOB;
+            ldst = ((hh * SW_XW + 2 * pp - 1) * 32 + cb * 16) | (pp == 0 ? 1 : 0) | (pp == SW_XPAIRS - 1 ? 2 : 0);
+        } else if (s_role == 2) {
+            const int cb = s_i & 1, r2 = (s_i >> 1) & (SW_TH * SW_TW / 2 - 1), zh = r2 / (SW_TW / 2), zw = 2 * (r2 - zh * (SW_TW / 2));
+            const bool live = h0 + zh < H && w0 + zw < W && cot * 16 + cb * 8 < Cdz;
+            off0 = live ? ((cot * 16 + cb * 8) * V + (z_ds * H + h0 + zh) * W + w0 + zw) << 2 : VXM_OOB;
+            ldst = ((z_ds * SW_TH + zh) * SW_TW + zw) * 32 + cb * 16;
         }
 
-        // planes p0, p0 + 1 of this task (plane p = global depth dbase - 1 + p) -> registers / -> ring slots p % 6
-        auto load_planes = [&](int p0) __attribute__((always_inline)) {
+        // planes p0, p0 + 1 of this task (plane p = global depth dbase - 1 + p) and the dZ tile tz (tz < 0: none) -> registers.  Branch-free:
+        // a plane outside the volume ORs the out-of-range bit into the lane offsets (selects on wave-uniform conditions would become
+        // branches around the loads, and the joins behind them make the compiler wait for the prefetch at the START of the MFMA phase)
+        auto load_tile = [&](int p0, int tz) __attribute__((always_inline)) {
+            const int gd0 = dbase - 1 + p0, gd1 = gd0 + 1;           // wave-uniform
+            int o0 = (unsigned)gd0 < (unsigned)D ? (gd0 * HW) << 2 : 0, f0 = (unsigned)gd0 < (unsigned)D ? 0 : VXM_OOB;
+            int o1 = (unsigned)gd1 < (unsigned)D ? (gd1 * HW) << 2 : 0, f1 = (unsigned)gd1 < (unsigned)D ? 0 : VXM_OOB;
+            const int gz = dbase + (tz < 0 ? 0 : tz) * SW_TD;         // first depth slice of the dZ tile (always < D)
+            int fz = tz < 0 ? VXM_OOB : 0, fz1 = (tz < 0 || gz + 1 >= D) ? VXM_OOB : 0;
+            asm volatile("" : "+v"(f0), "+v"(f1), "+v"(fz), "+v"(fz1));
+            const bool xrole = s_role != 2;                           // wave-uniform
+            vk = xrole ? ((off0 + (x_pl ? o1 : o0)) | (x_pl ? f1 : f0)) : (off0 | (z_ds ? fz1 : fz));
+            const __amdgpu_buffer_rsrc_t rd = xrole ? rx : rz;
+            const int sb = xrole ? 0 : (gz * HW) << 2;
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                const int gd = dbase - 1 + p0 + pl;                 // wave-uniform
-                const bool dok = (unsigned)gd < (unsigned)D;
-                const int soff = dok ? (gd * HW) << 2 : 0;
-                // branch-free: a plane outside the volume ORs the out-of-range bit into every lane offset.  (Written as a select on the
-                // wave-uniform `dok`, the compiler branches around the loads, and the joins behind those branches make it wait for
-                // the prefetch -- s_waitcnt vmcnt -- at the START of the MFMA phase: seen in the ISA.)
-                int bad = dok ? 0 : VXM_OOB;
-                asm volatile("" : "+v"(bad));
-#pragma unroll
-                for (int j = 0; j < NXI; ++j) {
-                    xv[pl][j] = xoff[j] | bad;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xr[pl][j][e] = vxm_bload(rx, xv[pl][j], soff + ((e * V) << 2));
-                }
+            for (int e = 0; e < 8; ++e) {
+                const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, vk, sb + ((e * V) << 2), 0));
+                ra[e] = t2.x; rb[e] = t2.y;
             }
         };
-        // split (registers only) and write (LDS) are separate steps: a wave splits the tile it prefetched right after ITS OWN MFMA loop,
-        // while the waves it shares the SIMD with are still multiplying, and only the LDS writes wait for the barrier
-        unsigned xk[2][NXI][3][4], zk[NZI][3][4];
-        auto split_planes = [&]() __attribute__((always_inline)) {
+        // split (registers only) and write (LDS) are separate steps: a wave splits the tile it prefetched right after ITS OWN MFMA loop
+        auto split_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                for (int j = 0; j < NXI; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) s3_split2(xr[pl][j][2 * e], xr[pl][j][2 * e + 1], xk[pl][j][0][e], xk[pl][j][1][e], xk[pl][j][2][e]);
+            for (int e = 0; e < 4; ++e) {
+                s3_split2(ra[2 * e], ra[2 * e + 1], ka[0][e], ka[1][e], ka[2][e]);
+                s3_split2(rb[2 * e], rb[2 * e + 1], kb[0][e], kb[1][e], kb[2][e]);
+            }
         };
-        auto write_planes = [&](int p0) __attribute__((always_inline)) {
+        auto write_tile = [&](int p0, bool with_z) __attribute__((always_inline)) {
+            if (s_role == 1) {
+                if (s_i < 2 * NXS) {
+                    char* const d = Xs + ((p0 + x_pl) % SW_RING) * SW_PLANE + (ldst & ~3);
+                    if (!(ldst & 1)) {
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                char* const dst = Xs + ((p0 + pl) % SW_RING) * SW_PLANE;
-#pragma unroll
-                for (int j = 0; j < NXI; ++j)
-                    if (tid + SW_THREADS * j < NXP) {
-#pragma unroll
-                        for (int p = 0; p < 3; ++p)
-                            *reinterpret_cast<u32x4*>(dst + p * SW_XPIECE + (tid + SW_THREADS * j) * 16) =
-                                (u32x4){xk[pl][j][p][0], xk[pl][j][p][1], xk[pl][j][p][2], xk[pl][j][p][3]};
+                        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(d + p * SW_XPIECE) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
                     }
-            }
-        };
-        auto store_planes = [&](int p0) __attribute__((always_inline)) { split_planes(); write_planes(p0); };
-        auto load_z = [&](int t) __attribute__((always_inline)) {
-            const int gd = dbase + t * SW_TD;                      // first depth slice of the tile (always < D)
-            int nolast = gd + 1 < D ? 0 : 1;                      // the tile's second depth slice lies beyond the volume
-            asm volatile("" : "+v"(nolast));
-            const int soff = (gd * HW) << 2;
+                    if (!(ldst & 2)) {
 #pragma unroll
-            for (int j = 0; j < NZI; ++j) {
-                zv[j] = (zoff[j] & ~3) | ((zoff[j] & nolast) << 31);                // branch-free, as load_planes
-#pragma unroll
-                for (int e = 0; e < 8; ++e) zr[j][e] = vxm_bload(rz, zv[j], soff + ((e * V) << 2));
-            }
-        };
-        auto split_z = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < NZI; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s3_split2(zr[j][2 * e], zr[j][2 * e + 1], zk[j][0][e], zk[j][1][e], zk[j][2][e]);
-        };
-        auto write_z = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < NZI; ++j)
-                if (tid + SW_THREADS * j < NZ) {
-#pragma unroll
-                    for (int p = 0; p < 3; ++p)
-                        *reinterpret_cast<u32x4*>(Zs + p * SW_ZPIECE + (tid + SW_THREADS * j) * 16) = (u32x4){zk[j][p][0], zk[j][p][1], zk[j][p][2], zk[j][p][3]};
+                        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(d + p * SW_XPIECE + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                    }
                 }
+            } else if (s_role == 2 && with_z) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    *reinterpret_cast<u32x4*>(Zs + p * SW_ZPIECE + ldst) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
+                    *reinterpret_cast<u32x4*>(Zs + p * SW_ZPIECE + ldst + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                }
+            }
         };
-        auto store_z = [&]() __attribute__((always_inline)) { split_z(); write_z(); };
 
         __syncthreads();                                        // every wave is done with the previous task
-        load_planes(0);
-        load_z(0);
-        store_planes(0);
-        load_planes(2);
-        store_z();
-        store_planes(2);
+        load_tile(0, 0);
+        split_tile();
+        write_tile(0, true);
+        load_tile(2, -1);
+        split_tile();
+        write_tile(2, false);
         __syncthreads();
 
         for (int t = 0; t < ntile; ++t) {
@@ -548,8 +530,7 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
             const char* const xp = Xs + ((2 * t + ds + kd) % SW_RING) * SW_PLANE;
             // the raw loads of tile t + 1 (2 X planes + the dZ tile) are in flight under the MFMAs of tile t; unconditional: past
             // the last tile the planes lie beyond this task's depth range and are simply not stored
-            load_planes(2 * t + 4);
-            load_z(more ? t + 1 : t);
+            load_tile(2 * t + 4, more ? t + 1 : t);
             __builtin_amdgcn_sched_barrier(0);
             // The fp32 accumulation of the bf16 MFMA TRUNCATES (tools/bw_accuracy.py: a chain of ~10^4 MFMAs into one accumulator drifts,
             // 1.5e-5 against 4e-6 for the fp32 MFMA on cancelling sums).  So an MFMA chain lives for ONE tile -- it starts from zero and is
@@ -600,17 +581,10 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
             __builtin_amdgcn_sched_barrier(0);
             // the address registers of the loads in flight stay live until here: reused earlier, the compiler guards every reuse
             // with s_waitcnt vmcnt(..), i.e. waits for the prefetch at the start of the MFMA phase (seen in the ISA)
-#pragma unroll
-            for (int j = 0; j < NXI; ++j) asm volatile("" ::"v"(xv[0][j]), "v"(xv[1][j]));
-#pragma unroll
-            for (int j = 0; j < NZI; ++j) asm volatile("" ::"v"(zv[j]));
-            split_planes();                                      // before the barrier: overlaps the other waves' MFMAs
-            split_z();
+            asm volatile("" ::"v"(vk));
+            split_tile();                                        // before the barrier: overlaps the other waves' MFMAs
             __syncthreads();                                     // every wave is done reading tile t (X ring slots of t - 1 and the dZ tile are free)
-            if (more) {
-                write_planes(2 * t + 4);
-                write_z();
-            }
+            if (more) write_tile(2 * t + 4, true);
             __syncthreads();
         }
     }
@@ -822,7 +796,7 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
 
 int vxm_conv3d_k3_s3_bwd_weight_ok(int C, int Cout, int B, int D, int H, int W) {
     if (C <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    if (C % 16 || Cout % 16 || Cout < 16) return 0;
+    if (C % 16 || Cout % 16 || Cout < 16 || W % 2) return 0;      // W even: the staging loads voxel pairs
     if ((C / 16) * (Cout / 16) > sw_cus()) return 0;
     if ((long long)(C > Cout ? C : Cout) * D * H * W >= (1ll << 29)) return 0;
     const long long ntiles = (long long)B * ((D + S3_TD - 1) / S3_TD) * ((H + 3) / 4) * ((W + 15) / 16);
@@ -841,9 +815,9 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
                                 int ci_off, float* gb, void* work, size_t work_bytes, int B, int D, int H, int W, void* stream) {
     VXM_REQUIRE(x && dz && gw && work, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3_bwd_weight: null pointer");
     if (int e = check_conv("vxm_conv3d_k3_s3_bwd_weight", C, 0, 0, Cout, B, D, H, W)) return e;
-    VXM_REQUIRE(C % 16 == 0 && Cout % 16 == 0 && ci_off >= 0 && ci_off + C <= gw_cin, VXM_ERR_BAD_SHAPE,
-                "vxm_conv3d_k3_s3_bwd_weight: %d input / %d output channels (multiples of 16), destination channels [%d, %d) of %d", C, Cout, ci_off,
-                ci_off + C, gw_cin);
+    VXM_REQUIRE(C % 16 == 0 && Cout % 16 == 0 && ci_off >= 0 && ci_off + C <= gw_cin && W % 2 == 0, VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3_bwd_weight: %d input / %d output channels (multiples of 16), destination channels [%d, %d) of %d, W = %d (even)", C,
+                Cout, ci_off, ci_off + C, gw_cin, W);
     const int Q = C / 16, NCO = Cout / 16;
     VXM_REQUIRE(Q * NCO <= sw_cus(), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_bwd_weight: %d x %d channel tiles exceed the compute units", Q, NCO);
     int NBLK = 1;
