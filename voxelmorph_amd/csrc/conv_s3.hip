@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) k_s3_pack_weights(const S3PackBatch batch
 // four haloed X planes in a 6-slot LDS ring, the raw fp32 loads of tile t + 1 are in flight in registers under the MFMAs of tile
 // t.  LDS: 3 pieces x (6 planes x 6 x 34 voxels + 2 x 4 x 32 voxels) x 32 B = 142,080 B (three pieces leave no room for a second
 // dZ buffer: two barriers per tile).  Partials per block, summed in a fixed order by k_s3_reduce_partials (deterministic).
-constexpr int SW_WAVES = 12, SW_THREADS = 64 * SW_WAVES, SW_NSL = 4;     // waves = (row half, depth slice, kd); partial slices = (depth slice, row half)
+constexpr int SW_WAVES = 12, SW_THREADS = 64 * SW_WAVES, SW_NSL = 1;     // waves = (row half, depth slice, kd); a block combines its four (depth slice, row half) sums and writes ONE partial slice
 constexpr int SW_TD = 2, SW_TH = 4, SW_TW = 32, SW_XW = SW_TW + 2, SW_HR = SW_TH + 2, SW_RING = 6;
 constexpr int SW_PLANE = SW_HR * SW_XW * 32;                  // bytes of one haloed X plane of one piece: [hh][hw][16 ci]
 constexpr int SW_XPIECE = SW_RING * SW_PLANE;
@@ -589,19 +589,37 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
         }
     }
 
-    // ---- partials: part[bx][q][slice = 2 ds + rh][tap 0..27][co 16 NCO][ci 16]; D layout: lane (kg, n) holds co = 4 kg + r, ci = n
+    // ---- partials: part[bx][q][tap 0..27][co 16 NCO][ci 16].  The four waves (row half, depth slice) that share a kd hold sums of the same
+    // taps: they are combined through LDS in a fixed order first (the staging buffers are free now), so a block writes 28 x 16 x 16
+    // floats instead of four times that -- the partials were 29 MB per launch on rem1, read back by the reducer.
+    // D layout: lane (kg, n) holds co = 4 kg + r, ci = n
     const int Q = NCOMBO / NCO;
-    float* const pp = part + ((((size_t)bx * Q + q) * SW_NSL + 2 * ds + rh) * 28) * (16 * NCO) * 16;
+    float* const Ls = reinterpret_cast<float*>(smem);            // [wave 12][tap 9][co 16][ci 16] + [slice 4][co 16][ci 16] (bias sums)
+    __syncthreads();
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                pp[((size_t)(kd * 9 + kh * 3 + kw) * (16 * NCO) + cot * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = tot[kh][kw][r];
+            for (int r = 0; r < 4; ++r) Ls[((wave * 9 + kh * 3 + kw) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = tot[kh][kw][r];
     if (kd == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pp[((size_t)27 * (16 * NCO) + cot * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = totb[r];
+        for (int r = 0; r < 4; ++r) Ls[((SW_WAVES * 9 + 2 * ds + rh) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = totb[r];
+    }
+    __syncthreads();
+    float* const pp = part + (((size_t)bx * Q + q) * 28) * (16 * NCO) * 16 + cot * 256;
+    for (int e = tid; e < 28 * 256; e += SW_THREADS) {
+        const int tap = e >> 8, i = e & 255;
+        float v;
+        if (tap < 27) {
+            const int kd_ = tap / 9, t9 = tap - 9 * kd_;         // waves (rh, ds, kd_) = rh 6 + ds 3 + kd_, summed in slice order 2 ds + rh
+            const float* const l = Ls + (kd_ * 9 + t9) * 256 + i;
+            v = ((l[0] + l[6 * 9 * 256]) + (l[3 * 9 * 256] + l[9 * 9 * 256]));
+        } else {
+            const float* const l = Ls + SW_WAVES * 9 * 256 + i;
+            v = ((l[0] + l[256]) + (l[512] + l[768]));
+        }
+        pp[(size_t)tap * (16 * NCO) * 16 + i] = v;
     }
 }
 
