@@ -192,25 +192,62 @@ __device__ __forceinline__ void vg_axis(float xp, int p, int S, float& fr, int& 
     (void)S;
 }
 
-// One thread per voxel of the 4 x 8 x 32 tile (1024-thread blocks, two per CU: 32 waves hide the latency chain load -> corners ->
-// 24 gathers -> LDS reads that a 4-voxel-per-thread loop exposed).  The staged record of a sender is SIX floats: per axis one
-// value E_a = fr_a with the floor code in its SIGN BIT (negative: floor(x'_a) = p_a - 1; -0.0 is a valid value), and its gradient
-// with the "near" test folded in (a sender that is not near stages g = 0: its scatter belongs to the atomic pass) -- 24 bytes per
-// voxel (one ds_read_b128 + one ds_read_b64 per candidate, 49 KB of LDS per block).  The sender's weight towards the target at
-// offset o is rebuilt per candidate from E_a with the offset known at compile time: o = +1: floor code 1 ? 1 - fr : 0;  o = 0:
-// code ? fr : 1 - fr;  o = -1: code ? 0 : fr  (~10 vector instructions per candidate; the first gather unpacked a code word and
-// compared it against every offset, ~24 per candidate, and a version with all nine weights precomputed in 48-byte records needed
-// 96 KB of LDS, one block per CU, and was SLOWER, 39 vs 30 us per step: the step is bound by latency, i.e. by resident waves).
+// One thread per voxel of the 4 x 8 x 32 tile (1024-thread blocks, two per CU).  A block makes ONE trip to memory (the first gather made
+// four: v -> near test -> g -> barrier -> own v, g -> 24 corner gathers): a thread loads v and g of its own voxel and of one halo voxel
+// of the tile grown by one (1016 halo voxels on 1024 threads) in a single batch of 12 loads, and everything after the barrier is served
+// from LDS.  That took the backward chain of the headline pair from 235 to 212 us; what bounds the step now is the vector ALU: 816 VALU
+// instructions per thread (ISA count; 27 candidates x ~14, three IEEE divisions per staged voxel for the reference's normalise /
+// un-normalise round trip, the 8-corner derivative) = 13440 waves x 816 x 4 cycles over 1024 SIMDs = 21 us of a 27 us step.
+//   * the staged record of a sender is SIX floats: per axis one value E_a = fr_a with the floor code in its SIGN BIT (negative:
+//     floor(x'_a) = p_a - 1; -0.0 is a valid value), and its gradient with the "near" test folded in (a sender that is not near stages
+//     g = 0: its scatter belongs to the atomic pass) -- one ds_read_b128 + one ds_read_b64 per candidate.  The sender's weight towards
+//     the target at offset o is rebuilt per candidate from E_a with the offset known at compile time: o = +1: floor code 1 ? 1 - fr : 0;
+//     o = 0: code ? fr : 1 - fr;  o = -1: code ? 0 : fr  (~10 vector instructions per candidate; the first gather unpacked a code word
+//     and compared it against every offset, ~24 per candidate, and a version with all nine weights precomputed in 48-byte records
+//     needed 96 KB of LDS, one block per CU, and was SLOWER, 39 vs 30 us per step);
+//   * v of the grown tile (3 planes of floats): the 8 corners of x'(q) of a near voxel q lie in its 3x3x3 neighbourhood, so the
+//     derivative through the sampling position reads them from LDS (a voxel that is not near gathers them from global memory).
+// 36 bytes per staged voxel, 73 KB per block.
 typedef float vg_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float vg_weight(float e, int o) {
     const bool r = (__float_as_uint(e) >> 31) != 0u;              // floor code: 1 <=> floor(x') = p - 1
     const float a = fabsf(e);
     return o > 0 ? (r ? 1.0f - a : 0.0f) : (o == 0 ? (r ? a : 1.0f - a) : (r ? 0.0f : a));
 }
+constexpr int VG_NHALO = VG_LN - VG_TD * VG_TH * VG_TW;          // 1016 voxels of the grown tile outside the tile
+static_assert(VG_NHALO <= VG_TD * VG_TH * VG_TW, "one halo voxel per thread");
+// halo voxel j -> (lz, ly, lx) of the grown tile: the two z faces, then the y faces of the inner planes, then their x edges
+__device__ __forceinline__ void vg_halo_cell(int j, int& lz, int& ly, int& lx) {
+    constexpr int FZ = VG_LH * VG_LW, NZ = 2 * FZ, NY = VG_TD * 2 * VG_LW;
+    if (j < NZ) {
+        const int s = j / FZ, r = j - s * FZ;
+        lz = s ? VG_LD - 1 : 0; ly = r / VG_LW; lx = r - ly * VG_LW;
+    } else if (j < NZ + NY) {
+        const int r = j - NZ, z = r / (2 * VG_LW), r2 = r - z * (2 * VG_LW), s = r2 / VG_LW;
+        lz = 1 + z; ly = s ? VG_LH - 1 : 0; lx = r2 - s * VG_LW;
+    } else {
+        const int r = j - NZ - NY, z = r / (2 * VG_TH), r2 = r - z * (2 * VG_TH);
+        lz = 1 + z; ly = 1 + (r2 >> 1); lx = (r2 & 1) ? VG_LW - 1 : 0;
+    }
+}
+struct VgStaged { float e[3]; bool near; int frel[3]; };
+// fr / floor code / near test of a voxel with step vector v at (pz, py, px)
+__device__ __forceinline__ VgStaged vg_stage(float v0, float v1, float v2, int pz, int py, int px, int D, int H, int W) {
+    VgStaged s;
+    float fz, fy, fx;
+    bool nz, ny, nx;
+    vg_axis(vxm_src_coord(pz, v0, D), pz, D, fz, s.frel[0], nz);
+    vg_axis(vxm_src_coord(py, v1, H), py, H, fy, s.frel[1], ny);
+    vg_axis(vxm_src_coord(px, v2, W), px, W, fx, s.frel[2], nx);
+    s.near = nz && ny && nx;
+    s.e[0] = s.frel[0] ? -fz : fz; s.e[1] = s.frel[1] ? -fy : fy; s.e[2] = s.frel[2] ? -fx : fx;      // fr >= 0: the sign bit is free (-0.0 when fr == 0)
+    return s;
+}
 __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __restrict__ in, float scale, const float* __restrict__ gout,
                                                                  float* __restrict__ gin, unsigned* __restrict__ far_count, int D, int H, int W) {
     __shared__ f32x4 recA[VG_LN];                                 // {E_z, E_y, E_x, g_0 (0 when not near)}
-    __shared__ vg_f32x2 recB[VG_LN];                                 // {g_1, g_2}
+    __shared__ vg_f32x2 recB[VG_LN];                              // {g_1, g_2}
+    __shared__ float vL[3][VG_LN];                                // v = in * scale
     const int tid = threadIdx.x, tx = tid & 31, ty = (tid >> 5) & 7, dd = tid >> 8;
     const int ntw = (W + VG_TW - 1) / VG_TW, nth = (H + VG_TH - 1) / VG_TH;
     int t = blockIdx.x;
@@ -219,55 +256,66 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __
     const int d0 = (t / nth) * VG_TD;
     const int b = blockIdx.y;
     const int HW = H * W, V = D * HW;
-    // three planes per tensor behind one buffer descriptor each: 32-bit byte offsets, channel step in the scalar offset
+    // three planes per tensor behind one buffer descriptor each: 32-bit byte offsets, channel step in the scalar offset; a voxel outside
+    // the volume gets an out-of-range offset and loads zeros
     const __amdgpu_buffer_rsrc_t rv = vxm_rsrc(in + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
     const __amdgpu_buffer_rsrc_t rgo = vxm_rsrc(gout + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
     const __amdgpu_buffer_rsrc_t rgi = vxm_rsrc(gin + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
     const int V4 = V << 2;
-    unsigned nfar = 0;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int i = tid + 1024 * k;
-        if (i < VG_LN) {
-            const int lx = i % VG_LW, r = i / VG_LW, ly = r % VG_LH, lz = r / VG_LH;
-            const int pz = d0 - 1 + lz, py = h0 - 1 + ly, px = w0 - 1 + lx;
-            float ez = 0.f, ey = 0.f, ex = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f;
-            if ((unsigned)pz < (unsigned)D && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W) {
-                const int p4 = (pz * HW + py * W + px) << 2;
-                const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
-                float fz, fy, fx;
-                int rz, ry, rx;
-                bool nz, ny, nx;
-                vg_axis(vxm_src_coord(pz, v0, D), pz, D, fz, rz, nz);
-                vg_axis(vxm_src_coord(py, v1, H), py, H, fy, ry, ny);
-                vg_axis(vxm_src_coord(px, v2, W), px, W, fx, rx, nx);
-                if (nz && ny && nx) {
-                    g0 = vxm_bload(rgo, p4, 0); g1 = vxm_bload(rgo, p4, V4); g2 = vxm_bload(rgo, p4, 2 * V4);
-                    ez = rz ? -fz : fz; ey = ry ? -fy : fy; ex = rx ? -fx : fx;          // fr >= 0: the sign bit is free (-0.0 when fr == 0)
-                } else if (lz >= 1 && lz <= VG_TD && ly >= 1 && ly <= VG_TH && lx >= 1 && lx <= VG_TW) {
-                    ++nfar;                               // counted once, by the tile that owns the voxel
-                }
-            }
-            recA[i] = (f32x4){ez, ey, ex, g0};
-            recB[i] = (vg_f32x2){g1, g2};
-        }
-    }
-    if (nfar) atomicAdd(far_count, nfar);
-    __syncthreads();
+    // own voxel q and one halo voxel: 12 loads in one batch
     const int h = h0 + ty, w = w0 + tx, d = d0 + dd;
-    if (h >= H || w >= W || d >= D) return;
+    const bool own_in = h < H && w < W && d < D;
     const int p4 = (d * HW + h * W + w) << 2;
-    // ---- local part: identity + derivative through the sampling position (the 8 corners of x'(q) gathered from v itself)
-    const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
-    const float g0 = vxm_bload(rgo, p4, 0), g1 = vxm_bload(rgo, p4, V4), g2 = vxm_bload(rgo, p4, 2 * V4);     // the voxel's own upstream gradient
     const int lq = ((dd + 1) * VG_LH + ty + 1) * VG_LW + tx + 1;
+    int hz = 0, hy = 0, hx = 0;
+    if (tid < VG_NHALO) vg_halo_cell(tid, hz, hy, hx);
+    const int qz = d0 - 1 + hz, qy = h0 - 1 + hy, qx = w0 - 1 + hx;
+    const bool halo_in = tid < VG_NHALO && (unsigned)qz < (unsigned)D && (unsigned)qy < (unsigned)H && (unsigned)qx < (unsigned)W;
+    const int q4 = (qz * HW + qy * W + qx) << 2;
+    const int lh = (hz * VG_LH + hy) * VG_LW + hx;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, g0 = 0.f, g1 = 0.f, g2 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, k0 = 0.f, k1 = 0.f, k2 = 0.f;
+    if (own_in) {
+        v0 = vxm_bload(rv, p4, 0); v1 = vxm_bload(rv, p4, V4); v2 = vxm_bload(rv, p4, 2 * V4);
+        g0 = vxm_bload(rgo, p4, 0); g1 = vxm_bload(rgo, p4, V4); g2 = vxm_bload(rgo, p4, 2 * V4);      // the voxel's own upstream gradient
+    }
+    if (halo_in) {
+        u0 = vxm_bload(rv, q4, 0); u1 = vxm_bload(rv, q4, V4); u2 = vxm_bload(rv, q4, 2 * V4);
+        k0 = vxm_bload(rgo, q4, 0); k1 = vxm_bload(rgo, q4, V4); k2 = vxm_bload(rgo, q4, 2 * V4);
+    }
+    v0 *= scale; v1 *= scale; v2 *= scale; u0 *= scale; u1 *= scale; u2 *= scale;
+    const VgStaged so = vg_stage(v0, v1, v2, d, h, w, D, H, W);
+    {
+        const bool send = own_in && so.near;                      // a sender that is not near (or not in the volume) stages g = 0
+        recA[lq] = (f32x4){so.e[0], so.e[1], so.e[2], send ? g0 : 0.0f};
+        recB[lq] = (vg_f32x2){send ? g1 : 0.0f, send ? g2 : 0.0f};
+        vL[0][lq] = v0; vL[1][lq] = v1; vL[2][lq] = v2;
+        if (own_in && !so.near) atomicAdd(far_count, 1u);         // rare: left to the atomic pass
+    }
+    if (tid < VG_NHALO) {
+        const VgStaged sh = vg_stage(u0, u1, u2, qz, qy, qx, D, H, W);
+        const bool send = halo_in && sh.near;
+        recA[lh] = (f32x4){sh.e[0], sh.e[1], sh.e[2], send ? k0 : 0.0f};
+        recB[lh] = (vg_f32x2){send ? k1 : 0.0f, send ? k2 : 0.0f};
+        vL[0][lh] = u0; vL[1][lh] = u1; vL[2][lh] = u2;
+    }
+    __syncthreads();
+    if (!own_in) return;
+    // ---- local part: identity + derivative through the sampling position (the 8 corners of x'(q) sampled from v itself)
     const Corners8 cn = corners8(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W);
     float gz = g0, gy = g1, gx = g2;
+    const int lc = lq - (so.frel[0] * VG_LH + so.frel[1]) * VG_LW - so.frel[2];        // corner 0 in the grown tile (near voxels)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int i4 = cn.idx[k] << 2;
         const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
-        const float sk = cn.ok[k] ? (vxm_bload(rv, i4, 0) * scale) * g0 + (vxm_bload(rv, i4, V4) * scale) * g1 + (vxm_bload(rv, i4, 2 * V4) * scale) * g2 : 0.0f;
+        float c0, c1, c2;
+        if (so.near) {
+            const int i = lc + (dz * VG_LH + dy) * VG_LW + dx;
+            c0 = vL[0][i]; c1 = vL[1][i]; c2 = vL[2][i];
+        } else {
+            const int i4 = cn.idx[k] << 2;
+            c0 = vxm_bload(rv, i4, 0) * scale; c1 = vxm_bload(rv, i4, V4) * scale; c2 = vxm_bload(rv, i4, 2 * V4) * scale;
+        }
+        const float sk = cn.ok[k] ? c0 * g0 + c1 * g1 + c2 * g2 : 0.0f;
         gz += (dz ? sk : -sk) * (cn.wy[dy] * cn.wx[dx]);
         gy += (dy ? sk : -sk) * (cn.wz[dz] * cn.wx[dx]);
         gx += (dx ? sk : -sk) * (cn.wz[dz] * cn.wy[dy]);
