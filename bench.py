@@ -273,6 +273,7 @@ def timed_steps(wl, steps, vdist, dev, timer=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = wl.step()
+    timed_steps.host_enqueue_s = time.perf_counter() - t0        # the host's share: all launches of the region enqueued (no sync inside a step)
     torch.cuda.synchronize()
     vdist.barrier()
     elapsed = vdist.max_over_ranks(time.perf_counter() - t0, dev)
@@ -381,6 +382,7 @@ def main():
     # chip with the backward-data chain on the second stream)
     keep = VF.OVERLAP_MIN_LEVEL
     elapsed, final_loss = timed_steps(wl, args.steps, vdist, dev)
+    host_ms = timed_steps.host_enqueue_s / args.steps * 1e3
     # pass 2 -- per-kernel table and `roofline`: every C-ABI launch bracketed by HIP events on the launch stream, the full-resolution
     # launches serialised (one kernel on the chip at a time, so that a launch's duration is its own)
     if "VXM_OVERLAP_MIN_LEVEL" not in os.environ:
@@ -445,6 +447,7 @@ def main():
         "config": {"workload": wl_desc(args, shape, B), "global_batch": world * B, "parallelism": "dp%d" % world,
                    "fp32_engine": VF.fp32_engine_note()},
         "roofline": roof, "kernels": kernels, "final_loss": final_loss,
+        "host_enqueue_ms_per_step": host_ms,        # rank 0's Python + launch time per step of the value pass; the rest of ms_per_step the host waits
     }
     if comm_ev is not None:
         out["comm"] = comm_ev
