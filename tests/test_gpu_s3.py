@@ -136,6 +136,19 @@ def test_s3_scale_invariance_and_small_magnitudes(VF):
     assert bool((z == 0).all())
 
 
+def test_s3_forward_many_tiles(VF):
+    """a volume of 2 x 3 x 9 x 5 = 270 tiles (partial in every direction) against the fp64 reference: with VXM_S3_PERSIST=-16 (subprocess
+    test below) each of the 16 blocks walks ~17 tiles of its XCD's range"""
+    torch.manual_seed(77)
+    vol, B, cin, cout = (20, 35, 72), 2, 16, 32
+    x = torch.randn(B, cin, *vol, device="cuda")
+    w = torch.randn(cout, cin, 3, 3, 3, device="cuda") / (27 * cin) ** 0.5
+    bias = torch.randn(cout, device="cuda")
+    y = _s3_forward(VF, x, False, None, w, bias, 0.2, cout, vol, B)
+    e = rel_l2(y.cpu().numpy(), _ref_conv(x.cpu(), False, None, w.cpu(), bias.cpu(), 0.2).numpy())
+    assert e <= 1e-6, e
+
+
 @pytest.mark.parametrize("c,cout,vol,B", [(16, 16, (4, 8, 32), 2), (32, 16, (5, 7, 40), 2), (16, 32, (6, 4, 64), 1), (48, 32, (3, 9, 34), 2)])
 def test_s3_backward_weight_vs_fp64(VF, c, cout, vol, B):
     """vxm_conv3d_k3_s3_bwd_weight directly: weight and bias gradient against fp64 autograd, partial tiles in every direction, a
@@ -189,6 +202,9 @@ def test_s3_other_kernel_instances_in_subprocess():
         pytest.skip("already inside a variant run")
     _rerun({"VXM_S3_CB": "2"}, "forward_vs_fp64 or fused_mask or scale_invariance")
     _rerun({"VXM_S3_NCT": "1"}, "forward_vs_fp64 or fused_mask")
+    # 16 blocks in all: every block walks several tiles of its XCD's range (the default grid only does so on volumes with > 2048 tiles)
+    _rerun({"VXM_S3_PERSIST": "-16"}, "forward_vs_fp64 or fused_mask or many_tiles")
+    _rerun({"VXM_S3_PERSIST": "0"}, "many_tiles")
 
 
 def test_s3_through_the_dispatcher_on_small_volumes_in_subprocess():

@@ -102,18 +102,19 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = lane >> 4, n = lane & 15;
 
-    // tile of this block: block b runs on XCD b % 8 (observed; speed only), XCD x takes a contiguous tile range
+    // tiles of this block: block b runs on XCD b % 8 (observed; speed only), XCD x takes a contiguous tile range and its blocks walk it
+    // with the stride of the blocks per XCD (one tile per block when the grid covers every tile)
     const int nw = (W + 15) / 16, nh = (H + ROWS - 1) / ROWS, nd = (D + S3_TD - 1) / S3_TD;
     const int ntiles = B * nd * nh * nw;
-    int tile = blockIdx.x;
+    int t_lo, t_hi, t_step;
     if (ntiles >= 64) {
-        const int x = tile & 7, j = tile >> 3;
-        const int lo = (int)((long long)ntiles * x / 8), hi = (int)((long long)ntiles * (x + 1) / 8);
-        tile = lo + j;
-        if (tile >= hi) return;
-    } else if (tile >= ntiles) {
-        return;
+        const int x = blockIdx.x & 7;
+        t_lo = (int)((long long)ntiles * x / 8) + (int)(blockIdx.x >> 3); t_hi = (int)((long long)ntiles * (x + 1) / 8); t_step = (int)(gridDim.x >> 3);
+    } else {
+        t_lo = blockIdx.x; t_hi = ntiles; t_step = gridDim.x;
     }
+    for (int tile = t_lo; tile < t_hi; tile += t_step) {
+    if (tile != t_lo) __syncthreads();                          // every wave is done with the LDS of the previous tile
     const int tw = tile % nw; int tq = tile / nw;
     const int th = tq % nh; tq /= nh;
     const int td = tq % nd; const int b = tq / nd;
@@ -290,6 +291,7 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     conv_load_bias<NCT>(bz, bias, Cout, g, kg);
     conv_epilogue_store<NCT, ROWS, 1>(acc, y + (size_t)b * y_bs, bz, mask ? mask + (size_t)b * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
                                       d < D && w < W, (d * H + h0) * W + w, h0, H, W, V);
+    }
 }
 
 // w: [Cw_out][Cw_in][27] fp32 (reference layout) -> [G][Q]{[NS][kh][piece][NCT][64 lanes], [RT][piece][NCT][64 lanes]} x 8 bf16: lane (kg, m) of
@@ -742,8 +744,19 @@ void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, lo
     (void)attr;
     const int Q0 = s3_chunks(in.C0, CB), Q = Q0 + s3_chunks(in.C1, CB);
     const long long ntiles = (long long)B * ((D + S3_TD - 1) / S3_TD) * ((H + ROWS - 1) / ROWS) * ((W + 15) / 16);
-    const unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
+    unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
     const int G = (Cout + 16 * NCT - 1) / (16 * NCT);
+    // A grid of at most 8 blocks per CU whose blocks walk their XCD's tile range (VXM_S3_PERSIST=n: n per CU, 0: one tile per block).
+    // Measured on the full-resolution layers: 16 -> 16 operators (two chunks per tile, i.e. short blocks) 0.80 -> 0.74 and 0.745 -> 0.69 ms,
+    // the up-sampling gather 2.64 -> 2.48 ms, the 32 <-> 16 operators unchanged (2, 4 and 8 blocks per CU within 1 % of each other).
+    // What a tile still pays is its first chunk -- load, split, LDS, barrier before the first MFMA: with that stage skipped altogether
+    // (wrong results, timing only) the same operators ran 7 - 21 % faster, which bounds what a cross-tile prefetch could gain.
+    static const int persist = [] { const char* e = getenv("VXM_S3_PERSIST"); return e ? atoi(e) : 8; }();      // < 0: that many blocks in all (tests)
+    if (persist != 0 && ntiles >= 64) {
+        const unsigned want = persist > 0 ? (unsigned)(sw_cus() * persist / G) : (unsigned)(-persist);
+        const unsigned cap = 8 * ((want + 7) / 8);
+        if (cap < gx) gx = cap;
+    }
     hipLaunchKernelGGL((k_s3_conv<NCT, ROWS, CB>), dim3(gx, G), dim3(S3_THREADS), C::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
                        Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q);
 }
