@@ -98,7 +98,7 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     constexpr int HR = C::HR, PLANE = C::PLANE, PUSED = C::PLANE_USED, SLOTS = C::SLOTS, NSLOT = C::NSLOT, NS = C::NS, NI = C::NI, WCH = C::WCH, WIT = C::WIT;
     u32x4* const Xs = smem;                 // [3][CB][SLOTS]
     u32x4* const Ws = smem + C::XW;         // [NS][3][3][NCT][64]
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, tid_ = tid, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = lane >> 4, n = lane & 15;
 
@@ -113,40 +113,41 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     } else {
         t_lo = blockIdx.x; t_hi = ntiles; t_step = gridDim.x;
     }
-    for (int tile = t_lo; tile < t_hi; tile += t_step) {
-    if (tile != t_lo) __syncthreads();                          // every wave is done with the LDS of the previous tile
-    const int tw = tile % nw; int tq = tile / nw;
-    const int th = tq % nh; tq /= nh;
-    const int td = tq % nd; const int b = tq / nd;
-    const int d0 = td * S3_TD, h0 = th * ROWS, w0 = tw * 16;
     const int g = blockIdx.y;
-
     const int V = D * H * W;
     const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
     const int V0 = in.up0 ? Dl * Hl * Wl : V;
-    const __amdgpu_buffer_rsrc_t r0 = vxm_rsrc(in.x0 + (size_t)b * in.bs0, (unsigned)in.C0 * (unsigned)V0 * 4u);
-    const __amdgpu_buffer_rsrc_t r1 = vxm_rsrc(in.C1 ? in.x1 + (size_t)b * in.bs1 : in.x0, (unsigned)in.C1 * (unsigned)V * 4u);
 
-    // staging roles of this thread, fixed for the block: slot i = tid + 512 j = (cb, hd, hh, hw) of the haloed tile; element
-    // offsets of its voxel in a full-resolution plane set / in the half-resolution source of an upsampled segment (-1: padding)
-    // one register per slot: (hd, hh, hw) of the haloed tile packed as hd << 10 | hh << 5 | hw, -1 where there is no slot or the
-    // voxel is outside the volume (padding); global offsets and the LDS word are rebuilt from it per chunk (a few VALU)
+    // The STAGING tile (whose chunks are fetched and written to LDS): origin, batch descriptors and the staging roles of this thread.
+    // slot i = tid + 512 j = (cb, hd, hh, hw) of the haloed tile, one register per slot: (hd, hh, hw) packed as hd << 10 | hh << 5 | hw,
+    // -1 where there is no slot or the voxel is outside the volume (padding); global offsets and the LDS word are rebuilt from it per chunk
+    // (a few VALU).  It runs ahead of the tile being computed by one chunk: under the MFMAs of a tile's LAST chunk, chunk 0 of the block's
+    // NEXT tile is in flight, so only a block's first tile waits for load -> split -> LDS -> barrier before its first MFMA.
+    int d0 = 0, h0 = 0, w0 = 0, bt = 0;
+    __amdgpu_buffer_rsrc_t r0, r1;
     int spos[NI];
+    auto set_tile = [&](int tile) __attribute__((always_inline)) {
+        int tid = tid_;
+        asm volatile("" : "+v"(tid));
+        const bool live = tile < t_hi;                        // past the block's last tile: every slot is padding, nothing is fetched
+        const int tl = live ? tile : t_lo;
+        const int tw = tl % nw; int tq = tl / nw;
+        const int th = tq % nh; tq /= nh;
+        const int td = tq % nd;
+        bt = tq / nd;
+        d0 = td * S3_TD; h0 = th * ROWS; w0 = tw * 16;
+        r0 = vxm_rsrc(in.x0 + (size_t)bt * in.bs0, (unsigned)in.C0 * (unsigned)V0 * 4u);
+        r1 = vxm_rsrc(in.C1 ? in.x1 + (size_t)bt * in.bs1 : in.x0, (unsigned)in.C1 * (unsigned)V * 4u);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int i = tid + S3_THREADS * j;
-        const int cb = i / ((S3_TD + 2) * PUSED), rem = i - cb * (S3_TD + 2) * PUSED;
-        const int hd = rem / PUSED, r2 = rem - hd * PUSED, hh = r2 / S3_HWV, hw = r2 - hh * S3_HWV;
-        const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-        const bool ok = i < NSLOT && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-        spos[j] = ok ? (hd << 10 | hh << 5 | hw) : -1;
-    }
-
-    f32x4 acc[NCT][ROWS];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NI; ++j) {
+            const int i = tid + S3_THREADS * j;
+            const int cb = i / ((S3_TD + 2) * PUSED), rem = i - cb * (S3_TD + 2) * PUSED;
+            const int hd = rem / PUSED, r2 = rem - hd * PUSED, hh = r2 / S3_HWV, hw = r2 - hh * S3_HWV;
+            const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+            const bool ok = live && i < NSLOT && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            spos[j] = ok ? (hd << 10 | hh << 5 | hw) : -1;
+        }
+    };
 
     // per-lane LDS word offset of the unit this lane group reads in K-step s (s3_unit; zero-weight units read their partner's word)
     int xoff[NS];
@@ -162,6 +163,8 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     float xr[NI][8];                                         // chunk q + 1 in flight under the MFMAs of chunk q
     int voffs[NI];                                           // its per-lane offsets: kept live across the MFMA phase (see keep_offsets)
     auto load_chunk = [&](int q) __attribute__((always_inline)) {
+        int tid = tid_;
+        asm volatile("" : "+v"(tid));
         const bool s0 = q < Q0;                               // wave-uniform
         const bool up = s0 && in.up0;
         const __amdgpu_buffer_rsrc_t r = s0 ? r0 : r1;
@@ -185,6 +188,10 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
         for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(voffs[j]));
     };
     auto store_chunk = [&](int q) __attribute__((always_inline)) {
+        // (an opaque copy of the thread index: the slot arithmetic below is loop-invariant, and hoisted out of the tile loop it would
+        // occupy registers across the MFMA phases -- 24 spilled VGPRs in the 128-register instance)
+        int tid = tid_;
+        asm volatile("" : "+v"(tid));
         // the chunk's packed weights: requested first, written to LDS after the split arithmetic below has covered their latency
         u32x4 wv[WIT];
         const __amdgpu_buffer_rsrc_t rw = vxm_rsrc(reinterpret_cast<const float*>(wp + ((size_t)g * Q + q) * WCH), WCH * 16u);
@@ -211,13 +218,23 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
         }
     };
 
+    set_tile(t_lo);
     load_chunk(0);
     store_chunk(0);
-    __syncthreads();
+    for (int tile = t_lo; tile < t_hi; tile += t_step) {
+    const int cd0 = d0, ch0 = h0, cw0 = w0, cbt = bt;           // the tile being computed (the staging tile moves on under its last chunk)
+    __syncthreads();                                            // chunk 0 of this tile is in LDS
+    f32x4 acc[NCT][ROWS];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < Q; ++q) {
-        // unconditional (past the last chunk every lane is out of range and nothing is fetched): a branch around the prefetch makes
+        const bool last = q + 1 == Q;                           // wave-uniform
+        if (last) set_tile(tile + t_step);
+        // unconditional (past the block's last tile every lane is out of range and nothing is fetched): a branch around the prefetch makes
         // the compiler wait for it at the join, right after it was issued (s_waitcnt vmcnt(0) in front of the first MFMA, seen in the ISA)
-        load_chunk(q + 1);
+        load_chunk(last ? 0 : q + 1);
         // ---- NS K-steps x (ROWS + 2) haloed rows: three B pieces per row, up to 3 kh x NCT x 6 piece products per read set.
         // The B pieces of row hr + 1 are requested before the MFMAs of row hr (register double buffer; sched_barrier pins the order:
         // unpinned, the compiler sinks every ds_read to right before its first use and the wave stalls on LDS latency once per row).
@@ -276,21 +293,23 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (q + 1 < Q) {
-            keep_offsets();
-            __syncthreads();                        // every wave is done reading chunk q
+        keep_offsets();
+        __syncthreads();                            // every wave is done reading chunk q
+        if (!last) {
             store_chunk(q + 1);
             __syncthreads();
+        } else if (tile + t_step < t_hi) {
+            store_chunk(0);                         // chunk 0 of the next tile; the barrier at the top of the tile loop publishes it
         }
     }
 
     // ---- epilogue: the D layout of the bf16 MFMA is the fp32 one's (lane (kg, n): channels 4 kg + j of voxel column n):
     // bias + LeakyReLU (+ fused leaky_relu_backward mask), planar fp32 store, shared with the fp32-MFMA kernels
-    const int d = d0 + wave, w = w0 + n;
+    const int d = cd0 + wave, w = cw0 + n;
     float bz[NCT][4];
     conv_load_bias<NCT>(bz, bias, Cout, g, kg);
-    conv_epilogue_store<NCT, ROWS, 1>(acc, y + (size_t)b * y_bs, bz, mask ? mask + (size_t)b * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
-                                      d < D && w < W, (d * H + h0) * W + w, h0, H, W, V);
+    conv_epilogue_store<NCT, ROWS, 1>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
+                                      d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V);
     }
 }
 
