@@ -570,6 +570,11 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
 #pragma unroll
             for (int hl = 0; hl < 4; ++hl) {                     // haloed rows 2 rh + hl serve output rows 2 rh + hl - kh
                 const int hr = 2 * rh + hl;                      // wave-uniform
+                // a wave's priority falls as it advances through the tile: the three waves of a SIMD then progress evenly instead of oldest
+                // first and share the matrix pipe to the end of the phase -- a lone last wave cannot keep it busy (s_memtime stamps: the
+                // waves finished at 3.5 k, 5.7 k and 7.7 k cycles of a tile whose MFMAs need 5.5 k).  -2 .. -3 % on the three big launches;
+                // the same in k_s3_conv (two blocks per CU: four waves per SIMD from two phases) changed nothing and is not there.
+                if (hl == 0) __builtin_amdgcn_s_setprio(3); else if (hl == 1) __builtin_amdgcn_s_setprio(2); else if (hl == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                 if (hl < 2) {
 #pragma unroll
                     for (int p = 0; p < 3; ++p) {
@@ -607,6 +612,7 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) tot[kh][kw] += acc[kh][kw];
             totb += accb;
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             // the address registers of the loads in flight stay live until here: reused earlier, the compiler guards every reuse
             // with s_waitcnt vmcnt(..), i.e. waits for the prefetch at the start of the MFMA phase (seen in the ISA)
