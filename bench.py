@@ -302,6 +302,10 @@ def comm_evidence(opt, dev):
     import statistics
     ev = {"backend": "libvxm_comm" if opt.comm is not None else "torch.distributed(nccl)", "ranks_seen": opt.world,
           "bucket_bytes": 4 * opt.n}
+    if opt.comm is None and os.environ.get("VXM_COMM", "") != "torch":
+        from voxelmorph_amd import comm as vcomm
+        ev["native_error"] = vcomm.NativeComm.last_failure or "native communicator not attempted (backend %s)" % (
+            torch.distributed.get_backend() if torch.distributed.is_initialized() else "none")
     if opt.comm is not None:
         from voxelmorph_amd import comm as vcomm
         ev["ranks_seen"] = int(vcomm.lib().vxm_comm_world())
@@ -365,7 +369,11 @@ def main():
     shape = tuple(int(s) for s in args.shape.split(","))
     B = args.batch_per_gpu
     # a multi-rank HIP job whose native communicator cannot be built fails HERE, loudly, unless VXM_COMM=torch was asked for
-    comm = vdist.native_comm(required=world > 1 and os.environ.get("VXM_COMM", "") != "torch")
+    # Multi-rank: the libvxm_comm.so communicator carries the exchange.  When it cannot be built (or fails its known-answer self-check)
+    # the run goes on over torch.distributed's RCCL -- reported on stderr by rank 0 and in `comm.backend` / `comm.native_error` of the
+    # line, so a scaling run leaves numbers AND says which exchange they were measured on; VXM_COMM=rccl makes that a hard error on
+    # every rank instead, VXM_COMM=torch skips the native communicator.
+    comm = vdist.native_comm(required=world > 1 and os.environ.get("VXM_COMM", "") == "rccl")
     wl = Workload(vxm, vdist, args.config, shape, B, dev, rank, args.int_steps, comm)
     args.int_steps = wl.int_steps
     bf16, dense = wl.bf16, wl.dense

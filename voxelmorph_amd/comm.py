@@ -80,6 +80,8 @@ class NativeComm:
         dist.broadcast_object_list(box, src=0, group=group)
         return cls(rank, world, box[0])
 
+    last_failure = ""          # why the last try_from_torch_dist() returned None (bench.py puts it into its `comm` object)
+
     @classmethod
     def try_from_torch_dist(cls, group=None):
         """`from_torch_dist`, agreed on by all ranks: if the communicator cannot be created on ANY rank (e.g. two ranks on
@@ -94,6 +96,7 @@ class NativeComm:
             return flags
 
         def report(flags, err, what):
+            cls.last_failure = "libvxm_comm.so %s on %d of %d ranks (%s)" % (what, flags.count(False), len(flags), err or "see other ranks")
             if rank == 0:
                 import sys
                 print("voxelmorph_amd: libvxm_comm.so %s on %d of %d ranks (%s); gradient all-reduce through "
@@ -129,11 +132,28 @@ class NativeComm:
         except (VxmHipError, OSError) as exc:
             err = str(exc)
         flags = agree(comm is not None)
+        if not all(flags):
+            if comm is not None:
+                comm.destroy()
+            report(flags, err, "communicator unavailable")
+            return None
+        # round 4: one small all-reduce with a known answer (rank r contributes r + 1), so that a communicator that was built but does
+        # not exchange correctly is dropped here, by every rank, and not found out by a diverging training run
+        ok = False
+        try:
+            probe = torch.full((1024,), float(rank + 1), device="cuda")
+            comm.all_reduce_sum(probe)
+            torch.cuda.synchronize()
+            ok = bool((probe == world * (world + 1) / 2.0).all())
+            if not ok:
+                err = "self-check all-reduce returned %r, expected %r" % (float(probe[0]), world * (world + 1) / 2.0)
+        except (VxmHipError, OSError, RuntimeError) as exc:
+            err = str(exc)
+        flags = agree(ok)
         if all(flags):
             return comm
-        if comm is not None:
-            comm.destroy()
-        report(flags, err, "communicator unavailable")
+        comm.destroy()
+        report(flags, err, "self-check failed")
         return None
 
     def _check(self, t):
