@@ -771,12 +771,15 @@ void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, lo
     const long long ntiles = (long long)B * ((D + S3_TD - 1) / S3_TD) * ((H + ROWS - 1) / ROWS) * ((W + 15) / 16);
     unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
     const int G = (Cout + 16 * NCT - 1) / (16 * NCT);
-    // A grid of at most 8 blocks per CU whose blocks walk their XCD's tile range (VXM_S3_PERSIST=n: n per CU, 0: one tile per block).
+    // A grid of at most n blocks per CU whose blocks walk their XCD's tile range (VXM_S3_PERSIST=n: n per CU, 0: one tile per block).
     // Measured on the full-resolution layers: 16 -> 16 operators (two chunks per tile, i.e. short blocks) 0.80 -> 0.74 and 0.745 -> 0.69 ms,
     // the up-sampling gather 2.64 -> 2.48 ms, the 32 <-> 16 operators unchanged (2, 4 and 8 blocks per CU within 1 % of each other).
     // What a tile still pays is its first chunk -- load, split, LDS, barrier before the first MFMA: with that stage skipped altogether
     // (wrong results, timing only) the same operators ran 7 - 21 % faster, which bounds what a cross-tile prefetch could gain.
-    static const int persist = [] { const char* e = getenv("VXM_S3_PERSIST"); return e ? atoi(e) : 8; }();      // < 0: that many blocks in all (tests)
+    // The one-block-per-CU instances (32-channel operators) run best with exactly one block per CU -- every block then walks several
+    // tiles even at half resolution and stages ahead across them (same-box A/B, 20 iterations x 2: enc1 forward 0.143 -> 0.130 ms, rem1
+    // backward-data 1.22 -> 1.175, dec3 0.448 -> 0.439) --, the two-blocks-per-CU instances with 8 (1 per CU: +12 %, 2 .. 8 within 2 %).
+    static const int persist = [] { const char* e = getenv("VXM_S3_PERSIST"); return e ? atoi(e) : (C::MIN_WAVES == 2 ? 1 : 8); }();      // < 0: that many blocks in all (tests)
     if (persist != 0 && ntiles >= 64) {
         const unsigned want = persist > 0 ? (unsigned)(sw_cus() * persist / G) : (unsigned)(-persist);
         const unsigned cap = 8 * ((want + 7) / 8);
