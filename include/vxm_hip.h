@@ -310,7 +310,8 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
 /* convolution_backward w.r.t. weight and bias (autograd twin of networks.py:299) of ONE full-resolution tensor x [B,C,D,H,W] on the
  * same split arithmetic (contraction over voxels, K = 32 voxels of a W row per MFMA): gw[co][ci_off + ci][tap] for ci < C inside a
  * [Cout][gw_cin][3][3][3] array (the channel sub-range a segment of a virtual concat owns), gb[Cout] (nullable).  C, Cout multiples
- * of 16.  Deterministic (fixed-order partial sums in `work`).  _ok: 1 when the split kernel takes a launch of this shape. */
+ * of 16, W even (the staging loads W-neighbouring voxel pairs; an odd W is VXM_ERR_BAD_SHAPE and _ok returns 0).  Deterministic
+ * (fixed-order partial sums in `work`).  _ok: 1 when the split kernel takes a launch of this shape. */
 int vxm_conv3d_k3_s3_bwd_weight_ok(int C, int Cout, int B, int D, int H, int W);
 size_t vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(int C, int Cout, int B, int D, int H, int W);
 int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw,
