@@ -221,6 +221,10 @@ int vxm_ncc2d_fwd(const float* I, const float* J, float* loss, float* sums, floa
                   int B, int H, int W, int win, void* stream);
 int vxm_ncc2d_bwd(const float* I, const float* J, const float* sums, const float* gloss, float* gJ, float* work,
                   int B, int H, int W, int win, void* stream);
+/* NCC on 1-D signals [B,1,L] (voxelmorph/torch/losses.py:15-67 with ndims = 1: conv1d box filter of `win` taps); planes as above */
+int vxm_ncc1d_fwd(const float* I, const float* J, float* loss, float* sums, float* work, double* acc, int B, int L, int win, void* stream);
+int vxm_ncc1d_bwd(const float* I, const float* J, const float* sums, const float* gloss, float* gJ, float* work, int B, int L, int win,
+                  void* stream);
 int vxm_gradloss2d_fwd(const float* y, float* loss, double* acc, int B, int C, int H, int W, int penalty, float mult,
                        void* stream);
 int vxm_gradloss2d_bwd(const float* y, const float* gloss, float* gy, int B, int C, int H, int W, int penalty,

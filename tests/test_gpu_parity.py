@@ -199,6 +199,28 @@ def test_ncc_windows_batches_segments_vs_fp64(vxm, win):
     assert rel_l2(N(Jg.grad), Jd.grad.numpy()) < 1e-3
 
 
+@pytest.mark.parametrize("win", [None, 5])
+def test_ncc_one_dimensional_vs_reference_formula(vxm, win):
+    """NCC on [B,1,L] signals (losses.py:15-67 with ndims = 1: conv1d box filter): the oracle IS the reference's formula (same ATen
+    calls, filter on the input's device); loss against its fp32 and fp64 evaluations, both gradients against fp64."""
+    rng = np.random.default_rng(11)
+    L = 777
+    I = rng.random((3, 1, L)).astype(np.float32)
+    J = (0.5 * I + 0.5 * rng.random((3, 1, L))).astype(np.float32)
+    w = None if win is None else [win]
+    Ig, Jg = G(I, True), G(J, True)
+    l = vxm.losses.NCC(win=w).loss(Ig, Jg)
+    l.backward()
+    l32 = orc.ncc_loss(torch.from_numpy(I), torch.from_numpy(J), win=w)
+    Id, Jd = torch.from_numpy(I).double().requires_grad_(), torch.from_numpy(J).double().requires_grad_()
+    ld = orc.ncc_loss(Id, Jd, win=w)
+    ld.backward()
+    assert abs(float(l.detach()) - float(l32)) < 1e-4 and abs(float(l.detach()) - float(ld.detach())) < 1e-5
+    assert rel_l2(N(Jg.grad), Jd.grad.numpy()) < 1e-3 and rel_l2(N(Ig.grad), Id.grad.numpy()) < 1e-3
+    with pytest.raises(NotImplementedError):
+        vxm.losses.NCC(win=[4]).loss(Ig, Jg)
+
+
 def test_grad_mse_dice_golden(vxm, g_losses):
     for pen, mult in (("l1", None), ("l2", 2)):
         fl = G(g_losses["flow"], True)

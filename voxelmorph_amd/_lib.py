@@ -83,6 +83,8 @@ SIGNATURES = {
     "vxm_upsample2d_bwd": [_P, _I, _P, _I, _I, _I, _I, _P],
     "vxm_ncc2d_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vxm_ncc2d_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vxm_ncc1d_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "vxm_ncc1d_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "vxm_gradloss2d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "vxm_gradloss2d_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
     "vxm_bf16_to_blocked": [_P, _I, _L, _P, _I, _L, _P, _I, _I, _L, _P],

@@ -650,6 +650,27 @@ int vxm_ncc2d_bwd(const float* I, const float* J, const float* sums, const float
     return vxm_check_launch("vxm_ncc2d_bwd");
 }
 
+/* NCC on 1-D signals [B,1,L] (losses.py:15-67 with ndims = 1: conv1d box filter of `win` taps, win_size = win): the separable passes
+ * with a depth and a height of one */
+int vxm_ncc1d_fwd(const float* I, const float* J, float* loss, float* sums, float* work, double* acc, int B, int L, int win, void* stream) {
+    VXM_REQUIRE(I && J && loss && sums && work && acc, VXM_ERR_NULL_POINTER, "vxm_ncc1d_fwd: null pointer");
+    VXM_REQUIRE(B > 0 && L > 0 && win > 0 && (win & 1), VXM_ERR_BAD_SHAPE, "vxm_ncc1d_fwd: bad shape / even window %d", win);
+    const long long BV = (long long)B * L;
+    hipStream_t s = VXM_STREAM(stream);
+    (void)hipMemsetAsync(acc, 0, sizeof(double), s);
+    ncc_generic_fwd(I, J, sums, work, acc, BV, 1, 1, L, win / 2, (float)win, s);
+    hipLaunchKernelGGL(k_finish_mean, dim3(1), dim3(64), 0, s, acc, loss, -1.0 / (double)BV);
+    return vxm_check_launch("vxm_ncc1d_fwd");
+}
+
+int vxm_ncc1d_bwd(const float* I, const float* J, const float* sums, const float* gloss, float* gJ, float* work, int B, int L, int win,
+                  void* stream) {
+    VXM_REQUIRE(I && J && sums && gloss && gJ && work, VXM_ERR_NULL_POINTER, "vxm_ncc1d_bwd: null pointer");
+    VXM_REQUIRE(B > 0 && L > 0 && win > 0 && (win & 1), VXM_ERR_BAD_SHAPE, "vxm_ncc1d_bwd: bad shape / even window %d", win);
+    ncc_generic_bwd(I, J, sums, gloss, gJ, work, (long long)B * L, 1, 1, L, win / 2, (float)win, VXM_STREAM(stream));
+    return vxm_check_launch("vxm_ncc1d_bwd");
+}
+
 static int gradloss_fwd(const char* fn, const float* y, float* loss, double* acc, int B, int C, int D, int H, int W, int penalty, float mult,
                         int axes, void* stream) {
     VXM_REQUIRE(y && loss && acc, VXM_ERR_NULL_POINTER, "%s: null pointer", fn);

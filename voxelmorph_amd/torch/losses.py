@@ -16,9 +16,13 @@ class NCC:
         ndims = len(list(y_true.size())) - 2
         assert ndims in [1, 2, 3], "volumes should be 1 to 3 dimensions. found: %d" % ndims
         win = [9] * ndims if self.win is None else list(self.win)
-        if ndims == 1 or len(win) != ndims or len(set(win)) != 1 or win[0] % 2 == 0:
-            raise NotImplementedError("the MI355X NCC kernels implement square / cubic odd windows on 2-D / 3-D inputs; "
+        if len(win) != ndims or len(set(win)) != 1 or win[0] % 2 == 0:
+            # (the reference pads every axis by win[0] // 2 whatever the other window sizes are, losses.py:31-36: a window that is not
+            # square / cubic changes the SHAPE of its box sums; that corner of its behaviour is not built)
+            raise NotImplementedError("the MI355X NCC kernels implement odd windows of one size per axis (line / square / cube); "
                                       "got win=%s on %d-D" % (win, ndims))
+        if ndims == 1:
+            return VP.NCC1dFn.apply(y_true, y_pred, int(win[0]))
         if ndims == 2:
             return VP.NCC2dFn.apply(y_true, y_pred, int(win[0]))
         return VF.NCCFn.apply(y_true, y_pred, int(win[0]))

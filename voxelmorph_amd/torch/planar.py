@@ -138,6 +138,43 @@ class NCC2dFn(torch.autograd.Function):
         return gI, gJ, None
 
 
+class NCC1dFn(torch.autograd.Function):
+    """NCC.loss (voxelmorph/torch/losses.py:15-67) on 1-D signals [B,1,L] with a window of `win` taps."""
+
+    @staticmethod
+    def forward(ctx, y_true, y_pred, win):
+        require_device(y_true, y_pred)
+        I, J = _c(y_true), _c(y_pred)
+        if I.dim() != 3 or I.shape[1] != 1 or I.shape != J.shape or I.dtype != torch.float32:
+            raise ValueError("NCC: expected two fp32 [B,1,L] tensors (the reference's box filter has one input channel, "
+                             "losses.py:29), got %s / %s" % (tuple(I.shape), tuple(J.shape)))
+        B, _, L = I.shape
+        loss = torch.empty((), dtype=I.dtype, device=I.device)
+        sums = torch.empty((5, B, L), dtype=I.dtype, device=I.device)
+        work = torch.empty((5, B, L), dtype=I.dtype, device=I.device)
+        acc = torch.empty(1, dtype=torch.float64, device=I.device)
+        call("vxm_ncc1d_fwd", ptr(I), ptr(J), ptr(loss), ptr(sums), ptr(work), ptr(acc), B, L, win, stream())
+        ctx.save_for_backward(I, J, sums)
+        ctx.win = win
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        I, J, sums = ctx.saved_tensors
+        B, _, L = I.shape
+        gloss = _c(gloss)
+        work = torch.empty((6, B, L), dtype=I.dtype, device=I.device)
+        gI = gJ = None
+        if ctx.needs_input_grad[1]:
+            gJ = torch.empty_like(J)
+            call("vxm_ncc1d_bwd", ptr(I), ptr(J), ptr(sums), ptr(gloss), ptr(gJ), ptr(work), B, L, ctx.win, stream())
+        if ctx.needs_input_grad[0]:      # cc is symmetric in (I, J): box-sum planes 0<->1 and 2<->3
+            swapped = torch.stack([sums[1], sums[0], sums[3], sums[2], sums[4]])
+            gI = torch.empty_like(I)
+            call("vxm_ncc1d_bwd", ptr(J), ptr(I), ptr(swapped), ptr(gloss), ptr(gI), ptr(work), B, L, ctx.win, stream())
+        return gI, gJ, None
+
+
 class GradLoss2dFn(torch.autograd.Function):
     """Grad.loss (voxelmorph/torch/losses.py:102-135), 2-D."""
 
