@@ -233,19 +233,16 @@ class Workload:
             self.dice = vxm.losses.Dice().loss
         self.img = vxm.losses.MSE().loss if self.dense else vxm.losses.NCC().loss
         self.reg = vxm.losses.Grad("l2", loss_mult=2).loss
-        self._inflight, self._k, self.wait_s = [None, None], 0, 0.0
+        from voxelmorph_amd.pacing import InFlight
+        self.pace = InFlight(2)
 
     def step(self):
-        # At most two steps in flight: the host waits for the end of step k - 2 before it enqueues step k.  The GPU never starves (two
+        # At most two steps in flight (voxelmorph_amd/pacing.py): the host waits for the end of step k - 2 before it enqueues step k.  The GPU never starves (two
         # steps are 35 ms of queued work, the host needs 2.5 ms per step), and the caching allocator reaches its steady state within the
         # warm-up: with an unbounded run-ahead the timed region (K = 20 steps deep) holds more blocks in flight than the warm-up (W = 5)
         # ever did, and the hipMallocs that follow -- 10-15 ms each -- land inside it (seen once: 19.6 instead of 17.5 ms per step with
         # `host_enqueue_ms_per_step` = 19.4, the per-kernel pass right after it at 17.7).
-        ev = self._inflight[self._k & 1]
-        if ev is not None:
-            t0 = time.perf_counter()
-            ev.synchronize()
-            self.wait_s += time.perf_counter() - t0
+        self.pace.wait()
         self.opt.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):      # bf16: blocked-bf16 activations between the convs
             if self.semi:
@@ -256,11 +253,7 @@ class Workload:
                 loss = self.img(self.trg, y) + self.lam * self.reg(None, pre)
         loss.backward()
         self.opt.step()                                            # all-reduce (world>1) + fused Adam
-        if self.src.is_cuda:
-            ev = torch.cuda.Event()
-            ev.record()
-            self._inflight[self._k & 1] = ev
-        self._k += 1
+        self.pace.mark()
         return loss
 
     def describe(self):
@@ -286,12 +279,12 @@ def timed_steps(wl, steps, vdist, dev, timer=None):
         profiler.install(timer)
     vdist.barrier()
     torch.cuda.synchronize()
-    wl.wait_s = 0.0
+    wl.pace.wait_s = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = wl.step()
     # the host's share: Python + launches of the region, without the time it spent waiting for step k - 2 (Workload.step keeps two in flight)
-    timed_steps.host_enqueue_s = time.perf_counter() - t0 - wl.wait_s
+    timed_steps.host_enqueue_s = time.perf_counter() - t0 - wl.pace.wait_s
     torch.cuda.synchronize()
     vdist.barrier()
     elapsed = vdist.max_over_ranks(time.perf_counter() - t0, dev)

@@ -119,6 +119,8 @@ def main(argv=None):
     weights.append(args.weight)
 
     os.makedirs(args.model_dir, exist_ok=True)
+    from voxelmorph_amd.pacing import InFlight
+    pace = InFlight(2)
     for epoch in range(args.initial_epoch, args.epochs):
         if rank == 0 and epoch % args.save_every == 0:
             model.save(os.path.join(args.model_dir, '%04d.pt' % epoch))
@@ -126,6 +128,7 @@ def main(argv=None):
         torch.cuda.synchronize()
         t0 = time.time()
         for _ in range(args.steps_per_epoch):
+            pace.wait()                      # at most two steps in flight (voxelmorph_amd/pacing.py)
             inputs, y_true = next(loader)
             y_pred = model(*inputs)
             loss = 0
@@ -137,6 +140,7 @@ def main(argv=None):
             opt.zero_grad()
             loss.backward()
             opt.step()
+            pace.mark()
         torch.cuda.synchronize()
         dt = (time.time() - t0) / args.steps_per_epoch
         if rank == 0:

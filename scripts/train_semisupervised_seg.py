@@ -107,11 +107,14 @@ def main(argv=None):
     os.makedirs(args.model_dir, exist_ok=True)
     if rank == 0:
         model.save(os.path.join(args.model_dir, '%04d.pt' % args.initial_epoch))       # tf script :143
+    from voxelmorph_amd.pacing import InFlight
+    pace = InFlight(2)
     for epoch in range(args.initial_epoch, args.epochs):
         terms = torch.zeros(len(losses) + 1, device=dev)
         torch.cuda.synchronize()
         t0 = time.time()
         for _ in range(args.steps_per_epoch):
+            pace.wait()                      # at most two steps in flight (voxelmorph_amd/pacing.py)
             inputs, y_true = next(loader)
             y_pred = model(*inputs)
             loss = 0
@@ -123,6 +126,7 @@ def main(argv=None):
             opt.zero_grad()
             loss.backward()
             opt.step()
+            pace.mark()
         torch.cuda.synchronize()
         dt = (time.time() - t0) / args.steps_per_epoch
         if rank == 0:
