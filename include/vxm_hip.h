@@ -225,6 +225,17 @@ int vxm_ncc2d_bwd(const float* I, const float* J, const float* sums, const float
 int vxm_ncc1d_fwd(const float* I, const float* J, float* loss, float* sums, float* work, double* acc, int B, int L, int win, void* stream);
 int vxm_ncc1d_bwd(const float* I, const float* J, const float* sums, const float* gloss, float* gJ, float* work, int B, int L, int win,
                   void* stream);
+/* NCC.loss with ANY window (voxelmorph/torch/losses.py:26-36,47-67): `w*` taps per axis and `p*` zeros on both sides of it.  The
+ * reference pads every axis the tensor has by win[0] // 2 whatever the other window sizes are (:31-36), so non-cubic and even windows
+ * change the extent of the box sums: O = S + 2 p - w + 1 per axis; cc (:65) and its mean (:67) are taken on [B, Od, Oh, Ow].  An axis
+ * the tensor does not have is passed as extent 1, w 1, p 0.  vxm_ncc_win_elems returns the plane size P the scratch is counted in
+ * (0: the shape has no box sums -- the reference's conv raises there too) and *n_out = B*Od*Oh*Ow.
+ * sums: 5 * n_out floats (kept for backward); work: 10 * P floats (forward), 6 * P floats (backward); acc: one double. */
+int64_t vxm_ncc_win_elems(int B, int D, int H, int W, int wd, int wh, int ww, int pd, int ph, int pw, int64_t* n_out);
+int vxm_ncc_win_fwd(const float* I, const float* J, float* loss, float* sums, float* work, double* acc, int B, int D, int H, int W,
+                    int wd, int wh, int ww, int pd, int ph, int pw, void* stream);
+int vxm_ncc_win_bwd(const float* I, const float* J, const float* sums, const float* gloss, float* gJ, float* work, int B, int D, int H, int W,
+                    int wd, int wh, int ww, int pd, int ph, int pw, void* stream);
 int vxm_gradloss2d_fwd(const float* y, float* loss, double* acc, int B, int C, int H, int W, int penalty, float mult,
                        void* stream);
 int vxm_gradloss2d_bwd(const float* y, const float* gloss, float* gy, int B, int C, int H, int W, int penalty,

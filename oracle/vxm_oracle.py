@@ -518,6 +518,75 @@ def ncc_explicit(I, J, win=9):
     return -np.mean(cross * cross / (Iv * Jv + 1e-5))
 
 
+def _box_axis_explicit(x, ax, w, p, adjoint=False):
+    """One axis of the reference's box filter in fp64: `conv(ones[w], stride 1, padding p)` (losses.py:47-55) takes an axis of S entries
+    to O = S + 2p - w + 1 sums, out[o] = sum_k in[o - p + k]; `adjoint=True` applies its transpose (O entries back to S)."""
+    S = x.shape[ax]
+    if adjoint:                        # x has O entries; S_in of the forward filter is O - 2p + w - 1
+        O, S = S, S - 2 * p + w - 1
+        out_shape = list(x.shape)
+        out_shape[ax] = S
+        out = np.zeros(out_shape, dtype=np.float64)
+        for o in range(O):
+            lo, hi = max(0, o - p), min(S, o - p + w)
+            if hi > lo:
+                sl = [slice(None)] * x.ndim
+                sl[ax] = slice(lo, hi)
+                out[tuple(sl)] += np.take(x, [o], axis=ax)
+        return out
+    O = S + 2 * p - w + 1
+    if O <= 0:
+        raise ValueError("window %d larger than the padded axis (%d + 2*%d)" % (w, S, p))
+    pad = [(0, 0)] * x.ndim
+    pad[ax] = (p + 1, p)
+    cs = np.cumsum(np.pad(x, pad), axis=ax)
+    return np.take(cs, np.arange(w, w + O), axis=ax) - np.take(cs, np.arange(0, O), axis=ax)
+
+
+def ncc_explicit_win(I, J, win, grad=False):
+    """fp64 separable restatement of losses.py:26-67 for ANY window: every axis padded by win[0] // 2 (:31-36), box sums of extent
+    S + 2 pad - win + 1 per axis, cc and its mean on that shape.  With `grad=True` also returns dL/dJ and dL/dI through the
+    transposed box filters (the arbiter of the HIP kernels' separable passes)."""
+    I = np.asarray(I, dtype=np.float64)
+    J = np.asarray(J, dtype=np.float64)
+    nd = I.ndim - 2
+    win = [int(w) for w in win]
+    assert len(win) == nd
+    pad = win[0] // 2
+    axes = list(range(2, 2 + nd))
+
+    def box(x):
+        for ax, w in zip(axes, win):
+            x = _box_axis_explicit(x, ax, w, pad)
+        return x
+
+    def box_t(x):
+        for ax, w in zip(axes, win):
+            x = _box_axis_explicit(x, ax, w, pad, adjoint=True)
+        return x
+
+    n = float(np.prod(win))
+    Is, Js, I2, J2, IJ = box(I), box(J), box(I * I), box(J * J), box(I * J)
+    uI, uJ = Is / n, Js / n
+    cross = IJ - uJ * Is - uI * Js + uI * uJ * n
+    Iv = I2 - 2 * uI * Is + uI * uI * n
+    Jv = J2 - 2 * uJ * Js + uJ * uJ * n
+    den = Iv * Jv + 1e-5
+    loss = -np.mean(cross * cross / den)
+    if not grad:
+        return loss
+    N = cross.size
+    t = cross / den
+
+    def side(Xs, Ys, Xv, X, Y):          # d(-mean cc)/dY with cross = IJ - Xs Ys / n, Yv = Y2 - Ys^2 / n
+        a = 2 * t * (-Xs / n) + t * t * Xv * (2 * Ys / n)
+        b = -(t * t) * Xv
+        c = 2 * t
+        return -(box_t(a) + 2 * Y * box_t(b) + X * box_t(c)) / N
+
+    return loss, side(Is, Js, Iv, I, J), side(Js, Is, Jv, J, I)
+
+
 # ----------------------------------------------------------------------------
 # Training step (the north-star path; scripts/torch/train.py:194-223)
 # ----------------------------------------------------------------------------

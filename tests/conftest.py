@@ -42,3 +42,8 @@ def g_dice():
 @pytest.fixture(scope="session")
 def g_planar():
     return load_golden("planar.npz")
+
+
+@pytest.fixture(scope="session")
+def g_nccwin():
+    return load_golden("ncc_windows.npz")

@@ -317,11 +317,40 @@ def gold_planar():
     save("planar.npz", **out)
 
 
+def gold_ncc_windows():
+    """NCC with windows that are not odd and of one size per axis (losses.py:26-36: every axis is padded by win[0] // 2, so the box sums
+    change shape), from the unmodified reference: value, gradient onto y_pred, and for one case onto y_true."""
+    rng = np.random.default_rng(21)
+    out = {}
+    vol = (10, 13, 15)
+    I3 = rng.random((2, 1) + vol).astype(np.float32)
+    J3 = (0.6 * I3 + 0.4 * rng.random((2, 1) + vol)).astype(np.float32)
+    img = (14, 19)
+    I2 = rng.random((2, 1) + img).astype(np.float32)
+    J2 = (0.6 * I2 + 0.4 * rng.random((2, 1) + img)).astype(np.float32)
+    I1 = rng.random((3, 1, 37)).astype(np.float32)
+    J1 = (0.6 * I1 + 0.4 * rng.random((3, 1, 37))).astype(np.float32)
+    out.update(I3=I3, J3=J3, I2=I2, J2=J2, I1=I1, J1=J1)
+    cases = [("w995", I3, J3, [9, 9, 5]), ("w579", I3, J3, [5, 7, 9]), ("w444", I3, J3, [4, 4, 4]), ("w357", I3, J3, [3, 5, 7]),
+             ("w73", I2, J2, [7, 3]), ("w66", I2, J2, [6, 6]), ("w4", I1, J1, [4])]
+    with ref_loader.cuda_alias_to_cpu():
+        for tag, I, J, win in cases:
+            It, Jt = t(I).requires_grad_(), t(J).requires_grad_()
+            ncc = LS.NCC(win=win).loss(It, Jt)
+            ncc.backward()
+            out[tag] = ncc.detach().numpy()
+            out[tag + "_gJ"] = Jt.grad.numpy()
+            out[tag + "_gI"] = It.grad.numpy()
+            out[tag + "_win"] = np.array(win)
+    out["cases"] = np.array([c[0] for c in cases])
+    save("ncc_windows.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]          # e.g. `make_golden.py planar` regenerates one file and leaves the others untouched
     for name, fn in (("layers", gold_layers), ("losses", gold_losses), ("network", gold_network),
-                     ("dice_metric", gold_dice_metric), ("planar", gold_planar)):
+                     ("dice_metric", gold_dice_metric), ("planar", gold_planar), ("ncc_windows", gold_ncc_windows)):
         if not only or name in only:
             fn()

@@ -413,3 +413,32 @@ def test_bf16_engine_enumerates_the_weight_operators_of_a_step():
     assert not any(sh == (16, 2) for sh, _, _ in adj)
     with_inputs = VB._pack_jobs(plan, params, 2, True, True)
     assert len(with_inputs) == 28 and ((16, 2), 0, 2) in [(tuple(w.shape[:2]), lo, n) for w, lo, n, flip in with_inputs if flip]
+
+
+def test_pack_cache_key_sees_reseated_storage_and_invalidate_accepts_modules():
+    """the packed-operator cache key is (version counter, storage address, generation) -- `p.data = other` moves the
+    address without touching the counter; a write INTO the same storage needs `voxelmorph_amd.invalidate_packs` (exported, takes a module
+    or an iterable of parameters); VXM_FP32_ENGINE is validated."""
+    import subprocess
+    import sys
+    import voxelmorph_amd as vxm
+    from voxelmorph_amd.torch import functional_bf16 as VB
+    lin = torch.nn.Conv3d(2, 4, 3)
+    k0 = VB._ver(lin.weight)
+    lin.weight.data = lin.weight.data.clone()
+    k1 = VB._ver(lin.weight)
+    assert k0 != k1 and k0[0] == k1[0]                       # same version counter, another address
+    lin.weight.data.mul_(2.0)                                # invisible to the counter and the address ...
+    assert VB._ver(lin.weight) == k1
+    vxm.invalidate_packs(lin)                                # ... hence the exported call
+    assert VB._ver(lin.weight) != k1 and VB._ver(lin.bias)[2] == 1
+    with torch.no_grad():
+        lin.weight.add_(1.0)                                 # what every optimiser does: bumps the counter
+    assert VB._ver(lin.weight)[0] == k1[0] + 1
+    r = subprocess.run([sys.executable, "-c", "import voxelmorph_amd"], env=dict(os.environ, VXM_FP32_ENGINE="splitt"),
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode != 0 and "VXM_FP32_ENGINE" in r.stderr
+    r = subprocess.run([sys.executable, "-c", "import torch, voxelmorph_amd\nfrom voxelmorph_amd.torch import functional_bf16 as VB\n"
+                        "w = torch.nn.Parameter(torch.zeros(3))\nassert VB._ver(w) != VB._ver(w)\nassert VB._inplace_ver(w) == VB._inplace_ver(w)"],
+                       env=dict(os.environ, VXM_PACK_CACHE="0"), capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr

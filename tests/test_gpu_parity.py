@@ -41,6 +41,12 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
+def gate(what, measured, bound):
+    """Assert measured < bound and print the margin (`pytest -s` / the committed GPU log shows how tight the gate is)."""
+    print("[gate] %-58s measured %.3e  bound %.1e" % (what, measured, bound))
+    assert measured < bound, "%s: %.3e >= %.1e" % (what, measured, bound)
+
+
 # ------------------------------------------------------------------ SpatialTransformer
 def test_warp_trilinear_golden(vxm, g_layers):
     st = vxm.layers.SpatialTransformer(g_layers["warp_src"].shape[2:]).cuda()
@@ -148,20 +154,64 @@ def test_resize_golden(vxm, g_layers):
 
 
 # ------------------------------------------------------------------ losses
+# NCC gates: the loss against the reference's fp32 evaluation <= 1e-3 is the documented conditioning bound of its formula, not
+# the kernel's accuracy -- that is the fp64 arbiter (loss <= 1e-5 abs) and the gradients against fp64, gated at <= 5x what was measured
+# on the MI355X (profiles/r04*_gpu_tests.log prints the measured values).
+NCC_GRAD_GATE = 2e-5
+
+
 def test_ncc_golden(vxm, g_losses):
     I, J = G(g_losses["I"]), G(g_losses["J"], True)
     l = vxm.losses.NCC().loss(I, J)
-    assert abs(float(l) - float(g_losses["ncc"])) < 1e-3                       # vs fp32 reference
-    assert abs(float(l) - orc.ncc_explicit(g_losses["I"], g_losses["J"])) < 1e-5  # vs fp64 arbiter
+    gate("ncc golden: loss vs fp32 reference", abs(float(l) - float(g_losses["ncc"])), 1e-3)
+    gate("ncc golden: loss vs fp64 arbiter", abs(float(l) - orc.ncc_explicit(g_losses["I"], g_losses["J"])), 1e-5)
     l.backward()
-    assert rel_l2(N(J.grad), g_losses["ncc_gJ"]) < 1e-3
+    gate("ncc golden: dJ vs reference (fp32)", rel_l2(N(J.grad), g_losses["ncc_gJ"]), NCC_GRAD_GATE)
     J5 = G(g_losses["J"], True)
     l5 = vxm.losses.NCC(win=[5, 5, 5]).loss(I, J5)
-    assert abs(float(l5) - float(g_losses["ncc5"])) < 1e-3
+    gate("ncc5 golden: loss vs fp32 reference", abs(float(l5) - float(g_losses["ncc5"])), 1e-3)
     l5.backward()
-    assert rel_l2(N(J5.grad), g_losses["ncc5_gJ"]) < 1e-3
-    with pytest.raises(NotImplementedError):
-        vxm.losses.NCC(win=[9, 9, 5]).loss(I, J)
+    gate("ncc5 golden: dJ vs reference (fp32)", rel_l2(N(J5.grad), g_losses["ncc5_gJ"]), NCC_GRAD_GATE)
+
+
+def test_ncc_any_window_golden(vxm, g_nccwin):
+    """Windows that are not odd and of one size per axis (losses.py:26-36: every axis padded by win[0] // 2, box sums of extent
+    S + 2 pad - win + 1): value and both gradients against the fixtures of the unmodified reference and against the fp64 arbiter."""
+    for tag in g_nccwin["cases"]:
+        tag = str(tag)
+        win = [int(w) for w in g_nccwin[tag + "_win"]]
+        nd = len(win)
+        Ia, Ja = g_nccwin["I%d" % nd], g_nccwin["J%d" % nd]
+        I, J = G(Ia, True), G(Ja, True)
+        l = vxm.losses.NCC(win=win).loss(I, J)
+        l.backward()
+        le, gJ, gI = orc.ncc_explicit_win(Ia, Ja, win, grad=True)
+        gate("ncc win=%s: loss vs fp32 reference" % win, abs(float(l) - float(g_nccwin[tag])), 1e-4)
+        gate("ncc win=%s: loss vs fp64 arbiter" % win, abs(float(l) - le), 1e-5)
+        gate("ncc win=%s: dJ vs reference" % win, rel_l2(N(J.grad), g_nccwin[tag + "_gJ"]), NCC_GRAD_GATE)
+        gate("ncc win=%s: dI vs reference" % win, rel_l2(N(I.grad), g_nccwin[tag + "_gI"]), NCC_GRAD_GATE)
+        gate("ncc win=%s: dJ vs fp64" % win, rel_l2(N(J.grad), gJ), NCC_GRAD_GATE)
+        gate("ncc win=%s: dI vs fp64" % win, rel_l2(N(I.grad), gI), NCC_GRAD_GATE)
+    # a window that leaves no box sums raises, as the reference's conv does
+    with pytest.raises(ValueError):
+        vxm.losses.NCC(win=[3, 9]).loss(G(g_nccwin["I2"][..., :4]), G(g_nccwin["J2"][..., :4]))
+    with pytest.raises(ValueError):
+        vxm.losses.NCC(win=[9, 9]).loss(G(g_nccwin["I3"]), G(g_nccwin["J3"]))
+
+
+@pytest.mark.parametrize("win", [[9, 9, 5], [4, 6, 8], [11, 3, 3]])
+def test_ncc_any_window_larger_volume_vs_fp64(vxm, win):
+    rng = np.random.default_rng(sum(win))
+    vol = (21, 34, 45)
+    I = rng.random((2, 1) + vol).astype(np.float32)
+    J = (0.6 * I + 0.4 * rng.random((2, 1) + vol)).astype(np.float32)
+    Ig, Jg = G(I, True), G(J, True)
+    l = vxm.losses.NCC(win=win).loss(Ig, Jg)
+    l.backward()
+    le, gJ, gI = orc.ncc_explicit_win(I, J, win, grad=True)
+    gate("ncc win=%s %s: loss vs fp64" % (win, vol), abs(float(l) - le), 1e-5)
+    gate("ncc win=%s %s: dJ vs fp64" % (win, vol), rel_l2(N(Jg.grad), gJ), NCC_GRAD_GATE)
+    gate("ncc win=%s %s: dI vs fp64" % (win, vol), rel_l2(N(Ig.grad), gI), NCC_GRAD_GATE)
 
 
 def test_ncc_grad_vs_fp64(vxm):
@@ -177,9 +227,9 @@ def test_ncc_grad_vs_fp64(vxm):
     Id = torch.from_numpy(I).double().requires_grad_()
     ld = orc.ncc_loss(Id, Jd)
     ld.backward()
-    assert abs(float(l) - float(ld)) < 1e-5
-    assert rel_l2(N(Jg.grad), Jd.grad.numpy()) < 1e-3
-    assert rel_l2(N(Ig.grad), Id.grad.numpy()) < 1e-3
+    gate("ncc 9^3: loss vs fp64", abs(float(l) - float(ld)), 1e-5)
+    gate("ncc 9^3: dJ vs fp64", rel_l2(N(Jg.grad), Jd.grad.numpy()), NCC_GRAD_GATE)
+    gate("ncc 9^3: dI vs fp64", rel_l2(N(Ig.grad), Id.grad.numpy()), NCC_GRAD_GATE)
 
 
 @pytest.mark.parametrize("win", [3, 7, 9, 11])
@@ -195,14 +245,15 @@ def test_ncc_windows_batches_segments_vs_fp64(vxm, win):
     Jd = torch.from_numpy(J).double().requires_grad_()
     ld = orc.ncc_loss(torch.from_numpy(I).double(), Jd, win=[win] * 3)
     ld.backward()
-    assert abs(float(l) - float(ld)) < 1e-5
-    assert rel_l2(N(Jg.grad), Jd.grad.numpy()) < 1e-3
+    gate("ncc %d^3 B=2: loss vs fp64" % win, abs(float(l) - float(ld)), 1e-5)
+    gate("ncc %d^3 B=2: dJ vs fp64" % win, rel_l2(N(Jg.grad), Jd.grad.numpy()), NCC_GRAD_GATE)
 
 
-@pytest.mark.parametrize("win", [None, 5])
+@pytest.mark.parametrize("win", [None, 5, 4])
 def test_ncc_one_dimensional_vs_reference_formula(vxm, win):
     """NCC on [B,1,L] signals (losses.py:15-67 with ndims = 1: conv1d box filter): the oracle IS the reference's formula (same ATen
-    calls, filter on the input's device); loss against its fp32 and fp64 evaluations, both gradients against fp64."""
+    calls, filter on the input's device); loss against its fp32 and fp64 evaluations, both gradients against fp64.  win = 4: an even
+    window (L + 1 box sums, losses.py:31)."""
     rng = np.random.default_rng(11)
     L = 777
     I = rng.random((3, 1, L)).astype(np.float32)
@@ -215,10 +266,10 @@ def test_ncc_one_dimensional_vs_reference_formula(vxm, win):
     Id, Jd = torch.from_numpy(I).double().requires_grad_(), torch.from_numpy(J).double().requires_grad_()
     ld = orc.ncc_loss(Id, Jd, win=w)
     ld.backward()
-    assert abs(float(l.detach()) - float(l32)) < 1e-4 and abs(float(l.detach()) - float(ld.detach())) < 1e-5
-    assert rel_l2(N(Jg.grad), Jd.grad.numpy()) < 1e-3 and rel_l2(N(Ig.grad), Id.grad.numpy()) < 1e-3
-    with pytest.raises(NotImplementedError):
-        vxm.losses.NCC(win=[4]).loss(Ig, Jg)
+    gate("ncc 1-D win=%s: loss vs fp32 formula" % w, abs(float(l.detach()) - float(l32)), 1e-4)
+    gate("ncc 1-D win=%s: loss vs fp64" % w, abs(float(l.detach()) - float(ld.detach())), 1e-5)
+    gate("ncc 1-D win=%s: dJ vs fp64" % w, rel_l2(N(Jg.grad), Jd.grad.numpy()), NCC_GRAD_GATE)
+    gate("ncc 1-D win=%s: dI vs fp64" % w, rel_l2(N(Ig.grad), Id.grad.numpy()), NCC_GRAD_GATE)
 
 
 def test_grad_mse_dice_golden(vxm, g_losses):

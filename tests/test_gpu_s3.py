@@ -226,3 +226,21 @@ def test_native_fp32_engine_at_full_size_in_subprocess():
         pytest.skip("already inside the native run")
     _rerun({"VXM_FP32_ENGINE": "native"}, "(full_size_conv_adjoint_identity and not four_pairs) or full_size_train_step_vs_oracle_noise_pair",
            files=("tests/test_gpu_parity.py",), timeout=1500)
+
+
+def test_packed_operator_cache_follows_reseated_and_invalidated_weights(VF):
+    """the split engine caches its packed operators on the weight tensor.  `w.data = other` (no version bump) must be seen
+    through the storage address in the key; a write into the SAME storage through `.data` is seen after `voxelmorph_amd.invalidate_packs`."""
+    import voxelmorph_amd
+    torch.manual_seed(3)
+    vol, B = (8, 8, 16), 1
+    x = torch.randn((B, 16) + vol, device="cuda")
+    w = torch.nn.Parameter(torch.randn(16, 16, 3, 3, 3, device="cuda") * 0.1)
+    y0 = _s3_forward(VF, x, False, None, w, None, 1.0, 16, vol, B).clone()
+    w.data = (w.data * 2.0).clone()                                   # re-seated storage, same version counter
+    y1 = _s3_forward(VF, x, False, None, w, None, 1.0, 16, vol, B).clone()
+    assert rel_l2(y1.cpu().numpy(), 2.0 * y0.cpu().numpy()) < 1e-6
+    w.data.mul_(0.5)                                                  # same storage, same counter: the cache cannot know ...
+    voxelmorph_amd.invalidate_packs([w])                              # ... until it is told
+    y2 = _s3_forward(VF, x, False, None, w, None, 1.0, 16, vol, B)
+    assert rel_l2(y2.cpu().numpy(), y0.cpu().numpy()) < 1e-6

@@ -97,6 +97,36 @@ def test_ncc(g_losses):
     assert abs(a - float(g_losses["ncc"])) < 1e-3
 
 
+def test_ncc_any_window_matches_reference(g_nccwin):
+    """Windows that are not odd and of one size (losses.py:26-36 pads every axis by win[0] // 2): the torch oracle is the reference's
+    call sequence (same ATen calls: tight), the explicit fp64 restatement carries the shape rule and the transposed filters the HIP
+    kernels implement."""
+    for tag in g_nccwin["cases"]:
+        tag = str(tag)
+        nd = len(g_nccwin[tag + "_win"])
+        win = [int(w) for w in g_nccwin[tag + "_win"]]
+        Ia, Ja = g_nccwin["I%d" % nd], g_nccwin["J%d" % nd]
+        I, J = T(Ia).requires_grad_(), T(Ja).requires_grad_()
+        l = orc.ncc_loss(I, J, win=win)
+        np.testing.assert_allclose(l.item(), g_nccwin[tag], rtol=1e-6, err_msg=tag)
+        l.backward()
+        np.testing.assert_allclose(J.grad.numpy(), g_nccwin[tag + "_gJ"], atol=5e-7, rtol=1e-5, err_msg=tag)   # (thread-count dependent sums)
+        np.testing.assert_allclose(I.grad.numpy(), g_nccwin[tag + "_gI"], atol=5e-7, rtol=1e-5, err_msg=tag)
+        le, gJ, gI = orc.ncc_explicit_win(Ia, Ja, win, grad=True)
+        Id, Jd = T(Ia).double().requires_grad_(), T(Ja).double().requires_grad_()
+        ld = orc.ncc_loss(Id, Jd, win=win)
+        ld.backward()
+        assert abs(le - ld.item()) < 1e-12, tag
+        assert np.abs(gJ - Jd.grad.numpy()).max() < 1e-12 and np.abs(gI - Id.grad.numpy()).max() < 1e-12, tag
+        assert abs(le - float(g_nccwin[tag])) < 1e-5, tag                 # fp64 arbiter vs the reference's fp32 evaluation
+    # odd windows of one size: the general restatement is the cubic one
+    assert abs(orc.ncc_explicit_win(g_nccwin["I3"], g_nccwin["J3"], [5, 5, 5]) - orc.ncc_explicit(g_nccwin["I3"], g_nccwin["J3"], 5)) < 1e-14
+    with pytest.raises(ValueError):
+        orc.ncc_explicit_win(g_nccwin["I2"][..., :4], g_nccwin["J2"][..., :4], [3, 9])      # 4 + 2 * (3 // 2) < 9: no box sums along W
+    with pytest.raises(RuntimeError):
+        orc.ncc_loss(T(g_nccwin["I2"][..., :4]), T(g_nccwin["J2"][..., :4]), win=[3, 9])    # ... and the reference's conv raises
+
+
 def test_mse_grad_dice(g_losses):
     I, J = T(g_losses["I"]), T(g_losses["J"])
     np.testing.assert_allclose(orc.mse_loss(I, J).item(), g_losses["mse"], rtol=1e-6)

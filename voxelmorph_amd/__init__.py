@@ -8,5 +8,6 @@ of `include/vxm_hip.h` (libvxm_hip.so).  No CPU or ATen fallback exists for the 
 from .torch import layers, losses, networks  # noqa: F401
 from .torch.networks import default_unet_features  # noqa: F401
 from . import torch  # noqa: F401
+from .torch.functional_bf16 import invalidate_packs  # noqa: F401
 
 __version__ = "0.1.0"

@@ -108,6 +108,9 @@ SIGNATURES = {
     "vxm_conv3d_k3_s3_bwd_weight_ok": [_I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3_bwd_weight_workspace_bytes": [_I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3_bwd_weight": [_P, _I, _L, _P, _L, _I, _P, _I, _I, _P, _P, _S, _I, _I, _I, _I, _P],
+    "vxm_ncc_win_elems": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vxm_ncc_win_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vxm_ncc_win_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vxm_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
 }
 _RESTYPES = {
@@ -120,6 +123,7 @@ _RESTYPES = {
     "vxm_conv3d_k3_s3_packed_bytes": _S,
     "vxm_conv3d_k3_s3_bwd_weight_workspace_bytes": _S,
     "vxm_bf16_conv_bwd_weight_workspace_bytes": _S,
+    "vxm_ncc_win_elems": _L,
 }
 
 _lib = None

@@ -128,6 +128,90 @@ __global__ void __launch_bounds__(256) k_ncc_grad_w(const float* __restrict__ u2
     gJ[p] = scale * (sa + 2.0f * J[p] * sb + I[p] * sc);
 }
 
+// ---- NCC with ANY window (losses.py:26-36,47-67).  The reference pads EVERY axis by win[0] // 2 whatever the other window sizes are,
+// so a window that is not cubic (or an even one) changes the extent of its box sums: O = S + 2 pad - win + 1 per axis; cc and its mean
+// live on that shape.  Separable passes whose axis filter may change the extent; tensors are [outer][S][inner] -> [outer][O][inner]
+// (planes and batch are part of `outer`, every stage buffer is densely packed at its own size).
+//   forward : out[o] = sum_{k=0..w-1} in[o - p + k]   (taps inside [0, S), ascending k as in the cubic passes above)
+//   adjoint : the same kernel from O back to S with p' = w - 1 - p
+__global__ void __launch_bounds__(256) k_box_axis_g(const float* __restrict__ in, float* __restrict__ out, long long n_out, int S, int O,
+                                                    long long inner, int w, int p) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_out) return;
+    const long long r = idx % inner, t = idx / inner;
+    const int o = (int)(t % O);
+    const long long outer = t / O;
+    const float* base = in + outer * S * inner + r;
+    const int lo = max(0, p - o), hi = min(w - 1, S - 1 - o + p);
+    float s = 0.f;
+    for (int k = lo; k <= hi; ++k) s += base[(long long)(o - p + k) * inner];
+    out[idx] = s;
+}
+
+// products + box sum along W: I, J [rows][W] -> out [5][rows][Ow]
+__global__ void __launch_bounds__(256) k_ncc_win_prod_w(const float* __restrict__ I, const float* __restrict__ J, float* __restrict__ out,
+                                                        long long rows, int W, int Ow, int w, int p) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x, n = rows * Ow;
+    if (idx >= n) return;
+    const int o = (int)(idx % Ow);
+    const long long row = idx / Ow;
+    const float* Ir = I + row * W;
+    const float* Jr = J + row * W;
+    const int lo = max(0, p - o), hi = min(w - 1, W - 1 - o + p);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    for (int k = lo; k <= hi; ++k) {
+        const float a = Ir[o - p + k], b = Jr[o - p + k];
+        s0 += a; s1 += b; s2 += a * a; s3 += b * b; s4 += a * b;
+    }
+    out[idx] = s0; out[n + idx] = s1; out[2 * n + idx] = s2; out[3 * n + idx] = s3; out[4 * n + idx] = s4;
+}
+
+// cc from the five box sums (losses.py:57-65), fp64 block reduction
+__global__ void __launch_bounds__(256) k_ncc_win_cc(const float* __restrict__ sums, double* __restrict__ acc, long long N, float n) {
+    __shared__ double red[4];
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    double cc = 0.0;
+    if (p < N) {
+        float cross, Ivar, Jvar;
+        ncc_terms(sums[p], sums[N + p], sums[2 * N + p], sums[3 * N + p], sums[4 * N + p], n, cross, Ivar, Jvar);
+        cc = (double)(cross * cross / (Ivar * Jvar + 1e-5f));
+    }
+    block_atomic_add(cc, acc, red);
+}
+
+// (a, b, c) = d cc / d(J sum, J^2 sum, IJ sum) on the shape of the box sums (as k_ncc_abc_d)
+__global__ void __launch_bounds__(256) k_ncc_win_abc(const float* __restrict__ sums, float* __restrict__ abc, long long N, float n) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= N) return;
+    const float Is = sums[q], Js = sums[N + q];
+    float cross, Ivar, Jvar;
+    ncc_terms(Is, Js, sums[2 * N + q], sums[3 * N + q], sums[4 * N + q], n, cross, Ivar, Jvar);
+    const float den = Ivar * Jvar + 1e-5f;
+    const float t = cross / den;
+    const float t2 = t * t * Ivar;
+    abc[q] = 2.0f * t * (-Is / n) + t2 * (2.0f * Js / n);
+    abc[N + q] = -t2;
+    abc[2 * N + q] = 2.0f * t;
+}
+
+// adjoint box filter along W of the three planes [3][rows][Ow] and the chain rule onto J [rows][W]:
+// dL/dJ = gloss * (-1/N) * [ S^T(a) + 2 J S^T(b) + I S^T(c) ],  N = number of box sums
+__global__ void __launch_bounds__(256) k_ncc_win_grad_w(const float* __restrict__ u, const float* __restrict__ I, const float* __restrict__ J,
+                                                        const float* __restrict__ gloss, float* __restrict__ gJ, long long rows, int W, int Ow,
+                                                        int w, int p, double N) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * W) return;
+    const int i = (int)(idx % W);
+    const long long row = idx / W, n = rows * Ow;
+    const float* ur = u + row * Ow;
+    const int pa = w - 1 - p;
+    const int lo = max(0, pa - i), hi = min(w - 1, Ow - 1 - i + pa);
+    float sa = 0.f, sb = 0.f, sc = 0.f;
+    for (int k = lo; k <= hi; ++k) { const int o = i - pa + k; sa += ur[o]; sb += ur[n + o]; sc += ur[2 * n + o]; }
+    const float scale = -gloss[0] / (float)N;
+    gJ[idx] = scale * (sa + 2.0f * J[idx] * sb + I[idx] * sc);
+}
+
 // ---- fused NCC for windows <= 9: one kernel marches a (8 x 32)-pixel column along D.  Per depth slice the haloed
 // products tile goes through LDS (W box sum, then H box sum: direct 2R+1-tap sums in the same order as the generic
 // passes above, so the values are identical), the last 2R+1 slices of 2-D sums live in a register shift ring, and
@@ -669,6 +753,68 @@ int vxm_ncc1d_bwd(const float* I, const float* J, const float* sums, const float
     VXM_REQUIRE(B > 0 && L > 0 && win > 0 && (win & 1), VXM_ERR_BAD_SHAPE, "vxm_ncc1d_bwd: bad shape / even window %d", win);
     ncc_generic_bwd(I, J, sums, gloss, gJ, work, (long long)B * L, 1, 1, L, win / 2, (float)win, VXM_STREAM(stream));
     return vxm_check_launch("vxm_ncc1d_bwd");
+}
+
+/* NCC.loss with any window (losses.py:26-36,47-67): per axis `win` taps and `pad` zeros on both sides; the reference's rule is
+ * pad = win[0] // 2 on every axis the tensor has (win 1 / pad 0 on the axes it does not have).  Box sums, cc and the mean live on
+ * O = S + 2 pad - win + 1 per axis. */
+struct NccWinShape { long long od, oh, ow, n_out, plane; };
+static bool ncc_win_shape(int B, int D, int H, int W, int wd, int wh, int ww, int pd, int ph, int pw, NccWinShape& s) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || wd <= 0 || wh <= 0 || ww <= 0 || pd < 0 || ph < 0 || pw < 0) return false;
+    s.od = (long long)D + 2 * pd - wd + 1; s.oh = (long long)H + 2 * ph - wh + 1; s.ow = (long long)W + 2 * pw - ww + 1;
+    if (s.od <= 0 || s.oh <= 0 || s.ow <= 0) return false;       // the reference's conv raises there too (kernel larger than the padded input)
+    const long long st1 = (long long)B * D * H * s.ow, st2 = (long long)B * D * s.oh * s.ow;
+    s.n_out = (long long)B * s.od * s.oh * s.ow;
+    s.plane = st1 > st2 ? st1 : st2;
+    if (s.n_out > s.plane) s.plane = s.n_out;
+    return true;
+}
+
+int64_t vxm_ncc_win_elems(int B, int D, int H, int W, int wd, int wh, int ww, int pd, int ph, int pw, int64_t* n_out) {
+    NccWinShape sh;
+    if (!ncc_win_shape(B, D, H, W, wd, wh, ww, pd, ph, pw, sh)) { if (n_out) *n_out = 0; return 0; }
+    if (n_out) *n_out = sh.n_out;
+    return sh.plane;
+}
+
+int vxm_ncc_win_fwd(const float* I, const float* J, float* loss, float* sums, float* work, double* acc, int B, int D, int H, int W,
+                    int wd, int wh, int ww, int pd, int ph, int pw, void* stream) {
+    VXM_REQUIRE(I && J && loss && sums && work && acc, VXM_ERR_NULL_POINTER, "vxm_ncc_win_fwd: null pointer");
+    NccWinShape sh;
+    VXM_REQUIRE(ncc_win_shape(B, D, H, W, wd, wh, ww, pd, ph, pw, sh), VXM_ERR_BAD_SHAPE,
+                "vxm_ncc_win_fwd: bad shape [%d,%d,%d,%d] window (%d,%d,%d) pad (%d,%d,%d) (a window larger than the padded axis has no box sums)",
+                B, D, H, W, wd, wh, ww, pd, ph, pw);
+    hipStream_t s = VXM_STREAM(stream);
+    (void)hipMemsetAsync(acc, 0, sizeof(double), s);
+    float* t1 = work;                    // [5][B D H Ow]
+    float* t2 = work + 5 * sh.plane;     // [5][B D Oh Ow]
+    const long long rows = (long long)B * D * H, n1 = rows * sh.ow, n2 = (long long)B * D * sh.oh * sh.ow;
+    hipLaunchKernelGGL(k_ncc_win_prod_w, dim3(vxm_blocks(n1, 256)), dim3(256), 0, s, I, J, t1, rows, W, (int)sh.ow, ww, pw);
+    hipLaunchKernelGGL(k_box_axis_g, dim3(vxm_blocks(5 * n2, 256)), dim3(256), 0, s, t1, t2, 5 * n2, H, (int)sh.oh, sh.ow, wh, ph);
+    hipLaunchKernelGGL(k_box_axis_g, dim3(vxm_blocks(5 * sh.n_out, 256)), dim3(256), 0, s, t2, sums, 5 * sh.n_out, D, (int)sh.od,
+                       sh.oh * sh.ow, wd, pd);
+    hipLaunchKernelGGL(k_ncc_win_cc, dim3(vxm_blocks(sh.n_out, 256)), dim3(256), 0, s, sums, acc, sh.n_out, (float)wd * wh * ww);
+    hipLaunchKernelGGL(k_finish_mean, dim3(1), dim3(64), 0, s, acc, loss, -1.0 / (double)sh.n_out);
+    return vxm_check_launch("vxm_ncc_win_fwd");
+}
+
+int vxm_ncc_win_bwd(const float* I, const float* J, const float* sums, const float* gloss, float* gJ, float* work, int B, int D, int H, int W,
+                    int wd, int wh, int ww, int pd, int ph, int pw, void* stream) {
+    VXM_REQUIRE(I && J && sums && gloss && gJ && work, VXM_ERR_NULL_POINTER, "vxm_ncc_win_bwd: null pointer");
+    NccWinShape sh;
+    VXM_REQUIRE(ncc_win_shape(B, D, H, W, wd, wh, ww, pd, ph, pw, sh), VXM_ERR_BAD_SHAPE,
+                "vxm_ncc_win_bwd: bad shape [%d,%d,%d,%d] window (%d,%d,%d) pad (%d,%d,%d)", B, D, H, W, wd, wh, ww, pd, ph, pw);
+    hipStream_t s = VXM_STREAM(stream);
+    float* u0 = work;                    // [3][B Od Oh Ow], then [3][B D H Ow]
+    float* u1 = work + 3 * sh.plane;     // [3][B D Oh Ow]
+    const long long rows = (long long)B * D * H, n1 = rows * sh.ow, n2 = (long long)B * D * sh.oh * sh.ow;
+    hipLaunchKernelGGL(k_ncc_win_abc, dim3(vxm_blocks(sh.n_out, 256)), dim3(256), 0, s, sums, u0, sh.n_out, (float)wd * wh * ww);
+    hipLaunchKernelGGL(k_box_axis_g, dim3(vxm_blocks(3 * n2, 256)), dim3(256), 0, s, u0, u1, 3 * n2, (int)sh.od, D, sh.oh * sh.ow, wd,
+                       wd - 1 - pd);
+    hipLaunchKernelGGL(k_box_axis_g, dim3(vxm_blocks(3 * n1, 256)), dim3(256), 0, s, u1, u0, 3 * n1, (int)sh.oh, H, sh.ow, wh, wh - 1 - ph);
+    hipLaunchKernelGGL(k_ncc_win_grad_w, dim3(vxm_blocks(rows * W, 256)), dim3(256), 0, s, u0, I, J, gloss, gJ, rows, W, (int)sh.ow, ww, pw,
+                       (double)sh.n_out);
+    return vxm_check_launch("vxm_ncc_win_bwd");
 }
 
 static int gradloss_fwd(const char* fn, const float* y, float* loss, double* acc, int B, int C, int D, int H, int W, int penalty, float mult,

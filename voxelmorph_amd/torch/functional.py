@@ -4,6 +4,7 @@ Each Function replaces one ATen op chain of the reference (file:line in the docs
 calls into libvxm_hip.so on the current HIP stream.  PyTorch is used for device memory
 (torch.empty through the caching allocator), streams and autograd bookkeeping only.
 """
+import ctypes
 import math
 import os
 
@@ -24,6 +25,8 @@ OVERLAP_MIN_LEVEL = int(os.environ.get("VXM_OVERLAP_MIN_LEVEL", "0"))
 # everywhere (csrc/conv_fwd.hip).  VXM_S3_UP=1 also sends cat([upsample(x0), x1]) layers through the split kernel (nominal FLOPs,
 # gather through the upsampling) instead of the collapsed-weight fp32 kernel.
 FP32_ENGINE = os.environ.get("VXM_FP32_ENGINE", "split")
+if FP32_ENGINE not in ("split", "native"):
+    raise ValueError("VXM_FP32_ENGINE must be 'split' or 'native', got %r" % FP32_ENGINE)
 S3_UP = os.environ.get("VXM_S3_UP", "") == "1"
 _SIDE_STREAMS = {}
 
@@ -191,6 +194,55 @@ class NCCFn(torch.autograd.Function):
                 swapped = torch.stack([sums[1], sums[0], sums[3], sums[2], sums[4]])
             gI = torch.empty_like(I)
             call("vxm_ncc_bwd", ptr(J), ptr(I), ptr(swapped), ptr(gloss), ptr(gI), ptr(work), B, D, H, W, ctx.win, stream())
+        return gI, gJ, None
+
+
+class NCCWinFn(torch.autograd.Function):
+    """NCC.loss (voxelmorph/torch/losses.py:15-67) with ANY window on 1-, 2- or 3-D volumes: the reference pads every axis by
+    win[0] // 2 (:31-36), so windows that are not odd and of one size change the extent of the box sums, and with it the
+    shape cc is averaged over (:65-67).  `win` is the per-axis list, len(win) == number of spatial axes."""
+
+    @staticmethod
+    def forward(ctx, y_true, y_pred, win):
+        require_device(y_true, y_pred)
+        I, J = _c(y_true), _c(y_pred)
+        nd = I.dim() - 2
+        if nd not in (1, 2, 3) or I.shape[1] != 1 or I.shape != J.shape or len(win) != nd:
+            raise ValueError("NCC: expected two [B,1,*vol] tensors (the reference's box filter has one input channel, losses.py:29) "
+                             "and one window size per axis, got %s / %s, win=%s" % (tuple(I.shape), tuple(J.shape), list(win)))
+        B = I.shape[0]
+        size = [1] * (3 - nd) + [int(v) for v in I.shape[2:]]
+        w3 = [1] * (3 - nd) + [int(v) for v in win]
+        pad = int(win[0]) // 2                                            # losses.py:31
+        p3 = [0] * (3 - nd) + [pad] * nd
+        geo = (B, *size, *w3, *p3)
+        n_out = ctypes.c_int64(0)
+        plane = int(_lib.lib().vxm_ncc_win_elems(*geo, ctypes.byref(n_out)))
+        if plane <= 0:
+            raise ValueError("NCC: window %s with padding %d leaves no box sums on a volume of shape %s (the reference's conv raises "
+                             "for a kernel larger than the padded input too)" % (list(win), pad, tuple(I.shape[2:])))
+        loss = torch.empty((), dtype=I.dtype, device=I.device)
+        sums = torch.empty((5, n_out.value), dtype=I.dtype, device=I.device)
+        work = torch.empty(10 * plane, dtype=I.dtype, device=I.device)
+        acc = torch.empty(1, dtype=torch.float64, device=I.device)
+        call("vxm_ncc_win_fwd", ptr(I), ptr(J), ptr(loss), ptr(sums), ptr(work), ptr(acc), *geo, stream())
+        ctx.save_for_backward(I, J, sums)
+        ctx.geo, ctx.plane = geo, plane
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        I, J, sums = ctx.saved_tensors
+        gloss = _c(gloss)
+        work = torch.empty(6 * ctx.plane, dtype=I.dtype, device=I.device)
+        gI = gJ = None
+        if ctx.needs_input_grad[1]:
+            gJ = torch.empty_like(J)
+            call("vxm_ncc_win_bwd", ptr(I), ptr(J), ptr(sums), ptr(gloss), ptr(gJ), ptr(work), *ctx.geo, stream())
+        if ctx.needs_input_grad[0]:      # cc is symmetric in (I, J): box-sum planes 0<->1 and 2<->3
+            swapped = torch.stack([sums[1], sums[0], sums[3], sums[2], sums[4]])
+            gI = torch.empty_like(I)
+            call("vxm_ncc_win_bwd", ptr(J), ptr(I), ptr(swapped), ptr(gloss), ptr(gI), ptr(work), *ctx.geo, stream())
         return gI, gJ, None
 
 

@@ -12,6 +12,8 @@ MIOpen for `ConvBlock` / flow conv / MaxPool3d / Upsample + cat (voxelmorph/torc
 """
 import ctypes
 
+import os
+
 import torch
 
 from .. import _lib
@@ -36,18 +38,41 @@ def enabled():
     return torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
 
 
+# VXM_PACK_CACHE=0: never reuse a packed operator (every launch re-packs, the behaviour of rounds 1-2 on the fp32 path).  For training
+# loops that write parameter VALUES behind the version counter (`p.data.copy_()`, `vector_to_parameters`, an EMA swap) and cannot call
+# `invalidate_packs`: costs one small pack launch per conv launch.
+PACK_CACHE = os.environ.get("VXM_PACK_CACHE", "1") != "0"
+_NOCACHE_TICK = [0]
+
+
 def _ver(t):
-    """Version counter of a parameter for the packed-weight cache and the hand-made in-place check.  Inference tensors (a model
-    built or loaded under torch.inference_mode()) have none: they cannot be modified in place by autograd-visible code either, so
-    the cache key is their storage address + a generation number bumped by `invalidate_packs`."""
+    """Cache key of the packed copies of a parameter (and of the hand-made in-place check): its version counter, the address of its
+    storage (`p.data = other` re-seats it without touching the counter) and a generation number bumped by `invalidate_packs`.
+    Inference tensors (a model built or loaded under torch.inference_mode()) have no version counter; they cannot be modified in
+    place by autograd-visible code either.  A write through `.data` INTO the same storage is invisible to all three: such writers
+    call `voxelmorph_amd.invalidate_packs(model)` (or run with VXM_PACK_CACHE=0)."""
+    gen = t.__dict__.get("_vxm_pack_gen", 0)
+    if not PACK_CACHE:
+        _NOCACHE_TICK[0] += 1
+        gen = ("nocache", _NOCACHE_TICK[0])          # never equal to a stored key
     if t.is_inference():
-        return ("inference", t.data_ptr(), t.__dict__.get("_vxm_pack_gen", 0))
-    return (t._version, t.__dict__.get("_vxm_pack_gen", 0))
+        return ("inference", t.data_ptr(), gen)
+    return (t._version, t.data_ptr(), gen)
+
+
+def _inplace_ver(t):
+    """what the hand-made in-place-modification check of the fused engine compares between forward and backward"""
+    gen = t.__dict__.get("_vxm_pack_gen", 0)
+    return ("inference", t.data_ptr(), gen) if t.is_inference() else (t._version, t.data_ptr(), gen)
 
 
 def invalidate_packs(params):
-    """Writers that change parameter VALUES without bumping the version counter (`.data` writes, collectives into the flat
-    buffer: FlatAdam.broadcast_params) call this so that the cached bf16 operators are re-packed."""
+    """Drop the packed (bf16 / split-fp32) operators cached on `params` (an iterable of parameters, or a module).  Needed after
+    parameter VALUES were changed without bumping the version counter -- `p.data.copy_(...)`, `vector_to_parameters`, an EMA weight
+    swap, collectives into the flat buffer (`FlatAdam.broadcast_params` calls it itself).  Ordinary in-place updates (`p.add_`, every
+    torch optimiser, `load_state_dict`, `FlatAdam.step`) bump the counter and need nothing."""
+    if hasattr(params, "parameters"):
+        params = params.parameters()
     for p in params:
         p.__dict__["_vxm_pack_gen"] = p.__dict__.get("_vxm_pack_gen", 0) + 1
 
@@ -225,7 +250,7 @@ class UnetBf16Fn(torch.autograd.Function):
             out = torch.empty((B, plan.ch[plan.out], D, H, W), dtype=torch.float32, device=dev)
             call("vxm_bf16_from_blocked", ptr(T[plan.out]), plan.ch[plan.out], ptr(out), plan.ch[plan.out], B, D * H * W, stream())
         ctx.plan, ctx.T, ctx.xin, ctx.params, ctx.shape3, ctx.B, ctx.cin0 = plan, T, xin, params, shape3, B, cin0
-        ctx.versions = [_ver(t) for t in params]
+        ctx.versions = [_inplace_ver(t) for t in params]
         return out
 
     @staticmethod
@@ -233,7 +258,7 @@ class UnetBf16Fn(torch.autograd.Function):
         plan, params, shape3, B, xin, cin0 = ctx.plan, ctx.params, ctx.shape3, ctx.B, ctx.xin, ctx.cin0
         if ctx.T is None:
             raise RuntimeError("UnetBf16Fn: backward a second time: the saved activations were released by the first pass")
-        if [_ver(t) for t in params] != ctx.versions:
+        if [_inplace_ver(t) for t in params] != ctx.versions:
             raise RuntimeError("UnetBf16Fn: a parameter was modified in place between forward and backward "
                                "(e.g. an optimizer step before loss.backward()); gradients would be wrong")
         T, ctx.T, ctx.xin = ctx.T, None, None

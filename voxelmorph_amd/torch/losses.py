@@ -16,11 +16,13 @@ class NCC:
         ndims = len(list(y_true.size())) - 2
         assert ndims in [1, 2, 3], "volumes should be 1 to 3 dimensions. found: %d" % ndims
         win = [9] * ndims if self.win is None else list(self.win)
-        if len(win) != ndims or len(set(win)) != 1 or win[0] % 2 == 0:
-            # (the reference pads every axis by win[0] // 2 whatever the other window sizes are, losses.py:31-36: a window that is not
-            # square / cubic changes the SHAPE of its box sums; that corner of its behaviour is not built)
-            raise NotImplementedError("the MI355X NCC kernels implement odd windows of one size per axis (line / square / cube); "
-                                      "got win=%s on %d-D" % (win, ndims))
+        if len(win) != ndims or len(set(win)) != 1 or int(win[0]) % 2 == 0 or int(win[0]) != win[0]:
+            # the reference pads every axis by win[0] // 2 whatever the other window sizes are (losses.py:31-36): windows that are not
+            # odd and of one size change the SHAPE of the box sums -- the general separable passes follow that rule
+            if len(win) != ndims:
+                # (torch.ones([1, 1, *win]) of another rank makes the reference's conv raise)
+                raise ValueError("NCC: %d window sizes for a %d-D volume" % (len(win), ndims))
+            return VF.NCCWinFn.apply(y_true, y_pred, [int(w) for w in win])
         if ndims == 1:
             return VP.NCC1dFn.apply(y_true, y_pred, int(win[0]))
         if ndims == 2:
