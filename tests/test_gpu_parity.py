@@ -2,8 +2,8 @@
 golden fixtures produced by the unmodified reference.  Run on the MI355X box: `pytest -m gpu`.
 
 Tolerances (SURVEY.md §8c / BASELINE.md §4): nearest warp + index grid bit-exact; trilinear warp
-<= 1e-5 abs; integrated flows <= 1e-4 abs; conv activations rel-L2 <= 1e-5; NCC <= 1e-3 vs the fp32
-oracle and <= 1e-5 vs the fp64 arbiter; parameter gradients rel-L2 <= 1e-4.
+<= 1e-5 abs; integrated flows <= 1e-4 abs; conv activations rel-L2 <= 1e-5; NCC kernels: loss <= 2.5e-7 vs the fp64
+arbiter, gradients <= 2.5e-6 vs fp64 (the NCC_* gates below); parameter gradients rel-L2 <= 1e-4.
 """
 import os
 
@@ -154,24 +154,28 @@ def test_resize_golden(vxm, g_layers):
 
 
 # ------------------------------------------------------------------ losses
-# NCC gates: the loss against the reference's fp32 evaluation <= 1e-3 is the documented conditioning bound of its formula, not
-# the kernel's accuracy -- that is the fp64 arbiter (loss <= 1e-5 abs) and the gradients against fp64, gated at <= 5x what was measured
-# on the MI355X (profiles/r04*_gpu_tests.log prints the measured values).
-NCC_GRAD_GATE = 2e-5
+# NCC gates, all <= 5x what was measured on the MI355X (round 4, profiles/r04*_gpu_tests.log prints the measured values):
+#   gradients against the fp64 evaluation      2-D / 3-D  measured <= 4.98e-7  -> 2.5e-6;  1-D (4..9-tap windows: the formula's conditioning)  2.05e-5 -> 1e-4
+#   gradients against the reference's own fp32 gradients (which carry their own fp32 error)   measured <= 5.9e-6 -> 1.5e-5 ... 3e-5 (1-D)
+#   loss against the fp64 arbiter  measured <= 4.5e-8 -> 2.5e-7;  against the reference's fp32 value  measured <= 4.8e-7 -> 2.5e-6
+NCC_GRAD_GATE = 2.5e-6
+NCC_GRAD_GATE_REF = 1.5e-5
+NCC_GRAD_GATE_1D = 1e-4
+NCC_LOSS_GATE, NCC_LOSS_GATE_REF = 2.5e-7, 2.5e-6
 
 
 def test_ncc_golden(vxm, g_losses):
     I, J = G(g_losses["I"]), G(g_losses["J"], True)
     l = vxm.losses.NCC().loss(I, J)
-    gate("ncc golden: loss vs fp32 reference", abs(float(l) - float(g_losses["ncc"])), 1e-3)
-    gate("ncc golden: loss vs fp64 arbiter", abs(float(l) - orc.ncc_explicit(g_losses["I"], g_losses["J"])), 1e-5)
+    gate("ncc golden: loss vs fp32 reference", abs(float(l) - float(g_losses["ncc"])), NCC_LOSS_GATE_REF)
+    gate("ncc golden: loss vs fp64 arbiter", abs(float(l) - orc.ncc_explicit(g_losses["I"], g_losses["J"])), NCC_LOSS_GATE)
     l.backward()
-    gate("ncc golden: dJ vs reference (fp32)", rel_l2(N(J.grad), g_losses["ncc_gJ"]), NCC_GRAD_GATE)
+    gate("ncc golden: dJ vs reference (fp32)", rel_l2(N(J.grad), g_losses["ncc_gJ"]), NCC_GRAD_GATE_REF)
     J5 = G(g_losses["J"], True)
     l5 = vxm.losses.NCC(win=[5, 5, 5]).loss(I, J5)
-    gate("ncc5 golden: loss vs fp32 reference", abs(float(l5) - float(g_losses["ncc5"])), 1e-3)
+    gate("ncc5 golden: loss vs fp32 reference", abs(float(l5) - float(g_losses["ncc5"])), NCC_LOSS_GATE_REF)
     l5.backward()
-    gate("ncc5 golden: dJ vs reference (fp32)", rel_l2(N(J5.grad), g_losses["ncc5_gJ"]), NCC_GRAD_GATE)
+    gate("ncc5 golden: dJ vs reference (fp32)", rel_l2(N(J5.grad), g_losses["ncc5_gJ"]), NCC_GRAD_GATE_REF)
 
 
 def test_ncc_any_window_golden(vxm, g_nccwin):
@@ -186,12 +190,13 @@ def test_ncc_any_window_golden(vxm, g_nccwin):
         l = vxm.losses.NCC(win=win).loss(I, J)
         l.backward()
         le, gJ, gI = orc.ncc_explicit_win(Ia, Ja, win, grad=True)
-        gate("ncc win=%s: loss vs fp32 reference" % win, abs(float(l) - float(g_nccwin[tag])), 1e-4)
-        gate("ncc win=%s: loss vs fp64 arbiter" % win, abs(float(l) - le), 1e-5)
-        gate("ncc win=%s: dJ vs reference" % win, rel_l2(N(J.grad), g_nccwin[tag + "_gJ"]), NCC_GRAD_GATE)
-        gate("ncc win=%s: dI vs reference" % win, rel_l2(N(I.grad), g_nccwin[tag + "_gI"]), NCC_GRAD_GATE)
-        gate("ncc win=%s: dJ vs fp64" % win, rel_l2(N(J.grad), gJ), NCC_GRAD_GATE)
-        gate("ncc win=%s: dI vs fp64" % win, rel_l2(N(I.grad), gI), NCC_GRAD_GATE)
+        g64, gref = (NCC_GRAD_GATE_1D, 2 * NCC_GRAD_GATE_REF) if nd == 1 else (NCC_GRAD_GATE, NCC_GRAD_GATE_REF)
+        gate("ncc win=%s: loss vs fp32 reference" % win, abs(float(l) - float(g_nccwin[tag])), NCC_LOSS_GATE_REF)
+        gate("ncc win=%s: loss vs fp64 arbiter" % win, abs(float(l) - le), NCC_LOSS_GATE)
+        gate("ncc win=%s: dJ vs reference" % win, rel_l2(N(J.grad), g_nccwin[tag + "_gJ"]), gref)
+        gate("ncc win=%s: dI vs reference" % win, rel_l2(N(I.grad), g_nccwin[tag + "_gI"]), gref)
+        gate("ncc win=%s: dJ vs fp64" % win, rel_l2(N(J.grad), gJ), g64)
+        gate("ncc win=%s: dI vs fp64" % win, rel_l2(N(I.grad), gI), g64)
     # a window that leaves no box sums raises, as the reference's conv does
     with pytest.raises(ValueError):
         vxm.losses.NCC(win=[3, 9]).loss(G(g_nccwin["I2"][..., :4]), G(g_nccwin["J2"][..., :4]))
@@ -209,7 +214,7 @@ def test_ncc_any_window_larger_volume_vs_fp64(vxm, win):
     l = vxm.losses.NCC(win=win).loss(Ig, Jg)
     l.backward()
     le, gJ, gI = orc.ncc_explicit_win(I, J, win, grad=True)
-    gate("ncc win=%s %s: loss vs fp64" % (win, vol), abs(float(l) - le), 1e-5)
+    gate("ncc win=%s %s: loss vs fp64" % (win, vol), abs(float(l) - le), NCC_LOSS_GATE)
     gate("ncc win=%s %s: dJ vs fp64" % (win, vol), rel_l2(N(Jg.grad), gJ), NCC_GRAD_GATE)
     gate("ncc win=%s %s: dI vs fp64" % (win, vol), rel_l2(N(Ig.grad), gI), NCC_GRAD_GATE)
 
@@ -227,7 +232,7 @@ def test_ncc_grad_vs_fp64(vxm):
     Id = torch.from_numpy(I).double().requires_grad_()
     ld = orc.ncc_loss(Id, Jd)
     ld.backward()
-    gate("ncc 9^3: loss vs fp64", abs(float(l) - float(ld)), 1e-5)
+    gate("ncc 9^3: loss vs fp64", abs(float(l) - float(ld)), NCC_LOSS_GATE)
     gate("ncc 9^3: dJ vs fp64", rel_l2(N(Jg.grad), Jd.grad.numpy()), NCC_GRAD_GATE)
     gate("ncc 9^3: dI vs fp64", rel_l2(N(Ig.grad), Id.grad.numpy()), NCC_GRAD_GATE)
 
@@ -245,7 +250,7 @@ def test_ncc_windows_batches_segments_vs_fp64(vxm, win):
     Jd = torch.from_numpy(J).double().requires_grad_()
     ld = orc.ncc_loss(torch.from_numpy(I).double(), Jd, win=[win] * 3)
     ld.backward()
-    gate("ncc %d^3 B=2: loss vs fp64" % win, abs(float(l) - float(ld)), 1e-5)
+    gate("ncc %d^3 B=2: loss vs fp64" % win, abs(float(l) - float(ld)), NCC_LOSS_GATE)
     gate("ncc %d^3 B=2: dJ vs fp64" % win, rel_l2(N(Jg.grad), Jd.grad.numpy()), NCC_GRAD_GATE)
 
 
@@ -266,10 +271,10 @@ def test_ncc_one_dimensional_vs_reference_formula(vxm, win):
     Id, Jd = torch.from_numpy(I).double().requires_grad_(), torch.from_numpy(J).double().requires_grad_()
     ld = orc.ncc_loss(Id, Jd, win=w)
     ld.backward()
-    gate("ncc 1-D win=%s: loss vs fp32 formula" % w, abs(float(l.detach()) - float(l32)), 1e-4)
-    gate("ncc 1-D win=%s: loss vs fp64" % w, abs(float(l.detach()) - float(ld.detach())), 1e-5)
-    gate("ncc 1-D win=%s: dJ vs fp64" % w, rel_l2(N(Jg.grad), Jd.grad.numpy()), NCC_GRAD_GATE)
-    gate("ncc 1-D win=%s: dI vs fp64" % w, rel_l2(N(Ig.grad), Id.grad.numpy()), NCC_GRAD_GATE)
+    gate("ncc 1-D win=%s: loss vs fp32 formula" % w, abs(float(l.detach()) - float(l32)), NCC_LOSS_GATE_REF)
+    gate("ncc 1-D win=%s: loss vs fp64" % w, abs(float(l.detach()) - float(ld.detach())), NCC_LOSS_GATE)
+    gate("ncc 1-D win=%s: dJ vs fp64" % w, rel_l2(N(Jg.grad), Jd.grad.numpy()), NCC_GRAD_GATE_1D)
+    gate("ncc 1-D win=%s: dI vs fp64" % w, rel_l2(N(Ig.grad), Id.grad.numpy()), NCC_GRAD_GATE_1D)
 
 
 def test_grad_mse_dice_golden(vxm, g_losses):
@@ -1111,11 +1116,11 @@ def test_planar_losses_golden(vxm, g_planar):
     for tag, win in (("ncc", None), ("ncc5", [5, 5])):
         J = G(g["J"], True)
         l = vxm.losses.NCC(win=win).loss(G(g["I"]), J)
-        assert abs(float(l) - float(g[tag])) < 1e-3
+        gate("planar %s: loss vs fp32 reference" % tag, abs(float(l) - float(g[tag])), NCC_LOSS_GATE_REF)
         ref64 = orc.ncc_loss(torch.from_numpy(g["I"]), torch.from_numpy(g["J"]), win=win, dtype=torch.float64).item()
-        assert abs(float(l) - ref64) < 1e-5
+        gate("planar %s: loss vs fp64" % tag, abs(float(l) - ref64), NCC_LOSS_GATE)
         l.backward()
-        assert rel_l2(N(J.grad), g[tag + "_gJ"]) < 2e-3
+        gate("planar %s: dJ vs reference (fp32)" % tag, rel_l2(N(J.grad), g[tag + "_gJ"]), NCC_GRAD_GATE_REF)
     for pen, mult in (("l1", None), ("l2", 2)):
         fl = G(g["warp_flow"], True)
         l = vxm.losses.Grad(pen, loss_mult=mult).loss(None, fl)
