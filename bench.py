@@ -167,18 +167,21 @@ def binding_roofline(name, st):
     is_bf = name.startswith("k_bf16")
     is_split = name.startswith("k_s3_")
     alg = st["nominal"] if is_bf else st["flops"]
-    # split-fp32 kernels (csrc/conv_s3.hip) run on the bf16 pipe, six v_mfma_f32_16x16x32_bf16 per fp32-equivalent MAC block: their
-    # ceiling in fp32-equivalent FLOPs is the dense bf16 peak / 6 -- NOT the fp32-MFMA peak, which they can (and do) exceed
-    peak = BF16_MFMA_PEAK_TFLOPS if is_bf else (BF16_MFMA_PEAK_TFLOPS / 6.0 if is_split else FP32_MFMA_PEAK_TFLOPS)
+    # split-fp32 kernels (csrc/conv_s3.hip) run on the 16-bit matrix pipe with `nprod` MFMAs per fp32-equivalent MAC block -- six
+    # v_mfma_f32_16x16x32_bf16 (three bf16 pieces, region label ends in ",3>" / "<3>") or three v_mfma_f32_16x16x32_f16 (two fp16 pieces,
+    # ",2>" / "<2>"): their ceiling in fp32-equivalent FLOPs is the dense 16-bit peak / nprod -- NOT the fp32-MFMA peak, which they exceed
+    nprod = 3.0 if (is_split and name.rstrip(">").endswith("2")) else 6.0
+    peak = BF16_MFMA_PEAK_TFLOPS if is_bf else (BF16_MFMA_PEAK_TFLOPS / nprod if is_split else FP32_MFMA_PEAK_TFLOPS)
     ach = alg / sec / 1e12
     if hbm is not None and st["bytes"] / (HBM_PEAK_GBS * 1e9) > alg / (peak * 1e12):
         hbm["mfma_frac"] = ach / peak
         return hbm
     out = dict(per, kernel=name, bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, algorithmic_per_launch=alg / st["launches"])
     if is_split:
-        out["peak_note"] = ("fp32-equivalent FLOPs of a kernel that executes 6 bf16 MFMAs per fp32 MAC block: peak = 2500 / 6 TFLOP/s; the same rate "
-                            "is %.2f x the fp32-MFMA peak (157.3)" % (ach / FP32_MFMA_PEAK_TFLOPS))
-        out["bf16_pipe_tflops"] = 6.0 * ach
+        out["peak_note"] = ("fp32-equivalent FLOPs of a kernel that executes %d 16-bit MFMAs (%s) per fp32 MAC block: peak = 2500 / %d TFLOP/s; the "
+                            "same rate is %.2f x the fp32-MFMA peak (157.3)" % (nprod, "fp16 x 2 pieces" if nprod == 3.0 else "bf16 x 3 pieces", nprod,
+                                                                               ach / FP32_MFMA_PEAK_TFLOPS))
+        out["matrix_pipe_tflops"] = nprod * ach
     return out
 
 
@@ -419,13 +422,18 @@ def main():
         del wl
         torch.cuda.empty_cache()
         for key, name, eb, esteps in (("dense_bf16", "dense_bf16", 1, 8), ("diffeo_fp32_4_pairs_per_gpu", "diffeo_fp32", 4, 4),
-                                      ("semisup_fp32", "semisup_fp32", 1, 8), ("diffeo_fp32_native_engine", "diffeo_fp32", 1, 8)):
+                                      ("semisup_fp32", "semisup_fp32", 1, 8), ("diffeo_fp32_bf16x3_engine", "diffeo_fp32", 1, 8),
+                                      ("diffeo_fp32_native_engine", "diffeo_fp32", 1, 8)):
             engine = VF.FP32_ENGINE
             try:
                 if key == "diffeo_fp32_native_engine":     # the headline workload on the exact-fp32 MFMA kernels of rounds 1-2, for comparison
                     if engine == "native":
                         continue
                     VF.FP32_ENGINE = "native"
+                if key == "diffeo_fp32_bf16x3_engine":     # ... and on the three-piece bf16 split of round 3
+                    if engine == "split":
+                        continue
+                    VF.FP32_ENGINE = "split"
                 w2 = Workload(vxm, vdist, name, shape, eb, dev, rank)
                 # warm-up = the timed pattern itself (esteps steps enqueued back to back): the caching allocator only reaches its steady
                 # state under the run-ahead of the real loop (blocks held by the side stream's pending events are not reusable yet); with two

@@ -305,11 +305,18 @@ int vxm_bf16_lrelu_bwd(const void* g, const void* y, void* dz, float slope, int6
  * split into three bf16 pieces (exactly: x = h + m + l up to 2^-24 |x|) while it is staged, and a product is accumulated in fp32
  * from its six leading piece products on v_mfma_f32_16x16x32_bf16: fp32-level accuracy (same rel-L2 <= 1e-5 gate against an fp64
  * evaluation as the fp32-MFMA kernels), 2.67x the matrix-pipe rate.  C0, C1 multiples of 8.
+ * `pieces` selects the split: 3 = the three bf16 pieces above; 2 = TWO fp16 pieces (x s = h + l up to 2^-22 |x s|, three products
+ * hh + hl + lh on v_mfma_f32_16x16x32_f16: half the matrix instructions).  fp16 has a 5-bit exponent, so every staged tile is scaled by
+ * the power of two s that brings its largest magnitude into [2^14, 2^15) and an MFMA chain lives for one staged chunk before the vector
+ * ALU folds it, unscaled, into the fp32 totals; weights carry one scale per packed operator.  Same accuracy gates as pieces = 3; the
+ * difference is range: inside ONE staged tile, values below 2^-18 of the tile's largest magnitude lose relative precision (absolute
+ * error 2^-40 of that magnitude), which bf16's 8-bit exponent does not.  The packed weights of the two schemes differ (pass the same
+ * `pieces` to packed_bytes / the pack job / the launch).
  * vxm_conv3d_k3_s3_ok: 1 when the split kernel takes a launch of this shape (otherwise use vxm_conv3d_k3_fwd). */
 int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W);
 int vxm_conv3d_k3_s3_variant(int Cout);                     /* 10 * NCT + CB of the kernel instance (profiling labels) */
 /* packed, pre-split weights of one operator: seg0 / seg1 = input channels of the two segments of the virtual concat it reads */
-size_t vxm_conv3d_k3_s3_packed_bytes(int seg0, int seg1, int OutC);
+size_t vxm_conv3d_k3_s3_packed_bytes(int seg0, int seg1, int OutC, int pieces);
 typedef struct VxmS3PackJob {
     const float* w;                                         /* [Cw_out][Cw_in][3][3][3], reference layout */
     void* wpacked;                                          /* vxm_conv3d_k3_s3_packed_bytes(seg0, InC - seg0, OutC) bytes, 16-byte aligned */
@@ -317,11 +324,13 @@ typedef struct VxmS3PackJob {
                                                              * [ci_lo, ci_lo + ci_n) (InC = ci_n, OutC = Cw_out), or its adjoint onto them
                                                              * (transpose_flip: InC = Cw_out, OutC = ci_n) */
     int seg0;                                               /* operator input channels that belong to segment 0 (InC for one tensor) */
+    int pieces;                                             /* 3: bf16 (h, m, l); 2: fp16 (h, l) with the operator's power-of-two scale */
 } VxmS3PackJob;
 int vxm_conv3d_k3_s3_pack_weights_batch(const VxmS3PackJob* jobs, int n_jobs, void* stream);
 int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
                          const void* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope,
-                         const float* mask_src, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, void* stream);
+                         const float* mask_src, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, int pieces,
+                         void* stream);
 /* convolution_backward w.r.t. weight and bias (autograd twin of networks.py:299) of ONE full-resolution tensor x [B,C,D,H,W] on the
  * same split arithmetic (contraction over voxels, K = 32 voxels of a W row per MFMA): gw[co][ci_off + ci][tap] for ci < C inside a
  * [Cout][gw_cin][3][3][3] array (the channel sub-range a segment of a virtual concat owns), gb[Cout] (nullable).  C, Cout multiples
@@ -331,7 +340,7 @@ int vxm_conv3d_k3_s3_bwd_weight_ok(int C, int Cout, int B, int D, int H, int W);
 size_t vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(int C, int Cout, int B, int D, int H, int W);
 int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw,
                                 int gw_cin, int ci_off, float* gb, void* work, size_t work_bytes, int B, int D, int H, int W,
-                                void* stream);
+                                int pieces, void* stream);
 
 #ifdef __cplusplus
 }

@@ -366,10 +366,15 @@ def test_bench_reports_the_roofline_that_binds_the_kernel():
     assert w["bound"] == "hbm" and abs(w["frac"] - 2800.0 / 8000.0) < 1e-9
     for r in (t8, a, b, w):
         assert r["traffic"] is None and r["avg_launch_ms"] > 0
-    # split-fp32 kernels run on the bf16 pipe with six MFMAs per fp32 MAC block: priced against 2500 / 6, not against the fp32-MFMA peak
-    sp = bench.binding_roofline("k_s3_conv<1,4,1>", dict(launches=5, ms=2.94, flops=594.5e9, nominal=594.5e9, bytes=0.0))
+    # split-fp32 kernels run on the 16-bit matrix pipe with six (three bf16 pieces) or three (two fp16 pieces) MFMAs per fp32 MAC block: priced
+    # against 2500 / 6 resp. 2500 / 3, not against the fp32-MFMA peak; the piece scheme is the last template argument of the region label
+    sp = bench.binding_roofline("k_s3_conv<1,4,1,3>", dict(launches=5, ms=2.94, flops=594.5e9, nominal=594.5e9, bytes=0.0))
     assert sp["bound"] == "mfma" and abs(sp["peak"] - 2500.0 / 6.0) < 1e-9 and abs(sp["achieved"] - 202.2) < 0.1 and abs(sp["frac"] - 202.2 / 416.67) < 1e-3
-    assert abs(sp["bf16_pipe_tflops"] - 6 * sp["achieved"]) < 1e-9 and "1.29 x the fp32-MFMA peak" in sp["peak_note"]
+    assert abs(sp["matrix_pipe_tflops"] - 6 * sp["achieved"]) < 1e-9 and "1.29 x the fp32-MFMA peak" in sp["peak_note"]
+    s2 = bench.binding_roofline("k_s3_conv<2,4,1,2>", dict(launches=5, ms=2.94, flops=594.5e9, nominal=594.5e9, bytes=0.0))
+    assert abs(s2["peak"] - 2500.0 / 3.0) < 1e-9 and abs(s2["matrix_pipe_tflops"] - 3 * s2["achieved"]) < 1e-9 and "fp16 x 2" in s2["peak_note"]
+    for label, peak in (("k_s3_bwd_weight<2>", 2500.0 / 3.0), ("k_s3_bwd_weight<3>", 2500.0 / 6.0)):
+        assert abs(bench.binding_roofline(label, dict(launches=5, ms=3.9, flops=547e9, nominal=547e9, bytes=0.0))["peak"] - peak) < 1e-9
 
 
 def test_split_engine_enumerates_its_operators(monkeypatch):
@@ -435,6 +440,8 @@ def test_pack_cache_key_sees_reseated_storage_and_invalidate_accepts_modules():
     with torch.no_grad():
         lin.weight.add_(1.0)                                 # what every optimiser does: bumps the counter
     assert VB._ver(lin.weight)[0] == k1[0] + 1
+    from voxelmorph_amd.torch import functional as VF
+    assert VF.FP32_ENGINE in ("f16x2", "split", "native") and VF.s3_pieces() == (2 if VF.FP32_ENGINE == "f16x2" else 3)
     r = subprocess.run([sys.executable, "-c", "import voxelmorph_amd"], env=dict(os.environ, VXM_FP32_ENGINE="splitt"),
                        capture_output=True, text=True, cwd=ROOT)
     assert r.returncode != 0 and "VXM_FP32_ENGINE" in r.stderr

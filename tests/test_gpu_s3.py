@@ -1,6 +1,7 @@
-"""Parity of the split-fp32 convolution kernels (csrc/conv_s3.hip: every fp32 operand as three bf16 pieces, six piece products on
-the bf16 matrix pipe, fp32 accumulation) -- the forward / backward-data products of ConvBlock (voxelmorph/torch/networks.py:299-305)
--- against fp64 evaluations of the same operator, through the C ABI.  `pytest -m gpu`.
+"""Parity of the split-fp32 convolution kernels (csrc/conv_s3.hip: every fp32 operand as two fp16 pieces / three products with a
+per-tile power-of-two scale -- engine "f16x2", the default -- or as three bf16 pieces / six products -- engine "split" --, fp32
+accumulation) -- the forward / backward-data / backward-weight products of ConvBlock (voxelmorph/torch/networks.py:299-305)
+-- against fp64 evaluations of the same operator, through the C ABI.  Every direct test runs on BOTH piece schemes.  `pytest -m gpu`.
 
 Gate: the conv tolerance of the fp32-MFMA kernels (rel-L2 <= 1e-5 against fp64) AND "fp32-level": the error
 must stay within a small factor of what the exact-fp32 kernel leaves on the same operands (measured ~1e-7 for both).
@@ -18,14 +19,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def VF():
+@pytest.fixture(scope="module", params=["f16x2", "split"])
+def VF(request):
+    """the functional module with its split engine switched to one piece scheme for the duration of the module's tests"""
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need a HIP device")
     from voxelmorph_amd import _lib
     _lib.lib()
     from voxelmorph_amd.torch import functional
-    return functional
+    keep = functional.FP32_ENGINE
+    functional.FP32_ENGINE = request.param
+    yield functional
+    functional.FP32_ENGINE = keep
 
 
 def rel_l2(a, b):
@@ -88,8 +93,8 @@ def test_s3_forward_vs_fp64(VF, c0, up0, c1, cout, vol, slope):
     # the exact-fp32 evaluation of the same operator on the same device (torch's conv3d, fp32) as the yardstick for "fp32-level"
     y32 = _ref_conv(x0.cpu(), up0, x1.cpu() if c1 else None, w.cpu(), bias.cpu(), slope).float()
     e32 = rel_l2(y32.numpy(), ref.numpy())
-    print("s3 forward (%d%s+%d -> %d, %s): rel-L2 vs fp64 %.2e (fp32 rounding of the exact result alone: %.2e)"
-          % (c0, "^" if up0 else "", c1, cout, "x".join(map(str, vol)), e, e32))
+    print("s3 forward [%s] (%d%s+%d -> %d, %s): rel-L2 vs fp64 %.2e (fp32 rounding of the exact result alone: %.2e)"
+          % (VF.FP32_ENGINE, c0, "^" if up0 else "", c1, cout, "x".join(map(str, vol)), e, e32))
     assert e <= 1e-5, e
     assert e <= 1e-6, e                      # measured ~1e-7: a dropped piece product (2^-16 relative) would be ~1e-5
 
@@ -134,6 +139,36 @@ def test_s3_scale_invariance_and_small_magnitudes(VF):
     assert e <= 1e-6, e
     z = _s3_forward(VF, torch.zeros_like(x), False, None, w, None, 1.0, cout, vol, B)
     assert bool((z == 0).all())
+    # fp32's own range: magnitudes near the ends of it (the per-tile scale of f16x2 / the pieces of bf16x3 must not over- or underflow)
+    for k in (-100, 100):
+        yk = _s3_forward(VF, x * 2.0 ** k, False, None, w, None, 1.0, cout, vol, B)
+        assert torch.equal(yk, y * 2.0 ** k), k
+
+
+def test_s3_dynamic_range_inside_one_tile(VF):
+    """What the two piece schemes do with an outlier INSIDE a staged tile (documented in include/vxm_hip.h): one activation 2^24 times the
+    rest.  Outputs that see the outlier are dominated by it (fp32-level relative error in both schemes).  Outputs of the same tile that do
+    NOT see it: bf16x3 keeps fp32-level relative error (8-bit exponents per piece); f16x2 keeps an ABSOLUTE error of 2^-40 of the tile's
+    largest magnitude per term -- asserted here as the bound -- which is a relative error of ~1e-5 on those outputs for this 2^24 outlier.
+    The whole tensor stays inside the 1e-6 rel-L2 gate either way."""
+    B, c, cout, vol = 1, 16, 16, (8, 8, 16)
+    torch.manual_seed(21)
+    x = torch.randn(B, c, *vol, device="cuda")
+    x[0, 3, 4, 2, 5] = 2.0 ** 24
+    w = torch.randn(cout, c, 3, 3, 3, device="cuda") / (27 * c) ** 0.5
+    y = _s3_forward(VF, x, False, None, w, None, 1.0, cout, vol, B).cpu().double()
+    ref = _ref_conv(x.cpu(), False, None, w.cpu(), None, 1.0)
+    assert rel_l2(y.numpy(), ref.numpy()) <= 1e-6
+    far = torch.ones(vol, dtype=torch.bool)
+    far[3:6, 1:4, 4:7] = False                                   # voxels whose 3 x 3 x 3 window does not contain the outlier
+    err = (y - ref)[0][:, far].abs().max().item()
+    scale = ref[0][:, far].abs().mean().item()
+    l1 = w.abs().sum(dim=(1, 2, 3, 4)).max().item()
+    print("dynamic range [%s]: max abs error away from a 2^24 outlier %.3e (typical output %.3e)" % (VF.FP32_ENGINE, err, scale))
+    if VF.FP32_ENGINE == "split":
+        assert err <= 1e-5 * scale
+    else:
+        assert err <= 2.0 ** -38 * 2.0 ** 24 * l1              # 2^-40 of the tile maximum per term (x2 for the two roundings), summed against |w|
 
 
 def test_s3_forward_many_tiles(VF):
@@ -168,7 +203,7 @@ def test_s3_backward_weight_vs_fp64(VF, c, cout, vol, B):
     br = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
     torch.nn.functional.conv3d(x.cpu().double(), wr, br, padding=1).backward(dz.cpu().double())
     e_w, e_b = rel_l2(gw[:, pad:].cpu().numpy(), wr.grad.numpy()), rel_l2(gb.cpu().numpy(), br.grad.numpy())
-    print("s3 backward-weight (%d -> %d, %s, B=%d): rel-L2 vs fp64 gw %.2e gb %.2e" % (c, cout, "x".join(map(str, vol)), B, e_w, e_b))
+    print("s3 backward-weight [%s] (%d -> %d, %s, B=%d): rel-L2 vs fp64 gw %.2e gb %.2e" % (VF.FP32_ENGINE, c, cout, "x".join(map(str, vol)), B, e_w, e_b))
     assert e_w <= 3e-6 and e_b <= 3e-6, (e_w, e_b)          # fp32 accumulation over B V voxels (measured ~3e-7)
     gw2 = torch.full_like(gw, 7.25)
     gb2 = torch.empty_like(gb)
@@ -198,7 +233,7 @@ def _rerun(env_extra, select, files=("tests/test_gpu_s3.py",), timeout=900):
 def test_s3_other_kernel_instances_in_subprocess():
     """The packed layout depends on the kernel instance, which is chosen once per process: 16-channel chunks (VXM_S3_CB=2) and
     32-channel operators as two 16-channel groups (VXM_S3_NCT=1) re-run the direct tests above."""
-    if os.environ.get("VXM_S3_CB") or os.environ.get("VXM_S3_NCT"):
+    if os.environ.get("VXM_S3_CB") or os.environ.get("VXM_S3_NCT") or os.environ.get("VXM_S3_PERSIST"):
         pytest.skip("already inside a variant run")
     _rerun({"VXM_S3_CB": "2"}, "forward_vs_fp64 or fused_mask or scale_invariance")
     _rerun({"VXM_S3_NCT": "1"}, "forward_vs_fp64 or fused_mask")
@@ -213,19 +248,22 @@ def test_s3_through_the_dispatcher_on_small_volumes_in_subprocess():
     topologies, and the VxmDense goldens generated by the unmodified reference."""
     if os.environ.get("VXM_S3_MIN_TILES"):
         pytest.skip("already inside the forced run")
-    _rerun({"VXM_S3_MIN_TILES": "1", "VXM_FP32_ENGINE": "split"},
-           "conv_block_vs_oracle or conv_block_output_guard or unet_vs_oracle or vxm_dense_golden or collapsed_weights", files=("tests/test_gpu_parity.py",))
-    _rerun({"VXM_S3_MIN_TILES": "1", "VXM_FP32_ENGINE": "split", "VXM_S3_UP": "1"},
-           "unet_vs_oracle or collapsed_weights", files=("tests/test_gpu_parity.py",))
+    for engine in ("f16x2", "split"):
+        _rerun({"VXM_S3_MIN_TILES": "1", "VXM_FP32_ENGINE": engine},
+               "conv_block_vs_oracle or conv_block_output_guard or unet_vs_oracle or vxm_dense_golden or collapsed_weights", files=("tests/test_gpu_parity.py",))
+        _rerun({"VXM_S3_MIN_TILES": "1", "VXM_FP32_ENGINE": engine, "VXM_S3_UP": "1"},
+               "unet_vs_oracle or collapsed_weights", files=("tests/test_gpu_parity.py",))
 
 
-def test_native_fp32_engine_at_full_size_in_subprocess():
-    """VXM_FP32_ENGINE=native: the exact-fp32 MFMA kernels (conv_fwd.hip) keep their full-size coverage -- the adjoint identity of
-    every full-resolution conv product and the whole headline step against the reference restatement on the host."""
-    if os.environ.get("VXM_FP32_ENGINE") == "native":
-        pytest.skip("already inside the native run")
-    _rerun({"VXM_FP32_ENGINE": "native"}, "(full_size_conv_adjoint_identity and not four_pairs) or full_size_train_step_vs_oracle_noise_pair",
-           files=("tests/test_gpu_parity.py",), timeout=1500)
+def test_other_fp32_engines_at_full_size_in_subprocess():
+    """The engines that are not the default keep their full-size coverage -- the adjoint identity of every full-resolution conv product
+    and the whole headline step against the reference restatement on the host: VXM_FP32_ENGINE=native (the exact-fp32 MFMA kernels of
+    conv_fwd.hip) and VXM_FP32_ENGINE=split (three bf16 pieces, the default of round 3)."""
+    if os.environ.get("VXM_FP32_ENGINE") in ("native", "split", "bf16x3"):
+        pytest.skip("already inside a non-default engine run")
+    for engine in ("native", "split"):
+        _rerun({"VXM_FP32_ENGINE": engine}, "(full_size_conv_adjoint_identity and not four_pairs) or full_size_train_step_vs_oracle_noise_pair",
+               files=("tests/test_gpu_parity.py",), timeout=1500)
 
 
 def test_packed_operator_cache_follows_reseated_and_invalidated_weights(VF):

@@ -75,15 +75,17 @@ def main():
         slope = 1.0 if flip else 0.2
         wp_s3 = VF.s3_pack(w, flip, 0, cout if flip else cin, cin if flip else c0)
 
+        keep = VF.FP32_ENGINE
+
         def run_s3():
+            VF.FP32_ENGINE = keep                  # the piece scheme follows the engine at call time: the one wp_s3 was packed for
             VF.s3_launch(x0, c0, x0[0].numel(), up0, x1, c1, c1 * V, wp_s3, bias, y_s3, cout * V, cout, slope, mask, cout * V, 0.2, B, D, H, W)
 
         if up0 and not flip:
-            keep = VF.FP32_ENGINE
-            VF.FP32_ENGINE = "native"
-
             def run_nat():
+                VF.FP32_ENGINE = "native"
                 VF.conv_forward(x0, c0, x0[0].numel(), True, x1, c1, c1 * V, w, bias, y_nat, cout * V, cout, slope, B, D, H, W)
+                VF.FP32_ENGINE = keep
         else:
             wp_nat = VF.pack_weights(w, flip, 0, cout if flip else cin)
 
@@ -92,8 +94,7 @@ def main():
         ok = bool(_lib.lib().vxm_conv3d_k3_s3_ok(c0, c1, cout, B, D, H, W))
         t_s3 = timed(run_s3, args.iters)
         t_nat = timed(run_nat, args.iters)
-        if up0 and not flip:
-            VF.FP32_ENGINE = keep
+        VF.FP32_ENGINE = keep
         gf = 2.0 * 27 * cin * cout * B * V / 1e9
         diff = float((y_s3.double() - y_nat.double()).norm() / y_nat.double().norm())
         row = dict(op=name, gflop=gf, s3_ms=t_s3, s3_tflops=gf / t_s3, native_ms=t_nat, native_tflops=gf / t_nat, rel_l2_s3_vs_native=diff, s3_eligible=ok)

@@ -26,7 +26,7 @@ class Bf16PackJob(_c.Structure):
 class S3PackJob(_c.Structure):
     """`VxmS3PackJob` of include/vxm_hip.h"""
     _fields_ = [("w", _c.c_void_p), ("wpacked", _c.c_void_p), ("Cw_in", _c.c_int), ("Cw_out", _c.c_int), ("ci_lo", _c.c_int),
-                ("ci_n", _c.c_int), ("transpose_flip", _c.c_int), ("seg0", _c.c_int)]
+                ("ci_n", _c.c_int), ("transpose_flip", _c.c_int), ("seg0", _c.c_int), ("pieces", _c.c_int)]
 
 
 # name -> argtypes (return type is int unless listed in _RESTYPES); mirrors include/vxm_hip.h
@@ -102,12 +102,12 @@ SIGNATURES = {
     "vxm_bf16_lrelu_bwd": [_P, _P, _P, _F, _L, _P],
     "vxm_conv3d_k3_s3_ok": [_I, _I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3_variant": [_I],
-    "vxm_conv3d_k3_s3_packed_bytes": [_I, _I, _I],
+    "vxm_conv3d_k3_s3_packed_bytes": [_I, _I, _I, _I],
     "vxm_conv3d_k3_s3_pack_weights_batch": [_P, _I, _P],
-    "vxm_conv3d_k3_s3_fwd": [_P, _I, _L, _I, _P, _I, _L, _P, _P, _P, _L, _I, _F, _P, _L, _F, _I, _I, _I, _I, _P],
+    "vxm_conv3d_k3_s3_fwd": [_P, _I, _L, _I, _P, _I, _L, _P, _P, _P, _L, _I, _F, _P, _L, _F, _I, _I, _I, _I, _I, _P],
     "vxm_conv3d_k3_s3_bwd_weight_ok": [_I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3_bwd_weight_workspace_bytes": [_I, _I, _I, _I, _I, _I],
-    "vxm_conv3d_k3_s3_bwd_weight": [_P, _I, _L, _P, _L, _I, _P, _I, _I, _P, _P, _S, _I, _I, _I, _I, _P],
+    "vxm_conv3d_k3_s3_bwd_weight": [_P, _I, _L, _P, _L, _I, _P, _I, _I, _P, _P, _S, _I, _I, _I, _I, _I, _P],
     "vxm_ncc_win_elems": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vxm_ncc_win_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vxm_ncc_win_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],

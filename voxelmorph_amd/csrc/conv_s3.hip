@@ -50,6 +50,61 @@ __device__ __forceinline__ void s3_split2(float x0, float x1, unsigned& h, unsig
     l = s3_pack2(q0, q1);
 }
 
+// ---- the second piece scheme (round 4): TWO fp16 pieces, three products ("f16x2").
+// fp16 carries 11 significand bits against bf16's 8: x s = h + l up to 2^-22 |x s| with h = fp16(x s), l = fp16(x s - h), and a product
+// needs only hh + hl + lh (the dropped l l is below 2^-22 |x w|) -- three MFMAs of the same shape and rate instead of six, two LDS
+// planes per operand instead of three.  What fp16 lacks is exponent range (5 bits), so every staged tile is scaled by a power of two s
+// (exact) that brings ITS largest magnitude into [2^14, 2^15): the high piece cannot overflow, and the low piece of a value v keeps
+// full precision down to |v| = 2^-18 max and an absolute error of 2^-40 max below that (fp16 subnormals, which the MFMA and the
+// conversion keep -- tools/probe/f16_mfma_probe.hip, measured on the MI355X).  Because the scale is per staged tile / chunk, an MFMA
+// chain lives for one chunk and is folded into the fp32 running totals by the vector ALU with the inverse scale (exact power of two,
+// round-to-nearest add) -- which also keeps the chains short (the matrix pipe's accumulation truncates, see k_s3_bwd_weight).
+// Weights get one scale per packed operator (k_s3_wmax), undone in the epilogue.
+typedef _Float16 s3_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 s3_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 s3_mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(s3_f16x8, a), __builtin_bit_cast(s3_f16x8, b), c, 0, 0, 0);
+}
+// (x0, x1) * s -> packed fp16 pairs (h, l); s is a power of two (exact), the remainder an exact fp32 difference
+__device__ __forceinline__ void s3_split2_f16(float x0, float x1, float s, unsigned& h, unsigned& l) {
+#pragma clang fp contract(off)
+    const float a0 = x0 * s, a1 = x1 * s;
+    const s3_f16x2 hh = __builtin_convertvector((f32x2){a0, a1}, s3_f16x2);       // v_cvt_pk_f16_f32, round to nearest even
+    const float r0 = a0 - (float)hh[0], r1 = a1 - (float)hh[1];
+    const s3_f16x2 ll = __builtin_convertvector((f32x2){r0, r1}, s3_f16x2);
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, ll);
+}
+// scale of a tile whose largest magnitude is mx (>= 0): s = 2^k with mx s in [2^14, 2^15), and its inverse.  Exponent field E of mx,
+// k = 141 - E.  E is clamped from below at 15 (mx < 2^-112: everything is far below the range anyway); E = 255 (inf / nan) gives 2^-114.
+__device__ __forceinline__ void s3_scale_of(float mx, float& s, float& inv) {
+    int E = (int)(__float_as_uint(mx) >> 23) & 255;
+    E = E < 15 ? 15 : E;
+    s = __uint_as_float((unsigned)(268 - E) << 23);
+    inv = __uint_as_float((unsigned)(E - 14) << 23);
+}
+__device__ __forceinline__ float s3_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// piece scheme NP: 3 = bf16 (h, m, l), six products; 2 = fp16 (h, l), three products.  PA / PB: piece of the A / B operand of product t,
+// small terms first.
+template <bool FIRST, class T> __device__ __forceinline__ T& s3_sel(T& a, T& b) { if constexpr (FIRST) return a; else return b; }
+template <int NP> struct S3P;
+template <> struct S3P<3> {
+    static constexpr int NPROD = 6;
+    static constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};       // (m,m) (l,h) (h,l) (m,h) (h,m) (h,h)
+    static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) { return s3_mfma(a, b, c); }
+    static constexpr unsigned ONES = 0x3f803f80u;                                      // bf16 1.0 x 2
+};
+template <> struct S3P<2> {
+    static constexpr int NPROD = 3;
+    static constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};                         // (l,h) (h,l) (h,h)
+    static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) { return s3_mfma_f16(a, b, c); }
+    static constexpr unsigned ONES = 0x3c003c00u;                                      // fp16 1.0 x 2
+};
+
 constexpr int S3_TD = 8, S3_THREADS = 512, S3_HWV = 18;
 
 // Which unit (kd, kw, 8-channel block) lane group kg multiplies in K-step s.  A ds_read_b128 is served in four groups of 16 lanes
@@ -73,31 +128,35 @@ __host__ __device__ constexpr S3Unit s3_unit(int CB, int s, int kg) {
     return kg < 2 ? S3Unit{kg, 2, 0, 1} : S3Unit{2, kg - 2, 0, 1};       // s == 1 (CB = 1 has two sliding steps)
 }
 
-template <int NCT, int ROWS, int CB>
+template <int NCT, int ROWS, int CB, int NP>
 struct S3Cfg {
     static constexpr int HR = ROWS + 2, PLANE_USED = HR * S3_HWV;
     static constexpr int PLANE = (PLANE_USED + 15) / 16 * 16, SLOTS = (S3_TD + 2) * PLANE;    // 16-byte words of one (piece, block); strides = 0 mod 16
     static constexpr int NSLOT = CB * (S3_TD + 2) * PLANE_USED;                               // haloed voxels x blocks to stage
     static constexpr int NS = CB == 2 ? 5 : 2;                                                // sliding K-steps of a chunk
     static constexpr int RT = CB == 2 ? 0 : 1;                                                // row-tap steps (CB = 1: unit (2, 2))
-    static constexpr int XW = 3 * CB * SLOTS;                                                 // [piece][cb][slot]
-    static constexpr int WCH = (NS * 9 + RT * 3) * NCT * 64;                                  // [s][kh][piece][ct][lane], then [piece][ct][lane] of the row-tap step
-    static constexpr int LDS_BYTES = (XW + WCH) * 16;
+    static constexpr int XW = NP * CB * SLOTS;                                                // [piece][cb][slot]
+    static constexpr int WCH = (NS * 3 + RT) * NP * NCT * 64;                                 // [s][kh][piece][ct][lane], then [piece][ct][lane] of the row-tap step
+    static constexpr int LDS_BYTES = (XW + WCH) * 16 + (NP == 2 ? 64 : 0);                    // NP = 2: + the eight wave maxima of the chunk in flight
     static constexpr int NI = (NSLOT + S3_THREADS - 1) / S3_THREADS;                          // staging slots per thread
     static constexpr int WIT = (WCH + S3_THREADS - 1) / S3_THREADS;
-    static constexpr int MIN_WAVES = LDS_BYTES <= 80 * 1024 ? 4 : 2;                          // two blocks per CU when the LDS allows it
+    // two blocks per CU when the LDS allows it and the accumulators fit 128 registers (NP = 2 carries a second, per-chunk accumulator set)
+    static constexpr int MIN_WAVES = (LDS_BYTES <= 80 * 1024 && !(NP == 2 && NCT == 2)) ? 4 : 2;
 };
 
-// wp: [G][Q]{[NS][kh 3][piece 3][NCT][64 lanes], [RT][piece 3][NCT][64 lanes]} 16-byte words (k_s3_pack_weights).  Q0 chunks cover segment 0.
-template <int NCT, int ROWS, int CB>
-__global__ void __launch_bounds__(S3_THREADS, (S3Cfg<NCT, ROWS, CB>::MIN_WAVES))
+// wp: [G][Q]{[NS][kh 3][piece NP][NCT][64 lanes], [RT][piece NP][NCT][64 lanes]} 16-byte words (k_s3_pack_weights), NP = 2: followed by one
+// trailer word {1 / weight scale, weight scale, -, -}.  Q0 chunks cover segment 0.
+template <int NCT, int ROWS, int CB, int NP>
+__global__ void __launch_bounds__(S3_THREADS, (S3Cfg<NCT, ROWS, CB, NP>::MIN_WAVES))
 k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout,
           float act_slope, const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W, int Q0, int Q) {
-    using C = S3Cfg<NCT, ROWS, CB>;
+    using C = S3Cfg<NCT, ROWS, CB, NP>;
+    using P = S3P<NP>;
     VXM_DYN_SMEM(u32x4, smem);
     constexpr int HR = C::HR, PLANE = C::PLANE, PUSED = C::PLANE_USED, SLOTS = C::SLOTS, NSLOT = C::NSLOT, NS = C::NS, NI = C::NI, WCH = C::WCH, WIT = C::WIT;
-    u32x4* const Xs = smem;                 // [3][CB][SLOTS]
-    u32x4* const Ws = smem + C::XW;         // [NS][3][3][NCT][64]
+    u32x4* const Xs = smem;                 // [NP][CB][SLOTS]
+    u32x4* const Ws = smem + C::XW;         // [NS][3][NP][NCT][64]
+    float* const Wm = reinterpret_cast<float*>(smem + C::XW + WCH);      // NP = 2: largest magnitude each wave loaded for the chunk in flight
     const int tid = threadIdx.x, tid_ = tid, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = lane >> 4, n = lane & 15;
@@ -187,6 +246,20 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
 #pragma unroll
         for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(voffs[j]));
     };
+    // NP = 2: the largest magnitude of the chunk in flight.  A wave publishes the maximum over what ITS lanes loaded right after its
+    // MFMA loop (the loads have had the whole phase to land), i.e. before the barrier that ends the phase anyway: no extra barrier.
+    auto publish_max = [&]() __attribute__((always_inline)) {
+        if constexpr (NP == 2) {
+            float m = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, __builtin_fabsf(xr[j][e]));
+            m = s3_wave_max(m);
+            if (lane == 0) Wm[wave] = m;
+        }
+    };
+    float inv_cur = 1.0f;                                    // NP = 2: 1 / scale of the chunk that is in LDS
     auto store_chunk = [&](int q) __attribute__((always_inline)) {
         // (an opaque copy of the thread index: the slot arithmetic below is loop-invariant, and hoisted out of the tile loop it would
         // occupy registers across the MFMA phases -- 24 spilled VGPRs in the 128-register instance)
@@ -198,17 +271,26 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
 #pragma unroll
         for (int it = 0; it < WIT; ++it)
             wv[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid + S3_THREADS * it) * 16, 0, 0));
+        float sc = 1.0f;
+        if constexpr (NP == 2) {
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(Wm), m1 = *reinterpret_cast<const f32x4*>(Wm + 4);
+            const float mx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+            s3_scale_of(mx, sc, inv_cur);
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            unsigned pk[3][4];
+            unsigned pk[NP][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s3_split2(xr[j][2 * e], xr[j][2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (NP == 3) s3_split2(xr[j][2 * e], xr[j][2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+                else s3_split2_f16(xr[j][2 * e], xr[j][2 * e + 1], sc, pk[0][e], pk[1][e]);
+            }
             const int i = tid + S3_THREADS * j;
             if (i < NSLOT) {                                   // (padding slots are written too: zeros from the out-of-range loads)
                 const int cb = i / ((S3_TD + 2) * PUSED), rem = i - cb * (S3_TD + 2) * PUSED;
                 const int hd = rem / PUSED, lw = cb * SLOTS + hd * PLANE + (rem - hd * PUSED);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) Xs[p * CB * SLOTS + lw] = (u32x4){pk[p][0], pk[p][1], pk[p][2], pk[p][3]};
+                for (int p = 0; p < NP; ++p) Xs[p * CB * SLOTS + lw] = (u32x4){pk[p][0], pk[p][1], pk[p][2], pk[p][3]};
             }
         }
 #pragma unroll
@@ -220,6 +302,7 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
 
     set_tile(t_lo);
     load_chunk(0);
+    if constexpr (NP == 2) { publish_max(); __syncthreads(); }
     store_chunk(0);
     for (int tile = t_lo; tile < t_hi; tile += t_step) {
     const int cd0 = d0, ch0 = h0, cw0 = w0, cbt = bt;           // the tile being computed (the staging tile moves on under its last chunk)
@@ -235,65 +318,83 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
         // unconditional (past the block's last tile every lane is out of range and nothing is fetched): a branch around the prefetch makes
         // the compiler wait for it at the join, right after it was issued (s_waitcnt vmcnt(0) in front of the first MFMA, seen in the ISA)
         load_chunk(last ? 0 : q + 1);
-        // ---- NS K-steps x (ROWS + 2) haloed rows: three B pieces per row, up to 3 kh x NCT x 6 piece products per read set.
+        // NP = 3: the MFMA chains run into the tile's accumulators.  NP = 2: a chain lives for this chunk (its operands carry this chunk's
+        // scale) and is folded into the tile's accumulators below.
+        f32x4 accq[NCT][ROWS];                                  // (NP = 3: unused, eliminated)
+        if constexpr (NP == 2) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) accq[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 (&A_)[NCT][ROWS] = s3_sel<NP == 2>(accq, acc);
+        // ---- NS K-steps x (ROWS + 2) haloed rows: NP B pieces per row, up to 3 kh x NCT x NPROD piece products per read set.
         // The B pieces of row hr + 1 are requested before the MFMAs of row hr (register double buffer; sched_barrier pins the order:
         // unpinned, the compiler sinks every ds_read to right before its first use and the wave stalls on LDS latency once per row).
-        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};       // (m,m) (l,h) (h,l) (m,h) (h,m) (h,h): small terms first
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            u32x4 a[3][3][NCT], bf[2][3];
+            u32x4 a[3][NP][NCT], bf[2][NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[0][p] = Xs[p * CB * SLOTS + xoff[s]];
+            for (int p = 0; p < NP; ++p) bf[0][p] = Xs[p * CB * SLOTS + xoff[s]];
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < NP; ++p)
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) a[kh][p][ct] = Ws[(((s * 3 + kh) * 3 + p) * NCT + ct) * 64 + lane];
+                    for (int ct = 0; ct < NCT; ++ct) a[kh][p][ct] = Ws[(((s * 3 + kh) * NP + p) * NCT + ct) * 64 + lane];
 #pragma unroll
             for (int hr = 0; hr < HR; ++hr) {
                 if (hr + 1 < HR) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bf[(hr + 1) & 1][p] = Xs[p * CB * SLOTS + xoff[s] + (hr + 1) * S3_HWV];
+                    for (int p = 0; p < NP; ++p) bf[(hr + 1) & 1][p] = Xs[p * CB * SLOTS + xoff[s] + (hr + 1) * S3_HWV];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // consecutive MFMAs go to different accumulators (rows hr, hr-1, hr-2)
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < P::NPROD; ++t)
 #pragma unroll
                     for (int kh = 0; kh < 3; ++kh) {
                         const int row = hr - kh;
                         if (row >= 0 && row < ROWS) {
 #pragma unroll
-                            for (int ct = 0; ct < NCT; ++ct) acc[ct][row] = s3_mfma(a[kh][PA[t]][ct], bf[hr & 1][PB[t]], acc[ct][row]);
+                            for (int ct = 0; ct < NCT; ++ct) A_[ct][row] = P::mfma(a[kh][P::PA[t]][ct], bf[hr & 1][P::PB[t]], A_[ct][row]);
                         }
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if constexpr (C::RT) {
-            u32x4 a[3][NCT], bf[2][3];
+            u32x4 a[NP][NCT], bf[2][NP];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[0][p] = Xs[p * CB * SLOTS + xoff_rt];
+            for (int p = 0; p < NP; ++p) bf[0][p] = Xs[p * CB * SLOTS + xoff_rt];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) a[p][ct] = Ws[((NS * 9 + p) * NCT + ct) * 64 + lane];
+                for (int ct = 0; ct < NCT; ++ct) a[p][ct] = Ws[((NS * 3 * NP + p) * NCT + ct) * 64 + lane];
 #pragma unroll
             for (int row = 0; row < ROWS; ++row) {
                 if (row + 1 < ROWS) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bf[(row + 1) & 1][p] = Xs[p * CB * SLOTS + xoff_rt + (row + 1) * S3_HWV];
+                    for (int p = 0; p < NP; ++p) bf[(row + 1) & 1][p] = Xs[p * CB * SLOTS + xoff_rt + (row + 1) * S3_HWV];
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < P::NPROD; ++t)
 #pragma unroll
-                    for (int ct = 0; ct < NCT; ++ct) acc[ct][row] = s3_mfma(a[PA[t]][ct], bf[row & 1][PB[t]], acc[ct][row]);
+                    for (int ct = 0; ct < NCT; ++ct) A_[ct][row] = P::mfma(a[P::PA[t]][ct], bf[row & 1][P::PB[t]], A_[ct][row]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         keep_offsets();
+        if constexpr (NP == 2) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[ct][r][j] = __builtin_fmaf(accq[ct][r][j], inv_cur, acc[ct][r][j]);
+            publish_max();                          // of the chunk in flight (q + 1, or chunk 0 of the next tile)
+        }
         __syncthreads();                            // every wave is done reading chunk q
         if (!last) {
             store_chunk(q + 1);
@@ -305,6 +406,13 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
 
     // ---- epilogue: the D layout of the bf16 MFMA is the fp32 one's (lane (kg, n): channels 4 kg + j of voxel column n):
     // bias + LeakyReLU (+ fused leaky_relu_backward mask), planar fp32 store, shared with the fp32-MFMA kernels
+    if constexpr (NP == 2) {
+        const float inv_w = __uint_as_float(__builtin_amdgcn_readfirstlane((int)wp[(size_t)gridDim.y * Q * WCH].x));      // trailer of the packed operator
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) acc[ct][r] *= inv_w;
+    }
     const int d = cd0 + wave, w = cw0 + n;
     float bz[NCT][4];
     conv_load_bias<NCT>(bz, bias, Cout, g, kg);
@@ -313,36 +421,37 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     }
 }
 
-// w: [Cw_out][Cw_in][27] fp32 (reference layout) -> [G][Q]{[NS][kh][piece][NCT][64 lanes], [RT][piece][NCT][64 lanes]} x 8 bf16: lane (kg, m) of
+// w: [Cw_out][Cw_in][27] fp32 (reference layout) -> [G][Q]{[NS][kh][piece][NCT][64 lanes], [RT][piece][NCT][64 lanes]} x 8 bf16 / fp16: lane (kg, m) of
 // sliding step s / row tap kh / piece p holds, for output channel 16 (g NCT + ct) + m, piece p of the weights of unit s3_unit(CB, s, kg);
 // lane (kg, m) of the row-tap step those of tap (kd, kh, kw) = (2, kg, 2) (kg = 3: zeros).
 // Operator: y[o] = sum_i Wop[o][i][tap] x[i] over the virtual input channels i (segment 0: [0, seg0), segment 1: the rest);
 // chunk q < Q0 holds segment-0 channels 8 CB q + 8 cb + e, chunk q >= Q0 segment-1 channels seg0 + 8 CB (q - Q0) + 8 cb + e.
 // forward: Wop[o][i][t] = w[o][ci_lo + i][t]; flip (backward-data onto input channels [ci_lo, ci_lo + OutC)): Wop[o][i][t] = w[i][ci_lo + o][26 - t].
+// NP = 2: the values are multiplied by the operator's scale first (k_s3_wmax wrote {1 / scale, scale} into the trailer word `words`).
 struct S3PackJob {
     const float* w; u32x4* wp;
-    int Cw_in, ci_lo, flip, InC, seg0, OutC, NCT, CB, Q0, Q;
+    int Cw_in, Cw_out, ci_lo, ci_n, flip, InC, seg0, OutC, NCT, CB, Q0, Q, NP;
     unsigned first_block, words;
 };
 __device__ __forceinline__ void s3_pack_word(const S3PackJob& jb, size_t i) {
-    const int NS = jb.CB == 2 ? 5 : 2, RT = jb.CB == 2 ? 0 : 1;
-    const int per_chunk = (NS * 9 + RT * 3) * jb.NCT * 64;
+    const int NS = jb.CB == 2 ? 5 : 2, RT = jb.CB == 2 ? 0 : 1, NP = jb.NP;
+    const int per_chunk = (NS * 3 + RT) * NP * jb.NCT * 64;
     size_t r = i;
     const int wi = (int)(r % per_chunk); r /= per_chunk;       // word inside the chunk
     const int q = r % jb.Q; const int g = (int)(r / jb.Q);
     const int lane = wi % 64;
     int t2 = wi / 64;
-    const int ct = t2 % jb.NCT; t2 /= jb.NCT;                   // t2: (s, kh, piece) of a sliding step, or NS * 9 + piece of the row-tap step
+    const int ct = t2 % jb.NCT; t2 /= jb.NCT;                   // t2: (s, kh, piece) of a sliding step, or NS * 3 * NP + piece of the row-tap step
     const int kg = lane >> 4, m = lane & 15;
     int p, tap, cb;
     bool valid;
-    if (t2 < NS * 9) {
-        p = t2 % 3;
-        const int kh = (t2 / 3) % 3, st = t2 / 9;
+    if (t2 < NS * 3 * NP) {
+        p = t2 % NP;
+        const int kh = (t2 / NP) % 3, st = t2 / (3 * NP);
         const S3Unit un = s3_unit(jb.CB, st, kg);
         valid = un.valid != 0; cb = un.cb; tap = un.kd * 9 + kh * 3 + un.kw;
     } else {
-        p = t2 - NS * 9;
+        p = t2 - NS * 3 * NP;
         valid = kg < 3; cb = 0; tap = 2 * 9 + kg * 3 + 2;       // (kd, kh, kw) = (2, kg, 2)
     }
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -358,8 +467,14 @@ __device__ __forceinline__ void s3_pack_word(const S3PackJob& jb, size_t i) {
         }
     }
     unsigned pk[3][4];
+    if (NP == 3) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) s3_split2(v[2 * e], v[2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+        for (int e = 0; e < 4; ++e) s3_split2(v[2 * e], v[2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+    } else {
+        const float sc = __uint_as_float(jb.wp[jb.words].y);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s3_split2_f16(v[2 * e], v[2 * e + 1], sc, pk[0][e], pk[1][e]); pk[2][e] = 0u; }
+    }
     jb.wp[i] = (u32x4){pk[p][0], pk[p][1], pk[p][2], pk[p][3]};
 }
 
@@ -375,6 +490,27 @@ __global__ void __launch_bounds__(256) k_s3_pack_weights(const S3PackBatch batch
     const S3PackJob& jb = batch.job[j];
     const size_t i = (size_t)(blockIdx.x - jb.first_block) * 256 + threadIdx.x;
     if (i < jb.words) s3_pack_word(jb, i);
+}
+// NP = 2: the scale of each operator of the batch -- one block per job takes the largest magnitude of the weights the operator reads
+// (w[a][ci_lo + b][*], a < Cw_out, b < ci_n: the same set for the forward operator and its adjoint) and writes {1 / s, s} to the trailer.
+__global__ void __launch_bounds__(256) k_s3_wmax(const S3PackBatch batch) {
+    __shared__ float red[4];
+    const S3PackJob& jb = batch.job[blockIdx.x];
+    if (jb.NP != 2) return;                                                             // block-uniform
+    const int n = jb.Cw_out * jb.ci_n * 27, row = jb.ci_n * 27;
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int a = i / row, r = i - a * row;
+        m = fmaxf(m, __builtin_fabsf(jb.w[((size_t)a * jb.Cw_in + jb.ci_lo) * 27 + r]));
+    }
+    m = s3_wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s, inv;
+        s3_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), s, inv);
+        jb.wp[jb.words] = (u32x4){__float_as_uint(inv), __float_as_uint(s), 0u, 0u};
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -399,7 +535,15 @@ constexpr int SW_TD = 2, SW_TH = 4, SW_TW = 32, SW_XW = SW_TW + 2, SW_HR = SW_TH
 constexpr int SW_PLANE = SW_HR * SW_XW * 32;                  // bytes of one haloed X plane of one piece: [hh][hw][16 ci]
 constexpr int SW_XPIECE = SW_RING * SW_PLANE;
 constexpr int SW_ZPIECE = SW_TD * SW_TH * SW_TW * 32;         // dZ tile of one piece: [ds][row][w][16 co]
-constexpr int SW_LDS_BYTES = 3 * (SW_XPIECE + SW_ZPIECE);
+constexpr int SW_EPI_BYTES = (SW_WAVES * 9 + 4) * 256 * 4;    // the epilogue's combine buffer (reuses the staging space)
+// NP = 3: single dZ buffer (three pieces leave no room for a second).  NP = 2: the dZ tile is double-buffered, and a table of the
+// inverse scales of the six ring planes and the two dZ buffers + the wave maxima of the tile in flight follow the tiles.
+template <int NP> struct SwCfg {
+    static constexpr int ZB = NP == 2 ? 2 : 1;
+    static constexpr int TILE_BYTES = NP * (SW_XPIECE + ZB * SW_ZPIECE);
+    static constexpr int TAB_BYTES = NP == 2 ? 256 : 0;       // floats: [0..5] ring planes, [6..7] dZ buffers, [8..31] wave maxima (two sets of 12)
+    static constexpr int LDS_BYTES = (TILE_BYTES + TAB_BYTES > SW_EPI_BYTES ? TILE_BYTES + TAB_BYTES : SW_EPI_BYTES);
+};
 
 __device__ __forceinline__ u32x2 s3_tr_read(const char* lds_base, int byte_off) {
     typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -411,12 +555,16 @@ __device__ __forceinline__ u32x2 s3_tr_read(const char* lds_base, int byte_off) 
 struct SwTasks { int ncol, nseg, seg_len, nd, nh, nw; };       // tasks = (column (b, th, tw), depth segment), seg_len tiles each
 
 // x: [B][C][D][H][W] fp32 (batch stride x_bs), dz: [B][Cdz][D][H][W] fp32; grid = NBLK x NCOMBO, combo = (16-channel chunk q of x, 16-channel tile of dz)
+template <int NP>
 __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __restrict__ x, long long x_bs, int C, const float* __restrict__ dz,
                                                               long long dz_bs, int Cdz, float* __restrict__ part, int D, int H, int W, int NBLK,
                                                               int NCO, SwTasks tk) {
+    using P = S3P<NP>;
+    using CF = SwCfg<NP>;
     VXM_DYN_SMEM(char, smem);
-    char* const Xs = smem;                                       // [3 pieces][6 ring planes][SW_PLANE]
-    char* const Zs = smem + 3 * SW_XPIECE;                       // [3 pieces][SW_ZPIECE]
+    char* const Xs = smem;                                       // [NP pieces][6 ring planes][SW_PLANE]
+    char* const Zs = smem + NP * SW_XPIECE;                      // [ZB buffers][NP pieces][SW_ZPIECE]
+    float* const Tab = reinterpret_cast<float*>(smem + CF::TILE_BYTES);      // NP = 2: inverse scales + wave maxima
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rh = wave / 6, w6 = wave - 6 * rh, ds = w6 / 3, kd = w6 - 3 * ds;      // rows 2 rh, 2 rh + 1 of depth slice ds, taps kd
@@ -444,10 +592,10 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) tot[kh][kw] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int lp = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;     // lane pattern of the transposing read
-    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};       // bf16 1.0 x 8: B operand of the bias sum
+    const u32x4 ones = {P::ONES, P::ONES, P::ONES, P::ONES};    // 1.0 x 8: B operand of the bias sum
 
     // Staging roles of a thread, fixed for the kernel.  A slot is (PAIR of W-neighbouring voxels, 8-channel half): 8 planar fp32 dwordx2 loads
-    // (one per channel), split into 2 x 3 16-byte words.  Pairs start at even w (W is even, tiles start at multiples of 32), so a pair is inside
+    // (one per channel), split into 2 x NP 16-byte words.  Pairs start at even w (W is even, tiles start at multiples of 32), so a pair is inside
     // the volume or outside it as a whole: the haloed row w0 - 1 .. w0 + 32 is covered by the 18 pairs from w0 - 2, whose first and last voxel
     // are dropped at the LDS write.  A tile stages 2 haloed X planes (2 x 6 rows x 18 pairs x 2 halves = 432 slots) and the dZ tile (2 x 4
     // rows x 16 pairs x 2 = 256 slots) on 768 threads in ONE round: waves 0 .. 6 stage X, waves 7 .. 10 dZ (wave-uniform roles: one
@@ -461,7 +609,7 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
     const int x_pl = s_i >= NXS ? 1 : 0, x_r = s_i - x_pl * NXS;                         // X role: plane of the pair, slot inside the plane
     const int z_ds = wave >= 9 ? 1 : 0;                                                  // dZ role: depth slice of the tile (wave-uniform)
     float ra[8], rb[8];                                          // first / second voxel of the pair, 8 channels
-    unsigned ka[3][4], kb[3][4];
+    unsigned ka[NP][4], kb[NP][4];
     int off0 = VXM_OOB, ldst = 0;                                // per task: byte offset inside a depth slice; LDS byte offset of the first voxel's word inside
                                                                  // a plane / the dZ tile, | 1: drop the first voxel, | 2: drop the second
     int vk;                                                      // the offset the in-flight loads were issued with (kept live until the MFMA phase is over)
@@ -507,49 +655,83 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
                 ra[e] = t2.x; rb[e] = t2.y;
             }
         };
+        // NP = 2: the largest magnitude this wave loaded for the tile in flight -> Tab[8 + 12 set + wave]; after the next barrier every thread
+        // takes the maximum over the X waves (0 .. 6) resp. the dZ waves (7 .. 10) and derives the scale of the plane pair / the dZ tile
+        auto publish_max = [&](int set) __attribute__((always_inline)) {
+            if constexpr (NP == 2) {
+                float m = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[e]), __builtin_fabsf(rb[e])));
+                m = s3_wave_max(m);
+                if (lane == 0) Tab[8 + 12 * set + wave] = m;
+            }
+        };
+        float sc_role = 1.0f;                                    // NP = 2: scale of what this thread staged (X pair of planes, or the dZ tile)
+        auto take_scales = [&](int set, int p0, int zbuf) __attribute__((always_inline)) {
+            if constexpr (NP == 2) {
+                const f32x4* const t4 = reinterpret_cast<const f32x4*>(Tab + 8 + 12 * set);
+                const f32x4 m0 = t4[0], m1 = t4[1], m2 = t4[2];
+                const float mxx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), m1.z));
+                const float mxz = fmaxf(fmaxf(m1.w, m2.x), fmaxf(m2.y, m2.z));
+                float sx, ix, sz, iz;
+                s3_scale_of(mxx, sx, ix);
+                s3_scale_of(mxz, sz, iz);
+                sc_role = s_role == 2 ? sz : sx;
+                if (tid == 0) { Tab[p0 % SW_RING] = ix; Tab[(p0 + 1) % SW_RING] = ix; }
+                if (tid == 64 && zbuf >= 0) Tab[6 + zbuf] = iz;
+            }
+        };
         // split (registers only) and write (LDS) are separate steps: a wave splits the tile it prefetched right after ITS OWN MFMA loop
         auto split_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                s3_split2(ra[2 * e], ra[2 * e + 1], ka[0][e], ka[1][e], ka[2][e]);
-                s3_split2(rb[2 * e], rb[2 * e + 1], kb[0][e], kb[1][e], kb[2][e]);
+                if constexpr (NP == 3) {
+                    s3_split2(ra[2 * e], ra[2 * e + 1], ka[0][e], ka[1][e], ka[2][e]);
+                    s3_split2(rb[2 * e], rb[2 * e + 1], kb[0][e], kb[1][e], kb[2][e]);
+                } else {
+                    s3_split2_f16(ra[2 * e], ra[2 * e + 1], sc_role, ka[0][e], ka[1][e]);
+                    s3_split2_f16(rb[2 * e], rb[2 * e + 1], sc_role, kb[0][e], kb[1][e]);
+                }
             }
         };
         // X planes go to ring slots the current tile does not read, so their writes need no barrier: they are issued right after the wave's own
         // MFMA loop and overlap the MFMAs of the waves still computing (waves 0 .. 6 stage X and are the first to finish: the matrix pipe of
         // a SIMD serves its oldest wave first).  The dZ tile is single-buffered and is written between the two barriers.  Measured with
         // s_memtime stamps: the phase between the barriers 1620 -> 430 cycles of ~11.7 k per tile, 2.50 -> 2.44 M cycles per launch on rem1.
+        // (NP = 2: the split needs the block's scale, so split and both writes sit between the barriers; the dZ tile is double-buffered.)
         auto write_x = [&](int p0) __attribute__((always_inline)) {
             if (s_role == 1) {
                 if (s_i < 2 * NXS) {
                     char* const d = Xs + ((p0 + x_pl) % SW_RING) * SW_PLANE + (ldst & ~3);
                     if (!(ldst & 1)) {
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(d + p * SW_XPIECE) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
+                        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * SW_XPIECE) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
                     }
                     if (!(ldst & 2)) {
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(d + p * SW_XPIECE + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * SW_XPIECE + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
                     }
                 }
             }
         };
-        auto write_z = [&]() __attribute__((always_inline)) {
+        auto write_z = [&](int zbuf) __attribute__((always_inline)) {
             if (s_role == 2) {
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    *reinterpret_cast<u32x4*>(Zs + p * SW_ZPIECE + ldst) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
-                    *reinterpret_cast<u32x4*>(Zs + p * SW_ZPIECE + ldst + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                for (int p = 0; p < NP; ++p) {
+                    *reinterpret_cast<u32x4*>(Zs + (zbuf * NP + p) * SW_ZPIECE + ldst) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
+                    *reinterpret_cast<u32x4*>(Zs + (zbuf * NP + p) * SW_ZPIECE + ldst + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
                 }
             }
         };
 
         __syncthreads();                                        // every wave is done with the previous task
         load_tile(0, 0);
+        if constexpr (NP == 2) { publish_max(0); __syncthreads(); take_scales(0, 0, 0); }
         split_tile();
         write_x(0);
-        write_z();
+        write_z(0);
         load_tile(2, -1);
+        if constexpr (NP == 2) { publish_max(1); __syncthreads(); take_scales(1, 2, -1); }
         split_tile();
         write_x(2);
         __syncthreads();
@@ -557,6 +739,9 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
         for (int t = 0; t < ntile; ++t) {
             const bool more = t + 1 < ntile;                     // wave-uniform
             const char* const xp = Xs + ((2 * t + ds + kd) % SW_RING) * SW_PLANE;
+            const int zcur = NP == 2 ? (t & 1) : 0;              // dZ buffer of this tile
+            float unscale_x = 1.0f, unscale_z = 1.0f;
+            if constexpr (NP == 2) { unscale_x = Tab[(2 * t + ds + kd) % SW_RING]; unscale_z = Tab[6 + zcur]; }
             // the raw loads of tile t + 1 (2 X planes + the dZ tile) are in flight under the MFMAs of tile t; unconditional: past
             // the last tile the planes lie beyond this task's depth range and are simply not stored
             load_tile(2 * t + 4, more ? t + 1 : t);
@@ -564,7 +749,7 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
             // The fp32 accumulation of the bf16 MFMA TRUNCATES (tools/bw_accuracy.py: a chain of ~10^4 MFMAs into one accumulator drifts,
             // 1.5e-5 against 4e-6 for the fp32 MFMA on cancelling sums).  So an MFMA chain lives for ONE tile -- it starts from zero and is
             // at most 12 links long -- and is then added to the running totals by the vector ALU (round to nearest, unbiased).
-            u32x4 az[2][3];                                      // dZ fragment sets (3 pieces) of this wave's two output rows
+            u32x4 az[2][NP];                                     // dZ fragment sets (NP pieces) of this wave's two output rows
             f32x4 acc[3][3], accb = {0.f, 0.f, 0.f, 0.f};
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -577,51 +762,73 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
                 if (hl == 0) __builtin_amdgcn_s_setprio(3); else if (hl == 1) __builtin_amdgcn_s_setprio(2); else if (hl == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                 if (hl < 2) {
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        const int zb = p * SW_ZPIECE + ((ds * SW_TH + hr) * SW_TW) * 32 + lp;
+                    for (int p = 0; p < NP; ++p) {
+                        const int zb = (zcur * NP + p) * SW_ZPIECE + ((ds * SW_TH + hr) * SW_TW) * 32 + lp;
                         const u32x2 lo = s3_tr_read(Zs, zb), hi = s3_tr_read(Zs, zb + 16 * 32);
                         az[hl][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
                     }
-                    if (kd == 0) {                               // wave-uniform: bias gradient = sum of the three pieces against ones
+                    if (kd == 0) {                               // wave-uniform: bias gradient = sum of the pieces against ones
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) accb = s3_mfma(az[hl][p], ones, accb);
+                        for (int p = 0; p < NP; ++p) accb = P::mfma(az[hl][p], ones, accb);
                     }
                 }
-                constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};       // (m,m) (l,h) (h,l) (m,h) (h,m) (h,h)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {                 // one kw-shifted B fragment set at a time (12 instead of 36 registers)
-                    u32x4 bxf[3];
+                    u32x4 bxf[NP];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
+                    for (int p = 0; p < NP; ++p) {
                         const int xb = p * SW_XPIECE + (hr * SW_XW + kw) * 32 + lp;
                         const u32x2 lo = s3_tr_read(xp, xb), hi = s3_tr_read(xp, xb + 16 * 32);
                         bxf[p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
                     }
 #pragma unroll
-                    for (int tp = 0; tp < 6; ++tp)
+                    for (int tp = 0; tp < P::NPROD; ++tp)
 #pragma unroll
                         for (int kh = 0; kh < 3; ++kh) {
                             const int rl = hl - kh;              // local output row
                             if (rl >= 0 && rl < 2)               // the first link of a tile's chain (output row 0, first product) starts from zero
-                                acc[kh][kw] = s3_mfma(az[rl][PA[tp]], bxf[PB[tp]], (rl == 0 && tp == 0) ? zero4 : acc[kh][kw]);
+                                acc[kh][kw] = P::mfma(az[rl][P::PA[tp]], bxf[P::PB[tp]], (rl == 0 && tp == 0) ? zero4 : acc[kh][kw]);
                         }
                 }
             }
+            if constexpr (NP == 3) {
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+                for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) tot[kh][kw] += acc[kh][kw];
-            totb += accb;
+                    for (int kw = 0; kw < 3; ++kw) tot[kh][kw] += acc[kh][kw];
+                totb += accb;
+            } else {                                             // the chain carries the scales of its X plane and its dZ tile: undone here (exact)
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tot[kh][kw][j] = __builtin_fmaf(acc[kh][kw][j] * unscale_x, unscale_z, tot[kh][kw][j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) totb[j] = __builtin_fmaf(accb[j], unscale_z, totb[j]);
+            }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             // the address registers of the loads in flight stay live until here: reused earlier, the compiler guards every reuse
             // with s_waitcnt vmcnt(..), i.e. waits for the prefetch at the start of the MFMA phase (seen in the ISA)
             asm volatile("" ::"v"(vk));
-            split_tile();                                        // before the barrier: overlaps the other waves' MFMAs
-            if (more) write_x(2 * t + 4);
-            __syncthreads();                                     // every wave is done reading tile t (X ring slots of t - 1 and the dZ tile are free)
-            if (more) write_z();
-            __syncthreads();
+            if constexpr (NP == 3) {
+                split_tile();                                    // before the barrier: overlaps the other waves' MFMAs
+                if (more) write_x(2 * t + 4);
+                __syncthreads();                                 // every wave is done reading tile t (X ring slots of t - 1 and the dZ tile are free)
+                if (more) write_z(0);
+                __syncthreads();
+            } else {
+                publish_max(0);
+                __syncthreads();                                 // every wave is done reading tile t; the maxima of tile t + 1 are published
+                if (more) {
+                    take_scales(0, 2 * t + 4, zcur ^ 1);
+                    split_tile();
+                    write_x(2 * t + 4);
+                    write_z(zcur ^ 1);
+                }
+                __syncthreads();
+            }
         }
     }
 
@@ -746,23 +953,25 @@ long long s3_min_tiles() {
     return v;
 }
 int s3_chunks(int C, int CB) { return (C + 8 * CB - 1) / (8 * CB); }
-size_t s3_packed_words(int seg0, int seg1, int OutC) {
+// 16-byte words of the packed operator proper (NP = 2: one trailer word {1 / scale, scale} follows them)
+size_t s3_packed_words(int seg0, int seg1, int OutC, int NP) {
     const S3Variant v = s3_variant(OutC);
     const int Q = s3_chunks(seg0, v.CB) + s3_chunks(seg1, v.CB), G = (OutC + 16 * v.NCT - 1) / (16 * v.NCT);
     const int NS = v.CB == 2 ? 5 : 2, RT = v.CB == 2 ? 0 : 1;
-    return (size_t)G * Q * (NS * 9 + RT * 3) * v.NCT * 64;
+    return (size_t)G * Q * (NS * 3 + RT) * NP * v.NCT * 64;
 }
+bool s3_pieces_ok(int np) { return np == 2 || np == 3; }
 
-template <int NCT, int ROWS, int CB>
+template <int NCT, int ROWS, int CB, int NP>
 void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, long long y_bs, int Cout, float slope, const float* mask,
                long long mask_bs, float mask_slope, int B, int D, int H, int W, hipStream_t s) {
-    using C = S3Cfg<NCT, ROWS, CB>;
+    using C = S3Cfg<NCT, ROWS, CB, NP>;
     static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_conv<NCT, ROWS, CB>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_conv<NCT, ROWS, CB, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (getenv("VXM_S3_DEBUG")) {             // developer switch: what the runtime says about co-residency
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_s3_conv<NCT, ROWS, CB>, S3_THREADS, C::LDS_BYTES);
-            fprintf(stderr, "k_s3_conv<%d,%d,%d>: %d bytes of LDS, %d block(s) per CU\n", NCT, ROWS, CB, C::LDS_BYTES, nb);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_s3_conv<NCT, ROWS, CB, NP>, S3_THREADS, C::LDS_BYTES);
+            fprintf(stderr, "k_s3_conv<%d,%d,%d,%d>: %d bytes of LDS, %d block(s) per CU\n", NCT, ROWS, CB, NP, C::LDS_BYTES, nb);
         }
         return true;
     }();
@@ -785,7 +994,7 @@ void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, lo
         const unsigned cap = 8 * ((want + 7) / 8);
         if (cap < gx) gx = cap;
     }
-    hipLaunchKernelGGL((k_s3_conv<NCT, ROWS, CB>), dim3(gx, G), dim3(S3_THREADS), C::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
+    hipLaunchKernelGGL((k_s3_conv<NCT, ROWS, CB, NP>), dim3(gx, G), dim3(S3_THREADS), C::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
                        Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q);
 }
 
@@ -807,9 +1016,9 @@ int vxm_conv3d_k3_s3_variant(int Cout) {
     return 10 * v.NCT + v.CB;
 }
 
-size_t vxm_conv3d_k3_s3_packed_bytes(int seg0, int seg1, int OutC) {
-    if (seg0 <= 0 || seg1 < 0 || OutC <= 0) return 0;
-    return s3_packed_words(seg0, seg1, OutC) * 16;
+size_t vxm_conv3d_k3_s3_packed_bytes(int seg0, int seg1, int OutC, int pieces) {
+    if (seg0 <= 0 || seg1 < 0 || OutC <= 0 || !s3_pieces_ok(pieces)) return 0;
+    return (s3_packed_words(seg0, seg1, OutC, pieces) + (pieces == 2 ? 1 : 0)) * 16;
 }
 
 int vxm_conv3d_k3_s3_pack_weights_batch(const VxmS3PackJob* jobs, int n_jobs, void* stream) {
@@ -822,21 +1031,25 @@ int vxm_conv3d_k3_s3_pack_weights_batch(const VxmS3PackJob* jobs, int n_jobs, vo
         const int InC = a.transpose_flip ? a.Cw_out : a.ci_n;
         VXM_REQUIRE(a.seg0 > 0 && a.seg0 <= InC && (reinterpret_cast<uintptr_t>(a.wpacked) & 15) == 0, VXM_ERR_BAD_SHAPE,
                     "vxm_conv3d_k3_s3_pack_weights_batch: job %d: segment split %d of %d input channels / alignment", j, a.seg0, InC);
+        VXM_REQUIRE(s3_pieces_ok(a.pieces), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_pack_weights_batch: job %d: pieces = %d (3: bf16, 2: fp16)", j, a.pieces);
     }
     for (int j0 = 0; j0 < n_jobs; j0 += S3_PACK_JOBS) {
         S3PackBatch batch;
         batch.n = n_jobs - j0 < S3_PACK_JOBS ? n_jobs - j0 : S3_PACK_JOBS;
         unsigned blocks = 0;
+        bool any2 = false;
         for (int j = 0; j < batch.n; ++j) {
             const VxmS3PackJob& a = jobs[j0 + j];
             const int InC = a.transpose_flip ? a.Cw_out : a.ci_n, OutC = a.transpose_flip ? a.ci_n : a.Cw_out;
             const S3Variant v = s3_variant(OutC);
             const int Q0 = s3_chunks(a.seg0, v.CB), Q = Q0 + s3_chunks(InC - a.seg0, v.CB);
-            const size_t words = s3_packed_words(a.seg0, InC - a.seg0, OutC);
-            batch.job[j] = {a.w, static_cast<u32x4*>(a.wpacked), a.Cw_in, a.ci_lo, a.transpose_flip ? 1 : 0, InC, a.seg0, OutC, v.NCT, v.CB, Q0, Q,
-                            blocks, (unsigned)words};
+            const size_t words = s3_packed_words(a.seg0, InC - a.seg0, OutC, a.pieces);
+            batch.job[j] = {a.w, static_cast<u32x4*>(a.wpacked), a.Cw_in, a.Cw_out, a.ci_lo, a.ci_n, a.transpose_flip ? 1 : 0, InC, a.seg0, OutC,
+                            v.NCT, v.CB, Q0, Q, a.pieces, blocks, (unsigned)words};
             blocks += (unsigned)((words + 255) / 256);
+            any2 = any2 || a.pieces == 2;
         }
+        if (any2) hipLaunchKernelGGL(k_s3_wmax, dim3(batch.n), dim3(256), 0, VXM_STREAM(stream), batch);      // the operators' scales, read by the pack below
         hipLaunchKernelGGL(k_s3_pack_weights, dim3(blocks), dim3(256), 0, VXM_STREAM(stream), batch);
     }
     return vxm_check_launch("vxm_conv3d_k3_s3_pack_weights_batch");
@@ -844,8 +1057,9 @@ int vxm_conv3d_k3_s3_pack_weights_batch(const VxmS3PackJob* jobs, int n_jobs, vo
 
 int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride, const void* wpacked,
                          const float* bias, float* y, int64_t y_bstride, int Cout, float leaky_slope, const float* mask, int64_t mask_bstride,
-                         float mask_slope, int B, int D, int H, int W, void* stream) {
+                         float mask_slope, int B, int D, int H, int W, int pieces, void* stream) {
     VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3_fwd: null pointer");
+    VXM_REQUIRE(s3_pieces_ok(pieces), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_fwd: pieces = %d (3: bf16, 2: fp16)", pieces);
     if (int e = check_conv("vxm_conv3d_k3_s3_fwd", C0, C1, x0_up, Cout, B, D, H, W)) return e;
     VXM_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_fwd: segments carry multiples of 8 channels, got %d + %d", C0, C1);
     const S3Variant v = s3_variant(Cout);
@@ -856,9 +1070,15 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
     // (32-channel operators with two blocks per CU were measured twice and not kept: on 8 x 2 x 16 tiles -- 81 KB of LDS -- 32 spilled registers
     // at the 128-VGPR limit of four waves per SIMD, 2.56 instead of 2.02 ms per step on these launches; as two passes of the 16-channel
     // instance over one staged chunk -- weights of one pass in LDS at a time -- 41 spilled registers, rem1 backward-data 1.49 instead of 1.39 ms)
-    if (v.NCT == 2) s3_launch<2, 4, 1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
-    else if (v.CB == 2) s3_launch<1, 4, 2>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
-    else s3_launch<1, 4, 1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
+#define S3_GO(NCT, CB)                                                                                                                    \
+    do {                                                                                                                                 \
+        if (pieces == 2) s3_launch<NCT, 4, CB, 2>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s); \
+        else s3_launch<NCT, 4, CB, 3>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);            \
+    } while (0)
+    if (v.NCT == 2) S3_GO(2, 1);
+    else if (v.CB == 2) S3_GO(1, 2);
+    else S3_GO(1, 1);
+#undef S3_GO
     return vxm_check_launch("vxm_conv3d_k3_s3_fwd");
 }
 
@@ -880,8 +1100,9 @@ size_t vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(int C, int Cout, int B, int D
 }
 
 int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw, int gw_cin,
-                                int ci_off, float* gb, void* work, size_t work_bytes, int B, int D, int H, int W, void* stream) {
+                                int ci_off, float* gb, void* work, size_t work_bytes, int B, int D, int H, int W, int pieces, void* stream) {
     VXM_REQUIRE(x && dz && gw && work, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3_bwd_weight: null pointer");
+    VXM_REQUIRE(s3_pieces_ok(pieces), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_bwd_weight: pieces = %d (3: bf16, 2: fp16)", pieces);
     if (int e = check_conv("vxm_conv3d_k3_s3_bwd_weight", C, 0, 0, Cout, B, D, H, W)) return e;
     VXM_REQUIRE(C % 16 == 0 && Cout % 16 == 0 && ci_off >= 0 && ci_off + C <= gw_cin && W % 2 == 0, VXM_ERR_BAD_SHAPE,
                 "vxm_conv3d_k3_s3_bwd_weight: %d input / %d output channels (multiples of 16), destination channels [%d, %d) of %d, W = %d (even)", C,
@@ -893,14 +1114,19 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
     VXM_REQUIRE(work_bytes >= (size_t)NBLK * Q * SW_NSL * 28 * (16 * NCO) * 16 * sizeof(float), VXM_ERR_WORKSPACE,
                 "vxm_conv3d_k3_s3_bwd_weight: workspace too small");
     static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight<3>), hipFuncAttributeMaxDynamicSharedMemorySize, SwCfg<3>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SwCfg<2>::LDS_BYTES);
         return true;
     }();
     (void)attr;
     hipStream_t s = VXM_STREAM(stream);
     float* part = static_cast<float*>(work);
-    hipLaunchKernelGGL(k_s3_bwd_weight, dim3(NBLK * Q * NCO), dim3(SW_THREADS), SW_LDS_BYTES, s, x, (long long)x_bstride, C, dz, (long long)dz_bstride,
-                       Cout, part, D, H, W, NBLK, NCO, tk);
+    if (pieces == 2)
+        hipLaunchKernelGGL(k_s3_bwd_weight<2>, dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
+                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk);
+    else
+        hipLaunchKernelGGL(k_s3_bwd_weight<3>, dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<3>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
+                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk);
     const int n = 16 * NCO * 16 * Q * 28;
     hipLaunchKernelGGL(k_s3_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(1024), 0, s, part, gw, gb, C, Cout, gw_cin, ci_off, Q, NCO, NBLK);
     return vxm_check_launch("vxm_conv3d_k3_s3_bwd_weight");

@@ -20,21 +20,40 @@ OVERLAP_SMALL_LEVELS = os.environ.get("VXM_NO_OVERLAP", "") != "1"     # UnetFn.
 # full-resolution launches fill with each other's blocks (-1.6 % per step, measured); 1 keeps the full-resolution launches serialised, which
 # is what bench.py's per-kernel pass sets so that a launch's duration is its own.
 OVERLAP_MIN_LEVEL = int(os.environ.get("VXM_OVERLAP_MIN_LEVEL", "0"))
-# fp32 engine of the 3-D convolutions: "split" = the plain full-resolution layers run on the bf16 matrix pipe with every fp32 operand
-# split into three bf16 pieces (csrc/conv_s3.hip: fp32-level accuracy, 2.67x the pipe rate); "native" = v_mfma_f32_16x16x4_f32
-# everywhere (csrc/conv_fwd.hip).  VXM_S3_UP=1 also sends cat([upsample(x0), x1]) layers through the split kernel (nominal FLOPs,
-# gather through the upsampling) instead of the collapsed-weight fp32 kernel.
-FP32_ENGINE = os.environ.get("VXM_FP32_ENGINE", "split")
-if FP32_ENGINE not in ("split", "native"):
-    raise ValueError("VXM_FP32_ENGINE must be 'split' or 'native', got %r" % FP32_ENGINE)
+# fp32 engine of the 3-D convolutions.  The split engines run the plain full-resolution layers on the 16-bit matrix pipe with every fp32
+# operand split into pieces while it is staged (csrc/conv_s3.hip; fp32-level accuracy, gated against fp64 in tests/test_gpu_s3.py):
+#   "f16x2"  two fp16 pieces (11 + 11 significand bits), three piece products, per-tile power-of-two scaling (round 4, default)
+#   "split"  three bf16 pieces (8 + 8 + 8 bits), six piece products (round 3; alias "bf16x3")
+#   "native" v_mfma_f32_16x16x4_f32 everywhere (csrc/conv_fwd.hip, rounds 1-2)
+# VXM_S3_UP=1 also sends cat([upsample(x0), x1]) layers through the split kernel (nominal FLOPs, gather through the upsampling)
+# instead of the collapsed-weight fp32 kernel.
+FP32_ENGINE = os.environ.get("VXM_FP32_ENGINE", "f16x2")
+if FP32_ENGINE == "bf16x3":
+    FP32_ENGINE = "split"
+if FP32_ENGINE not in ("f16x2", "split", "native"):
+    raise ValueError("VXM_FP32_ENGINE must be 'f16x2', 'split' (= 'bf16x3') or 'native', got %r" % FP32_ENGINE)
+
+
+def s3_pieces():
+    """piece scheme of the split kernels for the engine selected NOW (bench.py and the tests switch FP32_ENGINE inside a process)"""
+    return 2 if FP32_ENGINE == "f16x2" else 3
+
 S3_UP = os.environ.get("VXM_S3_UP", "") == "1"
 _SIDE_STREAMS = {}
 
 
+def split_engine():
+    return FP32_ENGINE != "native"
+
+
 def fp32_engine_note():
-    if FP32_ENGINE != "split":
+    if FP32_ENGINE == "native":
         return "native: v_mfma_f32_16x16x4_f32 for every conv product"
-    return ("split: forward / backward-data of the plain full-resolution layers as 3 x bf16 pieces per fp32 operand, 6 piece products on "
+    if FP32_ENGINE == "f16x2":
+        return ("f16x2: the three conv products of the plain full-resolution layers as 2 x fp16 pieces per fp32 operand (per-tile power-of-two "
+                "scale), 3 piece products on v_mfma_f32_16x16x32_f16, chains folded into fp32 totals per staged chunk (fp32-level accuracy, "
+                "parity-gated against fp64); every other conv product on v_mfma_f32_16x16x4_f32")
+    return ("split: the three conv products of the plain full-resolution layers as 3 x bf16 pieces per fp32 operand, 6 piece products on "
             "v_mfma_f32_16x16x32_bf16 with fp32 accumulation (fp32-level accuracy, parity-gated); every other conv product on "
             "v_mfma_f32_16x16x4_f32")
 
@@ -342,7 +361,7 @@ def _pack_ver(t):
 
 def s3_route(c0, up0, c1, cout, B, D, H, W):
     """does this conv launch (forward operator over the virtual concat, or an adjoint as a forward) go to the split kernel?"""
-    if FP32_ENGINE != "split":
+    if not split_engine():
         return False
     # cat([upsample(x0), x1]): through the upsampling gather the split kernel executes the nominal FLOPs, the fp32 kernel 8 / 27 of the
     # upsampled segment's -- measured, the split kernel wins when the skip segment is at least as wide as the upsampled one (dec3 at L1:
@@ -359,7 +378,7 @@ def s3_prepack(jobs):
     stale = []
     for w, lo, hi, flip, seg0 in jobs:
         cache = w.__dict__.setdefault("_vxm_s3_packs", {})
-        key = (lo, hi, bool(flip), seg0)
+        key = (lo, hi, bool(flip), seg0, s3_pieces())
         hit = cache.get(key)
         if hit is not None and hit[0] == _pack_ver(w) and hit[1].device == w.device:
             continue
@@ -367,7 +386,7 @@ def s3_prepack(jobs):
             continue
         cout, cin = w.shape[:2]
         inc, outc = (cout, hi - lo) if flip else (hi - lo, cout)
-        nbytes = _lib.lib().vxm_conv3d_k3_s3_packed_bytes(seg0, inc - seg0, outc)
+        nbytes = _lib.lib().vxm_conv3d_k3_s3_packed_bytes(seg0, inc - seg0, outc, s3_pieces())
         wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else \
             torch.empty(nbytes, dtype=torch.uint8, device=w.device)
         stale.append((_c(w), cin, cout, lo, hi - lo, bool(flip), seg0, wp, cache, key, _pack_ver(w)))
@@ -375,7 +394,7 @@ def s3_prepack(jobs):
         return
     table = (_lib.S3PackJob * len(stale))()
     for j, (w, cin, cout, lo, n, flip, seg0, wp, _, _, _) in enumerate(stale):
-        table[j] = _lib.S3PackJob(w.data_ptr(), wp.data_ptr(), cin, cout, lo, n, 1 if flip else 0, seg0)
+        table[j] = _lib.S3PackJob(w.data_ptr(), wp.data_ptr(), cin, cout, lo, n, 1 if flip else 0, seg0, s3_pieces())
     call("vxm_conv3d_k3_s3_pack_weights_batch", ctypes.cast(table, ctypes.c_void_p), len(stale), stream())
     for _, _, _, _, _, _, _, wp, cache, key, ver in stale:
         cache[key] = (ver, wp)
@@ -383,14 +402,14 @@ def s3_prepack(jobs):
 
 def s3_pack(w, flip, lo, hi, seg0):
     s3_prepack([(w, lo, hi, flip, seg0)])
-    return w.__dict__["_vxm_s3_packs"][(lo, hi, bool(flip), seg0)][1]
+    return w.__dict__["_vxm_s3_packs"][(lo, hi, bool(flip), seg0, s3_pieces())][1]
 
 
 def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
     v = _lib.lib().vxm_conv3d_k3_s3_variant(cout)
-    with _prof.region("k_s3_conv<%d,4,%d>" % (v // 10, v % 10), flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+    with _prof.region("k_s3_conv<%d,4,%d,%d>" % (v // 10, v % 10, s3_pieces()), flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_conv3d_k3_s3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
-             cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, stream())
+             cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, s3_pieces(), stream())
 
 
 def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
@@ -474,16 +493,16 @@ def s3_bwd_weight(ws, x, c, bs, dz, cout, gw, gw_cin, ci_off, gb, B, D, H, W):
     """weight / bias gradient of one full-resolution tensor on the split kernel (vxm_conv3d_k3_s3_bwd_weight)"""
     need = _lib.lib().vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(c, cout, B, D, H, W)
     buf = ws.get(need)
-    with _prof.region("k_s3_bwd_weight", flops=2.0 * 27 * c * cout * B * D * H * W):
+    with _prof.region("k_s3_bwd_weight<%d>" % s3_pieces(), flops=2.0 * 27 * c * cout * B * D * H * W):
         call("vxm_conv3d_k3_s3_bwd_weight", ptr(x), c, bs, ptr(dz), cout * D * H * W, cout, ptr(gw), gw_cin, ci_off, ptr(gb), ptr(buf), buf.numel(),
-             B, D, H, W, stream())
+             B, D, H, W, s3_pieces(), stream())
 
 
 def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H, W):
-    if FP32_ENGINE == "split" and not up0 and x1 is None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c0, cout, B, D, H, W):
+    if split_engine() and not up0 and x1 is None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c0, cout, B, D, H, W):
         s3_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, c0, 0, gb, B, D, H, W)
         return
-    if FP32_ENGINE == "split" and up0 and x1 is not None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c1, cout, B, D, H, W) and \
+    if split_engine() and up0 and x1 is not None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c1, cout, B, D, H, W) and \
             _lib.lib().vxm_conv3d_k3_bwd_weight_variant(ptr(x0), c0, bs0, 1, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, D, H, W) // 10 == 2:
         # cat([upsample(x0), x1]): the upsampled segment through the collapsed fp32-MFMA kernel, the full-resolution skip segment (and the
         # bias gradient) on the split kernel, each into its channel range of gw
@@ -701,7 +720,7 @@ class UnetFn(torch.autograd.Function):
         for i, t in T.items():
             if t.shape[1] != plan.ch[i] or t.shape[0] != B or tuple(t.shape[2:]) != shape3:
                 raise ValueError("Unet: input %d has shape %s, expected [%d,%d,%s]" % (i, tuple(t.shape), B, plan.ch[i], shape3))
-        if FP32_ENGINE == "split":
+        if split_engine():
             s3_prepack(_s3_jobs(plan, params, B, shape3, any(ctx.needs_input_grad[1:]), any(ctx.needs_input_grad[1:1 + plan.n_inputs])))
         for op in plan.ops:
             dst = op["dst"]
