@@ -342,6 +342,20 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
                                 int gw_cin, int ci_off, float* gb, void* work, size_t work_bytes, int B, int D, int H, int W,
                                 int pieces, void* stream);
 
+/* ---- cat([Upsample(2,'nearest')(x0), x1]) -> ConvBlock on the split engine, COLLAPSED (csrc/conv_s3u.hip): upsample_nearest3d + cat +
+ * convolution + leaky_relu of voxelmorph/torch/networks.py:133-138,299-305 in one launch.  The upsampled segment is evaluated at
+ * low-resolution cost -- per output parity class a 2x2x2 kernel of pre-summed taps on the low-resolution grid (8 instead of 27
+ * multiply-adds per input channel) --, the skip segment x1 as the plain 27-tap convolution, both with the split arithmetic selected by
+ * `pieces` (see vxm_conv3d_k3_s3_fwd).  x0: [B,C0,D/2,H/2,W/2], x1: [B,C1,D,H,W] (C1 may be 0), y: [B,Cout,D,H,W]; C0, C1 multiples of
+ * 8, D, H, W even.  The operator is packed from the reference-layout weights [Cout][C0+C1][3][3][3] by _pack_weights (per `pieces`).
+ * _ok: 1 when this kernel takes a launch of this shape. */
+int vxm_conv3d_k3_s3u_ok(int C0, int C1, int Cout, int B, int D, int H, int W, int pieces);
+size_t vxm_conv3d_k3_s3u_packed_bytes(int C0, int C1, int Cout, int pieces);
+int vxm_conv3d_k3_s3u_pack_weights(const float* w, void* wpacked, int C0, int C1, int Cout, int pieces, void* stream);
+int vxm_conv3d_k3_s3u_fwd(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const void* wpacked,
+                          const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope, int B, int D, int H, int W, int pieces,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

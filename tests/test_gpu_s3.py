@@ -99,6 +99,64 @@ def test_s3_forward_vs_fp64(VF, c0, up0, c1, cout, vol, slope):
     assert e <= 1e-6, e                      # measured ~1e-7: a dropped piece product (2^-16 relative) would be ~1e-5
 
 
+UP_CASES = [
+    # c0 (upsampled), c1 (skip), cout, full-resolution volume, batch
+    (32, 16, 32, (16, 8, 64), 2),          # rem0's channel split
+    (32, 32, 32, (8, 12, 32), 1),          # dec3's
+    (16, 8, 16, (10, 6, 36), 2),           # partial tiles in every direction, one 16-channel output tile
+    (8, 0, 16, (8, 4, 32), 1),             # no skip segment
+    (40, 24, 24, (4, 8, 34), 1),           # channel counts that do not fill the super-chunk / the output tiles
+    (16, 16, 48, (8, 4, 32), 1),           # two output-channel groups (blockIdx.y)
+]
+
+
+def _s3u_forward(VF, x0, x1, w, bias, slope, cout, vol, B):
+    c0, c1 = x0.shape[1], (x1.shape[1] if x1 is not None else 0)
+    D, H, W = vol
+    V = D * H * W
+    y = torch.full((B + 1, cout + 3) + tuple(vol), 7.25, device="cuda")          # guard channels and a guard sample around the destination
+    VF.s3u_launch(x0, c0, x0[0].numel(), x1, c1, c1 * V, VF.s3u_pack(w, c0, c1), bias, y, (cout + 3) * V, cout, slope, B, D, H, W)
+    assert bool((y[:B, cout:] == 7.25).all()) and bool((y[B] == 7.25).all())
+    return y[:B, :cout]
+
+
+@pytest.mark.parametrize("c0,c1,cout,vol,B", UP_CASES)
+def test_s3u_collapsed_forward_vs_fp64(VF, c0, c1, cout, vol, B):
+    """cat([upsample2(x0), x1]) -> ConvBlock on the split + collapsed kernel (csrc/conv_s3u.hip) against the fp64 evaluation of the
+    reference's op sequence (networks.py:133-138, 299-305), both piece schemes, output guards."""
+    torch.manual_seed(2000 + c0 + 3 * c1 + 7 * cout)
+    lo = tuple(s // 2 for s in vol)
+    x0 = torch.randn(B, c0, *lo, device="cuda")
+    x1 = torch.randn(B, c1, *vol, device="cuda") if c1 else None
+    w = torch.randn(cout, c0 + c1, 3, 3, 3, device="cuda") / (27 * (c0 + c1)) ** 0.5
+    bias = torch.randn(cout, device="cuda")
+    y = _s3u_forward(VF, x0, x1, w, bias, 0.2, cout, vol, B)
+    ref = _ref_conv(x0.cpu(), True, x1.cpu() if c1 else None, w.cpu(), bias.cpu(), 0.2)
+    e = rel_l2(y.cpu().numpy(), ref.numpy())
+    print("s3u forward [%s] (%d^+%d -> %d, %s, B=%d): rel-L2 vs fp64 %.2e" % (VF.FP32_ENGINE, c0, c1, cout, "x".join(map(str, vol)), B, e))
+    assert e <= 1e-6, e
+
+
+def test_s3u_collapsed_forward_many_tiles_and_scales(VF):
+    """several tiles per persistent block (VXM_S3U_PERSIST=-16 in the subprocess test), channel blocks of very different magnitude (the
+    running scale of the fp16 scheme moves between stages) and exact scale invariance under powers of two"""
+    torch.manual_seed(88)
+    vol, B, c0, c1, cout = (24, 20, 72), 2, 32, 16, 32
+    lo = tuple(s // 2 for s in vol)
+    x0 = torch.randn(B, c0, *lo, device="cuda")
+    x1 = torch.randn(B, c1, *vol, device="cuda")
+    x0[:, 8:16] *= 2.0 ** 12
+    x1[:, 8:] *= 2.0 ** -9
+    w = torch.randn(cout, c0 + c1, 3, 3, 3, device="cuda") / (27 * (c0 + c1)) ** 0.5
+    bias = torch.randn(cout, device="cuda")
+    y = _s3u_forward(VF, x0, x1, w, bias, 0.2, cout, vol, B).clone()
+    e = rel_l2(y.cpu().numpy(), _ref_conv(x0.cpu(), True, x1.cpu(), w.cpu(), bias.cpu(), 0.2).numpy())
+    assert e <= 1e-6, e
+    ys = _s3u_forward(VF, x0 * 2.0 ** -30, x1 * 2.0 ** -30, w, None, 1.0, cout, vol, B).clone()
+    y1 = _s3u_forward(VF, x0, x1, w, None, 1.0, cout, vol, B)
+    assert torch.equal(ys, y1 * 2.0 ** -30)
+
+
 def test_s3_backward_data_with_fused_mask_and_output_guard(VF):
     """The adjoint operator (transpose_flip pack) with the previous block's LeakyReLU' fused in the epilogue, written into a
     channel slice of a larger buffer: nothing outside the slice, the next sample or the tail may be touched."""
@@ -233,13 +291,15 @@ def _rerun(env_extra, select, files=("tests/test_gpu_s3.py",), timeout=900):
 def test_s3_other_kernel_instances_in_subprocess():
     """The packed layout depends on the kernel instance, which is chosen once per process: 16-channel chunks (VXM_S3_CB=2) and
     32-channel operators as two 16-channel groups (VXM_S3_NCT=1) re-run the direct tests above."""
-    if os.environ.get("VXM_S3_CB") or os.environ.get("VXM_S3_NCT") or os.environ.get("VXM_S3_PERSIST"):
+    if os.environ.get("VXM_S3_CB") or os.environ.get("VXM_S3_NCT") or os.environ.get("VXM_S3_PERSIST") or os.environ.get("VXM_S3U_PERSIST"):
         pytest.skip("already inside a variant run")
     _rerun({"VXM_S3_CB": "2"}, "forward_vs_fp64 or fused_mask or scale_invariance")
     _rerun({"VXM_S3_NCT": "1"}, "forward_vs_fp64 or fused_mask")
     # 16 blocks in all: every block walks several tiles of its XCD's range (the default grid only does so on volumes with > 2048 tiles)
     _rerun({"VXM_S3_PERSIST": "-16"}, "forward_vs_fp64 or fused_mask or many_tiles")
     _rerun({"VXM_S3_PERSIST": "0"}, "many_tiles")
+    _rerun({"VXM_S3U_PERSIST": "-16"}, "s3u_collapsed")
+    _rerun({"VXM_S3U_PERSIST": "0"}, "s3u_collapsed_forward_many_tiles")
 
 
 def test_s3_through_the_dispatcher_on_small_volumes_in_subprocess():
@@ -249,9 +309,9 @@ def test_s3_through_the_dispatcher_on_small_volumes_in_subprocess():
     if os.environ.get("VXM_S3_MIN_TILES"):
         pytest.skip("already inside the forced run")
     for engine in ("f16x2", "split"):
-        _rerun({"VXM_S3_MIN_TILES": "1", "VXM_FP32_ENGINE": engine},
+        _rerun({"VXM_S3_MIN_TILES": "1", "VXM_S3U_MIN_TILES": "1", "VXM_FP32_ENGINE": engine},
                "conv_block_vs_oracle or conv_block_output_guard or unet_vs_oracle or vxm_dense_golden or collapsed_weights", files=("tests/test_gpu_parity.py",))
-        _rerun({"VXM_S3_MIN_TILES": "1", "VXM_FP32_ENGINE": engine, "VXM_S3_UP": "1"},
+        _rerun({"VXM_S3_MIN_TILES": "1", "VXM_S3U": "0", "VXM_FP32_ENGINE": engine, "VXM_S3_UP": "1"},
                "unet_vs_oracle or collapsed_weights", files=("tests/test_gpu_parity.py",))
 
 

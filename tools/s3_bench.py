@@ -102,6 +102,35 @@ def main():
         print("%-28s %7.1f GFLOP | split %.3f ms = %6.1f TF-eq | fp32-MFMA %.3f ms = %6.1f TF | x%.2f | rel-L2(split, fp32) %.2e"
               % (name, gf, t_s3, gf / t_s3, t_nat, gf / t_nat, t_nat / t_s3, diff), flush=True)
         del x0, x1, y_s3, y_nat, mask
+    # cat([upsample(x0), x1]) forwards: the split + collapsed kernel (conv_s3u.hip) against the collapsed fp32-MFMA kernel (t8u)
+    for name, c0, c1, cout, lvl in (("rem0 fwd 32^+16->32 s3u", 32, 16, 32, 0), ("dec3 fwd 32^+32->32 s3u (L1)", 32, 32, 32, 1),
+                                    ("dec2 fwd 32^+32->32 s3u (L2)", 32, 32, 32, 2)):
+        if args.only and args.only not in name:
+            continue
+        D, H, W = (s >> lvl for s in shape)
+        V = D * H * W
+        x0 = torch.randn(B, c0, D // 2, H // 2, W // 2, device="cuda")
+        x1 = torch.randn(B, c1, D, H, W, device="cuda")
+        w = torch.randn(cout, c0 + c1, 3, 3, 3, device="cuda") / (27 * (c0 + c1)) ** 0.5
+        bias = torch.randn(cout, device="cuda")
+        y_s3, y_nat = torch.empty(B, cout, D, H, W, device="cuda"), torch.empty(B, cout, D, H, W, device="cuda")
+        wp = VF.s3u_pack(w, c0, c1)
+        keep = VF.FP32_ENGINE
+
+        def run_s3():
+            VF.s3u_launch(x0, c0, x0[0].numel(), x1, c1, c1 * V, wp, bias, y_s3, cout * V, cout, 0.2, B, D, H, W)
+
+        def run_nat():
+            VF.FP32_ENGINE = "native"
+            VF.conv_forward(x0, c0, x0[0].numel(), True, x1, c1, c1 * V, w, bias, y_nat, cout * V, cout, 0.2, B, D, H, W)
+            VF.FP32_ENGINE = keep
+        t_s3, t_nat = timed(run_s3, args.iters), timed(run_nat, args.iters)
+        gf = 2.0 * (8 * c0 + 27 * c1) * cout * B * V / 1e9
+        diff = float((y_s3.double() - y_nat.double()).norm() / y_nat.double().norm())
+        rows.append(dict(op=name, gflop_executed=gf, s3_ms=t_s3, s3_tflops=gf / t_s3, native_ms=t_nat, native_tflops=gf / t_nat, rel_l2_s3_vs_native=diff))
+        print("%-34s %7.1f GFLOP executed | split+collapsed %.3f ms = %6.1f TF-eq | fp32-MFMA collapsed %.3f ms = %6.1f TF | x%.2f | rel-L2 %.2e"
+              % (name, gf, t_s3, gf / t_s3, t_nat, gf / t_nat, t_nat / t_s3, diff), flush=True)
+        del x0, x1, y_s3, y_nat
     # backward-weight of the plain full-resolution tensors: split kernel vs the fp32-MFMA kernels
     for name, c, cout, lvl in (("rem1 bwd-weight 32->16", 32, 16, 0), ("rem2 bwd-weight 16->16", 16, 16, 0), ("rem0-skip bwd-weight 16->32", 16, 32, 0),
                                ("enc1 bwd-weight 16->32 (L1)", 16, 32, 1), ("dec3-skip bwd-weight 32->32 (L1)", 32, 32, 1)):

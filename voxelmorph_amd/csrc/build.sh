@@ -5,13 +5,13 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libvxm_hip.so
-SRCS="api.hip warp.hip planar.hip conv_fwd.hip conv_bwd_weight.hip conv_bf16.hip conv_s3.hip pool.hip losses.hip"
+SRCS="api.hip warp.hip planar.hip conv_fwd.hip conv_bwd_weight.hip conv_bf16.hip conv_s3.hip conv_s3u.hip pool.hip losses.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-comment"
 mkdir -p build
 objs=""
 for s in $SRCS; do
   o=build/${s%.hip}.o
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ vxm_device.h -nt "$o" ] || [ vxm_common.h -nt "$o" ] || [ conv_common.h -nt "$o" ] || [ ../../include/vxm_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ vxm_device.h -nt "$o" ] || [ vxm_common.h -nt "$o" ] || [ conv_common.h -nt "$o" ] || [ s3_pieces.h -nt "$o" ] || [ ../../include/vxm_hip.h -nt "$o" ]; then
     hipcc $FLAGS -c "$s" -o "$o" &
   fi
   objs="$objs $o"

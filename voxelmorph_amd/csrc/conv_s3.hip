@@ -25,85 +25,9 @@
 // Block = 8 waves, output tile 8(D) x ROWS(H) x 16(W), wave = depth slice; chunk = CB 8-channel blocks of one segment of the
 // virtual concat [x0 (optionally through a nearest x2 upsampling gather) | x1].
 #include "conv_common.h"
+#include "s3_pieces.h"
 
 namespace {
-
-typedef __bf16 s3_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 s3_bf16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f32x4 s3_mfma(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s3_bf16x8, a), __builtin_bit_cast(s3_bf16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ unsigned s3_pack2(float lo, float hi) {            // v_cvt_pk_bf16_f32 (round to nearest even)
-    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){lo, hi}, s3_bf16x2));
-}
-__device__ __forceinline__ float s3_lo(unsigned u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float s3_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
-
-// (x0, x1) -> the three packed bf16 pairs (h, m, l); both remainders are exact fp32 differences
-__device__ __forceinline__ void s3_split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-#pragma clang fp contract(off)
-    h = s3_pack2(x0, x1);
-    const float r0 = x0 - s3_lo(h), r1 = x1 - s3_hi(h);
-    m = s3_pack2(r0, r1);
-    const float q0 = r0 - s3_lo(m), q1 = r1 - s3_hi(m);
-    l = s3_pack2(q0, q1);
-}
-
-// ---- the second piece scheme (round 4): TWO fp16 pieces, three products ("f16x2").
-// fp16 carries 11 significand bits against bf16's 8: x s = h + l up to 2^-22 |x s| with h = fp16(x s), l = fp16(x s - h), and a product
-// needs only hh + hl + lh (the dropped l l is below 2^-22 |x w|) -- three MFMAs of the same shape and rate instead of six, two LDS
-// planes per operand instead of three.  What fp16 lacks is exponent range (5 bits), so every staged tile is scaled by a power of two s
-// (exact) that brings ITS largest magnitude into [2^14, 2^15): the high piece cannot overflow, and the low piece of a value v keeps
-// full precision down to |v| = 2^-18 max and an absolute error of 2^-40 max below that (fp16 subnormals, which the MFMA and the
-// conversion keep -- tools/probe/f16_mfma_probe.hip, measured on the MI355X).  Because the scale is per staged tile / chunk, an MFMA
-// chain lives for one chunk and is folded into the fp32 running totals by the vector ALU with the inverse scale (exact power of two,
-// round-to-nearest add) -- which also keeps the chains short (the matrix pipe's accumulation truncates, see k_s3_bwd_weight).
-// Weights get one scale per packed operator (k_s3_wmax), undone in the epilogue.
-typedef _Float16 s3_f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 s3_f16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 s3_mfma_f16(u32x4 a, u32x4 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(s3_f16x8, a), __builtin_bit_cast(s3_f16x8, b), c, 0, 0, 0);
-}
-// (x0, x1) * s -> packed fp16 pairs (h, l); s is a power of two (exact), the remainder an exact fp32 difference
-__device__ __forceinline__ void s3_split2_f16(float x0, float x1, float s, unsigned& h, unsigned& l) {
-#pragma clang fp contract(off)
-    const float a0 = x0 * s, a1 = x1 * s;
-    const s3_f16x2 hh = __builtin_convertvector((f32x2){a0, a1}, s3_f16x2);       // v_cvt_pk_f16_f32, round to nearest even
-    const float r0 = a0 - (float)hh[0], r1 = a1 - (float)hh[1];
-    const s3_f16x2 ll = __builtin_convertvector((f32x2){r0, r1}, s3_f16x2);
-    h = __builtin_bit_cast(unsigned, hh);
-    l = __builtin_bit_cast(unsigned, ll);
-}
-// scale of a tile whose largest magnitude is mx (>= 0): s = 2^k with mx s in [2^14, 2^15), and its inverse.  Exponent field E of mx,
-// k = 141 - E.  E is clamped from below at 15 (mx < 2^-112: everything is far below the range anyway); E = 255 (inf / nan) gives 2^-114.
-__device__ __forceinline__ void s3_scale_of(float mx, float& s, float& inv) {
-    int E = (int)(__float_as_uint(mx) >> 23) & 255;
-    E = E < 15 ? 15 : E;
-    s = __uint_as_float((unsigned)(268 - E) << 23);
-    inv = __uint_as_float((unsigned)(E - 14) << 23);
-}
-__device__ __forceinline__ float s3_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-// piece scheme NP: 3 = bf16 (h, m, l), six products; 2 = fp16 (h, l), three products.  PA / PB: piece of the A / B operand of product t,
-// small terms first.
-template <bool FIRST, class T> __device__ __forceinline__ T& s3_sel(T& a, T& b) { if constexpr (FIRST) return a; else return b; }
-template <int NP> struct S3P;
-template <> struct S3P<3> {
-    static constexpr int NPROD = 6;
-    static constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};       // (m,m) (l,h) (h,l) (m,h) (h,m) (h,h)
-    static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) { return s3_mfma(a, b, c); }
-    static constexpr unsigned ONES = 0x3f803f80u;                                      // bf16 1.0 x 2
-};
-template <> struct S3P<2> {
-    static constexpr int NPROD = 3;
-    static constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};                         // (l,h) (h,l) (h,h)
-    static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) { return s3_mfma_f16(a, b, c); }
-    static constexpr unsigned ONES = 0x3c003c00u;                                      // fp16 1.0 x 2
-};
 
 constexpr int S3_TD = 8, S3_THREADS = 512, S3_HWV = 18;
 

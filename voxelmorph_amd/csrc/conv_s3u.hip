@@ -1,0 +1,565 @@
+// cat([upsample2(x0), x1]) layers of the VxmDense U-Net on the split engine, COLLAPSED: the upsampled segment at low-resolution cost.
+//
+// Replaces, for the decoder / "remaining" blocks that read cat([Upsample(2, 'nearest')(x0), skip]):
+//   voxelmorph/torch/networks.py:133-138  x = upsample(x); x = cat([x, x_history.pop()])
+//   voxelmorph/torch/networks.py:299-305  ConvBlock = Conv3d(k3,s1,p1) + LeakyReLU(0.2)   (forward)
+// i.e. upsample_nearest3d + cat + convolution + leaky_relu in one launch (round 1-3: k_conv3d_k3_t8u on the fp32 matrix pipe).
+//
+// Algebra ("upsampled segment at low-resolution cost").  Per axis, a 3-tap convolution over a nearest-x2
+// upsampled signal touches only two low-resolution inputs: output o = 2 m + p reads (m-1, m, m) for p = 0 and (m, m, m+1) for p = 1.
+// Pre-summing the taps that share an input gives ONE 2 x 2 x 2 kernel per output parity class (pd, ph, pw):
+//     y[2 m + p] += sum_{j in {0,1}^3} Wc[p][j] xl[m - 1 + p + j],   Wc[p][j] = sum of the w[k] with k in S(p_a, j_a) per axis a,
+//     S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}
+// -- 8 instead of 27 multiply-adds per input channel, x0 read at its own resolution, borders unchanged (low-res -1 / M IS the padding).
+// The skip segment x1 is a plain 27-tap convolution accumulated into the same outputs.
+//
+// Mapping.  An MFMA's 16 columns share one weight fragment, so they must share the parity class: WAVE = CLASS.  A block of 8 waves owns
+// an 8 x 4 x 32 output tile (low-res 4 x 2 x 16); wave (pd, ph, pw) owns its 8 rows (d = 2 ld + pd, h = 2 lh + ph) of 16 voxels
+// w = 2 n + pw.  M = 16 output channels (x NCT tiles), K = 32 = four units of 8 input channels:
+//   * upsampled segment: unit = (jh, jw) of one jd, 8 channels -> K-step = jd: two FULL K-steps per 8 channels (K = 64, no padding).
+//     The class-specific weight fragments (8 classes x 2 x NP x NCT words per 8 channels: 64 KB per 8 channels for 32 outputs) do not
+//     go through LDS: a wave needs only ITS class, and loads it straight from the packed operator (L2-resident) one K-step ahead.
+//   * skip segment: the 27 taps of 8 channels as 7 K-steps (27 of 28 unit slots used), weights of the chunk in LDS (shared by all
+//     classes).  Its full-resolution haloed tile is stored DE-INTERLEAVED by W parity (word = plane, row, parity, w / 2), so that the
+//     stride-2 columns a class reads (w = 2 n + pw + kw - 1) are consecutive 16-byte words: conflict-free ds_read_b128.
+// Lane groups that are served together by a ds_read_b128 (kg 0 with 1, kg 2 with 3) read words that are congruent mod 16 (they differ by
+// whole rows / planes, whose strides are multiples of 16 words) -- the rule found for conv_s3.hip.
+//
+// Staging: the upsampled segment is staged in SUPER-CHUNKS of CBU 8-channel blocks (its haloed low-res tile is small: 6 x 4 x 18 voxels
+// per block), the skip segment in 8-channel chunks (10 x 6 x 34 voxels): both fill the same 4 x 8 staging registers per thread, so a
+// 32 + 16 channel layer is three stages per tile.  Persistent blocks, the next stage in flight in registers under the MFMAs of this one,
+// chunk 0 of the block's next tile under the last stage -- as k_s3_conv.
+//
+// Piece schemes (s3_pieces.h): NP = 2 (fp16 x 2, three products) scales every stage by a power of two from the stage's largest
+// magnitude.  Here the accumulators live for the whole tile (8 rows x NCT x 4 registers leave no room for a second set): the scale is a
+// RUNNING one -- a stage whose maximum exceeds every earlier one first rescales the accumulators down (exact), a later stage with a
+// smaller maximum reuses the running scale (its error floor is then 2^-40 of the tile's running maximum instead of its own).
+#include "conv_common.h"
+#include "s3_pieces.h"
+
+namespace {
+
+constexpr int SU_THREADS = 512, SU_NI = 4;
+constexpr int SU_UP_ROW = 32, SU_UP_PLANE = 4 * SU_UP_ROW, SU_UP_CB = 6 * SU_UP_PLANE;          // low-res haloed tile of one block: [6][4][32 (18 used)] words
+constexpr int SU_UP_SLOTS = 6 * 4 * 18;                                                        // 432
+constexpr int SU_SK_HALF = 20, SU_SK_ROW = 2 * SU_SK_HALF, SU_SK_PLANE = 6 * SU_SK_ROW;         // full-res haloed tile: [10][6][2 parities][20 (17 used)] words
+constexpr int SU_SK_SLOTS = 10 * 6 * 34;                                                       // 2040
+
+// unit (kd, kh, kw) lane group kg multiplies in skip K-step s: pair slot 2 s + (kg >> 1), member kg & 1.  Members of a pair differ by
+// whole planes (kd 0 | 1) or two rows (kh 0 | 2): congruent mod 16 words.  The last two pairs are (2,1,0) | (2,1,2) -- one word apart,
+// 6 instead of 4 LDS cycles -- and (2,1,1) | zero weights.
+struct SuUnit { int kd, kh, kw, valid; };
+__host__ __device__ constexpr SuUnit su_skip_unit(int s, int kg) {
+    const int ps = 2 * s + (kg >> 1), mem = kg & 1;
+    if (ps < 9) return SuUnit{mem, ps / 3, ps % 3, 1};
+    if (ps < 12) return SuUnit{2, mem ? 2 : 0, ps - 9, 1};
+    if (ps == 12) return SuUnit{2, 1, mem ? 2 : 0, 1};
+    return SuUnit{2, 1, 1, mem == 0 ? 1 : 0};
+}
+
+template <int NCT, int NP>
+struct SuCfg {
+    static constexpr int CBU = NP == 2 ? 4 : 2;                                                // 8-channel blocks of an upsampled super-chunk
+    static constexpr int XWORDS = CBU * SU_UP_CB > 10 * SU_SK_PLANE ? CBU * SU_UP_CB : 10 * SU_SK_PLANE;
+    static constexpr int WSK = 7 * NP * NCT * 64;                                              // skip-chunk weights [s][piece][ct][lane]
+    static constexpr int UPW = 8 * 2 * NP * NCT * 64;                                          // upsampled-segment weights of one 8-channel block [class][jd][piece][ct][lane]
+    static constexpr int LDS_BYTES = (NP * XWORDS + WSK) * 16 + 64;
+    static_assert(CBU * SU_UP_SLOTS <= SU_NI * SU_THREADS && SU_SK_SLOTS <= SU_NI * SU_THREADS, "staging slots");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+// wp: [G]{[Q0 blocks][class 8][jd 2][piece NP][NCT][64 lanes], [Q1 chunks][step 7][piece NP][NCT][64 lanes]} 16-byte words, then one trailer
+// word {1 / weight scale, weight scale, scratch, -} (k_s3u_pack).  y[b][o][d][h][w], Cout channels.
+template <int NCT, int NP>
+__global__ void __launch_bounds__(SU_THREADS, 2)
+k_s3u_conv(const float* __restrict__ x0, long long bs0, int C0, const float* __restrict__ x1, long long bs1, int C1, const u32x4* __restrict__ wp,
+           const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout, float act_slope, int B, int D, int H, int W) {
+    using C = SuCfg<NCT, NP>;
+    using P = S3P<NP>;
+    VXM_DYN_SMEM(u32x4, smem);
+    constexpr int XWORDS = C::XWORDS, WSK = C::WSK, UPW = C::UPW, CBU = C::CBU;
+    u32x4* const Xs = smem;                                  // [NP][XWORDS]
+    u32x4* const Ws = smem + NP * XWORDS;                    // skip-chunk weights
+    float* const Wm = reinterpret_cast<float*>(smem + NP * XWORDS + WSK);
+    const int tid = threadIdx.x, tid_ = tid, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = lane >> 4, n = lane & 15;
+    const int pd = wave >> 2, ph = (wave >> 1) & 1, pw = wave & 1;       // this wave's parity class (wave-uniform)
+
+    const int nw = (W + 31) / 32, nh = (H + 3) / 4, nd = (D + 7) / 8;
+    const int ntiles = B * nd * nh * nw;
+    int t_lo, t_hi, t_step;
+    if (ntiles >= 64) {
+        const int x = blockIdx.x & 7;
+        t_lo = (int)((long long)ntiles * x / 8) + (int)(blockIdx.x >> 3); t_hi = (int)((long long)ntiles * (x + 1) / 8); t_step = (int)(gridDim.x >> 3);
+    } else {
+        t_lo = blockIdx.x; t_hi = ntiles; t_step = gridDim.x;
+    }
+    const int g = blockIdx.y;
+    const int V = D * H * W, Dl = D >> 1, Hl = H >> 1, Wl = W >> 1, V0 = Dl * Hl * Wl;
+    const int Q0 = C0 >> 3, Q1 = C1 >> 3, NU = (Q0 + CBU - 1) / CBU, NST = NU + Q1;
+    const u32x4* const wg = wp + (size_t)g * ((size_t)Q0 * UPW + (size_t)Q1 * WSK);
+
+    // ---- staging roles of this thread (tile-independent): slot i = tid + 512 j.
+    //   upsampled super-chunk: i = (cb, hd 6, hh 4, hw 18) of the low-res haloed tile  -> LDS word cb 768 + hd 128 + hh 32 + hw
+    //   skip chunk:            i = (hd 10, hh 6, hw 34) of the full-res haloed tile     -> LDS word hd 240 + hh 40 + (hw & 1) 20 + (hw >> 1)
+    // kept as (position, LDS word) pairs; -1: no slot
+    int up_pos[SU_NI], up_lw[SU_NI], sk_pos[SU_NI], sk_lw[SU_NI];
+#pragma unroll
+    for (int j = 0; j < SU_NI; ++j) {
+        const int i = tid + SU_THREADS * j;
+        {
+            const int cb = i / SU_UP_SLOTS, rem = i - cb * SU_UP_SLOTS;
+            const int hd = rem / 72, r2 = rem - hd * 72, hh = r2 / 18, hw = r2 - hh * 18;
+            const bool ok = i < CBU * SU_UP_SLOTS;
+            up_pos[j] = ok ? (cb << 16 | hd << 10 | hh << 5 | hw) : -1;
+            up_lw[j] = cb * SU_UP_CB + hd * SU_UP_PLANE + hh * SU_UP_ROW + hw;
+        }
+        {
+            const int hd = i / 204, rem = i - hd * 204, hh = rem / 34, hw = rem - hh * 34;
+            const bool ok = i < SU_SK_SLOTS;
+            sk_pos[j] = ok ? (hd << 10 | hh << 6 | hw) : -1;
+            sk_lw[j] = hd * SU_SK_PLANE + hh * SU_SK_ROW + (hw & 1) * SU_SK_HALF + (hw >> 1);
+        }
+    }
+    // ---- per-lane LDS word offsets of the B fragments
+    // upsampled: lane group kg = 2 jw + jh reads low-res voxel (ld + pd + jd, lh + ph + jh, n + pw + jw) of the haloed tile
+    const int up_base = pd * SU_UP_PLANE + (ph + (kg & 1)) * SU_UP_ROW + pw + (kg >> 1) + n;
+    // skip: lane group kg reads full-res haloed voxel (2 ld + pd + kd, 2 lh + ph + kh, 2 n + pw + kw) for the unit (kd, kh, kw) of step s
+    int sk_base[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const SuUnit u0 = su_skip_unit(s, 0), u1 = su_skip_unit(s, 1), u2 = su_skip_unit(s, 2), u3 = su_skip_unit(s, 3);
+        const SuUnit u = kg == 0 ? u0 : kg == 1 ? u1 : kg == 2 ? u2 : u3;
+        const int hw = pw + u.kw;
+        sk_base[s] = (pd + u.kd) * SU_SK_PLANE + (ph + u.kh) * SU_SK_ROW + (hw & 1) * SU_SK_HALF + (hw >> 1) + n;
+    }
+
+    // ---- the staging tile (runs one stage ahead of the tile being computed, across tiles)
+    int d0 = 0, h0 = 0, w0 = 0, bt = 0;
+    bool live = false;
+    __amdgpu_buffer_rsrc_t r0, r1;
+    auto set_tile = [&](int tile) __attribute__((always_inline)) {
+        live = tile < t_hi;
+        const int tl = live ? tile : t_lo;
+        const int tw = tl % nw; int tq = tl / nw;
+        const int th = tq % nh; tq /= nh;
+        const int td = tq % nd;
+        bt = tq / nd;
+        d0 = td * 8; h0 = th * 4; w0 = tw * 32;
+        r0 = vxm_rsrc(x0 + (size_t)bt * bs0, (unsigned)C0 * (unsigned)V0 * 4u);
+        r1 = vxm_rsrc(C1 ? x1 + (size_t)bt * bs1 : x0, (unsigned)C1 * (unsigned)V * 4u);
+    };
+    float xr[SU_NI][8];
+    int voffs[SU_NI];
+    auto load_stage = [&](int st) __attribute__((always_inline)) {
+        const bool up = st < NU;                                 // wave-uniform
+        const __amdgpu_buffer_rsrc_t r = up ? r0 : r1;
+        const int Vs = up ? V0 : V;
+        const int cbg = up ? st * CBU : st - NU;                 // first 8-channel block of the stage inside its segment
+        const int nblk = up ? Q0 : Q1;
+#pragma unroll
+        for (int j = 0; j < SU_NI; ++j) {
+            const int pos = up ? up_pos[j] : sk_pos[j];
+            int cb, gd, gh, gw, De, He, We;
+            if (up) { cb = pos >> 16; gd = (d0 >> 1) - 1 + ((pos >> 10) & 63); gh = (h0 >> 1) - 1 + ((pos >> 5) & 31); gw = (w0 >> 1) - 1 + (pos & 31); De = Dl; He = Hl; We = Wl; }
+            else { cb = 0; gd = d0 - 1 + (pos >> 10); gh = h0 - 1 + ((pos >> 6) & 15); gw = w0 - 1 + (pos & 63); De = D; He = H; We = W; }
+            const bool ok = live && pos >= 0 && st < NST && cbg + cb < nblk && (unsigned)gd < (unsigned)De && (unsigned)gh < (unsigned)He &&
+                            (unsigned)gw < (unsigned)We;
+            voffs[j] = ok ? ((cbg + cb) * 8 * Vs + (gd * He + gh) * We + gw) << 2 : VXM_OOB;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xr[j][e] = vxm_bload(r, voffs[j], (e * Vs) << 2);
+        }
+    };
+    auto keep_offsets = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < SU_NI; ++j) asm volatile("" ::"v"(voffs[j]));
+    };
+    auto publish_max = [&]() __attribute__((always_inline)) {
+        if constexpr (NP == 2) {
+            float m = 0.0f;
+#pragma unroll
+            for (int j = 0; j < SU_NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, __builtin_fabsf(xr[j][e]));
+            m = s3_wave_max(m);
+            if (lane == 0) Wm[wave] = m;
+        }
+    };
+    // NP = 2: the running scale of the tile.  E_run = exponent field the scale is built from; `ratio` = what the accumulators are
+    // multiplied by before the MFMAs of the stage just stored (1 unless that stage raised the running maximum); inv_run = 1 / scale.
+    int E_run = 15;
+    float ratio = 1.0f, inv_run = 1.0f;
+    auto store_stage = [&](int st, bool first) __attribute__((always_inline)) {
+        const bool up = st < NU;                                 // wave-uniform
+        // the skip chunk's packed weights: requested first, written to LDS after the split arithmetic has covered their latency
+        constexpr int WIT = (WSK + SU_THREADS - 1) / SU_THREADS;
+        u32x4 wv[WIT];
+        const __amdgpu_buffer_rsrc_t rw = vxm_rsrc(reinterpret_cast<const float*>(wg + (size_t)Q0 * UPW + (size_t)(up ? 0 : st - NU) * WSK), up ? 0u : WSK * 16u);
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            wv[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid_ + SU_THREADS * it) * 16, 0, 0));
+        float sc = 1.0f;
+        if constexpr (NP == 2) {
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(Wm), m1 = *reinterpret_cast<const f32x4*>(Wm + 4);
+            const float mx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+            int E = (int)(__float_as_uint(mx) >> 23) & 255;
+            E = E < 15 ? 15 : E;
+            const int E_new = first ? E : (E > E_run ? E : E_run);
+            const int dE = E_new - E_run;                                                          // >= 0 unless `first`
+            ratio = (first || dE == 0) ? 1.0f : (dE > 126 ? 0.0f : __uint_as_float((unsigned)(127 - dE) << 23));      // 2^(E_run - E_new) <= 1
+            E_run = E_new;
+            sc = __uint_as_float((unsigned)(268 - E_run) << 23);
+            inv_run = __uint_as_float((unsigned)(E_run - 14) << 23);
+        }
+#pragma unroll
+        for (int j = 0; j < SU_NI; ++j) {
+            unsigned pk[NP][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (NP == 3) s3_split2(xr[j][2 * e], xr[j][2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+                else s3_split2_f16(xr[j][2 * e], xr[j][2 * e + 1], sc, pk[0][e], pk[1][e]);
+            }
+            const int pos = up ? up_pos[j] : sk_pos[j];
+            const int lw = up ? up_lw[j] : sk_lw[j];
+            if (pos >= 0) {                                    // (padding slots are written too: zeros from the out-of-range loads)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) Xs[p * XWORDS + lw] = (u32x4){pk[p][0], pk[p][1], pk[p][2], pk[p][3]};
+            }
+        }
+        if (!up) {
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int i = tid_ + SU_THREADS * it;
+                if (i < WSK) Ws[i] = wv[it];
+            }
+        }
+    };
+
+    set_tile(t_lo);
+    load_stage(0);
+    if constexpr (NP == 2) { publish_max(); __syncthreads(); }
+    store_stage(0, true);
+    for (int tile = t_lo; tile < t_hi; tile += t_step) {
+    const int cd0 = d0, ch0 = h0, cw0 = w0, cbt = bt;           // the tile being computed
+    __syncthreads();                                            // stage 0 of this tile is in LDS
+    f32x4 acc[8][NCT];                                          // row r = 2 ld + lh
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float inv_fin = 1.0f;
+    for (int st = 0; st < NST; ++st) {
+        const bool last = st + 1 == NST;                        // wave-uniform
+        if (last) set_tile(tile + t_step);
+        load_stage(last ? 0 : st + 1);
+        if constexpr (NP == 2) {
+            if (ratio != 1.0f) {                                // wave-uniform (every thread derives it from the same maxima)
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) acc[r][ct] *= ratio;
+            }
+        }
+        if (st < NU) {
+            // ---- upsampled super-chunk: per 8-channel block two K-steps (jd); this class's weight fragments come from global memory,
+            // one K-step ahead (register double buffer)
+            const int cbg = st * CBU, ncb = min(CBU, Q0 - cbg);
+            const u32x4* wa = wg + (size_t)cbg * UPW + (size_t)wave * (2 * NP * NCT * 64) + lane;
+            u32x4 a0[NP][NCT], a1[NP][NCT];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) a0[p][ct] = wa[(p * NCT + ct) * 64];
+            for (int cb = 0; cb < ncb; ++cb) {
+#pragma unroll
+                for (int jd = 0; jd < 2; ++jd) {
+                    u32x4 (&ac)[NP][NCT] = jd ? a1 : a0;
+                    u32x4 (&an)[NP][NCT] = jd ? a0 : a1;
+                    const bool more = jd == 0 || cb + 1 < ncb;   // wave-uniform
+                    const u32x4* wn = jd == 0 ? wa + NP * NCT * 64 : wa + UPW;      // (cb, jd = 1) resp. (cb + 1, jd = 0)
+                    if (more) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+#pragma unroll
+                            for (int ct = 0; ct < NCT; ++ct) an[p][ct] = wn[(p * NCT + ct) * 64];
+                    }
+                    const int xo = up_base + cb * SU_UP_CB + jd * SU_UP_PLANE;
+                    u32x4 bf[2][NP];
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) bf[0][p] = Xs[p * XWORDS + xo];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        if (r + 1 < 8) {
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) bf[(r + 1) & 1][p] = Xs[p * XWORDS + xo + ((r + 1) >> 1) * SU_UP_PLANE + ((r + 1) & 1) * SU_UP_ROW];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int t = 0; t < P::NPROD; ++t)
+#pragma unroll
+                            for (int ct = 0; ct < NCT; ++ct) acc[r][ct] = P::mfma(ac[P::PA[t]][ct], bf[r & 1][P::PB[t]], acc[r][ct]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                wa += UPW;
+            }
+        } else {
+            // ---- skip chunk: 7 K-steps over the 27 taps of 8 channels, weights from LDS
+#pragma unroll
+            for (int s = 0; s < 7; ++s) {
+                u32x4 a[NP][NCT], bf[2][NP];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) bf[0][p] = Xs[p * XWORDS + sk_base[s]];
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) a[p][ct] = Ws[((s * NP + p) * NCT + ct) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r + 1 < 8) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+                            bf[(r + 1) & 1][p] = Xs[p * XWORDS + sk_base[s] + ((r + 1) >> 1) * 2 * SU_SK_PLANE + ((r + 1) & 1) * 2 * SU_SK_ROW];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < P::NPROD; ++t)
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) acc[r][ct] = P::mfma(a[P::PA[t]][ct], bf[r & 1][P::PB[t]], acc[r][ct]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        keep_offsets();
+        if (last) inv_fin = inv_run;                // the scale the finished accumulators carry (store_stage below moves on to the next tile)
+        publish_max();                              // of the stage in flight
+        __syncthreads();                            // every wave is done reading this stage
+        if (!last) {
+            store_stage(st + 1, false);
+            __syncthreads();
+        } else if (tile + t_step < t_hi) {
+            store_stage(0, true);                   // stage 0 of the next tile; the barrier at the top of the tile loop publishes it
+        }
+    }
+
+    // ---- epilogue: lane (kg, n) holds, in acc[r][ct][j], channel 16 (g NCT + ct) + 4 kg + j of voxel (cd0 + 2 ld + pd, ch0 + 2 lh + ph,
+    // cw0 + 2 n + pw).  bias + LeakyReLU, planar fp32 store through the sample's buffer descriptor (out-of-volume lanes and channels
+    // >= Cout get an out-of-range offset).  The two classes that differ in pw write the two halves of every 8-byte pair from the same
+    // block at about the same time (merged in L2).
+    float unscale = 1.0f;
+    if constexpr (NP == 2) {
+        const size_t GW = (size_t)Q0 * UPW + (size_t)Q1 * WSK;
+        const float inv_w = __uint_as_float(__builtin_amdgcn_readfirstlane((int)wp[(size_t)gridDim.y * GW].x));
+        unscale = inv_fin * inv_w;
+    }
+    const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(y + (size_t)cbt * y_bs, (unsigned)Cout * (unsigned)V * 4u);
+    const int cbase = g * NCT * 16 + kg * 4;
+    const int wv_ = cw0 + 2 * n + pw;
+    float bz[NCT][4];
+    conv_load_bias<NCT>(bz, bias, Cout, g, kg);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int dd = cd0 + 2 * (r >> 1) + pd, hh = ch0 + 2 * (r & 1) + ph;       // wave-uniform
+        if (dd < D && hh < H) {
+            const int vox = (dd * H + hh) * W + wv_;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = cbase + 16 * ct + j;
+                    float v = acc[r][ct][j];
+                    if constexpr (NP == 2) v *= unscale;
+                    v += bz[ct][j];
+                    v = v > 0.0f ? v : v * act_slope;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (wv_ < W && ch < Cout) ? (ch * V + vox) << 2 : VXM_OOB, 0, 0);
+                }
+        }
+    }
+    }
+}
+
+// ---- packed operator.  w: [Cout][C0 + C1][27] fp32 (reference layout).
+struct SuPack {
+    const float* w; u32x4* wp;
+    int C0, C1, Cout, NCT, NP, Q0, Q1, G;
+    unsigned words;                          // 16-byte words of the operator proper; the trailer follows
+};
+// the 8 values (8 consecutive input channels) of packed word i
+__device__ __forceinline__ void su_word_values(const SuPack& jb, size_t i, float (&v)[8], int& piece) {
+    const int NP = jb.NP, NCT = jb.NCT;
+    const int UPW = 8 * 2 * NP * NCT * 64, WSK = 7 * NP * NCT * 64, Cin = jb.C0 + jb.C1;
+    const size_t GW = (size_t)jb.Q0 * UPW + (size_t)jb.Q1 * WSK;
+    const int g = (int)(i / GW);
+    size_t r = i - (size_t)g * GW;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+    if (r < (size_t)jb.Q0 * UPW) {
+        const int cb = (int)(r / UPW); int r2 = (int)(r - (size_t)cb * UPW);
+        const int cls = r2 / (2 * NP * NCT * 64); r2 -= cls * (2 * NP * NCT * 64);
+        const int jd = r2 / (NP * NCT * 64); r2 -= jd * (NP * NCT * 64);
+        piece = r2 / (NCT * 64); r2 -= piece * (NCT * 64);
+        const int ct = r2 / 64, lane = r2 & 63, kg = lane >> 4, m = lane & 15;
+        const int jh = kg & 1, jw = kg >> 1, pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
+        const int o = (g * NCT + ct) * 16 + m;
+        if (o >= jb.Cout) return;
+        // taps of axis parity p that read low-res input j: S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}
+        const int dlo = pd ? (jd ? 2 : 0) : (jd ? 1 : 0), dhi = pd ? (jd ? 2 : 1) : (jd ? 2 : 0);
+        const int hlo = ph ? (jh ? 2 : 0) : (jh ? 1 : 0), hhi = ph ? (jh ? 2 : 1) : (jh ? 2 : 0);
+        const int wlo = pw ? (jw ? 2 : 0) : (jw ? 1 : 0), whi = pw ? (jw ? 2 : 1) : (jw ? 2 : 0);
+        for (int e = 0; e < 8; ++e) {
+            const int ci = cb * 8 + e;
+            if (ci >= jb.C0) continue;
+            const float* wr = jb.w + ((size_t)o * Cin + ci) * 27;
+            float s = 0.0f;
+            for (int kd = dlo; kd <= dhi; ++kd)
+                for (int kh = hlo; kh <= hhi; ++kh)
+                    for (int kw = wlo; kw <= whi; ++kw) s += wr[kd * 9 + kh * 3 + kw];
+            v[e] = s;
+        }
+    } else {
+        r -= (size_t)jb.Q0 * UPW;
+        const int q = (int)(r / WSK); int r2 = (int)(r - (size_t)q * WSK);
+        const int s = r2 / (NP * NCT * 64); r2 -= s * (NP * NCT * 64);
+        piece = r2 / (NCT * 64); r2 -= piece * (NCT * 64);
+        const int ct = r2 / 64, lane = r2 & 63, kg = lane >> 4, m = lane & 15;
+        const SuUnit u = su_skip_unit(s, kg);
+        const int o = (g * NCT + ct) * 16 + m;
+        if (!u.valid || o >= jb.Cout) return;
+        for (int e = 0; e < 8; ++e) {
+            const int ci = q * 8 + e;
+            if (ci < jb.C1) v[e] = jb.w[((size_t)o * Cin + jb.C0 + ci) * 27 + u.kd * 9 + u.kh * 3 + u.kw];
+        }
+    }
+}
+// PHASE 0: largest magnitude of the packed values -> trailer.z (float bits, zeroed by the host side first).  PHASE 1: the words.
+template <int PHASE>
+__global__ void __launch_bounds__(256) k_s3u_pack(const SuPack jb) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float v[8];
+    int piece = 0;
+    if (PHASE == 0) {
+        float m = 0.0f;
+        if (i < jb.words) {
+            su_word_values(jb, i, v, piece);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, __builtin_fabsf(v[e]));
+        }
+        m = s3_wave_max(m);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(&jb.wp[jb.words]) + 2, __float_as_uint(m));
+        return;
+    }
+    if (i >= jb.words) return;
+    su_word_values(jb, i, v, piece);
+    unsigned pk[3][4];
+    if (jb.NP == 3) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s3_split2(v[2 * e], v[2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+    } else {
+        float sc, inv;
+        s3_scale_of(__uint_as_float(jb.wp[jb.words].z), sc, inv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s3_split2_f16(v[2 * e], v[2 * e + 1], sc, pk[0][e], pk[1][e]); pk[2][e] = 0u; }
+        if (i == 0) {                                         // (.z is only read by the other threads)
+            unsigned* t = reinterpret_cast<unsigned*>(&jb.wp[jb.words]);
+            t[0] = __float_as_uint(inv); t[1] = __float_as_uint(sc);
+        }
+    }
+    jb.wp[i] = (u32x4){pk[piece][0], pk[piece][1], pk[piece][2], pk[piece][3]};
+}
+
+int su_cus() {
+    static const int cus = [] {
+        int dev = 0; hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+        return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    }();
+    return cus;
+}
+int su_nct(int Cout) { return Cout > 16 ? 2 : 1; }
+size_t su_words(int C0, int C1, int Cout, int NP) {
+    const int NCT = su_nct(Cout), G = (Cout + 16 * NCT - 1) / (16 * NCT);
+    return (size_t)G * ((size_t)(C0 / 8) * (8 * 2 * NP * NCT * 64) + (size_t)(C1 / 8) * (7 * NP * NCT * 64));
+}
+long long su_min_tiles() {
+    static const long long v = [] { const char* e = getenv("VXM_S3U_MIN_TILES"); return e ? atoll(e) : 512ll; }();
+    return v;
+}
+
+template <int NCT, int NP>
+void su_launch(const float* x0, long long bs0, int C0, const float* x1, long long bs1, int C1, const void* wp, const float* bias, float* y,
+               long long y_bs, int Cout, float slope, int B, int D, int H, int W, hipStream_t s) {
+    using C = SuCfg<NCT, NP>;
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3u_conv<NCT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        return true;
+    }();
+    (void)attr;
+    const long long ntiles = (long long)B * ((D + 7) / 8) * ((H + 3) / 4) * ((W + 31) / 32);
+    const int G = (Cout + 16 * NCT - 1) / (16 * NCT);
+    unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
+    // one persistent block per CU (the LDS holds one): its blocks walk their XCD's tile range and stage ahead across tiles
+    static const int persist = [] { const char* e = getenv("VXM_S3U_PERSIST"); return e ? atoi(e) : 1; }();      // < 0: that many blocks in all (tests)
+    if (persist != 0 && ntiles >= 64) {
+        const unsigned want = persist > 0 ? (unsigned)(su_cus() * persist / G) : (unsigned)(-persist);
+        const unsigned cap = 8 * ((want + 7) / 8);
+        if (cap < gx) gx = cap;
+    }
+    hipLaunchKernelGGL((k_s3u_conv<NCT, NP>), dim3(gx, G), dim3(SU_THREADS), C::LDS_BYTES, s, x0, bs0, C0, x1, bs1, C1, static_cast<const u32x4*>(wp),
+                       bias, y, y_bs, Cout, slope, B, D, H, W);
+}
+
+}  // namespace
+
+extern "C" {
+
+int vxm_conv3d_k3_s3u_ok(int C0, int C1, int Cout, int B, int D, int H, int W, int pieces) {
+    if (C0 <= 0 || C1 < 0 || Cout < 8 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || (pieces != 2 && pieces != 3)) return 0;
+    if (C0 % 8 || C1 % 8 || (D | H | W) & 1) return 0;
+    if ((long long)(C0 + C1 > Cout ? C0 + C1 : Cout) * D * H * W >= (1ll << 29)) return 0;
+    const long long ntiles = (long long)B * ((D + 7) / 8) * ((H + 3) / 4) * ((W + 31) / 32);
+    return ntiles >= su_min_tiles() ? 1 : 0;
+}
+
+size_t vxm_conv3d_k3_s3u_packed_bytes(int C0, int C1, int Cout, int pieces) {
+    if (C0 <= 0 || C1 < 0 || Cout <= 0 || C0 % 8 || C1 % 8 || (pieces != 2 && pieces != 3)) return 0;
+    return (su_words(C0, C1, Cout, pieces) + 1) * 16;
+}
+
+int vxm_conv3d_k3_s3u_pack_weights(const float* w, void* wpacked, int C0, int C1, int Cout, int pieces, void* stream) {
+    VXM_REQUIRE(w && wpacked, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3u_pack_weights: null pointer");
+    VXM_REQUIRE(C0 > 0 && C1 >= 0 && Cout > 0 && C0 % 8 == 0 && C1 % 8 == 0 && (pieces == 2 || pieces == 3) &&
+                    (reinterpret_cast<uintptr_t>(wpacked) & 15) == 0, VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3u_pack_weights: %d + %d -> %d channels (segments in multiples of 8), pieces %d, 16-byte aligned destination", C0, C1, Cout, pieces);
+    const int NCT = su_nct(Cout);
+    SuPack jb = {w, static_cast<u32x4*>(wpacked), C0, C1, Cout, NCT, pieces, C0 / 8, C1 / 8, (Cout + 16 * NCT - 1) / (16 * NCT),
+                 (unsigned)su_words(C0, C1, Cout, pieces)};
+    hipStream_t s = VXM_STREAM(stream);
+    (void)hipMemsetAsync(jb.wp + jb.words, 0, 16, s);
+    const unsigned blocks = (jb.words + 255) / 256;
+    if (pieces == 2) hipLaunchKernelGGL(k_s3u_pack<0>, dim3(blocks), dim3(256), 0, s, jb);
+    hipLaunchKernelGGL(k_s3u_pack<1>, dim3(blocks), dim3(256), 0, s, jb);
+    return vxm_check_launch("vxm_conv3d_k3_s3u_pack_weights");
+}
+
+int vxm_conv3d_k3_s3u_fwd(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const void* wpacked,
+                          const float* bias, float* y, int64_t y_bstride, int Cout, float leaky_slope, int B, int D, int H, int W, int pieces,
+                          void* stream) {
+    VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3u_fwd: null pointer");
+    if (int e = check_conv("vxm_conv3d_k3_s3u_fwd", C0, C1, 1, Cout, B, D, H, W)) return e;
+    VXM_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && (pieces == 2 || pieces == 3), VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3u_fwd: segments carry multiples of 8 channels (got %d + %d), pieces 2 or 3 (got %d)", C0, C1, pieces);
+    VXM_REQUIRE((reinterpret_cast<uintptr_t>(wpacked) & 15) == 0, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3u_fwd: packed weights must be 16-byte aligned");
+    hipStream_t s = VXM_STREAM(stream);
+    const int NCT = su_nct(Cout);
+#define SU_GO(NCT_)                                                                                                                  \
+    do {                                                                                                                             \
+        if (pieces == 2) su_launch<NCT_, 2>(x0, x0_bstride, C0, x1, x1_bstride, C1, wpacked, bias, y, y_bstride, Cout, leaky_slope, B, D, H, W, s); \
+        else su_launch<NCT_, 3>(x0, x0_bstride, C0, x1, x1_bstride, C1, wpacked, bias, y, y_bstride, Cout, leaky_slope, B, D, H, W, s);            \
+    } while (0)
+    if (NCT == 2) SU_GO(2); else SU_GO(1);
+#undef SU_GO
+    return vxm_check_launch("vxm_conv3d_k3_s3u_fwd");
+}
+
+}  // extern "C"

@@ -39,6 +39,9 @@ def s3_pieces():
     return 2 if FP32_ENGINE == "f16x2" else 3
 
 S3_UP = os.environ.get("VXM_S3_UP", "") == "1"
+# cat([upsample(x0), x1]) forwards on the split + collapsed kernel (csrc/conv_s3u.hip: the upsampled segment at low-resolution cost AND on
+# the 16-bit matrix pipe); VXM_S3U=0 keeps them on the round-3 kernels (collapsed fp32-MFMA kernel / split kernel through the gather)
+S3U = os.environ.get("VXM_S3U", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -405,6 +408,34 @@ def s3_pack(w, flip, lo, hi, seg0):
     return w.__dict__["_vxm_s3_packs"][(lo, hi, bool(flip), seg0, s3_pieces())][1]
 
 
+def s3u_route(c0, c1, cout, B, D, H, W):
+    """does a cat([upsample(x0), x1]) forward go to the split + collapsed kernel?"""
+    return S3U and split_engine() and bool(_lib.lib().vxm_conv3d_k3_s3u_ok(c0, c1, cout, B, D, H, W, s3_pieces()))
+
+
+def s3u_pack(w, c0, c1):
+    """packed operator of the split + collapsed forward kernel (collapsed 2x2x2 weights per output parity class for the upsampled
+    segment, the 27 taps for the skip segment, pre-split), cached on the weight tensor until its version moves"""
+    cache = w.__dict__.setdefault("_vxm_s3_packs", {})
+    key = ("s3u", c0, c1, s3_pieces())
+    hit = cache.get(key)
+    if hit is not None and hit[0] == _pack_ver(w) and hit[1].device == w.device:
+        return hit[1]
+    cout = w.shape[0]
+    nbytes = _lib.lib().vxm_conv3d_k3_s3u_packed_bytes(c0, c1, cout, s3_pieces())
+    wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    call("vxm_conv3d_k3_s3u_pack_weights", ptr(_c(w)), ptr(wp), c0, c1, cout, s3_pieces(), stream())
+    cache[key] = (_pack_ver(w), wp)
+    return wp
+
+
+def s3u_launch(x0, c0, bs0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, B, D, H, W):
+    with _prof.region("k_s3u_conv<%d,%d>" % (1 if cout <= 16 else 2, s3_pieces()), flops=2.0 * (8 * c0 + 27 * c1) * cout * B * D * H * W,
+                      nominal=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+        call("vxm_conv3d_k3_s3u_fwd", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W,
+             s3_pieces(), stream())
+
+
 def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
     v = _lib.lib().vxm_conv3d_k3_s3_variant(cout)
     with _prof.region("k_s3_conv<%d,4,%d,%d>" % (v // 10, v % 10, s3_pieces()), flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
@@ -429,6 +460,9 @@ def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B,
     if cout <= 4 and x1 is None and not up0 and _lib.lib().vxm_conv3d_k3_fewout_ok(ptr(x0), bs0, ptr(y), ybs, c0, cout, W):
         with _prof.region("k_conv3d_k3_fewout<%d>" % cout, flops=2.0 * 27 * c0 * cout * B * D * H * W):
             call("vxm_conv3d_k3_fewout_fwd", ptr(x0), c0, bs0, ptr(_c(w)), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W, stream())
+        return
+    if up0 and s3u_route(c0, c1, cout, B, D, H, W):
+        s3u_launch(x0, c0, bs0, x1, c1, bs1, s3u_pack(w, c0, c1), bias, y, ybs, cout, slope, B, D, H, W)
         return
     if s3_route(c0, up0, c1, cout, B, D, H, W):
         s3_launch(x0, c0, bs0, up0, x1, c1, bs1, s3_pack(w, False, 0, c0 + c1, c0), bias, y, ybs, cout, slope, None, 0, 1.0, B, D, H, W)
@@ -682,7 +716,7 @@ def _s3_jobs(plan, params, B, shape3, with_backward, input_grads):
             c0, c1 = sum(plan.ch[i] for i in range(plan.n_inputs)), 0 if plan.n_inputs == 1 else plan.ch[1]
             c0 -= c1
         D, H, W = _dims(shape3, plan.lvl[op["dst"]])
-        if cout > 4 and s3_route(c0, up0, c1, cout, B, D, H, W):
+        if cout > 4 and not (up0 and s3u_route(c0, c1, cout, B, D, H, W)) and s3_route(c0, up0, c1, cout, B, D, H, W):
             jobs.append((w, 0, c0 + c1, False, c0))
         if not with_backward or (s0 < plan.n_inputs and not input_grads):
             continue
