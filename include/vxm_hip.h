@@ -56,8 +56,11 @@ int vxm_warp3d_bwd(const float* src, const float* flow, const float* gout, float
 /* ---- VecInt.forward, layers.py:64-68: v0 = vec/2^n; v_{k+1} = v_k + warp(v_k, v_k).
  * steps: [nsteps][B,3,D,H,W]; steps[k] receives v_{k+1}; the result is steps[nsteps-1]. */
 int vxm_vecint_fwd(const float* vec, float* steps, int B, int D, int H, int W, int nsteps, void* stream);
-/* backward: gout = dL/dv_n; gvec = dL/dvec.  work: 2*B*3*D*H*W + 32 floats of scratch (two gradient buffers and the
- * per-step counters of voxels displaced by a voxel or more, which take the atomic path). */
+/* backward: gout = dL/dv_n; gvec = dL/dvec.  work: 2*B*3*D*H*W + VXM_VECINT_WORK_EXTRA floats of scratch (two gradient buffers and
+ * the per-step statistics of the voxels displaced by a voxel or more: they are scattered by a second, deterministic pass -- per output
+ * tile into 64-bit fixed-point LDS accumulators -- so the result is bit-reproducible; only steps that displace a voxel by more than 24
+ * voxels fall back to global float atomics).  nsteps < 31. */
+#define VXM_VECINT_WORK_EXTRA 128
 int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, float* gvec, float* work,
                    int B, int D, int H, int W, int nsteps, void* stream);
 
@@ -355,6 +358,18 @@ int vxm_conv3d_k3_s3u_pack_weights(const float* w, void* wpacked, int C0, int C1
 int vxm_conv3d_k3_s3u_fwd(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const void* wpacked,
                           const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope, int B, int D, int H, int W, int pieces,
                           void* stream);
+
+/* convolution_backward (input) of the UPSAMPLED segment of such a layer, straight onto the low-resolution tensor it was upsampled from:
+ * conv backward + upsample_nearest3d_backward + leaky_relu_backward(mask_src) in one launch on the split arithmetic (csrc/conv_s3u.hip:
+ * a stride-2, 4x4x4-tap convolution of the full-resolution dz [B,Cout,D,H,W] with the transposed collapsed weights; the full-resolution
+ * gradient of those channels is never written).  gxl: [B,C0,D/2,H/2,W/2]; w: [Cout][Cin][27] whose first C0 input channels are the
+ * upsampled segment.  pieces = 2 only (_ok returns 0 otherwise: callers keep vxm_conv3d_k3_up_bwd_low). */
+int vxm_conv3d_k3_s3u_bwd_low_ok(int C0, int Cout, int B, int D, int H, int W, int pieces);
+size_t vxm_conv3d_k3_s3u_bwd_low_packed_bytes(int C0, int Cout, int pieces);
+int vxm_conv3d_k3_s3u_bwd_low_pack_weights(const float* w, void* wpacked, int C0, int Cin, int Cout, int pieces, void* stream);
+int vxm_conv3d_k3_s3u_bwd_low(const float* dz, int64_t dz_bstride, int Cout, const void* wpacked, float* gxl, int64_t gxl_bstride, int C0,
+                              const float* mask_src, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, int pieces,
+                              void* stream);
 
 #ifdef __cplusplus
 }

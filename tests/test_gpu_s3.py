@@ -157,6 +157,38 @@ def test_s3u_collapsed_forward_many_tiles_and_scales(VF):
     assert torch.equal(ys, y1 * 2.0 ** -30)
 
 
+@pytest.mark.parametrize("c0,c1,cout,vol,B", [(32, 16, 32, (16, 8, 64), 2), (16, 8, 24, (10, 6, 36), 2), (8, 0, 16, (8, 4, 32), 1), (40, 24, 32, (12, 8, 34), 1)])
+def test_s3u_backward_data_onto_the_low_resolution_tensor_vs_fp64(VF, c0, c1, cout, vol, B):
+    """k_s3u_dlow: conv backward + upsample_nearest3d_backward + leaky_relu_backward of the upsampled segment in one launch against fp64
+    autograd of the reference's op sequence (networks.py:133-138, 299-305); destination guards.  fp16 scheme only (the bf16 scheme keeps
+    the fp32-MFMA kernel: _ok says so)."""
+    from voxelmorph_amd import _lib
+    D, H, W = vol
+    if VF.FP32_ENGINE != "f16x2":
+        assert _lib.lib().vxm_conv3d_k3_s3u_bwd_low_ok(c0, cout, B, 64, 64, 64, 3) == 0
+        pytest.skip("k_s3u_dlow runs the fp16 scheme")
+    torch.manual_seed(4000 + c0 + cout)
+    lo = tuple(s // 2 for s in vol)
+    w = torch.randn(cout, c0 + c1, 3, 3, 3, device="cuda") / (27 * (c0 + c1)) ** 0.5
+    dz = torch.randn(B, cout, *vol, device="cuda")
+    act = torch.randn(B, c0, *lo, device="cuda")                      # the decoder block's activation (mask source)
+    big = torch.full((B + 1, c0 + 3) + lo, 7.25, device="cuda")
+    gxl = big[:B, :c0]
+    # (s3u_bwd_low takes contiguous per-sample strides of c0 * V / 8: give it its own tensor and copy into the guarded one)
+    out = torch.empty(B, c0, *lo, device="cuda")
+    VF.s3u_bwd_low(dz, cout, w, c0, c0 + c1, out, act, 0.2, B, D, H, W)
+    xl = torch.zeros(B, c0, *lo, dtype=torch.float64, requires_grad=True)
+    xin = torch.nn.functional.interpolate(xl, scale_factor=2, mode="nearest")
+    if c1:
+        xin = torch.cat([xin, torch.zeros(B, c1, *vol, dtype=torch.float64)], 1)
+    torch.nn.functional.conv3d(xin, w.cpu().double(), None, padding=1).backward(dz.cpu().double())
+    want = xl.grad * torch.where(act.cpu().double() > 0, 1.0, 0.2)
+    e = rel_l2(out.cpu().numpy(), want.numpy())
+    print("s3u backward-data-low [%s] (%d^(+%d) <- %d, %s, B=%d): rel-L2 vs fp64 %.2e" % (VF.FP32_ENGINE, c0, c1, cout, "x".join(map(str, vol)), B, e))
+    assert e <= 1e-6, e
+    del gxl, big
+
+
 def test_s3_backward_data_with_fused_mask_and_output_guard(VF):
     """The adjoint operator (transpose_flip pack) with the previous block's LeakyReLU' fused in the epilogue, written into a
     channel slice of a larger buffer: nothing outside the slice, the next sample or the tail may be touched."""

@@ -384,6 +384,7 @@ struct SuPack {
     const float* w; u32x4* wp;
     int C0, C1, Cout, NCT, NP, Q0, Q1, G;
     unsigned words;                          // 16-byte words of the operator proper; the trailer follows
+    int kind;                                // 0: forward operator (k_s3u_conv), 1: adjoint onto the low-resolution tensor (k_s3u_dlow)
 };
 // the 8 values (8 consecutive input channels) of packed word i
 __device__ __forceinline__ void su_word_values(const SuPack& jb, size_t i, float (&v)[8], int& piece) {
@@ -432,6 +433,42 @@ __device__ __forceinline__ void su_word_values(const SuPack& jb, size_t i, float
         }
     }
 }
+// Adjoint of the upsampled segment onto the LOW-resolution tensor (k_s3u_dlow): gxl[ci][m] = sum_o sum_{a in {-1,0,1,2}^3} Wt[a][ci][o] dz[o][2 m + a]
+// with, per axis, Wt(-1) = w2, Wt(0) = w1 + w2, Wt(1) = w0 + w1, Wt(2) = w0 (the transpose of the collapsed forward).
+// words: [G][Q = Cout / 8 chunks of dz channels][step 16 = (a_h, a_w)][piece][NCT][64 lanes]; lane (kg, m): a_d index kg, input channel
+// ci = 16 (g NCT + ct) + m, the 8 values = dz channels o = 8 q + e.
+__device__ __forceinline__ void su_dlow_word_values(const SuPack& jb, size_t i, float (&v)[8], int& piece) {
+    const int NP = jb.NP, NCT = jb.NCT, Cin = jb.C0 + jb.C1, Q = (jb.Cout + 7) / 8;
+    const int per_chunk = 16 * NP * NCT * 64;
+    size_t r = i;
+    int r2 = (int)(r % per_chunk); r /= per_chunk;
+    const int q = (int)(r % Q), g = (int)(r / Q);
+    const int step = r2 / (NP * NCT * 64); r2 -= step * (NP * NCT * 64);
+    piece = r2 / (NCT * 64); r2 -= piece * (NCT * 64);
+    const int ct = r2 / 64, lane = r2 & 63, kg = lane >> 4, m = lane & 15;
+    const int ad = kg, ah = step >> 2, aw = step & 3;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+    const int ci = (g * NCT + ct) * 16 + m;
+    if (ci >= jb.C0) return;
+    // taps that reach offset index t (a = t - 1): T(0) = {2}, T(1) = {1,2}, T(2) = {0,1}, T(3) = {0}
+    const int dlo = ad == 0 ? 2 : (ad == 1 ? 1 : 0), dhi = ad <= 1 ? 2 : (ad == 2 ? 1 : 0);
+    const int hlo = ah == 0 ? 2 : (ah == 1 ? 1 : 0), hhi = ah <= 1 ? 2 : (ah == 2 ? 1 : 0);
+    const int wlo = aw == 0 ? 2 : (aw == 1 ? 1 : 0), whi = aw <= 1 ? 2 : (aw == 2 ? 1 : 0);
+    for (int e = 0; e < 8; ++e) {
+        const int o = q * 8 + e;
+        if (o >= jb.Cout) continue;
+        const float* wr = jb.w + ((size_t)o * Cin + ci) * 27;
+        float s = 0.0f;
+        for (int kd = dlo; kd <= dhi; ++kd)
+            for (int kh = hlo; kh <= hhi; ++kh)
+                for (int kw = wlo; kw <= whi; ++kw) s += wr[kd * 9 + kh * 3 + kw];
+        v[e] = s;
+    }
+}
+__device__ __forceinline__ void su_values(const SuPack& jb, size_t i, float (&v)[8], int& piece) {
+    if (jb.kind == 0) su_word_values(jb, i, v, piece); else su_dlow_word_values(jb, i, v, piece);
+}
 // PHASE 0: largest magnitude of the packed values -> trailer.z (float bits, zeroed by the host side first).  PHASE 1: the words.
 template <int PHASE>
 __global__ void __launch_bounds__(256) k_s3u_pack(const SuPack jb) {
@@ -441,7 +478,7 @@ __global__ void __launch_bounds__(256) k_s3u_pack(const SuPack jb) {
     if (PHASE == 0) {
         float m = 0.0f;
         if (i < jb.words) {
-            su_word_values(jb, i, v, piece);
+            su_values(jb, i, v, piece);
 #pragma unroll
             for (int e = 0; e < 8; ++e) m = fmaxf(m, __builtin_fabsf(v[e]));
         }
@@ -450,7 +487,7 @@ __global__ void __launch_bounds__(256) k_s3u_pack(const SuPack jb) {
         return;
     }
     if (i >= jb.words) return;
-    su_word_values(jb, i, v, piece);
+    su_values(jb, i, v, piece);
     unsigned pk[3][4];
     if (jb.NP == 3) {
 #pragma unroll
@@ -466,6 +503,251 @@ __global__ void __launch_bounds__(256) k_s3u_pack(const SuPack jb) {
         }
     }
     jb.wp[i] = (u32x4){pk[piece][0], pk[piece][1], pk[piece][2], pk[piece][3]};
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// backward-data of the upsampled segment, straight onto the LOW-resolution tensor:
+//   convolution_backward (input) + upsample_nearest3d_backward + leaky_relu_backward of the decoder block in one launch
+//   (autograd twins of networks.py:133-138, 299-305; rounds 1-3: k_conv3d_k3_dlow on the fp32 matrix pipe).
+// gxl[ci][m] = LeakyReLU'(mask[ci][m]) sum_o sum_{a in {-1,0,1,2}^3} Wt[a][ci][o] dz[o][2 m + a]   (su_dlow_word_values): a stride-2, 4x4x4-tap
+// convolution of the full-resolution dZ; the full-resolution gradient of those channels is never written.
+// Implicit GEMM: M = 16 input channels (x NCT), N = 16 low-res voxels of a W row, K = 32 = four units of 8 dZ channels, unit = a_d
+// (lane group), K-step = (a_h, a_w): 16 K-steps per 8 dZ channels.  dZ is staged like the forward kernel's skip segment (haloed
+// 10 x 6 x 34 tile, W-parity de-interleaved), output tile = low-res 4 x 2 x 16.  With only 8 output rows per tile a wave cannot own
+// rows AND reuse a weight fragment, so the block splits K: wave = (a_h, row half) multiplies its a_h's four K-steps for four output rows
+// (a weight fragment serves four rows), and the four a_h partial sums of a row are combined through LDS in a fixed order
+// (deterministic) before the epilogue.
+template <int NCT, int NP>
+struct SdCfg {
+    static constexpr int XWORDS = 10 * SU_SK_PLANE;
+    static constexpr int WCH = 16 * NP * NCT * 64;                                             // [step 16][piece][ct][lane]
+    static constexpr int LDS_BYTES = (NP * XWORDS + WCH) * 16 + 64;
+    static_assert(4 * 8 * NCT * 64 <= NP * XWORDS, "the combine buffer reuses the staging tile");
+};
+
+template <int NCT, int NP>
+__global__ void __launch_bounds__(SU_THREADS, 2)
+k_s3u_dlow(const float* __restrict__ dz, long long dz_bs, int Cout, const u32x4* __restrict__ wp, float* __restrict__ gxl, long long gxl_bs, int C0,
+           const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W) {
+    using C = SdCfg<NCT, NP>;
+    using P = S3P<NP>;
+    VXM_DYN_SMEM(u32x4, smem);
+    constexpr int XWORDS = C::XWORDS, WCH = C::WCH;
+    u32x4* const Xs = smem;
+    u32x4* const Ws = smem + NP * XWORDS;
+    float* const Wm = reinterpret_cast<float*>(smem + NP * XWORDS + WCH);
+    const int tid = threadIdx.x, tid_ = tid, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = lane >> 4, n = lane & 15;
+    const int kq = wave & 3, rh = wave >> 2;                 // this wave's a_h index and row half (wave-uniform)
+
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1, V = D * H * W, Vl = Dl * Hl * Wl;
+    const int nw = (Wl + 15) / 16, nh = (Hl + 1) / 2, nd = (Dl + 3) / 4;
+    const int ntiles = B * nd * nh * nw;
+    int t_lo, t_hi, t_step;
+    if (ntiles >= 64) {
+        const int x = blockIdx.x & 7;
+        t_lo = (int)((long long)ntiles * x / 8) + (int)(blockIdx.x >> 3); t_hi = (int)((long long)ntiles * (x + 1) / 8); t_step = (int)(gridDim.x >> 3);
+    } else {
+        t_lo = blockIdx.x; t_hi = ntiles; t_step = gridDim.x;
+    }
+    const int g = blockIdx.y;
+    const int Q = (Cout + 7) >> 3;
+    const u32x4* const wg = wp + (size_t)g * Q * WCH;
+
+    // staging slots (as the forward kernel's skip chunk): i = tid + 512 j = (hd 10, hh 6, hw 34) -> word hd 240 + hh 40 + (hw & 1) 20 + (hw >> 1)
+    int sk_pos[SU_NI], sk_lw[SU_NI];
+#pragma unroll
+    for (int j = 0; j < SU_NI; ++j) {
+        const int i = tid + SU_THREADS * j;
+        const int hd = i / 204, rem = i - hd * 204, hh = rem / 34, hw = rem - hh * 34;
+        sk_pos[j] = i < SU_SK_SLOTS ? (hd << 10 | hh << 6 | hw) : -1;
+        sk_lw[j] = hd * SU_SK_PLANE + hh * SU_SK_ROW + (hw & 1) * SU_SK_HALF + (hw >> 1);
+    }
+    // B fragments: lane group kg = a_d index reads haloed voxel (2 ld + kg, 2 lh + kq, 2 n + aw) in K-step aw of this wave's a_h
+    int xb[4];
+#pragma unroll
+    for (int aw = 0; aw < 4; ++aw) xb[aw] = kg * SU_SK_PLANE + kq * SU_SK_ROW + (aw & 1) * SU_SK_HALF + (aw >> 1) + n + rh * 4 * SU_SK_PLANE;
+
+    int d0 = 0, h0 = 0, w0 = 0, bt = 0;                       // full-resolution origin of the staging tile
+    bool live = false;
+    __amdgpu_buffer_rsrc_t rz;
+    auto set_tile = [&](int tile) __attribute__((always_inline)) {
+        live = tile < t_hi;
+        const int tl = live ? tile : t_lo;
+        const int tw = tl % nw; int tq = tl / nw;
+        const int th = tq % nh; tq /= nh;
+        const int td = tq % nd;
+        bt = tq / nd;
+        d0 = td * 8; h0 = th * 4; w0 = tw * 32;
+        rz = vxm_rsrc(dz + (size_t)bt * dz_bs, (unsigned)Cout * (unsigned)V * 4u);
+    };
+    float xr[SU_NI][8];
+    int voffs[SU_NI];
+    auto load_stage = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < SU_NI; ++j) {
+            const int pos = sk_pos[j];
+            const int gd = d0 - 1 + (pos >> 10), gh = h0 - 1 + ((pos >> 6) & 15), gw = w0 - 1 + (pos & 63);
+            const bool ok = live && pos >= 0 && q < Q && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            voffs[j] = ok ? (q * 8 * V + (gd * H + gh) * W + gw) << 2 : VXM_OOB;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xr[j][e] = (q * 8 + e < Cout) ? vxm_bload(rz, voffs[j], (e * V) << 2) : 0.0f;       // (wave-uniform test: Cout % 8 != 0)
+        }
+    };
+    auto keep_offsets = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < SU_NI; ++j) asm volatile("" ::"v"(voffs[j]));
+    };
+    auto publish_max = [&]() __attribute__((always_inline)) {
+        if constexpr (NP == 2) {
+            float m = 0.0f;
+#pragma unroll
+            for (int j = 0; j < SU_NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, __builtin_fabsf(xr[j][e]));
+            m = s3_wave_max(m);
+            if (lane == 0) Wm[wave] = m;
+        }
+    };
+    int E_run = 15;
+    float ratio = 1.0f, inv_run = 1.0f;
+    auto store_stage = [&](int q, bool first) __attribute__((always_inline)) {
+        constexpr int WIT = (WCH + SU_THREADS - 1) / SU_THREADS;
+        u32x4 wv[WIT];
+        const __amdgpu_buffer_rsrc_t rw = vxm_rsrc(reinterpret_cast<const float*>(wg + (size_t)q * WCH), WCH * 16u);
+#pragma unroll
+        for (int it = 0; it < WIT; ++it)
+            wv[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid_ + SU_THREADS * it) * 16, 0, 0));
+        float sc = 1.0f;
+        if constexpr (NP == 2) {
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(Wm), m1 = *reinterpret_cast<const f32x4*>(Wm + 4);
+            const float mx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+            int E = (int)(__float_as_uint(mx) >> 23) & 255;
+            E = E < 15 ? 15 : E;
+            const int E_new = first ? E : (E > E_run ? E : E_run);
+            const int dE = E_new - E_run;
+            ratio = (first || dE == 0) ? 1.0f : (dE > 126 ? 0.0f : __uint_as_float((unsigned)(127 - dE) << 23));
+            E_run = E_new;
+            sc = __uint_as_float((unsigned)(268 - E_run) << 23);
+            inv_run = __uint_as_float((unsigned)(E_run - 14) << 23);
+        }
+#pragma unroll
+        for (int j = 0; j < SU_NI; ++j) {
+            unsigned pk[NP][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (NP == 3) s3_split2(xr[j][2 * e], xr[j][2 * e + 1], pk[0][e], pk[1][e], pk[2][e]);
+                else s3_split2_f16(xr[j][2 * e], xr[j][2 * e + 1], sc, pk[0][e], pk[1][e]);
+            }
+            if (sk_pos[j] >= 0) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) Xs[p * XWORDS + sk_lw[j]] = (u32x4){pk[p][0], pk[p][1], pk[p][2], pk[p][3]};
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const int i = tid_ + SU_THREADS * it;
+            if (i < WCH) Ws[i] = wv[it];
+        }
+    };
+
+    set_tile(t_lo);
+    load_stage(0);
+    if constexpr (NP == 2) { publish_max(); __syncthreads(); }
+    store_stage(0, true);
+    for (int tile = t_lo; tile < t_hi; tile += t_step) {
+    const int cd0 = d0 >> 1, ch0 = h0 >> 1, cw0 = w0 >> 1, cbt = bt;      // low-resolution origin of the tile being computed
+    __syncthreads();
+    f32x4 acc[4][NCT];                                          // row r = 2 (ld - 2 rh) + lh of this wave's half
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float inv_fin = 1.0f;
+    for (int q = 0; q < Q; ++q) {
+        const bool last = q + 1 == Q;
+        if (last) set_tile(tile + t_step);
+        load_stage(last ? 0 : q + 1);
+        if constexpr (NP == 2) {
+            if (ratio != 1.0f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) acc[r][ct] *= ratio;
+            }
+        }
+#pragma unroll
+        for (int aw = 0; aw < 4; ++aw) {
+            u32x4 a[NP][NCT], bf[2][NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) bf[0][p] = Xs[p * XWORDS + xb[aw]];
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) a[p][ct] = Ws[(((kq * 4 + aw) * NP + p) * NCT + ct) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (r + 1 < 4) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) bf[(r + 1) & 1][p] = Xs[p * XWORDS + xb[aw] + ((r + 1) >> 1) * 2 * SU_SK_PLANE + ((r + 1) & 1) * 2 * SU_SK_ROW];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < P::NPROD; ++t)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) acc[r][ct] = P::mfma(a[P::PA[t]][ct], bf[r & 1][P::PB[t]], acc[r][ct]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        keep_offsets();
+        if (last) inv_fin = inv_run;
+        publish_max();
+        __syncthreads();                            // every wave is done reading this chunk
+        if (!last) {
+            store_stage(q + 1, false);
+            __syncthreads();
+        }
+    }
+    // ---- combine the four a_h partial sums of every output row through LDS (the staging tile is free), fixed order; then the epilogue:
+    // wave w finishes output row w = (ld, lh) = (w >> 1, w & 1): unscale, LeakyReLU'(mask), planar fp32 store at low resolution
+    f32x4* const Rs = reinterpret_cast<f32x4*>(smem);            // [kq 4][row 8][ct][lane]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) Rs[((kq * 8 + rh * 4 + r) * NCT + ct) * 64 + lane] = acc[r][ct];
+    __syncthreads();
+    {
+        float unscale = 1.0f;
+        if constexpr (NP == 2) {
+            const float inv_w = __uint_as_float(__builtin_amdgcn_readfirstlane((int)wp[(size_t)gridDim.y * Q * WCH].x));
+            unscale = inv_fin * inv_w;
+        }
+        const int ld = wave >> 1, lh = wave & 1;
+        const int dd = cd0 + ld, hh = ch0 + lh, ww = cw0 + n;    // low-resolution voxel of this lane
+        const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(gxl + (size_t)cbt * gxl_bs, (unsigned)C0 * (unsigned)Vl * 4u);
+        const __amdgpu_buffer_rsrc_t rm = vxm_rsrc(mask ? mask + (size_t)cbt * mask_bs : gxl, (unsigned)C0 * (unsigned)Vl * 4u);
+        const bool vok = dd < Dl && hh < Hl && ww < Wl;
+        const int vox = (dd * Hl + hh) * Wl + ww;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const f32x4 p0 = Rs[((0 * 8 + wave) * NCT + ct) * 64 + lane], p1 = Rs[((1 * 8 + wave) * NCT + ct) * 64 + lane];
+            const f32x4 p2 = Rs[((2 * 8 + wave) * NCT + ct) * 64 + lane], p3 = Rs[((3 * 8 + wave) * NCT + ct) * 64 + lane];
+            const f32x4 sum = (p0 + p1) + (p2 + p3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = (g * NCT + ct) * 16 + kg * 4 + j;
+                const int off = (vok && ch < C0) ? (ch * Vl + vox) << 2 : VXM_OOB;
+                float v = sum[j];
+                if constexpr (NP == 2) v *= unscale;
+                if (mask) v *= vxm_lrelu_grad(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, off, 0, 0)), mask_slope);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, off, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                // the combine buffer is free again
+    if (tile + t_step < t_hi) store_stage(0, true); // chunk 0 of the next tile; the barrier at the top of the tile loop publishes it
+    }
 }
 
 int su_cus() {
@@ -509,6 +791,33 @@ void su_launch(const float* x0, long long bs0, int C0, const float* x1, long lon
                        bias, y, y_bs, Cout, slope, B, D, H, W);
 }
 
+
+size_t sd_words(int C0, int Cout, int NP, int NCT) {
+    const int G = (C0 + 16 * NCT - 1) / (16 * NCT), Q = (Cout + 7) / 8;
+    return (size_t)G * Q * 16 * NP * NCT * 64;
+}
+template <int NCT, int NP>
+void sd_launch(const float* dz, long long dz_bs, int Cout, const void* wp, float* gxl, long long gxl_bs, int C0, const float* mask, long long mask_bs,
+               float mask_slope, int B, int D, int H, int W, hipStream_t s) {
+    using C = SdCfg<NCT, NP>;
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3u_dlow<NCT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        return true;
+    }();
+    (void)attr;
+    const long long ntiles = (long long)B * ((D / 2 + 3) / 4) * ((H / 2 + 1) / 2) * ((W / 2 + 15) / 16);
+    const int G = (C0 + 16 * NCT - 1) / (16 * NCT);
+    unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
+    static const int persist = [] { const char* e = getenv("VXM_S3U_PERSIST"); return e ? atoi(e) : 1; }();
+    if (persist != 0 && ntiles >= 64) {
+        const unsigned want = persist > 0 ? (unsigned)(su_cus() * persist / G) : (unsigned)(-persist);
+        const unsigned cap = 8 * ((want + 7) / 8);
+        if (cap < gx) gx = cap;
+    }
+    hipLaunchKernelGGL((k_s3u_dlow<NCT, NP>), dim3(gx, G), dim3(SU_THREADS), C::LDS_BYTES, s, dz, dz_bs, Cout, static_cast<const u32x4*>(wp), gxl, gxl_bs,
+                       C0, mask, mask_bs, mask_slope, B, D, H, W);
+}
+
 }  // namespace
 
 extern "C" {
@@ -533,7 +842,7 @@ int vxm_conv3d_k3_s3u_pack_weights(const float* w, void* wpacked, int C0, int C1
                 "vxm_conv3d_k3_s3u_pack_weights: %d + %d -> %d channels (segments in multiples of 8), pieces %d, 16-byte aligned destination", C0, C1, Cout, pieces);
     const int NCT = su_nct(Cout);
     SuPack jb = {w, static_cast<u32x4*>(wpacked), C0, C1, Cout, NCT, pieces, C0 / 8, C1 / 8, (Cout + 16 * NCT - 1) / (16 * NCT),
-                 (unsigned)su_words(C0, C1, Cout, pieces)};
+                 (unsigned)su_words(C0, C1, Cout, pieces), 0};
     hipStream_t s = VXM_STREAM(stream);
     (void)hipMemsetAsync(jb.wp + jb.words, 0, 16, s);
     const unsigned blocks = (jb.words + 255) / 256;
@@ -560,6 +869,48 @@ int vxm_conv3d_k3_s3u_fwd(const float* x0, int C0, int64_t x0_bstride, const flo
     if (NCT == 2) SU_GO(2); else SU_GO(1);
 #undef SU_GO
     return vxm_check_launch("vxm_conv3d_k3_s3u_fwd");
+}
+
+/* backward-data of the upsampled segment onto the low-resolution tensor (k_s3u_dlow); the fp16 scheme only (the three bf16 pieces of the
+ * 16-step weight chunk do not fit the LDS beside the staging tile: pieces = 3 callers keep vxm_conv3d_k3_up_bwd_low) */
+int vxm_conv3d_k3_s3u_bwd_low_ok(int C0, int Cout, int B, int D, int H, int W, int pieces) {
+    if (C0 <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0 || pieces != 2) return 0;
+    if (C0 % 8 || ((D | H | W) & 1)) return 0;
+    if ((long long)(C0 > Cout ? C0 : Cout) * D * H * W >= (1ll << 29)) return 0;
+    const long long ntiles = (long long)B * ((D / 2 + 3) / 4) * ((H / 2 + 1) / 2) * ((W / 2 + 15) / 16);
+    return ntiles >= su_min_tiles() ? 1 : 0;
+}
+
+size_t vxm_conv3d_k3_s3u_bwd_low_packed_bytes(int C0, int Cout, int pieces) {
+    if (C0 <= 0 || Cout <= 0 || pieces != 2) return 0;
+    return (sd_words(C0, Cout, pieces, su_nct(C0)) + 1) * 16;
+}
+
+int vxm_conv3d_k3_s3u_bwd_low_pack_weights(const float* w, void* wpacked, int C0, int Cin, int Cout, int pieces, void* stream) {
+    VXM_REQUIRE(w && wpacked, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3u_bwd_low_pack_weights: null pointer");
+    VXM_REQUIRE(C0 > 0 && Cin >= C0 && Cout > 0 && pieces == 2 && (reinterpret_cast<uintptr_t>(wpacked) & 15) == 0, VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3u_bwd_low_pack_weights: %d of %d input channels, %d outputs, pieces %d (2), 16-byte aligned destination", C0, Cin, Cout, pieces);
+    const int NCT = su_nct(C0);
+    SuPack jb = {w, static_cast<u32x4*>(wpacked), C0, Cin - C0, Cout, NCT, pieces, 0, 0, (C0 + 16 * NCT - 1) / (16 * NCT),
+                 (unsigned)sd_words(C0, Cout, pieces, NCT), 1};
+    hipStream_t s = VXM_STREAM(stream);
+    (void)hipMemsetAsync(jb.wp + jb.words, 0, 16, s);
+    const unsigned blocks = (jb.words + 255) / 256;
+    hipLaunchKernelGGL(k_s3u_pack<0>, dim3(blocks), dim3(256), 0, s, jb);
+    hipLaunchKernelGGL(k_s3u_pack<1>, dim3(blocks), dim3(256), 0, s, jb);
+    return vxm_check_launch("vxm_conv3d_k3_s3u_bwd_low_pack_weights");
+}
+
+int vxm_conv3d_k3_s3u_bwd_low(const float* dz, int64_t dz_bstride, int Cout, const void* wpacked, float* gxl, int64_t gxl_bstride, int C0,
+                              const float* mask, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, int pieces, void* stream) {
+    VXM_REQUIRE(dz && wpacked && gxl, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3u_bwd_low: null pointer");
+    if (int e = check_conv("vxm_conv3d_k3_s3u_bwd_low", C0, 0, 1, Cout, B, D, H, W)) return e;
+    VXM_REQUIRE(pieces == 2 && (reinterpret_cast<uintptr_t>(wpacked) & 15) == 0, VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3u_bwd_low: pieces %d (this kernel runs the fp16 scheme, 2), 16-byte aligned packed weights", pieces);
+    hipStream_t s = VXM_STREAM(stream);
+    if (su_nct(C0) == 2) sd_launch<2, 2>(dz, dz_bstride, Cout, wpacked, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, B, D, H, W, s);
+    else sd_launch<1, 2>(dz, dz_bstride, Cout, wpacked, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, B, D, H, W, s);
+    return vxm_check_launch("vxm_conv3d_k3_s3u_bwd_low");
 }
 
 }  // extern "C"

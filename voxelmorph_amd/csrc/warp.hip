@@ -248,6 +248,7 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __
     __shared__ f32x4 recA[VG_LN];                                 // {E_z, E_y, E_x, g_0 (0 when not near)}
     __shared__ vg_f32x2 recB[VG_LN];                              // {g_1, g_2}
     __shared__ float vL[3][VG_LN];                                // v = in * scale
+    __shared__ unsigned farw[16][3];                              // per wave: far senders, their largest displacement / |g| (float bits)
     const int tid = threadIdx.x, tx = tid & 31, ty = (tid >> 5) & 7, dd = tid >> 8;
     const int ntw = (W + VG_TW - 1) / VG_TW, nth = (H + VG_TH - 1) / VG_TH;
     int t = blockIdx.x;
@@ -289,7 +290,19 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __
         recA[lq] = (f32x4){so.e[0], so.e[1], so.e[2], send ? g0 : 0.0f};
         recB[lq] = (vg_f32x2){send ? g1 : 0.0f, send ? g2 : 0.0f};
         vL[0][lq] = v0; vL[1][lq] = v1; vL[2][lq] = v2;
-        if (own_in && !so.near) atomicAdd(far_count, 1u);         // rare: left to the atomic pass
+    }
+    // the senders the gather leaves out (displacement >= 1 voxel): their number, largest displacement and largest |g| of the block ->
+    // far_count[0..2] (one set of atomics per BLOCK: in the regime of a trained network most voxels of the last steps are such senders)
+    {
+        const bool isfar = own_in && !so.near;
+        const float dsp = isfar ? fmaxf(fmaxf(fabsf(vxm_src_coord(d, v0, D) - (float)d), fabsf(vxm_src_coord(h, v1, H) - (float)h)),
+                                        fabsf(vxm_src_coord(w, v2, W) - (float)w)) : 0.0f;
+        const float gmx = isfar ? fmaxf(fmaxf(fabsf(g0), fabsf(g1)), fabsf(g2)) : 0.0f;
+        const unsigned long long bal = __ballot(isfar);
+        float wd = dsp, wg = gmx;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { wd = fmaxf(wd, __shfl_xor(wd, o, 64)); wg = fmaxf(wg, __shfl_xor(wg, o, 64)); }
+        if ((tid & 63) == 0) { farw[tid >> 6][0] = (unsigned)__popcll(bal); farw[tid >> 6][1] = __float_as_uint(wd); farw[tid >> 6][2] = __float_as_uint(wg); }
     }
     if (tid < VG_NHALO) {
         const VgStaged sh = vg_stage(u0, u1, u2, qz, qy, qx, D, H, W);
@@ -299,6 +312,11 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __
         vL[0][lh] = u0; vL[1][lh] = u1; vL[2][lh] = u2;
     }
     __syncthreads();
+    if (tid == 0) {
+        unsigned cnt = 0, dm = 0, gm = 0;
+        for (int i = 0; i < 16; ++i) { cnt += farw[i][0]; dm = max(dm, farw[i][1]); gm = max(gm, farw[i][2]); }       // (non-negative floats order as their bits)
+        if (cnt) { atomicAdd(far_count, cnt); atomicMax(far_count + 1, dm); atomicMax(far_count + 2, gm); }
+    }
     if (!own_in) return;
     // ---- local part: identity + derivative through the sampling position (the 8 corners of x'(q) sampled from v itself)
     const Corners8 cn = corners8(vxm_src_coord(d, v0, D), vxm_src_coord(h, v1, H), vxm_src_coord(w, v2, W), D, H, W);
@@ -367,13 +385,96 @@ __device__ __forceinline__ void vecint_far_voxel(const float* __restrict__ in, f
         atomicAdd(gi + 2 * (size_t)V + i, g2 * wk);
     }
 }
-// A SMALL persistent grid (the common case is count == 0: 256 blocks exit at once instead of several thousand, 5.7 -> ~2 us per step)
+// Far senders whose displacement exceeds what the tile pass below covers (> VF_RMAX voxels per step: not a registration field any more):
+// the atomic scatter, kept for completeness (order-dependent sums).  A small persistent grid that exits at once otherwise.
+constexpr int VF_RMAX = 24;
 __global__ void __launch_bounds__(256) k_vecint_step_bwd_far(const float* __restrict__ in, float scale, const float* __restrict__ gout,
                                                              float* __restrict__ gin, const unsigned* __restrict__ far_count, int B, int D, int H, int W) {
-    if (far_count[0] == 0) return;
+    if (far_count[0] == 0 || __uint_as_float(far_count[1]) < (float)VF_RMAX) return;
     const int HWf = H * W, V = D * HWf;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < (long long)B * V; idx += (long long)gridDim.x * 256)
         vecint_far_voxel(in, scale, gout, gin, (int)(idx / V), (int)(idx % V), D, H, W);
+}
+
+// The scatter of the far senders, DETERMINISTIC (round 4; rounds 1-3 added them to gin with global float atomics, whose order -- and
+// with it the sum -- changes from run to run).  One block per 4 x 8 x 32 OUTPUT tile walks the tile grown by R = the step's largest
+// displacement (known on the device: far_count[1]), recomputes the near test of every candidate sender, and adds the corner
+// contributions of the far ones that land inside ITS tile to 64-bit FIXED-POINT accumulators in LDS (ds_add_u64: integer addition is
+// associative, so the order of the LDS atomics does not matter).  The scale of the fixed point comes from the step's largest |g|
+// (far_count[2]): 2^46 <= max |g| 2^k < 2^47, i.e. 46 significant bits below the largest contribution and 16 bits of headroom above.
+// Every output voxel is then read-modify-written by exactly one thread.  Cost ~ (grown tile / tile) x the forward step's arithmetic.
+__global__ void __launch_bounds__(1024) k_vecint_step_bwd_far_tiles(const float* __restrict__ in, float scale, const float* __restrict__ gout,
+                                                                    float* __restrict__ gin, const unsigned* __restrict__ far_count, int D, int H, int W) {
+    if (far_count[0] == 0) return;                                // block-uniform: the regime of small steps
+    const float dm = __uint_as_float(far_count[1]);
+    if (!(dm < (float)VF_RMAX)) return;                           // left to k_vecint_step_bwd_far
+    __shared__ unsigned long long acc[3][VG_TD * VG_TH * VG_TW];
+    const int tid = threadIdx.x;
+    const int R = (int)dm + 1;                                    // corners of a sender lie within ceil(displacement) of it
+    int Eg = (int)(far_count[2] >> 23) & 255;
+    Eg = Eg < 1 ? 1 : Eg;                                         // fixed point: value * 2^(173 - Eg)
+    const int ntw = (W + VG_TW - 1) / VG_TW, nth = (H + VG_TH - 1) / VG_TH;
+    int t = blockIdx.x;
+    const int w0 = (t % ntw) * VG_TW; t /= ntw;
+    const int h0 = (t % nth) * VG_TH;
+    const int d0 = (t / nth) * VG_TD;
+    const int b = blockIdx.y;
+    const int HW = H * W, V = D * HW;
+    const __amdgpu_buffer_rsrc_t rv = vxm_rsrc(in + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
+    const __amdgpu_buffer_rsrc_t rgo = vxm_rsrc(gout + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
+    const int V4 = V << 2;
+    acc[0][tid] = 0ull; acc[1][tid] = 0ull; acc[2][tid] = 0ull;
+    __syncthreads();
+    const int gy = VG_TH + 2 * R, gx = VG_TW + 2 * R, ng = (VG_TD + 2 * R) * gy * gx;
+    for (int i = tid; i < ng; i += 1024) {
+        const int lz = i / (gy * gx), r2 = i - lz * gy * gx, ly = r2 / gx, lx = r2 - ly * gx;
+        const int pz = d0 - R + lz, py = h0 - R + ly, px = w0 - R + lx;
+        if ((unsigned)pz >= (unsigned)D || (unsigned)py >= (unsigned)H || (unsigned)px >= (unsigned)W) continue;
+        const int p4 = (pz * HW + py * W + px) << 2;
+        const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
+        const float xz = vxm_src_coord(pz, v0, D), xy = vxm_src_coord(py, v1, H), xx = vxm_src_coord(px, v2, W);
+        float fr;
+        int rr;
+        bool nz, ny, nx;
+        vg_axis(xz, pz, D, fr, rr, nz); vg_axis(xy, py, H, fr, rr, ny); vg_axis(xx, px, W, fr, rr, nx);
+        if (nz && ny && nx) continue;                             // a near sender: the gather has it
+        const AxisTaps az = axis_corners(xz, D), ay = axis_corners(xy, H), ax = axis_corners(xx, W);
+        const int iz[2] = {az.i0, az.i1}, iy[2] = {ay.i0, ay.i1}, ix[2] = {ax.i0, ax.i1};
+        const float wz[2] = {az.w0, az.w1}, wy[2] = {ay.w0, ay.w1}, wx[2] = {ax.w0, ax.w1};
+        const bool oz[2] = {az.ok0 && (unsigned)(az.i0 - d0) < (unsigned)VG_TD, az.ok1 && (unsigned)(az.i1 - d0) < (unsigned)VG_TD};
+        const bool oy[2] = {ay.ok0 && (unsigned)(ay.i0 - h0) < (unsigned)VG_TH, ay.ok1 && (unsigned)(ay.i1 - h0) < (unsigned)VG_TH};
+        const bool ox[2] = {ax.ok0 && (unsigned)(ax.i0 - w0) < (unsigned)VG_TW, ax.ok1 && (unsigned)(ax.i1 - w0) < (unsigned)VG_TW};
+        if (!((oz[0] || oz[1]) && (oy[0] || oy[1]) && (ox[0] || ox[1]))) continue;
+        const float g[3] = {vxm_bload(rgo, p4, 0), vxm_bload(rgo, p4, V4), vxm_bload(rgo, p4, 2 * V4)};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
+            if (!(oz[dz] && oy[dy] && ox[dx])) continue;
+            const int li = ((iz[dz] - d0) * VG_TH + (iy[dy] - h0)) * VG_TW + (ix[dx] - w0);
+            const float wk = (wz[dz] * wy[dy]) * wx[dx];           // the forward's weight of this corner
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned u = __float_as_uint(g[c] * wk);
+                const int ev = (int)(u >> 23) & 255, sh = ev - Eg + 23;     // <= 24: |g wk| <= the step's largest |g| (+ one rounding)
+                if (ev == 0 || sh <= -24) continue;
+                const unsigned long long m = (unsigned long long)((u & 0x7fffffu) | 0x800000u);
+                const unsigned long long mag = sh >= 0 ? m << sh : m >> (-sh);
+                atomicAdd(&acc[c][li], (u >> 31) ? (0ull - mag) : mag);      // two's complement: signed sums wrap correctly
+            }
+        }
+    }
+    __syncthreads();
+    const int tx = tid & 31, ty = (tid >> 5) & 7, dd = tid >> 8;
+    const int h = h0 + ty, w = w0 + tx, d = d0 + dd;
+    if (h >= H || w >= W || d >= D) return;
+    float* gi = gin + (size_t)b * 3 * V + (size_t)d * HW + h * W + w;
+    // 2^(Eg - 173) as a double (exponent field 1023 + Eg - 173)
+    const double unit = __longlong_as_double((long long)(1023 + Eg - 173) << 52);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const long long sacc = (long long)acc[c][tid];
+        if (sacc != 0) gi[(size_t)c * V] += (float)((double)sacc * unit) * scale;
+    }
 }
 
 // adjoint of the trilinear resize as a scatter (gx zeroed by the caller); only used for very large upsampling factors
@@ -692,16 +793,18 @@ int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, floa
     VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_vecint_bwd: too many tiles");
     const dim3 grid_t((unsigned)tiles, B);
     const float scale = 1.0f / (float)(1u << nsteps);
-    // per-step counters of the voxels the gather leaves to the atomic pass live behind the two gradient buffers
+    // per-step statistics of the senders the gather leaves to the far pass live behind the two gradient buffers: {count, largest
+    // displacement, largest |g|} (float bits) per step
     unsigned* far = reinterpret_cast<unsigned*>(work + 2 * n);
-    (void)hipMemsetAsync(far, 0, sizeof(unsigned) * 32, VXM_STREAM(stream));
+    (void)hipMemsetAsync(far, 0, sizeof(unsigned) * VXM_VECINT_WORK_EXTRA, VXM_STREAM(stream));
     const float* g = gout;
     for (int k = nsteps - 1; k >= 0; --k) {
         const float* in = k == 0 ? vec : steps + (size_t)(k - 1) * n;
         float* gn = k == 0 ? gvec : work + (size_t)(k & 1) * n;
         const float sc = k == 0 ? scale : 1.0f;
-        hipLaunchKernelGGL(k_vecint_step_bwd_gather, grid_t, dim3(1024), 0, VXM_STREAM(stream), in, sc, g, gn, far + k, D, H, W);
-        hipLaunchKernelGGL(k_vecint_step_bwd_far, dim3(256), dim3(256), 0, VXM_STREAM(stream), in, sc, g, gn, far + k, B, D, H, W);
+        hipLaunchKernelGGL(k_vecint_step_bwd_gather, grid_t, dim3(1024), 0, VXM_STREAM(stream), in, sc, g, gn, far + 4 * k, D, H, W);
+        hipLaunchKernelGGL(k_vecint_step_bwd_far_tiles, grid_t, dim3(1024), 0, VXM_STREAM(stream), in, sc, g, gn, far + 4 * k, D, H, W);
+        hipLaunchKernelGGL(k_vecint_step_bwd_far, dim3(256), dim3(256), 0, VXM_STREAM(stream), in, sc, g, gn, far + 4 * k, B, D, H, W);
         g = gn;
     }
     return vxm_check_launch("vxm_vecint_bwd");

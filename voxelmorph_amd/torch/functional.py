@@ -136,7 +136,7 @@ class VecIntFn(torch.autograd.Function):
         B, _, D, H, W = vec.shape
         gout = _c(gout)
         gvec = torch.empty_like(vec)
-        work = torch.empty(2 * vec.numel() + 32, dtype=vec.dtype, device=vec.device)     # two gradient buffers + step counters
+        work = torch.empty(2 * vec.numel() + 128, dtype=vec.dtype, device=vec.device)    # two gradient buffers + VXM_VECINT_WORK_EXTRA step statistics
         with _prof.region("vecint_bwd", nbytes=36.0 * B * D * H * W * ctx.nsteps):
             call("vxm_vecint_bwd", ptr(vec), ptr(steps), ptr(gout), ptr(gvec), ptr(work), B, D, H, W, ctx.nsteps, stream())
         return gvec, None
@@ -434,6 +434,28 @@ def s3u_launch(x0, c0, bs0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, B, D, H,
                       nominal=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_conv3d_k3_s3u_fwd", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W,
              s3_pieces(), stream())
+
+
+def s3u_bwd_low_route(c0, cout, B, D, H, W):
+    """does the backward-data of an upsampled segment go to the split kernel (csrc/conv_s3u.hip: k_s3u_dlow)?"""
+    return S3U and split_engine() and bool(_lib.lib().vxm_conv3d_k3_s3u_bwd_low_ok(c0, cout, B, D, H, W, s3_pieces()))
+
+
+def s3u_bwd_low(dz, cout, w, c0, cin, gxl, mask, mask_slope, B, D, H, W):
+    """gxl [B,c0,D/2,H/2,W/2] = LeakyReLU'(mask) * (conv backward + upsample backward of dz [B,cout,D,H,W]) for the first c0 input channels
+    of w [cout][cin][27]; the packed transposed-collapsed operator is cached on the weight tensor"""
+    cache = w.__dict__.setdefault("_vxm_s3_packs", {})
+    key = ("s3u_low", c0, cin, s3_pieces())
+    hit = cache.get(key)
+    if hit is None or hit[0] != _pack_ver(w) or hit[1].device != w.device:
+        nbytes = _lib.lib().vxm_conv3d_k3_s3u_bwd_low_packed_bytes(c0, cout, s3_pieces())
+        wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        call("vxm_conv3d_k3_s3u_bwd_low_pack_weights", ptr(_c(w)), ptr(wp), c0, cin, cout, s3_pieces(), stream())
+        cache[key] = hit = (_pack_ver(w), wp)
+    V = D * H * W
+    with _prof.region("k_s3u_dlow<%d,%d>" % (1 if c0 <= 16 else 2, s3_pieces()), flops=2.0 * 8 * c0 * cout * B * V, nominal=2.0 * 27 * c0 * cout * B * V):
+        call("vxm_conv3d_k3_s3u_bwd_low", ptr(dz), cout * V, cout, ptr(hit[1]), ptr(gxl), c0 * (V // 8), c0, ptr(mask), c0 * (V // 8), float(mask_slope),
+             B, D, H, W, s3_pieces(), stream())
 
 
 def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
@@ -901,18 +923,23 @@ class UnetFn(torch.autograd.Function):
                     continue
                 fuse = (not up0) and s1 is None and (not feeds_inputs) and len(plan.consumers[s0]) == 1 \
                     and plan.ops[plan.producer[s0]]["kind"] == "conv"
-                if up0 and plan.ops[plan.producer[s0]]["kind"] == "conv" and len(plan.consumers[s0]) == 1 and \
-                        _lib.lib().vxm_conv3d_k3_up_bwd_low_ok(ptr(dz), cout * V, c0, cout, B, D, H, W):
+                up_fused = up0 and plan.ops[plan.producer[s0]]["kind"] == "conv" and len(plan.consumers[s0]) == 1
+                if up_fused and (s3u_bwd_low_route(c0, cout, B, D, H, W) or
+                                 _lib.lib().vxm_conv3d_k3_up_bwd_low_ok(ptr(dz), cout * V, c0, cout, B, D, H, W)):
                     # upsampled segment: straight to the half-resolution gradient of the decoder block (stride-2 4x4x4 conv =
-                    # conv backward + upsample_nearest3d_backward + leaky_relu_backward in one kernel, conv_fwd.hip: k_conv3d_k3_dlow)
+                    # conv backward + upsample_nearest3d_backward + leaky_relu_backward in one kernel: conv_s3u.hip k_s3u_dlow on the split
+                    # engine, conv_fwd.hip k_conv3d_k3_dlow otherwise)
                     pslope = plan.ops[plan.producer[s0]]["slope"]
                     lD, lH, lW = D // 2, H // 2, W // 2
                     dzl = torch.empty((B, c0, lD, lH, lW), dtype=dt, device=dev)
-                    wpk = torch.empty(_lib.lib().vxm_conv3d_k3_up_bwd_low_packed_elems(c0, cout), dtype=dt, device=dev)
-                    with _prof.region("k_conv3d_k3_dlow<%d>" % (1 if c0 <= 16 else 2), flops=2.0 * 8 * c0 * cout * B * V,
-                                      nominal=2.0 * 27 * c0 * cout * B * V):
-                        call("vxm_conv3d_k3_up_bwd_low", ptr(dz), cout * V, cout, ptr(_c(w)), c0, cin, ptr(wpk), ptr(dzl), c0 * lD * lH * lW,
-                             ptr(T[s0]) if pslope != 1.0 else None, c0 * lD * lH * lW, float(pslope), B, D, H, W, stream())
+                    if s3u_bwd_low_route(c0, cout, B, D, H, W):
+                        s3u_bwd_low(dz, cout, w, c0, cin, dzl, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W)
+                    else:
+                        wpk = torch.empty(_lib.lib().vxm_conv3d_k3_up_bwd_low_packed_elems(c0, cout), dtype=dt, device=dev)
+                        with _prof.region("k_conv3d_k3_dlow<%d>" % (1 if c0 <= 16 else 2), flops=2.0 * 8 * c0 * cout * B * V,
+                                          nominal=2.0 * 27 * c0 * cout * B * V):
+                            call("vxm_conv3d_k3_up_bwd_low", ptr(dz), cout * V, cout, ptr(_c(w)), c0, cin, ptr(wpk), ptr(dzl), c0 * lD * lH * lW,
+                                 ptr(T[s0]) if pslope != 1.0 else None, c0 * lD * lH * lW, float(pslope), B, D, H, W, stream())
                     DZ[s0] = dzl
                     if s1 is not None:                       # skip segment: regular backward-data of its channels only
                         gxs = torch.empty((B, c1, D, H, W), dtype=dt, device=dev)
