@@ -139,6 +139,55 @@ def test_vecint_vs_oracle(vxm, nsteps):
     np.testing.assert_allclose(N(v.grad), vo.grad.numpy(), atol=2e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("std,nsteps", [(2.0, 4), (6.0, 3), (40.0, 2)])
+def test_vecint_large_displacements_deterministic_vs_oracle(vxm, std, nsteps):
+    """Steps that move voxels by one voxel or more (a trained network's field): the far senders are scattered by the deterministic
+    tile pass (64-bit fixed-point LDS accumulators) -- against the reference's autograd, and bit-identical from run to run.  std 40:
+    displacements beyond the tile pass's radius (24 voxels per step) take the atomic fallback (correct, not bit-reproducible)."""
+    vol = (16, 20, 36)
+    rng = np.random.default_rng(int(std) + nsteps)
+    vec = (rng.standard_normal((2, 3) + vol) * std).astype(np.float32)
+    gout = rng.standard_normal((2, 3) + vol).astype(np.float32)
+    grads = []
+    for _ in range(3):
+        v = G(vec, True)
+        out = vxm.layers.VecInt(vol, nsteps).cuda()(v)
+        out.backward(G(gout))
+        grads.append(v.grad.clone())
+    vo = torch.from_numpy(vec).requires_grad_()
+    ref = orc.vecint(vo, nsteps)
+    ref.backward(torch.from_numpy(gout))
+    np.testing.assert_allclose(N(out), ref.detach().numpy(), atol=1e-4 * max(1.0, std), rtol=0)
+    gate("vecint std %.0f: dL/dvec vs reference autograd" % std, rel_l2(N(grads[0]), vo.grad.numpy()), 2e-5)
+    if std < 30:
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
+def test_full_size_vecint_trained_flow_regime(vxm):
+    """The regime a trained network is in (smooth field, |v| ~ 5 voxels) at the size the metric is quoted on: the
+    half-resolution 80 x 96 x 112 field, 7 steps.  Forward and gradient against the reference's op sequence on the host, and the
+    gradient bit-identical between runs (most voxels of the last steps are far senders)."""
+    vol, nsteps = (80, 96, 112), 7
+    rng = np.random.default_rng(5)
+    low = torch.from_numpy(rng.standard_normal((1, 3, 5, 6, 7)).astype(np.float32))
+    vec = torch.nn.functional.interpolate(low, size=vol, mode="trilinear", align_corners=True)
+    vec = (vec * (5.0 / float(vec.abs().max()))).contiguous()
+    gout = torch.from_numpy(rng.standard_normal((1, 3) + vol).astype(np.float32))
+    grads = []
+    for _ in range(2):
+        v = vec.cuda().requires_grad_()
+        out = vxm.layers.VecInt(vol, nsteps).cuda()(v)
+        out.backward(gout.cuda())
+        grads.append(v.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    vo = vec.clone().requires_grad_()
+    ref = orc.vecint(vo, nsteps)
+    ref.backward(gout)
+    print("integrated field: max |v| %.2f voxels" % float(ref.abs().max()))
+    gate("full-size vecint, 5-voxel field: forward max abs", float((out.detach().cpu() - ref.detach()).abs().max()), 1e-4)
+    gate("full-size vecint, 5-voxel field: dL/dvec vs reference autograd", rel_l2(N(grads[0]), vo.grad.numpy()), 2e-5)
+
+
 def test_resize_golden(vxm, g_layers):
     x = G(g_layers["resize_in"], True)
     down = vxm.layers.ResizeTransform(2, 3)(x)

@@ -49,12 +49,13 @@ def main():
     if args.case in ("zero", "both"):
         cases.append(("near-zero field (std 1e-3)", 1e-3 * torch.randn(B, 3, *shape, device="cuda")))
     if args.case in ("smooth", "both"):
-        cases.append(("smooth field, max |v| %.1f voxels" % float(3.0 * smooth.abs().max()), (3.0 * smooth).contiguous()))
+        for amp in (1.6, 3.0):
+            cases.append(("smooth field, max |v| %.1f voxels" % float(amp * smooth.abs().max()), (amp * smooth).contiguous()))
     for name, vec in cases:
         gout = torch.randn_like(vec)
         steps = torch.empty((n,) + tuple(vec.shape), device="cuda")
         gvec = torch.empty_like(vec)
-        work = torch.zeros(VF.vecint_work_elems(vec.numel()) if hasattr(VF, "vecint_work_elems") else 2 * vec.numel() + 32, device="cuda")
+        work = torch.zeros(VF.vecint_work_elems(vec.numel()), device="cuda")
 
         def fwd():
             call("vxm_vecint_fwd", ptr(vec), ptr(steps), B, D, H, W, n, stream())

@@ -80,6 +80,11 @@ def _vol3(t, what):
                                   "(2-D support is listed as 'next' in DESIGN.md)" % (what, t.dim() - 2))
 
 
+def vecint_work_elems(numel):
+    """floats of scratch vxm_vecint_bwd wants for a [B,3,D,H,W] field of `numel` elements: two gradient buffers + VXM_VECINT_WORK_EXTRA"""
+    return 2 * numel + 128
+
+
 # --------------------------------------------------------------------------- layers
 class WarpFn(torch.autograd.Function):
     """SpatialTransformer.forward (voxelmorph/torch/layers.py:30-48)."""
@@ -136,7 +141,7 @@ class VecIntFn(torch.autograd.Function):
         B, _, D, H, W = vec.shape
         gout = _c(gout)
         gvec = torch.empty_like(vec)
-        work = torch.empty(2 * vec.numel() + 128, dtype=vec.dtype, device=vec.device)    # two gradient buffers + VXM_VECINT_WORK_EXTRA step statistics
+        work = torch.empty(vecint_work_elems(vec.numel()), dtype=vec.dtype, device=vec.device)
         with _prof.region("vecint_bwd", nbytes=36.0 * B * D * H * W * ctx.nsteps):
             call("vxm_vecint_bwd", ptr(vec), ptr(steps), ptr(gout), ptr(gvec), ptr(work), B, D, H, W, ctx.nsteps, stream())
         return gvec, None
