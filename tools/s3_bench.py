@@ -131,6 +131,33 @@ def main():
         print("%-34s %7.1f GFLOP executed | split+collapsed %.3f ms = %6.1f TF-eq | fp32-MFMA collapsed %.3f ms = %6.1f TF | x%.2f | rel-L2 %.2e"
               % (name, gf, t_s3, gf / t_s3, t_nat, gf / t_nat, t_nat / t_s3, diff), flush=True)
         del x0, x1, y_s3, y_nat
+    # backward-data of the upsampled segment onto the low-resolution tensor: k_s3u_dlow against k_conv3d_k3_dlow
+    for name, c0, c1, cout, lvl in (("rem0 dlow 32^ <- 32 s3u", 32, 16, 32, 0), ("dec3 dlow 32^ <- 32 s3u (L1)", 32, 32, 32, 1)):
+        if args.only and args.only not in name:
+            continue
+        D, H, W = (s >> lvl for s in shape)
+        V = D * H * W
+        if not VF.s3u_bwd_low_route(c0, cout, B, D, H, W):
+            continue
+        dz = torch.randn(B, cout, D, H, W, device="cuda")
+        act = torch.randn(B, c0, D // 2, H // 2, W // 2, device="cuda")
+        w = torch.randn(cout, c0 + c1, 3, 3, 3, device="cuda") / (27 * (c0 + c1)) ** 0.5
+        g_s3, g_nat = torch.empty_like(act), torch.empty_like(act)
+        wpk = torch.empty(_lib.lib().vxm_conv3d_k3_up_bwd_low_packed_elems(c0, cout), device="cuda")
+
+        def run_s3():
+            VF.s3u_bwd_low(dz, cout, w, c0, c0 + c1, g_s3, act, 0.2, B, D, H, W)
+
+        def run_nat():
+            VF.call("vxm_conv3d_k3_up_bwd_low", VF.ptr(dz), cout * V, cout, VF.ptr(w), c0, c0 + c1, VF.ptr(wpk), VF.ptr(g_nat), c0 * (V // 8),
+                    VF.ptr(act), c0 * (V // 8), 0.2, B, D, H, W, VF.stream())
+        t_s3, t_nat = timed(run_s3, args.iters), timed(run_nat, args.iters)
+        gf = 2.0 * 8 * c0 * cout * B * V / 1e9
+        diff = float((g_s3.double() - g_nat.double()).norm() / g_nat.double().norm())
+        rows.append(dict(op=name, gflop_executed=gf, s3_ms=t_s3, s3_tflops=gf / t_s3, native_ms=t_nat, native_tflops=gf / t_nat, rel_l2_s3_vs_native=diff))
+        print("%-34s %7.1f GFLOP executed | split %.3f ms = %6.1f TF-eq | fp32-MFMA %.3f ms = %6.1f TF | x%.2f | rel-L2 %.2e"
+              % (name, gf, t_s3, gf / t_s3, t_nat, gf / t_nat, t_nat / t_s3, diff), flush=True)
+        del dz, act, g_s3, g_nat
     # backward-weight of the plain full-resolution tensors: split kernel vs the fp32-MFMA kernels
     for name, c, cout, lvl in (("rem1 bwd-weight 32->16", 32, 16, 0), ("rem2 bwd-weight 16->16", 16, 16, 0), ("rem0-skip bwd-weight 16->32", 16, 32, 0),
                                ("enc1 bwd-weight 16->32 (L1)", 16, 32, 1), ("dec3-skip bwd-weight 32->32 (L1)", 32, 32, 1)):
@@ -153,6 +180,14 @@ def main():
             VF.conv_bwd_weight(ws, x, c, c * V, False, None, 0, 0, dz, cout, gw_n, gb_n, B, D, H, W)
             VF.FP32_ENGINE = keep
         t_s3, t_nat = timed(run_s3, args.iters), timed(run_nat, args.iters)
+        if os.environ.get("VXM_S3_BW_AB"):                 # same-box A/B of the backward-weight pipelines (alternating)
+            ab = {"0": [], "1": []}
+            for _ in range(3):
+                for mode in ("0", "1"):
+                    os.environ["VXM_S3_BW_PIPE"] = mode
+                    ab[mode].append(timed(run_s3, args.iters))
+            os.environ.pop("VXM_S3_BW_PIPE")
+            print("    A/B one-barrier %s ms | two-barrier %s ms" % (" ".join("%.3f" % v for v in ab["0"]), " ".join("%.3f" % v for v in ab["1"])))
         gf = 2.0 * 27 * c * cout * B * V / 1e9
         diff = float((gw_s.double() - gw_n.double()).norm() / gw_n.double().norm())
         rows.append(dict(op=name, gflop=gf, s3_ms=t_s3, s3_tflops=gf / t_s3, native_ms=t_nat, native_tflops=gf / t_nat, rel_l2_s3_vs_native=diff))

@@ -465,7 +465,7 @@ constexpr int SW_EPI_BYTES = (SW_WAVES * 9 + 4) * 256 * 4;    // the epilogue's 
 template <int NP> struct SwCfg {
     static constexpr int ZB = NP == 2 ? 2 : 1;
     static constexpr int TILE_BYTES = NP * (SW_XPIECE + ZB * SW_ZPIECE);
-    static constexpr int TAB_BYTES = NP == 2 ? 256 : 0;       // floats: [0..5] ring planes, [6..7] dZ buffers, [8..31] wave maxima (two sets of 12)
+    static constexpr int TAB_BYTES = NP == 2 ? 256 : 0;       // floats: [0..5] ring planes, [6..7] dZ buffers, [8..43] wave maxima (three slots of 12)
     static constexpr int LDS_BYTES = (TILE_BYTES + TAB_BYTES > SW_EPI_BYTES ? TILE_BYTES + TAB_BYTES : SW_EPI_BYTES);
 };
 
@@ -479,7 +479,7 @@ __device__ __forceinline__ u32x2 s3_tr_read(const char* lds_base, int byte_off) 
 struct SwTasks { int ncol, nseg, seg_len, nd, nh, nw; };       // tasks = (column (b, th, tw), depth segment), seg_len tiles each
 
 // x: [B][C][D][H][W] fp32 (batch stride x_bs), dz: [B][Cdz][D][H][W] fp32; grid = NBLK x NCOMBO, combo = (16-channel chunk q of x, 16-channel tile of dz)
-template <int NP>
+template <int NP, bool PIPE2 = true>
 __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __restrict__ x, long long x_bs, int C, const float* __restrict__ dz,
                                                               long long dz_bs, int Cdz, float* __restrict__ part, int D, int H, int W, int NBLK,
                                                               int NCO, SwTasks tk) {
@@ -532,11 +532,15 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
     const int s_i = s_role == 1 ? tid : tid - 7 * 64;                                    // X: slot of the plane pair (>= 2 NXS: idle lane); dZ: slot of the tile
     const int x_pl = s_i >= NXS ? 1 : 0, x_r = s_i - x_pl * NXS;                         // X role: plane of the pair, slot inside the plane
     const int z_ds = wave >= 9 ? 1 : 0;                                                  // dZ role: depth slice of the tile (wave-uniform)
-    float ra[8], rb[8];                                          // first / second voxel of the pair, 8 channels
+    // raw loads in flight: first / second voxel of the pair, 8 channels.  NP = 3: one set (the tile after the one being multiplied).
+    // NP = 2: TWO sets -- the scale of a tile is the block's maximum over it, which must be published one barrier before the tile is
+    // split; so a tile is requested two phases ahead and split one phase ahead (set = tile parity), and a phase needs ONE barrier.
+    constexpr int NSET = NP == 2 ? 2 : 1;
+    float ra[NSET][8], rb[NSET][8];
     unsigned ka[NP][4], kb[NP][4];
     int off0 = VXM_OOB, ldst = 0;                                // per task: byte offset inside a depth slice; LDS byte offset of the first voxel's word inside
                                                                  // a plane / the dZ tile, | 1: drop the first voxel, | 2: drop the second
-    int vk;                                                      // the offset the in-flight loads were issued with (kept live until the MFMA phase is over)
+    int vk[NSET];                                                // the offsets the in-flight loads were issued with (kept live until the MFMA phase is over)
 
     for (int task = k_lo; task < k_hi; ++task) {
         const int col = task / tk.nseg, seg = task - col * tk.nseg;
@@ -544,8 +548,10 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
         const int th = cq % tk.nh; const int b = cq / tk.nh;
         const int td0 = seg * tk.seg_len, ntile = min(tk.seg_len, tk.nd - td0);
         const int dbase = td0 * SW_TD, h0 = th * SW_TH, w0 = tw * SW_TW;
-        const __amdgpu_buffer_rsrc_t rx = vxm_rsrc(x + (size_t)b * x_bs, (unsigned)C * (unsigned)V * 4u);
-        const __amdgpu_buffer_rsrc_t rz = vxm_rsrc(dz + (size_t)b * dz_bs, (unsigned)Cdz * (unsigned)V * 4u);
+        // ONE descriptor per wave, chosen by its (wave-uniform) staging role here, on scalars: selecting between two descriptors inside the
+        // load lambda made the compiler keep both in scratch memory and pick one through a pointer + a waterfall loop (seen in the ISA)
+        const bool xrole = s_role != 2;
+        const __amdgpu_buffer_rsrc_t rd = vxm_rsrc(xrole ? x + (size_t)b * x_bs : dz + (size_t)b * dz_bs, (unsigned)(xrole ? C : Cdz) * (unsigned)V * 4u);
         if (s_role == 1) {
             const int cb = x_r & 1, pr = x_r >> 1, hh = pr / SW_XPAIRS, pp = pr - hh * SW_XPAIRS;
             const int gh = h0 - 1 + hh, gw = w0 - 2 + 2 * pp;
@@ -562,38 +568,38 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
         // planes p0, p0 + 1 of this task (plane p = global depth dbase - 1 + p) and the dZ tile tz (tz < 0: none) -> registers.  Branch-free:
         // a plane outside the volume ORs the out-of-range bit into the lane offsets (selects on wave-uniform conditions would become
         // branches around the loads, and the joins behind them make the compiler wait for the prefetch at the START of the MFMA phase)
-        auto load_tile = [&](int p0, int tz) __attribute__((always_inline)) {
+        auto load_tile = [&](auto set_, int p0, int tz) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value;
             const int gd0 = dbase - 1 + p0, gd1 = gd0 + 1;           // wave-uniform
             int o0 = (unsigned)gd0 < (unsigned)D ? (gd0 * HW) << 2 : 0, f0 = (unsigned)gd0 < (unsigned)D ? 0 : VXM_OOB;
             int o1 = (unsigned)gd1 < (unsigned)D ? (gd1 * HW) << 2 : 0, f1 = (unsigned)gd1 < (unsigned)D ? 0 : VXM_OOB;
             const int gz = dbase + (tz < 0 ? 0 : tz) * SW_TD;         // first depth slice of the dZ tile (always < D)
             int fz = tz < 0 ? VXM_OOB : 0, fz1 = (tz < 0 || gz + 1 >= D) ? VXM_OOB : 0;
             asm volatile("" : "+v"(f0), "+v"(f1), "+v"(fz), "+v"(fz1));
-            const bool xrole = s_role != 2;                           // wave-uniform
-            vk = xrole ? ((off0 + (x_pl ? o1 : o0)) | (x_pl ? f1 : f0)) : (off0 | (z_ds ? fz1 : fz));
-            const __amdgpu_buffer_rsrc_t rd = xrole ? rx : rz;
+            vk[S] = xrole ? ((off0 + (x_pl ? o1 : o0)) | (x_pl ? f1 : f0)) : (off0 | (z_ds ? fz1 : fz));
             const int sb = xrole ? 0 : (gz * HW) << 2;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, vk, sb + ((e * V) << 2), 0));
-                ra[e] = t2.x; rb[e] = t2.y;
+                const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, vk[S], sb + ((e * V) << 2), 0));
+                ra[S][e] = t2.x; rb[S][e] = t2.y;
             }
         };
-        // NP = 2: the largest magnitude this wave loaded for the tile in flight -> Tab[8 + 12 set + wave]; after the next barrier every thread
+        // NP = 2: the largest magnitude this wave loaded for a tile -> Tab[8 + 12 slot + wave]; after the next barrier every thread
         // takes the maximum over the X waves (0 .. 6) resp. the dZ waves (7 .. 10) and derives the scale of the plane pair / the dZ tile
-        auto publish_max = [&](int set) __attribute__((always_inline)) {
+        auto publish_max = [&](auto set_, int slot) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value;
             if constexpr (NP == 2) {
                 float m = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[e]), __builtin_fabsf(rb[e])));
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[S][e]), __builtin_fabsf(rb[S][e])));
                 m = s3_wave_max(m);
-                if (lane == 0) Tab[8 + 12 * set + wave] = m;
+                if (lane == 0) Tab[8 + 12 * slot + wave] = m;
             }
         };
         float sc_role = 1.0f;                                    // NP = 2: scale of what this thread staged (X pair of planes, or the dZ tile)
-        auto take_scales = [&](int set, int p0, int zbuf) __attribute__((always_inline)) {
+        auto take_scales = [&](int slot, int p0, int zbuf) __attribute__((always_inline)) {
             if constexpr (NP == 2) {
-                const f32x4* const t4 = reinterpret_cast<const f32x4*>(Tab + 8 + 12 * set);
+                const f32x4* const t4 = reinterpret_cast<const f32x4*>(Tab + 8 + 12 * slot);
                 const f32x4 m0 = t4[0], m1 = t4[1], m2 = t4[2];
                 const float mxx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), m1.z));
                 const float mxz = fmaxf(fmaxf(m1.w, m2.x), fmaxf(m2.y, m2.z));
@@ -606,15 +612,16 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
             }
         };
         // split (registers only) and write (LDS) are separate steps: a wave splits the tile it prefetched right after ITS OWN MFMA loop
-        auto split_tile = [&]() __attribute__((always_inline)) {
+        auto split_tile = [&](auto set_) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if constexpr (NP == 3) {
-                    s3_split2(ra[2 * e], ra[2 * e + 1], ka[0][e], ka[1][e], ka[2][e]);
-                    s3_split2(rb[2 * e], rb[2 * e + 1], kb[0][e], kb[1][e], kb[2][e]);
+                    s3_split2(ra[S][2 * e], ra[S][2 * e + 1], ka[0][e], ka[1][e], ka[2][e]);
+                    s3_split2(rb[S][2 * e], rb[S][2 * e + 1], kb[0][e], kb[1][e], kb[2][e]);
                 } else {
-                    s3_split2_f16(ra[2 * e], ra[2 * e + 1], sc_role, ka[0][e], ka[1][e]);
-                    s3_split2_f16(rb[2 * e], rb[2 * e + 1], sc_role, kb[0][e], kb[1][e]);
+                    s3_split2_f16(ra[S][2 * e], ra[S][2 * e + 1], sc_role, ka[0][e], ka[1][e]);
+                    s3_split2_f16(rb[S][2 * e], rb[S][2 * e + 1], sc_role, kb[0][e], kb[1][e]);
                 }
             }
         };
@@ -622,7 +629,8 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
         // MFMA loop and overlap the MFMAs of the waves still computing (waves 0 .. 6 stage X and are the first to finish: the matrix pipe of
         // a SIMD serves its oldest wave first).  The dZ tile is single-buffered and is written between the two barriers.  Measured with
         // s_memtime stamps: the phase between the barriers 1620 -> 430 cycles of ~11.7 k per tile, 2.50 -> 2.44 M cycles per launch on rem1.
-        // (NP = 2: the split needs the block's scale, so split and both writes sit between the barriers; the dZ tile is double-buffered.)
+        // (NP = 2: the dZ tile is double-buffered too, so both writes go to free space and the phase has ONE barrier; the block's scale the
+        // split needs was published one phase earlier -- see the raw sets above.)
         auto write_x = [&](int p0) __attribute__((always_inline)) {
             if (s_role == 1) {
                 if (s_i < 2 * NXS) {
@@ -648,56 +656,46 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
             }
         };
 
-        __syncthreads();                                        // every wave is done with the previous task
-        load_tile(0, 0);
-        if constexpr (NP == 2) { publish_max(0); __syncthreads(); take_scales(0, 0, 0); }
-        split_tile();
-        write_x(0);
-        write_z(0);
-        load_tile(2, -1);
-        if constexpr (NP == 2) { publish_max(1); __syncthreads(); take_scales(1, 2, -1); }
-        split_tile();
-        write_x(2);
-        __syncthreads();
-
-        for (int t = 0; t < ntile; ++t) {
-            const bool more = t + 1 < ntile;                     // wave-uniform
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, NP == 2 ? 1 : 0>;
+        // the MFMA phase of tile t: this wave's chains, folded into the running totals
+        auto mfma_tile = [&](int t) __attribute__((always_inline)) {
             const char* const xp = Xs + ((2 * t + ds + kd) % SW_RING) * SW_PLANE;
             const int zcur = NP == 2 ? (t & 1) : 0;              // dZ buffer of this tile
             float unscale_x = 1.0f, unscale_z = 1.0f;
             if constexpr (NP == 2) { unscale_x = Tab[(2 * t + ds + kd) % SW_RING]; unscale_z = Tab[6 + zcur]; }
-            // the raw loads of tile t + 1 (2 X planes + the dZ tile) are in flight under the MFMAs of tile t; unconditional: past
-            // the last tile the planes lie beyond this task's depth range and are simply not stored
-            load_tile(2 * t + 4, more ? t + 1 : t);
-            __builtin_amdgcn_sched_barrier(0);
             // The fp32 accumulation of the bf16 MFMA TRUNCATES (tools/bw_accuracy.py: a chain of ~10^4 MFMAs into one accumulator drifts,
             // 1.5e-5 against 4e-6 for the fp32 MFMA on cancelling sums).  So an MFMA chain lives for ONE tile -- it starts from zero and is
             // at most 12 links long -- and is then added to the running totals by the vector ALU (round to nearest, unbiased).
             u32x4 az[2][NP];                                     // dZ fragment sets (NP pieces) of this wave's two output rows
-            f32x4 acc[3][3], accb = {0.f, 0.f, 0.f, 0.f};
+            f32x4 accb = {0.f, 0.f, 0.f, 0.f};
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-            for (int hl = 0; hl < 4; ++hl) {                     // haloed rows 2 rh + hl serve output rows 2 rh + hl - kh
-                const int hr = 2 * rh + hl;                      // wave-uniform
-                // a wave's priority falls as it advances through the tile: the three waves of a SIMD then progress evenly instead of oldest
-                // first and share the matrix pipe to the end of the phase -- a lone last wave cannot keep it busy (s_memtime stamps: the
-                // waves finished at 3.5 k, 5.7 k and 7.7 k cycles of a tile whose MFMAs need 5.5 k).  -2 .. -3 % on the three big launches;
-                // the same in k_s3_conv (two blocks per CU: four waves per SIMD from two phases) changed nothing and is not there.
-                if (hl == 0) __builtin_amdgcn_s_setprio(3); else if (hl == 1) __builtin_amdgcn_s_setprio(2); else if (hl == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-                if (hl < 2) {
+            for (int hl = 0; hl < 2; ++hl) {
 #pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        const int zb = (zcur * NP + p) * SW_ZPIECE + ((ds * SW_TH + hr) * SW_TW) * 32 + lp;
-                        const u32x2 lo = s3_tr_read(Zs, zb), hi = s3_tr_read(Zs, zb + 16 * 32);
-                        az[hl][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
-                    }
-                    if (kd == 0) {                               // wave-uniform: bias gradient = sum of the pieces against ones
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) accb = P::mfma(az[hl][p], ones, accb);
-                    }
+                for (int p = 0; p < NP; ++p) {
+                    const int zb = (zcur * NP + p) * SW_ZPIECE + ((ds * SW_TH + 2 * rh + hl) * SW_TW) * 32 + lp;
+                    const u32x2 lo = s3_tr_read(Zs, zb), hi = s3_tr_read(Zs, zb + 16 * 32);
+                    az[hl][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
                 }
+                if (kd == 0) {                                   // wave-uniform: bias gradient = sum of the pieces against ones
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {                 // one kw-shifted B fragment set at a time (12 instead of 36 registers)
+                    for (int p = 0; p < NP; ++p) accb = P::mfma(az[hl][p], ones, accb);
+                }
+            }
+            // kw outermost: the three kh chains of one kw are alive at a time (12 accumulator registers instead of 36 -- the second raw set of
+            // the NP = 2 pipeline needs the room); every (haloed row, kw) B fragment set is still read exactly once
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                // a wave's priority falls as it advances through the tile: the three waves of a SIMD then progress evenly instead of oldest
+                // first and share the matrix pipe to the end of the phase -- a lone last wave cannot keep it busy (s_memtime stamps, round 3:
+                // the waves finished at 3.5 k, 5.7 k and 7.7 k cycles of a tile whose MFMAs need 5.5 k; -2 .. -3 % on the three big launches)
+                if (kw == 1) __builtin_amdgcn_s_setprio(2); else if (kw == 2) __builtin_amdgcn_s_setprio(1);
+                f32x4 acc[3];
+#pragma unroll
+                for (int hl = 0; hl < 4; ++hl) {                 // haloed rows 2 rh + hl serve output rows 2 rh + hl - kh
+                    const int hr = 2 * rh + hl;                  // wave-uniform
                     u32x4 bxf[NP];
 #pragma unroll
                     for (int p = 0; p < NP; ++p) {
@@ -711,47 +709,127 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
                         for (int kh = 0; kh < 3; ++kh) {
                             const int rl = hl - kh;              // local output row
                             if (rl >= 0 && rl < 2)               // the first link of a tile's chain (output row 0, first product) starts from zero
-                                acc[kh][kw] = P::mfma(az[rl][P::PA[tp]], bxf[P::PB[tp]], (rl == 0 && tp == 0) ? zero4 : acc[kh][kw]);
+                                acc[kh] = P::mfma(az[rl][P::PA[tp]], bxf[P::PB[tp]], (rl == 0 && tp == 0) ? zero4 : acc[kh]);
                         }
+                }
+                if constexpr (NP == 3) {
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh) tot[kh][kw] += acc[kh];
+                } else {                                         // the chain carries the scales of its X plane and its dZ tile: undone here (exact)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tot[kh][kw][j] = __builtin_fmaf(acc[kh][j] * unscale_x, unscale_z, tot[kh][kw][j]);
                 }
             }
             if constexpr (NP == 3) {
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) tot[kh][kw] += acc[kh][kw];
                 totb += accb;
-            } else {                                             // the chain carries the scales of its X plane and its dZ tile: undone here (exact)
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) tot[kh][kw][j] = __builtin_fmaf(acc[kh][kw][j] * unscale_x, unscale_z, tot[kh][kw][j]);
+            } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) totb[j] = __builtin_fmaf(accb[j], unscale_z, totb[j]);
             }
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            // the address registers of the loads in flight stay live until here: reused earlier, the compiler guards every reuse
-            // with s_waitcnt vmcnt(..), i.e. waits for the prefetch at the start of the MFMA phase (seen in the ISA)
-            asm volatile("" ::"v"(vk));
-            if constexpr (NP == 3) {
-                split_tile();                                    // before the barrier: overlaps the other waves' MFMAs
+        };
+
+        __syncthreads();                                        // every wave is done with the previous task
+        if constexpr (NP == 3) {
+            load_tile(I0{}, 0, 0);
+            split_tile(I0{});
+            write_x(0);
+            write_z(0);
+            load_tile(I0{}, 2, -1);
+            split_tile(I0{});
+            write_x(2);
+            __syncthreads();
+            for (int t = 0; t < ntile; ++t) {
+                const bool more = t + 1 < ntile;                 // wave-uniform
+                // the raw loads of tile t + 1 (2 X planes + the dZ tile) are in flight under the MFMAs of tile t; unconditional: past
+                // the last tile the planes lie beyond this task's depth range and are simply not stored
+                load_tile(I0{}, 2 * t + 4, more ? t + 1 : t);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(t);
+                // the address registers of the loads in flight stay live until here: reused earlier, the compiler guards every reuse
+                // with s_waitcnt vmcnt(..), i.e. waits for the prefetch at the start of the MFMA phase (seen in the ISA)
+                asm volatile("" ::"v"(vk[0]));
+                split_tile(I0{});                                // before the barrier: overlaps the other waves' MFMAs
                 if (more) write_x(2 * t + 4);
                 __syncthreads();                                 // every wave is done reading tile t (X ring slots of t - 1 and the dZ tile are free)
                 if (more) write_z(0);
                 __syncthreads();
-            } else {
-                publish_max(0);
-                __syncthreads();                                 // every wave is done reading tile t; the maxima of tile t + 1 are published
+            }
+        } else if constexpr (!PIPE2) {
+            // ---- NP = 2, the first version (kept for same-box A/B, VXM_S3_BW_PIPE=1): one tile ahead, the maxima published before a first
+            // barrier, split + writes between it and a second one
+            load_tile(I0{}, 0, 0);
+            publish_max(I0{}, 0);
+            __syncthreads();
+            take_scales(0, 0, 0);
+            split_tile(I0{});
+            write_x(0);
+            write_z(0);
+            load_tile(I0{}, 2, -1);
+            publish_max(I0{}, 2);
+            __syncthreads();
+            take_scales(2, 2, -1);
+            split_tile(I0{});
+            write_x(2);
+            __syncthreads();
+            for (int t = 0; t < ntile; ++t) {
+                const bool more = t + 1 < ntile;
+                load_tile(I0{}, 2 * t + 4, more ? t + 1 : t);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(t);
+                asm volatile("" ::"v"(vk[0]));
+                publish_max(I0{}, 0);
+                __syncthreads();
                 if (more) {
-                    take_scales(0, 2 * t + 4, zcur ^ 1);
-                    split_tile();
+                    take_scales(0, 2 * t + 4, (t & 1) ^ 1);
+                    split_tile(I0{});
                     write_x(2 * t + 4);
-                    write_z(zcur ^ 1);
+                    write_z((t & 1) ^ 1);
                 }
                 __syncthreads();
+            }
+        } else {
+            // ---- NP = 2.  Tile tau (tau >= 1) = planes 2 tau + 2, 2 tau + 3 and dZ tile tau; its raw loads live in set tau & 1, its maxima in
+            // table slot tau & 1 (tile 0's second plane pair: slot 2).  Phase t: request tile t + 2, multiply tile t, split + write tile
+            // t + 1 (scale from the maxima published during phase t - 1), publish the maxima of tile t + 2, ONE barrier.
+            load_tile(I0{}, 0, 0);
+            load_tile(I1{}, 2, -1);
+            publish_max(I0{}, 0);
+            publish_max(I1{}, 2);
+            __syncthreads();
+            take_scales(0, 0, 0);
+            split_tile(I0{});
+            write_x(0);
+            write_z(0);
+            take_scales(2, 2, -1);
+            split_tile(I1{});
+            write_x(2);
+            load_tile(I1{}, 4, ntile > 1 ? 1 : -1);              // tile 1
+            publish_max(I1{}, 1);
+            __syncthreads();
+            auto phase = [&](auto par_, int t) __attribute__((always_inline)) {
+                constexpr int PAR = decltype(par_)::value;       // = t & 1: tile t + 2 goes to set PAR, tile t + 1 sits in set PAR ^ 1
+                using SN = std::integral_constant<int, PAR>;
+                using SC = std::integral_constant<int, PAR ^ 1>;
+                load_tile(SN{}, 2 * t + 6, t + 2 < ntile ? t + 2 : -1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_tile(t);
+                asm volatile("" ::"v"(vk[PAR]));
+                if (t + 1 < ntile) {                              // wave-uniform
+                    take_scales((t + 1) & 1, 2 * t + 4, (t + 1) & 1);
+                    split_tile(SC{});
+                    write_x(2 * t + 4);
+                    write_z((t + 1) & 1);
+                }
+                publish_max(SN{}, t & 1);
+                __syncthreads();                                  // tile t is read, tile t + 1 is written, the maxima of tile t + 2 are published
+            };
+            for (int t = 0; t < ntile; t += 2) {
+                phase(I0{}, t);
+                if (t + 1 < ntile) phase(I1{}, t + 1);
             }
         }
     }
@@ -1038,18 +1116,23 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
     VXM_REQUIRE(work_bytes >= (size_t)NBLK * Q * SW_NSL * 28 * (16 * NCO) * 16 * sizeof(float), VXM_ERR_WORKSPACE,
                 "vxm_conv3d_k3_s3_bwd_weight: workspace too small");
     static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight<3>), hipFuncAttributeMaxDynamicSharedMemorySize, SwCfg<3>::LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SwCfg<2>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SwCfg<3>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SwCfg<2>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SwCfg<2>::LDS_BYTES);
         return true;
     }();
     (void)attr;
     hipStream_t s = VXM_STREAM(stream);
     float* part = static_cast<float*>(work);
-    if (pieces == 2)
-        hipLaunchKernelGGL(k_s3_bwd_weight<2>, dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
+    const char* pe = getenv("VXM_S3_BW_PIPE");                  // developer A/B switch: 1 = the two-barrier pipeline of the first fp16 version
+    if (pieces == 2 && pe && pe[0] == '1')
+        hipLaunchKernelGGL((k_s3_bwd_weight<2, false>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
+                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk);
+    else if (pieces == 2)
+        hipLaunchKernelGGL((k_s3_bwd_weight<2, true>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
                            (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk);
     else
-        hipLaunchKernelGGL(k_s3_bwd_weight<3>, dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<3>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
+        hipLaunchKernelGGL((k_s3_bwd_weight<3, true>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<3>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
                            (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk);
     const int n = 16 * NCO * 16 * Q * 28;
     hipLaunchKernelGGL(k_s3_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(1024), 0, s, part, gw, gb, C, Cout, gw_cin, ci_off, Q, NCO, NBLK);

@@ -2,6 +2,7 @@
 // matrix pipe, which piece products are accumulated, and the power-of-two scaling of the fp16 scheme.
 #ifndef VXM_S3_PIECES_H
 #define VXM_S3_PIECES_H
+#include <type_traits>
 #include "conv_common.h"
 
 namespace {
@@ -61,10 +62,21 @@ __device__ __forceinline__ void s3_scale_of(float mx, float& s, float& inv) {
     s = __uint_as_float((unsigned)(268 - E) << 23);
     inv = __uint_as_float((unsigned)(E - 14) << 23);
 }
+// maximum of a NON-NEGATIVE value over the wave, returned in every lane.  Four DPP steps fold each row of 16 lanes (quad permutes, then
+// row_half_mirror / row_mirror), three readlanes fetch the other rows' results: ~10 vector / scalar instructions.  (The first version
+// used six __shfl_xor steps = six dependent ds_bpermute round trips, on the critical path between a stage's last MFMA and its barrier.)
 __device__ __forceinline__ float s3_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    auto dpp = [](float x, auto ctrl) __attribute__((always_inline)) {
+        return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0xB1>{}));        // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x4E>{}));        // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x141>{}));       // row_half_mirror
+    v = fmaxf(v, dpp(v, std::integral_constant<int, 0x140>{}));       // row_mirror: every lane of a row holds the row's maximum
+    const int b = (int)__float_as_uint(v);
+    const float r0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 0)), r1 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 32)), r3 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 // piece scheme NP: 3 = bf16 (h, m, l), six products; 2 = fp16 (h, l), three products.  PA / PB: piece of the A / B operand of product t,
 // small terms first.
