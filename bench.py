@@ -114,8 +114,13 @@ def hbm_traffic(kernel, launches_per_step, suffix=""):
     """HBM bytes per launch of the region `kernel` from the committed rocprofv3 PMC summary of this same command
     (profiles/*_hbm_counters.json, written by tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes,
     kernel-trace only).  Units and gfx950 correction as /opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes: both
-    counters are in KiB; FETCH_SIZE tallies the 128-byte requests of wide coalesced reads at 64 bytes, so the read side is
-    doubled.  A region label names a kernel family ("k<1>"); its template instances ("k<1, 2, 32>", "k<1, 4, 16>") are
+    counters are in KiB; FETCH_SIZE tallies the 128-byte requests of coalesced reads at 64 bytes, so the read side is
+    multiplied by FETCH_FACTOR.  Calibrated in round 4 (tools/probe/fetch_size_probe.hip under rocprofv3,
+    profiles/r04j_fetch_size_probe.json): a streaming read of exactly 1 GiB reports 524,299 KiB at 4, 8 AND 16 bytes per lane and
+    for the 18-voxel haloed-row pattern the conv kernels stage with -- the factor is 2.00 whatever the load width (WRITE_SIZE of a
+    1 GiB fill: 1,048,576 KiB, factor 1).  The per-voxel GATHER kernels (VecInt, warp) issue 32 / 64-byte requests that the counter
+    tallies in full: their FETCH_SIZE equals their input size (31.1 MB for a 31.0 MB field, profiles/r03u_hbm_counters.json), so they
+    take factor 1.  A region label names a kernel family ("k<1>"); its template instances ("k<1, 2, 32>", "k<1, 4, 16>") are
     averaged weighted by their dispatch counts.  The file is REFUSED (traffic null, reason in the note) when it does not
     describe this run: no instance of the kernel in it, or a dispatch count that is not launches_per_step x the profiled
     steps recorded in its "_meta" entry.  Returns (bytes_per_launch or None, note)."""
@@ -143,9 +148,38 @@ def hbm_traffic(kernel, launches_per_step, suffix=""):
     if steps and abs(n - launches_per_step * steps) > 0.5:
         return None, "%s: %d dispatches of %s in %d profiled steps, this run launches %.1f per step: stale profile" % (
             rel, n, kernel, steps, launches_per_step)
-    tot = sum((2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * v["FETCH_SIZE"]["dispatches"] for v in hits.values())
-    return tot / n * 1024.0, "bytes/launch (2*FETCH_SIZE + WRITE_SIZE, KiB counters; rocprofv3 --pmc of this command: %s; instances %s)" % (
-        rel, ", ".join(sorted(hits)))
+    ff = fetch_factor(kernel)
+    tot = sum((ff * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * v["FETCH_SIZE"]["dispatches"] for v in hits.values())
+    return tot / n * 1024.0, "bytes/launch (%g*FETCH_SIZE + WRITE_SIZE, KiB counters; rocprofv3 --pmc of this command: %s; instances %s)" % (
+        ff, rel, ", ".join(sorted(hits)))
+
+
+def fetch_factor(kernel):
+    """FETCH_SIZE -> bytes: 2 for kernels that stream coalesced lines, 1 for the per-voxel gather kernels (see hbm_traffic)"""
+    return 1.0 if kernel.startswith(("vecint", "warp3d", "k_vecint", "k_warp3d")) else 2.0
+
+
+def shader_clock(kernel, suffix=""):
+    """Shader clock the kernel ran at under the profiler (GHz): GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same --pmc pass, written
+    by tools/rocprof_summary.py into profiles/*_mfma_counters.json (same staleness rule as hbm_traffic: the kernel sources must match)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_counters%s.json" % suffix)))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            ctr = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if (ctr.get("_meta") or {}).get("csrc_sha") != csrc_sha():
+        return None
+    kernel_ns = kernel.replace(" ", "")
+    stem = kernel_ns[:-1] if kernel_ns.endswith(">") else kernel_ns
+    hits = [v for k, v in ctr.items() if k != "_meta" and (k.replace(" ", "") == kernel_ns or k.replace(" ", "").startswith(stem + ","))]
+    hits = [v for v in hits if "shader_clock_ghz" in v]
+    if not hits:
+        return None
+    return sum(v["shader_clock_ghz"] for v in hits) / len(hits)
 
 
 def binding_roofline(name, st):
@@ -216,6 +250,8 @@ class Workload:
         self.bf16 = name in ("dense_bf16", "diffeo_bf16")
         self.dense = name == "dense_bf16"
         self.semi = name == "semisup_fp32"
+        self.trained = name == "diffeo_fp32_trained_flow"
+        self.flow_note = ""
         self.int_steps = (0 if self.dense else 7) if int_steps is None else int_steps
         self.lam = 0.01 if self.dense else 1.0                    # README.md:70: lambda 0.01 with MSE, 1 with NCC
         torch.manual_seed(1234)                                   # identical initial weights on every rank
@@ -238,6 +274,27 @@ class Workload:
         self.reg = vxm.losses.Grad("l2", loss_mult=2).loss
         from voxelmorph_amd.pacing import InFlight
         self.pace = InFlight(2)
+        if self.trained:
+            self._make_trained_flow()
+
+    def _make_trained_flow(self):
+        """The regime a TRAINED network is in (smooth field, |v| ~ 5 voxels): the random-init flow head predicts
+        ~1e-5 voxels, so every gather kernel of the headline step sees a zero field.  Here the flow head gets a bias (a 5 / 3 / 4-voxel
+        translation on the half-resolution integration grid) and weights rescaled until the spatially varying part has a standard
+        deviation of 0.25 half-resolution voxels: in the last scaling-and-squaring steps every voxel moves by more than one voxel."""
+        m = self.model
+        with torch.no_grad():
+            _, _, vel, disp, _ = m._forward_all(self.src, self.trg)
+            std = float((vel - vel.mean(dim=(2, 3, 4), keepdim=True)).std())
+            m.flow.weight.mul_(0.25 / max(std, 1e-30))
+            m.flow.bias.copy_(torch.tensor([10.0, -6.0, 8.0], device=m.flow.bias.device))       # full-resolution voxels: halved by the resize
+            from voxelmorph_amd import invalidate_packs
+            invalidate_packs(m)
+            _, _, vel, disp, _ = m._forward_all(self.src, self.trg)
+            self.flow_note = ("flow head rescaled: velocity on the half-resolution grid mean (%.2f, %.2f, %.2f), std of the varying part %.3f, "
+                              "integrated displacement max %.2f full-resolution voxels"
+                              % (*[float(v) for v in vel.mean(dim=(0, 2, 3, 4))], float((vel - vel.mean(dim=(2, 3, 4), keepdim=True)).std()),
+                                 float(disp.abs().max())))
 
     def step(self):
         # At most two steps in flight (voxelmorph_amd/pacing.py): the host waits for the end of step k - 2 before it enqueues step k.  The GPU never starves (two
@@ -270,6 +327,9 @@ class Workload:
         if self.semi:
             return ("VxmDenseSemiSupervisedSeg 3D %s, int_steps=%d, 30 one-hot labels at half resolution, NCC(9^3)+Grad(l2,x2)+0.01 Dice, "
                     "fp32, Adam lr 1e-4, %d pair(s)/GPU (BASELINE.json configs[4], per-GPU step)" % (sh, self.int_steps, self.B))
+        if getattr(self, "trained", False):
+            return ("VxmDense 3D %s, int_steps=%d diffeomorphic (int_downsize=2), NCC(9^3)+Grad(l2,x2), fp32, Adam lr 1e-4, %d pair(s)/GPU; the "
+                    "headline step with the field of a TRAINED network (SURVEY section 8d): %s" % (sh, self.int_steps, self.B, self.flow_note))
         return ("VxmDense 3D %s, int_steps=%d diffeomorphic (int_downsize=2), NCC(9^3)+Grad(l2,x2), fp32, Adam lr 1e-4, %d pair(s)/GPU "
                 "(BASELINE.json configs[2])" % (sh, self.int_steps, self.B))
 
@@ -296,7 +356,31 @@ def timed_steps(wl, steps, vdist, dev, timer=None):
     return elapsed, float(loss.detach())
 
 
-def kernel_table(stats, steps):
+# Vector-ALU issue roofline of the fused NCC march (csrc/losses.hip k_ncc_fused_fwd/bwd<4>): NOT an HBM kernel, although SURVEY.md section 8d
+# lists it as one -- its 55 / 83 MB of algorithmic traffic would take 7 / 10 us, its arithmetic (direct 9-tap box sums of five products in
+# three directions, no running sums: fp32 accuracy) takes ten times that.  Wave-instructions per (block, slice) counted in the gfx950 ISA of
+# this tree (static count of the march's body + its two inner loops at 3 and 2 trips): forward 4 waves x 417 = 1668 VALU (+ 376 LDS),
+# backward 4 x 248 = 992 (+ 212 LDS); a wave-instruction occupies its SIMD for 4 cycles (the model that matched the VecInt gather within
+# 25 %); 1024 SIMDs at 2.4 GHz.  (block, slice) pairs of a launch: columns of 8 x 32 pixels x depth segments x
+# (segment + 8 halo slices), csrc/losses.hip ncc_segment.
+NCC_VALU_PER_BLOCK_SLICE = {"ncc_fwd": 1668.0, "ncc_bwd": 992.0}
+
+
+def ncc_valu_roofline(name, st, shape, B):
+    D, H, W = shape
+    cols = ((W + 31) // 32) * ((H + 7) // 8) * B
+    seg = 40
+    while seg > 20 and cols * ((D + seg - 1) // seg) < 1024:
+        seg = (seg + 1) // 2
+    block_slices = cols * ((D + seg - 1) // seg) * (seg + 8)
+    instr = NCC_VALU_PER_BLOCK_SLICE[name] * block_slices
+    min_ms = instr * 4.0 / 1024.0 / 2.4e9 * 1e3
+    ms = st["ms"] / st["launches"]
+    return {"bound": "valu", "valu_wave_instructions_per_launch": instr, "valu_min_ms": min_ms, "valu_frac": min_ms / ms,
+            "note": "vector-ALU issue roofline (4 cycles per wave-instruction, 1024 SIMDs, 2.4 GHz); the HBM figure (gbs) is kept for reference"}
+
+
+def kernel_table(stats, steps, shape=None, B=1):
     kernels = {}
     for name, st in stats.items():
         ent = {"launches_per_step": st["launches"] / steps, "ms_per_step": st["ms"] / steps, "avg_launch_ms": st["ms"] / st["launches"]}
@@ -306,6 +390,8 @@ def kernel_table(stats, steps):
                 ent["nominal_tflops"] = st["nominal"] / (st["ms"] * 1e-3) / 1e12
         if st["bytes"]:
             ent["gbs"] = st["bytes"] / (st["ms"] * 1e-3) / 1e9
+        if name in NCC_VALU_PER_BLOCK_SLICE and shape is not None and len(shape) == 3:
+            ent.update(ncc_valu_roofline(name, st, shape, B))
         kernels[name] = ent
     return kernels
 
@@ -382,7 +468,6 @@ def main():
     dev = torch.device("cuda", local)
     shape = tuple(int(s) for s in args.shape.split(","))
     B = args.batch_per_gpu
-    # a multi-rank HIP job whose native communicator cannot be built fails HERE, loudly, unless VXM_COMM=torch was asked for
     # Multi-rank: the libvxm_comm.so communicator carries the exchange.  When it cannot be built (or fails its known-answer self-check)
     # the run goes on over torch.distributed's RCCL -- reported on stderr by rank 0 and in `comm.backend` / `comm.native_error` of the
     # line, so a scaling run leaves numbers AND says which exchange they were measured on; VXM_COMM=rccl makes that a hard error on
@@ -422,7 +507,8 @@ def main():
         del wl
         torch.cuda.empty_cache()
         for key, name, eb, esteps in (("dense_bf16", "dense_bf16", 1, 8), ("diffeo_fp32_4_pairs_per_gpu", "diffeo_fp32", 4, 4),
-                                      ("semisup_fp32", "semisup_fp32", 1, 8), ("diffeo_fp32_bf16x3_engine", "diffeo_fp32", 1, 8),
+                                      ("semisup_fp32", "semisup_fp32", 1, 8), ("diffeo_fp32_trained_flow", "diffeo_fp32_trained_flow", 1, 8),
+                                      ("diffeo_fp32_bf16x3_engine", "diffeo_fp32", 1, 8),
                                       ("diffeo_fp32_native_engine", "diffeo_fp32", 1, 8)):
             engine = VF.FP32_ENGINE
             try:
@@ -440,6 +526,7 @@ def main():
                 # synchronous warm-up steps a hipMalloc of several hundred ms could land inside the timed region
                 timed_steps(w2, esteps, vdist, dev)
                 t2, l2 = timed_steps(w2, esteps, vdist, dev)
+                host2 = 1e3 * timed_steps.host_enqueue_s / esteps
                 if "VXM_OVERLAP_MIN_LEVEL" not in os.environ:
                     VF.OVERLAP_MIN_LEVEL = 1                 # per-kernel pass: serialised, as the headline's
                 tm = profiler.KernelTimer()
@@ -448,7 +535,17 @@ def main():
                 d2 = max(st2, key=lambda k: st2[k]["ms"])
                 extra[key] = {"value": eb * esteps / t2, "unit": "volume-pairs/s", "ms_per_step": 1e3 * t2 / esteps, "steps": esteps,
                               "dtype": "bf16" if w2.bf16 else "f32", "workload": w2.describe(), "final_loss": l2,
-                              "roofline": binding_roofline(d2, st2[d2])}
+                              "host_enqueue_ms_per_step": host2, "roofline": binding_roofline(d2, st2[d2])}
+                if w2.trained:                             # the HBM-bound kernels in the regime they are in after training, with their own table
+                    kt = kernel_table(st2, 2, shape, eb)
+                    hb = {k: v for k, v in kt.items() if k.startswith(("warp3d", "vecint", "resize3d", "ncc", "gradloss"))}
+                    stv = [k for k in st2 if k.startswith(("warp3d", "vecint"))]
+                    b_ = sum(st2[k]["bytes"] for k in stv)
+                    ms_ = sum(st2[k]["ms"] for k in stv)
+                    extra[key]["kernels_hbm"] = hb
+                    extra[key]["spatial_transformer_plus_vecint"] = {"algorithmic_bytes_per_step": b_ / 2, "ms_per_step": ms_ / 2,
+                                                                     "gbs": b_ / (ms_ * 1e-3) / 1e9 if ms_ else 0.0,
+                                                                     "frac_of_hbm_peak": (b_ / (ms_ * 1e-3) / 1e9) / HBM_PEAK_GBS if ms_ else 0.0}
                 del w2
                 torch.cuda.empty_cache()
             except Exception as exc:                       # an extra line must never take the headline down with it
@@ -459,13 +556,16 @@ def main():
 
     if rank != 0:
         return
-    kernels = kernel_table(stats, ksteps)
+    kernels = kernel_table(stats, ksteps, shape, B)
     dom = max(stats, key=lambda k: stats[k]["ms"])
     ds = stats[dom]
     roof = binding_roofline(dom, ds)
     roof["traffic"], roof["traffic_unit"] = hbm_traffic(dom, ds["launches"] / ksteps, "_bf16" if bf16 else "")
     roof["measured_in"] = "per-kernel pass: %d steps with HIP-event bracketing, %.3f ms/step (the `value` pass runs un-instrumented)" % (
         ksteps, 1e3 * elapsed_k / ksteps)
+    roof["shader_clock_ghz"] = shader_clock(dom, "_bf16" if bf16 else "")     # under the profiler's counter pass; null without a matching profile
+    stv = [k for k in stats if k.startswith(("warp3d", "vecint"))]
+    st_bytes, st_ms = sum(stats[k]["bytes"] for k in stv), sum(stats[k]["ms"] for k in stv)
     out = {
         "metric": "volume-pairs/sec VxmDense 160x192x224 int_steps=0 MSE train (bf16 activations)" if dense
                   else ("volume-pairs/sec VxmDense 160x192x224 int_steps=7 NCC train (bf16 activations; not the fp32 headline)" if bf16
@@ -476,6 +576,11 @@ def main():
         "config": {"workload": wl_desc(args, shape, B), "global_batch": world * B, "parallelism": "dp%d" % world,
                    "fp32_engine": VF.fp32_engine_note()},
         "roofline": roof, "kernels": kernels, "final_loss": final_loss,
+        # SpatialTransformer + VecInt against the HBM roofline (north star: >= 50 %); on the near-zero field of a random-init flow head --
+        # extra_configs.diffeo_fp32_trained_flow carries the same figure on a 5-voxel field
+        "spatial_transformer_plus_vecint": {"algorithmic_bytes_per_step": st_bytes / ksteps, "ms_per_step": st_ms / ksteps,
+                                            "gbs": st_bytes / (st_ms * 1e-3) / 1e9 if st_ms else 0.0,
+                                            "frac_of_hbm_peak": (st_bytes / (st_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if st_ms else 0.0},
         "host_enqueue_ms_per_step": host_ms,        # rank 0's Python + launch time per step of the value pass (two steps in flight; the rest it waits)
     }
     if comm_ev is not None:

@@ -13,14 +13,19 @@ export VXM_PROFILED_STEPS=$((STEPS + WARM + (STEPS < 10 ? STEPS : 10)))
 SUF=${VXM_PROFILE_SUFFIX:-}
 ARGS="--steps $STEPS --warmup $WARM --no-cpu-baseline --no-extra-configs $*"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py $ARGS > $OUT/bench_stats.log 2>&1
+# the same, with every launch on ONE stream (VXM_NO_OVERLAP=1): the sum of kernel time is the step, small kernels are not inflated by sharing
+# the chip with the second stream's weight-gradient launches
+VXM_NO_OVERLAP=1 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -- python bench.py $ARGS > $OUT/bench_stats_serial.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python bench.py $ARGS > $OUT/bench_fetch.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python bench.py $ARGS > $OUT/bench_write.log 2>&1
 # MFMA utilisation of the conv kernels: SQ_VALU_MFMA_BUSY_CYCLES (cycles the matrix pipe is busy, summed over SIMDs),
 # SQ_BUSY_CYCLES / GRBM_GUI_ACTIVE (kernel time base), SQ_INSTS_MFMA, SQ_WAVE_CYCLES (quad-cycles)
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python bench.py $ARGS > $OUT/bench_mfma.log 2>&1
 python tools/rocprof_summary.py stats $OUT/stats gpurun_out/${TAG}_rocprof_kernel_stats${SUF}.csv
+python tools/rocprof_summary.py stats $OUT/stats_serial gpurun_out/${TAG}_rocprof_kernel_stats_serial${SUF}.csv
+grep -h '^{' $OUT/bench_stats_serial.log > gpurun_out/${TAG}_bench_under_rocprof_serial${SUF}.json
 python tools/rocprof_summary.py pmc $OUT/fetch $OUT/write gpurun_out/${TAG}_hbm_counters${SUF}.json
 python tools/rocprof_summary.py pmc $OUT/mfma gpurun_out/${TAG}_mfma_counters${SUF}.json
 grep -h '^{' $OUT/bench_stats.log > gpurun_out/${TAG}_bench_under_rocprof${SUF}.json
 # raw traces are large: keep only the summaries
-rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma
+rm -rf $OUT/stats $OUT/stats_serial $OUT/fetch $OUT/write $OUT/mfma

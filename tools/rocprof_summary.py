@@ -52,6 +52,14 @@ def pmc(roots, out):
                 c = k.setdefault(r["Counter_Name"], [0, 0.0])
                 c[0] += 1
                 c[1] += float(r["Counter_Value"])
+    # kernel durations of the SAME passes (rocprofv3 --kernel-trace beside --pmc): the clock a kernel ran at = GRBM_GUI_ACTIVE / 8 XCDs / duration
+    dur = collections.OrderedDict()
+    for root in roots:
+        for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)):
+            for r in csv.DictReader(open(f)):
+                d = dur.setdefault(short(r["Kernel_Name"]), [0, 0.0])
+                d[0] += 1
+                d[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     res = collections.OrderedDict()
     steps = os.environ.get("VXM_PROFILED_STEPS")
     if steps:                  # bench steps + warm-up steps of the profiled command: bench.py checks dispatch counts against it
@@ -65,6 +73,9 @@ def pmc(roots, out):
         # v_mfma_f32_16x16x4_f32), GRBM_GUI_ACTIVE over the 8 XCDs (checked against kernel duration x 2.4 GHz)
         if k != "_meta" and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"]["mean"] > 0:
             v["mfma_util"] = v["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / 1024.0 / (v["GRBM_GUI_ACTIVE"]["mean"] / 8.0)
+        if k != "_meta" and "GRBM_GUI_ACTIVE" in v and k in dur and dur[k][1] > 0:
+            v["duration_us_under_pmc"] = dur[k][1] / dur[k][0]
+            v["shader_clock_ghz"] = v["GRBM_GUI_ACTIVE"]["mean"] / 8.0 / (v["duration_us_under_pmc"] * 1e3)
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print("wrote", out, len(res), "kernels")
