@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """Register a moving volume to a fixed one with a trained VxmDense on MI355X — the command line of the reference's
 `scripts/torch/register.py` (:49-58: --moving --fixed --moved --model --warp -g/--gpu --multichannel); reference checkpoints load unchanged
-(`LoadableModel.load`, modelio.py:69-77).  npz / npy in and out (the reference's NIfTI I/O needs nibabel, absent
-here); `--seg` additionally warps a label map with the bit-exact nearest-neighbour transformer, and `--jacobian`
+(`LoadableModel.load`, modelio.py:69-77).  nii / nii.gz / mgz / npz / npy in, nii / nii.gz / npz / npy out (voxelmorph_amd/nifti.py: the
+reference's nibabel is not needed); the moved image and the warp are saved with the FIXED image's affine, as register.py:75,88-92 does;
+`--seg` additionally warps a label map with the bit-exact nearest-neighbour transformer, and `--jacobian`
 reports the fraction of voxels with a non-positive Jacobian determinant of the deformation (py/utils.py:473-516)."""
 import argparse
 import os
@@ -15,13 +16,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def save_vol(arr, path):
-    if path.endswith('.npz'):
-        np.savez_compressed(path, vol=arr)
-    elif path.endswith('.npy'):
+def save_vol(arr, path, affine=None):
+    from voxelmorph_amd import data as vdata
+    if path.endswith('.npy'):
         np.save(path, arr)
     else:
-        raise ValueError('unknown filetype for %s (npz / npy here; NIfTI needs nibabel)' % path)
+        vdata.save_volfile(arr, path, affine)          # nii / nii.gz / npz (py/utils.py:132-158)
 
 
 def jacobian_determinant(disp):
@@ -58,25 +58,29 @@ def main(argv=None):
     dev = torch.device('cuda', int(args.gpu))
     torch.cuda.set_device(dev)
 
+    affines = {}
+
     def load(path, multichannel=False):
         """[*vol] (or [*vol, C] with --multichannel, register.py:69-72) -> [1, C, *vol] fp32 on the device"""
-        vol = np.asarray(vdata.load_volfile(path))
+        vol, affines[path] = vdata.load_volfile(path, ret_affine=True)
+        vol = np.asarray(vol)
         vol = np.moveaxis(vol, -1, 0) if multichannel else vol[None]
         return torch.from_numpy(np.ascontiguousarray(vol, dtype=np.float32))[None].to(dev)
 
     moving, fixed = load(args.moving, args.multichannel), load(args.fixed, args.multichannel)
+    fixed_affine = affines[args.fixed]
     model = vxm.networks.VxmDense.load(args.model, dev)
     model.to(dev)
     model.eval()
     with torch.no_grad():
         moved, warp = model(moving, fixed, registration=True)
-        save_vol((moved[0].permute(1, 2, 3, 0) if args.multichannel else moved).cpu().numpy().squeeze(), args.moved)
+        save_vol((moved[0].permute(1, 2, 3, 0) if args.multichannel else moved).cpu().numpy().squeeze(), args.moved, fixed_affine)
         if args.warp:
-            save_vol(warp.cpu().numpy().squeeze(), args.warp)
+            save_vol(warp.cpu().numpy().squeeze(), args.warp, fixed_affine)
         if args.seg:
             seg = load(args.seg)
             out = vxm.layers.SpatialTransformer(seg.shape[2:], mode='nearest').to(dev)(seg, warp)
-            save_vol(out.cpu().numpy().squeeze(), args.moved_seg or (os.path.splitext(args.moved)[0] + '_seg.npz'))
+            save_vol(out.cpu().numpy().squeeze(), args.moved_seg or (os.path.splitext(args.moved)[0] + '_seg.npz'), fixed_affine)
         if args.jacobian:
             print('non-positive Jacobian fraction: %.6f' % nonpositive_jacobian_fraction(warp[0]))
 

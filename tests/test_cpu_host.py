@@ -449,3 +449,70 @@ def test_pack_cache_key_sees_reseated_storage_and_invalidate_accepts_modules():
                         "w = torch.nn.Parameter(torch.zeros(3))\nassert VB._ver(w) != VB._ver(w)\nassert VB._inplace_ver(w) == VB._inplace_ver(w)"],
                        env=dict(os.environ, VXM_PACK_CACHE="0"), capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stderr
+
+
+def test_nifti_and_mgz_io_without_nibabel(tmp_path):
+    """voxelmorph_amd.nifti + data.load_volfile / save_volfile (py/utils.py:69-158): NIfTI-1 round trips (dtype, Fortran data order,
+    sform affine, gzip), a hand-built big-endian header with qform only and scl_slope scaling, the reference's default LIA affine,
+    mgz, and the keyword arguments of load_volfile."""
+    import gzip
+    import struct
+    from voxelmorph_amd import data as vdata
+    from voxelmorph_amd import nifti
+    rng = np.random.default_rng(0)
+    aff = np.array([[-1.5, 0.1, 0.0, 90.0], [0.2, 0.0, 2.0, -126.0], [0.0, -1.0, 0.1, 72.0], [0, 0, 0, 1.0]])
+    for dt in (np.float32, np.int16, np.uint8, np.float64):
+        for name in ("v.nii", "v.nii.gz"):
+            v = (rng.random((5, 6, 7)) * 100).astype(dt)
+            vdata.save_volfile(v, str(tmp_path / name), aff)
+            got, a2 = vdata.load_volfile(str(tmp_path / name), ret_affine=True)
+            assert got.dtype == dt and np.array_equal(got, v)
+            np.testing.assert_allclose(a2, aff, rtol=0, atol=1e-5)          # (the header stores float32)
+    raw = gzip.open(tmp_path / "v.nii.gz").read()
+    assert struct.unpack("<i", raw[:4])[0] == 348 and raw[344:348] == b"n+1\0" and struct.unpack("<f", raw[108:112])[0] == 352.0
+    assert struct.unpack("<8h", raw[40:56])[:4] == (3, 5, 6, 7)
+    assert np.frombuffer(raw, "<f8", 3, 352).tolist() == v.reshape(-1, order="F")[:3].tolist()      # x fastest on disk
+    # default affine of the reference (LIA, volume centre at the origin) when none is given
+    vdata.save_volfile(v, str(tmp_path / "d.nii"))
+    _, ad = vdata.load_volfile(str(tmp_path / "d.nii"), ret_affine=True)
+    np.testing.assert_allclose(ad, [[-1, 0, 0, 2.5], [0, 0, 1, -3.5], [0, -1, 0, 3.0], [0, 0, 0, 1]], atol=1e-6)
+    # 4-D flow fields round-trip too ([3, D, H, W] as register.py --warp writes them)
+    w4 = rng.standard_normal((3, 4, 5, 6)).astype(np.float32)
+    vdata.save_volfile(w4, str(tmp_path / "w.nii.gz"), aff)
+    assert np.array_equal(vdata.load_volfile(str(tmp_path / "w.nii.gz")), w4)
+    # a big-endian file with a qform only (90 degree rotation about z, zooms 2 / 3 / 4) and scaled int16 data
+    hdr = bytearray(348)
+    struct.pack_into(">i", hdr, 0, 348)
+    struct.pack_into(">8h", hdr, 40, 3, 2, 3, 4, 1, 1, 1, 1)
+    struct.pack_into(">2h", hdr, 70, 4, 16)
+    struct.pack_into(">8f", hdr, 76, 1.0, 2.0, 3.0, 4.0, 1, 1, 1, 1)
+    struct.pack_into(">3f", hdr, 108, 352.0, 0.5, 10.0)
+    struct.pack_into(">2h", hdr, 252, 1, 0)
+    s2 = float(np.sqrt(0.5))
+    struct.pack_into(">6f", hdr, 256, 0.0, 0.0, s2, 7.0, 8.0, 9.0)
+    hdr[344:348] = b"n+1\0"
+    data = np.arange(24, dtype=">i2")
+    (tmp_path / "be.nii").write_bytes(bytes(hdr) + b"\0\0\0\0" + data.tobytes())
+    vb, ab = nifti.read_nifti(str(tmp_path / "be.nii"))
+    assert vb.dtype == np.float64 and vb.shape == (2, 3, 4) and vb[1, 0, 0] == 0.5 * 1 + 10 and vb[0, 1, 0] == 0.5 * 2 + 10
+    np.testing.assert_allclose(ab, [[0, -3, 0, 7], [2, 0, 0, 8], [0, 0, 4, 9], [0, 0, 0, 1]], atol=1e-6)
+    # mgz: big-endian MGH header, float data, direction cosines + centre
+    mh = bytearray(284)
+    struct.pack_into(">7ih", mh, 0, 1, 2, 3, 4, 1, 3, 0, 1)
+    struct.pack_into(">3f", mh, 30, 1.0, 1.0, 1.0)
+    struct.pack_into(">9f", mh, 42, -1, 0, 0, 0, 0, -1, 0, 1, 0)
+    struct.pack_into(">3f", mh, 78, 1.0, 2.0, 3.0)
+    md = np.arange(24, dtype=">f4")
+    with gzip.open(tmp_path / "m.mgz", "wb") as f:
+        f.write(bytes(mh) + md.tobytes())
+    vm, am = vdata.load_volfile(str(tmp_path / "m.mgz"), ret_affine=True)
+    assert vm.shape == (2, 3, 4) and vm[1, 0, 0] == 1.0 and vm[0, 0, 1] == 6.0
+    np.testing.assert_allclose(am, [[-1, 0, 0, 2.0], [0, 0, 1, 0.0], [0, -1, 0, 4.5], [0, 0, 0, 1]], atol=1e-6)
+    # keyword arguments of the reference's load_volfile
+    v0 = vdata.load_volfile(str(tmp_path / "v.nii"))
+    p = vdata.load_volfile(str(tmp_path / "v.nii"), add_batch_axis=True, add_feat_axis=True, pad_shape=(8, 8, 8))
+    assert p.shape == (1, 8, 8, 8, 1) and np.array_equal(p[0, 1:6, 1:7, 0:7, 0], v0) and float(np.abs(p).sum()) == float(np.abs(v0).sum())
+    z = vdata.load_volfile(str(tmp_path / "v.nii"), add_feat_axis=True, resize_factor=0.5)
+    assert z.shape[-1] == 1 and z.shape[:3] == (2, 3, 4)                    # scipy's nearest-neighbour zoom rounds 2.5 -> 2, 3.5 -> 4
+    with pytest.raises(ValueError):
+        vdata.save_volfile(v, str(tmp_path / "x.mgz"))

@@ -804,6 +804,21 @@ def test_train_and_register_cli_end_to_end(vxm, tmp_path):
     assert np.load(tmp_path / "warp.npz")["vol"].shape == (3, 32, 32, 32)
     assert set(np.unique(np.load(tmp_path / "mseg.npz")["vol"])) <= {0.0, 1.0}
     assert "non-positive Jacobian fraction" in r.stdout
+    # the reference's default file type: NIfTI in and out (voxelmorph_amd/nifti.py, no nibabel); the outputs carry the FIXED image's affine
+    from voxelmorph_amd import data as vdata
+    aff = np.array([[-1.0, 0, 0, 16.0], [0, 0, 1.0, -16.0], [0, -1.0, 0, 16.0], [0, 0, 0, 1.0]])
+    aff_fixed = aff.copy()
+    aff_fixed[:3, 3] += 2.0
+    vdata.save_volfile(np.load(names[0])["vol"], str(tmp_path / "mov.nii.gz"), aff)
+    vdata.save_volfile(np.load(names[1])["vol"], str(tmp_path / "fix.nii.gz"), aff_fixed)
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "register.py"), "--moving", str(tmp_path / "mov.nii.gz"), "--fixed",
+                        str(tmp_path / "fix.nii.gz"), "--moved", str(tmp_path / "moved.nii.gz"), "--warp", str(tmp_path / "warp.nii.gz"),
+                        "--model", str(ckpt)], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    mv, am = vdata.load_volfile(str(tmp_path / "moved.nii.gz"), ret_affine=True)
+    np.testing.assert_allclose(am, aff_fixed, atol=1e-5)
+    np.testing.assert_allclose(mv, np.load(tmp_path / "moved.npz")["vol"], atol=1e-6)          # same registration as the npz run
+    assert vdata.load_volfile(str(tmp_path / "warp.nii.gz")).shape == (3, 32, 32, 32)
 
 
 def test_checkpoint_roundtrip_reference_format(vxm, g_network, tmp_path):

@@ -7,8 +7,9 @@ Replaces, for this path only, `voxelmorph/generators.py:9-194` (`volgen`, `scan_
 tens of pairs/s per GPU that is the bottleneck.
 
 Here each rank owns a loader built on `VolumeBank`s:
-  * volumes (and label maps) are loaded once (npz `vol` / `seg` / npy / preloaded arrays — `py/utils.py:69-129`; NIfTI
-    needs nibabel, which this image does not have), converted to fp32 channels-first and kept in PINNED host memory;
+  * volumes (and label maps) are loaded once (nii / nii.gz / mgz / npz `vol` / `seg` / npy / preloaded arrays — `py/utils.py:69-129`;
+    the NIfTI-1 and mgz readers are `voxelmorph_amd/nifti.py`, nibabel is not needed), converted to fp32 channels-first and kept in
+    PINNED host memory;
     banks that fit are uploaded once and stay resident in HBM (288 GB per GPU: ~10,000 volumes of 160x192x224), so a
     step's "load" is a device-side gather into the batch tensors;
   * otherwise a background thread fills pinned staging batches and a dedicated HIP copy stream uploads batch k+1
@@ -31,21 +32,66 @@ import numpy as np
 import torch
 
 
-def load_volfile(filename, np_var='vol'):
-    """npz / npy subset of `voxelmorph/py/utils.py:69-129` (preloaded arrays are passed through)."""
+def load_volfile(filename, np_var='vol', add_batch_axis=False, add_feat_axis=False, pad_shape=None, resize_factor=1, ret_affine=False):
+    """`voxelmorph/py/utils.py:69-129`: nii / nii.gz / mgz / npz / npy (a preloaded array is passed through; with ret_affine a
+    preloaded `(vol, affine)` pair).  NIfTI-1 and mgz are read by `voxelmorph_amd.nifti` (no nibabel in this image): the volume as
+    `np.squeeze(img.dataobj)` and the best affine of the header.  pad_shape / resize_factor as `py/utils.py:235-262`."""
+    from . import nifti
+    affine = None
     if not isinstance(filename, (str, os.PathLike)):
-        return np.asarray(filename)
+        if ret_affine:
+            vol, affine = filename
+        else:
+            vol = filename
+        vol = np.asarray(vol)
+    else:
+        filename = str(filename)
+        if not os.path.isfile(filename):
+            raise ValueError("'%s' is not a file." % filename)
+        if filename.endswith(('.nii', '.nii.gz')):
+            vol, affine = nifti.read_nifti(filename)
+            vol = np.squeeze(vol)
+        elif filename.endswith(('.mgz', '.mgh')):
+            vol, affine = nifti.read_mgz(filename)
+            vol = np.squeeze(vol)
+        elif filename.endswith('.npy'):
+            vol = np.load(filename)
+        elif filename.endswith('.npz'):
+            npz = np.load(filename)
+            vol = next(iter(npz.values())) if len(npz.keys()) == 1 else npz[np_var]
+        else:
+            raise ValueError('unknown filetype for %s' % filename)
+    if pad_shape:
+        if vol.shape != tuple(pad_shape):                # py/utils.py:235-247: zero-pad, the array centred
+            padded = np.zeros(pad_shape, dtype=vol.dtype)
+            offsets = [int((p - v) / 2) for p, v in zip(pad_shape, vol.shape)]
+            padded[tuple(slice(o, n + o) for o, n in zip(offsets, vol.shape))] = vol
+            vol = padded
+    if add_feat_axis:
+        vol = vol[..., np.newaxis]
+    if resize_factor != 1:                               # py/utils.py:250-262: nearest-neighbour zoom of every axis but the feature axis
+        import scipy.ndimage
+        vol = scipy.ndimage.zoom(vol, [resize_factor] * (vol.ndim - 1) + [1], order=0)
+    if add_batch_axis:
+        vol = vol[np.newaxis, ...]
+    return (vol, affine) if ret_affine else vol
+
+
+def save_volfile(array, filename, affine=None):
+    """`voxelmorph/py/utils.py:132-158`: nii / nii.gz (the reference's default LIA affine centred on the volume when none is given) / npz"""
+    from . import nifti
     filename = str(filename)
-    if not os.path.isfile(filename):
-        raise ValueError("'%s' is not a file." % filename)
-    if filename.endswith('.npy'):
-        return np.load(filename)
-    if filename.endswith('.npz'):
-        npz = np.load(filename)
-        return next(iter(npz.values())) if len(npz.keys()) == 1 else npz[np_var]
-    if filename.endswith(('.nii', '.nii.gz', '.mgz')):
-        raise ValueError("NIfTI / mgz need nibabel, which is not available here; convert '%s' to npz" % filename)
-    raise ValueError('unknown filetype for %s' % filename)
+    array = np.asarray(array)
+    if filename.endswith(('.nii', '.nii.gz')):
+        if affine is None and array.ndim >= 3:
+            affine = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], dtype=float)
+            pcrs = np.append(np.array(array.shape[:3]) / 2, 1)
+            affine[:3, 3] = -np.matmul(affine, pcrs)[:3]
+        nifti.write_nifti(array, filename, affine)
+    elif filename.endswith('.npz'):
+        np.savez_compressed(filename, vol=array)
+    else:
+        raise ValueError('unknown filetype for %s' % filename)
 
 
 def _resolve(vol_names):
