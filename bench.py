@@ -199,12 +199,12 @@ def binding_roofline(name, st):
     if not st["flops"]:
         return hbm or dict(per, kernel=name, bound="hbm", achieved=0.0, peak=HBM_PEAK_GBS, unit="GB/s", frac=0.0, algorithmic_per_launch=0.0)
     is_bf = name.startswith("k_bf16")
-    is_split = name.startswith("k_s3_")
+    is_split = name.startswith(("k_s3_", "k_s3u_"))
     alg = st["nominal"] if is_bf else st["flops"]
     # split-fp32 kernels (csrc/conv_s3.hip) run on the 16-bit matrix pipe with `nprod` MFMAs per fp32-equivalent MAC block -- six
     # v_mfma_f32_16x16x32_bf16 (three bf16 pieces, region label ends in ",3>" / "<3>") or three v_mfma_f32_16x16x32_f16 (two fp16 pieces,
     # ",2>" / "<2>"): their ceiling in fp32-equivalent FLOPs is the dense 16-bit peak / nprod -- NOT the fp32-MFMA peak, which they exceed
-    nprod = 3.0 if (is_split and name.rstrip(">").endswith("2")) else 6.0
+    nprod = 3.0 if (is_split and (name.rstrip(">").endswith("2") or name.startswith("k_s3u_bww"))) else 6.0
     peak = BF16_MFMA_PEAK_TFLOPS if is_bf else (BF16_MFMA_PEAK_TFLOPS / nprod if is_split else FP32_MFMA_PEAK_TFLOPS)
     ach = alg / sec / 1e12
     if hbm is not None and st["bytes"] / (HBM_PEAK_GBS * 1e9) > alg / (peak * 1e12):

@@ -371,6 +371,16 @@ int vxm_conv3d_k3_s3u_bwd_low(const float* dz, int64_t dz_bstride, int Cout, con
                               const float* mask_src, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, int pieces,
                               void* stream);
 
+/* convolution_backward (weight) of the UPSAMPLED segment of such a layer, collapsed and on the split arithmetic (csrc/conv_s3u.hip:
+ * k_s3u_bww): gw[co][0:C0][tap] inside a [Cout][gw_cin][3][3][3] array from x0 [B,C0,D/2,H/2,W/2] and dz [B,Cout,D,H,W] -- per offset
+ * a in {-1,0,1,2}^3 the contraction sum_m dz[2 m + a] x0[m] over the low-resolution voxels, then the taps as sums of offsets.  The
+ * caller computes the skip segment's share and the bias gradient (vxm_conv3d_k3_s3_bwd_weight with ci_off = C0).  C0 = 16 or 32, Cout a
+ * multiple of 16, D, H even, W a multiple of 4, pieces = 2; deterministic (fixed-order partial sums in `work`). */
+int vxm_conv3d_k3_s3u_bwd_weight_ok(int C0, int Cout, int B, int D, int H, int W, int pieces);
+size_t vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes(int C0, int Cout, int B, int D, int H, int W);
+int vxm_conv3d_k3_s3u_bwd_weight(const float* x0, int C0, int64_t x0_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw,
+                                 int gw_cin, void* work, size_t work_bytes, int B, int D, int H, int W, int pieces, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,6 +189,36 @@ def test_s3u_backward_data_onto_the_low_resolution_tensor_vs_fp64(VF, c0, c1, co
     del gxl, big
 
 
+@pytest.mark.parametrize("c0,cout,vol,B", [(32, 32, (8, 8, 64), 2), (16, 16, (6, 12, 36), 1), (32, 16, (10, 4, 32), 2), (16, 48, (4, 6, 68), 1)])
+def test_s3u_backward_weight_of_the_upsampled_segment_vs_fp64(VF, c0, cout, vol, B):
+    """k_s3u_bww: weight gradient of the x2-upsampled segment (64 offset contractions on the low-resolution grid, mapped onto the 27 taps)
+    against fp64 autograd of upsample + conv (networks.py:133-138, 299); only its channel range of a wider gradient array is written;
+    bit-wise run-to-run determinism.  fp16 scheme only."""
+    from voxelmorph_amd import _lib
+    D, H, W = vol
+    if VF.FP32_ENGINE != "f16x2":
+        assert _lib.lib().vxm_conv3d_k3_s3u_bwd_weight_ok(c0, cout, B, 64, 64, 64, 3) == 0
+        pytest.skip("k_s3u_bww runs the fp16 scheme")
+    torch.manual_seed(5000 + c0 + cout)
+    lo = tuple(s // 2 for s in vol)
+    x0 = torch.randn(B, c0, *lo, device="cuda")
+    dz = torch.randn(B, cout, *vol, device="cuda")
+    pad = 16
+    gw = torch.full((cout, c0 + pad, 3, 3, 3), 7.25, device="cuda")
+    ws = VF._Workspace(x0.device)
+    VF.s3u_bwd_weight(ws, x0, c0, x0[0].numel(), dz, cout, gw, c0 + pad, B, D, H, W)
+    assert bool((gw[:, c0:] == 7.25).all())
+    wr = torch.zeros(cout, c0, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    xin = torch.nn.functional.interpolate(x0.cpu().double(), scale_factor=2, mode="nearest")
+    torch.nn.functional.conv3d(xin, wr, None, padding=1).backward(dz.cpu().double())
+    e = rel_l2(gw[:, :c0].cpu().numpy(), wr.grad.numpy())
+    print("s3u backward-weight [%s] (%d^ x %d, %s, B=%d): rel-L2 vs fp64 %.2e" % (VF.FP32_ENGINE, c0, cout, "x".join(map(str, vol)), B, e))
+    assert e <= 3e-6, e
+    gw2 = torch.full_like(gw, 7.25)
+    VF.s3u_bwd_weight(ws, x0, c0, x0[0].numel(), dz, cout, gw2, c0 + pad, B, D, H, W)
+    assert torch.equal(gw, gw2)
+
+
 def test_s3_backward_data_with_fused_mask_and_output_guard(VF):
     """The adjoint operator (transpose_flip pack) with the previous block's LeakyReLU' fused in the epilogue, written into a
     channel slice of a larger buffer: nothing outside the slice, the next sample or the tail may be touched."""
@@ -341,7 +371,7 @@ def test_s3_through_the_dispatcher_on_small_volumes_in_subprocess():
     if os.environ.get("VXM_S3_MIN_TILES"):
         pytest.skip("already inside the forced run")
     for engine in ("f16x2", "split"):
-        _rerun({"VXM_S3_MIN_TILES": "1", "VXM_S3U_MIN_TILES": "1", "VXM_FP32_ENGINE": engine},
+        _rerun({"VXM_S3_MIN_TILES": "1", "VXM_S3U_MIN_TILES": "1", "VXM_S3U_BWW_MIN_TILES": "1", "VXM_FP32_ENGINE": engine},
                "conv_block_vs_oracle or conv_block_output_guard or unet_vs_oracle or vxm_dense_golden or collapsed_weights", files=("tests/test_gpu_parity.py",))
         _rerun({"VXM_S3_MIN_TILES": "1", "VXM_S3U": "0", "VXM_FP32_ENGINE": engine, "VXM_S3_UP": "1"},
                "unet_vs_oracle or collapsed_weights", files=("tests/test_gpu_parity.py",))

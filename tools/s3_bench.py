@@ -158,6 +158,35 @@ def main():
         print("%-34s %7.1f GFLOP executed | split %.3f ms = %6.1f TF-eq | fp32-MFMA %.3f ms = %6.1f TF | x%.2f | rel-L2 %.2e"
               % (name, gf, t_s3, gf / t_s3, t_nat, gf / t_nat, t_nat / t_s3, diff), flush=True)
         del dz, act, g_s3, g_nat
+    # weight gradient of the upsampled segment: k_s3u_bww against k_conv3d_k3_bwd_weight_up
+    for name, c0, c1, cout, lvl in (("rem0 bww-up 32^ x 32 s3u", 32, 16, 32, 0), ("dec3 bww-up 32^ x 32 s3u (L1)", 32, 32, 32, 1)):
+        if args.only and args.only not in name:
+            continue
+        D, H, W = (s >> lvl for s in shape)
+        V = D * H * W
+        if not (VF.s3u_bwd_weight_route(c0, cout, B, D, H, W) or os.environ.get("VXM_S3U_BWW_MIN_TILES")):
+            continue
+        x0 = torch.randn(B, c0, D // 2, H // 2, W // 2, device="cuda")
+        x1 = torch.randn(B, c1, D, H, W, device="cuda")
+        dz = torch.randn(B, cout, D, H, W, device="cuda")
+        gw_s, gw_n = torch.zeros(cout, c0 + c1, 3, 3, 3, device="cuda"), torch.zeros(cout, c0 + c1, 3, 3, 3, device="cuda")
+        ws = VF._Workspace(dz.device)
+        need = _lib.lib().vxm_conv3d_k3_bwd_weight_workspace_bytes(c0 + c1, cout, B, D, H, W)
+
+        def run_s3():
+            VF.s3u_bwd_weight(ws, x0, c0, x0[0].numel(), dz, cout, gw_s, c0 + c1, B, D, H, W)
+
+        def run_nat():
+            buf = ws.get(need)
+            VF.call("vxm_conv3d_k3_bwd_weight_up_segment", VF.ptr(x0), c0, x0[0].numel(), VF.ptr(x1), c1, c1 * V, VF.ptr(dz), cout * V, cout,
+                    VF.ptr(gw_n), VF.ptr(buf), buf.numel(), B, D, H, W, VF.stream())
+        t_s3, t_nat = timed(run_s3, args.iters), timed(run_nat, args.iters)
+        gf = 2.0 * 8 * c0 * cout * B * V / 1e9
+        diff = float((gw_s[:, :c0].double() - gw_n[:, :c0].double()).norm() / gw_n[:, :c0].double().norm())
+        rows.append(dict(op=name, gflop_executed=gf, s3_ms=t_s3, s3_tflops=gf / t_s3, native_ms=t_nat, native_tflops=gf / t_nat, rel_l2_s3_vs_native=diff))
+        print("%-34s %7.1f GFLOP executed | split %.3f ms = %6.1f TF-eq | fp32-MFMA %.3f ms = %6.1f TF | x%.2f | rel-L2 %.2e"
+              % (name, gf, t_s3, gf / t_s3, t_nat, gf / t_nat, t_nat / t_s3, diff), flush=True)
+        del x0, x1, dz
     # backward-weight of the plain full-resolution tensors: split kernel vs the fp32-MFMA kernels
     for name, c, cout, lvl in (("rem1 bwd-weight 32->16", 32, 16, 0), ("rem2 bwd-weight 16->16", 16, 16, 0), ("rem0-skip bwd-weight 16->32", 16, 32, 0),
                                ("enc1 bwd-weight 16->32 (L1)", 16, 32, 1), ("dec3-skip bwd-weight 32->32 (L1)", 32, 32, 1)):

@@ -119,6 +119,9 @@ SIGNATURES = {
     "vxm_conv3d_k3_s3u_bwd_low_packed_bytes": [_I, _I, _I],
     "vxm_conv3d_k3_s3u_bwd_low_pack_weights": [_P, _P, _I, _I, _I, _I, _P],
     "vxm_conv3d_k3_s3u_bwd_low": [_P, _L, _I, _P, _P, _L, _I, _P, _L, _F, _I, _I, _I, _I, _I, _P],
+    "vxm_conv3d_k3_s3u_bwd_weight_ok": [_I, _I, _I, _I, _I, _I, _I],
+    "vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes": [_I, _I, _I, _I, _I, _I],
+    "vxm_conv3d_k3_s3u_bwd_weight": [_P, _I, _L, _P, _L, _I, _P, _I, _P, _S, _I, _I, _I, _I, _I, _P],
     "vxm_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
 }
 _RESTYPES = {
@@ -134,6 +137,7 @@ _RESTYPES = {
     "vxm_ncc_win_elems": _L,
     "vxm_conv3d_k3_s3u_packed_bytes": _S,
     "vxm_conv3d_k3_s3u_bwd_low_packed_bytes": _S,
+    "vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes": _S,
 }
 
 _lib = None

@@ -469,13 +469,6 @@ template <int NP> struct SwCfg {
     static constexpr int LDS_BYTES = (TILE_BYTES + TAB_BYTES > SW_EPI_BYTES ? TILE_BYTES + TAB_BYTES : SW_EPI_BYTES);
 };
 
-__device__ __forceinline__ u32x2 s3_tr_read(const char* lds_base, int byte_off) {
-    typedef short s16x4 __attribute__((ext_vector_type(4)));
-    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)(lds_base + byte_off));
-    return __builtin_bit_cast(u32x2, v);
-}
-
 struct SwTasks { int ncol, nseg, seg_len, nd, nh, nw; };       // tasks = (column (b, th, tw), depth segment), seg_len tiles each
 
 // x: [B][C][D][H][W] fp32 (batch stride x_bs), dz: [B][Cdz][D][H][W] fp32; grid = NBLK x NCOMBO, combo = (16-channel chunk q of x, 16-channel tile of dz)

@@ -750,6 +750,275 @@ k_s3u_dlow(const float* __restrict__ dz, long long dz_bs, int Cout, const u32x4*
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// backward-weight of the upsampled segment, collapsed and on the split arithmetic (fp16 scheme):
+//   convolution_backward (weight) of cat([upsample(x0), .]) restricted to the x0 channels (autograd twin of networks.py:133-138, 299);
+//   rounds 1-3: k_conv3d_k3_bwd_weight_up on the fp32 matrix pipe.
+// With G[a][co][ci] = sum over low-res voxels m of dz[co][2 m + a] x0[ci][m] for the 64 offsets a in {-1,0,1,2}^3 (the offsets of
+// k_s3u_dlow), the gradient of tap k is the sum of G over a_axis in A(k_axis), A(0) = {1,2}, A(1) = {0,1}, A(2) = {-1,0} per axis
+// (k_s3u_bww_reduce): 64 instead of 216 products per (voxel pair of channels), and x0 is read at its own resolution.
+// Contraction over VOXELS as k_s3_bwd_weight: M = 16 dz channels, N = 16 x0 channels (x NCI tiles), K = 32 = two low-res rows x 16
+// low-res voxels of a W row; both operands live in LDS as [voxel][16 channel] rows and are read with ds_read_b64_tr_b16.  dz is staged
+// like k_s3_bwd_weight's X (haloed planes of 6 rows x 34 voxels in a 6-plane depth ring: a tile of one low-res depth needs four
+// full-resolution planes and shares two with the next), but stored de-interleaved by W parity, so that the 16 voxels 2 v + a_w an
+// offset reads are consecutive rows; x0 has no halo (2 x 16 voxels per tile, double-buffered).  Block = 16 waves = (a_d, a_h); a wave
+// keeps its 4 (a_w) x NCI accumulator tiles over all its tiles (per-tile MFMA chains folded into fp32 totals, as k_s3_bwd_weight).
+// One block per CU and dz-channel tile walks a range of (column, depth segment) tasks; per-block partial sums of G, reduced and
+// mapped onto the 27 taps in a fixed order (deterministic).
+// A PHASE covers two low-res depths (two "tiles"): what bounds this kernel is not arithmetic (24 MFMAs per wave and tile) but the latency of
+// the loads of the next phase, which has to be hidden behind this one -- so a phase requests as many bytes as the block can hold: four dz
+// planes + two x0 tiles on all 1024 threads (one slot each), a 10-plane ring (six in use, four arriving).
+constexpr int UW_WAVES = 16, UW_THREADS = 64 * UW_WAVES, UW_RING = 10, UW_TPP = 2;
+constexpr int UW_ROWV = 17;                                    // voxels of one parity in a haloed row of 34
+constexpr int UW_PLANE = 6 * 2 * UW_ROWV * 32;                 // bytes of one haloed dz plane of one piece: [row 6][parity 2][17][16 co]
+constexpr int UW_XPIECE = UW_RING * UW_PLANE;
+constexpr int UW_LTILE = 2 * 16 * 32;                          // x0 tile of one (piece, ci tile): [low-res row 2][16 voxels][16 ci]
+template <int NCI> struct UwCfg {
+    static constexpr int NP = 2;
+    static constexpr int LBUF = UW_TPP * NP * NCI * UW_LTILE;  // one x0 buffer: the two tiles of a phase
+    static constexpr int TILE_BYTES = NP * UW_XPIECE + 2 * LBUF;
+    static constexpr int LDS_BYTES = TILE_BYTES + 256;         // + floats: [0..9] ring planes, [10..11] x0 buffers, [16..] wave maxima (two slots of 16)
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+// dz: [B][Cdz][D][H][W], x0: [B][C0][D/2][H/2][W/2]; grid = NBLK x NCOT (16-channel tiles of dz)
+template <int NCI>
+__global__ void __launch_bounds__(UW_THREADS, 4) k_s3u_bww(const float* __restrict__ x0, long long x0_bs, int C0, const float* __restrict__ dz,
+                                                           long long dz_bs, int Cdz, float* __restrict__ part, int D, int H, int W, int NBLK,
+                                                           int ncol, int nseg, int seg_len, int nh, int nw) {
+    using CF = UwCfg<NCI>;
+    using P = S3P<2>;
+    constexpr int NP = 2;
+    VXM_DYN_SMEM(char, smem);
+    char* const Xs = smem;                                       // [NP][10 ring planes][UW_PLANE]
+    char* const Ls = smem + NP * UW_XPIECE;                      // [2 buffers][tile of the phase 2][NP][NCI][UW_LTILE]
+    float* const Tab = reinterpret_cast<float*>(smem + CF::TILE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ad = wave >> 2, ah = wave & 3;                     // this wave's offsets (index = a + 1)
+    const int NCOT = gridDim.x / NBLK, xmain = NBLK & ~7;
+    int bx, cot;
+    if ((int)blockIdx.x < xmain * NCOT) {                        // the tiles of one task range 8 workgroup ids apart: one XCD's L2 serves both
+        const int j = blockIdx.x >> 3;
+        cot = j % NCOT;
+        bx = (j / NCOT) * 8 + (blockIdx.x & 7);
+    } else {
+        const int r = blockIdx.x - xmain * NCOT;
+        bx = xmain + r / NCOT;
+        cot = r % NCOT;
+    }
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
+    const int ntask = ncol * nseg;
+    const int k_lo = (int)((long long)ntask * bx / NBLK), k_hi = (int)((long long)ntask * (bx + 1) / NBLK);
+    const int V = D * H * W, HW = H * W, Vl = Dl * Hl * Wl, HWl = Hl * Wl;
+
+    f32x4 tot[4][NCI];
+#pragma unroll
+    for (int aw = 0; aw < 4; ++aw)
+#pragma unroll
+        for (int c = 0; c < NCI; ++c) tot[aw][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lp = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;     // lane pattern of the transposing read
+
+    // staging roles (wave-uniform): waves 0 .. 13 stage dz -- slot = (plane of the four 4, row 6, W pair 18, 8-channel half): 864 slots --,
+    // waves 14, 15 the two x0 tiles -- slot = (tile 2, low-res row 2, W pair 8, 8-channel block of the NCI x 16 channels)
+    constexpr int NXS = 6 * 18 * 2;
+    const int s_role = wave <= 13 ? 1 : 2;
+    const int s_i = s_role == 1 ? tid : tid - 14 * 64;
+    const int x_pl = s_role == 1 ? s_i / NXS : (s_i >> 6), x_r = s_role == 1 ? s_i - x_pl * NXS : (s_i & 63);      // plane of the four / tile of the two
+    float ra[8], rb[8];
+    unsigned ka[NP][4], kb[NP][4];
+    int off0 = VXM_OOB, ldst = 0, vk;
+
+    for (int task = k_lo; task < k_hi; ++task) {
+        const int col = task / nseg, seg = task - col * nseg;
+        const int tw = col % nw; int cq = col / nw;
+        const int th = cq % nh; const int b = cq / nh;
+        const int md0 = seg * seg_len, ntile = min(seg_len, Dl - md0), nphase = (ntile + UW_TPP - 1) / UW_TPP;
+        const int mh0 = th * 2, mw0 = tw * 16;
+        const bool xrole = s_role != 2;
+        const __amdgpu_buffer_rsrc_t rd = vxm_rsrc(xrole ? dz + (size_t)b * dz_bs : x0 + (size_t)b * x0_bs, (unsigned)(xrole ? Cdz * V : C0 * Vl) * 4u);
+        if (s_role == 1) {
+            const int cb = x_r & 1, pr = x_r >> 1, hh = pr / 18, pp = pr - hh * 18;
+            const int gh = 2 * mh0 - 1 + hh, gw = 2 * mw0 - 2 + 2 * pp;
+            const bool live = x_pl < 4 && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && cot * 16 + cb * 8 < Cdz;
+            off0 = live ? ((cot * 16 + cb * 8) * V + gh * W + gw) << 2 : VXM_OOB;
+            // first voxel of the pair: haloed column 2 pp - 1 (parity 1, index pp - 1), second: column 2 pp (parity 0, index pp)
+            ldst = (((hh * 2 + 1) * UW_ROWV + pp - 1) * 32 + cb * 16) | (pp == 0 ? 1 : 0) | (pp == 17 ? 2 : 0);
+        } else {
+            const int cbq = x_r & 3, r2 = x_r >> 2, lr = r2 >> 3, pair = r2 & 7;
+            const bool live = cbq * 8 < C0 && cbq < 2 * NCI && mh0 + lr < Hl && mw0 + 2 * pair < Wl;
+            off0 = live ? (cbq * 8 * Vl + (mh0 + lr) * Wl + mw0 + 2 * pair) << 2 : VXM_OOB;
+            ldst = ((cbq >> 1) * UW_LTILE) + (lr * 16 + 2 * pair) * 32 + (cbq & 1) * 16;
+        }
+        // dz planes p0 .. p0 + np - 1 of this task (plane p = full-resolution depth 2 md0 - 1 + p) and the x0 tiles tl, tl + 1 (tl < 0: none)
+        // -> registers; a plane outside the volume / a tile outside the task ORs the out-of-range bit into the lane offsets (branch-free)
+        auto load_phase = [&](int p0, int np, int tl) __attribute__((always_inline)) {
+            const int gd = 2 * md0 - 1 + p0 + x_pl;                                   // (dz role: per-lane plane)
+            const bool pok = x_pl < np && (unsigned)gd < (unsigned)D;
+            const int mt = tl + x_pl;                                                 // (x0 role: wave-uniform tile)
+            const bool lok = tl >= 0 && mt < ntile;
+            vk = xrole ? (pok ? off0 + ((gd * HW) << 2) : VXM_OOB) : (lok ? off0 : VXM_OOB);
+            const int sb = xrole ? 0 : ((md0 + (lok ? mt : 0)) * HWl) << 2;
+            const int cs = (xrole ? V : Vl) << 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, vk, sb + e * cs, 0));
+                ra[e] = t2.x; rb[e] = t2.y;
+            }
+        };
+        auto publish_max = [&](int slot) __attribute__((always_inline)) {
+            float m = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[e]), __builtin_fabsf(rb[e])));
+            m = s3_wave_max(m);
+            if (lane == 0) Tab[16 + 16 * slot + wave] = m;
+        };
+        float sc_role = 1.0f;
+        auto take_scales = [&](int slot, int p0, int np, int lbuf) __attribute__((always_inline)) {
+            const f32x4* const t4 = reinterpret_cast<const f32x4*>(Tab + 16 + 16 * slot);
+            const f32x4 m0 = t4[0], m1 = t4[1], m2 = t4[2], m3 = t4[3];
+            const float mxx = fmaxf(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))),
+                                    fmaxf(fmaxf(fmaxf(m2.x, m2.y), fmaxf(m2.z, m2.w)), fmaxf(m3.x, m3.y)));          // waves 0 .. 13
+            const float mxl = fmaxf(m3.z, m3.w);                                                                     // waves 14, 15
+            float sx, ix, sl, il;
+            s3_scale_of(mxx, sx, ix);
+            s3_scale_of(mxl, sl, il);
+            sc_role = s_role == 2 ? sl : sx;
+            if (tid < np) Tab[(p0 + tid) % UW_RING] = ix;
+            if (tid == 64 && lbuf >= 0) Tab[10 + lbuf] = il;
+        };
+        auto split_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s3_split2_f16(ra[2 * e], ra[2 * e + 1], sc_role, ka[0][e], ka[1][e]);
+                s3_split2_f16(rb[2 * e], rb[2 * e + 1], sc_role, kb[0][e], kb[1][e]);
+            }
+        };
+        auto write_phase = [&](int p0, int np, int lbuf) __attribute__((always_inline)) {
+            if (s_role == 1) {
+                if (x_pl < np) {
+                    char* const d = Xs + ((p0 + x_pl) % UW_RING) * UW_PLANE + (ldst & ~3);
+                    if (!(ldst & 1)) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * UW_XPIECE) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
+                    }
+                    if (!(ldst & 2)) {                           // the second voxel: parity 0, one parity block back and one index on
+#pragma unroll
+                        for (int p = 0; p < NP; ++p)
+                            *reinterpret_cast<u32x4*>(d + p * UW_XPIECE - UW_ROWV * 32 + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                    }
+                }
+            } else if (lbuf >= 0) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    char* const d = Ls + lbuf * CF::LBUF + (x_pl * NP + p) * NCI * UW_LTILE + ldst;
+                    *reinterpret_cast<u32x4*>(d) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
+                    *reinterpret_cast<u32x4*>(d + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                }
+            }
+        };
+
+        __syncthreads();                                        // every wave is done with the previous task
+        load_phase(0, 4, 0);                                    // planes 0 .. 3, tiles 0, 1
+        publish_max(0);
+        __syncthreads();
+        take_scales(0, 0, 4, 0);
+        split_tile();
+        write_phase(0, 4, 0);
+        load_phase(4, 2, -1);                                   // planes 4, 5
+        publish_max(1);
+        __syncthreads();
+        take_scales(1, 4, 2, -1);
+        split_tile();
+        write_phase(4, 2, -1);
+        __syncthreads();
+        for (int t = 0; t < nphase; ++t) {
+            const bool more = t + 1 < nphase;
+            const int lcur = t & 1;
+            load_phase(4 * t + 6, 4, more ? UW_TPP * (t + 1) : -1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma nounroll
+            for (int u = 0; u < UW_TPP; ++u) {                   // (not unrolled: the two tiles' fragment reads side by side cost 44 spilled registers)
+                const int slot = (4 * t + 2 * u + ad) % UW_RING;
+                const char* const xp = Xs + slot * UW_PLANE;
+                const float unscale = Tab[slot] * Tab[10 + lcur];
+                u32x4 bl[NCI][NP];                               // x0 fragments (B operand): K = (low-res row, 16 voxels)
+#pragma unroll
+                for (int c = 0; c < NCI; ++c)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const int lb = lcur * CF::LBUF + ((u * NP + p) * NCI + c) * UW_LTILE + lp;
+                        const u32x2 lo = s3_tr_read(Ls, lb), hi = s3_tr_read(Ls, lb + 16 * 32);
+                        bl[c][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+                    }
+#pragma unroll
+                for (int aw = 0; aw < 4; ++aw) {
+                    u32x4 az[NP];                                // dz fragment (A operand) of offset (ad, ah, aw): rows ah and ah + 2, parity aw & 1, from index aw >> 1
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const int zb = p * UW_XPIECE + ((ah * 2 + (aw & 1)) * UW_ROWV + (aw >> 1)) * 32 + lp;
+                        const u32x2 lo = s3_tr_read(xp, zb), hi = s3_tr_read(xp, zb + 2 * 2 * UW_ROWV * 32);
+                        az[p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+                    }
+#pragma unroll
+                    for (int c = 0; c < NCI; ++c) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int tp = 0; tp < P::NPROD; ++tp) acc = P::mfma(az[P::PA[tp]], bl[c][P::PB[tp]], acc);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tot[aw][c][j] = __builtin_fmaf(acc[j], unscale, tot[aw][c][j]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" ::"v"(vk));
+            publish_max(0);
+            __syncthreads();                                     // every wave is done reading this phase; the maxima of the next are published
+            if (more) {
+                take_scales(0, 4 * t + 6, 4, lcur ^ 1);
+                split_tile();
+                write_phase(4 * t + 6, 4, lcur ^ 1);
+            }
+            __syncthreads();
+        }
+    }
+    // ---- partials: part[bx][cot][a = (ad, ah, aw)][co 16][ci 16 NCI]; lane (kg, n) holds co = 4 kg + j, ci = 16 c + n
+    float* const pp = part + (((size_t)bx * NCOT + cot) * 64 + (ad * 4 + ah) * 4) * (16 * 16 * NCI);
+#pragma unroll
+    for (int aw = 0; aw < 4; ++aw)
+#pragma unroll
+        for (int c = 0; c < NCI; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pp[(size_t)aw * (16 * 16 * NCI) + (4 * (lane >> 4) + j) * (16 * NCI) + c * 16 + (lane & 15)] = tot[aw][c][j];
+}
+
+// gw[co][ci][tap] (row length gw_cin, the first C0 input channels) = sum over the blocks' partials and over the offsets of the tap, fixed order
+__global__ void __launch_bounds__(256) k_s3u_bww_reduce(const float* __restrict__ part, float* __restrict__ gw, int C0, int Cout, int gw_cin, int NCI,
+                                                        int NCOT, int NBLK) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int n = Cout * C0 * 27;
+    if (e >= n) return;
+    const int tap = e % 27, ci = (e / 27) % C0, co = e / (27 * C0);
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    const int cot = co >> 4, col = co & 15;
+    const size_t per_a = (size_t)16 * 16 * NCI, per_blk = (size_t)NCOT * 64 * per_a;
+    const float* const p0 = part + (size_t)cot * 64 * per_a + (size_t)col * (16 * NCI) + ci;
+    // offsets index (a + 1) that feed tap k: k = 0: {2, 3}; k = 1: {1, 2}; k = 2: {0, 1}
+    const int d0 = 2 - kd, h0 = 2 - kh, w0 = 2 - kw;
+    float s = 0.0f;
+    for (int blk = 0; blk < NBLK; ++blk) {
+        const float* const pb = p0 + (size_t)blk * per_blk;
+        float t = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int a = ((d0 + (i >> 2)) * 4 + (h0 + ((i >> 1) & 1))) * 4 + (w0 + (i & 1));
+            t += pb[(size_t)a * per_a];
+        }
+        s += t;
+    }
+    gw[((size_t)co * gw_cin + ci) * 27 + tap] = s;
+}
+
 int su_cus() {
     static const int cus = [] {
         int dev = 0; hipDeviceProp_t p;
@@ -816,6 +1085,24 @@ void sd_launch(const float* dz, long long dz_bs, int Cout, const void* wp, float
     }
     hipLaunchKernelGGL((k_s3u_dlow<NCT, NP>), dim3(gx, G), dim3(SU_THREADS), C::LDS_BYTES, s, dz, dz_bs, Cout, static_cast<const u32x4*>(wp), gxl, gxl_bs,
                        C0, mask, mask_bs, mask_slope, B, D, H, W);
+}
+
+
+struct UwTasks { int ncol, nseg, seg_len, nh, nw, NBLK; };
+UwTasks uw_tasks(int ncot, int B, int D, int H, int W) {
+    UwTasks tk;
+    const int Dl = D / 2, Hl = H / 2, Wl = W / 2;
+    tk.nh = (Hl + 1) / 2; tk.nw = (Wl + 15) / 16;
+    tk.ncol = B * tk.nh * tk.nw;
+    const int nb = su_cus() / ncot > 0 ? su_cus() / ncot : 1;
+    int nseg = (4 * nb + tk.ncol - 1) / tk.ncol;
+    if (nseg > Dl) nseg = Dl;
+    if (nseg < 1) nseg = 1;
+    tk.seg_len = (Dl + nseg - 1) / nseg;
+    tk.nseg = (Dl + tk.seg_len - 1) / tk.seg_len;
+    const long long ntask = (long long)tk.ncol * tk.nseg;
+    tk.NBLK = (int)(nb < ntask ? nb : ntask);
+    return tk;
 }
 
 }  // namespace
@@ -911,6 +1198,55 @@ int vxm_conv3d_k3_s3u_bwd_low(const float* dz, int64_t dz_bstride, int Cout, con
     if (su_nct(C0) == 2) sd_launch<2, 2>(dz, dz_bstride, Cout, wpacked, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, B, D, H, W, s);
     else sd_launch<1, 2>(dz, dz_bstride, Cout, wpacked, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, B, D, H, W, s);
     return vxm_check_launch("vxm_conv3d_k3_s3u_bwd_low");
+}
+
+/* backward-weight of the upsampled segment, collapsed, on the fp16 scheme (k_s3u_bww): gw[co][0:C0][tap] inside a [Cout][gw_cin][27] array */
+int vxm_conv3d_k3_s3u_bwd_weight_ok(int C0, int Cout, int B, int D, int H, int W, int pieces) {
+    if (pieces != 2 || (C0 != 16 && C0 != 32) || Cout <= 0 || Cout % 16 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (((D | H) & 1) || (W & 3)) return 0;                       // even extents; W / 2 even (the x0 staging loads voxel pairs)
+    if ((long long)(C0 > Cout ? C0 : Cout) * D * H * W >= (1ll << 29)) return 0;
+    if (Cout / 16 > su_cus()) return 0;
+    // measured (tools/s3_bench.py, same box): 0.95 against 1.18 ms at 160x192x224 (6720 tiles of 4 x 2 x 16 low-res voxels), but 0.235 against
+    // 0.204 ms at 80x96x112 (840 tiles: a block's task ranges are too short for its two-phase prologue) -- the half-resolution level keeps
+    // the fp32-MFMA kernel.  VXM_S3U_BWW_MIN_TILES overrides (tests).
+    static const long long min_tiles = [] { const char* e = getenv("VXM_S3U_BWW_MIN_TILES"); return e ? atoll(e) : 4096ll; }();
+    const long long ntiles = (long long)B * ((D / 2 + 3) / 4) * ((H / 2 + 1) / 2) * ((W / 2 + 15) / 16);
+    return ntiles >= min_tiles ? 1 : 0;
+}
+
+size_t vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes(int C0, int Cout, int B, int D, int H, int W) {
+    if (C0 <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const int NCOT = (Cout + 15) / 16, NCI = (C0 + 15) / 16;
+    const UwTasks tk = uw_tasks(NCOT, B, D, H, W);
+    return (size_t)tk.NBLK * NCOT * 64 * 16 * 16 * NCI * sizeof(float);
+}
+
+int vxm_conv3d_k3_s3u_bwd_weight(const float* x0, int C0, int64_t x0_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw, int gw_cin,
+                                 void* work, size_t work_bytes, int B, int D, int H, int W, int pieces, void* stream) {
+    VXM_REQUIRE(x0 && dz && gw && work, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3u_bwd_weight: null pointer");
+    if (int e = check_conv("vxm_conv3d_k3_s3u_bwd_weight", C0, 0, 1, Cout, B, D, H, W)) return e;
+    VXM_REQUIRE(pieces == 2 && (C0 == 16 || C0 == 32) && Cout % 16 == 0 && C0 <= gw_cin && W % 4 == 0, VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3u_bwd_weight: %d upsampled channels (16 or 32) of %d, %d outputs (multiple of 16), W = %d (multiple of 4), pieces %d (2)",
+                C0, gw_cin, Cout, W, pieces);
+    const int NCOT = Cout / 16, NCI = C0 / 16;
+    const UwTasks tk = uw_tasks(NCOT, B, D, H, W);
+    VXM_REQUIRE(work_bytes >= (size_t)tk.NBLK * NCOT * 64 * 16 * 16 * NCI * sizeof(float), VXM_ERR_WORKSPACE, "vxm_conv3d_k3_s3u_bwd_weight: workspace too small");
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3u_bww<1>), hipFuncAttributeMaxDynamicSharedMemorySize, UwCfg<1>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3u_bww<2>), hipFuncAttributeMaxDynamicSharedMemorySize, UwCfg<2>::LDS_BYTES);
+        return true;
+    }();
+    (void)attr;
+    hipStream_t s = VXM_STREAM(stream);
+    float* part = static_cast<float*>(work);
+    if (NCI == 2)
+        hipLaunchKernelGGL(k_s3u_bww<2>, dim3(tk.NBLK * NCOT), dim3(UW_THREADS), UwCfg<2>::LDS_BYTES, s, x0, (long long)x0_bstride, C0, dz,
+                           (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw);
+    else
+        hipLaunchKernelGGL(k_s3u_bww<1>, dim3(tk.NBLK * NCOT), dim3(UW_THREADS), UwCfg<1>::LDS_BYTES, s, x0, (long long)x0_bstride, C0, dz,
+                           (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw);
+    hipLaunchKernelGGL(k_s3u_bww_reduce, dim3(vxm_blocks((long long)Cout * C0 * 27, 256)), dim3(256), 0, s, part, gw, C0, Cout, gw_cin, NCI, NCOT, tk.NBLK);
+    return vxm_check_launch("vxm_conv3d_k3_s3u_bwd_weight");
 }
 
 }  // extern "C"

@@ -95,5 +95,14 @@ template <> struct S3P<2> {
     static constexpr unsigned ONES = 0x3c003c00u;                                      // fp16 1.0 x 2
 };
 
+// the transposing LDS read of gfx950 (ds_read_b64_tr_b16): from 16 consecutive 32-byte rows [voxel][16 channels] a lane receives four
+// consecutive voxels of one channel -- half of a K = 32 MFMA operand of a contraction over voxels (lane pattern: tools/probe/tr16_probe.hip)
+__device__ __forceinline__ u32x2 s3_tr_read(const char* lds_base, int byte_off) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)(lds_base + byte_off));
+    return __builtin_bit_cast(u32x2, v);
+}
+
 }  // namespace
 #endif

@@ -559,9 +559,29 @@ def s3_bwd_weight(ws, x, c, bs, dz, cout, gw, gw_cin, ci_off, gb, B, D, H, W):
              B, D, H, W, s3_pieces(), stream())
 
 
+def s3u_bwd_weight_route(c0, cout, B, D, H, W):
+    """does the weight gradient of an upsampled segment go to the split + collapsed kernel (csrc/conv_s3u.hip: k_s3u_bww)?"""
+    return S3U and split_engine() and bool(_lib.lib().vxm_conv3d_k3_s3u_bwd_weight_ok(c0, cout, B, D, H, W, s3_pieces()))
+
+
+def s3u_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, gw_cin, B, D, H, W):
+    """gw[:, 0:c0] of a [cout][gw_cin][27] array: weight gradient of the x2-upsampled segment x0 [B,c0,D/2,H/2,W/2] against dz [B,cout,D,H,W]"""
+    need = _lib.lib().vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes(c0, cout, B, D, H, W)
+    buf = ws.get(need)
+    with _prof.region("k_s3u_bww<%d>" % (c0 // 16), flops=2.0 * 8 * c0 * cout * B * D * H * W, nominal=2.0 * 27 * c0 * cout * B * D * H * W):
+        call("vxm_conv3d_k3_s3u_bwd_weight", ptr(x0), c0, bs0, ptr(dz), cout * D * H * W, cout, ptr(gw), gw_cin, ptr(buf), buf.numel(),
+             B, D, H, W, s3_pieces(), stream())
+
+
 def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H, W):
     if split_engine() and not up0 and x1 is None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c0, cout, B, D, H, W):
         s3_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, c0, 0, gb, B, D, H, W)
+        return
+    if up0 and x1 is not None and s3u_bwd_weight_route(c0, cout, B, D, H, W) and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c1, cout, B, D, H, W):
+        # cat([upsample(x0), x1]) on the split engine: the upsampled segment through the collapsed split kernel (conv_s3u.hip: k_s3u_bww), the
+        # full-resolution skip segment (and the bias gradient) through k_s3_bwd_weight, each into its channel range of gw
+        s3u_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, c0 + c1, B, D, H, W)
+        s3_bwd_weight(ws, x1, c1, bs1, dz, cout, gw, c0 + c1, c0, gb, B, D, H, W)
         return
     if split_engine() and up0 and x1 is not None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c1, cout, B, D, H, W) and \
             _lib.lib().vxm_conv3d_k3_bwd_weight_variant(ptr(x0), c0, bs0, 1, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, D, H, W) // 10 == 2:
