@@ -70,7 +70,9 @@ struct S3Cfg {
 
 // wp: [G][Q]{[NS][kh 3][piece NP][NCT][64 lanes], [RT][piece NP][NCT][64 lanes]} 16-byte words (k_s3_pack_weights), NP = 2: followed by one
 // trailer word {1 / weight scale, weight scale, -, -}.  Q0 chunks cover segment 0.
-template <int NCT, int ROWS, int CB, int NP>
+// RUN (NP = 2 only): the tile's accumulators take the MFMA chains directly and carry a RUNNING power-of-two scale (as conv_s3u.hip) instead of
+// a per-chunk accumulator set folded by the vector ALU: 4 NCT ROWS registers fewer -- what lets the 8-row tile keep two blocks per CU.
+template <int NCT, int ROWS, int CB, int NP, bool RUN = false>
 __global__ void __launch_bounds__(S3_THREADS, (S3Cfg<NCT, ROWS, CB, NP>::MIN_WAVES))
 k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout,
           float act_slope, const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W, int Q0, int Q) {
@@ -184,7 +186,9 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
         }
     };
     float inv_cur = 1.0f;                                    // NP = 2: 1 / scale of the chunk that is in LDS
-    auto store_chunk = [&](int q) __attribute__((always_inline)) {
+    int E_run = 15;                                          // RUN: exponent field the running scale of the tile is built from
+    float ratio = 1.0f;                                      // RUN: what the accumulators are multiplied by before the MFMAs of the chunk just stored
+    auto store_chunk = [&](int q, bool first = false) __attribute__((always_inline)) {
         // (an opaque copy of the thread index: the slot arithmetic below is loop-invariant, and hoisted out of the tile loop it would
         // occupy registers across the MFMA phases -- 24 spilled VGPRs in the 128-register instance)
         int tid = tid_;
@@ -199,7 +203,17 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
         if constexpr (NP == 2) {
             const f32x4 m0 = *reinterpret_cast<const f32x4*>(Wm), m1 = *reinterpret_cast<const f32x4*>(Wm + 4);
             const float mx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
-            s3_scale_of(mx, sc, inv_cur);
+            if constexpr (RUN) {
+                int E = (int)(__float_as_uint(mx) >> 23) & 255;
+                E = E < 15 ? 15 : E;
+                const int E_new = first ? E : (E > E_run ? E : E_run), dE = E_new - E_run;
+                ratio = (first || dE == 0) ? 1.0f : (dE > 126 ? 0.0f : __uint_as_float((unsigned)(127 - dE) << 23));
+                E_run = E_new;
+                sc = __uint_as_float((unsigned)(268 - E_run) << 23);
+                inv_cur = __uint_as_float((unsigned)(E_run - 14) << 23);
+            } else {
+                s3_scale_of(mx, sc, inv_cur);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -227,7 +241,7 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     set_tile(t_lo);
     load_chunk(0);
     if constexpr (NP == 2) { publish_max(); __syncthreads(); }
-    store_chunk(0);
+    store_chunk(0, true);
     for (int tile = t_lo; tile < t_hi; tile += t_step) {
     const int cd0 = d0, ch0 = h0, cw0 = w0, cbt = bt;           // the tile being computed (the staging tile moves on under its last chunk)
     __syncthreads();                                            // chunk 0 of this tile is in LDS
@@ -236,6 +250,7 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float inv_fin = 1.0f;
     for (int q = 0; q < Q; ++q) {
         const bool last = q + 1 == Q;                           // wave-uniform
         if (last) set_tile(tile + t_step);
@@ -244,14 +259,22 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
         load_chunk(last ? 0 : q + 1);
         // NP = 3: the MFMA chains run into the tile's accumulators.  NP = 2: a chain lives for this chunk (its operands carry this chunk's
         // scale) and is folded into the tile's accumulators below.
-        f32x4 accq[NCT][ROWS];                                  // (NP = 3: unused, eliminated)
-        if constexpr (NP == 2) {
+        f32x4 accq[NCT][ROWS];                                  // (NP = 3 / RUN: unused, eliminated)
+        if constexpr (NP == 2 && !RUN) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r) accq[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-        f32x4 (&A_)[NCT][ROWS] = s3_sel<NP == 2>(accq, acc);
+        if constexpr (NP == 2 && RUN) {
+            if (ratio != 1.0f) {                                // wave-uniform: this chunk raised the tile's running maximum
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r) acc[ct][r] *= ratio;
+            }
+        }
+        f32x4 (&A_)[NCT][ROWS] = s3_sel<(NP == 2 && !RUN)>(accq, acc);
         // ---- NS K-steps x (ROWS + 2) haloed rows: NP B pieces per row, up to 3 kh x NCT x NPROD piece products per read set.
         // The B pieces of row hr + 1 are requested before the MFMAs of row hr (register double buffer; sched_barrier pins the order:
         // unpinned, the compiler sinks every ds_read to right before its first use and the wave stalls on LDS latency once per row).
@@ -311,12 +334,16 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
         }
         keep_offsets();
         if constexpr (NP == 2) {
+            if constexpr (!RUN) {
 #pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
+                for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-                for (int r = 0; r < ROWS; ++r)
+                    for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[ct][r][j] = __builtin_fmaf(accq[ct][r][j], inv_cur, acc[ct][r][j]);
+                        for (int j = 0; j < 4; ++j) acc[ct][r][j] = __builtin_fmaf(accq[ct][r][j], inv_cur, acc[ct][r][j]);
+            } else if (last) {
+                inv_fin = inv_cur;                  // the scale the finished accumulators carry (store_chunk below moves on to the next tile)
+            }
             publish_max();                          // of the chunk in flight (q + 1, or chunk 0 of the next tile)
         }
         __syncthreads();                            // every wave is done reading chunk q
@@ -324,14 +351,15 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
             store_chunk(q + 1);
             __syncthreads();
         } else if (tile + t_step < t_hi) {
-            store_chunk(0);                         // chunk 0 of the next tile; the barrier at the top of the tile loop publishes it
+            store_chunk(0, true);                   // chunk 0 of the next tile; the barrier at the top of the tile loop publishes it
         }
     }
 
     // ---- epilogue: the D layout of the bf16 MFMA is the fp32 one's (lane (kg, n): channels 4 kg + j of voxel column n):
     // bias + LeakyReLU (+ fused leaky_relu_backward mask), planar fp32 store, shared with the fp32-MFMA kernels
     if constexpr (NP == 2) {
-        const float inv_w = __uint_as_float(__builtin_amdgcn_readfirstlane((int)wp[(size_t)gridDim.y * Q * WCH].x));      // trailer of the packed operator
+        float inv_w = __uint_as_float(__builtin_amdgcn_readfirstlane((int)wp[(size_t)gridDim.y * Q * WCH].x));      // trailer of the packed operator
+        if constexpr (RUN) inv_w *= inv_fin;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
@@ -957,22 +985,22 @@ size_t s3_packed_words(int seg0, int seg1, int OutC, int NP) {
 }
 bool s3_pieces_ok(int np) { return np == 2 || np == 3; }
 
-template <int NCT, int ROWS, int CB, int NP>
+template <int NCT, int ROWS, int CB, int NP, bool RUN = false>
 void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, long long y_bs, int Cout, float slope, const float* mask,
                long long mask_bs, float mask_slope, int B, int D, int H, int W, hipStream_t s) {
     using C = S3Cfg<NCT, ROWS, CB, NP>;
     static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_conv<NCT, ROWS, CB, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_conv<NCT, ROWS, CB, NP, RUN>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (getenv("VXM_S3_DEBUG")) {             // developer switch: what the runtime says about co-residency
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_s3_conv<NCT, ROWS, CB, NP>, S3_THREADS, C::LDS_BYTES);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_s3_conv<NCT, ROWS, CB, NP, RUN>, S3_THREADS, C::LDS_BYTES);
             fprintf(stderr, "k_s3_conv<%d,%d,%d,%d>: %d bytes of LDS, %d block(s) per CU\n", NCT, ROWS, CB, NP, C::LDS_BYTES, nb);
         }
         return true;
     }();
     (void)attr;
     const int Q0 = s3_chunks(in.C0, CB), Q = Q0 + s3_chunks(in.C1, CB);
-    const long long ntiles = (long long)B * ((D + S3_TD - 1) / S3_TD) * ((H + ROWS - 1) / ROWS) * ((W + 15) / 16);
+    const long long ntiles = (long long)B * ((D + S3_TD - 1) / S3_TD) * ((H + ROWS - 1) / ROWS) * ((W + 15) / 16);       // (of THIS instance's tiles)
     unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
     const int G = (Cout + 16 * NCT - 1) / (16 * NCT);
     // A grid of at most n blocks per CU whose blocks walk their XCD's tile range (VXM_S3_PERSIST=n: n per CU, 0: one tile per block).
@@ -989,7 +1017,7 @@ void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, lo
         const unsigned cap = 8 * ((want + 7) / 8);
         if (cap < gx) gx = cap;
     }
-    hipLaunchKernelGGL((k_s3_conv<NCT, ROWS, CB, NP>), dim3(gx, G), dim3(S3_THREADS), C::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
+    hipLaunchKernelGGL((k_s3_conv<NCT, ROWS, CB, NP, RUN>), dim3(gx, G), dim3(S3_THREADS), C::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
                        Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q);
 }
 
@@ -1070,8 +1098,14 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
         if (pieces == 2) s3_launch<NCT, 4, CB, 2>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s); \
         else s3_launch<NCT, 4, CB, 3>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);            \
     } while (0)
-    if (v.NCT == 2) S3_GO(2, 1);
+    // 16-channel operators on the fp16 scheme: 8 x 8 x 16 tiles (halo 1.76 instead of 2.11 staged voxels per output voxel) with the running
+    // scale; VXM_S3_ROWS=4 keeps the 8 x 4 x 16 tiles (A/B)
+    static const bool rows8 = [] { const char* e = getenv("VXM_S3_ROWS"); return !(e && e[0] == '4'); }();
+    if (v.NCT == 2 && pieces == 2 && rows8 && H >= 8 && v.CB == 1)
+        s3_launch<2, 8, 1, 2, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
+    else if (v.NCT == 2) S3_GO(2, 1);
     else if (v.CB == 2) S3_GO(1, 2);
+    else if (pieces == 2 && rows8 && H >= 8) s3_launch<1, 8, 1, 2, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
     else S3_GO(1, 1);
 #undef S3_GO
     return vxm_check_launch("vxm_conv3d_k3_s3_fwd");
