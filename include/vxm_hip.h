@@ -318,6 +318,7 @@ int vxm_bf16_lrelu_bwd(const void* g, const void* y, void* dz, float slope, int6
  * vxm_conv3d_k3_s3_ok: 1 when the split kernel takes a launch of this shape (otherwise use vxm_conv3d_k3_fwd). */
 int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W);
 int vxm_conv3d_k3_s3_variant(int Cout);                     /* 10 * NCT + CB of the kernel instance (profiling labels) */
+int vxm_conv3d_k3_s3_tile_rows(int Cout, int pieces, int H); /* rows of its output tile: 8 x 8 x 16 on the fp16 scheme, else 8 x 4 x 16 */
 /* packed, pre-split weights of one operator: seg0 / seg1 = input channels of the two segments of the virtual concat it reads */
 size_t vxm_conv3d_k3_s3_packed_bytes(int seg0, int seg1, int OutC, int pieces);
 typedef struct VxmS3PackJob {

@@ -1039,6 +1039,12 @@ int vxm_conv3d_k3_s3_variant(int Cout) {
     return 10 * v.NCT + v.CB;
 }
 
+/* rows of the output tile the launch of vxm_conv3d_k3_s3_fwd will use (profiling labels): 8 on the fp16 scheme with 8-channel chunks, else 4 */
+int vxm_conv3d_k3_s3_tile_rows(int Cout, int pieces, int H) {
+    static const bool rows8 = [] { const char* e = getenv("VXM_S3_ROWS"); return !(e && e[0] == '4'); }();
+    return (pieces == 2 && rows8 && H >= 8 && s3_variant(Cout).CB == 1) ? 8 : 4;
+}
+
 size_t vxm_conv3d_k3_s3_packed_bytes(int seg0, int seg1, int OutC, int pieces) {
     if (seg0 <= 0 || seg1 < 0 || OutC <= 0 || !s3_pieces_ok(pieces)) return 0;
     return (s3_packed_words(seg0, seg1, OutC, pieces) + (pieces == 2 ? 1 : 0)) * 16;

@@ -465,7 +465,8 @@ def s3u_bwd_low(dz, cout, w, c0, cin, gxl, mask, mask_slope, B, D, H, W):
 
 def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
     v = _lib.lib().vxm_conv3d_k3_s3_variant(cout)
-    with _prof.region("k_s3_conv<%d,4,%d,%d>" % (v // 10, v % 10, s3_pieces()), flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+    rows = _lib.lib().vxm_conv3d_k3_s3_tile_rows(cout, s3_pieces(), H) if _prof.ACTIVE is not None else 4
+    with _prof.region("k_s3_conv<%d,%d,%d,%d>" % (v // 10, rows, v % 10, s3_pieces()), flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_conv3d_k3_s3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
              cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, s3_pieces(), stream())
 
