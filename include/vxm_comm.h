@@ -19,7 +19,8 @@ const char* vxm_comm_last_error_string(void);
  * (the torchrun store, a file, MPI ...) */
 int vxm_comm_unique_id(void* out /* VXM_COMM_UNIQUE_ID_BYTES */);
 /* collective over all ranks: binds the communicator to the CURRENT HIP device of the calling process.  Bounded: if the other ranks
- * do not join within VXM_COMM_INIT_TIMEOUT_S seconds (default 180) it returns status 5 instead of blocking for ever. */
+ * do not join within VXM_COMM_INIT_TIMEOUT_S seconds (default 180) it returns status 5 instead of blocking for ever (a communicator
+ * that completes after the caller gave up is aborted by the helper thread that built it: no leak, no half-member). */
 int vxm_comm_init(int rank, int world, const void* unique_id);
 int vxm_comm_world(void);                      /* ranks of the communicator (ncclCommCount at init); 0 before init */
 int vxm_comm_rccl_version(void);               /* ncclGetVersion code of the RCCL the library resolved to (e.g. 22606); 0 on failure */
@@ -27,6 +28,8 @@ int vxm_comm_rccl_version(void);               /* ncclGetVersion code of the RCC
 int vxm_allreduce_sum_f32(float* buf, int64_t n, void* stream);
 int vxm_broadcast_f32(float* buf, int64_t n, int root, void* stream);
 int vxm_comm_destroy(void);
+/* ncclCommAbort: give up a communicator whose collective can no longer complete (a peer failed before entering it); frees it */
+int vxm_comm_abort(void);
 
 #ifdef __cplusplus
 }

@@ -393,6 +393,28 @@ def test_conv_block_vs_oracle(vxm, cin, cout, vol, slope):
     assert rel_l2(N(bg.grad), bo.grad.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("ndims,stride", [(3, 2), (3, 3), (2, 2)])
+def test_conv_block_with_a_stride_vs_fp64(vxm, ndims, stride):
+    """`ConvBlock(ndims, cin, cout, stride)` (networks.py:295-299): the reference accepts any stride; here it is the stride-1 block sampled at
+    every stride-th voxel.  Output and all three gradients against fp64 torch of the reference's op sequence."""
+    torch.manual_seed(40 + ndims + stride)
+    vol = (9, 12, 14)[3 - ndims:]
+    blk = vxm.networks.ConvBlock(ndims, 5, 7, stride).cuda()
+    x = torch.randn((2, 5) + vol, device="cuda", requires_grad=True)
+    y = blk(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    conv = torch.nn.functional.conv3d if ndims == 3 else torch.nn.functional.conv2d
+    xd = x.detach().cpu().double().requires_grad_()
+    wd, bd = blk.main.weight.detach().cpu().double().requires_grad_(), blk.main.bias.detach().cpu().double().requires_grad_()
+    yd = torch.nn.functional.leaky_relu(conv(xd, wd, bd, stride=stride, padding=1), 0.2)
+    assert tuple(y.shape) == tuple(yd.shape)
+    yd.backward(gy.cpu().double())
+    assert rel_l2(N(y), yd.detach().numpy()) < 1e-5
+    assert rel_l2(N(x.grad), xd.grad.numpy()) < 1e-5 and rel_l2(N(blk.main.weight.grad), wd.grad.numpy()) < 1e-5
+    assert rel_l2(N(blk.main.bias.grad), bd.grad.numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("cin,cout,vol", [(8, 2, (8, 8, 16)), (16, 3, (8, 8, 16)), (5, 7, (6, 7, 20)), (24, 20, (8, 8, 32)), (3, 16, (8, 12, 16))])
 def test_conv_block_output_guard(vxm, cin, cout, vol):
     """The epilogues store through buffer descriptors and let the hardware drop lanes that are out of range: channel counts that do

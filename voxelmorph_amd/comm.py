@@ -26,6 +26,7 @@ SIGNATURES = {
     "vxm_allreduce_sum_f32": [_c.c_void_p, _c.c_int64, _c.c_void_p],
     "vxm_broadcast_f32": [_c.c_void_p, _c.c_int64, _c.c_int, _c.c_void_p],
     "vxm_comm_destroy": [],
+    "vxm_comm_abort": [],
 }
 _lib = None
 
@@ -143,16 +144,27 @@ class NativeComm:
         try:
             probe = torch.full((1024,), float(rank + 1), device="cuda")
             comm.all_reduce_sum(probe)
-            torch.cuda.synchronize()
-            ok = bool((probe == world * (world + 1) / 2.0).all())
-            if not ok:
-                err = "self-check all-reduce returned %r, expected %r" % (float(probe[0]), world * (world + 1) / 2.0)
+            # BOUNDED wait: if a peer failed before entering this collective (its launch raised) it will never complete here, and an
+            # unbounded synchronize would keep this rank out of the agreement below for ever -- poll an event, abort on expiry
+            done = torch.cuda.Event()
+            done.record()
+            import time
+            deadline = time.monotonic() + float(os.environ.get("VXM_COMM_CHECK_TIMEOUT_S", "60"))
+            while not done.query() and time.monotonic() < deadline:
+                time.sleep(0.002)
+            if not done.query():
+                err = "self-check all-reduce did not complete within the time limit (a peer never entered it)"
+                comm.abort()
+            else:
+                ok = bool((probe == world * (world + 1) / 2.0).all())
+                if not ok:
+                    err = "self-check all-reduce returned %r, expected %r" % (float(probe[0]), world * (world + 1) / 2.0)
         except (VxmHipError, OSError, RuntimeError) as exc:
             err = str(exc)
         flags = agree(ok)
         if all(flags):
             return comm
-        comm.destroy()
+        comm.destroy()                                  # (no-op after an abort)
         report(flags, err, "self-check failed")
         return None
 
@@ -170,3 +182,7 @@ class NativeComm:
 
     def destroy(self):
         _call("vxm_comm_destroy")
+
+    def abort(self):
+        """ncclCommAbort: give up a communicator whose collective cannot complete (a peer failed before entering it)"""
+        _call("vxm_comm_abort")

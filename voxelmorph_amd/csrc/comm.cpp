@@ -59,20 +59,29 @@ int vxm_comm_init(int rank, int world, const void* unique_id) {
     // VXM_COMM_INIT_TIMEOUT_S seconds (default 180) and then reports an error instead of hanging (the helper is abandoned).
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return fail(4, "vxm_comm_init: no current HIP device");
-    struct Shared { std::mutex m; std::condition_variable cv; bool done = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr; };
+    struct Shared { std::mutex m; std::condition_variable cv; bool done = false, abandoned = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr; };
     auto sh = std::make_shared<Shared>();
     std::thread([sh, dev, world, id, rank] {
         ncclComm_t c = nullptr;
         ncclResult_t r = hipSetDevice(dev) == hipSuccess ? ncclCommInitRank(&c, world, id, rank) : ncclUnhandledCudaError;
-        std::lock_guard<std::mutex> lk(sh->m);
-        sh->res = r; sh->comm = c; sh->done = true;
-        sh->cv.notify_all();
+        bool late = false;
+        {
+            std::lock_guard<std::mutex> lk(sh->m);
+            sh->res = r; sh->comm = c; sh->done = true;
+            late = sh->abandoned;
+            sh->cv.notify_all();
+        }
+        // the caller gave up on this rank (timeout below) and told its peers so: a communicator that completes afterwards belongs to
+        // nobody -- abort it here, so that it neither leaks nor leaves peers that did finish with a member that reported failure
+        if (late && r == ncclSuccess && c) (void)ncclCommAbort(c);
     }).detach();
     const char* e = getenv("VXM_COMM_INIT_TIMEOUT_S");
     const long secs = e && atol(e) > 0 ? atol(e) : 180;
     std::unique_lock<std::mutex> lk(sh->m);
-    if (!sh->cv.wait_for(lk, std::chrono::seconds(secs), [&] { return sh->done; }))
+    if (!sh->cv.wait_for(lk, std::chrono::seconds(secs), [&] { return sh->done; })) {
+        sh->abandoned = true;
         return fail(5, "vxm_comm_init: ncclCommInitRank did not complete within %ld s (rank %d of %d): a rank is missing", secs, rank, world);
+    }
     if (sh->res != ncclSuccess) return fail(100 + (int)sh->res, "ncclCommInitRank: %s", ncclGetErrorString(sh->res));
     g_comm = sh->comm;
     int n = 0;
@@ -98,6 +107,15 @@ int vxm_broadcast_f32(float* buf, int64_t n, int root, void* stream) {
     if (!g_comm) return fail(3, "vxm_broadcast_f32: communicator not initialised");
     if (!buf || n <= 0 || root < 0 || root >= g_world) return fail(1, "vxm_broadcast_f32: bad arguments");
     COMM_CHECK(ncclBroadcast(buf, buf, (size_t)n, ncclFloat32, root, g_comm, reinterpret_cast<hipStream_t>(stream)), "ncclBroadcast");
+    return 0;
+}
+
+int vxm_comm_abort(void) {
+    if (!g_comm) return 0;
+    const ncclResult_t r = ncclCommAbort(g_comm);       // frees the communicator and abandons collectives that can no longer complete
+    g_comm = nullptr;
+    g_world = 0;
+    if (r != ncclSuccess) return fail(100 + (int)r, "ncclCommAbort: %s", ncclGetErrorString(r));
     return 0;
 }
 

@@ -42,17 +42,26 @@ class _Conv3dParams(nn.Module):
 
 
 class ConvBlock(nn.Module):
-    """ConvNd(3, stride 1, pad 1) + LeakyReLU(0.2) (reference: networks.py:290-305)."""
+    """ConvNd(3, stride, pad 1) + LeakyReLU(0.2) (reference: networks.py:290-305).  The U-Net only ever builds stride 1; a strided block
+    (accepted by the reference's constructor) is the stride-1 block's output sampled at every stride-th voxel -- with kernel 3 and padding
+    1 output i of the strided convolution IS output stride * i of the stride-1 one, and LeakyReLU commutes with the sampling -- so it runs
+    the same HIP kernels and takes a strided view (autograd zero-fills the skipped voxels on the way back)."""
 
     def __init__(self, ndims, in_channels, out_channels, stride=1):
         super().__init__()
-        if ndims not in (2, 3) or stride != 1:
-            raise NotImplementedError("the MI355X ConvBlock implements 2-D / 3-D, stride-1, kernel-3 convolutions")
+        if ndims not in (2, 3):
+            raise NotImplementedError("the MI355X ConvBlock implements 2-D / 3-D kernel-3 convolutions")
+        if int(stride) != stride or stride < 1:
+            raise ValueError("ConvBlock: stride must be a positive integer, got %r" % (stride,))
+        self.stride = int(stride)
         self.main = _Conv3dParams(in_channels, out_channels, ndims)
         self.activation = nn.LeakyReLU(0.2)          # attribute kept for parity; fused into the conv epilogue
 
     def forward(self, x):
-        return self.main(x, slope=0.2)
+        y = self.main(x, slope=0.2)
+        if self.stride != 1:
+            y = y[(slice(None), slice(None)) + (slice(None, None, self.stride),) * (y.dim() - 2)]
+        return y
 
 
 def _unet_feature_plan(nb_features, nb_levels, feat_mult, nb_conv_per_level):
