@@ -503,7 +503,7 @@ struct SwTasks { int ncol, nseg, seg_len, nd, nh, nw; };       // tasks = (colum
 template <int NP, bool PIPE2 = true>
 __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __restrict__ x, long long x_bs, int C, const float* __restrict__ dz,
                                                               long long dz_bs, int Cdz, float* __restrict__ part, int D, int H, int W, int NBLK,
-                                                              int NCO, SwTasks tk) {
+                                                              int NCO, SwTasks tk, int task_rr) {
     using P = S3P<NP>;
     using CF = SwCfg<NP>;
     VXM_DYN_SMEM(char, smem);
@@ -528,7 +528,19 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
     }
     const int q = combo / NCO, cot = combo - q * NCO;
     const int ntask = tk.ncol * tk.nseg;
-    const int k_lo = (int)((long long)ntask * bx / NBLK), k_hi = (int)((long long)ntask * (bx + 1) / NBLK);
+    // Which tasks this block walks.  Tasks are numbered depth-segment-major, columns (b, th, tw) consecutive, so task ids that are one
+    // apart are W-NEIGHBOURS at the same depth.  XCD x (= bx & 7: block ids map to XCDs round-robin) owns a contiguous task range and
+    // its blocks take the tasks of that range round-robin: at any moment the blocks of an XCD work on adjacent columns at the same depth,
+    // so the halo columns of a tile (w0 - 1 and w0 + 32: a 4-byte voxel each, a whole 64-byte sector from HBM) are hits in the XCD's L2
+    // when the neighbour already fetched that sector.  (Rounds 3 / early 4 gave every block a contiguous range of tasks: the counters
+    // showed 2.0 GB fetched per launch for 0.78 GB of operands.)  VXM_S3_BW_TASKS=range restores that order for A/B.
+    int k_lo, k_hi, k_step;
+    if ((NBLK & 7) == 0 && task_rr) {
+        const int x = bx & 7;
+        k_lo = (int)((long long)ntask * x / 8) + (bx >> 3); k_hi = (int)((long long)ntask * (x + 1) / 8); k_step = NBLK >> 3;
+    } else {
+        k_lo = (int)((long long)ntask * bx / NBLK); k_hi = (int)((long long)ntask * (bx + 1) / NBLK); k_step = 1;
+    }
     const int V = D * H * W, HW = H * W;
 
     f32x4 tot[3][3], totb = {0.f, 0.f, 0.f, 0.f};               // running totals (vector-ALU sums of the per-tile MFMA chains)
@@ -563,8 +575,8 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
                                                                  // a plane / the dZ tile, | 1: drop the first voxel, | 2: drop the second
     int vk[NSET];                                                // the offsets the in-flight loads were issued with (kept live until the MFMA phase is over)
 
-    for (int task = k_lo; task < k_hi; ++task) {
-        const int col = task / tk.nseg, seg = task - col * tk.nseg;
+    for (int task = k_lo; task < k_hi; task += k_step) {
+        const int seg = task_rr ? task / tk.ncol : task % tk.nseg, col = task_rr ? task - seg * tk.ncol : task / tk.nseg;      // (depth-segment-major when round-robin)
         const int tw = col % tk.nw; int cq = col / tk.nw;
         const int th = cq % tk.nh; const int b = cq / tk.nh;
         const int td0 = seg * tk.seg_len, ntile = min(tk.seg_len, tk.nd - td0);
@@ -1158,15 +1170,18 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
     hipStream_t s = VXM_STREAM(stream);
     float* part = static_cast<float*>(work);
     const char* pe = getenv("VXM_S3_BW_PIPE");                  // developer A/B switch: 1 = the two-barrier pipeline of the first fp16 version
+    const char* te = getenv("VXM_S3_BW_TASKS");                 // developer A/B switch: range = a contiguous task range per block (rounds 3 / early 4)
+    // (round-robin order: -8 .. -16 % at 160x192x224, +3 % at 80x96x112 -- same-box A/B, profiles/r04r_bw_task_order.txt)
+    const int task_rr = ((te && te[0] == 'r' && te[1] == 'a') || (long long)D * H * W < (1ll << 21)) ? 0 : 1;
     if (pieces == 2 && pe && pe[0] == '1')
         hipLaunchKernelGGL((k_s3_bwd_weight<2, false>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk);
+                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr);
     else if (pieces == 2)
         hipLaunchKernelGGL((k_s3_bwd_weight<2, true>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk);
+                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr);
     else
         hipLaunchKernelGGL((k_s3_bwd_weight<3, true>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<3>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk);
+                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr);
     const int n = 16 * NCO * 16 * Q * 28;
     hipLaunchKernelGGL(k_s3_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(1024), 0, s, part, gw, gb, C, Cout, gw_cin, ci_off, Q, NCO, NBLK);
     return vxm_check_launch("vxm_conv3d_k3_s3_bwd_weight");

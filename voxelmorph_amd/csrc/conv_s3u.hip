@@ -785,7 +785,7 @@ template <int NCI> struct UwCfg {
 template <int NCI>
 __global__ void __launch_bounds__(UW_THREADS, 4) k_s3u_bww(const float* __restrict__ x0, long long x0_bs, int C0, const float* __restrict__ dz,
                                                            long long dz_bs, int Cdz, float* __restrict__ part, int D, int H, int W, int NBLK,
-                                                           int ncol, int nseg, int seg_len, int nh, int nw) {
+                                                           int ncol, int nseg, int seg_len, int nh, int nw, int task_rr) {
     using CF = UwCfg<NCI>;
     using P = S3P<2>;
     constexpr int NP = 2;
@@ -809,7 +809,19 @@ __global__ void __launch_bounds__(UW_THREADS, 4) k_s3u_bww(const float* __restri
     }
     const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
     const int ntask = ncol * nseg;
-    const int k_lo = (int)((long long)ntask * bx / NBLK), k_hi = (int)((long long)ntask * (bx + 1) / NBLK);
+    // Which tasks this block walks.  Tasks are numbered depth-segment-major, columns (b, th, tw) consecutive, so task ids that are one
+    // apart are W-NEIGHBOURS at the same depth.  XCD x (= bx & 7: block ids map to XCDs round-robin) owns a contiguous task range and
+    // its blocks take the tasks of that range round-robin: at any moment the blocks of an XCD work on adjacent columns at the same depth,
+    // so the halo columns of a tile (w0 - 1 and w0 + 32: a 4-byte voxel each, a whole 64-byte sector from HBM) are hits in the XCD's L2
+    // when the neighbour already fetched that sector.  (Rounds 3 / early 4 gave every block a contiguous range of tasks: the counters
+    // showed 2.0 GB fetched per launch for 0.78 GB of operands.)  VXM_S3_BW_TASKS=range restores that order for A/B.
+    int k_lo, k_hi, k_step;
+    if ((NBLK & 7) == 0 && task_rr) {
+        const int x = bx & 7;
+        k_lo = (int)((long long)ntask * x / 8) + (bx >> 3); k_hi = (int)((long long)ntask * (x + 1) / 8); k_step = NBLK >> 3;
+    } else {
+        k_lo = (int)((long long)ntask * bx / NBLK); k_hi = (int)((long long)ntask * (bx + 1) / NBLK); k_step = 1;
+    }
     const int V = D * H * W, HW = H * W, Vl = Dl * Hl * Wl, HWl = Hl * Wl;
 
     f32x4 tot[4][NCI];
@@ -829,8 +841,8 @@ __global__ void __launch_bounds__(UW_THREADS, 4) k_s3u_bww(const float* __restri
     unsigned ka[NP][4], kb[NP][4];
     int off0 = VXM_OOB, ldst = 0, vk;
 
-    for (int task = k_lo; task < k_hi; ++task) {
-        const int col = task / nseg, seg = task - col * nseg;
+    for (int task = k_lo; task < k_hi; task += k_step) {
+        const int seg = task_rr ? task / ncol : task % nseg, col = task_rr ? task - seg * ncol : task / nseg;        // (depth-segment-major when round-robin)
         const int tw = col % nw; int cq = col / nw;
         const int th = cq % nh; const int b = cq / nh;
         const int md0 = seg * seg_len, ntile = min(seg_len, Dl - md0), nphase = (ntile + UW_TPP - 1) / UW_TPP;
@@ -1239,12 +1251,15 @@ int vxm_conv3d_k3_s3u_bwd_weight(const float* x0, int C0, int64_t x0_bstride, co
     (void)attr;
     hipStream_t s = VXM_STREAM(stream);
     float* part = static_cast<float*>(work);
+    const char* te = getenv("VXM_S3_BW_TASKS");
+    // (round-robin order: -8 .. -16 % at 160x192x224, +3 % at 80x96x112 -- same-box A/B, profiles/r04r_bw_task_order.txt)
+    const int task_rr = ((te && te[0] == 'r' && te[1] == 'a') || (long long)D * H * W < (1ll << 21)) ? 0 : 1;
     if (NCI == 2)
         hipLaunchKernelGGL(k_s3u_bww<2>, dim3(tk.NBLK * NCOT), dim3(UW_THREADS), UwCfg<2>::LDS_BYTES, s, x0, (long long)x0_bstride, C0, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw);
+                           (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw, task_rr);
     else
         hipLaunchKernelGGL(k_s3u_bww<1>, dim3(tk.NBLK * NCOT), dim3(UW_THREADS), UwCfg<1>::LDS_BYTES, s, x0, (long long)x0_bstride, C0, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw);
+                           (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw, task_rr);
     hipLaunchKernelGGL(k_s3u_bww_reduce, dim3(vxm_blocks((long long)Cout * C0 * 27, 256)), dim3(256), 0, s, part, gw, C0, Cout, gw_cin, NCI, NCOT, tk.NBLK);
     return vxm_check_launch("vxm_conv3d_k3_s3u_bwd_weight");
 }
