@@ -984,7 +984,9 @@ S3Variant s3_variant(int OutC) {
     return v;
 }
 long long s3_min_tiles() {
-    static const long long v = [] { const char* e = getenv("VXM_S3_MIN_TILES"); return e ? atoll(e) : 1024ll; }();
+    // 128 tiles of 8 x 4 x 16: the two finest levels and the 40 x 48 x 56 level of the headline shape (240 tiles; measured in the step with
+    // the level on the split kernels: 13.05 -> 12.81 ms, same box -- its backward-weight launches gain most); 20 x 24 x 28 (36 tiles) stays
+    static const long long v = [] { const char* e = getenv("VXM_S3_MIN_TILES"); return e ? atoll(e) : 128ll; }();
     return v;
 }
 int s3_chunks(int C, int CB) { return (C + 8 * CB - 1) / (8 * CB); }

@@ -229,7 +229,10 @@ __global__ void __launch_bounds__(256) k_ncc_fused_fwd(const float* __restrict__
     __shared__ double red[4];
     const int tid = threadIdx.x, wx = tid & 31, hy = tid >> 5;
     const int ntw = (W + NF_TW - 1) / NF_TW;
-    const int w0 = (blockIdx.x % ntw) * NF_TW, h0 = (blockIdx.x / ntw) * NF_TH;
+    // pixel column of this block: block ids go to the XCDs round-robin, so (when the count allows) XCD x takes a contiguous eighth of the
+    // columns -- the blocks it runs side by side are neighbours and share their 8-pixel halos in its L2
+    const int bcol = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    const int w0 = (bcol % ntw) * NF_TW, h0 = (bcol / ntw) * NF_TH;
     const int dlo = blockIdx.y * seg, dhi = min(D, dlo + seg);
     const size_t HW = (size_t)H * W, vol = (size_t)blockIdx.z * D * HW;
     const float n = (float)(WIN * WIN * WIN);
@@ -313,7 +316,10 @@ __global__ void __launch_bounds__(256) k_ncc_fused_bwd(const float* __restrict__
     __shared__ float Rw[3][PH][NF_TW];
     const int tid = threadIdx.x, wx = tid & 31, hy = tid >> 5;
     const int ntw = (W + NF_TW - 1) / NF_TW;
-    const int w0 = (blockIdx.x % ntw) * NF_TW, h0 = (blockIdx.x / ntw) * NF_TH;
+    // pixel column of this block: block ids go to the XCDs round-robin, so (when the count allows) XCD x takes a contiguous eighth of the
+    // columns -- the blocks it runs side by side are neighbours and share their 8-pixel halos in its L2
+    const int bcol = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    const int w0 = (bcol % ntw) * NF_TW, h0 = (bcol / ntw) * NF_TH;
     const int dlo = blockIdx.y * seg, dhi = min(D, dlo + seg);
     const size_t HW = (size_t)H * W, vol = (size_t)blockIdx.z * D * HW;
     const int gh = h0 + hy, gw = w0 + wx;
