@@ -526,7 +526,17 @@ __global__ void __launch_bounds__(bwb_threads(NCO), 1) k_bf16_conv_bwd_weight(Bf
         q = r % Q;
     }
     const int ntask = tk.ncol * tk.nseg;
-    const int k_lo = (int)((long long)ntask * bx / NBLK), k_hi = (int)((long long)ntask * (bx + 1) / NBLK);
+    // Which tasks this block walks (round 4, as k_s3_bwd_weight): tasks numbered depth-segment-major, columns consecutive; XCD x (= bx & 7)
+    // owns a contiguous task range and its blocks take the tasks of that range round-robin, so the blocks an XCD runs side by side work on
+    // W-neighbouring columns at the same depth and share the halo sectors in its L2.  Large volumes only (measured on the fp32 twin).
+    const bool task_rr = (NBLK & 7) == 0 && (long long)D * H * W >= (1ll << 21);
+    int k_lo, k_hi, k_step;
+    if (task_rr) {
+        const int x = bx & 7;
+        k_lo = (int)((long long)ntask * x / 8) + (bx >> 3); k_hi = (int)((long long)ntask * (x + 1) / 8); k_step = NBLK >> 3;
+    } else {
+        k_lo = (int)((long long)ntask * bx / NBLK); k_hi = (int)((long long)ntask * (bx + 1) / NBLK); k_step = 1;
+    }
 
     const int V = D * H * W;
     const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
@@ -553,8 +563,8 @@ __global__ void __launch_bounds__(bwb_threads(NCO), 1) k_bf16_conv_bwd_weight(Bf
     int xoff[NXI], zoff[NZI];                                    // byte offsets inside a depth slice of the tensor (VXM_OOB: padding)
     const int HWs = up ? Hl * Wl : H * W;                        // voxels per depth slice of the X source
 
-    for (int task = k_lo; task < k_hi; ++task) {
-        const int col = task / tk.nseg, seg = task - col * tk.nseg;
+    for (int task = k_lo; task < k_hi; task += k_step) {
+        const int seg = task_rr ? task / tk.ncol : task % tk.nseg, col = task_rr ? task - seg * tk.ncol : task / tk.nseg;
         const int tw = col % tk.nw; int cq = col / tk.nw;
         const int th = cq % tk.nh; const int b = cq / tk.nh;
         const int td0 = seg * tk.seg_len, ntile = min(tk.seg_len, tk.nd - td0);
