@@ -50,8 +50,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--json", type=str, default="")
+    ap.add_argument("--lib", type=str, default="", help="developer build to load instead of libvxm_hip.so (tools/build_exp.sh)")
+    ap.add_argument("--dbg", type=str, default="", help="comma list of VXM_S3_DBG words to time each forward / backward-data row with (--lib build)")
     args = ap.parse_args()
     from voxelmorph_amd import _lib
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     from voxelmorph_amd.torch import functional as VF
     shape = tuple(int(s) for s in args.shape.split(","))
     B = args.batch
@@ -95,6 +99,16 @@ def main():
         t_s3 = timed(run_s3, args.iters)
         t_nat = timed(run_nat, args.iters)
         VF.FP32_ENGINE = keep
+        if args.dbg:                                       # timing experiments (results wrong): alternate with the plain kernel, two rounds
+            words = [int(v) for v in args.dbg.split(",")]
+            res = {v: [] for v in [0] + words}
+            for _ in range(2):
+                for v in [0] + words:
+                    os.environ["VXM_S3_DBG"] = str(v)
+                    res[v].append(timed(run_s3, args.iters))
+            os.environ["VXM_S3_DBG"] = "0"
+            print("    dbg: " + " | ".join("%d: %s" % (v, "/".join("%.3f" % t for t in ts)) for v, ts in res.items()), flush=True)
+            run_s3()
         gf = 2.0 * 27 * cin * cout * B * V / 1e9
         diff = float((y_s3.double() - y_nat.double()).norm() / y_nat.double().norm())
         row = dict(op=name, gflop=gf, s3_ms=t_s3, s3_tflops=gf / t_s3, native_ms=t_nat, native_tflops=gf / t_nat, rel_l2_s3_vs_native=diff, s3_eligible=ok)

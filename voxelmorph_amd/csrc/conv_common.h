@@ -125,7 +125,7 @@ __device__ __forceinline__ void conv_load_bias(float (&bz)[NCT][4], const float*
 // offset is clamped into the tensor: the range check of a raw buffer compares the per-lane offset with num_records - soffset,
 // which must not be relied on once the scalar offset alone exceeds the range.)  Rows beyond H are skipped by a wave-uniform test.
 // HALVES = 16-voxel MFMA tiles side by side along W (acc index m = row * HALVES + half; needs W % (16 HALVES) == 0).
-template <int NCT, int ROWS, int HALVES = 1>
+template <int NCT, int ROWS, int HALVES = 1, int AUX = 0 /* cache policy bits of the stores (2: non-temporal) */>
 __device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS * HALVES], float* __restrict__ yb /* y + b * y_bs */, const float (&bz)[NCT][4],
                                                     const float* __restrict__ maskb /* mask + b * mask_bs or null */, float act_slope,
                                                     float mask_slope, int Cout, int g, int kq, bool vox_ok, int vox /* (d H + h0) W + w */,
@@ -167,7 +167,7 @@ __device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS * HAL
                         float v = acc[ct][r][j] + bz[ct][j];
                         v = (v > 0.0f ? v : v * act_slope) * mk[j][r];
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, ct * 16 + j < nvalid ? voff : VXM_OOB,
-                                                              (min(ct * 16 + j, navail - 1) * V + row * W + half * 16) << 2, 0);
+                                                              (min(ct * 16 + j, navail - 1) * V + row * W + half * 16) << 2, AUX);
                     }
             }
         }

@@ -27,6 +27,12 @@
 #include "conv_common.h"
 #include "s3_pieces.h"
 
+#ifdef VXM_S3_EXP
+#define S3_DBG(dbg, bit) (((dbg) & (bit)) != 0)
+#else
+#define S3_DBG(dbg, bit) false
+#endif
+
 namespace {
 
 constexpr int S3_TD = 8, S3_THREADS = 512, S3_HWV = 18;
@@ -75,7 +81,7 @@ struct S3Cfg {
 template <int NCT, int ROWS, int CB, int NP, bool RUN = false>
 __global__ void __launch_bounds__(S3_THREADS, (S3Cfg<NCT, ROWS, CB, NP>::MIN_WAVES))
 k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout,
-          float act_slope, const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W, int Q0, int Q) {
+          float act_slope, const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W, int Q0, int Q, int dbg) {
     using C = S3Cfg<NCT, ROWS, CB, NP>;
     using P = S3P<NP>;
     VXM_DYN_SMEM(u32x4, smem);
@@ -116,10 +122,17 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
         asm volatile("" : "+v"(tid));
         const bool live = tile < t_hi;                        // past the block's last tile: every slot is padding, nothing is fetched
         const int tl = live ? tile : t_lo;
-        const int tw = tl % nw; int tq = tl / nw;
-        const int th = tq % nh; tq /= nh;
-        const int td = tq % nd;
+        int tw = tl % nw; int tq = tl / nw;
+        int th = tq % nh; tq /= nh;
+        int td = tq % nd;
         bt = tq / nd;
+        if (S3_DBG(dbg, 64)) {                                  // depth fastest
+            td = tl % nd; tq = tl / nd; tw = tq % nw; tq /= nw; th = tq % nh; bt = tq / nh;
+        }
+        if (S3_DBG(dbg, 128)) {                                 // groups of (2 d, 2 h, every w); needs even nd, nh
+            const int gi = tl / (4 * nw), r = tl - gi * 4 * nw, ngh = nh >> 1, ngd = nd >> 1;
+            tw = r % nw; th = (gi % ngh) * 2 + ((r / nw) & 1); td = ((gi / ngh) % ngd) * 2 + ((r / nw) >> 1); bt = gi / (ngh * ngd);
+        }
         d0 = td * S3_TD; h0 = th * ROWS; w0 = tw * 16;
         r0 = vxm_rsrc(in.x0 + (size_t)bt * in.bs0, (unsigned)in.C0 * (unsigned)V0 * 4u);
         r1 = vxm_rsrc(in.C1 ? in.x1 + (size_t)bt * in.bs1 : in.x0, (unsigned)in.C1 * (unsigned)V * 4u);
@@ -129,7 +142,10 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
             const int cb = i / ((S3_TD + 2) * PUSED), rem = i - cb * (S3_TD + 2) * PUSED;
             const int hd = rem / PUSED, r2 = rem - hd * PUSED, hh = r2 / S3_HWV, hw = r2 - hh * S3_HWV;
             const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-            const bool ok = live && i < NSLOT && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            bool ok = live && i < NSLOT && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            if (S3_DBG(dbg, 1)) ok = false;                                                     // no global reads at all
+            if (S3_DBG(dbg, 16) && (hw == 0 || hw == 17)) ok = false;                           // no W halo: every row is one aligned 64-byte sector
+            if (S3_DBG(dbg, 32) && (hd == 0 || hd == S3_TD + 1 || hh == 0 || hh == ROWS + 1)) ok = false;      // no D / H halo
             spos[j] = ok ? (hd << 10 | hh << 5 | hw) : -1;
         }
     };
@@ -278,6 +294,7 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
         // ---- NS K-steps x (ROWS + 2) haloed rows: NP B pieces per row, up to 3 kh x NCT x NPROD piece products per read set.
         // The B pieces of row hr + 1 are requested before the MFMAs of row hr (register double buffer; sched_barrier pins the order:
         // unpinned, the compiler sinks every ds_read to right before its first use and the wave stalls on LDS latency once per row).
+        if (!S3_DBG(dbg, 2)) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             u32x4 a[3][NP][NCT], bf[2][NP];
@@ -332,6 +349,7 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        }
         keep_offsets();
         if constexpr (NP == 2) {
             if constexpr (!RUN) {
@@ -368,8 +386,12 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     const int d = cd0 + wave, w = cw0 + n;
     float bz[NCT][4];
     conv_load_bias<NCT>(bz, bias, Cout, g, kg);
+    if (S3_DBG(dbg, 8))
+        conv_epilogue_store<NCT, ROWS, 1, 2>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
+                                             d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V);
+    else
     conv_epilogue_store<NCT, ROWS, 1>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
-                                      d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V);
+                                      d < D && w < W && !S3_DBG(dbg, 4), (d * H + ch0) * W + w, ch0, H, W, V);
     }
 }
 
@@ -999,6 +1021,16 @@ size_t s3_packed_words(int seg0, int seg1, int OutC, int NP) {
 }
 bool s3_pieces_ok(int np) { return np == 2 || np == 3; }
 
+// Developer experiments (timing only, results wrong): compiled in only with -DVXM_S3_EXP (tools/build_exp.sh), selected per launch by VXM_S3_DBG
+int s3_dbg() {
+#ifdef VXM_S3_EXP
+    const char* e = getenv("VXM_S3_DBG");
+    return e ? atoi(e) : 0;
+#else
+    return 0;
+#endif
+}
+
 template <int NCT, int ROWS, int CB, int NP, bool RUN = false>
 void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, long long y_bs, int Cout, float slope, const float* mask,
                long long mask_bs, float mask_slope, int B, int D, int H, int W, hipStream_t s) {
@@ -1032,7 +1064,7 @@ void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, lo
         if (cap < gx) gx = cap;
     }
     hipLaunchKernelGGL((k_s3_conv<NCT, ROWS, CB, NP, RUN>), dim3(gx, G), dim3(S3_THREADS), C::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
-                       Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q);
+                       Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q, s3_dbg());
 }
 
 }  // namespace
