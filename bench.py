@@ -199,7 +199,7 @@ def binding_roofline(name, st):
     if not st["flops"]:
         return hbm or dict(per, kernel=name, bound="hbm", achieved=0.0, peak=HBM_PEAK_GBS, unit="GB/s", frac=0.0, algorithmic_per_launch=0.0)
     is_bf = name.startswith("k_bf16")
-    is_split = name.startswith(("k_s3_", "k_s3u_"))
+    is_split = name.startswith(("k_s3_", "k_s3u_", "k_s3p_"))
     alg = st["nominal"] if is_bf else st["flops"]
     # split-fp32 kernels (csrc/conv_s3.hip) run on the 16-bit matrix pipe with `nprod` MFMAs per fp32-equivalent MAC block -- six
     # v_mfma_f32_16x16x32_bf16 (three bf16 pieces, region label ends in ",3>" / "<3>") or three v_mfma_f32_16x16x32_f16 (two fp16 pieces,

@@ -150,6 +150,19 @@ int vxm_conv3d_k3_bwd_weight(const float* x0, int C0, int64_t x0_bstride, int x0
 int vxm_lrelu_bwd(const float* g, int64_t g_bstride, const float* y, int64_t y_bstride, float* dz,
                   int64_t dz_bstride, float slope, int B, int C, int64_t V, void* stream);
 
+/* ---- general pooling factors: Unet(max_pool=k or a list), networks.py:79-85,130,137-138 (VxmDense itself always builds k = 2, served by
+ * the fused entry points above).  Contiguous fp32 tensors, per-axis factors (a 2-D image: D = 1, kd = 1).
+ * vxm_maxpool3d_k_fwd: MaxPoolNd(k) -- kernel = stride = k, no padding, floor: x [BC][D][H][W] -> y [BC][D/kd][H/kh][W/kw], ATen's scan
+ *   (a later value replaces the maximum when it is greater or NaN).
+ * vxm_maxpool3d_k_bwd: gx [BC][D][H][W] = gy routed to the arg-max that scan ends on, zero elsewhere (every element is written).
+ * vxm_upsample3d_k_cat: y [B][C0+C1][D][H][W] = cat([Upsample(scale_factor=k, 'nearest')(x0 [B][C0][D/kd][H/kh][W/kw]), x1 [B][C1][D][H][W]]).
+ * vxm_upsample3d_k_bwd: gx0 [B][C0][D/kd][H/kh][W/kw] = gy[:, :C0] summed over each voxel's kd x kh x kw children (fixed order). */
+int vxm_maxpool3d_k_fwd(const float* x, float* y, int64_t BC, int D, int H, int W, int kd, int kh, int kw, void* stream);
+int vxm_maxpool3d_k_bwd(const float* x, const float* gy, float* gx, int64_t BC, int D, int H, int W, int kd, int kh, int kw, void* stream);
+int vxm_upsample3d_k_cat(const float* x0, int C0, const float* x1, int C1, float* y, int B, int D, int H, int W, int kd, int kh, int kw,
+                         void* stream);
+int vxm_upsample3d_k_bwd(const float* gy, int Ctot, int C0, float* gx0, int B, int D, int H, int W, int kd, int kh, int kw, void* stream);
+
 /* ---- MaxPool3d(2), networks.py:83-84,130.  x [B,C,D,H,W] (x_bstride) -> y [B,C,D/2,H/2,W/2]. */
 int vxm_maxpool2_fwd(const float* x, int64_t x_bstride, float* y, int B, int C, int D, int H, int W,
                      void* stream);
@@ -319,6 +332,9 @@ int vxm_bf16_lrelu_bwd(const void* g, const void* y, void* dz, float slope, int6
 int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W);
 int vxm_conv3d_k3_s3_variant(int Cout);                     /* 10 * NCT + CB of the kernel instance (profiling labels) */
 int vxm_conv3d_k3_s3_tile_rows(int Cout, int pieces, int H); /* rows of its output tile: 8 x 8 x 16 on the fp16 scheme, else 8 x 4 x 16 */
+/* 1 when the launch runs k_s3p_conv (the same tile, operator pack and results with producer and consumer waves: 16-output-channel
+ * forward launches of the fp16 scheme on large volumes; profiling labels) */
+int vxm_conv3d_k3_s3_producer_consumer(int Cout, int pieces, int has_mask, int B, int D, int H, int W);
 /* packed, pre-split weights of one operator: seg0 / seg1 = input channels of the two segments of the virtual concat it reads */
 size_t vxm_conv3d_k3_s3_packed_bytes(int seg0, int seg1, int OutC, int pieces);
 typedef struct VxmS3PackJob {

@@ -275,25 +275,29 @@ def _pool_margin(x, nd):
 
 
 def unet_forward(x, sd, prefix="unet_model.", nb_features=None, nb_levels=None, feat_mult=1,
-                 nb_conv_per_level=1, half_res=False):
-    """`Unet.forward` networks.py:122-144 over reference state-dict keys."""
+                 nb_conv_per_level=1, half_res=False, max_pool=2):
+    """`Unet.forward` networks.py:122-144 over reference state-dict keys.  `max_pool` (networks.py:79-85): one factor per level (an int is
+    repeated); level l pools by max_pool[l] going down and upsamples by max_pool[l] -- the same index -- going up."""
     enc_nf, dec_nf, final_nf, levels = unet_plan(nb_features, nb_levels, feat_mult, nb_conv_per_level)
     nd = x.dim() - 2
     pool = getattr(F, "max_pool%dd" % nd)
+    pools = [max_pool] * levels if isinstance(max_pool, int) else list(max_pool)
     hist = [x]
     for lvl in range(levels - 1):                                      # :125-130
         for c in range(nb_conv_per_level):
             k = "%sencoder.%d.%d.main." % (prefix, lvl, c)
             x = conv_block(x, sd[k + "weight"], sd[k + "bias"])
         hist.append(x)
-        _pool_margin(x, nd)
-        x = pool(x, 2)
+        if pools[lvl] == 2:
+            _pool_margin(x, nd)
+        x = pool(x, pools[lvl])
     for lvl in range(levels - 1):                                      # :133-138
         for c in range(nb_conv_per_level):
             k = "%sdecoder.%d.%d.main." % (prefix, lvl, c)
             x = conv_block(x, sd[k + "weight"], sd[k + "bias"])
         if not half_res or lvl < (levels - 2):
-            x = F.interpolate(x, scale_factor=2, mode="nearest")
+            k = pools[lvl]
+            x = F.interpolate(x, scale_factor=[float(v) for v in k] if isinstance(k, (tuple, list)) else float(k), mode="nearest")
             x = torch.cat([x, hist.pop()], dim=1)
     for n in range(len(final_nf)):                                     # :141-142
         k = "%sremaining.%d.main." % (prefix, n)

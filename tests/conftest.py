@@ -47,3 +47,17 @@ def g_planar():
 @pytest.fixture(scope="session")
 def g_nccwin():
     return load_golden("ncc_windows.npz")
+
+
+@pytest.fixture(scope="session")
+def g_unetpools():
+    return load_golden("unet_pools.npz")
+
+
+# tag -> (inshape, infeats, nb_features, max_pool) of tests/golden/make_golden.py:gold_unet_pools
+UNET_POOL_CASES = {
+    "p3_vol": ((18, 9, 18), 2, [[8, 8], [8, 8, 8]], 3),
+    "aniso_vol": ((4, 16, 12), 2, [[8, 8], [8, 8, 8]], [(1, 2, 2), (1, 2, 2), (1, 2, 2)]),
+    "p3_img": ((27, 18), 1, [[8, 8], [8, 8, 8]], 3),
+    "p42_img": ((16, 24), 2, [[8], [8, 8]], [4, 2]),
+}

@@ -346,11 +346,49 @@ def gold_ncc_windows():
     save("ncc_windows.npz", **out)
 
 
+UNET_POOL_CASES = {
+    # tag: (inshape, infeats, nb_features, max_pool)
+    "p3_vol": ((18, 9, 18), 2, [[8, 8], [8, 8, 8]], 3),
+    "aniso_vol": ((4, 16, 12), 2, [[8, 8], [8, 8, 8]], [(1, 2, 2), (1, 2, 2), (1, 2, 2)]),
+    "p3_img": ((27, 18), 1, [[8, 8], [8, 8, 8]], 3),
+    "p42_img": ((16, 24), 2, [[8], [8, 8]], [4, 2]),
+}
+
+
+def gold_unet_pools():
+    """Unet(max_pool = k != 2, per-level lists, per-axis tuples) of the unmodified reference (networks.py:79-85,122-144): output and the
+    gradients of sum(y * r) onto the input and every parameter (norms; the first encoder weight in full)."""
+    out = {}
+    for tag, (inshape, infeats, feats, pool) in UNET_POOL_CASES.items():
+        rng = np.random.default_rng({"p3_vol": 31, "aniso_vol": 32, "p3_img": 33, "p42_img": 34}[tag])
+        torch.manual_seed(40 + len(tag))
+        model = N.Unet(inshape=inshape, infeats=infeats, nb_features=feats, max_pool=pool)
+        x = rng.standard_normal((2, infeats) + inshape).astype(np.float32)
+        xt = t(x).requires_grad_()
+        y = model(xt)
+        r = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+        (y * t(r)).sum().backward()
+        out[tag + "_x"] = x
+        out[tag + "_r"] = r
+        out[tag + "_y"] = y.detach().numpy()
+        out[tag + "_gx"] = xt.grad.numpy()
+        names, norms = [], []
+        for k, p in model.named_parameters():
+            names.append(k)
+            norms.append(float(p.grad.double().norm()))
+            out[tag + "_param_" + k] = p.detach().numpy().copy()
+        out[tag + "_grad_names"] = np.array(names)
+        out[tag + "_grad_norms"] = np.array(norms)
+        out[tag + "_gw_enc0"] = model.encoder[0][0].main.weight.grad.numpy().copy()
+    save("unet_pools.npz", **out)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]          # e.g. `make_golden.py planar` regenerates one file and leaves the others untouched
     for name, fn in (("layers", gold_layers), ("losses", gold_losses), ("network", gold_network),
-                     ("dice_metric", gold_dice_metric), ("planar", gold_planar), ("ncc_windows", gold_ncc_windows)):
+                     ("dice_metric", gold_dice_metric), ("planar", gold_planar), ("ncc_windows", gold_ncc_windows),
+                     ("unet_pools", gold_unet_pools)):
         if not only or name in only:
             fn()

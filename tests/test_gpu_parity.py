@@ -613,6 +613,58 @@ def test_unet_vs_oracle(vxm, kw):
     assert checked >= 1, "no well-conditioned seed among the four"
 
 
+@pytest.mark.parametrize("tag", ["p3_vol", "aniso_vol", "p3_img", "p42_img"])
+def test_unet_with_other_pooling_factors_vs_reference_golden(vxm, g_unetpools, tag):
+    """Unet(max_pool = 3, per-axis tuples, per-level lists; networks.py:79-85,122-144) on the general-factor pooling kernels against the
+    fixtures of the unmodified reference: output, gradient onto the input and onto every parameter.  (The fixtures hold single samples,
+    not conditioned seeds: gates at the fp32-vs-fp32 level of two summation orders.)"""
+    from conftest import UNET_POOL_CASES
+    g = g_unetpools
+    inshape, infeats, feats, pool = UNET_POOL_CASES[tag]
+    net = vxm.networks.Unet(inshape=inshape, infeats=infeats, nb_features=feats, max_pool=pool).cuda()
+    names = [str(n) for n in g[tag + "_grad_names"]]
+    assert names == [k for k, _ in net.named_parameters()]
+    net.load_state_dict({n: torch.from_numpy(g[tag + "_param_" + n]) for n in names})
+    x = G(g[tag + "_x"], True)
+    y = net(x)
+    gate("unet %s output" % tag, rel_l2(N(y), g[tag + "_y"]), 2e-6)
+    (y * G(g[tag + "_r"])).sum().backward()
+    gate("unet %s grad x" % tag, rel_l2(N(x.grad), g[tag + "_gx"]), 4e-6)
+    gate("unet %s grad enc0" % tag, rel_l2(N(net.encoder[0][0].main.weight.grad), g[tag + "_gw_enc0"]), 4e-6)
+    for (n, p), ref in zip(net.named_parameters(), g[tag + "_grad_norms"]):
+        assert abs(float(p.grad.double().norm()) - ref) <= 1e-4 * ref + 1e-6, (tag, n)
+
+
+def test_unet_pooling_kernels_bit_exact_and_error_behaviour(vxm):
+    """MaxPoolNd(k) / Upsample(k)+cat of the general-factor kernels against ATen on the same values (bit-exact: pure selection / copies;
+    the gradient of the upsampling is a sum in a fixed order); a volume the pools do not divide is refused at the concat, as torch.cat
+    refuses it in the reference."""
+    from voxelmorph_amd.torch import functional as VF
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((2, 3, 7, 9, 11)).astype(np.float32)
+    x[0, 0, :3, :3, :3] = 1.0                                     # ties: the first maximum of the scan takes the gradient
+    for k in (3, (2, 3, 1), (1, 2, 4)):
+        xg, xo = G(x, True), torch.from_numpy(x).requires_grad_()
+        y, yo = VF.MaxPoolKFn.apply(xg, k), torch.nn.functional.max_pool3d(xo, k)
+        assert torch.equal(y.cpu(), yo.detach()), k
+        gy = rng.standard_normal(tuple(yo.shape)).astype(np.float32)
+        y.backward(G(gy)); yo.backward(torch.from_numpy(gy))
+        assert torch.equal(xg.grad.cpu(), xo.grad), k
+    lo, sk = rng.standard_normal((2, 3, 2, 3, 2)).astype(np.float32), rng.standard_normal((2, 2, 6, 6, 2)).astype(np.float32)
+    lg, sg = G(lo, True), G(sk, True)
+    lt, st = torch.from_numpy(lo).requires_grad_(), torch.from_numpy(sk).requires_grad_()
+    out = VF.UpsampleCatKFn.apply(lg, sg, (3, 2, 1))
+    ref = torch.cat([torch.nn.functional.interpolate(lt, scale_factor=(3.0, 2.0, 1.0), mode="nearest"), st], dim=1)
+    assert torch.equal(out.cpu(), ref.detach())
+    go = rng.standard_normal(tuple(ref.shape)).astype(np.float32)
+    out.backward(G(go)); ref.backward(torch.from_numpy(go))
+    assert torch.equal(sg.grad.cpu(), st.grad)
+    np.testing.assert_allclose(N(lg.grad), lt.grad.numpy(), rtol=1e-6, atol=1e-6)
+    net = vxm.networks.Unet(inshape=(10, 9, 9), infeats=1, nb_features=[[4], [4, 4]], max_pool=3).cuda()
+    with pytest.raises(RuntimeError, match="must match"):
+        net(torch.zeros(1, 1, 10, 9, 9, device="cuda"))
+
+
 @pytest.mark.parametrize("src_feats,trg_feats", [(2, 1), (1, 3)])
 def test_vxm_dense_multi_feature_inputs_vs_oracle(vxm, src_feats, trg_feats):
     """networks.py:161-162 `src_feats` / `trg_feats`: the first block reads the virtual concat of a multi-channel source and target

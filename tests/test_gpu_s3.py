@@ -353,13 +353,18 @@ def _rerun(env_extra, select, files=("tests/test_gpu_s3.py",), timeout=900):
 def test_s3_other_kernel_instances_in_subprocess():
     """The packed layout depends on the kernel instance, which is chosen once per process: 16-channel chunks (VXM_S3_CB=2) and
     32-channel operators as two 16-channel groups (VXM_S3_NCT=1) re-run the direct tests above."""
-    if os.environ.get("VXM_S3_CB") or os.environ.get("VXM_S3_NCT") or os.environ.get("VXM_S3_PERSIST") or os.environ.get("VXM_S3U_PERSIST"):
+    if any(os.environ.get(k) for k in ("VXM_S3_CB", "VXM_S3_NCT", "VXM_S3_PERSIST", "VXM_S3U_PERSIST", "VXM_S3_PC")):
         pytest.skip("already inside a variant run")
     _rerun({"VXM_S3_CB": "2"}, "forward_vs_fp64 or fused_mask or scale_invariance")
     _rerun({"VXM_S3_NCT": "1"}, "forward_vs_fp64 or fused_mask")
     # 16 blocks in all: every block walks several tiles of its XCD's range (the default grid only does so on volumes with > 2048 tiles)
     _rerun({"VXM_S3_PERSIST": "-16"}, "forward_vs_fp64 or fused_mask or many_tiles")
     _rerun({"VXM_S3_PERSIST": "0"}, "many_tiles")
+    # the producer / consumer kernel (k_s3p_conv: by default from 2048 tiles of 8 x 8 x 16 up) on every eligible launch, with one block per
+    # tile and with 16 blocks in all (every block streams several tiles through its two LDS buffers); and the alternating kernel everywhere
+    _rerun({"VXM_S3_PC": "1"}, "forward_vs_fp64 or fused_mask or scale_invariance or dynamic_range or many_tiles")
+    _rerun({"VXM_S3_PC": "1", "VXM_S3P_BLOCKS": "16"}, "forward_vs_fp64 or fused_mask or dynamic_range or many_tiles")
+    _rerun({"VXM_S3_PC": "0"}, "many_tiles")
     _rerun({"VXM_S3U_PERSIST": "-16"}, "s3u_collapsed")
     _rerun({"VXM_S3U_PERSIST": "0"}, "s3u_collapsed_forward_many_tiles")
 
@@ -375,6 +380,8 @@ def test_s3_through_the_dispatcher_on_small_volumes_in_subprocess():
                "conv_block_vs_oracle or conv_block_output_guard or unet_vs_oracle or vxm_dense_golden or collapsed_weights", files=("tests/test_gpu_parity.py",))
         _rerun({"VXM_S3_MIN_TILES": "1", "VXM_S3U": "0", "VXM_FP32_ENGINE": engine, "VXM_S3_UP": "1"},
                "unet_vs_oracle or collapsed_weights", files=("tests/test_gpu_parity.py",))
+    _rerun({"VXM_S3_MIN_TILES": "1", "VXM_S3U_MIN_TILES": "1", "VXM_S3_PC": "1", "VXM_S3P_BLOCKS": "16"},
+           "conv_block_vs_oracle or conv_block_output_guard or unet_vs_oracle or vxm_dense_golden", files=("tests/test_gpu_parity.py",))
 
 
 def test_other_fp32_engines_at_full_size_in_subprocess():

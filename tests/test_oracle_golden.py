@@ -127,6 +127,25 @@ def test_ncc_any_window_matches_reference(g_nccwin):
         orc.ncc_loss(T(g_nccwin["I2"][..., :4]), T(g_nccwin["J2"][..., :4]), win=[3, 9])    # ... and the reference's conv raises
 
 
+@pytest.mark.parametrize("tag", ["p3_vol", "aniso_vol", "p3_img", "p42_img"])
+def test_unet_with_other_pooling_factors_matches_reference(g_unetpools, tag):
+    """Unet(max_pool = 3, per-axis tuples, per-level lists; networks.py:79-85,122-144): the restatement against the output and the
+    gradients of the unmodified reference"""
+    from conftest import UNET_POOL_CASES
+    g = g_unetpools
+    inshape, infeats, feats, pool = UNET_POOL_CASES[tag]
+    names = [str(n) for n in g[tag + "_grad_names"]]
+    sd = {"unet_model." + n: T(g[tag + "_param_" + n]).requires_grad_() for n in names}
+    x = T(g[tag + "_x"]).requires_grad_()
+    y = orc.unet_forward(x, sd, nb_features=feats, max_pool=pool)
+    np.testing.assert_allclose(y.detach().numpy(), g[tag + "_y"], atol=2e-6, rtol=1e-5)
+    (y * T(g[tag + "_r"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g[tag + "_gx"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(sd["unet_model.encoder.0.0.main.weight"].grad.numpy(), g[tag + "_gw_enc0"], atol=2e-4, rtol=1e-4)
+    for n, ref in zip(names, g[tag + "_grad_norms"]):
+        assert abs(float(sd["unet_model." + n].grad.double().norm()) - ref) <= 1e-4 * ref + 1e-6, n
+
+
 def test_mse_grad_dice(g_losses):
     I, J = T(g_losses["I"]), T(g_losses["J"])
     np.testing.assert_allclose(orc.mse_loss(I, J).item(), g_losses["mse"], rtol=1e-6)

@@ -59,6 +59,10 @@ SIGNATURES = {
     "vxm_conv3d_k3_bwd_weight_up_segment": [_P, _I, _L, _P, _I, _L, _P, _L, _I, _P, _P, _S, _I, _I, _I, _I, _P],
     "vxm_lrelu_bwd": [_P, _L, _P, _L, _P, _L, _F, _I, _I, _L, _P],
     "vxm_maxpool2_fwd": [_P, _L, _P, _I, _I, _I, _I, _I, _P],
+    "vxm_maxpool3d_k_fwd": [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "vxm_maxpool3d_k_bwd": [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "vxm_upsample3d_k_cat": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "vxm_upsample3d_k_bwd": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "vxm_maxpool2_bwd": [_P, _L, _P, _P, _L, _P, _F, _I, _I, _I, _I, _I, _P],
     "vxm_upsample2_bwd": [_P, _L, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     "vxm_upsample2_cat": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
@@ -103,6 +107,7 @@ SIGNATURES = {
     "vxm_conv3d_k3_s3_ok": [_I, _I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3_variant": [_I],
     "vxm_conv3d_k3_s3_tile_rows": [_I, _I, _I],
+    "vxm_conv3d_k3_s3_producer_consumer": [_I, _I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3_packed_bytes": [_I, _I, _I, _I],
     "vxm_conv3d_k3_s3_pack_weights_batch": [_P, _I, _P],
     "vxm_conv3d_k3_s3_fwd": [_P, _I, _L, _I, _P, _I, _L, _P, _P, _P, _L, _I, _F, _P, _L, _F, _I, _I, _I, _I, _I, _P],

@@ -177,6 +177,14 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
             const int sv = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
             const bool ok = spos[j] >= 0 && (cbg + cb) * 8 < Cseg && q < Q;  // segments carry multiples of 8 channels; q == Q: nothing to fetch
             voffs[j] = ok ? ((cbg + cb) * 8 * Vs + sv) << 2 : VXM_OOB;
+            if (S3_DBG(dbg, 256)) {                                // timing experiment: the addresses of a channel-blocked tensor [C / 8][voxel][8]
+                voffs[j] = ok ? ((cbg + cb) * Vs + sv) << 5 : VXM_OOB;
+                const u32x4 lo = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[j], 0, 0));
+                const u32x4 hi = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[j], 16, 0));
+                xr[j][0] = __uint_as_float(lo.x); xr[j][1] = __uint_as_float(lo.y); xr[j][2] = __uint_as_float(lo.z); xr[j][3] = __uint_as_float(lo.w);
+                xr[j][4] = __uint_as_float(hi.x); xr[j][5] = __uint_as_float(hi.y); xr[j][6] = __uint_as_float(hi.z); xr[j][7] = __uint_as_float(hi.w);
+                continue;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) xr[j][e] = vxm_bload(r, voffs[j], (e * Vs) << 2);
         }
@@ -386,12 +394,322 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     const int d = cd0 + wave, w = cw0 + n;
     float bz[NCT][4];
     conv_load_bias<NCT>(bz, bias, Cout, g, kg);
-    if (S3_DBG(dbg, 8))
+    if (S3_DBG(dbg, 512)) {                                     // timing experiment: stores of a channel-blocked tensor, 16 bytes per lane, no mask
+        const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(y + (size_t)cbt * y_bs, (unsigned)Cout * (unsigned)V * 4u);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int row = 0; row < ROWS; ++row) {
+                const int vox = (d * H + ch0 + row) * W + w;
+                const bool ok = d < D && w < W && ch0 + row < H && (g * NCT + ct) * 16 + kg * 4 < Cout;
+                const f32x4 v = acc[ct][row];
+                __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, ry,
+                                                       ok ? ((((g * NCT + ct) * 2 + (kg >> 1)) * V + vox) << 5) + ((kg & 1) << 4) : VXM_OOB, 0, 0);
+            }
+    } else if (S3_DBG(dbg, 8))
         conv_epilogue_store<NCT, ROWS, 1, 2>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
                                              d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V);
     else
     conv_epilogue_store<NCT, ROWS, 1>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
                                       d < D && w < W && !S3_DBG(dbg, 4), (d * H + ch0) * W + w, ch0, H, W, V);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_s3p_conv: the same convolution (fp16 pieces, 8-channel chunks, 8 x 8 x 16 tile, running scale) with PRODUCER and CONSUMER waves.
+// ------------------------------------------------------------------------------------------
+// Why.  k_s3_conv alternates, inside every block, "multiply chunk q" and "wait for chunk q + 1, split it, write it to LDS": measured on
+// the full-resolution 16 -> 16 layer (tools/exp_s3.sh, -DVXM_S3_EXP) its time is the SUM of its parts -- 0.44 ms = reads 0.16 + MFMA 0.05 +
+// stores 0.08 + split / weights / barriers 0.15 -- although two blocks share a CU: every block of the chip starts at the same moment and
+// runs the same cadence, so the chip alternates between "everybody waits for memory" and "nobody loads".  Here one block of 16 waves
+// owns the CU: waves 8 .. 15 only fetch, split and write (chunk k + 2 in flight from HBM while chunk k + 1 is split into the second LDS
+// buffer), waves 0 .. 7 only multiply chunk k out of the first buffer and store finished tiles.  Requests are in flight all the time, the
+// split arithmetic runs beside the MFMAs of other waves of the same SIMD, and there is ONE barrier per chunk.
+// The chunk stream of a block: c = (tile i of the block, chunk q of the tile), c = 0 .. nphase - 1.  Phase k (k = -1 .. nphase - 1):
+//   producers: request the weights of chunk k + 1 and the raw fp32 of chunk k + 2 (register set k & 1), split chunk k + 1 (set (k + 1) & 1,
+//              scale from the maxima published in phase k - 1) into LDS buffer (k + 1) & 1, wait for chunk k + 2, publish its wave maxima
+//   consumers: multiply chunk k out of buffer k & 1; after the barrier, if it was the tile's last chunk: epilogue
+// LDS: 2 x (pieces 61,440 + weights 14,336) + tables = 151,680 bytes.  Same packed operator, same epilogue, same results as k_s3_conv<1,8,1,2,true>.
+constexpr int S3P_THREADS = 1024, S3P_PT = 512;                  // threads of the block / of its producer half
+template <int NCT> struct S3PCfg {
+    using C = S3Cfg<NCT, 8, 1, 2>;
+    static constexpr int BUF = C::XW + C::WCH;                   // 16-byte words of one buffer: the chunk's pieces, then its weights
+    static constexpr int NI = (C::NSLOT + S3P_PT - 1) / S3P_PT, WIT = (C::WCH + S3P_PT - 1) / S3P_PT;
+    static constexpr int LDS_BYTES = 2 * BUF * 16 + 128;         // + [2][8] wave maxima, [2]{ratio, 1 / scale}
+};
+
+template <int NCT>
+__global__ void __launch_bounds__(S3P_THREADS)
+k_s3p_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout,
+           float act_slope, const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W, int Q0, int Q) {
+    using PC = S3PCfg<NCT>;
+    using C = typename PC::C;
+    using P = S3P<2>;
+    VXM_DYN_SMEM(u32x4, smem);
+    constexpr int ROWS = 8, HR = C::HR, PLANE = C::PLANE, PUSED = C::PLANE_USED, SLOTS = C::SLOTS, NSLOT = C::NSLOT, NS = C::NS, WCH = C::WCH;
+    constexpr int BUF = PC::BUF, NI = PC::NI, WIT = PC::WIT;
+    float* const Tab = reinterpret_cast<float*>(smem + 2 * BUF);        // [0..15]: wave maxima [parity][producer wave]; [16..19]: {ratio, 1 / scale}[parity]
+    const int tid_ = threadIdx.x, lane = tid_ & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_ >> 6);
+
+    // the tiles of this block (as k_s3_conv: XCD x owns a contiguous tile range, its blocks take the tiles round-robin)
+    const int nw = (W + 15) / 16, nh = (H + ROWS - 1) / ROWS, nd = (D + S3_TD - 1) / S3_TD;
+    const int ntiles = B * nd * nh * nw;
+    int t_lo, t_hi, t_step;
+    if (ntiles >= 64) {
+        const int x = blockIdx.x & 7;
+        t_lo = (int)((long long)ntiles * x / 8) + (int)(blockIdx.x >> 3); t_hi = (int)((long long)ntiles * (x + 1) / 8); t_step = (int)(gridDim.x >> 3);
+    } else {
+        t_lo = blockIdx.x; t_hi = ntiles; t_step = gridDim.x;
+    }
+    const int n_my = t_lo < t_hi ? (t_hi - t_lo + t_step - 1) / t_step : 0;
+    const int nphase = n_my * Q;
+    const int g = blockIdx.y;
+    const int V = D * H * W;
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
+    const int V0 = in.up0 ? Dl * Hl * Wl : V;
+    auto tile_origin = [&](int tl, int& bt, int& d0, int& h0, int& w0) __attribute__((always_inline)) {
+        const int tw = tl % nw; int tq = tl / nw;
+        const int th = tq % nh; tq /= nh;
+        const int td = tq % nd;
+        bt = tq / nd; d0 = td * S3_TD; h0 = th * ROWS; w0 = tw * 16;
+    };
+
+    if (wave >= 8) {
+        // =========================== producers ===========================
+        const int ptid_ = tid_ - S3P_PT, pw = wave - 8;
+        int d0 = 0, h0 = 0, w0 = 0;
+        __amdgpu_buffer_rsrc_t r0, r1;
+        int spos[NI];
+        auto set_tile = [&](int tile) __attribute__((always_inline)) {
+            int ptid = ptid_;
+            asm volatile("" : "+v"(ptid));
+            const bool live = tile < t_hi;                        // past the block's last tile: every slot is padding, nothing is fetched
+            int bt;
+            tile_origin(live ? tile : t_lo, bt, d0, h0, w0);
+            r0 = vxm_rsrc(in.x0 + (size_t)bt * in.bs0, (unsigned)in.C0 * (unsigned)V0 * 4u);
+            r1 = vxm_rsrc(in.C1 ? in.x1 + (size_t)bt * in.bs1 : in.x0, (unsigned)in.C1 * (unsigned)V * 4u);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int i = ptid + S3P_PT * j;
+                const int hd = i / PUSED, r2 = i - hd * PUSED, hh = r2 / S3_HWV, hw = r2 - hh * S3_HWV;
+                const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
+                const bool ok = live && i < NSLOT && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+                spos[j] = ok ? (hd << 10 | hh << 5 | hw) : -1;
+            }
+        };
+        float xr[2][NI][8];                                       // raw fp32 of two chunks: set = chunk parity
+        int voffs[2][NI];
+        auto load_chunk = [&](auto set_, int q) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value;
+            const bool s0 = q < Q0;                               // wave-uniform
+            const bool up = s0 && in.up0;
+            const __amdgpu_buffer_rsrc_t r = s0 ? r0 : r1;
+            const int Cseg = s0 ? in.C0 : in.C1, cbg = s0 ? q : q - Q0, Vs = up ? V0 : V;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int gd = d0 - 1 + (spos[j] >> 10), gh = h0 - 1 + ((spos[j] >> 5) & 31), gw = w0 - 1 + (spos[j] & 31);
+                const int sv = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
+                const bool ok = spos[j] >= 0 && cbg * 8 < Cseg;  // segments carry multiples of 8 channels
+                voffs[S][j] = ok ? (cbg * 8 * Vs + sv) << 2 : VXM_OOB;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xr[S][j][e] = vxm_bload(r, voffs[S][j], (e * Vs) << 2);
+            }
+        };
+        auto publish_max = [&](auto set_) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value;
+            float m = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, __builtin_fabsf(xr[S][j][e]));
+            m = s3_wave_max(m);
+            if (lane == 0) Tab[8 * S + pw] = m;
+        };
+        int E_run = 15;
+        // split chunk (set S) of operator chunk q into buffer S: weights first (requested by `wv` BEFORE the raw loads of this phase,
+        // so that waiting for them leaves those loads in flight), then pieces
+        auto split_chunk = [&](auto set_, const u32x4 (&wv)[WIT], bool first) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value;
+            int ptid = ptid_;
+            asm volatile("" : "+v"(ptid));
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(Tab + 8 * S), m1 = *reinterpret_cast<const f32x4*>(Tab + 8 * S + 4);
+            const float mx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+            int E = (int)(__float_as_uint(mx) >> 23) & 255;
+            E = E < 15 ? 15 : E;
+            const int E_new = first ? E : (E > E_run ? E : E_run), dE = E_new - E_run;
+            const float ratio = (first || dE == 0) ? 1.0f : (dE > 126 ? 0.0f : __uint_as_float((unsigned)(127 - dE) << 23));
+            E_run = E_new;
+            const float sc = __uint_as_float((unsigned)(268 - E_run) << 23), inv = __uint_as_float((unsigned)(E_run - 14) << 23);
+            if (ptid == 0) { Tab[16 + 2 * S] = ratio; Tab[17 + 2 * S] = inv; }
+            u32x4* const Xs = smem + S * BUF;
+            u32x4* const Ws = Xs + C::XW;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                unsigned pk[2][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s3_split2_f16(xr[S][j][2 * e], xr[S][j][2 * e + 1], sc, pk[0][e], pk[1][e]);
+                const int i = ptid + S3P_PT * j;
+                if (i < NSLOT) {                                   // (padding slots are written too: zeros from the out-of-range loads)
+                    const int hd = i / PUSED, lw = hd * PLANE + (i - hd * PUSED);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) Xs[p * SLOTS + lw] = (u32x4){pk[p][0], pk[p][1], pk[p][2], pk[p][3]};
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int i = ptid + S3P_PT * it;
+                if (i < WCH) Ws[i] = wv[it];
+            }
+        };
+        auto load_weights = [&](u32x4 (&wv)[WIT], int q) __attribute__((always_inline)) {
+            int ptid = ptid_;
+            asm volatile("" : "+v"(ptid));
+            const __amdgpu_buffer_rsrc_t rw = vxm_rsrc(reinterpret_cast<const float*>(wp + ((size_t)g * Q + q) * WCH), WCH * 16u);
+#pragma unroll
+            for (int it = 0; it < WIT; ++it)
+                wv[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (ptid + S3P_PT * it) * 16, 0, 0));
+        };
+
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        int ltile = t_lo, lq = 0;                                 // the next chunk to request
+        int sq = 0;                                               // operator chunk of the next chunk to split
+        auto advance_load = [&]() __attribute__((always_inline)) {
+            if (++lq == Q) { lq = 0; ltile += t_step; set_tile(ltile); }
+        };
+        set_tile(ltile);
+        load_chunk(I0{}, lq);                                     // chunk 0
+        advance_load();
+        publish_max(I0{});
+        __syncthreads();
+        // phase k: PAR = (k + 1) & 1 = parity of the chunk that is split; the chunk requested (k + 2) has parity PAR ^ 1
+        auto phase = [&](auto par_, int k) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_)::value;
+            using SS = std::integral_constant<int, PAR>;
+            using SL = std::integral_constant<int, PAR ^ 1>;
+            u32x4 wv[WIT];
+            const bool do_split = k + 1 < nphase;                 // block-uniform
+            load_weights(wv, do_split ? sq : 0);
+            load_chunk(SL{}, lq);                                 // past the block's last tile every lane is out of range: nothing is fetched
+            advance_load();
+            if (do_split) {
+                split_chunk(SS{}, wv, sq == 0);
+                if (++sq == Q) sq = 0;
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(voffs[PAR ^ 1][j]));      // (see keep_offsets in k_s3_conv)
+            publish_max(SL{});
+            __syncthreads();
+        };
+        for (int k = -1; k < nphase; k += 2) {
+            phase(I0{}, k);                                       // k odd-from-minus-one: chunk k + 1 is even
+            if (k + 1 < nphase) phase(I1{}, k + 1);
+        }
+        return;
+    }
+
+    // =========================== consumers ===========================
+    const int kg = lane >> 4, n = lane & 15;
+    int xoff[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const S3Unit u0 = s3_unit(1, s, 0), u1 = s3_unit(1, s, 1), u2 = s3_unit(1, s, 2), u3 = s3_unit(1, s, 3);
+        const S3Unit u = kg == 0 ? u0 : kg == 1 ? u1 : kg == 2 ? u2 : u3;
+        xoff[s] = (wave + u.kd) * PLANE + u.kw + n;
+    }
+    const int xoff_rt = (wave + 2) * PLANE + (kg < 3 ? kg : 2) * S3_HWV + 2 + n;
+    const float inv_w = __uint_as_float(__builtin_amdgcn_readfirstlane((int)wp[(size_t)gridDim.y * Q * WCH].x));      // trailer of the packed operator
+    float bz[NCT][4];
+    conv_load_bias<NCT>(bz, bias, Cout, g, kg);
+    __syncthreads();                                            // (producers: the maxima of chunk 0)
+    __syncthreads();                                            // (producers: phase -1, chunk 0 is in buffer 0)
+    int k = 0;
+    for (int tile = t_lo; tile < t_hi; tile += t_step) {
+        int cbt, cd0, ch0, cw0;
+        tile_origin(tile, cbt, cd0, ch0, cw0);
+        f32x4 acc[NCT][ROWS];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float inv_fin = 1.0f;
+        for (int q = 0; q < Q; ++q, ++k) {
+            const int par = k & 1;
+            const u32x4* const Xs = smem + par * BUF;
+            const u32x4* const Ws = Xs + C::XW;
+            const float ratio = __uint_as_float(__builtin_amdgcn_readfirstlane((int)__float_as_uint(Tab[16 + 2 * par])));
+            inv_fin = __uint_as_float(__builtin_amdgcn_readfirstlane((int)__float_as_uint(Tab[17 + 2 * par])));
+            if (ratio != 1.0f) {                                // wave-uniform: this chunk raised the tile's running maximum
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                    for (int r = 0; r < ROWS; ++r) acc[ct][r] *= ratio;
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                u32x4 a[3][2][NCT], bf[2][2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bf[0][p] = Xs[p * SLOTS + xoff[s]];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) a[kh][p][ct] = Ws[(((s * 3 + kh) * 2 + p) * NCT + ct) * 64 + lane];
+#pragma unroll
+                for (int hr = 0; hr < HR; ++hr) {
+                    if (hr + 1 < HR) {
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) bf[(hr + 1) & 1][p] = Xs[p * SLOTS + xoff[s] + (hr + 1) * S3_HWV];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < P::NPROD; ++t)
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh) {
+                            const int row = hr - kh;
+                            if (row >= 0 && row < ROWS) {
+#pragma unroll
+                                for (int ct = 0; ct < NCT; ++ct) acc[ct][row] = P::mfma(a[kh][P::PA[t]][ct], bf[hr & 1][P::PB[t]], acc[ct][row]);
+                            }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            {
+                u32x4 a[2][NCT], bf[2][2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bf[0][p] = Xs[p * SLOTS + xoff_rt];
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) a[p][ct] = Ws[((NS * 3 * 2 + p) * NCT + ct) * 64 + lane];
+#pragma unroll
+                for (int row = 0; row < ROWS; ++row) {
+                    if (row + 1 < ROWS) {
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) bf[(row + 1) & 1][p] = Xs[p * SLOTS + xoff_rt + (row + 1) * S3_HWV];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < P::NPROD; ++t)
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) acc[ct][row] = P::mfma(a[P::PA[t]][ct], bf[row & 1][P::PB[t]], acc[ct][row]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();                                    // chunk k is read; chunk k + 1 is in the other buffer
+        }
+        // ---- epilogue (as k_s3_conv): undo the scales, bias + LeakyReLU (+ fused leaky_relu_backward mask), planar fp32 store
+        const float fin = inv_w * inv_fin;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) acc[ct][r] *= fin;
+        const int d = cd0 + wave, w = cw0 + n;
+        conv_epilogue_store<NCT, ROWS, 1>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
+                                          d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V);
     }
 }
 
@@ -1067,6 +1385,36 @@ void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, lo
                        Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q, s3_dbg());
 }
 
+bool s3_use_pc(int B, int D, int H, int W, bool has_mask) {
+    static const int pc = [] { const char* e = getenv("VXM_S3_PC"); return e ? atoi(e) : -1; }();
+    const long long nt8 = (long long)B * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 15) / 16);
+    return pc == 1 || (pc < 0 && nt8 >= 2048 && !has_mask);
+}
+
+// k_s3p_conv: one block of 16 waves per CU, every block walks its XCD's tile range (VXM_S3P_BLOCKS=n: n blocks in all, tests / A/B)
+template <int NCT>
+void s3p_launch(const ConvIn& in, const void* wp, const float* bias, float* y, long long y_bs, int Cout, float slope, const float* mask,
+                long long mask_bs, float mask_slope, int B, int D, int H, int W, hipStream_t s) {
+    using PC = S3PCfg<NCT>;
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3p_conv<NCT>), hipFuncAttributeMaxDynamicSharedMemorySize, PC::LDS_BYTES);
+        return true;
+    }();
+    (void)attr;
+    const int Q0 = s3_chunks(in.C0, 1), Q = Q0 + s3_chunks(in.C1, 1);
+    const long long ntiles = (long long)B * ((D + S3_TD - 1) / S3_TD) * ((H + 7) / 8) * ((W + 15) / 16);
+    unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
+    const int G = (Cout + 16 * NCT - 1) / (16 * NCT);
+    static const int nblk = [] { const char* e = getenv("VXM_S3P_BLOCKS"); return e ? atoi(e) : 0; }();
+    if (ntiles >= 64) {
+        const unsigned want = nblk > 0 ? (unsigned)nblk : (unsigned)(sw_cus() / G);
+        const unsigned cap = 8 * ((want + 7) / 8);
+        if (cap < gx) gx = cap;
+    }
+    hipLaunchKernelGGL((k_s3p_conv<NCT>), dim3(gx, G), dim3(S3P_THREADS), PC::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
+                       Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1083,6 +1431,13 @@ int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W) {
 int vxm_conv3d_k3_s3_variant(int Cout) {
     const S3Variant v = s3_variant(Cout);
     return 10 * v.NCT + v.CB;
+}
+
+/* 1 when vxm_conv3d_k3_s3_fwd will run the producer / consumer kernel k_s3p_conv for this launch (profiling labels) */
+int vxm_conv3d_k3_s3_producer_consumer(int Cout, int pieces, int has_mask, int B, int D, int H, int W) {
+    static const bool rows8 = [] { const char* e = getenv("VXM_S3_ROWS"); return !(e && e[0] == '4'); }();
+    const S3Variant v = s3_variant(Cout);
+    return (pieces == 2 && rows8 && H >= 8 && v.CB == 1 && v.NCT == 1 && s3_use_pc(B, D, H, W, has_mask != 0)) ? 1 : 0;
 }
 
 /* rows of the output tile the launch of vxm_conv3d_k3_s3_fwd will use (profiling labels): 8 on the fp16 scheme with 8-channel chunks, else 4 */
@@ -1157,7 +1512,14 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
         s3_launch<2, 8, 1, 2, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
     else if (v.NCT == 2) S3_GO(2, 1);
     else if (v.CB == 2) S3_GO(1, 2);
-    else if (pieces == 2 && rows8 && H >= 8) s3_launch<1, 8, 1, 2, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
+    else if (pieces == 2 && rows8 && H >= 8) {
+        // producer / consumer waves (k_s3p_conv) for forward launches from 2048 tiles up (same-box A/B at 160x192x224: 16 -> 16 0.498 -> 0.472 ms,
+        // 32 -> 16 0.848 -> 0.809; backward-data launches, whose epilogue waits for the mask it reads, 0.493 -> 0.500 and 0.813 -> 0.836: not routed;
+        // requesting the mask under the MFMAs of the tile's last chunk cost the forward launches their gain and did not help these).
+        // VXM_S3_PC=0: the alternating kernel everywhere, =1: k_s3p_conv on every eligible launch (tests)
+        if (s3_use_pc(B, D, H, W, mask != nullptr)) s3p_launch<1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
+        else s3_launch<1, 8, 1, 2, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
+    }
     else S3_GO(1, 1);
 #undef S3_GO
     return vxm_check_launch("vxm_conv3d_k3_s3_fwd");

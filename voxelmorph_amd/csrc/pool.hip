@@ -176,6 +176,82 @@ __global__ void __launch_bounds__(256) k_upsample2_cat(const float* __restrict__
     out[b * (size_t)(C0 + C1) * V + i] = v;
 }
 
+// ---- general pooling factors: Unet(max_pool=k or a list) of the reference (networks.py:79-85): MaxPoolNd(k) -- kernel = stride = k, no
+// padding, floor -- at :130 and Upsample(scale_factor=k, 'nearest') + cat at :137-138.  Elementwise, one thread per voxel, per-axis factors
+// (a 2-D image is a volume of depth 1 with kd = 1).  The U-Net of VxmDense (k = 2) runs the fused kernels above; these serve the op-by-op path.
+__global__ void __launch_bounds__(256) k_maxpoolk_fwd(const float* __restrict__ x, float* __restrict__ y, long long n_out, int D, int H, int W, int Do, int Ho,
+                                                      int Wo, int kd, int kh, int kw) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_out) return;
+    const int wo = (int)(i % Wo); long long t = i / Wo;
+    const int ho = (int)(t % Ho); t /= Ho;
+    const int dq = (int)(t % Do); const long long bc = t / Do;
+    const float* p = x + ((bc * D + (long long)dq * kd) * H + (long long)ho * kh) * W + (long long)wo * kw;
+    float m = p[0];
+    for (int a = 0; a < kd; ++a)
+        for (int b = 0; b < kh; ++b)
+            for (int c = 0; c < kw; ++c) {
+                const float v = p[((long long)a * H + b) * W + c];
+                m = (v > m || v != v) ? v : m;      // ATen: (val > maxval) || isnan(val)
+            }
+    y[i] = m;
+}
+// one thread per INPUT voxel: repeats the forward scan of its window and takes the gradient when it is the arg-max the scan ends on
+__global__ void __launch_bounds__(256) k_maxpoolk_bwd(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx, long long n_in, int D, int H,
+                                                      int W, int Do, int Ho, int Wo, int kd, int kh, int kw) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_in) return;
+    const int w = (int)(i % W); long long t = i / W;
+    const int h = (int)(t % H); t /= H;
+    const int d = (int)(t % D); const long long bc = t / D;
+    const int dq = d / kd, ho = h / kh, wo = w / kw;
+    float g = 0.0f;
+    if (dq < Do && ho < Ho && wo < Wo) {            // (voxels past the last full window belong to no output)
+        const float* p = x + ((bc * D + (long long)dq * kd) * H + (long long)ho * kh) * W + (long long)wo * kw;
+        const int mine = ((d - dq * kd) * kh + (h - ho * kh)) * kw + (w - wo * kw);
+        float m = p[0];
+        int arg = 0, idx = 0;
+        for (int a = 0; a < kd; ++a)
+            for (int b = 0; b < kh; ++b)
+                for (int c = 0; c < kw; ++c, ++idx) {
+                    const float v = p[((long long)a * H + b) * W + c];
+                    if (v > m || v != v) { m = v; arg = idx; }
+                }
+        if (arg == mine) g = gy[((bc * Do + dq) * Ho + ho) * (long long)Wo + wo];
+    }
+    gx[i] = g;
+}
+// y [B][C0 + C1][D][H][W] = cat([nearest upsampling of x0 [B][C0][D/kd][H/kh][W/kw], x1 [B][C1][D][H][W]])
+__global__ void __launch_bounds__(256) k_upsamplek_cat(const float* __restrict__ x0, int C0, const float* __restrict__ x1, int C1, float* __restrict__ y,
+                                                       long long n, int D, int H, int W, int kd, int kh, int kw) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int w = (int)(i % W); long long t = i / W;
+    const int h = (int)(t % H); t /= H;
+    const int d = (int)(t % D); t /= D;
+    const int c = (int)(t % (C0 + C1)); const long long b = t / (C0 + C1);
+    const int Dl = D / kd, Hl = H / kh, Wl = W / kw;
+    y[i] = c < C0 ? x0[(((b * C0 + c) * Dl + d / kd) * Hl + h / kh) * (long long)Wl + w / kw]
+                  : x1[(((b * C1 + (c - C0)) * D + d) * H + h) * (long long)W + w];
+}
+// gx0 [B][C0][D/kd][H/kh][W/kw] = sum of gy[:, :C0] over each voxel's kd x kh x kw children (fixed order)
+__global__ void __launch_bounds__(256) k_upsamplek_bwd(const float* __restrict__ gy, int Ctot, int C0, float* __restrict__ gx0, long long n, int D, int H, int W,
+                                                       int kd, int kh, int kw) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int Dl = D / kd, Hl = H / kh, Wl = W / kw;
+    const int wl = (int)(i % Wl); long long t = i / Wl;
+    const int hl = (int)(t % Hl); t /= Hl;
+    const int dl = (int)(t % Dl); t /= Dl;
+    const int c = (int)(t % C0); const long long b = t / C0;
+    const float* p = gy + (((b * Ctot + c) * D + (long long)dl * kd) * H + (long long)hl * kh) * W + (long long)wl * kw;
+    float s = 0.0f;
+    for (int a = 0; a < kd; ++a)
+        for (int bb = 0; bb < kh; ++bb)
+            for (int cc = 0; cc < kw; ++cc) s += p[((long long)a * H + bb) * W + cc];
+    gx0[i] = s;
+}
+
 }  // namespace
 
 extern "C" {
@@ -233,6 +309,42 @@ int vxm_upsample2_cat(const float* x0, int C0, const float* x1, int C1, float* o
     hipLaunchKernelGGL(k_upsample2_cat, dim3(vxm_blocks((long long)(C0 + C1) * D * H * W, 256), B), dim3(256), 0, VXM_STREAM(stream), x0, C0,
                        x1, C1, out, D, H, W);
     return vxm_check_launch("vxm_upsample2_cat");
+}
+
+int vxm_maxpool3d_k_fwd(const float* x, float* y, int64_t BC, int D, int H, int W, int kd, int kh, int kw, void* stream) {
+    VXM_REQUIRE(x && y, VXM_ERR_NULL_POINTER, "vxm_maxpool3d_k_fwd: null pointer");
+    VXM_REQUIRE(BC > 0 && kd > 0 && kh > 0 && kw > 0 && D >= kd && H >= kh && W >= kw, VXM_ERR_BAD_SHAPE,
+                "vxm_maxpool3d_k_fwd: window %dx%dx%d does not fit %dx%dx%d", kd, kh, kw, D, H, W);
+    const long long n = (long long)BC * (D / kd) * (H / kh) * (W / kw);
+    hipLaunchKernelGGL(k_maxpoolk_fwd, dim3(vxm_blocks(n, 256)), dim3(256), 0, VXM_STREAM(stream), x, y, n, D, H, W, D / kd, H / kh, W / kw, kd, kh, kw);
+    return vxm_check_launch("vxm_maxpool3d_k_fwd");
+}
+
+int vxm_maxpool3d_k_bwd(const float* x, const float* gy, float* gx, int64_t BC, int D, int H, int W, int kd, int kh, int kw, void* stream) {
+    VXM_REQUIRE(x && gy && gx, VXM_ERR_NULL_POINTER, "vxm_maxpool3d_k_bwd: null pointer");
+    VXM_REQUIRE(BC > 0 && kd > 0 && kh > 0 && kw > 0 && D >= kd && H >= kh && W >= kw, VXM_ERR_BAD_SHAPE,
+                "vxm_maxpool3d_k_bwd: window %dx%dx%d does not fit %dx%dx%d", kd, kh, kw, D, H, W);
+    const long long n = (long long)BC * D * H * W;
+    hipLaunchKernelGGL(k_maxpoolk_bwd, dim3(vxm_blocks(n, 256)), dim3(256), 0, VXM_STREAM(stream), x, gy, gx, n, D, H, W, D / kd, H / kh, W / kw, kd, kh, kw);
+    return vxm_check_launch("vxm_maxpool3d_k_bwd");
+}
+
+int vxm_upsample3d_k_cat(const float* x0, int C0, const float* x1, int C1, float* y, int B, int D, int H, int W, int kd, int kh, int kw, void* stream) {
+    VXM_REQUIRE(x0 && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_upsample3d_k_cat: null pointer");
+    VXM_REQUIRE(B > 0 && C0 > 0 && C1 >= 0 && kd > 0 && kh > 0 && kw > 0 && D > 0 && H > 0 && W > 0 && D % kd == 0 && H % kh == 0 && W % kw == 0,
+                VXM_ERR_BAD_SHAPE, "vxm_upsample3d_k_cat: %dx%dx%d is not a multiple of the factors %dx%dx%d", D, H, W, kd, kh, kw);
+    const long long n = (long long)B * (C0 + C1) * D * H * W;
+    hipLaunchKernelGGL(k_upsamplek_cat, dim3(vxm_blocks(n, 256)), dim3(256), 0, VXM_STREAM(stream), x0, C0, x1, C1, y, n, D, H, W, kd, kh, kw);
+    return vxm_check_launch("vxm_upsample3d_k_cat");
+}
+
+int vxm_upsample3d_k_bwd(const float* gy, int Ctot, int C0, float* gx0, int B, int D, int H, int W, int kd, int kh, int kw, void* stream) {
+    VXM_REQUIRE(gy && gx0, VXM_ERR_NULL_POINTER, "vxm_upsample3d_k_bwd: null pointer");
+    VXM_REQUIRE(B > 0 && C0 > 0 && Ctot >= C0 && kd > 0 && kh > 0 && kw > 0 && D > 0 && H > 0 && W > 0 && D % kd == 0 && H % kh == 0 && W % kw == 0,
+                VXM_ERR_BAD_SHAPE, "vxm_upsample3d_k_bwd: %dx%dx%d is not a multiple of the factors %dx%dx%d", D, H, W, kd, kh, kw);
+    const long long n = (long long)B * C0 * (D / kd) * (H / kh) * (W / kw);
+    hipLaunchKernelGGL(k_upsamplek_bwd, dim3(vxm_blocks(n, 256)), dim3(256), 0, VXM_STREAM(stream), gy, Ctot, C0, gx0, n, D, H, W, kd, kh, kw);
+    return vxm_check_launch("vxm_upsample3d_k_bwd");
 }
 
 }  // extern "C"

@@ -465,8 +465,12 @@ def s3u_bwd_low(dz, cout, w, c0, cin, gxl, mask, mask_slope, B, D, H, W):
 
 def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
     v = _lib.lib().vxm_conv3d_k3_s3_variant(cout)
-    rows = _lib.lib().vxm_conv3d_k3_s3_tile_rows(cout, s3_pieces(), H) if _prof.ACTIVE is not None else 4
-    with _prof.region("k_s3_conv<%d,%d,%d,%d>" % (v // 10, rows, v % 10, s3_pieces()), flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+    name = None
+    if _prof.ACTIVE is not None:          # label the region with the kernel the C ABI will dispatch to
+        rows = _lib.lib().vxm_conv3d_k3_s3_tile_rows(cout, s3_pieces(), H)
+        pc = _lib.lib().vxm_conv3d_k3_s3_producer_consumer(cout, s3_pieces(), 0 if mask is None else 1, B, D, H, W)
+        name = "k_s3p_conv<%d,%d>" % (v // 10, s3_pieces()) if pc else "k_s3_conv<%d,%d,%d,%d>" % (v // 10, rows, v % 10, s3_pieces())
+    with _prof.region(name, flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_conv3d_k3_s3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
              cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, s3_pieces(), stream())
 
@@ -609,6 +613,72 @@ def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H
     with _prof.region(name, flops=flops, nominal=nominal):
         call("vxm_conv3d_k3_bwd_weight", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W,
              cout, ptr(gw), ptr(gb), ptr(buf), buf.numel(), B, D, H, W, stream())
+
+
+def _factors3(k, nd):
+    """per-axis factors (kd, kh, kw) of an int or per-axis pooling factor for a 2-D image (depth 1) or a 3-D volume"""
+    ks = [int(v) for v in k] if isinstance(k, (tuple, list)) else [int(k)] * nd
+    if len(ks) != nd or any(v < 1 for v in ks):
+        raise ValueError("pooling factor %r does not fit %d spatial axes" % (k, nd))
+    return [1] * (3 - nd) + ks
+
+
+class MaxPoolKFn(torch.autograd.Function):
+    """MaxPoolNd(k): kernel = stride = k, no padding, floor (voxelmorph/torch/networks.py:83-84,130 with max_pool != 2; images and volumes)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        require_device(x)
+        x = _c(x)
+        nd = x.dim() - 2
+        kd, kh, kw = _factors3(k, nd)
+        D, H, W = [1] * (3 - nd) + list(x.shape[2:])
+        if D < kd or H < kh or W < kw:
+            raise RuntimeError("max_pool: window %s does not fit input %s" % ((kd, kh, kw)[3 - nd:], tuple(x.shape[2:])))
+        y = torch.empty(tuple(x.shape[:2]) + tuple(n // f for n, f in zip((D, H, W), (kd, kh, kw)))[3 - nd:], dtype=x.dtype, device=x.device)
+        call("vxm_maxpool3d_k_fwd", ptr(x), ptr(y), x.shape[0] * x.shape[1], D, H, W, kd, kh, kw, stream())
+        ctx.save_for_backward(x)
+        ctx.geom = (D, H, W, kd, kh, kw)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        D, H, W, kd, kh, kw = ctx.geom
+        gx = torch.empty_like(x)
+        call("vxm_maxpool3d_k_bwd", ptr(x), ptr(_c(gy)), ptr(gx), x.shape[0] * x.shape[1], D, H, W, kd, kh, kw, stream())
+        return gx, None
+
+
+class UpsampleCatKFn(torch.autograd.Function):
+    """cat([Upsample(scale_factor=k, 'nearest')(x), skip], 1) (voxelmorph/torch/networks.py:85,137-138 with max_pool != 2); a skip whose
+    extents differ from the upsampled ones is refused as torch.cat refuses it in the reference."""
+
+    @staticmethod
+    def forward(ctx, x, skip, k):
+        require_device(x, skip)
+        x, skip = _c(x), _c(skip)
+        nd = x.dim() - 2
+        kd, kh, kw = _factors3(k, nd)
+        up = tuple(n * f for n, f in zip(x.shape[2:], (kd, kh, kw)[3 - nd:]))
+        if tuple(skip.shape[2:]) != up or skip.shape[0] != x.shape[0]:
+            raise RuntimeError("Sizes of tensors must match except in dimension 1: upsampled %s, skip connection %s (Unet max_pool)"
+                               % ((x.shape[0],) + up, (skip.shape[0],) + tuple(skip.shape[2:])))
+        B, C0, C1 = x.shape[0], x.shape[1], skip.shape[1]
+        D, H, W = [1] * (3 - nd) + list(up)
+        out = torch.empty((B, C0 + C1) + up, dtype=x.dtype, device=x.device)
+        call("vxm_upsample3d_k_cat", ptr(x), C0, ptr(skip), C1, ptr(out), B, D, H, W, kd, kh, kw, stream())
+        ctx.geom = (B, C0, C1, D, H, W, kd, kh, kw, tuple(x.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C0, C1, D, H, W, kd, kh, kw, xshape = ctx.geom
+        g = _c(g)
+        gx = torch.empty(xshape, dtype=g.dtype, device=g.device)
+        call("vxm_upsample3d_k_bwd", ptr(g), C0 + C1, C0, ptr(gx), B, D, H, W, kd, kh, kw, stream())
+        gskip = g[:, C0:].contiguous() if ctx.needs_input_grad[1] else None
+        return gx, gskip, None
 
 
 class ConvFn(torch.autograd.Function):

@@ -100,9 +100,12 @@ class Unet(nn.Module):
         if ndims == 1:
             raise NotImplementedError("the MI355X Unet implements 2-D images and 3-D volumes")
         enc_nf, dec_nf, final_nf, self.nb_levels = _unet_feature_plan(nb_features, nb_levels, feat_mult, nb_conv_per_level)
-        pools = [max_pool] * self.nb_levels if isinstance(max_pool, int) else list(max_pool)
-        if any(p != 2 for p in pools):
-            raise NotImplementedError("the MI355X Unet implements max_pool=2")
+        # networks.py:79-85: one factor per level, an int is repeated.  Level l pools by max_pool[l] on the way down and upsamples by
+        # max_pool[l] on the way up (the SAME index, not the mirrored one -- as the reference); factors other than 2 take the op-by-op path
+        self.max_pool = [max_pool] * self.nb_levels if isinstance(max_pool, int) else list(max_pool)
+        if len(self.max_pool) < self.nb_levels - 1:
+            raise IndexError("Unet: max_pool lists %d factors for %d pooling levels" % (len(self.max_pool), self.nb_levels - 1))
+        self._pool2 = all(isinstance(p, int) and p == 2 for p in self.max_pool[:self.nb_levels - 1])
         self.ndims, self.half_res, self.nb_conv_per_level = ndims, half_res, nb_conv_per_level
         self._enc_nf, self._dec_nf, self._final_nf, self._infeats = enc_nf, dec_nf, final_nf, infeats
 
@@ -154,10 +157,30 @@ class Unet(nn.Module):
         return self._plans[key]
 
     def forward(self, x):
+        if not self._pool2:
+            return self._forward_general(x)
         if self.ndims == 2:
             return self._forward_planar(x)
         engine = VB.UnetBf16Fn if VB.enabled() else VF.UnetFn       # torch.autocast(bfloat16): blocked-bf16 activations
         return engine.apply(self.plan([x.shape[1]]), x, *self.conv_params())
+
+    def _forward_general(self, x):
+        """networks.py:122-144 op by op for pooling factors other than 2 (images and volumes): ConvBlocks on the HIP conv kernels,
+        MaxPoolNd(k) and Upsample(k, 'nearest') + cat on the general-factor kernels (csrc/pool.hip).  Not reachable through VxmDense."""
+        x_history = [x]
+        for level, convs in enumerate(self.encoder):
+            for conv in convs:
+                x = conv(x)
+            x_history.append(x)
+            x = VF.MaxPoolKFn.apply(x, self.max_pool[level])
+        for level, convs in enumerate(self.decoder):
+            for conv in convs:
+                x = conv(x)
+            if not self.half_res or level < (self.nb_levels - 2):
+                x = VF.UpsampleCatKFn.apply(x, x_history.pop(), self.max_pool[level])
+        for conv in self.remaining:
+            x = conv(x)
+        return x
 
     def _forward_planar(self, x):
         """networks.py:122-144 op by op (2-D slices are small: per-op autograd nodes instead of the fused 3-D engine)."""
