@@ -223,6 +223,16 @@ def main():
             VF.conv_bwd_weight(ws, x, c, c * V, False, None, 0, 0, dz, cout, gw_n, gb_n, B, D, H, W)
             VF.FP32_ENGINE = keep
         t_s3, t_nat = timed(run_s3, args.iters), timed(run_nat, args.iters)
+        if args.dbg:                                       # timing experiments (results wrong), alternating with the plain kernel
+            words = [int(v) for v in args.dbg.split(",")]
+            res = {v: [] for v in [0] + words}
+            for _ in range(2):
+                for v in [0] + words:
+                    os.environ["VXM_S3_DBG"] = str(v)
+                    res[v].append(timed(run_s3, args.iters))
+            os.environ["VXM_S3_DBG"] = "0"
+            print("    dbg: " + " | ".join("%d: %s" % (v, "/".join("%.3f" % t for t in ts)) for v, ts in res.items()), flush=True)
+            run_s3()
         if os.environ.get("VXM_S3_BW_AB"):                 # same-box A/B of the backward-weight pipelines (alternating)
             ab = {"0": [], "1": []}
             for _ in range(3):

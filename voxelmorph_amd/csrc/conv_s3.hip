@@ -418,13 +418,16 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
 // ------------------------------------------------------------------------------------------
 // k_s3p_conv: the same convolution (fp16 pieces, 8-channel chunks, 8 x 8 x 16 tile, running scale) with PRODUCER and CONSUMER waves.
 // ------------------------------------------------------------------------------------------
-// Why.  k_s3_conv alternates, inside every block, "multiply chunk q" and "wait for chunk q + 1, split it, write it to LDS": measured on
-// the full-resolution 16 -> 16 layer (tools/exp_s3.sh, -DVXM_S3_EXP) its time is the SUM of its parts -- 0.44 ms = reads 0.16 + MFMA 0.05 +
-// stores 0.08 + split / weights / barriers 0.15 -- although two blocks share a CU: every block of the chip starts at the same moment and
-// runs the same cadence, so the chip alternates between "everybody waits for memory" and "nobody loads".  Here one block of 16 waves
-// owns the CU: waves 8 .. 15 only fetch, split and write (chunk k + 2 in flight from HBM while chunk k + 1 is split into the second LDS
-// buffer), waves 0 .. 7 only multiply chunk k out of the first buffer and store finished tiles.  Requests are in flight all the time, the
-// split arithmetic runs beside the MFMAs of other waves of the same SIMD, and there is ONE barrier per chunk.
+// Why.  k_s3_conv alternates, inside every block, "multiply chunk q" and "wait for chunk q + 1, split it, write it to LDS"; its time on
+// the full-resolution 16 -> 16 layer is the SUM of its parts (profiles/r04y_conv_kernel_experiments.txt: 0.44 ms = reads 0.16 + MFMA 0.05 +
+// stores 0.08 + split / weights / barriers 0.15) although two blocks share a CU.  Here one block of 16 waves owns the CU: waves 8 .. 15
+// only fetch, split and write (chunk k + 2 in flight from HBM while chunk k + 1 is split into the second LDS buffer), waves 0 .. 7 only
+// multiply chunk k out of the first buffer and store finished tiles; the split arithmetic runs beside the MFMAs of other waves of the same
+// SIMD and there is ONE barrier per chunk.  Measured (same file): -4 .. -5 % on the forward launches, and -- because the 32 blocks of an
+// XCD now walk neighbouring tiles in step -- memory-side reads of 558 MB instead of 844 MB per launch for 440 MB of input (TCC_EA0_RDREQ,
+// all 128-byte requests) and writes of 448 instead of 543 MB.  What bounds both kernels is the vector L1: ~23 M 64-byte requests per
+// launch at ~510 cycles average L2 latency with the TCP stalled on pending data half of the time, i.e. ~12 GB/s per CU; a haloed 72-byte
+// row of a planar tensor costs three sector requests (with the addresses of a channel-blocked tensor the same kernel runs 20 - 28 % faster).
 // The chunk stream of a block: c = (tile i of the block, chunk q of the tile), c = 0 .. nphase - 1.  Phase k (k = -1 .. nphase - 1):
 //   producers: request the weights of chunk k + 1 and the raw fp32 of chunk k + 2 (register set k & 1), split chunk k + 1 (set (k + 1) & 1,
 //              scale from the maxima published in phase k - 1) into LDS buffer (k + 1) & 1, wait for chunk k + 2, publish its wave maxima
@@ -441,7 +444,7 @@ template <int NCT> struct S3PCfg {
 template <int NCT>
 __global__ void __launch_bounds__(S3P_THREADS)
 k_s3p_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout,
-           float act_slope, const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W, int Q0, int Q) {
+           float act_slope, const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W, int Q0, int Q, int dbg) {
     using PC = S3PCfg<NCT>;
     using C = typename PC::C;
     using P = S3P<2>;
@@ -510,8 +513,16 @@ k_s3p_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bi
             for (int j = 0; j < NI; ++j) {
                 const int gd = d0 - 1 + (spos[j] >> 10), gh = h0 - 1 + ((spos[j] >> 5) & 31), gw = w0 - 1 + (spos[j] & 31);
                 const int sv = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
-                const bool ok = spos[j] >= 0 && cbg * 8 < Cseg;  // segments carry multiples of 8 channels
+                const bool ok = spos[j] >= 0 && cbg * 8 < Cseg && !S3_DBG(dbg, 1);  // segments carry multiples of 8 channels
                 voffs[S][j] = ok ? (cbg * 8 * Vs + sv) << 2 : VXM_OOB;
+                if (S3_DBG(dbg, 256)) {                            // timing experiment: the addresses of a channel-blocked tensor [C / 8][voxel][8]
+                    voffs[S][j] = ok ? (cbg * Vs + sv) << 5 : VXM_OOB;
+                    const u32x4 lo = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[S][j], 0, 0));
+                    const u32x4 hi = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[S][j], 16, 0));
+                    xr[S][j][0] = __uint_as_float(lo.x); xr[S][j][1] = __uint_as_float(lo.y); xr[S][j][2] = __uint_as_float(lo.z); xr[S][j][3] = __uint_as_float(lo.w);
+                    xr[S][j][4] = __uint_as_float(hi.x); xr[S][j][5] = __uint_as_float(hi.y); xr[S][j][6] = __uint_as_float(hi.z); xr[S][j][7] = __uint_as_float(hi.w);
+                    continue;
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) xr[S][j][e] = vxm_bload(r, voffs[S][j], (e * Vs) << 2);
             }
@@ -646,6 +657,7 @@ k_s3p_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bi
 #pragma unroll
                     for (int r = 0; r < ROWS; ++r) acc[ct][r] *= ratio;
             }
+            if (!S3_DBG(dbg, 2)) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 u32x4 a[3][2][NCT], bf[2][2];
@@ -699,6 +711,7 @@ k_s3p_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bi
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            }
             __syncthreads();                                    // chunk k is read; chunk k + 1 is in the other buffer
         }
         // ---- epilogue (as k_s3_conv): undo the scales, bias + LeakyReLU (+ fused leaky_relu_backward mask), planar fp32 store
@@ -708,8 +721,21 @@ k_s3p_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bi
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) acc[ct][r] *= fin;
         const int d = cd0 + wave, w = cw0 + n;
+        if (S3_DBG(dbg, 512)) {                                 // timing experiment: stores of a channel-blocked tensor, 16 bytes per lane, no mask
+            const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(y + (size_t)cbt * y_bs, (unsigned)Cout * (unsigned)V * 4u);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int row = 0; row < ROWS; ++row) {
+                    const int vox = (d * H + ch0 + row) * W + w;
+                    const bool ok = d < D && w < W && ch0 + row < H && (g * NCT + ct) * 16 + kg * 4 < Cout;
+                    const f32x4 v = acc[ct][row];
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, ry,
+                                                           ok ? ((((g * NCT + ct) * 2 + (kg >> 1)) * V + vox) << 5) + ((kg & 1) << 4) : VXM_OOB, 0, 0);
+                }
+        } else
         conv_epilogue_store<NCT, ROWS, 1>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
-                                          d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V);
+                                          d < D && w < W && !S3_DBG(dbg, 4), (d * H + ch0) * W + w, ch0, H, W, V);
     }
 }
 
@@ -843,7 +869,7 @@ struct SwTasks { int ncol, nseg, seg_len, nd, nh, nw; };       // tasks = (colum
 template <int NP, bool PIPE2 = true>
 __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __restrict__ x, long long x_bs, int C, const float* __restrict__ dz,
                                                               long long dz_bs, int Cdz, float* __restrict__ part, int D, int H, int W, int NBLK,
-                                                              int NCO, SwTasks tk, int task_rr) {
+                                                              int NCO, SwTasks tk, int task_rr, int dbg) {
     using P = S3P<NP>;
     using CF = SwCfg<NP>;
     VXM_DYN_SMEM(char, smem);
@@ -951,6 +977,19 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
             asm volatile("" : "+v"(f0), "+v"(f1), "+v"(fz), "+v"(fz1));
             vk[S] = xrole ? ((off0 + (x_pl ? o1 : o0)) | (x_pl ? f1 : f0)) : (off0 | (z_ds ? fz1 : fz));
             const int sb = xrole ? 0 : (gz * HW) << 2;
+            if (S3_DBG(dbg, 1) && xrole) vk[S] = VXM_OOB;        // timing experiments: no X reads / no dZ reads
+            if (S3_DBG(dbg, 4) && !xrole) vk[S] = VXM_OOB;
+            if (S3_DBG(dbg, 256)) {                               // the addresses of a channel-blocked tensor [C / 8][voxel][8]: 64 contiguous bytes per slot
+                const int cb8 = (xrole ? q * 2 : cot * 2) + ((xrole ? x_r : s_i) & 1);
+                const int vox = ((vk[S] & 0x3fffffff) >> 2) % V;  // (voxel index of the planar offset; out-of-range lanes stay out of range)
+                const int bo = vk[S] < 0 || vk[S] >= VXM_OOB ? VXM_OOB : ((cb8 * V + vox + ((sb >> 2) % V)) << 5);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const u32x4 t4 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, bo, e * 16, 0));
+                    ra[S][2 * e] = __uint_as_float(t4.x); rb[S][2 * e] = __uint_as_float(t4.y); ra[S][2 * e + 1] = __uint_as_float(t4.z); rb[S][2 * e + 1] = __uint_as_float(t4.w);
+                }
+                return;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, vk[S], sb + ((e * V) << 2), 0));
@@ -1033,6 +1072,7 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
         using I1 = std::integral_constant<int, NP == 2 ? 1 : 0>;
         // the MFMA phase of tile t: this wave's chains, folded into the running totals
         auto mfma_tile = [&](int t) __attribute__((always_inline)) {
+            if (S3_DBG(dbg, 2)) return;
             const char* const xp = Xs + ((2 * t + ds + kd) % SW_RING) * SW_PLANE;
             const int zcur = NP == 2 ? (t & 1) : 0;              // dZ buffer of this tile
             float unscale_x = 1.0f, unscale_z = 1.0f;
@@ -1412,7 +1452,7 @@ void s3p_launch(const ConvIn& in, const void* wp, const float* bias, float* y, l
         if (cap < gx) gx = cap;
     }
     hipLaunchKernelGGL((k_s3p_conv<NCT>), dim3(gx, G), dim3(S3P_THREADS), PC::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
-                       Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q);
+                       Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q, s3_dbg());
 }
 
 }  // namespace
@@ -1571,13 +1611,13 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
     const int task_rr = ((te && te[0] == 'r' && te[1] == 'a') || (long long)D * H * W < (1ll << 21)) ? 0 : 1;
     if (pieces == 2 && pe && pe[0] == '1')
         hipLaunchKernelGGL((k_s3_bwd_weight<2, false>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr);
+                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, s3_dbg());
     else if (pieces == 2)
         hipLaunchKernelGGL((k_s3_bwd_weight<2, true>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr);
+                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, s3_dbg());
     else
         hipLaunchKernelGGL((k_s3_bwd_weight<3, true>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<3>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr);
+                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, s3_dbg());
     const int n = 16 * NCO * 16 * Q * 28;
     hipLaunchKernelGGL(k_s3_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(1024), 0, s, part, gw, gb, C, Cout, gw_cin, ci_off, Q, NCO, NBLK);
     return vxm_check_launch("vxm_conv3d_k3_s3_bwd_weight");
