@@ -330,6 +330,15 @@ int vxm_bf16_lrelu_bwd(const void* g, const void* y, void* dz, float slope, int6
  * `pieces` to packed_bytes / the pack job / the launch).
  * vxm_conv3d_k3_s3_ok: 1 when the split kernel takes a launch of this shape (otherwise use vxm_conv3d_k3_fwd). */
 int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W);
+/* Layout flags, OR-ed into the `pieces` argument of the launch entry points of the split engine (fp16 scheme only).  A flagged tensor is
+ * CHANNEL-BLOCKED: [B][C/8][D][H][W][8] fp32 (element (c, v) of a sample at ((c / 8) V + v) 8 + c % 8; C % 8 == 0; same batch strides as
+ * NCDHW).  Used BETWEEN the kernels of the fused U-Net for tensors only split kernels touch: a haloed row of a staged tile is then one
+ * contiguous run instead of eight 72-byte pieces.  Values and results are those of the planar launch, bit for bit.
+ * Which operand a flag names is stated at each entry point; vxm_conv3d_k3_s3_layout_ok tells whether vxm_conv3d_k3_s3_fwd takes them. */
+#define VXM_S3_IN0_BLOCKED 0x100   /* first tensor operand  */
+#define VXM_S3_IN1_BLOCKED 0x200   /* second tensor operand */
+#define VXM_S3_OUT_BLOCKED 0x400   /* output tensor and, where there is one, the mask tensor of the fused leaky_relu_backward */
+int vxm_conv3d_k3_s3_layout_ok(int C0, int C1, int x0_up, int Cout, int H, int pieces);
 int vxm_conv3d_k3_s3_variant(int Cout);                     /* 10 * NCT + CB of the kernel instance (profiling labels) */
 int vxm_conv3d_k3_s3_tile_rows(int Cout, int pieces, int H); /* rows of its output tile: 8 x 8 x 16 on the fp16 scheme, else 8 x 4 x 16 */
 /* 1 when the launch runs k_s3p_conv (the same tile, operator pack and results with producer and consumer waves: 16-output-channel

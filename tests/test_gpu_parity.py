@@ -1012,6 +1012,42 @@ def test_full_size_train_step_vs_oracle_noise_pair(vxm):
     _full_size_step_vs_oracle(vxm, src, trg, seed=11, flow_std=0.05)
 
 
+def test_channel_blocked_interior_tensors_change_no_bit_of_the_step(vxm):
+    """The fused U-Net keeps the activations that only split kernels touch channel-blocked (functional._blocked_tensors; VXM_BLOCKED=0
+    turns it off).  Layout is not arithmetic: the full headline step -- moved image, field, loss and every parameter gradient -- must be
+    BIT-IDENTICAL with and without it, at the size the metric is quoted on and at a size where only part of the chain qualifies."""
+    from voxelmorph_amd.torch import functional as VF
+    if VF.FP32_ENGINE != "f16x2":
+        pytest.skip("channel-blocked tensors exist on the fp16 piece scheme only")
+    keep = VF.BLOCKED
+    try:
+        for shape, B, expect in ((FULL, 1, 2), ((64, 96, 128), 2, 1)):
+            rng = np.random.default_rng(77)
+            src, trg = G(rng.random((B, 1) + shape)), G(rng.random((B, 1) + shape))
+            torch.manual_seed(3)
+            model = vxm.networks.VxmDense(shape, int_steps=7, int_downsize=2).cuda()
+            with torch.no_grad():
+                model.flow.weight.normal_(0, 0.02)
+            plan = model.unet_model.plan(model._feats, extra=((model.flow.out_channels, 1.0),))
+            VF.BLOCKED = True
+            assert len(VF._blocked_tensors(plan, B, shape)) >= expect, (shape, VF._blocked_tensors(plan, B, shape))
+            results = []
+            for flag in (False, True):
+                VF.BLOCKED = flag
+                for p in model.parameters():
+                    p.grad = None
+                moved, field = model(src, trg)
+                loss = vxm.losses.NCC().loss(trg, moved) + vxm.losses.Grad("l2", loss_mult=2).loss(None, field)
+                loss.backward()
+                results.append([moved.detach().clone(), field.detach().clone(), loss.detach().clone()] + [p.grad.clone() for p in model.parameters()])
+            for a, b in zip(*results):
+                assert torch.equal(a, b)
+            del model, results, src, trg
+            torch.cuda.empty_cache()
+    finally:
+        VF.BLOCKED = keep
+
+
 def test_full_size_train_step_batch_of_two_vs_oracle(vxm):
     """The same step with TWO pairs in the batch (scripts/torch/train.py:128-129,200-220: the per-GPU batch of BASELINE
     configs[3] is > 1): batch strides, 32-bit buffer offsets of the second sample and the batch mean of both losses at the

@@ -33,6 +33,20 @@ def VF(request):
     functional.FP32_ENGINE = keep
 
 
+@pytest.fixture()
+def VF16():
+    """the functional module on the fp16 piece scheme (the channel-blocked operands exist there only)"""
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a HIP device")
+    from voxelmorph_amd import _lib as lib_
+    lib_.lib()
+    from voxelmorph_amd.torch import functional
+    keep = functional.FP32_ENGINE
+    functional.FP32_ENGINE = "f16x2"
+    yield functional
+    functional.FP32_ENGINE = keep
+
+
 def rel_l2(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
@@ -343,6 +357,107 @@ def test_s3_backward_weight_refuses_odd_width(VF):
         VF.s3_bwd_weight(VF._Workspace(x.device), x, 16, x[0].numel(), x, 16, gw, 16, 0, gb, 1, 4, 8, 33)
 
 
+# ------------------------------------------------------------------ channel-blocked operands (VXM_S3_*_BLOCKED)
+def _eq(a, b):
+    return torch.equal(a, b)
+
+
+@pytest.mark.parametrize("vol", [(8, 16, 32), (9, 21, 37), (16, 24, 48)])
+@pytest.mark.parametrize("c0,cout", [(16, 16), (32, 16), (16, 32), (8, 24)])
+def test_s3_conv_channel_blocked_operands_bit_exact(VF16, c0, cout, vol):
+    """include/vxm_hip.h VXM_S3_IN0_BLOCKED / VXM_S3_OUT_BLOCKED on the 8-row instances of k_s3_conv (and k_s3p_conv: re-run with
+    VXM_S3_PC=1 in the subprocess test): the same values in the channel-blocked layout give the same bits -- forward operators (bias,
+    LeakyReLU) and adjoints with a fused mask, input / output / both, one and two samples, a 24-channel output (partial second tile)."""
+    VF = VF16
+    D, H, W = vol
+    V = D * H * W
+    torch.manual_seed(5)
+    for flip in (False, True):
+        for B in (1, 2):
+            x = torch.randn(B, c0, D, H, W, device="cuda")
+            w = torch.randn(*((c0, cout) if flip else (cout, c0)), 3, 3, 3, device="cuda") / (27 * c0) ** 0.5
+            bias = None if flip else torch.randn(cout, device="cuda")
+            mask = torch.randn(B, cout, D, H, W, device="cuda") if flip else None
+            wp = VF.s3_pack(w, flip, 0, cout if flip else c0, c0)
+            sl = 1.0 if flip else 0.2
+            y0 = torch.empty(B, cout, D, H, W, device="cuda")
+            VF.s3_launch(x, c0, c0 * V, False, None, 0, 0, wp, bias, y0, cout * V, cout, sl, mask, cout * V, 0.2, B, D, H, W)
+            for lay in (VF.S3_IN0_BLOCKED, VF.S3_OUT_BLOCKED, VF.S3_IN0_BLOCKED | VF.S3_OUT_BLOCKED):
+                xin = VF.to_blocked(x) if lay & VF.S3_IN0_BLOCKED else x
+                mk = (VF.to_blocked(mask) if lay & VF.S3_OUT_BLOCKED else mask) if mask is not None else None
+                y1 = torch.full_like(y0, float("nan"))
+                VF.s3_launch(xin, c0, c0 * V, False, None, 0, 0, wp, bias, y1, cout * V, cout, sl, mk, cout * V, 0.2, B, D, H, W, lay=lay)
+                assert _eq(y0, VF.from_blocked(y1) if lay & VF.S3_OUT_BLOCKED else y1), (flip, B, hex(lay))
+
+
+def test_s3_layout_flags_are_refused_where_no_blocked_variant_exists(VF16):
+    VF = VF16
+    x = torch.randn(1, 16, 8, 4, 32, device="cuda")               # H = 4: the 4-row instance
+    w = torch.randn(16, 16, 3, 3, 3, device="cuda")
+    y = torch.empty_like(x)
+    with pytest.raises(Exception, match="layout flags"):
+        VF.s3_launch(x, 16, x[0].numel(), False, None, 0, 0, VF.s3_pack(w, False, 0, 16, 16), None, y, y[0].numel(), 16, 0.2, None, 0, 1.0,
+                     1, 8, 4, 32, lay=VF.S3_IN0_BLOCKED)
+    from voxelmorph_amd import _lib
+    assert not _lib.lib().vxm_conv3d_k3_s3_layout_ok(16, 16, 0, 16, 16, 2)       # two segments
+    assert not _lib.lib().vxm_conv3d_k3_s3_layout_ok(16, 0, 0, 16, 16, 3)        # bf16 pieces
+    assert _lib.lib().vxm_conv3d_k3_s3_layout_ok(32, 0, 0, 16, 16, 2)
+
+
+@pytest.mark.parametrize("vol", [(8, 16, 32), (10, 20, 38), (16, 24, 64)])
+@pytest.mark.parametrize("c,cout", [(16, 16), (32, 16), (16, 32)])
+def test_s3_backward_weight_channel_blocked_operands_bit_exact(VF16, c, cout, vol):
+    """k_s3_bwd_weight with x and / or dz channel-blocked (the task loop is instantiated per staging role and layout): same bits"""
+    VF = VF16
+    D, H, W = vol
+    V = D * H * W
+    torch.manual_seed(6)
+    for B in (1, 2):
+        x, dz = torch.randn(B, c, D, H, W, device="cuda"), torch.randn(B, cout, D, H, W, device="cuda")
+        ws = VF._Workspace(x.device)
+        g0, b0 = torch.empty(cout, c, 3, 3, 3, device="cuda"), torch.empty(cout, device="cuda")
+        VF.s3_bwd_weight(ws, x, c, c * V, dz, cout, g0, c, 0, b0, B, D, H, W)
+        for lay in (VF.S3_IN0_BLOCKED, VF.S3_IN1_BLOCKED, VF.S3_IN0_BLOCKED | VF.S3_IN1_BLOCKED):
+            g1, b1 = torch.full_like(g0, float("nan")), torch.full_like(b0, float("nan"))
+            VF.s3_bwd_weight(ws, VF.to_blocked(x) if lay & VF.S3_IN0_BLOCKED else x, c, c * V, VF.to_blocked(dz) if lay & VF.S3_IN1_BLOCKED else dz,
+                             cout, g1, c, 0, b1, B, D, H, W, lay=lay)
+            assert _eq(g0, g1) and _eq(b0, b1), (B, hex(lay))
+
+
+@pytest.mark.parametrize("vol", [(8, 8, 32), (10, 12, 36), (16, 24, 64)])
+@pytest.mark.parametrize("c0,c1,cout", [(32, 16, 32), (16, 16, 16), (32, 32, 32), (16, 8, 24)])
+def test_s3u_kernels_channel_blocked_operands_bit_exact(VF16, c0, c1, cout, vol):
+    """the cat([upsample, skip]) kernels: channel-blocked OUTPUT of the forward (k_s3u_conv), channel-blocked dz of the backward-data onto
+    the low-resolution tensor (k_s3u_dlow) and of the weight gradient of the upsampled segment (k_s3u_bww): same bits as the planar launch"""
+    VF = VF16
+    D, H, W = vol
+    V = D * H * W
+    torch.manual_seed(7)
+    for B in (1, 2):
+        x0, x1 = torch.randn(B, c0, D // 2, H // 2, W // 2, device="cuda"), torch.randn(B, c1, D, H, W, device="cuda")
+        w = torch.randn(cout, c0 + c1, 3, 3, 3, device="cuda") / (27 * (c0 + c1)) ** 0.5
+        bias = torch.randn(cout, device="cuda")
+        wp = VF.s3u_pack(w, c0, c1)
+        y0 = torch.empty(B, cout, D, H, W, device="cuda")
+        y1 = torch.full_like(y0, float("nan"))
+        VF.s3u_launch(x0, c0, x0[0].numel(), x1, c1, c1 * V, wp, bias, y0, cout * V, cout, 0.2, B, D, H, W)
+        VF.s3u_launch(x0, c0, x0[0].numel(), x1, c1, c1 * V, wp, bias, y1, cout * V, cout, 0.2, B, D, H, W, lay=VF.S3_OUT_BLOCKED)
+        assert _eq(y0, VF.from_blocked(y1)), B
+        dz = torch.randn(B, cout, D, H, W, device="cuda")
+        dzb = VF.to_blocked(dz)
+        act = torch.randn(B, c0, D // 2, H // 2, W // 2, device="cuda")
+        g0, g1 = torch.empty_like(act), torch.full_like(act, float("nan"))
+        VF.s3u_bwd_low(dz, cout, w, c0, c0 + c1, g0, act, 0.2, B, D, H, W)
+        VF.s3u_bwd_low(dzb, cout, w, c0, c0 + c1, g1, act, 0.2, B, D, H, W, lay=VF.S3_IN0_BLOCKED)
+        assert _eq(g0, g1), B
+        if c0 in (16, 32) and cout % 16 == 0 and W % 4 == 0 and D % 2 == 0 and H % 2 == 0:
+            ws = VF._Workspace(dz.device)
+            gw0, gw1 = torch.zeros(cout, c0 + c1, 3, 3, 3, device="cuda"), torch.zeros(cout, c0 + c1, 3, 3, 3, device="cuda")
+            VF.s3u_bwd_weight(ws, x0, c0, x0[0].numel(), dz, cout, gw0, c0 + c1, B, D, H, W)
+            VF.s3u_bwd_weight(ws, x0, c0, x0[0].numel(), dzb, cout, gw1, c0 + c1, B, D, H, W, lay=VF.S3_IN1_BLOCKED)
+            assert _eq(gw0, gw1), B
+
+
 def _rerun(env_extra, select, files=("tests/test_gpu_s3.py",), timeout=900):
     env = dict(os.environ, **env_extra)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu"] + [os.path.join(ROOT, f) for f in files] + ["-k", select],
@@ -362,7 +477,7 @@ def test_s3_other_kernel_instances_in_subprocess():
     _rerun({"VXM_S3_PERSIST": "0"}, "many_tiles")
     # the producer / consumer kernel (k_s3p_conv: by default from 2048 tiles of 8 x 8 x 16 up) on every eligible launch, with one block per
     # tile and with 16 blocks in all (every block streams several tiles through its two LDS buffers); and the alternating kernel everywhere
-    _rerun({"VXM_S3_PC": "1"}, "forward_vs_fp64 or fused_mask or scale_invariance or dynamic_range or many_tiles")
+    _rerun({"VXM_S3_PC": "1"}, "forward_vs_fp64 or fused_mask or scale_invariance or dynamic_range or many_tiles or s3_conv_channel_blocked")
     _rerun({"VXM_S3_PC": "1", "VXM_S3P_BLOCKS": "16"}, "forward_vs_fp64 or fused_mask or dynamic_range or many_tiles")
     _rerun({"VXM_S3_PC": "0"}, "many_tiles")
     _rerun({"VXM_S3U_PERSIST": "-16"}, "s3u_collapsed")

@@ -108,6 +108,7 @@ SIGNATURES = {
     "vxm_conv3d_k3_s3_variant": [_I],
     "vxm_conv3d_k3_s3_tile_rows": [_I, _I, _I],
     "vxm_conv3d_k3_s3_producer_consumer": [_I, _I, _I, _I, _I, _I, _I],
+    "vxm_conv3d_k3_s3_layout_ok": [_I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3_packed_bytes": [_I, _I, _I, _I],
     "vxm_conv3d_k3_s3_pack_weights_batch": [_P, _I, _P],
     "vxm_conv3d_k3_s3_fwd": [_P, _I, _L, _I, _P, _I, _L, _P, _P, _P, _L, _I, _F, _P, _L, _F, _I, _I, _I, _I, _I, _P],

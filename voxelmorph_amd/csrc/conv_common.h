@@ -174,6 +174,48 @@ __device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS * HAL
     }
 }
 
+// ---- the same epilogue for a CHANNEL-BLOCKED output tensor [Cout / 8][voxel][8] (and mask, same layout): the 4 channels a lane holds per
+// 16-channel tile are 16 contiguous bytes of a voxel's 32-byte group -- one 16-byte store (and mask load) per row, 512 contiguous bytes
+// per pair of lane groups.  Cout % 8 == 0 (so a lane's 4 channels exist or not together).  Same arithmetic as conv_epilogue_store.
+template <int NCT, int ROWS>
+__device__ __forceinline__ void conv_epilogue_store_blocked(f32x4 (&acc)[NCT][ROWS], float* __restrict__ yb, const float (&bz)[NCT][4],
+                                                            const float* __restrict__ maskb, float act_slope, float mask_slope, int Cout, int g, int kq,
+                                                            bool vox_ok, int vox, int h0, int H, int W, int V) {
+    const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(yb, (unsigned)Cout * (unsigned)V * 4u);
+    const __amdgpu_buffer_rsrc_t rm = vxm_rsrc(maskb ? maskb : yb, (unsigned)Cout * (unsigned)V * 4u);
+    const int cbase = g * NCT * 16 + kq * 4;
+    const int voff = (((cbase >> 3) * V + vox) << 5) + ((kq & 1) << 4);
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+        const bool ok = vox_ok && cbase + 16 * ct < Cout;
+        const int soff_ct = ((g * NCT + ct) * 16 < Cout ? 2 * ct : 0) * V;      // wave-uniform, kept inside the tensor (see conv_epilogue_store); a tile beyond Cout is dropped by `ok`
+        f32x4 mk[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) mk[r] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
+        if (maskb) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+                mk[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, ok ? voff : VXM_OOB, (soff_ct + r * W) << 5, 0));
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mk[r][j] = vxm_lrelu_grad(mk[r][j], mask_slope);
+        }
+#pragma unroll
+        for (int row = 0; row < ROWS; ++row) {
+            if (h0 + row < H) {                      // wave-uniform
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[ct][row][j] + bz[ct][j];
+                    o[j] = (v > 0.0f ? v : v * act_slope) * mk[row][j];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, ok ? voff : VXM_OOB, (soff_ct + row * W) << 5, 0);
+            }
+        }
+    }
+}
+
 int check_conv(const char* fn, int C0, int C1, int x0_up, int Cout, int B, int D, int H, int W) {
     VXM_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C0 > 0 && C1 >= 0 && Cout > 0, VXM_ERR_BAD_SHAPE,
                 "%s: bad shape B=%d C0=%d C1=%d Cout=%d D=%d H=%d W=%d", fn, B, C0, C1, Cout, D, H, W);

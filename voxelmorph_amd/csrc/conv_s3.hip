@@ -78,10 +78,13 @@ struct S3Cfg {
 // trailer word {1 / weight scale, weight scale, -, -}.  Q0 chunks cover segment 0.
 // RUN (NP = 2 only): the tile's accumulators take the MFMA chains directly and carry a RUNNING power-of-two scale (as conv_s3u.hip) instead of
 // a per-chunk accumulator set folded by the vector ALU: 4 NCT ROWS registers fewer -- what lets the 8-row tile keep two blocks per CU.
-template <int NCT, int ROWS, int CB, int NP, bool RUN = false>
+// BLK (NP = 2, CB = 1, no upsampling gather): the input tensor is CHANNEL-BLOCKED [C / 8][voxel][8] -- the 8 channels of a staging slot are 32
+// contiguous bytes, a haloed row of the tile 576 contiguous bytes instead of 8 x 72 (the vector L1's sector requests bound
+// these kernels).  lay & VXM_S3_OUT_BLOCKED: output (and mask) tensor in the same layout.  Same values, same arithmetic, same results.
+template <int NCT, int ROWS, int CB, int NP, bool RUN = false, bool BLK = false>
 __global__ void __launch_bounds__(S3_THREADS, (S3Cfg<NCT, ROWS, CB, NP>::MIN_WAVES))
 k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout,
-          float act_slope, const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W, int Q0, int Q, int dbg) {
+          float act_slope, const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W, int Q0, int Q, int lay, int dbg) {
     using C = S3Cfg<NCT, ROWS, CB, NP>;
     using P = S3P<NP>;
     VXM_DYN_SMEM(u32x4, smem);
@@ -177,12 +180,12 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
             const int sv = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
             const bool ok = spos[j] >= 0 && (cbg + cb) * 8 < Cseg && q < Q;  // segments carry multiples of 8 channels; q == Q: nothing to fetch
             voffs[j] = ok ? ((cbg + cb) * 8 * Vs + sv) << 2 : VXM_OOB;
-            if (S3_DBG(dbg, 256)) {                                // timing experiment: the addresses of a channel-blocked tensor [C / 8][voxel][8]
+            if constexpr (BLK) {
                 voffs[j] = ok ? ((cbg + cb) * Vs + sv) << 5 : VXM_OOB;
-                const u32x4 lo = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[j], 0, 0));
-                const u32x4 hi = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[j], 16, 0));
-                xr[j][0] = __uint_as_float(lo.x); xr[j][1] = __uint_as_float(lo.y); xr[j][2] = __uint_as_float(lo.z); xr[j][3] = __uint_as_float(lo.w);
-                xr[j][4] = __uint_as_float(hi.x); xr[j][5] = __uint_as_float(hi.y); xr[j][6] = __uint_as_float(hi.z); xr[j][7] = __uint_as_float(hi.w);
+                const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[j], 0, 0));
+                const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[j], 16, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xr[j][e] = lo[e]; xr[j][4 + e] = hi[e]; }
                 continue;
             }
 #pragma unroll
@@ -394,18 +397,10 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     const int d = cd0 + wave, w = cw0 + n;
     float bz[NCT][4];
     conv_load_bias<NCT>(bz, bias, Cout, g, kg);
-    if (S3_DBG(dbg, 512)) {                                     // timing experiment: stores of a channel-blocked tensor, 16 bytes per lane, no mask
-        const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(y + (size_t)cbt * y_bs, (unsigned)Cout * (unsigned)V * 4u);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int row = 0; row < ROWS; ++row) {
-                const int vox = (d * H + ch0 + row) * W + w;
-                const bool ok = d < D && w < W && ch0 + row < H && (g * NCT + ct) * 16 + kg * 4 < Cout;
-                const f32x4 v = acc[ct][row];
-                __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, ry,
-                                                       ok ? ((((g * NCT + ct) * 2 + (kg >> 1)) * V + vox) << 5) + ((kg & 1) << 4) : VXM_OOB, 0, 0);
-            }
+    if (lay & VXM_S3_OUT_BLOCKED) {
+        if constexpr (NP == 2 && CB == 1)
+            conv_epilogue_store_blocked<NCT, ROWS>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g,
+                                                   kg, d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V);
     } else if (S3_DBG(dbg, 8))
         conv_epilogue_store<NCT, ROWS, 1, 2>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
                                              d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V);
@@ -441,10 +436,10 @@ template <int NCT> struct S3PCfg {
     static constexpr int LDS_BYTES = 2 * BUF * 16 + 128;         // + [2][8] wave maxima, [2]{ratio, 1 / scale}
 };
 
-template <int NCT>
+template <int NCT, bool BLK = false>
 __global__ void __launch_bounds__(S3P_THREADS)
 k_s3p_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout,
-           float act_slope, const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W, int Q0, int Q, int dbg) {
+           float act_slope, const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W, int Q0, int Q, int lay, int dbg) {
     using PC = S3PCfg<NCT>;
     using C = typename PC::C;
     using P = S3P<2>;
@@ -515,12 +510,12 @@ k_s3p_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bi
                 const int sv = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
                 const bool ok = spos[j] >= 0 && cbg * 8 < Cseg && !S3_DBG(dbg, 1);  // segments carry multiples of 8 channels
                 voffs[S][j] = ok ? (cbg * 8 * Vs + sv) << 2 : VXM_OOB;
-                if (S3_DBG(dbg, 256)) {                            // timing experiment: the addresses of a channel-blocked tensor [C / 8][voxel][8]
+                if constexpr (BLK) {                               // channel-blocked input [C / 8][voxel][8] (see k_s3_conv)
                     voffs[S][j] = ok ? (cbg * Vs + sv) << 5 : VXM_OOB;
-                    const u32x4 lo = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[S][j], 0, 0));
-                    const u32x4 hi = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[S][j], 16, 0));
-                    xr[S][j][0] = __uint_as_float(lo.x); xr[S][j][1] = __uint_as_float(lo.y); xr[S][j][2] = __uint_as_float(lo.z); xr[S][j][3] = __uint_as_float(lo.w);
-                    xr[S][j][4] = __uint_as_float(hi.x); xr[S][j][5] = __uint_as_float(hi.y); xr[S][j][6] = __uint_as_float(hi.z); xr[S][j][7] = __uint_as_float(hi.w);
+                    const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[S][j], 0, 0));
+                    const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[S][j], 16, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { xr[S][j][e] = lo[e]; xr[S][j][4 + e] = hi[e]; }
                     continue;
                 }
 #pragma unroll
@@ -721,18 +716,9 @@ k_s3p_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bi
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) acc[ct][r] *= fin;
         const int d = cd0 + wave, w = cw0 + n;
-        if (S3_DBG(dbg, 512)) {                                 // timing experiment: stores of a channel-blocked tensor, 16 bytes per lane, no mask
-            const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(y + (size_t)cbt * y_bs, (unsigned)Cout * (unsigned)V * 4u);
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-                for (int row = 0; row < ROWS; ++row) {
-                    const int vox = (d * H + ch0 + row) * W + w;
-                    const bool ok = d < D && w < W && ch0 + row < H && (g * NCT + ct) * 16 + kg * 4 < Cout;
-                    const f32x4 v = acc[ct][row];
-                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, ry,
-                                                           ok ? ((((g * NCT + ct) * 2 + (kg >> 1)) * V + vox) << 5) + ((kg & 1) << 4) : VXM_OOB, 0, 0);
-                }
+        if (lay & VXM_S3_OUT_BLOCKED) {
+            conv_epilogue_store_blocked<NCT, ROWS>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g,
+                                                   kg, d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V);
         } else
         conv_epilogue_store<NCT, ROWS, 1>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
                                           d < D && w < W && !S3_DBG(dbg, 4), (d * H + ch0) * W + w, ch0, H, W, V);
@@ -869,7 +855,7 @@ struct SwTasks { int ncol, nseg, seg_len, nd, nh, nw; };       // tasks = (colum
 template <int NP, bool PIPE2 = true>
 __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __restrict__ x, long long x_bs, int C, const float* __restrict__ dz,
                                                               long long dz_bs, int Cdz, float* __restrict__ part, int D, int H, int W, int NBLK,
-                                                              int NCO, SwTasks tk, int task_rr, int dbg) {
+                                                              int NCO, SwTasks tk, int task_rr, int lay, int dbg) {
     using P = S3P<NP>;
     using CF = SwCfg<NP>;
     VXM_DYN_SMEM(char, smem);
@@ -941,310 +927,328 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
                                                                  // a plane / the dZ tile, | 1: drop the first voxel, | 2: drop the second
     int vk[NSET];                                                // the offsets the in-flight loads were issued with (kept live until the MFMA phase is over)
 
-    for (int task = k_lo; task < k_hi; task += k_step) {
-        const int seg = task_rr ? task / tk.ncol : task % tk.nseg, col = task_rr ? task - seg * tk.ncol : task / tk.nseg;      // (depth-segment-major when round-robin)
-        const int tw = col % tk.nw; int cq = col / tk.nw;
-        const int th = cq % tk.nh; const int b = cq / tk.nh;
-        const int td0 = seg * tk.seg_len, ntile = min(tk.seg_len, tk.nd - td0);
-        const int dbase = td0 * SW_TD, h0 = th * SW_TH, w0 = tw * SW_TW;
-        // ONE descriptor per wave, chosen by its (wave-uniform) staging role here, on scalars: selecting between two descriptors inside the
-        // load lambda made the compiler keep both in scratch memory and pick one through a pointer + a waterfall loop (seen in the ISA)
-        const bool xrole = s_role != 2;
-        const __amdgpu_buffer_rsrc_t rd = vxm_rsrc(xrole ? x + (size_t)b * x_bs : dz + (size_t)b * dz_bs, (unsigned)(xrole ? C : Cdz) * (unsigned)V * 4u);
-        if (s_role == 1) {
-            const int cb = x_r & 1, pr = x_r >> 1, hh = pr / SW_XPAIRS, pp = pr - hh * SW_XPAIRS;
-            const int gh = h0 - 1 + hh, gw = w0 - 2 + 2 * pp;
-            const bool live = s_i < 2 * NXS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && q * 16 + cb * 8 < C;
-            off0 = live ? ((q * 16 + cb * 8) * V + gh * W + gw) << 2 : VXM_OOB;
-            ldst = ((hh * SW_XW + 2 * pp - 1) * 32 + cb * 16) | (pp == 0 ? 1 : 0) | (pp == SW_XPAIRS - 1 ? 2 : 0);
-        } else if (s_role == 2) {
-            const int cb = s_i & 1, r2 = (s_i >> 1) & (SW_TH * SW_TW / 2 - 1), zh = r2 / (SW_TW / 2), zw = 2 * (r2 - zh * (SW_TW / 2));
-            const bool live = h0 + zh < H && w0 + zw < W && cot * 16 + cb * 8 < Cdz;
-            off0 = live ? ((cot * 16 + cb * 8) * V + (z_ds * H + h0 + zh) * W + w0 + zw) << 2 : VXM_OOB;
-            ldst = ((z_ds * SW_TH + zh) * SW_TW + zw) * 32 + cb * 16;
-        }
-
-        // planes p0, p0 + 1 of this task (plane p = global depth dbase - 1 + p) and the dZ tile tz (tz < 0: none) -> registers.  Branch-free:
-        // a plane outside the volume ORs the out-of-range bit into the lane offsets (selects on wave-uniform conditions would become
-        // branches around the loads, and the joins behind them make the compiler wait for the prefetch at the START of the MFMA phase)
-        auto load_tile = [&](auto set_, int p0, int tz) __attribute__((always_inline)) {
-            constexpr int S = decltype(set_)::value;
-            const int gd0 = dbase - 1 + p0, gd1 = gd0 + 1;           // wave-uniform
-            int o0 = (unsigned)gd0 < (unsigned)D ? (gd0 * HW) << 2 : 0, f0 = (unsigned)gd0 < (unsigned)D ? 0 : VXM_OOB;
-            int o1 = (unsigned)gd1 < (unsigned)D ? (gd1 * HW) << 2 : 0, f1 = (unsigned)gd1 < (unsigned)D ? 0 : VXM_OOB;
-            const int gz = dbase + (tz < 0 ? 0 : tz) * SW_TD;         // first depth slice of the dZ tile (always < D)
-            int fz = tz < 0 ? VXM_OOB : 0, fz1 = (tz < 0 || gz + 1 >= D) ? VXM_OOB : 0;
-            asm volatile("" : "+v"(f0), "+v"(f1), "+v"(fz), "+v"(fz1));
-            vk[S] = xrole ? ((off0 + (x_pl ? o1 : o0)) | (x_pl ? f1 : f0)) : (off0 | (z_ds ? fz1 : fz));
-            const int sb = xrole ? 0 : (gz * HW) << 2;
-            if (S3_DBG(dbg, 1) && xrole) vk[S] = VXM_OOB;        // timing experiments: no X reads / no dZ reads
-            if (S3_DBG(dbg, 4) && !xrole) vk[S] = VXM_OOB;
-            if (S3_DBG(dbg, 256)) {                               // the addresses of a channel-blocked tensor [C / 8][voxel][8]: 64 contiguous bytes per slot
-                const int cb8 = (xrole ? q * 2 : cot * 2) + ((xrole ? x_r : s_i) & 1);
-                const int vox = ((vk[S] & 0x3fffffff) >> 2) % V;  // (voxel index of the planar offset; out-of-range lanes stay out of range)
-                const int bo = vk[S] < 0 || vk[S] >= VXM_OOB ? VXM_OOB : ((cb8 * V + vox + ((sb >> 2) % V)) << 5);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const u32x4 t4 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, bo, e * 16, 0));
-                    ra[S][2 * e] = __uint_as_float(t4.x); rb[S][2 * e] = __uint_as_float(t4.y); ra[S][2 * e + 1] = __uint_as_float(t4.z); rb[S][2 * e + 1] = __uint_as_float(t4.w);
-                }
-                return;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, vk[S], sb + ((e * V) << 2), 0));
-                ra[S][e] = t2.x; rb[S][e] = t2.y;
-            }
-        };
-        // NP = 2: the largest magnitude this wave loaded for a tile -> Tab[8 + 12 slot + wave]; after the next barrier every thread
-        // takes the maximum over the X waves (0 .. 6) resp. the dZ waves (7 .. 10) and derives the scale of the plane pair / the dZ tile
-        auto publish_max = [&](auto set_, int slot) __attribute__((always_inline)) {
-            constexpr int S = decltype(set_)::value;
-            if constexpr (NP == 2) {
-                float m = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[S][e]), __builtin_fabsf(rb[S][e])));
-                m = s3_wave_max(m);
-                if (lane == 0) Tab[8 + 12 * slot + wave] = m;
-            }
-        };
-        float sc_role = 1.0f;                                    // NP = 2: scale of what this thread staged (X pair of planes, or the dZ tile)
-        auto take_scales = [&](int slot, int p0, int zbuf) __attribute__((always_inline)) {
-            if constexpr (NP == 2) {
-                const f32x4* const t4 = reinterpret_cast<const f32x4*>(Tab + 8 + 12 * slot);
-                const f32x4 m0 = t4[0], m1 = t4[1], m2 = t4[2];
-                const float mxx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), m1.z));
-                const float mxz = fmaxf(fmaxf(m1.w, m2.x), fmaxf(m2.y, m2.z));
-                float sx, ix, sz, iz;
-                s3_scale_of(mxx, sx, ix);
-                s3_scale_of(mxz, sz, iz);
-                sc_role = s_role == 2 ? sz : sx;
-                if (tid == 0) { Tab[p0 % SW_RING] = ix; Tab[(p0 + 1) % SW_RING] = ix; }
-                if (tid == 64 && zbuf >= 0) Tab[6 + zbuf] = iz;
-            }
-        };
-        // split (registers only) and write (LDS) are separate steps: a wave splits the tile it prefetched right after ITS OWN MFMA loop
-        auto split_tile = [&](auto set_) __attribute__((always_inline)) {
-            constexpr int S = decltype(set_)::value;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if constexpr (NP == 3) {
-                    s3_split2(ra[S][2 * e], ra[S][2 * e + 1], ka[0][e], ka[1][e], ka[2][e]);
-                    s3_split2(rb[S][2 * e], rb[S][2 * e + 1], kb[0][e], kb[1][e], kb[2][e]);
-                } else {
-                    s3_split2_f16(ra[S][2 * e], ra[S][2 * e + 1], sc_role, ka[0][e], ka[1][e]);
-                    s3_split2_f16(rb[S][2 * e], rb[S][2 * e + 1], sc_role, kb[0][e], kb[1][e]);
-                }
-            }
-        };
-        // X planes go to ring slots the current tile does not read, so their writes need no barrier: they are issued right after the wave's own
-        // MFMA loop and overlap the MFMAs of the waves still computing (waves 0 .. 6 stage X and are the first to finish: the matrix pipe of
-        // a SIMD serves its oldest wave first).  The dZ tile is single-buffered and is written between the two barriers.  Measured with
-        // s_memtime stamps: the phase between the barriers 1620 -> 430 cycles of ~11.7 k per tile, 2.50 -> 2.44 M cycles per launch on rem1.
-        // (NP = 2: the dZ tile is double-buffered too, so both writes go to free space and the phase has ONE barrier; the block's scale the
-        // split needs was published one phase earlier -- see the raw sets above.)
-        auto write_x = [&](int p0) __attribute__((always_inline)) {
+    // The task loop is instantiated per STAGING ROLE of the wave (XR: stages X / nothing, else the dZ tile) and per layout of the tensor that
+    // role stages (BLK), so that role and layout are compile-time inside it: a planar and a channel-blocked operand need different load
+    // instructions, and a run-time choice between them would put branches around loads that must stay in flight across the MFMA phase.
+    // Every instance executes the same barriers; a wave runs exactly one of them for the whole kernel.
+    auto run_tasks = [&](auto xr_, auto bl_) __attribute__((always_inline)) {
+        constexpr bool XR = decltype(xr_)::value, BLK = decltype(bl_)::value;
+        for (int task = k_lo; task < k_hi; task += k_step) {
+            const int seg = task_rr ? task / tk.ncol : task % tk.nseg, col = task_rr ? task - seg * tk.ncol : task / tk.nseg;      // (depth-segment-major when round-robin)
+            const int tw = col % tk.nw; int cq = col / tk.nw;
+            const int th = cq % tk.nh; const int b = cq / tk.nh;
+            const int td0 = seg * tk.seg_len, ntile = min(tk.seg_len, tk.nd - td0);
+            const int dbase = td0 * SW_TD, h0 = th * SW_TH, w0 = tw * SW_TW;
+            // ONE descriptor per wave, chosen by its (wave-uniform) staging role here, on scalars: selecting between two descriptors inside the
+            // load lambda made the compiler keep both in scratch memory and pick one through a pointer + a waterfall loop (seen in the ISA)
+            constexpr bool xrole = XR;                             // (= s_role != 2: the whole task loop is instantiated per staging role, see below)
+            // blk: the tensor this wave stages (x: lay & VXM_S3_IN0_BLOCKED, dz: & VXM_S3_IN1_BLOCKED) is channel-blocked [C / 8][voxel][8].  A slot
+            // (pair of W neighbours, 8 channels) is then 64 contiguous bytes fetched by four 16-byte loads instead of eight 8-byte loads from
+            // eight planes, and a haloed X row is one run of 1152 bytes instead of sixteen of 144 (19 instead of 32 sector requests).
+            constexpr bool blk = BLK;
+            constexpr int lsh = blk ? 5 : 2;                           // byte offset of a voxel inside its plane / 8-channel block = voxel << lsh
+            const __amdgpu_buffer_rsrc_t rd = vxm_rsrc(xrole ? x + (size_t)b * x_bs : dz + (size_t)b * dz_bs, (unsigned)(xrole ? C : Cdz) * (unsigned)V * 4u);
             if (s_role == 1) {
-                if (s_i < 2 * NXS) {
-                    char* const d = Xs + ((p0 + x_pl) % SW_RING) * SW_PLANE + (ldst & ~3);
-                    if (!(ldst & 1)) {
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * SW_XPIECE) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
-                    }
-                    if (!(ldst & 2)) {
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * SW_XPIECE + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
-                    }
-                }
+                const int cb = x_r & 1, pr = x_r >> 1, hh = pr / SW_XPAIRS, pp = pr - hh * SW_XPAIRS;
+                const int gh = h0 - 1 + hh, gw = w0 - 2 + 2 * pp;
+                const bool live = s_i < 2 * NXS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && q * 16 + cb * 8 < C;
+                off0 = live ? (blk ? ((q * 2 + cb) * V + gh * W + gw) << 5 : ((q * 16 + cb * 8) * V + gh * W + gw) << 2) : VXM_OOB;
+                ldst = ((hh * SW_XW + 2 * pp - 1) * 32 + cb * 16) | (pp == 0 ? 1 : 0) | (pp == SW_XPAIRS - 1 ? 2 : 0);
+            } else if (s_role == 2) {
+                const int cb = s_i & 1, r2 = (s_i >> 1) & (SW_TH * SW_TW / 2 - 1), zh = r2 / (SW_TW / 2), zw = 2 * (r2 - zh * (SW_TW / 2));
+                const bool live = h0 + zh < H && w0 + zw < W && cot * 16 + cb * 8 < Cdz;
+                off0 = live ? (blk ? ((cot * 2 + cb) * V + (z_ds * H + h0 + zh) * W + w0 + zw) << 5 : ((cot * 16 + cb * 8) * V + (z_ds * H + h0 + zh) * W + w0 + zw) << 2)
+                            : VXM_OOB;
+                ldst = ((z_ds * SW_TH + zh) * SW_TW + zw) * 32 + cb * 16;
             }
-        };
-        auto write_z = [&](int zbuf) __attribute__((always_inline)) {
-            if (s_role == 2) {
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    *reinterpret_cast<u32x4*>(Zs + (zbuf * NP + p) * SW_ZPIECE + ldst) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
-                    *reinterpret_cast<u32x4*>(Zs + (zbuf * NP + p) * SW_ZPIECE + ldst + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
-                }
-            }
-        };
 
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, NP == 2 ? 1 : 0>;
-        // the MFMA phase of tile t: this wave's chains, folded into the running totals
-        auto mfma_tile = [&](int t) __attribute__((always_inline)) {
-            if (S3_DBG(dbg, 2)) return;
-            const char* const xp = Xs + ((2 * t + ds + kd) % SW_RING) * SW_PLANE;
-            const int zcur = NP == 2 ? (t & 1) : 0;              // dZ buffer of this tile
-            float unscale_x = 1.0f, unscale_z = 1.0f;
-            if constexpr (NP == 2) { unscale_x = Tab[(2 * t + ds + kd) % SW_RING]; unscale_z = Tab[6 + zcur]; }
-            // The fp32 accumulation of the bf16 MFMA TRUNCATES (tools/bw_accuracy.py: a chain of ~10^4 MFMAs into one accumulator drifts,
-            // 1.5e-5 against 4e-6 for the fp32 MFMA on cancelling sums).  So an MFMA chain lives for ONE tile -- it starts from zero and is
-            // at most 12 links long -- and is then added to the running totals by the vector ALU (round to nearest, unbiased).
-            u32x4 az[2][NP];                                     // dZ fragment sets (NP pieces) of this wave's two output rows
-            f32x4 accb = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            __builtin_amdgcn_s_setprio(3);
-#pragma unroll
-            for (int hl = 0; hl < 2; ++hl) {
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const int zb = (zcur * NP + p) * SW_ZPIECE + ((ds * SW_TH + 2 * rh + hl) * SW_TW) * 32 + lp;
-                    const u32x2 lo = s3_tr_read(Zs, zb), hi = s3_tr_read(Zs, zb + 16 * 32);
-                    az[hl][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
-                }
-                if (kd == 0) {                                   // wave-uniform: bias gradient = sum of the pieces against ones
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) accb = P::mfma(az[hl][p], ones, accb);
-                }
-            }
-            // kw outermost: the three kh chains of one kw are alive at a time (12 accumulator registers instead of 36 -- the second raw set of
-            // the NP = 2 pipeline needs the room); every (haloed row, kw) B fragment set is still read exactly once
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                // a wave's priority falls as it advances through the tile: the three waves of a SIMD then progress evenly instead of oldest
-                // first and share the matrix pipe to the end of the phase -- a lone last wave cannot keep it busy (s_memtime stamps, round 3:
-                // the waves finished at 3.5 k, 5.7 k and 7.7 k cycles of a tile whose MFMAs need 5.5 k; -2 .. -3 % on the three big launches)
-                if (kw == 1) __builtin_amdgcn_s_setprio(2); else if (kw == 2) __builtin_amdgcn_s_setprio(1);
-                f32x4 acc[3];
-#pragma unroll
-                for (int hl = 0; hl < 4; ++hl) {                 // haloed rows 2 rh + hl serve output rows 2 rh + hl - kh
-                    const int hr = 2 * rh + hl;                  // wave-uniform
-                    u32x4 bxf[NP];
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        const int xb = p * SW_XPIECE + (hr * SW_XW + kw) * 32 + lp;
-                        const u32x2 lo = s3_tr_read(xp, xb), hi = s3_tr_read(xp, xb + 16 * 32);
-                        bxf[p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+            // planes p0, p0 + 1 of this task (plane p = global depth dbase - 1 + p) and the dZ tile tz (tz < 0: none) -> registers.  Branch-free:
+            // a plane outside the volume ORs the out-of-range bit into the lane offsets (selects on wave-uniform conditions would become
+            // branches around the loads, and the joins behind them make the compiler wait for the prefetch at the START of the MFMA phase)
+            auto load_tile = [&](auto set_, int p0, int tz) __attribute__((always_inline)) {
+                constexpr int S = decltype(set_)::value;
+                const int gd0 = dbase - 1 + p0, gd1 = gd0 + 1;           // wave-uniform
+                int o0 = (unsigned)gd0 < (unsigned)D ? (gd0 * HW) << lsh : 0, f0 = (unsigned)gd0 < (unsigned)D ? 0 : VXM_OOB;
+                int o1 = (unsigned)gd1 < (unsigned)D ? (gd1 * HW) << lsh : 0, f1 = (unsigned)gd1 < (unsigned)D ? 0 : VXM_OOB;
+                const int gz = dbase + (tz < 0 ? 0 : tz) * SW_TD;         // first depth slice of the dZ tile (always < D)
+                int fz = tz < 0 ? VXM_OOB : 0, fz1 = (tz < 0 || gz + 1 >= D) ? VXM_OOB : 0;
+                asm volatile("" : "+v"(f0), "+v"(f1), "+v"(fz), "+v"(fz1));
+                vk[S] = xrole ? ((off0 + (x_pl ? o1 : o0)) | (x_pl ? f1 : f0)) : (off0 | (z_ds ? fz1 : fz));
+                const int sb = xrole ? 0 : (gz * HW) << lsh;
+                if (S3_DBG(dbg, 1) && xrole) vk[S] = VXM_OOB;        // timing experiments: no X reads / no dZ reads
+                if (S3_DBG(dbg, 4) && !xrole) vk[S] = VXM_OOB;
+                if constexpr (blk) {
+    #pragma unroll
+                    for (int k = 0; k < 2; ++k) {                    // first voxel: channels 4 k .. 4 k + 3; second voxel 32 bytes on
+                        const f32x4 ta = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, vk[S], sb + 16 * k, 0));
+                        const f32x4 tb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, vk[S], sb + 32 + 16 * k, 0));
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) { ra[S][4 * k + e] = ta[e]; rb[S][4 * k + e] = tb[e]; }
                     }
-#pragma unroll
-                    for (int tp = 0; tp < P::NPROD; ++tp)
-#pragma unroll
-                        for (int kh = 0; kh < 3; ++kh) {
-                            const int rl = hl - kh;              // local output row
-                            if (rl >= 0 && rl < 2)               // the first link of a tile's chain (output row 0, first product) starts from zero
-                                acc[kh] = P::mfma(az[rl][P::PA[tp]], bxf[P::PB[tp]], (rl == 0 && tp == 0) ? zero4 : acc[kh]);
+                } else {
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, vk[S], sb + ((e * V) << 2), 0));
+                        ra[S][e] = t2.x; rb[S][e] = t2.y;
+                    }
+                }
+            };
+            // NP = 2: the largest magnitude this wave loaded for a tile -> Tab[8 + 12 slot + wave]; after the next barrier every thread
+            // takes the maximum over the X waves (0 .. 6) resp. the dZ waves (7 .. 10) and derives the scale of the plane pair / the dZ tile
+            auto publish_max = [&](auto set_, int slot) __attribute__((always_inline)) {
+                constexpr int S = decltype(set_)::value;
+                if constexpr (NP == 2) {
+                    float m = 0.0f;
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[S][e]), __builtin_fabsf(rb[S][e])));
+                    m = s3_wave_max(m);
+                    if (lane == 0) Tab[8 + 12 * slot + wave] = m;
+                }
+            };
+            float sc_role = 1.0f;                                    // NP = 2: scale of what this thread staged (X pair of planes, or the dZ tile)
+            auto take_scales = [&](int slot, int p0, int zbuf) __attribute__((always_inline)) {
+                if constexpr (NP == 2) {
+                    const f32x4* const t4 = reinterpret_cast<const f32x4*>(Tab + 8 + 12 * slot);
+                    const f32x4 m0 = t4[0], m1 = t4[1], m2 = t4[2];
+                    const float mxx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), m1.z));
+                    const float mxz = fmaxf(fmaxf(m1.w, m2.x), fmaxf(m2.y, m2.z));
+                    float sx, ix, sz, iz;
+                    s3_scale_of(mxx, sx, ix);
+                    s3_scale_of(mxz, sz, iz);
+                    sc_role = s_role == 2 ? sz : sx;
+                    if (tid == 0) { Tab[p0 % SW_RING] = ix; Tab[(p0 + 1) % SW_RING] = ix; }
+                    if (tid == 64 && zbuf >= 0) Tab[6 + zbuf] = iz;
+                }
+            };
+            // split (registers only) and write (LDS) are separate steps: a wave splits the tile it prefetched right after ITS OWN MFMA loop
+            auto split_tile = [&](auto set_) __attribute__((always_inline)) {
+                constexpr int S = decltype(set_)::value;
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (NP == 3) {
+                        s3_split2(ra[S][2 * e], ra[S][2 * e + 1], ka[0][e], ka[1][e], ka[2][e]);
+                        s3_split2(rb[S][2 * e], rb[S][2 * e + 1], kb[0][e], kb[1][e], kb[2][e]);
+                    } else {
+                        s3_split2_f16(ra[S][2 * e], ra[S][2 * e + 1], sc_role, ka[0][e], ka[1][e]);
+                        s3_split2_f16(rb[S][2 * e], rb[S][2 * e + 1], sc_role, kb[0][e], kb[1][e]);
+                    }
+                }
+            };
+            // X planes go to ring slots the current tile does not read, so their writes need no barrier: they are issued right after the wave's own
+            // MFMA loop and overlap the MFMAs of the waves still computing (waves 0 .. 6 stage X and are the first to finish: the matrix pipe of
+            // a SIMD serves its oldest wave first).  The dZ tile is single-buffered and is written between the two barriers.  Measured with
+            // s_memtime stamps: the phase between the barriers 1620 -> 430 cycles of ~11.7 k per tile, 2.50 -> 2.44 M cycles per launch on rem1.
+            // (NP = 2: the dZ tile is double-buffered too, so both writes go to free space and the phase has ONE barrier; the block's scale the
+            // split needs was published one phase earlier -- see the raw sets above.)
+            auto write_x = [&](int p0) __attribute__((always_inline)) {
+                if (s_role == 1) {
+                    if (s_i < 2 * NXS) {
+                        char* const d = Xs + ((p0 + x_pl) % SW_RING) * SW_PLANE + (ldst & ~3);
+                        if (!(ldst & 1)) {
+    #pragma unroll
+                            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * SW_XPIECE) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
                         }
+                        if (!(ldst & 2)) {
+    #pragma unroll
+                            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * SW_XPIECE + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                        }
+                    }
+                }
+            };
+            auto write_z = [&](int zbuf) __attribute__((always_inline)) {
+                if (s_role == 2) {
+    #pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        *reinterpret_cast<u32x4*>(Zs + (zbuf * NP + p) * SW_ZPIECE + ldst) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
+                        *reinterpret_cast<u32x4*>(Zs + (zbuf * NP + p) * SW_ZPIECE + ldst + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                    }
+                }
+            };
+
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, NP == 2 ? 1 : 0>;
+            // the MFMA phase of tile t: this wave's chains, folded into the running totals
+            auto mfma_tile = [&](int t) __attribute__((always_inline)) {
+                if (S3_DBG(dbg, 2)) return;
+                const char* const xp = Xs + ((2 * t + ds + kd) % SW_RING) * SW_PLANE;
+                const int zcur = NP == 2 ? (t & 1) : 0;              // dZ buffer of this tile
+                float unscale_x = 1.0f, unscale_z = 1.0f;
+                if constexpr (NP == 2) { unscale_x = Tab[(2 * t + ds + kd) % SW_RING]; unscale_z = Tab[6 + zcur]; }
+                // The fp32 accumulation of the bf16 MFMA TRUNCATES (tools/bw_accuracy.py: a chain of ~10^4 MFMAs into one accumulator drifts,
+                // 1.5e-5 against 4e-6 for the fp32 MFMA on cancelling sums).  So an MFMA chain lives for ONE tile -- it starts from zero and is
+                // at most 12 links long -- and is then added to the running totals by the vector ALU (round to nearest, unbiased).
+                u32x4 az[2][NP];                                     // dZ fragment sets (NP pieces) of this wave's two output rows
+                f32x4 accb = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                __builtin_amdgcn_s_setprio(3);
+    #pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+    #pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const int zb = (zcur * NP + p) * SW_ZPIECE + ((ds * SW_TH + 2 * rh + hl) * SW_TW) * 32 + lp;
+                        const u32x2 lo = s3_tr_read(Zs, zb), hi = s3_tr_read(Zs, zb + 16 * 32);
+                        az[hl][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+                    }
+                    if (kd == 0) {                                   // wave-uniform: bias gradient = sum of the pieces against ones
+    #pragma unroll
+                        for (int p = 0; p < NP; ++p) accb = P::mfma(az[hl][p], ones, accb);
+                    }
+                }
+                // kw outermost: the three kh chains of one kw are alive at a time (12 accumulator registers instead of 36 -- the second raw set of
+                // the NP = 2 pipeline needs the room); every (haloed row, kw) B fragment set is still read exactly once
+    #pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    // a wave's priority falls as it advances through the tile: the three waves of a SIMD then progress evenly instead of oldest
+                    // first and share the matrix pipe to the end of the phase -- a lone last wave cannot keep it busy (s_memtime stamps, round 3:
+                    // the waves finished at 3.5 k, 5.7 k and 7.7 k cycles of a tile whose MFMAs need 5.5 k; -2 .. -3 % on the three big launches)
+                    if (kw == 1) __builtin_amdgcn_s_setprio(2); else if (kw == 2) __builtin_amdgcn_s_setprio(1);
+                    f32x4 acc[3];
+    #pragma unroll
+                    for (int hl = 0; hl < 4; ++hl) {                 // haloed rows 2 rh + hl serve output rows 2 rh + hl - kh
+                        const int hr = 2 * rh + hl;                  // wave-uniform
+                        u32x4 bxf[NP];
+    #pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            const int xb = p * SW_XPIECE + (hr * SW_XW + kw) * 32 + lp;
+                            const u32x2 lo = s3_tr_read(xp, xb), hi = s3_tr_read(xp, xb + 16 * 32);
+                            bxf[p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+                        }
+    #pragma unroll
+                        for (int tp = 0; tp < P::NPROD; ++tp)
+    #pragma unroll
+                            for (int kh = 0; kh < 3; ++kh) {
+                                const int rl = hl - kh;              // local output row
+                                if (rl >= 0 && rl < 2)               // the first link of a tile's chain (output row 0, first product) starts from zero
+                                    acc[kh] = P::mfma(az[rl][P::PA[tp]], bxf[P::PB[tp]], (rl == 0 && tp == 0) ? zero4 : acc[kh]);
+                            }
+                    }
+                    if constexpr (NP == 3) {
+    #pragma unroll
+                        for (int kh = 0; kh < 3; ++kh) tot[kh][kw] += acc[kh];
+                    } else {                                         // the chain carries the scales of its X plane and its dZ tile: undone here (exact)
+    #pragma unroll
+                        for (int kh = 0; kh < 3; ++kh)
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) tot[kh][kw][j] = __builtin_fmaf(acc[kh][j] * unscale_x, unscale_z, tot[kh][kw][j]);
+                    }
                 }
                 if constexpr (NP == 3) {
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh) tot[kh][kw] += acc[kh];
-                } else {                                         // the chain carries the scales of its X plane and its dZ tile: undone here (exact)
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) tot[kh][kw][j] = __builtin_fmaf(acc[kh][j] * unscale_x, unscale_z, tot[kh][kw][j]);
+                    totb += accb;
+                } else {
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) totb[j] = __builtin_fmaf(accb[j], unscale_z, totb[j]);
                 }
-            }
-            if constexpr (NP == 3) {
-                totb += accb;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) totb[j] = __builtin_fmaf(accb[j], unscale_z, totb[j]);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
 
-        __syncthreads();                                        // every wave is done with the previous task
-        if constexpr (NP == 3) {
-            load_tile(I0{}, 0, 0);
-            split_tile(I0{});
-            write_x(0);
-            write_z(0);
-            load_tile(I0{}, 2, -1);
-            split_tile(I0{});
-            write_x(2);
-            __syncthreads();
-            for (int t = 0; t < ntile; ++t) {
-                const bool more = t + 1 < ntile;                 // wave-uniform
-                // the raw loads of tile t + 1 (2 X planes + the dZ tile) are in flight under the MFMAs of tile t; unconditional: past
-                // the last tile the planes lie beyond this task's depth range and are simply not stored
-                load_tile(I0{}, 2 * t + 4, more ? t + 1 : t);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_tile(t);
-                // the address registers of the loads in flight stay live until here: reused earlier, the compiler guards every reuse
-                // with s_waitcnt vmcnt(..), i.e. waits for the prefetch at the start of the MFMA phase (seen in the ISA)
-                asm volatile("" ::"v"(vk[0]));
-                split_tile(I0{});                                // before the barrier: overlaps the other waves' MFMAs
-                if (more) write_x(2 * t + 4);
-                __syncthreads();                                 // every wave is done reading tile t (X ring slots of t - 1 and the dZ tile are free)
-                if (more) write_z(0);
+            __syncthreads();                                        // every wave is done with the previous task
+            if constexpr (NP == 3) {
+                load_tile(I0{}, 0, 0);
+                split_tile(I0{});
+                write_x(0);
+                write_z(0);
+                load_tile(I0{}, 2, -1);
+                split_tile(I0{});
+                write_x(2);
                 __syncthreads();
-            }
-        } else if constexpr (!PIPE2) {
-            // ---- NP = 2, the first version (kept for same-box A/B, VXM_S3_BW_PIPE=1): one tile ahead, the maxima published before a first
-            // barrier, split + writes between it and a second one
-            load_tile(I0{}, 0, 0);
-            publish_max(I0{}, 0);
-            __syncthreads();
-            take_scales(0, 0, 0);
-            split_tile(I0{});
-            write_x(0);
-            write_z(0);
-            load_tile(I0{}, 2, -1);
-            publish_max(I0{}, 2);
-            __syncthreads();
-            take_scales(2, 2, -1);
-            split_tile(I0{});
-            write_x(2);
-            __syncthreads();
-            for (int t = 0; t < ntile; ++t) {
-                const bool more = t + 1 < ntile;
-                load_tile(I0{}, 2 * t + 4, more ? t + 1 : t);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_tile(t);
-                asm volatile("" ::"v"(vk[0]));
+                for (int t = 0; t < ntile; ++t) {
+                    const bool more = t + 1 < ntile;                 // wave-uniform
+                    // the raw loads of tile t + 1 (2 X planes + the dZ tile) are in flight under the MFMAs of tile t; unconditional: past
+                    // the last tile the planes lie beyond this task's depth range and are simply not stored
+                    load_tile(I0{}, 2 * t + 4, more ? t + 1 : t);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_tile(t);
+                    // the address registers of the loads in flight stay live until here: reused earlier, the compiler guards every reuse
+                    // with s_waitcnt vmcnt(..), i.e. waits for the prefetch at the start of the MFMA phase (seen in the ISA)
+                    asm volatile("" ::"v"(vk[0]));
+                    split_tile(I0{});                                // before the barrier: overlaps the other waves' MFMAs
+                    if (more) write_x(2 * t + 4);
+                    __syncthreads();                                 // every wave is done reading tile t (X ring slots of t - 1 and the dZ tile are free)
+                    if (more) write_z(0);
+                    __syncthreads();
+                }
+            } else if constexpr (!PIPE2) {
+                // ---- NP = 2, the first version (kept for same-box A/B, VXM_S3_BW_PIPE=1): one tile ahead, the maxima published before a first
+                // barrier, split + writes between it and a second one
+                load_tile(I0{}, 0, 0);
                 publish_max(I0{}, 0);
                 __syncthreads();
-                if (more) {
-                    take_scales(0, 2 * t + 4, (t & 1) ^ 1);
-                    split_tile(I0{});
-                    write_x(2 * t + 4);
-                    write_z((t & 1) ^ 1);
-                }
+                take_scales(0, 0, 0);
+                split_tile(I0{});
+                write_x(0);
+                write_z(0);
+                load_tile(I0{}, 2, -1);
+                publish_max(I0{}, 2);
                 __syncthreads();
-            }
-        } else {
-            // ---- NP = 2.  Tile tau (tau >= 1) = planes 2 tau + 2, 2 tau + 3 and dZ tile tau; its raw loads live in set tau & 1, its maxima in
-            // table slot tau & 1 (tile 0's second plane pair: slot 2).  Phase t: request tile t + 2, multiply tile t, split + write tile
-            // t + 1 (scale from the maxima published during phase t - 1), publish the maxima of tile t + 2, ONE barrier.
-            load_tile(I0{}, 0, 0);
-            load_tile(I1{}, 2, -1);
-            publish_max(I0{}, 0);
-            publish_max(I1{}, 2);
-            __syncthreads();
-            take_scales(0, 0, 0);
-            split_tile(I0{});
-            write_x(0);
-            write_z(0);
-            take_scales(2, 2, -1);
-            split_tile(I1{});
-            write_x(2);
-            load_tile(I1{}, 4, ntile > 1 ? 1 : -1);              // tile 1
-            publish_max(I1{}, 1);
-            __syncthreads();
-            auto phase = [&](auto par_, int t) __attribute__((always_inline)) {
-                constexpr int PAR = decltype(par_)::value;       // = t & 1: tile t + 2 goes to set PAR, tile t + 1 sits in set PAR ^ 1
-                using SN = std::integral_constant<int, PAR>;
-                using SC = std::integral_constant<int, PAR ^ 1>;
-                load_tile(SN{}, 2 * t + 6, t + 2 < ntile ? t + 2 : -1);
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_tile(t);
-                asm volatile("" ::"v"(vk[PAR]));
-                if (t + 1 < ntile) {                              // wave-uniform
-                    take_scales((t + 1) & 1, 2 * t + 4, (t + 1) & 1);
-                    split_tile(SC{});
-                    write_x(2 * t + 4);
-                    write_z((t + 1) & 1);
+                take_scales(2, 2, -1);
+                split_tile(I0{});
+                write_x(2);
+                __syncthreads();
+                for (int t = 0; t < ntile; ++t) {
+                    const bool more = t + 1 < ntile;
+                    load_tile(I0{}, 2 * t + 4, more ? t + 1 : t);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_tile(t);
+                    asm volatile("" ::"v"(vk[0]));
+                    publish_max(I0{}, 0);
+                    __syncthreads();
+                    if (more) {
+                        take_scales(0, 2 * t + 4, (t & 1) ^ 1);
+                        split_tile(I0{});
+                        write_x(2 * t + 4);
+                        write_z((t & 1) ^ 1);
+                    }
+                    __syncthreads();
                 }
-                publish_max(SN{}, t & 1);
-                __syncthreads();                                  // tile t is read, tile t + 1 is written, the maxima of tile t + 2 are published
-            };
-            for (int t = 0; t < ntile; t += 2) {
-                phase(I0{}, t);
-                if (t + 1 < ntile) phase(I1{}, t + 1);
+            } else {
+                // ---- NP = 2.  Tile tau (tau >= 1) = planes 2 tau + 2, 2 tau + 3 and dZ tile tau; its raw loads live in set tau & 1, its maxima in
+                // table slot tau & 1 (tile 0's second plane pair: slot 2).  Phase t: request tile t + 2, multiply tile t, split + write tile
+                // t + 1 (scale from the maxima published during phase t - 1), publish the maxima of tile t + 2, ONE barrier.
+                load_tile(I0{}, 0, 0);
+                load_tile(I1{}, 2, -1);
+                publish_max(I0{}, 0);
+                publish_max(I1{}, 2);
+                __syncthreads();
+                take_scales(0, 0, 0);
+                split_tile(I0{});
+                write_x(0);
+                write_z(0);
+                take_scales(2, 2, -1);
+                split_tile(I1{});
+                write_x(2);
+                load_tile(I1{}, 4, ntile > 1 ? 1 : -1);              // tile 1
+                publish_max(I1{}, 1);
+                __syncthreads();
+                auto phase = [&](auto par_, int t) __attribute__((always_inline)) {
+                    constexpr int PAR = decltype(par_)::value;       // = t & 1: tile t + 2 goes to set PAR, tile t + 1 sits in set PAR ^ 1
+                    using SN = std::integral_constant<int, PAR>;
+                    using SC = std::integral_constant<int, PAR ^ 1>;
+                    load_tile(SN{}, 2 * t + 6, t + 2 < ntile ? t + 2 : -1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_tile(t);
+                    asm volatile("" ::"v"(vk[PAR]));
+                    if (t + 1 < ntile) {                              // wave-uniform
+                        take_scales((t + 1) & 1, 2 * t + 4, (t + 1) & 1);
+                        split_tile(SC{});
+                        write_x(2 * t + 4);
+                        write_z((t + 1) & 1);
+                    }
+                    publish_max(SN{}, t & 1);
+                    __syncthreads();                                  // tile t is read, tile t + 1 is written, the maxima of tile t + 2 are published
+                };
+                for (int t = 0; t < ntile; t += 2) {
+                    phase(I0{}, t);
+                    if (t + 1 < ntile) phase(I1{}, t + 1);
+                }
             }
         }
+    };
+    if constexpr (NP == 2) {
+        if (s_role != 2) { if (lay & VXM_S3_IN0_BLOCKED) run_tasks(std::true_type{}, std::true_type{}); else run_tasks(std::true_type{}, std::false_type{}); }
+        else             { if (lay & VXM_S3_IN1_BLOCKED) run_tasks(std::false_type{}, std::true_type{}); else run_tasks(std::false_type{}, std::false_type{}); }
+    } else {
+        if (s_role != 2) run_tasks(std::true_type{}, std::false_type{}); else run_tasks(std::false_type{}, std::false_type{});
     }
 
     // ---- partials: part[bx][q][tap 0..27][co 16 NCO][ci 16].  The four waves (row half, depth slice) that share a kd hold sums of the same
@@ -1389,15 +1393,15 @@ int s3_dbg() {
 #endif
 }
 
-template <int NCT, int ROWS, int CB, int NP, bool RUN = false>
+template <int NCT, int ROWS, int CB, int NP, bool RUN = false, bool BLK = false>
 void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, long long y_bs, int Cout, float slope, const float* mask,
-               long long mask_bs, float mask_slope, int B, int D, int H, int W, hipStream_t s) {
+               long long mask_bs, float mask_slope, int B, int D, int H, int W, hipStream_t s, int lay = 0) {
     using C = S3Cfg<NCT, ROWS, CB, NP>;
     static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_conv<NCT, ROWS, CB, NP, RUN>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_conv<NCT, ROWS, CB, NP, RUN, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (getenv("VXM_S3_DEBUG")) {             // developer switch: what the runtime says about co-residency
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_s3_conv<NCT, ROWS, CB, NP, RUN>, S3_THREADS, C::LDS_BYTES);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_s3_conv<NCT, ROWS, CB, NP, RUN, BLK>, S3_THREADS, C::LDS_BYTES);
             fprintf(stderr, "k_s3_conv<%d,%d,%d,%d>: %d bytes of LDS, %d block(s) per CU\n", NCT, ROWS, CB, NP, C::LDS_BYTES, nb);
         }
         return true;
@@ -1421,8 +1425,8 @@ void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, lo
         const unsigned cap = 8 * ((want + 7) / 8);
         if (cap < gx) gx = cap;
     }
-    hipLaunchKernelGGL((k_s3_conv<NCT, ROWS, CB, NP, RUN>), dim3(gx, G), dim3(S3_THREADS), C::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
-                       Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q, s3_dbg());
+    hipLaunchKernelGGL((k_s3_conv<NCT, ROWS, CB, NP, RUN, BLK>), dim3(gx, G), dim3(S3_THREADS), C::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
+                       Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q, lay, s3_dbg());
 }
 
 bool s3_use_pc(int B, int D, int H, int W, bool has_mask) {
@@ -1432,12 +1436,12 @@ bool s3_use_pc(int B, int D, int H, int W, bool has_mask) {
 }
 
 // k_s3p_conv: one block of 16 waves per CU, every block walks its XCD's tile range (VXM_S3P_BLOCKS=n: n blocks in all, tests / A/B)
-template <int NCT>
+template <int NCT, bool BLK = false>
 void s3p_launch(const ConvIn& in, const void* wp, const float* bias, float* y, long long y_bs, int Cout, float slope, const float* mask,
-                long long mask_bs, float mask_slope, int B, int D, int H, int W, hipStream_t s) {
+                long long mask_bs, float mask_slope, int B, int D, int H, int W, hipStream_t s, int lay = 0) {
     using PC = S3PCfg<NCT>;
     static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3p_conv<NCT>), hipFuncAttributeMaxDynamicSharedMemorySize, PC::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3p_conv<NCT, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, PC::LDS_BYTES);
         return true;
     }();
     (void)attr;
@@ -1451,8 +1455,8 @@ void s3p_launch(const ConvIn& in, const void* wp, const float* bias, float* y, l
         const unsigned cap = 8 * ((want + 7) / 8);
         if (cap < gx) gx = cap;
     }
-    hipLaunchKernelGGL((k_s3p_conv<NCT>), dim3(gx, G), dim3(S3P_THREADS), PC::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
-                       Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q, s3_dbg());
+    hipLaunchKernelGGL((k_s3p_conv<NCT, BLK>), dim3(gx, G), dim3(S3P_THREADS), PC::LDS_BYTES, s, in, static_cast<const u32x4*>(wp), bias, y, y_bs,
+                       Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q, lay, s3_dbg());
 }
 
 }  // namespace
@@ -1471,6 +1475,13 @@ int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W) {
 int vxm_conv3d_k3_s3_variant(int Cout) {
     const S3Variant v = s3_variant(Cout);
     return 10 * v.NCT + v.CB;
+}
+
+/* 1 when vxm_conv3d_k3_s3_fwd accepts the layout flags for a launch of this shape: the 8-row instances of the fp16 scheme (the tensors of the
+ * plain full-resolution layers), one segment, no upsampling gather, channel counts in multiples of 8 */
+int vxm_conv3d_k3_s3_layout_ok(int C0, int C1, int x0_up, int Cout, int H, int pieces) {
+    static const bool rows8 = [] { const char* e = getenv("VXM_S3_ROWS"); return !(e && e[0] == '4'); }();
+    return (pieces == 2 && rows8 && H >= 8 && s3_variant(Cout).CB == 1 && C1 == 0 && !x0_up && C0 > 0 && C0 % 8 == 0 && Cout % 8 == 0) ? 1 : 0;
 }
 
 /* 1 when vxm_conv3d_k3_s3_fwd will run the producer / consumer kernel k_s3p_conv for this launch (profiling labels) */
@@ -1527,9 +1538,13 @@ int vxm_conv3d_k3_s3_pack_weights_batch(const VxmS3PackJob* jobs, int n_jobs, vo
 
 int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride, const void* wpacked,
                          const float* bias, float* y, int64_t y_bstride, int Cout, float leaky_slope, const float* mask, int64_t mask_bstride,
-                         float mask_slope, int B, int D, int H, int W, int pieces, void* stream) {
+                         float mask_slope, int B, int D, int H, int W, int pieces_and_layout, void* stream) {
+    const int pieces = pieces_and_layout & 0xff, lay = pieces_and_layout & ~0xff;
     VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3_fwd: null pointer");
     VXM_REQUIRE(s3_pieces_ok(pieces), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_fwd: pieces = %d (3: bf16, 2: fp16)", pieces);
+    VXM_REQUIRE(lay == 0 || ((lay & ~(VXM_S3_IN0_BLOCKED | VXM_S3_OUT_BLOCKED)) == 0 && vxm_conv3d_k3_s3_layout_ok(C0, C1, x0_up, Cout, H, pieces)), VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3_fwd: layout flags 0x%x are not available for this launch (%d + %d -> %d channels, upsampled %d, H = %d, pieces %d)", lay, C0, C1,
+                Cout, x0_up, H, pieces);
     if (int e = check_conv("vxm_conv3d_k3_s3_fwd", C0, C1, x0_up, Cout, B, D, H, W)) return e;
     VXM_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_fwd: segments carry multiples of 8 channels, got %d + %d", C0, C1);
     const S3Variant v = s3_variant(Cout);
@@ -1548,8 +1563,11 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
     // 16-channel operators on the fp16 scheme: 8 x 8 x 16 tiles (halo 1.76 instead of 2.11 staged voxels per output voxel) with the running
     // scale; VXM_S3_ROWS=4 keeps the 8 x 4 x 16 tiles (A/B)
     static const bool rows8 = [] { const char* e = getenv("VXM_S3_ROWS"); return !(e && e[0] == '4'); }();
-    if (v.NCT == 2 && pieces == 2 && rows8 && H >= 8 && v.CB == 1)
-        s3_launch<2, 8, 1, 2, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
+    const bool blk_in = (lay & VXM_S3_IN0_BLOCKED) != 0;
+    if (v.NCT == 2 && pieces == 2 && rows8 && H >= 8 && v.CB == 1) {
+        if (blk_in) s3_launch<2, 8, 1, 2, true, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s, lay);
+        else s3_launch<2, 8, 1, 2, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s, lay);
+    }
     else if (v.NCT == 2) S3_GO(2, 1);
     else if (v.CB == 2) S3_GO(1, 2);
     else if (pieces == 2 && rows8 && H >= 8) {
@@ -1557,8 +1575,13 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
         // 32 -> 16 0.848 -> 0.809; backward-data launches, whose epilogue waits for the mask it reads, 0.493 -> 0.500 and 0.813 -> 0.836: not routed;
         // requesting the mask under the MFMAs of the tile's last chunk cost the forward launches their gain and did not help these).
         // VXM_S3_PC=0: the alternating kernel everywhere, =1: k_s3p_conv on every eligible launch (tests)
-        if (s3_use_pc(B, D, H, W, mask != nullptr)) s3p_launch<1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
-        else s3_launch<1, 8, 1, 2, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s);
+        if (s3_use_pc(B, D, H, W, mask != nullptr)) {
+            if (blk_in) s3p_launch<1, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s, lay);
+            else s3p_launch<1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s, lay);
+        } else {
+            if (blk_in) s3_launch<1, 8, 1, 2, true, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s, lay);
+            else s3_launch<1, 8, 1, 2, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s, lay);
+        }
     }
     else S3_GO(1, 1);
 #undef S3_GO
@@ -1583,9 +1606,12 @@ size_t vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(int C, int Cout, int B, int D
 }
 
 int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw, int gw_cin,
-                                int ci_off, float* gb, void* work, size_t work_bytes, int B, int D, int H, int W, int pieces, void* stream) {
+                                int ci_off, float* gb, void* work, size_t work_bytes, int B, int D, int H, int W, int pieces_and_layout, void* stream) {
+    const int pieces = pieces_and_layout & 0xff, lay = pieces_and_layout & ~0xff;
     VXM_REQUIRE(x && dz && gw && work, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3_bwd_weight: null pointer");
     VXM_REQUIRE(s3_pieces_ok(pieces), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_bwd_weight: pieces = %d (3: bf16, 2: fp16)", pieces);
+    VXM_REQUIRE(lay == 0 || (pieces == 2 && (lay & ~(VXM_S3_IN0_BLOCKED | VXM_S3_IN1_BLOCKED)) == 0), VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3_bwd_weight: layout flags 0x%x (x: IN0, dz: IN1; fp16 scheme only)", lay);
     if (int e = check_conv("vxm_conv3d_k3_s3_bwd_weight", C, 0, 0, Cout, B, D, H, W)) return e;
     VXM_REQUIRE(C % 16 == 0 && Cout % 16 == 0 && ci_off >= 0 && ci_off + C <= gw_cin && W % 2 == 0, VXM_ERR_BAD_SHAPE,
                 "vxm_conv3d_k3_s3_bwd_weight: %d input / %d output channels (multiples of 16), destination channels [%d, %d) of %d, W = %d (even)", C,
@@ -1611,13 +1637,13 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
     const int task_rr = ((te && te[0] == 'r' && te[1] == 'a') || (long long)D * H * W < (1ll << 21)) ? 0 : 1;
     if (pieces == 2 && pe && pe[0] == '1')
         hipLaunchKernelGGL((k_s3_bwd_weight<2, false>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, s3_dbg());
+                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, lay, s3_dbg());
     else if (pieces == 2)
         hipLaunchKernelGGL((k_s3_bwd_weight<2, true>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, s3_dbg());
+                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, lay, s3_dbg());
     else
         hipLaunchKernelGGL((k_s3_bwd_weight<3, true>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<3>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, s3_dbg());
+                           (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, lay, s3_dbg());
     const int n = 16 * NCO * 16 * Q * 28;
     hipLaunchKernelGGL(k_s3_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(1024), 0, s, part, gw, gb, C, Cout, gw_cin, ci_off, Q, NCO, NBLK);
     return vxm_check_launch("vxm_conv3d_k3_s3_bwd_weight");

@@ -73,7 +73,7 @@ struct SuCfg {
 template <int NCT, int NP>
 __global__ void __launch_bounds__(SU_THREADS, 2)
 k_s3u_conv(const float* __restrict__ x0, long long bs0, int C0, const float* __restrict__ x1, long long bs1, int C1, const u32x4* __restrict__ wp,
-           const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout, float act_slope, int B, int D, int H, int W) {
+           const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout, float act_slope, int B, int D, int H, int W, int lay) {
     using C = SuCfg<NCT, NP>;
     using P = S3P<NP>;
     VXM_DYN_SMEM(u32x4, smem);
@@ -358,6 +358,30 @@ k_s3u_conv(const float* __restrict__ x0, long long bs0, int C0, const float* __r
     const int wv_ = cw0 + 2 * n + pw;
     float bz[NCT][4];
     conv_load_bias<NCT>(bz, bias, Cout, g, kg);
+    if (lay & VXM_S3_OUT_BLOCKED) {
+        // channel-blocked output [Cout / 8][voxel][8] (Cout % 8 == 0): the lane's four channels are 16 contiguous bytes of the voxel's group
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int dd = cd0 + 2 * (r >> 1) + pd, hh = ch0 + 2 * (r & 1) + ph;       // wave-uniform
+            if (dd < D && hh < H) {
+                const int vox = (dd * H + hh) * W + wv_;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const int ch = cbase + 16 * ct;
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[r][ct][j];
+                        if constexpr (NP == 2) v *= unscale;
+                        v += bz[ct][j];
+                        o[j] = v > 0.0f ? v : v * act_slope;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry,
+                                                           (wv_ < W && ch < Cout) ? ((((ch >> 3) * V + vox) << 5) + ((kg & 1) << 4)) : VXM_OOB, 0, 0);
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int dd = cd0 + 2 * (r >> 1) + pd, hh = ch0 + 2 * (r & 1) + ph;       // wave-uniform
@@ -375,6 +399,7 @@ k_s3u_conv(const float* __restrict__ x0, long long bs0, int C0, const float* __r
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, (wv_ < W && ch < Cout) ? (ch * V + vox) << 2 : VXM_OOB, 0, 0);
                 }
         }
+    }
     }
     }
 }
@@ -525,7 +550,8 @@ struct SdCfg {
     static_assert(4 * 8 * NCT * 64 <= NP * XWORDS, "the combine buffer reuses the staging tile");
 };
 
-template <int NCT, int NP>
+// BLK: dz is channel-blocked [Cout / 8][voxel][8] (Cout % 8 == 0): a staging slot is 32 contiguous bytes (two 16-byte loads)
+template <int NCT, int NP, bool BLK = false>
 __global__ void __launch_bounds__(SU_THREADS, 2)
 k_s3u_dlow(const float* __restrict__ dz, long long dz_bs, int Cout, const u32x4* __restrict__ wp, float* __restrict__ gxl, long long gxl_bs, int C0,
            const float* __restrict__ mask, long long mask_bs, float mask_slope, int B, int D, int H, int W) {
@@ -590,6 +616,14 @@ k_s3u_dlow(const float* __restrict__ dz, long long dz_bs, int Cout, const u32x4*
             const int pos = sk_pos[j];
             const int gd = d0 - 1 + (pos >> 10), gh = h0 - 1 + ((pos >> 6) & 15), gw = w0 - 1 + (pos & 63);
             const bool ok = live && pos >= 0 && q < Q && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            if constexpr (BLK) {
+                voffs[j] = ok ? (q * V + (gd * H + gh) * W + gw) << 5 : VXM_OOB;
+                const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, voffs[j], 0, 0));
+                const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, voffs[j], 16, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { xr[j][e] = lo[e]; xr[j][4 + e] = hi[e]; }
+                continue;
+            }
             voffs[j] = ok ? (q * 8 * V + (gd * H + gh) * W + gw) << 2 : VXM_OOB;
 #pragma unroll
             for (int e = 0; e < 8; ++e) xr[j][e] = (q * 8 + e < Cout) ? vxm_bload(rz, voffs[j], (e * V) << 2) : 0.0f;       // (wave-uniform test: Cout % 8 != 0)
@@ -785,7 +819,7 @@ template <int NCI> struct UwCfg {
 template <int NCI>
 __global__ void __launch_bounds__(UW_THREADS, 4) k_s3u_bww(const float* __restrict__ x0, long long x0_bs, int C0, const float* __restrict__ dz,
                                                            long long dz_bs, int Cdz, float* __restrict__ part, int D, int H, int W, int NBLK,
-                                                           int ncol, int nseg, int seg_len, int nh, int nw, int task_rr) {
+                                                           int ncol, int nseg, int seg_len, int nh, int nw, int task_rr, int lay) {
     using CF = UwCfg<NCI>;
     using P = S3P<2>;
     constexpr int NP = 2;
@@ -841,159 +875,177 @@ __global__ void __launch_bounds__(UW_THREADS, 4) k_s3u_bww(const float* __restri
     unsigned ka[NP][4], kb[NP][4];
     int off0 = VXM_OOB, ldst = 0, vk;
 
-    for (int task = k_lo; task < k_hi; task += k_step) {
-        const int seg = task_rr ? task / ncol : task % nseg, col = task_rr ? task - seg * ncol : task / nseg;        // (depth-segment-major when round-robin)
-        const int tw = col % nw; int cq = col / nw;
-        const int th = cq % nh; const int b = cq / nh;
-        const int md0 = seg * seg_len, ntile = min(seg_len, Dl - md0), nphase = (ntile + UW_TPP - 1) / UW_TPP;
-        const int mh0 = th * 2, mw0 = tw * 16;
-        const bool xrole = s_role != 2;
-        const __amdgpu_buffer_rsrc_t rd = vxm_rsrc(xrole ? dz + (size_t)b * dz_bs : x0 + (size_t)b * x0_bs, (unsigned)(xrole ? Cdz * V : C0 * Vl) * 4u);
-        if (s_role == 1) {
-            const int cb = x_r & 1, pr = x_r >> 1, hh = pr / 18, pp = pr - hh * 18;
-            const int gh = 2 * mh0 - 1 + hh, gw = 2 * mw0 - 2 + 2 * pp;
-            const bool live = x_pl < 4 && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && cot * 16 + cb * 8 < Cdz;
-            off0 = live ? ((cot * 16 + cb * 8) * V + gh * W + gw) << 2 : VXM_OOB;
-            // first voxel of the pair: haloed column 2 pp - 1 (parity 1, index pp - 1), second: column 2 pp (parity 0, index pp)
-            ldst = (((hh * 2 + 1) * UW_ROWV + pp - 1) * 32 + cb * 16) | (pp == 0 ? 1 : 0) | (pp == 17 ? 2 : 0);
-        } else {
-            const int cbq = x_r & 3, r2 = x_r >> 2, lr = r2 >> 3, pair = r2 & 7;
-            const bool live = cbq * 8 < C0 && cbq < 2 * NCI && mh0 + lr < Hl && mw0 + 2 * pair < Wl;
-            off0 = live ? (cbq * 8 * Vl + (mh0 + lr) * Wl + mw0 + 2 * pair) << 2 : VXM_OOB;
-            ldst = ((cbq >> 1) * UW_LTILE) + (lr * 16 + 2 * pair) * 32 + (cbq & 1) * 16;
-        }
-        // dz planes p0 .. p0 + np - 1 of this task (plane p = full-resolution depth 2 md0 - 1 + p) and the x0 tiles tl, tl + 1 (tl < 0: none)
-        // -> registers; a plane outside the volume / a tile outside the task ORs the out-of-range bit into the lane offsets (branch-free)
-        auto load_phase = [&](int p0, int np, int tl) __attribute__((always_inline)) {
-            const int gd = 2 * md0 - 1 + p0 + x_pl;                                   // (dz role: per-lane plane)
-            const bool pok = x_pl < np && (unsigned)gd < (unsigned)D;
-            const int mt = tl + x_pl;                                                 // (x0 role: wave-uniform tile)
-            const bool lok = tl >= 0 && mt < ntile;
-            vk = xrole ? (pok ? off0 + ((gd * HW) << 2) : VXM_OOB) : (lok ? off0 : VXM_OOB);
-            const int sb = xrole ? 0 : ((md0 + (lok ? mt : 0)) * HWl) << 2;
-            const int cs = (xrole ? V : Vl) << 2;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, vk, sb + e * cs, 0));
-                ra[e] = t2.x; rb[e] = t2.y;
-            }
-        };
-        auto publish_max = [&](int slot) __attribute__((always_inline)) {
-            float m = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[e]), __builtin_fabsf(rb[e])));
-            m = s3_wave_max(m);
-            if (lane == 0) Tab[16 + 16 * slot + wave] = m;
-        };
-        float sc_role = 1.0f;
-        auto take_scales = [&](int slot, int p0, int np, int lbuf) __attribute__((always_inline)) {
-            const f32x4* const t4 = reinterpret_cast<const f32x4*>(Tab + 16 + 16 * slot);
-            const f32x4 m0 = t4[0], m1 = t4[1], m2 = t4[2], m3 = t4[3];
-            const float mxx = fmaxf(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))),
-                                    fmaxf(fmaxf(fmaxf(m2.x, m2.y), fmaxf(m2.z, m2.w)), fmaxf(m3.x, m3.y)));          // waves 0 .. 13
-            const float mxl = fmaxf(m3.z, m3.w);                                                                     // waves 14, 15
-            float sx, ix, sl, il;
-            s3_scale_of(mxx, sx, ix);
-            s3_scale_of(mxl, sl, il);
-            sc_role = s_role == 2 ? sl : sx;
-            if (tid < np) Tab[(p0 + tid) % UW_RING] = ix;
-            if (tid == 64 && lbuf >= 0) Tab[10 + lbuf] = il;
-        };
-        auto split_tile = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s3_split2_f16(ra[2 * e], ra[2 * e + 1], sc_role, ka[0][e], ka[1][e]);
-                s3_split2_f16(rb[2 * e], rb[2 * e + 1], sc_role, kb[0][e], kb[1][e]);
-            }
-        };
-        auto write_phase = [&](int p0, int np, int lbuf) __attribute__((always_inline)) {
+    // (the task loop per staging role and dz layout, compile-time inside it: see k_s3_bwd_weight)
+    auto run_tasks = [&](auto xr_, auto bl_) __attribute__((always_inline)) {
+        constexpr bool XR = decltype(xr_)::value, BLK = decltype(bl_)::value;
+        for (int task = k_lo; task < k_hi; task += k_step) {
+            const int seg = task_rr ? task / ncol : task % nseg, col = task_rr ? task - seg * ncol : task / nseg;        // (depth-segment-major when round-robin)
+            const int tw = col % nw; int cq = col / nw;
+            const int th = cq % nh; const int b = cq / nh;
+            const int md0 = seg * seg_len, ntile = min(seg_len, Dl - md0), nphase = (ntile + UW_TPP - 1) / UW_TPP;
+            const int mh0 = th * 2, mw0 = tw * 16;
+            constexpr bool xrole = XR;                             // (= s_role != 2: the task loop is instantiated per staging role, as k_s3_bwd_weight)
+            constexpr bool blk = XR && BLK;                          // dz channel-blocked [Cdz / 8][voxel][8] (lay & VXM_S3_IN1_BLOCKED); x0 stays planar
+            constexpr int lsh = blk ? 5 : 2;
+            const __amdgpu_buffer_rsrc_t rd = vxm_rsrc(xrole ? dz + (size_t)b * dz_bs : x0 + (size_t)b * x0_bs, (unsigned)(xrole ? Cdz * V : C0 * Vl) * 4u);
             if (s_role == 1) {
-                if (x_pl < np) {
-                    char* const d = Xs + ((p0 + x_pl) % UW_RING) * UW_PLANE + (ldst & ~3);
-                    if (!(ldst & 1)) {
-#pragma unroll
-                        for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * UW_XPIECE) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
-                    }
-                    if (!(ldst & 2)) {                           // the second voxel: parity 0, one parity block back and one index on
-#pragma unroll
-                        for (int p = 0; p < NP; ++p)
-                            *reinterpret_cast<u32x4*>(d + p * UW_XPIECE - UW_ROWV * 32 + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
-                    }
-                }
-            } else if (lbuf >= 0) {
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    char* const d = Ls + lbuf * CF::LBUF + (x_pl * NP + p) * NCI * UW_LTILE + ldst;
-                    *reinterpret_cast<u32x4*>(d) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
-                    *reinterpret_cast<u32x4*>(d + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
-                }
+                const int cb = x_r & 1, pr = x_r >> 1, hh = pr / 18, pp = pr - hh * 18;
+                const int gh = 2 * mh0 - 1 + hh, gw = 2 * mw0 - 2 + 2 * pp;
+                const bool live = x_pl < 4 && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && cot * 16 + cb * 8 < Cdz;
+                off0 = live ? (blk ? ((cot * 2 + cb) * V + gh * W + gw) << 5 : ((cot * 16 + cb * 8) * V + gh * W + gw) << 2) : VXM_OOB;
+                // first voxel of the pair: haloed column 2 pp - 1 (parity 1, index pp - 1), second: column 2 pp (parity 0, index pp)
+                ldst = (((hh * 2 + 1) * UW_ROWV + pp - 1) * 32 + cb * 16) | (pp == 0 ? 1 : 0) | (pp == 17 ? 2 : 0);
+            } else {
+                const int cbq = x_r & 3, r2 = x_r >> 2, lr = r2 >> 3, pair = r2 & 7;
+                const bool live = cbq * 8 < C0 && cbq < 2 * NCI && mh0 + lr < Hl && mw0 + 2 * pair < Wl;
+                off0 = live ? (cbq * 8 * Vl + (mh0 + lr) * Wl + mw0 + 2 * pair) << 2 : VXM_OOB;
+                ldst = ((cbq >> 1) * UW_LTILE) + (lr * 16 + 2 * pair) * 32 + (cbq & 1) * 16;
             }
-        };
+            // dz planes p0 .. p0 + np - 1 of this task (plane p = full-resolution depth 2 md0 - 1 + p) and the x0 tiles tl, tl + 1 (tl < 0: none)
+            // -> registers; a plane outside the volume / a tile outside the task ORs the out-of-range bit into the lane offsets (branch-free)
+            auto load_phase = [&](int p0, int np, int tl) __attribute__((always_inline)) {
+                const int gd = 2 * md0 - 1 + p0 + x_pl;                                   // (dz role: per-lane plane)
+                const bool pok = x_pl < np && (unsigned)gd < (unsigned)D;
+                const int mt = tl + x_pl;                                                 // (x0 role: wave-uniform tile)
+                const bool lok = tl >= 0 && mt < ntile;
+                vk = xrole ? (pok ? off0 + ((gd * HW) << lsh) : VXM_OOB) : (lok ? off0 : VXM_OOB);
+                const int sb = xrole ? 0 : ((md0 + (lok ? mt : 0)) * HWl) << 2;
+                const int cs = (xrole ? V : Vl) << 2;
+                if constexpr (blk) {
+    #pragma unroll
+                    for (int k = 0; k < 2; ++k) {                    // first voxel: channels 4 k .. 4 k + 3; second voxel 32 bytes on
+                        const f32x4 ta = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, vk, 16 * k, 0));
+                        const f32x4 tb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, vk, 32 + 16 * k, 0));
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) { ra[4 * k + e] = ta[e]; rb[4 * k + e] = tb[e]; }
+                    }
+                } else {
+    #pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, vk, sb + e * cs, 0));
+                        ra[e] = t2.x; rb[e] = t2.y;
+                    }
+                }
+            };
+            auto publish_max = [&](int slot) __attribute__((always_inline)) {
+                float m = 0.0f;
+    #pragma unroll
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[e]), __builtin_fabsf(rb[e])));
+                m = s3_wave_max(m);
+                if (lane == 0) Tab[16 + 16 * slot + wave] = m;
+            };
+            float sc_role = 1.0f;
+            auto take_scales = [&](int slot, int p0, int np, int lbuf) __attribute__((always_inline)) {
+                const f32x4* const t4 = reinterpret_cast<const f32x4*>(Tab + 16 + 16 * slot);
+                const f32x4 m0 = t4[0], m1 = t4[1], m2 = t4[2], m3 = t4[3];
+                const float mxx = fmaxf(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))),
+                                        fmaxf(fmaxf(fmaxf(m2.x, m2.y), fmaxf(m2.z, m2.w)), fmaxf(m3.x, m3.y)));          // waves 0 .. 13
+                const float mxl = fmaxf(m3.z, m3.w);                                                                     // waves 14, 15
+                float sx, ix, sl, il;
+                s3_scale_of(mxx, sx, ix);
+                s3_scale_of(mxl, sl, il);
+                sc_role = s_role == 2 ? sl : sx;
+                if (tid < np) Tab[(p0 + tid) % UW_RING] = ix;
+                if (tid == 64 && lbuf >= 0) Tab[10 + lbuf] = il;
+            };
+            auto split_tile = [&]() __attribute__((always_inline)) {
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s3_split2_f16(ra[2 * e], ra[2 * e + 1], sc_role, ka[0][e], ka[1][e]);
+                    s3_split2_f16(rb[2 * e], rb[2 * e + 1], sc_role, kb[0][e], kb[1][e]);
+                }
+            };
+            auto write_phase = [&](int p0, int np, int lbuf) __attribute__((always_inline)) {
+                if (s_role == 1) {
+                    if (x_pl < np) {
+                        char* const d = Xs + ((p0 + x_pl) % UW_RING) * UW_PLANE + (ldst & ~3);
+                        if (!(ldst & 1)) {
+    #pragma unroll
+                            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(d + p * UW_XPIECE) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
+                        }
+                        if (!(ldst & 2)) {                           // the second voxel: parity 0, one parity block back and one index on
+    #pragma unroll
+                            for (int p = 0; p < NP; ++p)
+                                *reinterpret_cast<u32x4*>(d + p * UW_XPIECE - UW_ROWV * 32 + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                        }
+                    }
+                } else if (lbuf >= 0) {
+    #pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        char* const d = Ls + lbuf * CF::LBUF + (x_pl * NP + p) * NCI * UW_LTILE + ldst;
+                        *reinterpret_cast<u32x4*>(d) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
+                        *reinterpret_cast<u32x4*>(d + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                    }
+                }
+            };
 
-        __syncthreads();                                        // every wave is done with the previous task
-        load_phase(0, 4, 0);                                    // planes 0 .. 3, tiles 0, 1
-        publish_max(0);
-        __syncthreads();
-        take_scales(0, 0, 4, 0);
-        split_tile();
-        write_phase(0, 4, 0);
-        load_phase(4, 2, -1);                                   // planes 4, 5
-        publish_max(1);
-        __syncthreads();
-        take_scales(1, 4, 2, -1);
-        split_tile();
-        write_phase(4, 2, -1);
-        __syncthreads();
-        for (int t = 0; t < nphase; ++t) {
-            const bool more = t + 1 < nphase;
-            const int lcur = t & 1;
-            load_phase(4 * t + 6, 4, more ? UW_TPP * (t + 1) : -1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma nounroll
-            for (int u = 0; u < UW_TPP; ++u) {                   // (not unrolled: the two tiles' fragment reads side by side cost 44 spilled registers)
-                const int slot = (4 * t + 2 * u + ad) % UW_RING;
-                const char* const xp = Xs + slot * UW_PLANE;
-                const float unscale = Tab[slot] * Tab[10 + lcur];
-                u32x4 bl[NCI][NP];                               // x0 fragments (B operand): K = (low-res row, 16 voxels)
-#pragma unroll
-                for (int c = 0; c < NCI; ++c)
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        const int lb = lcur * CF::LBUF + ((u * NP + p) * NCI + c) * UW_LTILE + lp;
-                        const u32x2 lo = s3_tr_read(Ls, lb), hi = s3_tr_read(Ls, lb + 16 * 32);
-                        bl[c][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
-                    }
-#pragma unroll
-                for (int aw = 0; aw < 4; ++aw) {
-                    u32x4 az[NP];                                // dz fragment (A operand) of offset (ad, ah, aw): rows ah and ah + 2, parity aw & 1, from index aw >> 1
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) {
-                        const int zb = p * UW_XPIECE + ((ah * 2 + (aw & 1)) * UW_ROWV + (aw >> 1)) * 32 + lp;
-                        const u32x2 lo = s3_tr_read(xp, zb), hi = s3_tr_read(xp, zb + 2 * 2 * UW_ROWV * 32);
-                        az[p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
-                    }
-#pragma unroll
-                    for (int c = 0; c < NCI; ++c) {
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int tp = 0; tp < P::NPROD; ++tp) acc = P::mfma(az[P::PA[tp]], bl[c][P::PB[tp]], acc);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) tot[aw][c][j] = __builtin_fmaf(acc[j], unscale, tot[aw][c][j]);
+            __syncthreads();                                        // every wave is done with the previous task
+            load_phase(0, 4, 0);                                    // planes 0 .. 3, tiles 0, 1
+            publish_max(0);
+            __syncthreads();
+            take_scales(0, 0, 4, 0);
+            split_tile();
+            write_phase(0, 4, 0);
+            load_phase(4, 2, -1);                                   // planes 4, 5
+            publish_max(1);
+            __syncthreads();
+            take_scales(1, 4, 2, -1);
+            split_tile();
+            write_phase(4, 2, -1);
+            __syncthreads();
+            for (int t = 0; t < nphase; ++t) {
+                const bool more = t + 1 < nphase;
+                const int lcur = t & 1;
+                load_phase(4 * t + 6, 4, more ? UW_TPP * (t + 1) : -1);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma nounroll
+                for (int u = 0; u < UW_TPP; ++u) {                   // (not unrolled: the two tiles' fragment reads side by side cost 44 spilled registers)
+                    const int slot = (4 * t + 2 * u + ad) % UW_RING;
+                    const char* const xp = Xs + slot * UW_PLANE;
+                    const float unscale = Tab[slot] * Tab[10 + lcur];
+                    u32x4 bl[NCI][NP];                               // x0 fragments (B operand): K = (low-res row, 16 voxels)
+    #pragma unroll
+                    for (int c = 0; c < NCI; ++c)
+    #pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            const int lb = lcur * CF::LBUF + ((u * NP + p) * NCI + c) * UW_LTILE + lp;
+                            const u32x2 lo = s3_tr_read(Ls, lb), hi = s3_tr_read(Ls, lb + 16 * 32);
+                            bl[c][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+                        }
+    #pragma unroll
+                    for (int aw = 0; aw < 4; ++aw) {
+                        u32x4 az[NP];                                // dz fragment (A operand) of offset (ad, ah, aw): rows ah and ah + 2, parity aw & 1, from index aw >> 1
+    #pragma unroll
+                        for (int p = 0; p < NP; ++p) {
+                            const int zb = p * UW_XPIECE + ((ah * 2 + (aw & 1)) * UW_ROWV + (aw >> 1)) * 32 + lp;
+                            const u32x2 lo = s3_tr_read(xp, zb), hi = s3_tr_read(xp, zb + 2 * 2 * UW_ROWV * 32);
+                            az[p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+                        }
+    #pragma unroll
+                        for (int c = 0; c < NCI; ++c) {
+                            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    #pragma unroll
+                            for (int tp = 0; tp < P::NPROD; ++tp) acc = P::mfma(az[P::PA[tp]], bl[c][P::PB[tp]], acc);
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) tot[aw][c][j] = __builtin_fmaf(acc[j], unscale, tot[aw][c][j]);
+                        }
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("" ::"v"(vk));
+                publish_max(0);
+                __syncthreads();                                     // every wave is done reading this phase; the maxima of the next are published
+                if (more) {
+                    take_scales(0, 4 * t + 6, 4, lcur ^ 1);
+                    split_tile();
+                    write_phase(4 * t + 6, 4, lcur ^ 1);
+                }
+                __syncthreads();
             }
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("" ::"v"(vk));
-            publish_max(0);
-            __syncthreads();                                     // every wave is done reading this phase; the maxima of the next are published
-            if (more) {
-                take_scales(0, 4 * t + 6, 4, lcur ^ 1);
-                split_tile();
-                write_phase(4 * t + 6, 4, lcur ^ 1);
-            }
-            __syncthreads();
         }
-    }
+    };
+    if (s_role != 2) { if (lay & VXM_S3_IN1_BLOCKED) run_tasks(std::true_type{}, std::true_type{}); else run_tasks(std::true_type{}, std::false_type{}); }
+    else run_tasks(std::false_type{}, std::false_type{});
     // ---- partials: part[bx][cot][a = (ad, ah, aw)][co 16][ci 16 NCI]; lane (kg, n) holds co = 4 kg + j, ci = 16 c + n
     float* const pp = part + (((size_t)bx * NCOT + cot) * 64 + (ad * 4 + ah) * 4) * (16 * 16 * NCI);
 #pragma unroll
@@ -1051,7 +1103,7 @@ long long su_min_tiles() {
 
 template <int NCT, int NP>
 void su_launch(const float* x0, long long bs0, int C0, const float* x1, long long bs1, int C1, const void* wp, const float* bias, float* y,
-               long long y_bs, int Cout, float slope, int B, int D, int H, int W, hipStream_t s) {
+               long long y_bs, int Cout, float slope, int B, int D, int H, int W, hipStream_t s, int lay) {
     using C = SuCfg<NCT, NP>;
     static const bool attr = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3u_conv<NCT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -1069,7 +1121,7 @@ void su_launch(const float* x0, long long bs0, int C0, const float* x1, long lon
         if (cap < gx) gx = cap;
     }
     hipLaunchKernelGGL((k_s3u_conv<NCT, NP>), dim3(gx, G), dim3(SU_THREADS), C::LDS_BYTES, s, x0, bs0, C0, x1, bs1, C1, static_cast<const u32x4*>(wp),
-                       bias, y, y_bs, Cout, slope, B, D, H, W);
+                       bias, y, y_bs, Cout, slope, B, D, H, W, lay);
 }
 
 
@@ -1077,12 +1129,12 @@ size_t sd_words(int C0, int Cout, int NP, int NCT) {
     const int G = (C0 + 16 * NCT - 1) / (16 * NCT), Q = (Cout + 7) / 8;
     return (size_t)G * Q * 16 * NP * NCT * 64;
 }
-template <int NCT, int NP>
+template <int NCT, int NP, bool BLK = false>
 void sd_launch(const float* dz, long long dz_bs, int Cout, const void* wp, float* gxl, long long gxl_bs, int C0, const float* mask, long long mask_bs,
                float mask_slope, int B, int D, int H, int W, hipStream_t s) {
     using C = SdCfg<NCT, NP>;
     static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3u_dlow<NCT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3u_dlow<NCT, NP, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         return true;
     }();
     (void)attr;
@@ -1095,7 +1147,7 @@ void sd_launch(const float* dz, long long dz_bs, int Cout, const void* wp, float
         const unsigned cap = 8 * ((want + 7) / 8);
         if (cap < gx) gx = cap;
     }
-    hipLaunchKernelGGL((k_s3u_dlow<NCT, NP>), dim3(gx, G), dim3(SU_THREADS), C::LDS_BYTES, s, dz, dz_bs, Cout, static_cast<const u32x4*>(wp), gxl, gxl_bs,
+    hipLaunchKernelGGL((k_s3u_dlow<NCT, NP, BLK>), dim3(gx, G), dim3(SU_THREADS), C::LDS_BYTES, s, dz, dz_bs, Cout, static_cast<const u32x4*>(wp), gxl, gxl_bs,
                        C0, mask, mask_bs, mask_slope, B, D, H, W);
 }
 
@@ -1151,9 +1203,12 @@ int vxm_conv3d_k3_s3u_pack_weights(const float* w, void* wpacked, int C0, int C1
 }
 
 int vxm_conv3d_k3_s3u_fwd(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const void* wpacked,
-                          const float* bias, float* y, int64_t y_bstride, int Cout, float leaky_slope, int B, int D, int H, int W, int pieces,
+                          const float* bias, float* y, int64_t y_bstride, int Cout, float leaky_slope, int B, int D, int H, int W, int pieces_and_layout,
                           void* stream) {
+    const int pieces = pieces_and_layout & 0xff, lay = pieces_and_layout & ~0xff;
     VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3u_fwd: null pointer");
+    VXM_REQUIRE(lay == 0 || (lay == VXM_S3_OUT_BLOCKED && Cout % 8 == 0), VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3u_fwd: layout flags 0x%x (only the output may be channel-blocked; Cout = %d in multiples of 8)", lay, Cout);
     if (int e = check_conv("vxm_conv3d_k3_s3u_fwd", C0, C1, 1, Cout, B, D, H, W)) return e;
     VXM_REQUIRE(C0 % 8 == 0 && C1 % 8 == 0 && (pieces == 2 || pieces == 3), VXM_ERR_BAD_SHAPE,
                 "vxm_conv3d_k3_s3u_fwd: segments carry multiples of 8 channels (got %d + %d), pieces 2 or 3 (got %d)", C0, C1, pieces);
@@ -1162,8 +1217,8 @@ int vxm_conv3d_k3_s3u_fwd(const float* x0, int C0, int64_t x0_bstride, const flo
     const int NCT = su_nct(Cout);
 #define SU_GO(NCT_)                                                                                                                  \
     do {                                                                                                                             \
-        if (pieces == 2) su_launch<NCT_, 2>(x0, x0_bstride, C0, x1, x1_bstride, C1, wpacked, bias, y, y_bstride, Cout, leaky_slope, B, D, H, W, s); \
-        else su_launch<NCT_, 3>(x0, x0_bstride, C0, x1, x1_bstride, C1, wpacked, bias, y, y_bstride, Cout, leaky_slope, B, D, H, W, s);            \
+        if (pieces == 2) su_launch<NCT_, 2>(x0, x0_bstride, C0, x1, x1_bstride, C1, wpacked, bias, y, y_bstride, Cout, leaky_slope, B, D, H, W, s, lay); \
+        else su_launch<NCT_, 3>(x0, x0_bstride, C0, x1, x1_bstride, C1, wpacked, bias, y, y_bstride, Cout, leaky_slope, B, D, H, W, s, lay);            \
     } while (0)
     if (NCT == 2) SU_GO(2); else SU_GO(1);
 #undef SU_GO
@@ -1201,14 +1256,22 @@ int vxm_conv3d_k3_s3u_bwd_low_pack_weights(const float* w, void* wpacked, int C0
 }
 
 int vxm_conv3d_k3_s3u_bwd_low(const float* dz, int64_t dz_bstride, int Cout, const void* wpacked, float* gxl, int64_t gxl_bstride, int C0,
-                              const float* mask, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, int pieces, void* stream) {
+                              const float* mask, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, int pieces_and_layout, void* stream) {
+    const int pieces = pieces_and_layout & 0xff, lay = pieces_and_layout & ~0xff;
     VXM_REQUIRE(dz && wpacked && gxl, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3u_bwd_low: null pointer");
+    VXM_REQUIRE(lay == 0 || (lay == VXM_S3_IN0_BLOCKED && Cout % 8 == 0), VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3u_bwd_low: layout flags 0x%x (only dz, the first operand, may be channel-blocked; Cout = %d in multiples of 8)", lay, Cout);
     if (int e = check_conv("vxm_conv3d_k3_s3u_bwd_low", C0, 0, 1, Cout, B, D, H, W)) return e;
     VXM_REQUIRE(pieces == 2 && (reinterpret_cast<uintptr_t>(wpacked) & 15) == 0, VXM_ERR_BAD_SHAPE,
                 "vxm_conv3d_k3_s3u_bwd_low: pieces %d (this kernel runs the fp16 scheme, 2), 16-byte aligned packed weights", pieces);
     hipStream_t s = VXM_STREAM(stream);
-    if (su_nct(C0) == 2) sd_launch<2, 2>(dz, dz_bstride, Cout, wpacked, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, B, D, H, W, s);
-    else sd_launch<1, 2>(dz, dz_bstride, Cout, wpacked, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, B, D, H, W, s);
+    if (su_nct(C0) == 2) {
+        if (lay) sd_launch<2, 2, true>(dz, dz_bstride, Cout, wpacked, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, B, D, H, W, s);
+        else sd_launch<2, 2>(dz, dz_bstride, Cout, wpacked, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, B, D, H, W, s);
+    } else {
+        if (lay) sd_launch<1, 2, true>(dz, dz_bstride, Cout, wpacked, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, B, D, H, W, s);
+        else sd_launch<1, 2>(dz, dz_bstride, Cout, wpacked, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, B, D, H, W, s);
+    }
     return vxm_check_launch("vxm_conv3d_k3_s3u_bwd_low");
 }
 
@@ -1234,8 +1297,11 @@ size_t vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes(int C0, int Cout, int B, int
 }
 
 int vxm_conv3d_k3_s3u_bwd_weight(const float* x0, int C0, int64_t x0_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw, int gw_cin,
-                                 void* work, size_t work_bytes, int B, int D, int H, int W, int pieces, void* stream) {
+                                 void* work, size_t work_bytes, int B, int D, int H, int W, int pieces_and_layout, void* stream) {
+    const int pieces = pieces_and_layout & 0xff, lay = pieces_and_layout & ~0xff;
     VXM_REQUIRE(x0 && dz && gw && work, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3u_bwd_weight: null pointer");
+    VXM_REQUIRE(lay == 0 || lay == VXM_S3_IN1_BLOCKED, VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3u_bwd_weight: layout flags 0x%x (only dz, the second operand, may be channel-blocked)", lay);
     if (int e = check_conv("vxm_conv3d_k3_s3u_bwd_weight", C0, 0, 1, Cout, B, D, H, W)) return e;
     VXM_REQUIRE(pieces == 2 && (C0 == 16 || C0 == 32) && Cout % 16 == 0 && C0 <= gw_cin && W % 4 == 0, VXM_ERR_BAD_SHAPE,
                 "vxm_conv3d_k3_s3u_bwd_weight: %d upsampled channels (16 or 32) of %d, %d outputs (multiple of 16), W = %d (multiple of 4), pieces %d (2)",
@@ -1256,10 +1322,10 @@ int vxm_conv3d_k3_s3u_bwd_weight(const float* x0, int C0, int64_t x0_bstride, co
     const int task_rr = ((te && te[0] == 'r' && te[1] == 'a') || (long long)D * H * W < (1ll << 21)) ? 0 : 1;
     if (NCI == 2)
         hipLaunchKernelGGL(k_s3u_bww<2>, dim3(tk.NBLK * NCOT), dim3(UW_THREADS), UwCfg<2>::LDS_BYTES, s, x0, (long long)x0_bstride, C0, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw, task_rr);
+                           (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw, task_rr, lay);
     else
         hipLaunchKernelGGL(k_s3u_bww<1>, dim3(tk.NBLK * NCOT), dim3(UW_THREADS), UwCfg<1>::LDS_BYTES, s, x0, (long long)x0_bstride, C0, dz,
-                           (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw, task_rr);
+                           (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw, task_rr, lay);
     hipLaunchKernelGGL(k_s3u_bww_reduce, dim3(vxm_blocks((long long)Cout * C0 * 27, 256)), dim3(256), 0, s, part, gw, C0, Cout, gw_cin, NCI, NCOT, tk.NBLK);
     return vxm_check_launch("vxm_conv3d_k3_s3u_bwd_weight");
 }

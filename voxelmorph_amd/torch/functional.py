@@ -42,6 +42,8 @@ S3_UP = os.environ.get("VXM_S3_UP", "") == "1"
 # cat([upsample(x0), x1]) forwards on the split + collapsed kernel (csrc/conv_s3u.hip: the upsampled segment at low-resolution cost AND on
 # the 16-bit matrix pipe); VXM_S3U=0 keeps them on the round-3 kernels (collapsed fp32-MFMA kernel / split kernel through the gather)
 S3U = os.environ.get("VXM_S3U", "1") != "0"
+# channel-blocked interior tensors of the fused U-Net (tensors that only split kernels write and read: _blocked_tensors); VXM_BLOCKED=0: all planar
+BLOCKED = os.environ.get("VXM_BLOCKED", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -434,11 +436,11 @@ def s3u_pack(w, c0, c1):
     return wp
 
 
-def s3u_launch(x0, c0, bs0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, B, D, H, W):
+def s3u_launch(x0, c0, bs0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, B, D, H, W, lay=0):
     with _prof.region("k_s3u_conv<%d,%d>" % (1 if cout <= 16 else 2, s3_pieces()), flops=2.0 * (8 * c0 + 27 * c1) * cout * B * D * H * W,
                       nominal=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_conv3d_k3_s3u_fwd", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W,
-             s3_pieces(), stream())
+             s3_pieces() | lay, stream())
 
 
 def s3u_bwd_low_route(c0, cout, B, D, H, W):
@@ -446,7 +448,7 @@ def s3u_bwd_low_route(c0, cout, B, D, H, W):
     return S3U and split_engine() and bool(_lib.lib().vxm_conv3d_k3_s3u_bwd_low_ok(c0, cout, B, D, H, W, s3_pieces()))
 
 
-def s3u_bwd_low(dz, cout, w, c0, cin, gxl, mask, mask_slope, B, D, H, W):
+def s3u_bwd_low(dz, cout, w, c0, cin, gxl, mask, mask_slope, B, D, H, W, lay=0):
     """gxl [B,c0,D/2,H/2,W/2] = LeakyReLU'(mask) * (conv backward + upsample backward of dz [B,cout,D,H,W]) for the first c0 input channels
     of w [cout][cin][27]; the packed transposed-collapsed operator is cached on the weight tensor"""
     cache = w.__dict__.setdefault("_vxm_s3_packs", {})
@@ -460,10 +462,25 @@ def s3u_bwd_low(dz, cout, w, c0, cin, gxl, mask, mask_slope, B, D, H, W):
     V = D * H * W
     with _prof.region("k_s3u_dlow<%d,%d>" % (1 if c0 <= 16 else 2, s3_pieces()), flops=2.0 * 8 * c0 * cout * B * V, nominal=2.0 * 27 * c0 * cout * B * V):
         call("vxm_conv3d_k3_s3u_bwd_low", ptr(dz), cout * V, cout, ptr(hit[1]), ptr(gxl), c0 * (V // 8), c0, ptr(mask), c0 * (V // 8), float(mask_slope),
-             B, D, H, W, s3_pieces(), stream())
+             B, D, H, W, s3_pieces() | lay, stream())
 
 
-def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
+# layout flags of include/vxm_hip.h (OR-ed into `pieces`): a flagged tensor is channel-blocked [B][C/8][D][H][W][8]
+S3_IN0_BLOCKED, S3_IN1_BLOCKED, S3_OUT_BLOCKED = 0x100, 0x200, 0x400
+
+
+def to_blocked(x):
+    """NCDHW -> channel-blocked [B][C/8][D][H][W][8] (same shape attribute, different element order); tests and tools"""
+    B, C = x.shape[:2]
+    return x.reshape(B, C // 8, 8, -1).permute(0, 1, 3, 2).contiguous().view(x.shape)
+
+
+def from_blocked(x):
+    B, C = x.shape[:2]
+    return x.reshape(B, C // 8, -1, 8).permute(0, 1, 3, 2).contiguous().view(x.shape)
+
+
+def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W, lay=0):
     v = _lib.lib().vxm_conv3d_k3_s3_variant(cout)
     name = None
     if _prof.ACTIVE is not None:          # label the region with the kernel the C ABI will dispatch to
@@ -472,7 +489,7 @@ def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask
         name = "k_s3p_conv<%d,%d>" % (v // 10, s3_pieces()) if pc else "k_s3_conv<%d,%d,%d,%d>" % (v // 10, rows, v % 10, s3_pieces())
     with _prof.region(name, flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_conv3d_k3_s3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
-             cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, s3_pieces(), stream())
+             cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, s3_pieces() | lay, stream())
 
 
 def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
@@ -486,19 +503,27 @@ def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, ma
              cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, stream())
 
 
-def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B, D, H, W):
+def _need_split_kernel(lay, what):
+    if lay:
+        raise RuntimeError("%s: a channel-blocked operand (layout flags 0x%x) needs the split kernels; the plan of the fused U-Net only marks "
+                           "tensors whose producer and consumers run on them" % (what, lay))
+
+
+def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B, D, H, W, lay=0):
     """ConvBlock / flow conv forward (networks.py:299-305, 211,257) from the reference-layout weights: the MFMA implicit
-    GEMM (weights packed per call), or the vector-ALU kernel when there are at most 4 output channels (flow conv)."""
-    if cout <= 4 and x1 is None and not up0 and _lib.lib().vxm_conv3d_k3_fewout_ok(ptr(x0), bs0, ptr(y), ybs, c0, cout, W):
+    GEMM (weights packed per call), or the vector-ALU kernel when there are at most 4 output channels (flow conv).
+    lay: S3_IN0_BLOCKED (x0) / S3_OUT_BLOCKED (y) for channel-blocked tensors between split kernels (fused U-Net only)."""
+    if lay == 0 and cout <= 4 and x1 is None and not up0 and _lib.lib().vxm_conv3d_k3_fewout_ok(ptr(x0), bs0, ptr(y), ybs, c0, cout, W):
         with _prof.region("k_conv3d_k3_fewout<%d>" % cout, flops=2.0 * 27 * c0 * cout * B * D * H * W):
             call("vxm_conv3d_k3_fewout_fwd", ptr(x0), c0, bs0, ptr(_c(w)), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W, stream())
         return
     if up0 and s3u_route(c0, c1, cout, B, D, H, W):
-        s3u_launch(x0, c0, bs0, x1, c1, bs1, s3u_pack(w, c0, c1), bias, y, ybs, cout, slope, B, D, H, W)
+        s3u_launch(x0, c0, bs0, x1, c1, bs1, s3u_pack(w, c0, c1), bias, y, ybs, cout, slope, B, D, H, W, lay=lay)
         return
     if s3_route(c0, up0, c1, cout, B, D, H, W):
-        s3_launch(x0, c0, bs0, up0, x1, c1, bs1, s3_pack(w, False, 0, c0 + c1, c0), bias, y, ybs, cout, slope, None, 0, 1.0, B, D, H, W)
+        s3_launch(x0, c0, bs0, up0, x1, c1, bs1, s3_pack(w, False, 0, c0 + c1, c0), bias, y, ybs, cout, slope, None, 0, 1.0, B, D, H, W, lay=lay)
         return
+    _need_split_kernel(lay, "conv_forward")
     if up0 and _lib.lib().vxm_conv3d_k3_up_ok(ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(y), cout, B, D, H, W):
         # upsampled segment at low-resolution cost: collapsed 2x2x2 weights per output parity (conv_fwd.hip: k_conv3d_k3_t8u)
         wp = torch.empty(_lib.lib().vxm_conv3d_k3_up_packed_elems(c0, c1, cout), dtype=w.dtype, device=w.device)
@@ -511,7 +536,7 @@ def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B,
     conv_launch(x0, c0, bs0, up0, x1, c1, bs1, pack_weights(w, False), bias, y, ybs, cout, slope, None, 0, 1.0, B, D, H, W)
 
 
-def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W, w_lo=0):
+def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W, w_lo=0, lay=0):
     """convolution_backward w.r.t. the input = the forward kernel with the flipped / transposed weights
     (networks.py:299 autograd twin), optionally multiplied by LeakyReLU'(mask) of the previous ConvBlock.
     A 48-channel result (16 mod 32) is produced as 32 + 16 channels: two launches of the 8-wave kernel's 2- and
@@ -520,9 +545,12 @@ def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W, w_lo=0):
     bounds = _bwd_bounds(cin)
     for lo, hi in zip(bounds[:-1], bounds[1:]):         # w_lo: gx covers the input channels [w_lo, w_lo + cin) of w
         if s3_route(cout, False, 0, hi - lo, B, D, H, W):
+            if lay & S3_OUT_BLOCKED and (lo, hi) != (0, cin):
+                raise RuntimeError("conv_bwd_data: a channel-blocked gradient is written by one launch")
             s3_launch(dz, cout, cout * V, False, None, 0, 0, s3_pack(w, True, w_lo + lo, w_lo + hi, cout), None, gx[:, lo:hi], cin * V, hi - lo,
-                      1.0, mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W)
+                      1.0, mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W, lay=lay)
             continue
+        _need_split_kernel(lay, "conv_bwd_data")
         conv_launch(dz, cout, cout * V, False, None, 0, 0, pack_weights(w, True, w_lo + lo, w_lo + hi), None, gx[:, lo:hi], cin * V, hi - lo, 1.0,
                     mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W)
 
@@ -555,13 +583,13 @@ class _Workspace:
         return self.buf
 
 
-def s3_bwd_weight(ws, x, c, bs, dz, cout, gw, gw_cin, ci_off, gb, B, D, H, W):
+def s3_bwd_weight(ws, x, c, bs, dz, cout, gw, gw_cin, ci_off, gb, B, D, H, W, lay=0):
     """weight / bias gradient of one full-resolution tensor on the split kernel (vxm_conv3d_k3_s3_bwd_weight)"""
     need = _lib.lib().vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(c, cout, B, D, H, W)
     buf = ws.get(need)
     with _prof.region("k_s3_bwd_weight<%d>" % s3_pieces(), flops=2.0 * 27 * c * cout * B * D * H * W):
         call("vxm_conv3d_k3_s3_bwd_weight", ptr(x), c, bs, ptr(dz), cout * D * H * W, cout, ptr(gw), gw_cin, ci_off, ptr(gb), ptr(buf), buf.numel(),
-             B, D, H, W, s3_pieces(), stream())
+             B, D, H, W, s3_pieces() | lay, stream())
 
 
 def s3u_bwd_weight_route(c0, cout, B, D, H, W):
@@ -569,25 +597,27 @@ def s3u_bwd_weight_route(c0, cout, B, D, H, W):
     return S3U and split_engine() and bool(_lib.lib().vxm_conv3d_k3_s3u_bwd_weight_ok(c0, cout, B, D, H, W, s3_pieces()))
 
 
-def s3u_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, gw_cin, B, D, H, W):
+def s3u_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, gw_cin, B, D, H, W, lay=0):
     """gw[:, 0:c0] of a [cout][gw_cin][27] array: weight gradient of the x2-upsampled segment x0 [B,c0,D/2,H/2,W/2] against dz [B,cout,D,H,W]"""
     need = _lib.lib().vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes(c0, cout, B, D, H, W)
     buf = ws.get(need)
     with _prof.region("k_s3u_bww<%d>" % (c0 // 16), flops=2.0 * 8 * c0 * cout * B * D * H * W, nominal=2.0 * 27 * c0 * cout * B * D * H * W):
         call("vxm_conv3d_k3_s3u_bwd_weight", ptr(x0), c0, bs0, ptr(dz), cout * D * H * W, cout, ptr(gw), gw_cin, ptr(buf), buf.numel(),
-             B, D, H, W, s3_pieces(), stream())
+             B, D, H, W, s3_pieces() | lay, stream())
 
 
-def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H, W):
+def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H, W, lay=0):
+    """lay: S3_IN0_BLOCKED (x0 of a plain conv) / S3_IN1_BLOCKED (dz) for channel-blocked tensors between split kernels (fused U-Net only)"""
     if split_engine() and not up0 and x1 is None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c0, cout, B, D, H, W):
-        s3_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, c0, 0, gb, B, D, H, W)
+        s3_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, c0, 0, gb, B, D, H, W, lay=lay)
         return
     if up0 and x1 is not None and s3u_bwd_weight_route(c0, cout, B, D, H, W) and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c1, cout, B, D, H, W):
         # cat([upsample(x0), x1]) on the split engine: the upsampled segment through the collapsed split kernel (conv_s3u.hip: k_s3u_bww), the
         # full-resolution skip segment (and the bias gradient) through k_s3_bwd_weight, each into its channel range of gw
-        s3u_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, c0 + c1, B, D, H, W)
-        s3_bwd_weight(ws, x1, c1, bs1, dz, cout, gw, c0 + c1, c0, gb, B, D, H, W)
+        s3u_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, c0 + c1, B, D, H, W, lay=lay & S3_IN1_BLOCKED)
+        s3_bwd_weight(ws, x1, c1, bs1, dz, cout, gw, c0 + c1, c0, gb, B, D, H, W, lay=lay & S3_IN1_BLOCKED)
         return
+    _need_split_kernel(lay, "conv_bwd_weight")
     if split_engine() and up0 and x1 is not None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c1, cout, B, D, H, W) and \
             _lib.lib().vxm_conv3d_k3_bwd_weight_variant(ptr(x0), c0, bs0, 1, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, D, H, W) // 10 == 2:
         # cat([upsample(x0), x1]): the upsampled segment through the collapsed fp32-MFMA kernel, the full-resolution skip segment (and the
@@ -847,6 +877,59 @@ def _s3_jobs(plan, params, B, shape3, with_backward, input_grads):
     return jobs
 
 
+def _blocked_tensors(plan, B, shape3):
+    """Which activations of the fused U-Net are kept CHANNEL-BLOCKED ([B][C/8][D][H][W][8], include/vxm_hip.h VXM_S3_*_BLOCKED) instead of
+    NCDHW.  The tensors never leave the engine, so their layout is its own business; a haloed row of a blocked tensor is one contiguous run
+    and the split kernels, which are bound by the vector L1's sector requests, stage it 15 - 20 % faster.  A tensor t
+    qualifies when every kernel that writes or reads t, or the gradient DZ[t] (which takes the same layout), is a split kernel with a
+    blocked variant at this shape: t is the output of a ConvBlock, read by exactly one plain ConvBlock (forward, weight gradient, and the
+    fused backward-data that produces DZ[t] with t as its mask), and its producer's backward (weight gradient and backward-data, which read
+    DZ[t]) runs on the split kernels too.  In the default VxmDense U-Net: the outputs of remaining[0] and remaining[1]."""
+    if not (BLOCKED and split_engine() and s3_pieces() == 2):
+        return frozenset()
+    L = _lib.lib()
+    out = set()
+
+    def plain_ok(cin, cout, D, H, W):
+        """forward-type launch cin -> cout of a plain single-segment tensor on an 8-row split instance"""
+        return cout > 4 and s3_route(cin, False, 0, cout, B, D, H, W) and bool(L.vxm_conv3d_k3_s3_layout_ok(cin, 0, 0, cout, H, 2))
+
+    for t, pn in plan.producer.items():
+        prod = plan.ops[pn]
+        cons = plan.consumers[t]
+        if prod["kind"] != "conv" or t == plan.out or len(cons) != 1:
+            continue
+        cop = plan.ops[cons[0]]
+        if cop["kind"] != "conv" or tuple(cop["src"]) != (t, False, None):
+            continue
+        C, cc = plan.ch[t], plan.ch[cop["dst"]]
+        D, H, W = _dims(shape3, plan.lvl[t])
+        if C % 16 or _bwd_bounds(C) != [0, C]:
+            continue
+        # the consumer: forward (reads t), weight gradient (x = t), fused backward-data (mask t, writes DZ[t])
+        if not (plain_ok(C, cc, D, H, W) and L.vxm_conv3d_k3_s3_bwd_weight_ok(C, cc, B, D, H, W) and plain_ok(cc, C, D, H, W)):
+            continue
+        # the producer: forward (writes t), weight gradient (dz = DZ[t]), backward-data (reads DZ[t])
+        s0, up0, s1 = prod["src"]
+        if s0 < plan.n_inputs:
+            continue
+        c0 = plan.ch[s0]
+        c1 = plan.ch[s1] if s1 is not None else 0
+        if up0:
+            up_fused = plan.ops[plan.producer[s0]]["kind"] == "conv" and len(plan.consumers[s0]) == 1
+            if not (s1 is not None and up_fused and s3u_route(c0, c1, C, B, D, H, W) and s3u_bwd_low_route(c0, C, B, D, H, W)
+                    and s3u_bwd_weight_route(c0, C, B, D, H, W) and L.vxm_conv3d_k3_s3_bwd_weight_ok(c1, C, B, D, H, W)
+                    and _bwd_bounds(c1) == [0, c1] and plain_ok(C, c1, D, H, W)):
+                continue
+        else:
+            if s1 is not None or _bwd_bounds(c0) != [0, c0]:
+                continue
+            if not (plain_ok(c0, C, D, H, W) and L.vxm_conv3d_k3_s3_bwd_weight_ok(c0, C, B, D, H, W) and plain_ok(C, c0, D, H, W)):
+                continue
+        out.add(t)
+    return frozenset(out)
+
+
 class UnetFn(torch.autograd.Function):
     """Whole U-Net (+ trailing convs) forward/backward on the HIP kernels: 12 MFMA conv launches,
     4 pool launches forward; backward = per conv one bwd-data launch (the forward kernel with the
@@ -874,6 +957,7 @@ class UnetFn(torch.autograd.Function):
                 raise ValueError("Unet: input %d has shape %s, expected [%d,%d,%s]" % (i, tuple(t.shape), B, plan.ch[i], shape3))
         if split_engine():
             s3_prepack(_s3_jobs(plan, params, B, shape3, any(ctx.needs_input_grad[1:]), any(ctx.needs_input_grad[1:1 + plan.n_inputs])))
+        blocked = _blocked_tensors(plan, B, shape3)
         for op in plan.ops:
             dst = op["dst"]
             D, H, W = _dims(shape3, plan.lvl[dst])
@@ -883,8 +967,9 @@ class UnetFn(torch.autograd.Function):
                 s0, up0, s1 = op["src"]
                 w, b = params[2 * op["k"]], params[2 * op["k"] + 1]
                 x0, x1 = T[s0], (T[s1] if s1 is not None else None)
+                lay = (S3_IN0_BLOCKED if s0 in blocked else 0) | (S3_OUT_BLOCKED if dst in blocked else 0)
                 conv_forward(x0, plan.ch[s0], x0[0].numel(), up0, x1, plan.ch[s1] if s1 is not None else 0,
-                             x1[0].numel() if x1 is not None else 0, w, b, out, plan.ch[dst] * V, plan.ch[dst], op["slope"], B, D, H, W)
+                             x1[0].numel() if x1 is not None else 0, w, b, out, plan.ch[dst] * V, plan.ch[dst], op["slope"], B, D, H, W, lay=lay)
             elif op["kind"] == "pool":
                 src = T[op["src"]]
                 sD, sH, sW = src.shape[2:]
@@ -898,7 +983,7 @@ class UnetFn(torch.autograd.Function):
         # until Python's cyclic GC runs (tens of GB per step at 160x192x224).
         out = T.pop(plan.out)
         ctx.save_for_backward(out)
-        ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B = plan, T, params, shape3, B
+        ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B, ctx.blocked = plan, T, params, shape3, B, blocked
         # activations and parameters are held as plain attributes (the returned tensor alone goes through
         # save_for_backward, see above), so autograd's version-counter check is done by hand in backward
         # (inference tensors -- torch.inference_mode() -- carry no version counter and can never reach backward)
@@ -907,7 +992,7 @@ class UnetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        plan, params, shape3, B = ctx.plan, ctx.params, ctx.shape3, ctx.B
+        plan, params, shape3, B, blocked = ctx.plan, ctx.params, ctx.shape3, ctx.B, ctx.blocked
         if ctx.T is None:
             raise RuntimeError("UnetFn: backward a second time: the saved activations were released by the first pass "
                                "(a retained graph is not supported by the fused engine)")
@@ -988,6 +1073,10 @@ class UnetFn(torch.autograd.Function):
                 cin = c0 + c1
                 dz = DZ.pop(dst)
                 x0, x1 = T[s0], (T[s1] if s1 is not None else None)
+                # channel-blocked tensors (_blocked_tensors): the activation s0 of a plain conv and / or this conv's own output, whose DZ shares its layout
+                dz_blk, x_blk = dst in blocked, s0 in blocked
+                lay_w = (S3_IN0_BLOCKED if x_blk else 0) | (S3_IN1_BLOCKED if dz_blk else 0)
+                lay_d = S3_IN0_BLOCKED if dz_blk else 0
                 # parameter gradients go straight into the optimiser's flat bucket when one is attached
                 # (voxelmorph_amd.optim.FlatAdam): no per-tensor accumulate / copy launches
                 # The kernel OVERWRITES its destination: only the first gradient of a parameter since zero_grad() may land in
@@ -1004,14 +1093,14 @@ class UnetFn(torch.autograd.Function):
                     side.wait_event(ev)
                     with torch.cuda.stream(side):
                         conv_bwd_weight(ws_side, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
-                                        gw, gb, B, D, H, W)
+                                        gw, gb, B, D, H, W, lay=lay_w)
                     dz.record_stream(side)          # dz is released by the main-stream chain before the side stream may be done
                     for g, sink in ((gw, gw_sink), (gb, gb_sink)):
                         if sink is None:            # allocated on the main stream, written on the side stream
                             g.record_stream(side)
                 else:
                     conv_bwd_weight(ws, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
-                                    gw, gb, B, D, H, W)
+                                    gw, gb, B, D, H, W, lay=lay_w)
                 grads[n_in + 2 * op["k"]] = None if gw_sink is not None else gw
                 grads[n_in + 2 * op["k"] + 1] = None if gb_sink is not None else gb
                 feeds_inputs = s0 < n_in
@@ -1029,8 +1118,9 @@ class UnetFn(torch.autograd.Function):
                     lD, lH, lW = D // 2, H // 2, W // 2
                     dzl = torch.empty((B, c0, lD, lH, lW), dtype=dt, device=dev)
                     if s3u_bwd_low_route(c0, cout, B, D, H, W):
-                        s3u_bwd_low(dz, cout, w, c0, cin, dzl, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W)
+                        s3u_bwd_low(dz, cout, w, c0, cin, dzl, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W, lay=lay_d)
                     else:
+                        _need_split_kernel(lay_d, "backward-data onto the low-resolution tensor")
                         wpk = torch.empty(_lib.lib().vxm_conv3d_k3_up_bwd_low_packed_elems(c0, cout), dtype=dt, device=dev)
                         with _prof.region("k_conv3d_k3_dlow<%d>" % (1 if c0 <= 16 else 2), flops=2.0 * 8 * c0 * cout * B * V,
                                           nominal=2.0 * 27 * c0 * cout * B * V):
@@ -1039,7 +1129,7 @@ class UnetFn(torch.autograd.Function):
                     DZ[s0] = dzl
                     if s1 is not None:                       # skip segment: regular backward-data of its channels only
                         gxs = torch.empty((B, c1, D, H, W), dtype=dt, device=dev)
-                        conv_bwd_data(dz, cout, w, gxs, c1, None, 1.0, B, D, H, W, w_lo=c0)
+                        conv_bwd_data(dz, cout, w, gxs, c1, None, 1.0, B, D, H, W, w_lo=c0, lay=lay_d)
                         GS[s1] = (gxs, 0, c1 * V)
                         if not any(plan.ops[m]["kind"] == "pool" for m in plan.consumers[s1]):
                             g = GS.pop(s1)
@@ -1048,10 +1138,13 @@ class UnetFn(torch.autograd.Function):
                 gx = torch.empty((B, cin, D, H, W), dtype=dt, device=dev)
                 if fuse:   # dX * LeakyReLU'(y_prev) in the epilogue == DZ of the previous ConvBlock
                     pslope = plan.ops[plan.producer[s0]]["slope"]
-                    conv_bwd_data(dz, cout, w, gx, cin, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W)
+                    conv_bwd_data(dz, cout, w, gx, cin, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W,
+                                  lay=lay_d | (S3_OUT_BLOCKED if x_blk else 0))
                     DZ[s0] = gx
                     continue
-                conv_bwd_data(dz, cout, w, gx, cin, None, 1.0, B, D, H, W)
+                if x_blk:
+                    raise RuntimeError("UnetFn: a channel-blocked activation reached the unfused backward-data path")
+                conv_bwd_data(dz, cout, w, gx, cin, None, 1.0, B, D, H, W, lay=lay_d)
                 if feeds_inputs:
                     for i, sid in enumerate([s0] + ([s1] if s1 is not None else [])):
                         lo = 0 if i == 0 else c0
