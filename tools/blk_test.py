@@ -1,3 +1,5 @@
+"""Developer check + timing of the channel-blocked operand variants of the split kernels against their planar launches (bit-exact);
+BLK_TIME=1 adds timings at 160x192x224.  The same comparisons run as tests in tests/test_gpu_s3.py."""
 import os, sys, torch
 sys.path.insert(0, "/root/repo")
 from voxelmorph_amd.torch import functional as VF
