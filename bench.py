@@ -110,6 +110,23 @@ def cpu_baseline(shape, int_steps, timed_steps, threads, image_loss="ncc", lam=1
     }
 
 
+def _counter_file(pattern):
+    """The committed counter summary to use: among profiles/<pattern> the one collected on THIS tree's kernel sources (its `_meta.csrc_sha`),
+    newest name first; when none matches, the newest, which the callers then refuse as stale with the reason in the line."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=lambda f: (len(os.path.basename(f)), f))
+    if not files:
+        return None
+    for f in reversed(files):
+        try:
+            with open(f) as fh:
+                if (json.load(fh).get("_meta") or {}).get("csrc_sha") == csrc_sha():
+                    return f
+        except (OSError, ValueError):
+            continue
+    return files[-1]
+
+
 def hbm_traffic(kernel, launches_per_step, suffix=""):
     """HBM bytes per launch of the region `kernel` from the committed rocprofv3 PMC summary of this same command
     (profiles/*_hbm_counters.json, written by tools/profile_bench.sh: FETCH_SIZE and WRITE_SIZE in separate --pmc passes,
@@ -124,13 +141,12 @@ def hbm_traffic(kernel, launches_per_step, suffix=""):
     averaged weighted by their dispatch counts.  The file is REFUSED (traffic null, reason in the note) when it does not
     describe this run: no instance of the kernel in it, or a dispatch count that is not launches_per_step x the profiled
     steps recorded in its "_meta" entry.  Returns (bytes_per_launch or None, note)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_counters%s.json" % suffix)))
-    if not files:
+    path = _counter_file("*_hbm_counters%s.json" % suffix)
+    if path is None:
         return None, "no profiles/*_hbm_counters%s.json" % suffix
-    rel = os.path.relpath(files[-1], ROOT)
+    rel = os.path.relpath(path, ROOT)
     try:
-        with open(files[-1]) as f:
+        with open(path) as f:
             ctr = json.load(f)
     except (OSError, ValueError):
         return None, "%s unreadable" % rel
@@ -162,12 +178,11 @@ def fetch_factor(kernel):
 def shader_clock(kernel, suffix=""):
     """Shader clock the kernel ran at under the profiler (GHz): GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same --pmc pass, written
     by tools/rocprof_summary.py into profiles/*_mfma_counters.json (same staleness rule as hbm_traffic: the kernel sources must match)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_mfma_counters%s.json" % suffix)))
-    if not files:
+    path = _counter_file("*_mfma_counters%s.json" % suffix)
+    if path is None:
         return None
     try:
-        with open(files[-1]) as f:
+        with open(path) as f:
             ctr = json.load(f)
     except (OSError, ValueError):
         return None

@@ -887,6 +887,10 @@ def _blocked_tensors(plan, B, shape3):
     DZ[t]) runs on the split kernels too.  In the default VxmDense U-Net: the outputs of remaining[0] and remaining[1]."""
     if not (BLOCKED and split_engine() and s3_pieces() == 2):
         return frozenset()
+    key = (B, tuple(shape3), FP32_ENGINE, S3U, S3_UP, SPLIT_48)          # (the route predicates below depend on these switches)
+    cache = plan.__dict__.setdefault("_blocked_cache", {})
+    if key in cache:
+        return cache[key]
     L = _lib.lib()
     out = set()
 
@@ -927,7 +931,8 @@ def _blocked_tensors(plan, B, shape3):
             if not (plain_ok(c0, C, D, H, W) and L.vxm_conv3d_k3_s3_bwd_weight_ok(c0, C, B, D, H, W) and plain_ok(C, c0, D, H, W)):
                 continue
         out.add(t)
-    return frozenset(out)
+    cache[key] = frozenset(out)
+    return cache[key]
 
 
 class UnetFn(torch.autograd.Function):
