@@ -398,6 +398,51 @@ def test_split_engine_enumerates_its_operators(monkeypatch):
     assert [j for j in train if not j[3]] == fwd
 
 
+def test_channel_blocked_tensor_rule(monkeypatch):
+    """`functional._blocked_tensors`: which activations of the fused U-Net are kept channel-blocked between the split kernels.  With every
+    shape test of the C side answering yes for multiples-of-8 channels at the two finest levels (stand-ins below), the default VxmDense plan
+    yields exactly the outputs of remaining[0] and remaining[1]: the last ConvBlock feeds the flow conv (3 channels: not a split kernel),
+    the first layer's output and the encoder / decoder outputs are read by MaxPool / as skip or upsampled segments.  A U-Net with two
+    convolutions per level also keeps the first output of every encoder / decoder pair -- except the first layer's, whose producer is the
+    few-input-channel kernel -- and VXM_BLOCKED=0 / the other engines keep everything planar."""
+    import types
+    from voxelmorph_amd.torch import functional as VF
+    stub = types.SimpleNamespace(
+        vxm_conv3d_k3_s3_layout_ok=lambda c0, c1, up, cout, H, pieces: int(pieces == 2 and c1 == 0 and not up and c0 % 8 == 0 and cout % 8 == 0 and H >= 8),
+        vxm_conv3d_k3_s3_bwd_weight_ok=lambda c, cout, B, D, H, W: int(c % 16 == 0 and cout % 16 == 0 and D >= 80))
+    monkeypatch.setattr(VF, "_lib", types.SimpleNamespace(lib=lambda: stub))
+    monkeypatch.setattr(VF, "FP32_ENGINE", "f16x2")
+    monkeypatch.setattr(VF, "BLOCKED", True)
+    fine = lambda *a: a[-3] >= 80                      # D of the launch: levels 0 and 1 of a 160x192x224 volume
+    monkeypatch.setattr(VF, "s3_route", lambda c0, up0, c1, cout, B, D, H, W: (not up0) and c0 % 8 == 0 and c1 % 8 == 0 and cout >= 8 and D >= 80)
+    for name in ("s3u_route", "s3u_bwd_low_route", "s3u_bwd_weight_route"):
+        monkeypatch.setattr(VF, name, lambda *a: fine(*a))
+    shape = (160, 192, 224)
+    m = vxm.networks.VxmDense(shape, int_steps=0)
+    plan = m.unet_model.plan(m._feats, extra=((m.flow.out_channels, 1.0),))
+    convs = [op for op in plan.ops if op["kind"] == "conv"]
+    rem0, rem1 = convs[8]["dst"], convs[9]["dst"]        # execution order: 4 encoder, 4 decoder, 3 remaining, flow
+    assert (plan.ch[rem0], plan.ch[rem1], plan.lvl[rem0], plan.lvl[rem1]) == (32, 16, 0, 0)
+    assert VF._blocked_tensors(plan, 1, shape) == frozenset({rem0, rem1})
+    assert VF._blocked_tensors(plan, 4, shape) == frozenset({rem0, rem1})
+    monkeypatch.setattr(VF, "BLOCKED", False)
+    assert VF._blocked_tensors(plan, 1, shape) == frozenset()
+    monkeypatch.setattr(VF, "BLOCKED", True)
+    monkeypatch.setattr(VF, "FP32_ENGINE", "split")
+    assert VF._blocked_tensors(plan, 1, shape) == frozenset()
+    monkeypatch.setattr(VF, "FP32_ENGINE", "f16x2")
+    # two ConvBlocks per level, 16 features everywhere: (first, second) pairs at the two finest levels
+    u = vxm.networks.Unet(shape, infeats=2, nb_features=16, nb_levels=3, nb_conv_per_level=2)
+    plan2 = u.plan([2])
+    got = VF._blocked_tensors(plan2, 1, shape)
+    convs2 = [op for op in plan2.ops if op["kind"] == "conv"]
+    firsts = {convs2[2]["dst"]}                            # encoder level 1, first conv (level 0's first conv is the first layer: excluded)
+    assert firsts <= got and convs2[0]["dst"] not in got
+    for t in got:                                          # every member: one plain conv consumer, multiple-of-16 channels, not the network output
+        assert len(plan2.consumers[t]) == 1 and plan2.ch[t] % 16 == 0 and t != plan2.out
+        assert tuple(plan2.ops[plan2.consumers[t][0]]["src"]) == (t, False, None)
+
+
 def test_bf16_engine_enumerates_the_weight_operators_of_a_step():
     """`functional_bf16._pack_jobs`: what one pass over the default VxmDense plan packs in its single launch — the forward operator of
     each of the 12 convolutions; for a training step also the adjoint per input segment (two for the decoder layers that read
