@@ -9,6 +9,9 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
+from voxelmorph_amd import _lib  # noqa: E402
+if os.environ.get("BLK_LIB"):                       # a developer build (tools/build_exp.sh) instead of libvxm_hip.so
+    _lib.LIB_PATH = os.path.abspath(os.environ["BLK_LIB"])
 from voxelmorph_amd.torch import functional as VF  # noqa: E402
 
 op, layout = sys.argv[1], sys.argv[2]
@@ -37,3 +40,11 @@ else:                                # rem1 backward-weight 32 -> 16 (k_s3_bwd_w
 for _ in range(5):
     fn()
 torch.cuda.synchronize()
+if os.environ.get("BLK_TIME"):
+    s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s_.record()
+    for _ in range(20):
+        fn()
+    e_.record()
+    torch.cuda.synchronize()
+    print("%s %s dbg=%s: %.4f ms" % (op, layout, os.environ.get("VXM_S3_DBG", "0"), s_.elapsed_time(e_) / 20))
