@@ -356,6 +356,7 @@ typedef struct VxmS3PackJob {
     int pieces;                                             /* 3: bf16 (h, m, l); 2: fp16 (h, l) with the operator's power-of-two scale */
 } VxmS3PackJob;
 int vxm_conv3d_k3_s3_pack_weights_batch(const VxmS3PackJob* jobs, int n_jobs, void* stream);
+/* `pieces` may carry VXM_S3_IN0_BLOCKED (x0) and / or VXM_S3_OUT_BLOCKED (y and mask_src) where vxm_conv3d_k3_s3_layout_ok says so. */
 int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
                          const void* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope,
                          const float* mask_src, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, int pieces,
@@ -364,7 +365,8 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
  * same split arithmetic (contraction over voxels, K = 32 voxels of a W row per MFMA): gw[co][ci_off + ci][tap] for ci < C inside a
  * [Cout][gw_cin][3][3][3] array (the channel sub-range a segment of a virtual concat owns), gb[Cout] (nullable).  C, Cout multiples
  * of 16, W even (the staging loads W-neighbouring voxel pairs; an odd W is VXM_ERR_BAD_SHAPE and _ok returns 0).  Deterministic
- * (fixed-order partial sums in `work`).  _ok: 1 when the split kernel takes a launch of this shape. */
+ * (fixed-order partial sums in `work`).  _ok: 1 when the split kernel takes a launch of this shape.  On the fp16 scheme `pieces` may carry
+ * VXM_S3_IN0_BLOCKED (x) and / or VXM_S3_IN1_BLOCKED (dz). */
 int vxm_conv3d_k3_s3_bwd_weight_ok(int C, int Cout, int B, int D, int H, int W);
 size_t vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(int C, int Cout, int B, int D, int H, int W);
 int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw,
@@ -377,7 +379,7 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
  * multiply-adds per input channel) --, the skip segment x1 as the plain 27-tap convolution, both with the split arithmetic selected by
  * `pieces` (see vxm_conv3d_k3_s3_fwd).  x0: [B,C0,D/2,H/2,W/2], x1: [B,C1,D,H,W] (C1 may be 0), y: [B,Cout,D,H,W]; C0, C1 multiples of
  * 8, D, H, W even.  The operator is packed from the reference-layout weights [Cout][C0+C1][3][3][3] by _pack_weights (per `pieces`).
- * _ok: 1 when this kernel takes a launch of this shape. */
+ * _ok: 1 when this kernel takes a launch of this shape.  `pieces` of _fwd may carry VXM_S3_OUT_BLOCKED (y; Cout a multiple of 8). */
 int vxm_conv3d_k3_s3u_ok(int C0, int C1, int Cout, int B, int D, int H, int W, int pieces);
 size_t vxm_conv3d_k3_s3u_packed_bytes(int C0, int C1, int Cout, int pieces);
 int vxm_conv3d_k3_s3u_pack_weights(const float* w, void* wpacked, int C0, int C1, int Cout, int pieces, void* stream);
@@ -389,7 +391,8 @@ int vxm_conv3d_k3_s3u_fwd(const float* x0, int C0, int64_t x0_bstride, const flo
  * conv backward + upsample_nearest3d_backward + leaky_relu_backward(mask_src) in one launch on the split arithmetic (csrc/conv_s3u.hip:
  * a stride-2, 4x4x4-tap convolution of the full-resolution dz [B,Cout,D,H,W] with the transposed collapsed weights; the full-resolution
  * gradient of those channels is never written).  gxl: [B,C0,D/2,H/2,W/2]; w: [Cout][Cin][27] whose first C0 input channels are the
- * upsampled segment.  pieces = 2 only (_ok returns 0 otherwise: callers keep vxm_conv3d_k3_up_bwd_low). */
+ * upsampled segment.  pieces = 2 only (_ok returns 0 otherwise: callers keep vxm_conv3d_k3_up_bwd_low); it may carry VXM_S3_IN0_BLOCKED (dz;
+ * Cout a multiple of 8). */
 int vxm_conv3d_k3_s3u_bwd_low_ok(int C0, int Cout, int B, int D, int H, int W, int pieces);
 size_t vxm_conv3d_k3_s3u_bwd_low_packed_bytes(int C0, int Cout, int pieces);
 int vxm_conv3d_k3_s3u_bwd_low_pack_weights(const float* w, void* wpacked, int C0, int Cin, int Cout, int pieces, void* stream);
@@ -401,7 +404,8 @@ int vxm_conv3d_k3_s3u_bwd_low(const float* dz, int64_t dz_bstride, int Cout, con
  * k_s3u_bww): gw[co][0:C0][tap] inside a [Cout][gw_cin][3][3][3] array from x0 [B,C0,D/2,H/2,W/2] and dz [B,Cout,D,H,W] -- per offset
  * a in {-1,0,1,2}^3 the contraction sum_m dz[2 m + a] x0[m] over the low-resolution voxels, then the taps as sums of offsets.  The
  * caller computes the skip segment's share and the bias gradient (vxm_conv3d_k3_s3_bwd_weight with ci_off = C0).  C0 = 16 or 32, Cout a
- * multiple of 16, D, H even, W a multiple of 4, pieces = 2; deterministic (fixed-order partial sums in `work`). */
+ * multiple of 16, D, H even, W a multiple of 4, pieces = 2 (it may carry VXM_S3_IN1_BLOCKED: dz); deterministic (fixed-order partial sums
+ * in `work`). */
 int vxm_conv3d_k3_s3u_bwd_weight_ok(int C0, int Cout, int B, int D, int H, int W, int pieces);
 size_t vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes(int C0, int Cout, int B, int D, int H, int W);
 int vxm_conv3d_k3_s3u_bwd_weight(const float* x0, int C0, int64_t x0_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw,
