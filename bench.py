@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-extra-configs", action="store_true")                 # only the headline (profiling runs)
     ap.add_argument("--cpu-baseline-steps", type=int, default=2)               # timed CPU steps after one warm-up, at the FULL shape
     ap.add_argument("--cpu-threads", type=int, default=0)                      # 0: min(32, cores), see cpu_baseline()
+    ap.add_argument("--no-gpu-baseline", action="store_true")                  # skip the stock torch-ROCm (MIOpen / ATen) leg on this GPU
+    ap.add_argument("--torch-rocm-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -256,6 +258,86 @@ def csrc_sha():
     return buildinfo.csrc_sha()
 
 
+def torch_rocm_worker(shape, int_steps, timed=2):
+    """Child process of gpu_baseline(): the reference's ATen call sequence (the oracle's restatement of scripts/torch/train.py:194-223 --
+    F.conv3d / max_pool3d / interpolate / grid_sample / the five 9^3 box-filter convs of NCC, torch.optim.Adam over 24 tensors) on cuda:0
+    through STOCK torch-ROCm: MIOpen convolutions, ATen elementwise and grid-sampler kernels.  Nothing of voxelmorph_amd is imported."""
+    import numpy as np
+    from oracle import vxm_oracle as orc
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(1234)
+    src = torch.from_numpy(rng.random((1, 1) + shape).astype(np.float32)).to(dev)
+    trg = torch.from_numpy(rng.random((1, 1) + shape).astype(np.float32)).to(dev)
+    sd = {k: v.to(dev) for k, v in orc.seeded_state_dict(shape, seed=0, flow_std=1e-5).items()}
+    params = [v.requires_grad_() for v in sd.values()]
+    opt = torch.optim.Adam(params, lr=1e-4)
+
+    def step():
+        opt.zero_grad()
+        loss, _ = orc.train_step_loss(src, trg, sd, "ncc", 1.0, int_steps=int_steps, int_downsize=2)
+        loss.backward()
+        opt.step()
+        return loss
+
+    t0 = time.perf_counter()
+    for _ in range(2):                      # warm-up: MIOpen picks its solvers in the first calls
+        step()
+    torch.cuda.synchronize()
+    warm = time.perf_counter() - t0
+    torch.cuda.reset_peak_memory_stats()
+    times = []
+    for _ in range(timed):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
+    print(json.dumps({"value": 1.0 / dt, "unit": "volume-pairs/s", "kind": "torch-rocm", "ms_per_step": 1e3 * dt,
+                      "sample": "2 warm-up (%.1f s) + %d timed training steps of the reference's ATen call sequence on cuda:0, B=1, fp32, %s: %s ms"
+                                % (warm, timed, "x".join(map(str, shape)), ", ".join("%.1f" % (1e3 * t) for t in times)),
+                      "final_loss": float(loss.detach()), "peak_allocated_gb": torch.cuda.max_memory_allocated() / 1e9,
+                      "torch": torch.__version__, "hip": torch.version.hip}))
+
+
+def gpu_baseline(shape, int_steps, timeout_s=240):
+    """SURVEY.md section 8d, second reference point: the reference path on THIS MI355X through stock torch-ROCm, in a child process with a
+    deadline (MIOpen's first-call solver search is not ours to bound).  A reported baseline next to `cpu_baseline`, never `value`."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--torch-rocm-baseline-worker", "--shape", ",".join(map(str, shape)),
+           "--int-steps", str(int_steps)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "torch-rocm baseline did not finish in %d s" % timeout_s, "kind": "torch-rocm"}
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if out.returncode != 0 or not lines:
+        return {"error": "torch-rocm baseline failed (rc %d): %s" % (out.returncode, out.stderr.strip()[-400:]), "kind": "torch-rocm"}
+    return json.loads(lines[-1])
+
+
+def register_extra(vxm, shape, dev, reps=10):
+    """`scripts/torch/register.py:87`: model(moving, fixed, registration=True) under torch.no_grad() -- the inference half of the path:
+    forward only (U-Net, flow head, resize, VecInt, resize, SpatialTransformer), per-pair latency on one GPU, launches from Python."""
+    torch.manual_seed(1234)
+    model = vxm.networks.VxmDense(shape, int_steps=7, int_downsize=2).to(dev)
+    model.eval()
+    src, trg = torch.rand(1, 1, *shape, device=dev), torch.rand(1, 1, *shape, device=dev)
+    with torch.no_grad():
+        for _ in range(3):
+            moved, warp = model(src, trg, registration=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            moved, warp = model(src, trg, registration=True)
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+    return {"value": 1.0 / dt, "unit": "volume-pairs/s", "ms_per_pair": 1e3 * dt, "host_enqueue_ms_per_pair": 1e3 * host / reps, "reps": reps,
+            "dtype": "f32", "workload": "VxmDense 3D %s registration=True forward (register.py:87), int_steps=7, B=1, fp32, torch.no_grad()"
+                                        % "x".join(map(str, shape))}
+
+
 class Workload:
     """One benchmark configuration: model + optimiser + synthetic batch resident in HBM + the training step."""
 
@@ -288,7 +370,10 @@ class Workload:
         self.img = vxm.losses.MSE().loss if self.dense else vxm.losses.NCC().loss
         self.reg = vxm.losses.Grad("l2", loss_mult=2).loss
         from voxelmorph_amd.pacing import InFlight
+        from voxelmorph_amd.graph import GraphedStep
         self.pace = InFlight(2)
+        # the step is submitted as ONE hipGraph launch (voxelmorph_amd/graph.py) after two eager steps; VXM_GRAPH=0: every launch from Python
+        self.graphed = GraphedStep(self._forward_loss, self.opt, eager_steps=2, enabled=os.environ.get("VXM_GRAPH", "1") != "0")
         if self.trained:
             self._make_trained_flow()
 
@@ -311,23 +396,23 @@ class Workload:
                               % (*[float(v) for v in vel.mean(dim=(0, 2, 3, 4))], float((vel - vel.mean(dim=(2, 3, 4), keepdim=True)).std()),
                                  float(disp.abs().max())))
 
-    def step(self):
-        # At most two steps in flight (voxelmorph_amd/pacing.py): the host waits for the end of step k - 2 before it enqueues step k.  The GPU never starves (two
-        # steps are 35 ms of queued work, the host needs 2.5 ms per step), and the caching allocator reaches its steady state within the
-        # warm-up: with an unbounded run-ahead the timed region (K = 20 steps deep) holds more blocks in flight than the warm-up (W = 5)
-        # ever did, and the hipMallocs that follow -- 10-15 ms each -- land inside it (seen once: 19.6 instead of 17.5 ms per step with
-        # `host_enqueue_ms_per_step` = 19.4, the per-kernel pass right after it at 17.7).
-        self.pace.wait()
-        self.opt.zero_grad()
+    def _forward_loss(self):
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):      # bf16: blocked-bf16 activations between the convs
             if self.semi:
                 y, pre, yseg = self.model(self.src, self.trg, self.seg_src)
-                loss = self.img(self.trg, y) + self.lam * self.reg(None, pre) + 0.01 * self.dice(self.seg_trg, yseg)
-            else:
-                y, pre = self.model(self.src, self.trg)
-                loss = self.img(self.trg, y) + self.lam * self.reg(None, pre)
-        loss.backward()
-        self.opt.step()                                            # all-reduce (world>1) + fused Adam
+                return self.img(self.trg, y) + self.lam * self.reg(None, pre) + 0.01 * self.dice(self.seg_trg, yseg)
+            y, pre = self.model(self.src, self.trg)
+            return self.img(self.trg, y) + self.lam * self.reg(None, pre)
+
+    def step(self):
+        # One step = zero_grad + forward + loss + backward + (all-reduce) + Adam, submitted as one hipGraph launch (GraphedStep; eagerly --
+        # launch by launch from Python -- for the first two steps, under the per-kernel timer, and with VXM_GRAPH=0).
+        # At most two steps in flight (voxelmorph_amd/pacing.py): the host waits for the end of step k - 2 before it enqueues step k.  The
+        # GPU never starves, and in eager mode the caching allocator reaches its steady state within the warm-up (with an unbounded
+        # run-ahead the timed region holds more blocks in flight than the warm-up ever did, and hipMallocs of 10-15 ms land inside it).
+        from voxelmorph_amd import profiler
+        self.pace.wait()
+        loss = self.graphed.eager() if profiler.ACTIVE is not None else self.graphed()
         self.pace.mark()
         return loss
 
@@ -358,6 +443,8 @@ def timed_steps(wl, steps, vdist, dev, timer=None):
     vdist.barrier()
     torch.cuda.synchronize()
     wl.pace.wait_s = 0.0
+    ms0 = torch.cuda.memory_stats(dev)
+    replays0 = wl.graphed.replays
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = wl.step()
@@ -368,6 +455,15 @@ def timed_steps(wl, steps, vdist, dev, timer=None):
     elapsed = vdist.max_over_ranks(time.perf_counter() - t0, dev)
     if timer is not None:
         profiler.uninstall()
+    ms1 = torch.cuda.memory_stats(dev)
+    # what the caching allocator did inside the region (hipMalloc / hipFree calls stall the host for 10+ ms each) and how the steps were submitted
+    timed_steps.submission = {
+        "graph_replays": wl.graphed.replays - replays0, "eager_steps": steps - (wl.graphed.replays - replays0),
+        "device_allocs": ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
+        "device_frees": ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0),
+        "alloc_retries": ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0),
+        "allocator_calls": ms1.get("allocation.all.allocated", 0) - ms0.get("allocation.all.allocated", 0),
+        "reserved_gb": ms1.get("reserved_bytes.all.current", 0) / 1e9}
     return elapsed, float(loss.detach())
 
 
@@ -415,9 +511,12 @@ def comm_evidence(opt, dev):
     """What a multi-rank run leaves behind about its exchange (the scaling run is the driver's, not the builder's): which library
     carries the all-reduce, how many ranks its communicator spans, and the median of 20 timed all-reduces of the 1.31 MB bucket."""
     import statistics
-    ev = {"backend": "libvxm_comm" if opt.comm is not None else "torch.distributed(nccl)", "ranks_seen": opt.world,
-          "bucket_bytes": 4 * opt.n}
-    if opt.comm is None and os.environ.get("VXM_COMM", "") != "torch":
+    from voxelmorph_amd.optim import FlatAdam
+    tbackend = torch.distributed.get_backend() if torch.distributed.is_initialized() else "none"
+    ev = {"backend": "libvxm_comm" if opt.comm is not None else "torch.distributed(%s%s)" % (
+              tbackend, ", bucket staged through the host" if tbackend == "gloo" and opt.flat_grad.is_cuda else ""),
+          "ranks_seen": opt.world, "bucket_bytes": 4 * opt.n}
+    if opt.comm is None and tbackend == "nccl" and os.environ.get("VXM_COMM", "") != "torch":
         from voxelmorph_amd import comm as vcomm
         ev["native_error"] = vcomm.NativeComm.last_failure or "native communicator not attempted (backend %s)" % (
             torch.distributed.get_backend() if torch.distributed.is_initialized() else "none")
@@ -431,10 +530,7 @@ def comm_evidence(opt, dev):
     for i in range(25):
         sync()
         t0 = time.perf_counter()
-        if opt.comm is not None:
-            opt.comm.all_reduce_sum(buf)
-        else:
-            torch.distributed.all_reduce(buf, group=opt.group)
+        FlatAdam.all_reduce_sum(opt, buf)          # (unbound: the CPU test passes a stand-in with the same attributes)
         sync()
         if i >= 5:
             times.append((time.perf_counter() - t0) * 1e6)
@@ -459,6 +555,9 @@ def _transport_note():
 
 def main():
     args = parse()
+    if args.torch_rocm_baseline_worker:
+        torch_rocm_worker(tuple(int(v) for v in args.shape.split(",")), 7 if args.int_steps is None else args.int_steps)
+        return
     from voxelmorph_amd import dist as vdist
     # `python bench.py --gpus N` without a torchrun environment: become `python -m torch.distributed.run --nproc-per-node N
     # ... bench.py --gpus N ...` (one rank per GPU, 127.0.0.1 rendezvous); under torchrun this returns at once
@@ -484,10 +583,10 @@ def main():
     shape = tuple(int(s) for s in args.shape.split(","))
     B = args.batch_per_gpu
     # Multi-rank: the libvxm_comm.so communicator carries the exchange.  When it cannot be built (or fails its known-answer self-check)
-    # the run goes on over torch.distributed's RCCL -- reported on stderr by rank 0 and in `comm.backend` / `comm.native_error` of the
-    # line, so a scaling run leaves numbers AND says which exchange they were measured on; VXM_COMM=rccl makes that a hard error on
-    # every rank instead, VXM_COMM=torch skips the native communicator.
-    comm = vdist.native_comm(required=world > 1 and os.environ.get("VXM_COMM", "") == "rccl")
+    # every rank raises (they agree on the decision): a scaling run never silently measures another exchange than the one it reports.
+    # VXM_COMM=torch asks for torch.distributed's RCCL instead (reported in `comm.backend`); a job whose torch.distributed backend is not
+    # 'nccl' (VXM_DIST_BACKEND=gloo: ranks sharing one device in the 1-GPU tests) has no native communicator to build.
+    comm = vdist.native_comm(required=world > 1 and os.environ.get("VXM_COMM", "") != "torch")
     wl = Workload(vxm, vdist, args.config, shape, B, dev, rank, args.int_steps, comm)
     args.int_steps = wl.int_steps
     bf16, dense = wl.bf16, wl.dense
@@ -505,6 +604,7 @@ def main():
     keep = VF.OVERLAP_MIN_LEVEL
     elapsed, final_loss = timed_steps(wl, args.steps, vdist, dev)
     host_ms = timed_steps.host_enqueue_s / args.steps * 1e3
+    submission = timed_steps.submission
     # pass 2 -- per-kernel table and `roofline`: every C-ABI launch bracketed by HIP events on the launch stream, the full-resolution
     # launches serialised (one kernel on the chip at a time, so that a launch's duration is its own)
     if "VXM_OVERLAP_MIN_LEVEL" not in os.environ:
@@ -542,6 +642,7 @@ def main():
                 timed_steps(w2, esteps, vdist, dev)
                 t2, l2 = timed_steps(w2, esteps, vdist, dev)
                 host2 = 1e3 * timed_steps.host_enqueue_s / esteps
+                sub2 = timed_steps.submission
                 if "VXM_OVERLAP_MIN_LEVEL" not in os.environ:
                     VF.OVERLAP_MIN_LEVEL = 1                 # per-kernel pass: serialised, as the headline's
                 tm = profiler.KernelTimer()
@@ -550,7 +651,7 @@ def main():
                 d2 = max(st2, key=lambda k: st2[k]["ms"])
                 extra[key] = {"value": eb * esteps / t2, "unit": "volume-pairs/s", "ms_per_step": 1e3 * t2 / esteps, "steps": esteps,
                               "dtype": "bf16" if w2.bf16 else "f32", "workload": w2.describe(), "final_loss": l2,
-                              "host_enqueue_ms_per_step": host2, "roofline": binding_roofline(d2, st2[d2])}
+                              "host_enqueue_ms_per_step": host2, "submission": sub2, "roofline": binding_roofline(d2, st2[d2])}
                 if w2.trained:                             # the HBM-bound kernels in the regime they are in after training, with their own table
                     kt = kernel_table(st2, 2, shape, eb)
                     hb = {k: v for k, v in kt.items() if k.startswith(("warp3d", "vecint", "resize3d", "ncc", "gradloss"))}
@@ -568,6 +669,12 @@ def main():
             finally:
                 VF.FP32_ENGINE = engine
                 VF.OVERLAP_MIN_LEVEL = keep
+
+        try:
+            extra["register_fp32"] = register_extra(vxm, shape, dev)
+        except Exception as exc:
+            extra["register_fp32"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        torch.cuda.empty_cache()
 
     if rank != 0:
         return
@@ -596,12 +703,18 @@ def main():
         "spatial_transformer_plus_vecint": {"algorithmic_bytes_per_step": st_bytes / ksteps, "ms_per_step": st_ms / ksteps,
                                             "gbs": st_bytes / (st_ms * 1e-3) / 1e9 if st_ms else 0.0,
                                             "frac_of_hbm_peak": (st_bytes / (st_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if st_ms else 0.0},
-        "host_enqueue_ms_per_step": host_ms,        # rank 0's Python + launch time per step of the value pass (two steps in flight; the rest it waits)
+        "host_enqueue_ms_per_step": host_ms,        # rank 0's host time per step of the value pass (hipGraphLaunch, or Python + launches when eager), without the pacing wait
+        "submission": submission,                   # value pass: graph replays vs eager steps, caching-allocator activity inside the timed region
     }
     if comm_ev is not None:
         out["comm"] = comm_ev
     if extra:
         out["extra_configs"] = extra
+    if world == 1 and not args.no_gpu_baseline and args.config == "diffeo_fp32":
+        torch.cuda.empty_cache()
+        out["gpu_baseline"] = gpu_baseline(shape, args.int_steps)
+        if "value" in out["gpu_baseline"]:
+            out["gpu_baseline"]["speedup_of_value"] = out["value"] / out["gpu_baseline"]["value"]
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(shape, args.int_steps, args.cpu_baseline_steps, args.cpu_threads,
                                            "mse" if dense else "ncc", 0.01 if dense else 1.0)

@@ -261,6 +261,13 @@ int vxm_gradloss2d_bwd(const float* y, const float* gloss, float* gy, int B, int
  * also the RCCL all-reduce bucket).  g is pre-multiplied by gscale (1/world_size). */
 int vxm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, int step, float gscale, void* stream);
+/* The same update with the step counter in DEVICE memory (torch.optim.Adam(capturable=True)): `state` points at VXM_ADAM_STATE_BYTES
+ * zero-initialised, 8-byte aligned bytes {int64 step; float lr / (1 - beta1^step); float sqrt(1 - beta2^step)}; the call advances the
+ * counter by one on the stream and applies the update with the new value.  No argument changes from step to step, so the launch pair
+ * can be replayed from a hipGraph (voxelmorph_amd/graph.py). */
+#define VXM_ADAM_STATE_BYTES 16
+int vxm_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                      float beta2, float eps, void* state, float gscale, void* stream);
 
 /* ---- bf16 activations / fp32 accumulate path of the U-Net (BASELINE.json configs[1]); csrc/conv_bf16.hip.
  * What torch.autocast(bfloat16) over ConvBlock / flow conv / MaxPool3d / Upsample + cat (networks.py:83-85,130,137-138,211,257,

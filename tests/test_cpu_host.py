@@ -316,6 +316,17 @@ assert got is None, got
 # engages on the nccl backend, so the rule is checked on its decision function
 os.environ["VXM_COMM"] = ""
 assert vdist.native_comm(required=True) is None          # gloo: not a HIP job, nothing required
+real_backend = dist.get_backend
+dist.get_backend = lambda *a, **k: "nccl"                # a HIP job whose communicator cannot be built (the library is gone on rank 1, see (2))
+try:
+    assert vdist.native_comm(required=False) is None
+    try:
+        vdist.native_comm(required=True)
+        raise SystemExit("native_comm(required=True) returned without its communicator")
+    except RuntimeError as exc:
+        assert "VXM_COMM=torch" in str(exc)
+finally:
+    dist.get_backend = real_backend
 dist.barrier()
 print("ok")
 """

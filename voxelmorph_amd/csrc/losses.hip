@@ -626,6 +626,33 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     p[i] = p[i] - step_size * (mi / denom);
 }
 
+// Capturable variant (vxm_adam_step_dev): the step counter and the two bias-correction factors live in DEVICE memory, so a hipGraph that
+// contains the optimiser step replays correctly (a kernel argument would freeze `step` at its capture-time value).  k_adam_tick advances
+// the counter and publishes the factors with the arithmetic of vxm_adam_step (double precision, then rounded to float); k_adam_dev is
+// k_adam reading them.
+struct AdamDevState { long long step; float step_size; float bc2_sqrt; };
+
+__global__ void k_adam_tick(AdamDevState* st, float lr, float beta1, float beta2) {
+    const long long t = st->step + 1;
+    const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+    st->step = t;
+    st->step_size = (float)((double)lr / bc1);
+    st->bc2_sqrt = (float)sqrt(bc2);
+}
+
+__global__ void __launch_bounds__(256) k_adam_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                  long long n, const AdamDevState* __restrict__ st, float beta1, float beta2, float eps, float gscale) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float step_size = st->step_size, bc2_sqrt = st->bc2_sqrt;
+    const float gi = g[i] * gscale;
+    const float mi = m[i] + (1.0f - beta1) * (gi - m[i]);
+    const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+}
+
 // grid of a reduction kernel: every block ends in fp64 atomics on a handful of addresses, which the L2 serialises
 // (8192 blocks x 3 atomics on 3 addresses cost 0.3 ms for a 10 MB field): few, fat blocks.
 unsigned reduce_blocks(long long n) {
@@ -923,6 +950,16 @@ int vxm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
     hipLaunchKernelGGL(k_adam, dim3(vxm_blocks(n, 256)), dim3(256), 0, VXM_STREAM(stream), p, g, m, v, (long long)n, (float)(lr / bc1), beta1,
                        beta2, eps, (float)sqrt(bc2), gscale);
     return vxm_check_launch("vxm_adam_step");
+}
+
+int vxm_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, void* state,
+                      float gscale, void* stream) {
+    VXM_REQUIRE(p && g && m && v && state, VXM_ERR_NULL_POINTER, "vxm_adam_step_dev: null pointer");
+    VXM_REQUIRE(n > 0 && (reinterpret_cast<uintptr_t>(state) & 7) == 0, VXM_ERR_BAD_SHAPE, "vxm_adam_step_dev: n=%lld / state alignment", (long long)n);
+    AdamDevState* st = static_cast<AdamDevState*>(state);
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, VXM_STREAM(stream), st, lr, beta1, beta2);
+    hipLaunchKernelGGL(k_adam_dev, dim3(vxm_blocks(n, 256)), dim3(256), 0, VXM_STREAM(stream), p, g, m, v, (long long)n, st, beta1, beta2, eps, gscale);
+    return vxm_check_launch("vxm_adam_step_dev");
 }
 
 }  // extern "C"

@@ -19,11 +19,15 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VXM_SHARE_DEVICE", "") == "1" and torch.cuda.is_available():
+        # several ranks on the devices this box has (the multi-rank path exercised on a 1-GPU box: tests/test_gpu_graph.py); RCCL refuses two
+        # ranks on one device, so such a job names its transport itself (VXM_DIST_BACKEND=gloo: the bucket is staged through the host)
+        local = local % torch.cuda.device_count()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("VXM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -66,7 +70,7 @@ def max_over_ranks(value, device):
     """MAX-reduce a python float over ranks (bench timing contract)."""
     if not (dist.is_available() and dist.is_initialized()):
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

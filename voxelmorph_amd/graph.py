@@ -1,0 +1,78 @@
+"""One training step as ONE hipGraph launch.
+
+The eager step of this package is ~250 C-ABI launches driven from Python (autograd nodes, ctypes calls, caching-allocator traffic):
+2.5 - 6 ms of host time per step on the bench hosts, and -- at 4 pairs per GPU -- hipMalloc / hipFree calls of the caching allocator
+that stall the host for tens of milliseconds when its block reuse pattern slips.  Every launch of the step has
+arguments that do not change from step to step (static shapes, the weights and the optimiser state updated in place, the Adam step
+counter in device memory: `FlatAdam(capturable=True)`), so the whole step -- zero_grad, forward, losses, backward on both streams,
+weight re-packing, Adam -- is captured once into a hipGraph and replayed with one `hipGraphLaunch` per step: no Python per launch, no
+allocator call, memory of the step fixed at capture (a private pool of the caching allocator).
+
+    step = GraphedStep(lambda: loss_fn(model(src, trg)), opt)        # fn: forward + loss, returns the loss (or a tuple starting with it)
+    for batch in loader:
+        src.copy_(batch.src); trg.copy_(batch.trg)                   # inputs are STATIC tensors: refill them in place
+        loss = step()                                                # eager for the first `eager_steps` calls, then capture + replay
+
+Every call performs exactly one optimiser step, whichever way it is submitted.  Multi-rank (`opt.world > 1`): the graph holds
+zero_grad + forward + backward; the all-reduce of the flat bucket and the Adam launch follow it eagerly (two calls), so the collective
+keeps its own stream semantics.  Reference: the loop body of scripts/torch/train.py:194-223.
+"""
+import torch
+
+
+class GraphedStep:
+    def __init__(self, fn, opt, eager_steps=2, enabled=True):
+        self.fn, self.opt = fn, opt
+        self.eager_steps = max(1, int(eager_steps))      # at least one eager step: lazy one-off work (hipFuncSetAttribute, plans) must not be captured
+        self.enabled = bool(enabled)
+        self.calls = 0
+        self.graph = None
+        self.out = None
+        self.replays = 0
+
+    # the step, eagerly (also what is captured)
+    def _body(self, with_update):
+        self.opt.zero_grad()
+        out = self.fn()
+        loss = out[0] if isinstance(out, (tuple, list)) else out
+        loss.backward()
+        if with_update:
+            self.opt.step()
+        return out
+
+    def eager(self):
+        self.calls += 1
+        return self._body(True)
+
+    def _capture(self):
+        from .torch.functional_bf16 import invalidate_packs
+        if not getattr(self.opt, "capturable", False):
+            raise RuntimeError("GraphedStep: the optimiser's step counter must live on the device (FlatAdam(capturable=True))")
+        # the packed operators must be rebuilt INSIDE the graph on every replay (the weights change under it): make every cached copy stale
+        invalidate_packs(self.opt.params)
+        self.single = self.opt.world == 1
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._body(self.single)
+        self.graph, self.out = g, out
+        if self.single:
+            self.opt._stale = True
+
+    def __call__(self):
+        if not self.enabled or self.calls < self.eager_steps:
+            return self.eager()
+        if self.graph is None:
+            self._capture()
+        self.calls += 1
+        self.replays += 1
+        self.graph.replay()
+        if self.single:
+            # Adam ran inside the graph: the parameters changed behind autograd's back
+            torch.autograd.graph.increment_version(tuple(self.opt.params))
+        else:
+            self.opt._stale = False
+            for p in self.opt.params:          # the bucket was written by the graph: a second eager backward must not overwrite it
+                p._vxm_sink_written = True
+            self.opt.step()
+        return self.out

@@ -12,7 +12,7 @@ from ._lib import call, ptr, require_device, stream
 
 
 class FlatAdam:
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, direct_grads=True, comm=None):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, process_group=None, direct_grads=True, comm=None, capturable=True):
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("FlatAdam: model has no trainable parameters")
@@ -23,7 +23,11 @@ class FlatAdam:
         self.exp_avg = torch.zeros_like(self.flat_grad)
         self.exp_avg_sq = torch.zeros_like(self.flat_grad)
         self.lr, self.betas, self.eps = lr, betas, eps
-        self.step_count = 0
+        # capturable (torch.optim.Adam's flag of the same name): the step counter and the bias-correction factors live in device memory
+        # (vxm_adam_step_dev), so the update can sit inside a replayed hipGraph (voxelmorph_amd/graph.py); False keeps them on the host
+        self.capturable = bool(capturable) and self.flat_param.is_cuda
+        self._host_steps = 0
+        self.dev_state = torch.zeros(2, dtype=torch.int64, device=dev) if self.capturable else None     # VXM_ADAM_STATE_BYTES
         self.group = process_group
         self.world = 1
         self.comm = comm                       # voxelmorph_amd.comm.NativeComm: direct RCCL calls instead of torch.distributed
@@ -45,13 +49,31 @@ class FlatAdam:
             off += n
         self.direct = direct_grads
 
+    @property
+    def step_count(self):
+        """optimiser steps taken so far (capturable: read back from the device counter, a synchronising copy -- not for the hot loop)"""
+        return int(self.dev_state[0].item()) if self.capturable else self._host_steps
+
+    @step_count.setter
+    def step_count(self, k):
+        if self.capturable:
+            self.dev_state.zero_()
+            self.dev_state[0] = int(k)
+        else:
+            self._host_steps = int(k)
+
     def broadcast_params(self, src=0):
         """One-off: make every rank start from rank `src`'s weights (replaces DataParallel's per-step
         broadcast_coalesced)."""
         if self.comm is not None:
             self.comm.broadcast(self.flat_param, src)
         elif self.world > 1:
-            torch.distributed.broadcast(self.flat_param, src, group=self.group)
+            if self.flat_param.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
+                host = self.flat_param.cpu()
+                torch.distributed.broadcast(host, src, group=self.group)
+                self.flat_param.copy_(host)
+            else:
+                torch.distributed.broadcast(self.flat_param, src, group=self.group)
         self._params_rewritten()
 
     def _params_rewritten(self):
@@ -78,13 +100,24 @@ class FlatAdam:
                 g.add_(p.grad)
                 p.grad = None
 
+    def all_reduce_sum(self, t):
+        """SUM all-reduce of `t` in place over the job's ranks through the exchange this optimiser was built on: the libvxm_comm.so RCCL
+        communicator, torch.distributed's RCCL ('nccl'), or -- ranks that share one device in the 1-GPU tests, CPU tensors in the CPU tests --
+        gloo (device tensors staged through the host: gloo is a rendezvous-only backend here)."""
+        if self.comm is not None:
+            self.comm.all_reduce_sum(t)
+        elif self.world > 1:
+            if t.is_cuda and torch.distributed.get_backend(self.group) == "gloo":
+                host = t.cpu()
+                torch.distributed.all_reduce(host, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                t.copy_(host)
+            else:
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=self.group)
+
     def reduce_grads(self):
         """The only data-path collective: SUM all-reduce of the flat gradient bucket (RCCL over xGMI when
         the backend is 'nccl'; gloo in the CPU tests).  The 1/world average is applied by the Adam kernel."""
-        if self.comm is not None:
-            self.comm.all_reduce_sum(self.flat_grad)
-        elif self.world > 1:
-            torch.distributed.all_reduce(self.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        self.all_reduce_sum(self.flat_grad)
 
     def step(self):
         if getattr(self, "_stale", False):
@@ -96,10 +129,14 @@ class FlatAdam:
         self.load_grads_from_params()
         self.reduce_grads()
         require_device(self.flat_param)            # the update itself is a HIP kernel: no CPU fallback
-        self.step_count += 1
-        call("vxm_adam_step", ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
-             float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count,
-             1.0 / self.world, stream())
+        if self.capturable:
+            call("vxm_adam_step_dev", ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
+                 float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), ptr(self.dev_state), 1.0 / self.world, stream())
+        else:
+            self._host_steps += 1
+            call("vxm_adam_step", ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.n,
+                 float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self._host_steps,
+                 1.0 / self.world, stream())
         # the kernel wrote the parameters behind autograd's back: bump their version counters so that a backward pass over
         # a graph recorded BEFORE this step fails loudly (UnetFn checks them) instead of using the new weights
         torch.autograd.graph.increment_version(tuple(self.params))
