@@ -601,18 +601,20 @@ def main():
     gc.freeze()
     # pass 1 -- `value`: the K timed steps and nothing else (no event bracketing; library defaults: the weight-gradient launches share the
     # chip with the backward-data chain on the second stream)
-    keep = VF.OVERLAP_MIN_LEVEL
     elapsed, final_loss = timed_steps(wl, args.steps, vdist, dev)
     host_ms = timed_steps.host_enqueue_s / args.steps * 1e3
     submission = timed_steps.submission
     # pass 2 -- per-kernel table and `roofline`: every C-ABI launch bracketed by HIP events on the launch stream, the full-resolution
     # launches serialised (one kernel on the chip at a time, so that a launch's duration is its own)
-    if "VXM_OVERLAP_MIN_LEVEL" not in os.environ:
-        VF.OVERLAP_MIN_LEVEL = 1
+    # every launch on ONE stream (the weight-gradient launches of the coarse levels too: a launch that shares the chip with the other stream's
+    # kernels would be timed longer than rocprofv3's serial pass times it -- VERDICT round 4: 455 vs 387 us on the dominant kernel)
+    keep_overlap = VF.OVERLAP_SMALL_LEVELS
+    VF.OVERLAP_SMALL_LEVELS = False
+    wl.graphed.eager()                       # the capture emptied the caching allocator's pool: one eager step outside the pass re-populates it
     timer = profiler.KernelTimer()
     ksteps = min(args.steps, 10)
     elapsed_k, _ = timed_steps(wl, ksteps, vdist, dev, timer)
-    VF.OVERLAP_MIN_LEVEL = keep
+    VF.OVERLAP_SMALL_LEVELS = keep_overlap
     stats = timer.resolve()
     comm_ev = comm_evidence(wl.opt, dev) if world > 1 else None
 
@@ -643,10 +645,11 @@ def main():
                 t2, l2 = timed_steps(w2, esteps, vdist, dev)
                 host2 = 1e3 * timed_steps.host_enqueue_s / esteps
                 sub2 = timed_steps.submission
-                if "VXM_OVERLAP_MIN_LEVEL" not in os.environ:
-                    VF.OVERLAP_MIN_LEVEL = 1                 # per-kernel pass: serialised, as the headline's
+                VF.OVERLAP_SMALL_LEVELS = False            # per-kernel pass: one stream, as the headline's
+                w2.graphed.eager()
                 tm = profiler.KernelTimer()
                 timed_steps(w2, 2, vdist, dev, tm)
+                VF.OVERLAP_SMALL_LEVELS = keep_overlap
                 st2 = tm.resolve()
                 d2 = max(st2, key=lambda k: st2[k]["ms"])
                 extra[key] = {"value": eb * esteps / t2, "unit": "volume-pairs/s", "ms_per_step": 1e3 * t2 / esteps, "steps": esteps,
@@ -668,7 +671,7 @@ def main():
                 extra[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             finally:
                 VF.FP32_ENGINE = engine
-                VF.OVERLAP_MIN_LEVEL = keep
+                VF.OVERLAP_SMALL_LEVELS = keep_overlap
 
         try:
             extra["register_fp32"] = register_extra(vxm, shape, dev)

@@ -178,7 +178,9 @@ def test_two_rank_step_on_the_shared_device_equals_one_process_on_the_concatenat
     for graphed in (0, 1):
         assert res["ranks_equal_%d" % graphed]
         assert res["first_grad_rel_%d" % graphed] < 1e-5
-        assert res["weights_vs_one_process_%d" % graphed] < 2e-6         # 4 Adam steps of 1e-3: a sign flip of a ~0 gradient would show as 1e-3
+        # 4 Adam steps of 1e-3: the update m / sqrt(v) of a parameter whose gradient is ~0 amplifies the 5e-8 summation-order difference of
+        # the gradients (measured 2.1e-5 = 2 % of one step); a wrong average (sum instead of mean, a missing rank) would show as ~1e-3
+        assert res["weights_vs_one_process_%d" % graphed] < 1e-4
     assert res["replays_0"] == 0 and res["replays_1"] == 3
 
 
