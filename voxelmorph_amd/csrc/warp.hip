@@ -385,17 +385,10 @@ __device__ __forceinline__ void vecint_far_voxel(const float* __restrict__ in, f
         atomicAdd(gi + 2 * (size_t)V + i, g2 * wk);
     }
 }
-// Far senders whose displacement exceeds what the tile pass below covers (> VF_RMAX voxels per step: not a registration field any more):
-// the atomic scatter, kept for completeness (order-dependent sums).  A small persistent grid that exits at once otherwise.
+// Far senders whose displacement exceeds what the tile pass below covers (> VF_RMAX voxels per step: not a registration field any more)
+// keep the atomic scatter (order-dependent sums); it runs inside the same launch as the tile pass (k_vecint_step_bwd_far_tiles), one
+// thread per voxel of the block's tile.
 constexpr int VF_RMAX = 24;
-__global__ void __launch_bounds__(256) k_vecint_step_bwd_far(const float* __restrict__ in, float scale, const float* __restrict__ gout,
-                                                             float* __restrict__ gin, const unsigned* __restrict__ far_count, int B, int D, int H, int W) {
-    if (far_count[0] == 0 || __uint_as_float(far_count[1]) < (float)VF_RMAX) return;
-    const int HWf = H * W, V = D * HWf;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < (long long)B * V; idx += (long long)gridDim.x * 256)
-        vecint_far_voxel(in, scale, gout, gin, (int)(idx / V), (int)(idx % V), D, H, W);
-}
-
 // The scatter of the far senders, DETERMINISTIC (round 4; rounds 1-3 added them to gin with global float atomics, whose order -- and
 // with it the sum -- changes from run to run).  One block per 4 x 8 x 32 OUTPUT tile walks the tile grown by R = the step's largest
 // displacement (known on the device: far_count[1]), recomputes the near test of every candidate sender, and adds the corner
@@ -404,76 +397,92 @@ __global__ void __launch_bounds__(256) k_vecint_step_bwd_far(const float* __rest
 // (far_count[2]): 2^46 <= max |g| 2^k < 2^47, i.e. 46 significant bits below the largest contribution and 16 bits of headroom above.
 // Every output voxel is then read-modify-written by exactly one thread.  Cost ~ (grown tile / tile) x the forward step's arithmetic.
 __global__ void __launch_bounds__(1024) k_vecint_step_bwd_far_tiles(const float* __restrict__ in, float scale, const float* __restrict__ gout,
-                                                                    float* __restrict__ gin, const unsigned* __restrict__ far_count, int D, int H, int W) {
-    if (far_count[0] == 0) return;                                // block-uniform: the regime of small steps
+                                                                    float* __restrict__ gin, const unsigned* __restrict__ far_count, int B, int D, int H, int W) {
+    if (far_count[0] == 0) return;                                // block-uniform: the regime of small steps (the launch is a small persistent grid)
     const float dm = __uint_as_float(far_count[1]);
-    if (!(dm < (float)VF_RMAX)) return;                           // left to k_vecint_step_bwd_far
     __shared__ unsigned long long acc[3][VG_TD * VG_TH * VG_TW];
+    __shared__ int poison;                                        // a far sender of this tile carried a non-finite gradient: its targets become NaN
     const int tid = threadIdx.x;
-    const int R = (int)dm + 1;                                    // corners of a sender lie within ceil(displacement) of it
+    const int tx = tid & 31, ty = (tid >> 5) & 7, dd = tid >> 8;
     int Eg = (int)(far_count[2] >> 23) & 255;
     Eg = Eg < 1 ? 1 : Eg;                                         // fixed point: value * 2^(173 - Eg)
-    const int ntw = (W + VG_TW - 1) / VG_TW, nth = (H + VG_TH - 1) / VG_TH;
-    int t = blockIdx.x;
-    const int w0 = (t % ntw) * VG_TW; t /= ntw;
-    const int h0 = (t % nth) * VG_TH;
-    const int d0 = (t / nth) * VG_TD;
-    const int b = blockIdx.y;
-    const int HW = H * W, V = D * HW;
-    const __amdgpu_buffer_rsrc_t rv = vxm_rsrc(in + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
-    const __amdgpu_buffer_rsrc_t rgo = vxm_rsrc(gout + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
-    const int V4 = V << 2;
-    acc[0][tid] = 0ull; acc[1][tid] = 0ull; acc[2][tid] = 0ull;
-    __syncthreads();
-    const int gy = VG_TH + 2 * R, gx = VG_TW + 2 * R, ng = (VG_TD + 2 * R) * gy * gx;
-    for (int i = tid; i < ng; i += 1024) {
-        const int lz = i / (gy * gx), r2 = i - lz * gy * gx, ly = r2 / gx, lx = r2 - ly * gx;
-        const int pz = d0 - R + lz, py = h0 - R + ly, px = w0 - R + lx;
-        if ((unsigned)pz >= (unsigned)D || (unsigned)py >= (unsigned)H || (unsigned)px >= (unsigned)W) continue;
-        const int p4 = (pz * HW + py * W + px) << 2;
-        const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
-        const float xz = vxm_src_coord(pz, v0, D), xy = vxm_src_coord(py, v1, H), xx = vxm_src_coord(px, v2, W);
-        float fr;
-        int rr;
-        bool nz, ny, nx;
-        vg_axis(xz, pz, D, fr, rr, nz); vg_axis(xy, py, H, fr, rr, ny); vg_axis(xx, px, W, fr, rr, nx);
-        if (nz && ny && nx) continue;                             // a near sender: the gather has it
-        const AxisTaps az = axis_corners(xz, D), ay = axis_corners(xy, H), ax = axis_corners(xx, W);
-        const int iz[2] = {az.i0, az.i1}, iy[2] = {ay.i0, ay.i1}, ix[2] = {ax.i0, ax.i1};
-        const float wz[2] = {az.w0, az.w1}, wy[2] = {ay.w0, ay.w1}, wx[2] = {ax.w0, ax.w1};
-        const bool oz[2] = {az.ok0 && (unsigned)(az.i0 - d0) < (unsigned)VG_TD, az.ok1 && (unsigned)(az.i1 - d0) < (unsigned)VG_TD};
-        const bool oy[2] = {ay.ok0 && (unsigned)(ay.i0 - h0) < (unsigned)VG_TH, ay.ok1 && (unsigned)(ay.i1 - h0) < (unsigned)VG_TH};
-        const bool ox[2] = {ax.ok0 && (unsigned)(ax.i0 - w0) < (unsigned)VG_TW, ax.ok1 && (unsigned)(ax.i1 - w0) < (unsigned)VG_TW};
-        if (!((oz[0] || oz[1]) && (oy[0] || oy[1]) && (ox[0] || ox[1]))) continue;
-        const float g[3] = {vxm_bload(rgo, p4, 0), vxm_bload(rgo, p4, V4), vxm_bload(rgo, p4, 2 * V4)};
+    const bool finite_g = Eg < 255;                               // the step's largest |g| is finite (NaN never wins the maxima: checked per contribution below)
+    const int ntw = (W + VG_TW - 1) / VG_TW, nth = (H + VG_TH - 1) / VG_TH, ntd = (D + VG_TD - 1) / VG_TD;
+    const int HW = H * W, V = D * HW, V4 = V << 2;
+    const int ntile = ntw * nth * ntd;
+    const bool atomic_pass = !(dm < (float)VF_RMAX) || !finite_g;  // beyond the tile pass (or an Inf among the gradients): the atomic scatter, which propagates NaN / Inf
+    for (int job = blockIdx.x; job < ntile * B; job += gridDim.x) {
+        const int b = job / ntile;
+        int t = job - b * ntile;
+        const int w0 = (t % ntw) * VG_TW; t /= ntw;
+        const int h0 = (t % nth) * VG_TH;
+        const int d0 = (t / nth) * VG_TD;
+        if (atomic_pass) {
+            const int h = h0 + ty, w = w0 + tx, d = d0 + dd;
+            if (h < H && w < W && d < D) vecint_far_voxel(in, scale, gout, gin, b, d * HW + h * W + w, D, H, W);
+            continue;
+        }
+        const int R = (int)dm + 1;                                // corners of a sender lie within ceil(displacement) of it
+        const __amdgpu_buffer_rsrc_t rv = vxm_rsrc(in + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
+        const __amdgpu_buffer_rsrc_t rgo = vxm_rsrc(gout + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
+        __syncthreads();                                          // the previous tile of this block is written back
+        acc[0][tid] = 0ull; acc[1][tid] = 0ull; acc[2][tid] = 0ull;
+        if (tid == 0) poison = 0;
+        __syncthreads();
+        const int gy = VG_TH + 2 * R, gx = VG_TW + 2 * R, ng = (VG_TD + 2 * R) * gy * gx;
+        for (int i = tid; i < ng; i += 1024) {
+            const int lz = i / (gy * gx), r2 = i - lz * gy * gx, ly = r2 / gx, lx = r2 - ly * gx;
+            const int pz = d0 - R + lz, py = h0 - R + ly, px = w0 - R + lx;
+            if ((unsigned)pz >= (unsigned)D || (unsigned)py >= (unsigned)H || (unsigned)px >= (unsigned)W) continue;
+            const int p4 = (pz * HW + py * W + px) << 2;
+            const float v0 = vxm_bload(rv, p4, 0) * scale, v1 = vxm_bload(rv, p4, V4) * scale, v2 = vxm_bload(rv, p4, 2 * V4) * scale;
+            const float xz = vxm_src_coord(pz, v0, D), xy = vxm_src_coord(py, v1, H), xx = vxm_src_coord(px, v2, W);
+            float fr;
+            int rr;
+            bool nz, ny, nx;
+            vg_axis(xz, pz, D, fr, rr, nz); vg_axis(xy, py, H, fr, rr, ny); vg_axis(xx, px, W, fr, rr, nx);
+            if (nz && ny && nx) continue;                             // a near sender: the gather has it
+            const AxisTaps az = axis_corners(xz, D), ay = axis_corners(xy, H), ax = axis_corners(xx, W);
+            const int iz[2] = {az.i0, az.i1}, iy[2] = {ay.i0, ay.i1}, ix[2] = {ax.i0, ax.i1};
+            const float wz[2] = {az.w0, az.w1}, wy[2] = {ay.w0, ay.w1}, wx[2] = {ax.w0, ax.w1};
+            const bool oz[2] = {az.ok0 && (unsigned)(az.i0 - d0) < (unsigned)VG_TD, az.ok1 && (unsigned)(az.i1 - d0) < (unsigned)VG_TD};
+            const bool oy[2] = {ay.ok0 && (unsigned)(ay.i0 - h0) < (unsigned)VG_TH, ay.ok1 && (unsigned)(ay.i1 - h0) < (unsigned)VG_TH};
+            const bool ox[2] = {ax.ok0 && (unsigned)(ax.i0 - w0) < (unsigned)VG_TW, ax.ok1 && (unsigned)(ax.i1 - w0) < (unsigned)VG_TW};
+            if (!((oz[0] || oz[1]) && (oy[0] || oy[1]) && (ox[0] || ox[1]))) continue;
+            const float g[3] = {vxm_bload(rgo, p4, 0), vxm_bload(rgo, p4, V4), vxm_bload(rgo, p4, 2 * V4)};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
-            if (!(oz[dz] && oy[dy] && ox[dx])) continue;
-            const int li = ((iz[dz] - d0) * VG_TH + (iy[dy] - h0)) * VG_TW + (ix[dx] - w0);
-            const float wk = (wz[dz] * wy[dy]) * wx[dx];           // the forward's weight of this corner
+            for (int k = 0; k < 8; ++k) {
+                const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
+                if (!(oz[dz] && oy[dy] && ox[dx])) continue;
+                const int li = ((iz[dz] - d0) * VG_TH + (iy[dy] - h0)) * VG_TW + (ix[dx] - w0);
+                const float wk = (wz[dz] * wy[dy]) * wx[dx];           // the forward's weight of this corner
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const unsigned u = __float_as_uint(g[c] * wk);
-                const int ev = (int)(u >> 23) & 255, sh = ev - Eg + 23;     // <= 24: |g wk| <= the step's largest |g| (+ one rounding)
-                if (ev == 0 || sh <= -24) continue;
-                const unsigned long long m = (unsigned long long)((u & 0x7fffffu) | 0x800000u);
-                const unsigned long long mag = sh >= 0 ? m << sh : m >> (-sh);
-                atomicAdd(&acc[c][li], (u >> 31) ? (0ull - mag) : mag);      // two's complement: signed sums wrap correctly
+                for (int c = 0; c < 3; ++c) {
+                    const unsigned u = __float_as_uint(g[c] * wk);
+                    const int ev = (int)(u >> 23) & 255;
+                    if (ev == 255) { poison = 1; continue; }          // NaN (fmaxf / atomicMax drop it from far_count[2]) or Inf: fixed point cannot carry it
+                    int sh = ev - Eg + 23;                            // <= 24: |g wk| <= the step's largest |g| (+ one rounding)
+                    if (ev == 0 || sh <= -24) continue;
+                    sh = sh > 24 ? 24 : sh;
+                    const unsigned long long m = (unsigned long long)((u & 0x7fffffu) | 0x800000u);
+                    const unsigned long long mag = sh >= 0 ? m << sh : m >> (-sh);
+                    atomicAdd(&acc[c][li], (u >> 31) ? (0ull - mag) : mag);      // two's complement: signed sums wrap correctly
+                }
             }
         }
-    }
-    __syncthreads();
-    const int tx = tid & 31, ty = (tid >> 5) & 7, dd = tid >> 8;
-    const int h = h0 + ty, w = w0 + tx, d = d0 + dd;
-    if (h >= H || w >= W || d >= D) return;
-    float* gi = gin + (size_t)b * 3 * V + (size_t)d * HW + h * W + w;
-    // 2^(Eg - 173) as a double (exponent field 1023 + Eg - 173)
-    const double unit = __longlong_as_double((long long)(1023 + Eg - 173) << 52);
+        __syncthreads();
+        const int h = h0 + ty, w = w0 + tx, d = d0 + dd;
+        if (h >= H || w >= W || d >= D) continue;
+        float* gi = gin + (size_t)b * 3 * V + (size_t)d * HW + h * W + w;
+        // 2^(Eg - 173) as a double (exponent field 1023 + Eg - 173)
+        const double unit = __longlong_as_double((long long)(1023 + Eg - 173) << 52);
+        const bool bad = poison != 0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const long long sacc = (long long)acc[c][tid];
-        if (sacc != 0) gi[(size_t)c * V] += (float)((double)sacc * unit) * scale;
+        for (int c = 0; c < 3; ++c) {
+            const long long sacc = (long long)acc[c][tid];
+            if (bad) gi[(size_t)c * V] = __uint_as_float(0x7fc00000u);        // a diverged step surfaces in dL/dvec instead of being masked
+            else if (sacc != 0) gi[(size_t)c * V] += (float)((double)sacc * unit) * scale;
+        }
     }
 }
 
@@ -792,6 +801,7 @@ int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, floa
     const long long tiles = (long long)((W + VG_TW - 1) / VG_TW) * ((H + VG_TH - 1) / VG_TH) * ((D + VG_TD - 1) / VG_TD);
     VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_vecint_bwd: too many tiles");
     const dim3 grid_t((unsigned)tiles, B);
+    const unsigned far_blocks = (unsigned)(tiles * B < 512 ? tiles * B : 512);
     const float scale = 1.0f / (float)(1u << nsteps);
     // per-step statistics of the senders the gather leaves to the far pass live behind the two gradient buffers: {count, largest
     // displacement, largest |g|} (float bits) per step
@@ -803,8 +813,9 @@ int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, floa
         float* gn = k == 0 ? gvec : work + (size_t)(k & 1) * n;
         const float sc = k == 0 ? scale : 1.0f;
         hipLaunchKernelGGL(k_vecint_step_bwd_gather, grid_t, dim3(1024), 0, VXM_STREAM(stream), in, sc, g, gn, far + 4 * k, D, H, W);
-        hipLaunchKernelGGL(k_vecint_step_bwd_far_tiles, grid_t, dim3(1024), 0, VXM_STREAM(stream), in, sc, g, gn, far + 4 * k, D, H, W);
-        hipLaunchKernelGGL(k_vecint_step_bwd_far, dim3(256), dim3(256), 0, VXM_STREAM(stream), in, sc, g, gn, far + 4 * k, B, D, H, W);
+        // ONE far launch per step (rounds 3-4: two, 4.8 us each when they had nothing to do): a persistent grid of at most two blocks per CU
+        // that exits at once when the gather counted no far sender, walks the output tiles otherwise
+        hipLaunchKernelGGL(k_vecint_step_bwd_far_tiles, dim3(far_blocks), dim3(1024), 0, VXM_STREAM(stream), in, sc, g, gn, far + 4 * k, B, D, H, W);
         g = gn;
     }
     return vxm_check_launch("vxm_vecint_bwd");
