@@ -257,6 +257,13 @@ int vxm_gradloss2d_fwd(const float* y, float* loss, double* acc, int B, int C, i
 int vxm_gradloss2d_bwd(const float* y, const float* gloss, float* gy, int B, int C, int H, int W, int penalty,
                        float mult, void* stream);
 
+/* ---- diagnostics of the fp16-piece engine (csrc/diag.hip; not on the hot path): accumulates into out[0] the sum over the aligned
+ * 8-channel x 8 x 8 x 16 voxel tiles of x [B][C][D][H][W] (blocked != 0: channel-blocked [B][C/8][D][H][W][8]) of
+ * (non-zero values below 2^-18 of the tile's largest magnitude m) * m^2, into out[1] the sum of x^2, into out[2] the number of such values
+ * and into out[3] the number of non-zero values (four doubles, zeroed by the caller): out[2] / out[3] is the share of values that keep an
+ * absolute instead of a relative error bound under the per-tile scaling of the two-piece representation (include/vxm_hip.h, pieces = 2). */
+int vxm_s3_range_probe(const float* x, int C, int64_t bstride, int blocked, int B, int D, int H, int W, double* out, void* stream);
+
 /* ---- torch.optim.Adam.step (scripts/torch/train.py:161,220) over ONE flat fp32 buffer (which is
  * also the RCCL all-reduce bucket).  g is pre-multiplied by gscale (1/world_size). */
 int vxm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

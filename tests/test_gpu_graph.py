@@ -194,3 +194,44 @@ def test_bench_two_ranks_on_the_shared_device(vxm):
     assert line["comm"]["ranks_seen"] == 2 and "gloo" in line["comm"]["backend"]
     assert line["submission"]["graph_replays"] == 3 and line["submission"]["device_allocs"] == 0
     assert line["value"] > 0
+
+
+def test_range_report_separates_heavy_tails_from_ordinary_batches(vxm):
+    """voxelmorph_amd.diagnostics: the share of values that fall below 2^-18 of their staged tile's largest magnitude (where the fp16-piece
+    engine keeps an absolute instead of a relative error bound) is ~0 for an ordinary batch -- noise pairs, the bench's workload -- and
+    large for the heavy-tailed one of test_full_size_step_with_heavy_tailed_activations_on_all_three_engines; the guard of GraphedStep moves
+    the process to the three-piece engine for the latter only."""
+    import warnings
+    from voxelmorph_amd import diagnostics
+    from voxelmorph_amd.graph import GraphedStep
+    from voxelmorph_amd.torch import functional as VF
+    if VF.FP32_ENGINE != "f16x2":
+        pytest.skip("the guard acts on the fp16-piece engine")
+    shape = (64, 96, 128)
+    model, opt, fwd, (src, trg) = _setup(vxm, shape, 1, seed=5)
+
+    def step():
+        opt.zero_grad()
+        fwd().backward()
+    rep = diagnostics.range_report(step)
+    print("noise pair: worst", rep["worst"])
+    assert rep["recommended_engine"] == "f16x2" and len(rep["tensors"]) >= 20
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for img in (src, trg):
+        idx = torch.randint(0, img.numel(), (img.numel() // 1000,), device="cuda", generator=g)
+        img.view(-1)[idx] *= torch.exp2(12.0 + 8.0 * torch.rand(idx.numel(), device="cuda", generator=g))
+    rep2 = diagnostics.range_report(step)
+    print("heavy tails: worst", rep2["worst"])
+    assert rep2["recommended_engine"] == "split"
+    keep = VF.FP32_ENGINE
+    try:
+        gs = GraphedStep(fwd, opt, eager_steps=1, range_guard=True)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            gs()
+        assert VF.FP32_ENGINE == "split" and any("three-piece" in str(w.message) for w in caught)
+        gs()                                   # captured and replayed on the engine the guard chose
+        gs()
+        assert gs.replays == 2
+    finally:
+        VF.FP32_ENGINE = keep

@@ -5,7 +5,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libvxm_hip.so
-SRCS="api.hip warp.hip planar.hip conv_fwd.hip conv_bwd_weight.hip conv_bf16.hip conv_s3.hip conv_s3u.hip pool.hip losses.hip"
+SRCS="api.hip warp.hip planar.hip conv_fwd.hip conv_bwd_weight.hip conv_bf16.hip conv_s3.hip conv_s3u.hip pool.hip losses.hip diag.hip"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-comment"
 mkdir -p build
 objs=""

@@ -726,11 +726,15 @@ constexpr int CS_SLICES = 256;
 __global__ void __launch_bounds__(256) k_channel_sum_partial(const float* __restrict__ dz, long long dz_bs, float* __restrict__ ws, int B, size_t V) {
     __shared__ float red[4];
     const int co = blockIdx.x;
-    float s = 0.0f;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;          // four independent chains: four loads in flight per thread
+    constexpr size_t STEP = (size_t)CS_SLICES * 256;
     for (int b = 0; b < B; ++b) {
         const float* p = dz + (size_t)b * dz_bs + (size_t)co * V;
-        for (size_t i = (size_t)blockIdx.y * 256 + threadIdx.x; i < V; i += (size_t)CS_SLICES * 256) s += p[i];
+        size_t i = (size_t)blockIdx.y * 256 + threadIdx.x;
+        for (; i + 3 * STEP < V; i += 4 * STEP) { s0 += p[i]; s1 += p[i + STEP]; s2 += p[i + 2 * STEP]; s3 += p[i + 3 * STEP]; }
+        for (; i < V; i += STEP) s0 += p[i];
     }
+    float s = (s0 + s1) + (s2 + s3);
     s = vxm_wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();

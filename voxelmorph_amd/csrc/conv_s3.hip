@@ -797,22 +797,32 @@ __global__ void __launch_bounds__(256) k_s3_pack_weights(const S3PackBatch batch
 }
 // NP = 2: the scale of each operator of the batch -- one block per job takes the largest magnitude of the weights the operator reads
 // (w[a][ci_lo + b][*], a < Cw_out, b < ci_n: the same set for the forward operator and its adjoint) and writes {1 / s, s} to the trailer.
-__global__ void __launch_bounds__(256) k_s3_wmax(const S3PackBatch batch) {
-    __shared__ float red[4];
+__global__ void __launch_bounds__(1024) k_s3_wmax(const S3PackBatch batch) {
+    __shared__ float red[16];
     const S3PackJob& jb = batch.job[blockIdx.x];
     if (jb.NP != 2) return;                                                             // block-uniform
+    // one block per operator: 1024 threads, four independent loads in flight per thread (the first version -- 256 threads, one dependent
+    // load per iteration -- took 57 us for the 41 k weights of rem0 and sat on the step's critical path twice)
     const int n = jb.Cw_out * jb.ci_n * 27, row = jb.ci_n * 27;
-    float m = 0.0f;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
+    auto at = [&](int i) __attribute__((always_inline)) {
+        if (i >= n) return 0.0f;
         const int a = i / row, r = i - a * row;
-        m = fmaxf(m, __builtin_fabsf(jb.w[((size_t)a * jb.Cw_in + jb.ci_lo) * 27 + r]));
+        return __builtin_fabsf(jb.w[((size_t)a * jb.Cw_in + jb.ci_lo) * 27 + r]);
+    };
+    for (int i = threadIdx.x; i < n; i += 4096) {
+        const float a0 = at(i), a1 = at(i + 1024), a2 = at(i + 2048), a3 = at(i + 3072);
+        m0 = fmaxf(m0, a0); m1 = fmaxf(m1, a1); m2 = fmaxf(m2, a2); m3 = fmaxf(m3, a3);
     }
-    m = s3_wave_max(m);
+    const float m = s3_wave_max(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
+        float mx = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, red[i]);
         float s, inv;
-        s3_scale_of(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), s, inv);
+        s3_scale_of(mx, s, inv);
         jb.wp[jb.words] = (u32x4){__float_as_uint(inv), __float_as_uint(s), 0u, 0u};
     }
 }
@@ -1530,7 +1540,7 @@ int vxm_conv3d_k3_s3_pack_weights_batch(const VxmS3PackJob* jobs, int n_jobs, vo
             blocks += (unsigned)((words + 255) / 256);
             any2 = any2 || a.pieces == 2;
         }
-        if (any2) hipLaunchKernelGGL(k_s3_wmax, dim3(batch.n), dim3(256), 0, VXM_STREAM(stream), batch);      // the operators' scales, read by the pack below
+        if (any2) hipLaunchKernelGGL(k_s3_wmax, dim3(batch.n), dim3(1024), 0, VXM_STREAM(stream), batch);      // the operators' scales, read by the pack below
         hipLaunchKernelGGL(k_s3_pack_weights, dim3(blocks), dim3(256), 0, VXM_STREAM(stream), batch);
     }
     return vxm_check_launch("vxm_conv3d_k3_s3_pack_weights_batch");

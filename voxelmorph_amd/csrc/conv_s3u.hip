@@ -1056,21 +1056,26 @@ __global__ void __launch_bounds__(UW_THREADS, 4) k_s3u_bww(const float* __restri
             for (int j = 0; j < 4; ++j) pp[(size_t)aw * (16 * 16 * NCI) + (4 * (lane >> 4) + j) * (16 * NCI) + c * 16 + (lane & 15)] = tot[aw][c][j];
 }
 
-// gw[co][ci][tap] (row length gw_cin, the first C0 input channels) = sum over the blocks' partials and over the offsets of the tap, fixed order
-__global__ void __launch_bounds__(256) k_s3u_bww_reduce(const float* __restrict__ part, float* __restrict__ gw, int C0, int Cout, int gw_cin, int NCI,
-                                                        int NCOT, int NBLK) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    const int n = Cout * C0 * 27;
-    if (e >= n) return;
-    const int tap = e % 27, ci = (e / 27) % C0, co = e / (27 * C0);
+// gw[co][ci][tap] (row length gw_cin, the first C0 input channels) = sum over the blocks' partials and over the offsets of the tap, fixed order.
+// Block = 64 consecutive (col, ci-tile, ci) elements of one (dz-channel tile, tap) x 16 slices of the blocks' partials: a thread sums the 8
+// offsets of its tap over every 16th block (256-byte coalesced reads), the slices are combined through LDS in a fixed tree (deterministic).
+// (The first version -- one thread per output walking all NBLK partials, 108 blocks -- took 123 us for 67 MB of partials.)
+__global__ void __launch_bounds__(1024) k_s3u_bww_reduce(const float* __restrict__ part, float* __restrict__ gw, int C0, int Cout, int gw_cin, int NCI,
+                                                         int NCOT, int NBLK) {
+    __shared__ float sm[16][64];
+    const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+    const int per_a = 16 * 16 * NCI, chunks = per_a / 64;                 // elements of one (block, dz tile, offset); 64-element chunks of them
+    int j = blockIdx.x;
+    const int chunk = j % chunks; j /= chunks;
+    const int tap = j % 27, cot = j / 27;
     const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-    const int cot = co >> 4, col = co & 15;
-    const size_t per_a = (size_t)16 * 16 * NCI, per_blk = (size_t)NCOT * 64 * per_a;
-    const float* const p0 = part + (size_t)cot * 64 * per_a + (size_t)col * (16 * NCI) + ci;
+    const int el = chunk * 64 + x;                                        // (col 16, c NCI, ci16 16)
+    const size_t per_blk = (size_t)NCOT * 64 * per_a;
+    const float* const p0 = part + (size_t)cot * 64 * per_a + el;
     // offsets index (a + 1) that feed tap k: k = 0: {2, 3}; k = 1: {1, 2}; k = 2: {0, 1}
     const int d0 = 2 - kd, h0 = 2 - kh, w0 = 2 - kw;
     float s = 0.0f;
-    for (int blk = 0; blk < NBLK; ++blk) {
+    for (int blk = y; blk < NBLK; blk += 16) {
         const float* const pb = p0 + (size_t)blk * per_blk;
         float t = 0.0f;
 #pragma unroll
@@ -1080,7 +1085,16 @@ __global__ void __launch_bounds__(256) k_s3u_bww_reduce(const float* __restrict_
         }
         s += t;
     }
-    gw[((size_t)co * gw_cin + ci) * 27 + tap] = s;
+    sm[y][x] = s;
+    __syncthreads();
+    if (y != 0) return;
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = sm[u][x];
+    const float sum = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+                      (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+    const int col = el / (16 * NCI), c = (el / 16) % NCI, ci = c * 16 + (el & 15), co = cot * 16 + col;
+    if (co < Cout && ci < C0) gw[((size_t)co * gw_cin + ci) * 27 + tap] = sum;
 }
 
 int su_cus() {
@@ -1326,7 +1340,7 @@ int vxm_conv3d_k3_s3u_bwd_weight(const float* x0, int C0, int64_t x0_bstride, co
     else
         hipLaunchKernelGGL(k_s3u_bww<1>, dim3(tk.NBLK * NCOT), dim3(UW_THREADS), UwCfg<1>::LDS_BYTES, s, x0, (long long)x0_bstride, C0, dz,
                            (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw, task_rr, lay);
-    hipLaunchKernelGGL(k_s3u_bww_reduce, dim3(vxm_blocks((long long)Cout * C0 * 27, 256)), dim3(256), 0, s, part, gw, C0, Cout, gw_cin, NCI, NCOT, tk.NBLK);
+    hipLaunchKernelGGL(k_s3u_bww_reduce, dim3((unsigned)(NCOT * 27 * (16 * 16 * NCI / 64))), dim3(1024), 0, s, part, gw, C0, Cout, gw_cin, NCI, NCOT, tk.NBLK);
     return vxm_check_launch("vxm_conv3d_k3_s3u_bwd_weight");
 }
 

@@ -21,7 +21,7 @@ import torch
 
 
 class GraphedStep:
-    def __init__(self, fn, opt, eager_steps=2, enabled=True):
+    def __init__(self, fn, opt, eager_steps=2, enabled=True, range_guard=None):
         self.fn, self.opt = fn, opt
         self.eager_steps = max(1, int(eager_steps))      # at least one eager step: lazy one-off work (hipFuncSetAttribute, plans) must not be captured
         self.enabled = bool(enabled)
@@ -29,6 +29,11 @@ class GraphedStep:
         self.graph = None
         self.out = None
         self.replays = 0
+        # first eager step under the dynamic-range probe of the fp16-piece conv engine (voxelmorph_amd/diagnostics.py): a batch whose tensors
+        # it does not fit moves this process to the three-piece engine BEFORE anything is captured.  VXM_RANGE_GUARD=0 turns it off.
+        import os
+        self.range_guard = (os.environ.get("VXM_RANGE_GUARD", "1") != "0") if range_guard is None else bool(range_guard)
+        self.range_report = None
 
     # the step, eagerly (also what is captured)
     def _body(self, with_update):
@@ -42,6 +47,12 @@ class GraphedStep:
 
     def eager(self):
         self.calls += 1
+        if self.range_guard and self.calls == 1:
+            from .diagnostics import guard_engine
+            box = []
+            self.range_report = guard_engine(lambda: box.append(self._body(True)))
+            if box:
+                return box[0]
         return self._body(True)
 
     def _capture(self):

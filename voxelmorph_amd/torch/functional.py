@@ -381,6 +381,36 @@ def s3_route(c0, up0, c1, cout, B, D, H, W):
     return bool(_lib.lib().vxm_conv3d_k3_s3_ok(c0, c1, cout, B, D, H, W))
 
 
+_RANGE_PROBE = None    # voxelmorph_amd.diagnostics.range_report(): list of (tag, four doubles on the device) while a report is being taken
+
+
+def _probe(tag, t, C, blocked):
+    """dynamic range of one tensor the split kernels read, as the fp16-piece scheme sees it (csrc/diag.hip); only under range_report()"""
+    if _RANGE_PROBE is None or C < 8 or t.dim() != 5:
+        return
+    out = torch.zeros(4, dtype=torch.float64, device=t.device)
+    B, _, D, H, W = t.shape
+    call("vxm_s3_range_probe", ptr(t), C, t[0].numel(), 1 if blocked else 0, B, D, H, W, ptr(out), stream())
+    _RANGE_PROBE.append((tag, out))
+
+
+_FRESH_PACKS = []      # pack buffers allocated since the last _adopt_fresh_packs(): allocated under the second stream, read on the main one
+
+
+def _new_pack(nbytes, device):
+    t = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    _FRESH_PACKS.append(t)
+    return t
+
+
+def _adopt_fresh_packs(stream_):
+    """tell the caching allocator that `stream_` reads the pack buffers allocated (under another stream) since the last call"""
+    while _FRESH_PACKS:
+        t = _FRESH_PACKS.pop()
+        if stream_ is not None and t.is_cuda:
+            t.record_stream(stream_)
+
+
 def s3_prepack(jobs):
     """Pack every stale split operator of `jobs` = [(w, lo, hi, flip, seg0), ...] in ONE launch (vxm_conv3d_k3_s3_pack_weights_batch).
     The packed, pre-split copies are cached on the weight tensor until its version moves (once per optimiser step)."""
@@ -397,8 +427,7 @@ def s3_prepack(jobs):
         cout, cin = w.shape[:2]
         inc, outc = (cout, hi - lo) if flip else (hi - lo, cout)
         nbytes = _lib.lib().vxm_conv3d_k3_s3_packed_bytes(seg0, inc - seg0, outc, s3_pieces())
-        wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else \
-            torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else _new_pack(nbytes, w.device)
         stale.append((_c(w), cin, cout, lo, hi - lo, bool(flip), seg0, wp, cache, key, _pack_ver(w)))
     if not stale:
         return
@@ -430,7 +459,7 @@ def s3u_pack(w, c0, c1):
         return hit[1]
     cout = w.shape[0]
     nbytes = _lib.lib().vxm_conv3d_k3_s3u_packed_bytes(c0, c1, cout, s3_pieces())
-    wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else _new_pack(nbytes, w.device)
     call("vxm_conv3d_k3_s3u_pack_weights", ptr(_c(w)), ptr(wp), c0, c1, cout, s3_pieces(), stream())
     cache[key] = (_pack_ver(w), wp)
     return wp
@@ -448,20 +477,28 @@ def s3u_bwd_low_route(c0, cout, B, D, H, W):
     return S3U and split_engine() and bool(_lib.lib().vxm_conv3d_k3_s3u_bwd_low_ok(c0, cout, B, D, H, W, s3_pieces()))
 
 
-def s3u_bwd_low(dz, cout, w, c0, cin, gxl, mask, mask_slope, B, D, H, W, lay=0):
-    """gxl [B,c0,D/2,H/2,W/2] = LeakyReLU'(mask) * (conv backward + upsample backward of dz [B,cout,D,H,W]) for the first c0 input channels
-    of w [cout][cin][27]; the packed transposed-collapsed operator is cached on the weight tensor"""
+def s3u_bwd_low_pack(w, c0, cin):
+    """packed transposed-collapsed operator of k_s3u_dlow for the first c0 input channels of w [cout][cin][27], cached on the weight tensor until
+    its version moves"""
+    cout = w.shape[0]
     cache = w.__dict__.setdefault("_vxm_s3_packs", {})
     key = ("s3u_low", c0, cin, s3_pieces())
     hit = cache.get(key)
     if hit is None or hit[0] != _pack_ver(w) or hit[1].device != w.device:
         nbytes = _lib.lib().vxm_conv3d_k3_s3u_bwd_low_packed_bytes(c0, cout, s3_pieces())
-        wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else _new_pack(nbytes, w.device)
         call("vxm_conv3d_k3_s3u_bwd_low_pack_weights", ptr(_c(w)), ptr(wp), c0, cin, cout, s3_pieces(), stream())
         cache[key] = hit = (_pack_ver(w), wp)
+    return hit[1]
+
+
+def s3u_bwd_low(dz, cout, w, c0, cin, gxl, mask, mask_slope, B, D, H, W, lay=0):
+    """gxl [B,c0,D/2,H/2,W/2] = LeakyReLU'(mask) * (conv backward + upsample backward of dz [B,cout,D,H,W]) for the first c0 input channels
+    of w [cout][cin][27]"""
+    wp = s3u_bwd_low_pack(w, c0, cin)
     V = D * H * W
     with _prof.region("k_s3u_dlow<%d,%d>" % (1 if c0 <= 16 else 2, s3_pieces()), flops=2.0 * 8 * c0 * cout * B * V, nominal=2.0 * 27 * c0 * cout * B * V):
-        call("vxm_conv3d_k3_s3u_bwd_low", ptr(dz), cout * V, cout, ptr(hit[1]), ptr(gxl), c0 * (V // 8), c0, ptr(mask), c0 * (V // 8), float(mask_slope),
+        call("vxm_conv3d_k3_s3u_bwd_low", ptr(dz), cout * V, cout, ptr(wp), ptr(gxl), c0 * (V // 8), c0, ptr(mask), c0 * (V // 8), float(mask_slope),
              B, D, H, W, s3_pieces() | lay, stream())
 
 
@@ -877,6 +914,35 @@ def _s3_jobs(plan, params, B, shape3, with_backward, input_grads):
     return jobs
 
 
+def _prepack_plan(plan, params, B, shape3, with_backward, input_grads):
+    """Every packed operator one pass over `plan` will ask for, built now: the split operators in one batched launch (_s3_jobs), the collapsed
+    operators of the cat([upsample, skip]) layers (forward: k_s3u_conv; backward-data onto the low-resolution tensor: k_s3u_dlow) one by one.
+    Returns the index of the first op that reads one of them (len(ops) when none does)."""
+    s3_prepack(_s3_jobs(plan, params, B, shape3, with_backward, input_grads))
+    first = len(plan.ops)
+    for n, op in enumerate(plan.ops):
+        if op["kind"] != "conv":
+            continue
+        s0, up0, s1 = op["src"]
+        w = params[2 * op["k"]]
+        cout, c0 = plan.ch[op["dst"]], plan.ch[s0]
+        c1 = plan.ch[s1] if s1 is not None else 0
+        if s0 < plan.n_inputs:
+            c0, c1 = sum(plan.ch[i] for i in range(plan.n_inputs)), 0 if plan.n_inputs == 1 else plan.ch[1]
+            c0 -= c1
+        D, H, W = _dims(shape3, plan.lvl[op["dst"]])
+        uses = cout > 4 and s3_route(c0, up0, c1, cout, B, D, H, W)
+        if up0 and cout > 4 and s3u_route(c0, c1, cout, B, D, H, W):
+            s3u_pack(w, c0, c1)
+            uses = True
+        if up0 and with_backward and s3u_bwd_low_route(c0, cout, B, D, H, W) and plan.ops[plan.producer[s0]]["kind"] == "conv" \
+                and len(plan.consumers[s0]) == 1:
+            s3u_bwd_low_pack(w, c0, c0 + c1)
+        if uses:
+            first = min(first, n)
+    return first
+
+
 def _blocked_tensors(plan, B, shape3):
     """Which activations of the fused U-Net are kept CHANNEL-BLOCKED ([B][C/8][D][H][W][8], include/vxm_hip.h VXM_S3_*_BLOCKED) instead of
     NCDHW.  The tensors never leave the engine, so their layout is its own business; a haloed row of a blocked tensor is one contiguous run
@@ -960,10 +1026,30 @@ class UnetFn(torch.autograd.Function):
         for i, t in T.items():
             if t.shape[1] != plan.ch[i] or t.shape[0] != B or tuple(t.shape[2:]) != shape3:
                 raise ValueError("Unet: input %d has shape %s, expected [%d,%d,%s]" % (i, tuple(t.shape), B, plan.ch[i], shape3))
+        packs_ready, first_packed = None, len(plan.ops)
         if split_engine():
-            s3_prepack(_s3_jobs(plan, params, B, shape3, any(ctx.needs_input_grad[1:]), any(ctx.needs_input_grad[1:1 + plan.n_inputs])))
+            # The packed operators (weight scales, pre-split pieces, collapsed upsample operators: ~10 small launches, 0.25 ms in a row) are
+            # rebuilt once per optimiser step.  They go to the second stream and run beside the first layers, which do not read them; the
+            # main stream waits for them in front of the first launch that does.
+            want_bwd, want_in = any(ctx.needs_input_grad[1:]), any(ctx.needs_input_grad[1:1 + plan.n_inputs])
+            if OVERLAP_SMALL_LEVELS:
+                main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+                fork = torch.cuda.Event()
+                fork.record(main)
+                side.wait_event(fork)
+                with torch.cuda.stream(side):
+                    first_packed = _prepack_plan(plan, params, B, shape3, want_bwd, want_in)
+                    packs_ready = torch.cuda.Event()
+                    packs_ready.record(side)
+                _adopt_fresh_packs(main)
+            else:
+                _prepack_plan(plan, params, B, shape3, want_bwd, want_in)
+                _adopt_fresh_packs(None)
         blocked = _blocked_tensors(plan, B, shape3)
-        for op in plan.ops:
+        for n_op, op in enumerate(plan.ops):
+            if packs_ready is not None and n_op >= first_packed:
+                torch.cuda.current_stream(dev).wait_event(packs_ready)
+                packs_ready = None
             dst = op["dst"]
             D, H, W = _dims(shape3, plan.lvl[dst])
             V = D * H * W
@@ -983,9 +1069,13 @@ class UnetFn(torch.autograd.Function):
                 s0, up0, s1 = op["src"]
                 call("vxm_upsample2_cat", ptr(T[s0]), plan.ch[s0], ptr(T[s1]), plan.ch[s1], ptr(out), B, D, H, W, stream())
             T[dst] = out
+            if _RANGE_PROBE is not None and op["kind"] == "conv":
+                _probe("activation of conv %d (%d channels, level %d)" % (op["k"], plan.ch[dst], plan.lvl[dst]), out, plan.ch[dst], dst in blocked)
         # The returned tensor must not be reachable from ctx except through save_for_backward: out.grad_fn is this
         # node, so `ctx.T[plan.out] = out` would be a reference cycle that keeps EVERY activation of the step alive
         # until Python's cyclic GC runs (tens of GB per step at 160x192x224).
+        if packs_ready is not None:             # no op of this plan read a packed operator: still join the second stream
+            torch.cuda.current_stream(dev).wait_event(packs_ready)
         out = T.pop(plan.out)
         ctx.save_for_backward(out)
         ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B, ctx.blocked = plan, T, params, shape3, B, blocked
@@ -1077,6 +1167,8 @@ class UnetFn(torch.autograd.Function):
                 c1 = plan.ch[s1] if s1 is not None else 0
                 cin = c0 + c1
                 dz = DZ.pop(dst)
+                if _RANGE_PROBE is not None:
+                    _probe("gradient at conv %d (%d channels, level %d)" % (op["k"], cout, plan.lvl[dst]), dz, cout, dst in blocked)
                 x0, x1 = T[s0], (T[s1] if s1 is not None else None)
                 # channel-blocked tensors (_blocked_tensors): the activation s0 of a plain conv and / or this conv's own output, whose DZ shares its layout
                 dz_blk, x_blk = dst in blocked, s0 in blocked

@@ -265,6 +265,11 @@ class UnetBf16Fn(torch.autograd.Function):
         dev = gout.device
         gout = _c(gout)
         ws = _Workspace(dev)
+        # weight gradients on the second HIP stream beside the backward-data chain they do not feed (as UnetFn.backward of the fp32 engine,
+        # functional.py: the tails of the big launches fill with each other's blocks); VXM_NO_OVERLAP=1: one stream
+        from . import functional as VF
+        main = torch.cuda.current_stream(dev)
+        side = VF._side_stream(dev) if VF.OVERLAP_SMALL_LEVELS else None
         n_in = plan.n_inputs
         grads = [None] * (n_in + len(params))
         DZ, GP, GS = {}, {}, {}
@@ -311,7 +316,18 @@ class UnetBf16Fn(torch.autograd.Function):
             gw_sink, gb_sink = _claim_sink(w), _claim_sink(b)
             gw = gw_sink if gw_sink is not None else torch.empty_like(w)
             gb = gb_sink if gb_sink is not None else torch.empty_like(b)
-            conv_bwd_weight(ws, x0, c0, up0, x1b, c1, dz, cdz, gw, gb, B, D, H, W)
+            if side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    conv_bwd_weight(ws, x0, c0, up0, x1b, c1, dz, cdz, gw, gb, B, D, H, W)      # (ws is only ever used on the second stream then)
+                dz.record_stream(side)              # released by the main-stream chain before the second stream may be done
+                for g_, sink in ((gw, gw_sink), (gb, gb_sink)):
+                    if sink is None:
+                        g_.record_stream(side)
+            else:
+                conv_bwd_weight(ws, x0, c0, up0, x1b, c1, dz, cdz, gw, gb, B, D, H, W)
             grads[n_in + 2 * op["k"]] = None if gw_sink is not None else gw
             grads[n_in + 2 * op["k"] + 1] = None if gb_sink is not None else gb
             if feeds_inputs:
@@ -363,4 +379,6 @@ class UnetBf16Fn(torch.autograd.Function):
                     GS[s1] = gs
                 else:
                     DZ[s1] = lrelu_bwd(gs, T[s1], plan.ops[plan.producer[s1]]["slope"])
+        if side is not None:
+            main.wait_stream(side)                  # parameter gradients (and the activations the second stream read) are final past this point
         return (None,) + tuple(grads)
