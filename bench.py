@@ -44,7 +44,10 @@ def parse():
     ap.add_argument("--no-extra-configs", action="store_true")                 # only the headline (profiling runs)
     ap.add_argument("--cpu-baseline-steps", type=int, default=2)               # timed CPU steps after one warm-up, at the FULL shape
     ap.add_argument("--cpu-threads", type=int, default=0)                      # 0: min(32, cores), see cpu_baseline()
-    ap.add_argument("--no-gpu-baseline", action="store_true")                  # skip the stock torch-ROCm (MIOpen / ATen) leg on this GPU
+    ap.add_argument("--gpu-baseline", action="store_true",
+                    help="time the reference's ATen call sequence on THIS GPU through stock torch-ROCm now (minutes: this image has no MIOpen "
+                         "kernel database for gfx950); without the flag the line carries the measurement committed under profiles/")
+    ap.add_argument("--no-gpu-baseline", action="store_true")                  # neither run nor quote the stock torch-ROCm leg
     ap.add_argument("--torch-rocm-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -265,6 +268,11 @@ def torch_rocm_worker(shape, int_steps, timed=2):
     import numpy as np
     from oracle import vxm_oracle as orc
     dev = torch.device("cuda", 0)
+    # This image ships no MIOpen kernel / find database for gfx950: with MIOpen enabled every convolution configuration is JIT-compiled on
+    # first use (the leg did not finish in 240 s).  VXM_BASELINE_MIOPEN=0 (the default of gpu_baseline()) runs ATen's own convolution path
+    # instead (vol2col + rocBLAS GEMM, torch.backends.cudnn.enabled = False) -- still stock torch-ROCm, and said so in the result.
+    miopen = os.environ.get("VXM_BASELINE_MIOPEN", "0") == "1"
+    torch.backends.cudnn.enabled = miopen
     rng = np.random.default_rng(1234)
     src = torch.from_numpy(rng.random((1, 1) + shape).astype(np.float32)).to(dev)
     trg = torch.from_numpy(rng.random((1, 1) + shape).astype(np.float32)).to(dev)
@@ -294,13 +302,30 @@ def torch_rocm_worker(shape, int_steps, timed=2):
         times.append(time.perf_counter() - t0)
     dt = sum(times) / len(times)
     print(json.dumps({"value": 1.0 / dt, "unit": "volume-pairs/s", "kind": "torch-rocm", "ms_per_step": 1e3 * dt,
+                      "convolutions": "MIOpen" if miopen else "ATen vol2col + rocBLAS GEMM (torch.backends.cudnn.enabled = False: no MIOpen kernel "
+                                                              "database for gfx950 in this image)",
                       "sample": "2 warm-up (%.1f s) + %d timed training steps of the reference's ATen call sequence on cuda:0, B=1, fp32, %s: %s ms"
                                 % (warm, timed, "x".join(map(str, shape)), ", ".join("%.1f" % (1e3 * t) for t in times)),
                       "final_loss": float(loss.detach()), "peak_allocated_gb": torch.cuda.max_memory_allocated() / 1e9,
                       "torch": torch.__version__, "hip": torch.version.hip}))
 
 
-def gpu_baseline(shape, int_steps, timeout_s=240):
+def recorded_gpu_baseline():
+    """the newest profiles/*_torch_rocm_baseline.json (a --gpu-baseline run committed by the builder), labelled as recorded"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_torch_rocm_baseline.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            rec = json.load(f)
+    except (OSError, ValueError):
+        return None
+    rec["recorded"] = "%s (committed measurement of `bench.py --gpu-baseline`; not re-run in this invocation)" % os.path.relpath(files[-1], ROOT)
+    return rec
+
+
+def gpu_baseline(shape, int_steps, timeout_s=900):
     """SURVEY.md section 8d, second reference point: the reference path on THIS MI355X through stock torch-ROCm, in a child process with a
     deadline (MIOpen's first-call solver search is not ours to bound).  A reported baseline next to `cpu_baseline`, never `value`."""
     import subprocess
@@ -715,9 +740,11 @@ def main():
         out["extra_configs"] = extra
     if world == 1 and not args.no_gpu_baseline and args.config == "diffeo_fp32":
         torch.cuda.empty_cache()
-        out["gpu_baseline"] = gpu_baseline(shape, args.int_steps)
-        if "value" in out["gpu_baseline"]:
-            out["gpu_baseline"]["speedup_of_value"] = out["value"] / out["gpu_baseline"]["value"]
+        gb = gpu_baseline(shape, args.int_steps) if args.gpu_baseline else recorded_gpu_baseline()
+        if gb is not None:
+            out["gpu_baseline"] = gb
+            if "value" in gb:
+                gb["speedup_of_value"] = out["value"] / gb["value"]
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(shape, args.int_steps, args.cpu_baseline_steps, args.cpu_threads,
                                            "mse" if dense else "ncc", 0.01 if dense else 1.0)

@@ -40,8 +40,22 @@ typedef enum {
 enum { VXM_INTERP_LINEAR = 0, VXM_INTERP_NEAREST = 1 };   /* SpatialTransformer mode, layers.py:11 */
 enum { VXM_PENALTY_L1 = 0, VXM_PENALTY_L2 = 1 };          /* Grad penalty, losses.py:98 */
 
-int vxm_version(void);                 /* 10000 major + 100 minor + patch of this ABI: 300 = 0.3.0 (round 3) */
+int vxm_version(void);                 /* 10000 major + 100 minor + patch of this ABI: 400 = 0.4.0 (round 5) */
 const char* vxm_last_error_string(void);
+
+/* ---- the two umbrella names SURVEY.md section 8b lists.  Every op has its own *_workspace_bytes() query next to it; this one dispatches
+ * on an op code (0 for an unknown op or a shape the op refuses).  Cin / Cout are those of the FORWARD layer. */
+enum { VXM_WS_CONV_BWD_WEIGHT = 1, VXM_WS_S3_BWD_WEIGHT = 2, VXM_WS_S3U_BWD_WEIGHT = 3, VXM_WS_BF16_BWD_WEIGHT = 4, VXM_WS_CONV_BWD_DATA = 5,
+       VXM_WS_VECINT_BWD = 6 };
+size_t vxm_workspace_bytes(int op, int Cin, int Cout, int B, int D, int H, int W);
+/* convolution_backward w.r.t. the input (autograd twin of networks.py:299) for the input channels [ci_lo, ci_lo + ci_n) of w [Cout][Cw_in][27]:
+ * gx [B][ci_n][D][H][W] = adjoint conv of dz [B][Cout][D][H][W], times LeakyReLU'(mask) when mask != NULL (the fused leaky_relu_backward of
+ * the previous ConvBlock).  It IS vxm_conv3d_k3_fwd on the transposed / flipped operator, which this call packs into wpacked_scratch
+ * (vxm_workspace_bytes(VXM_WS_CONV_BWD_DATA, ci_n, Cout, ...) bytes) first; callers that keep the packed operator (the fused U-Net engine,
+ * the split kernels' vxm_conv3d_k3_s3_fwd with a transpose_flip pack job) call the forward entry points directly. */
+int vxm_conv3d_k3_bwd_data(const float* dz, int Cout, int64_t dz_bstride, const float* w, int Cw_in, int ci_lo, int ci_n, float* wpacked_scratch,
+                           float* gx, int64_t gx_bstride, const float* mask, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W,
+                           void* stream);
 
 /* ---- SpatialTransformer.forward, layers.py:30-48 (add + normalise + permute + index +
  * grid_sampler_3d, align_corners=True, padding zeros).  out[b,c,p] = sample(src[b,c], p+flow[b,:,p]).

@@ -120,26 +120,42 @@ def main(argv=None):
 
     os.makedirs(args.model_dir, exist_ok=True)
     from voxelmorph_amd.pacing import InFlight
+    from voxelmorph_amd.graph import GraphedStep
     pace = InFlight(2)
+    # The loop body of the reference (train.py:194-223) as ONE hipGraph launch per step (voxelmorph_amd/graph.py): the batch lives in static
+    # tensors that every step refills in place, the loss terms accumulate into a static tensor; the first two steps run launch by launch
+    # (VXM_GRAPH=0: every step does).
+    inputs, y_true = next(loader)
+    static_in, static_true = [t.clone() for t in inputs], [t.clone() if torch.is_tensor(t) else t for t in y_true]
+    terms = torch.zeros(len(losses) + 1, device=dev)
+
+    def forward_loss():
+        y_pred = model(*static_in)
+        loss = 0
+        for n, fn in enumerate(losses):
+            cur = fn(static_true[n], y_pred[n]) * weights[n]
+            terms[n] += cur.detach()
+            loss = loss + cur
+        terms[-1] += loss.detach()
+        return loss
+
+    step = GraphedStep(forward_loss, opt, eager_steps=2, enabled=os.environ.get('VXM_GRAPH', '1') != '0')
+    fresh = False                            # the first batch is in the static tensors already
     for epoch in range(args.initial_epoch, args.epochs):
         if rank == 0 and epoch % args.save_every == 0:
             model.save(os.path.join(args.model_dir, '%04d.pt' % epoch))
-        terms = torch.zeros(len(losses) + 1, device=dev)
+        terms.zero_()
         torch.cuda.synchronize()
         t0 = time.time()
         for _ in range(args.steps_per_epoch):
             pace.wait()                      # at most two steps in flight (voxelmorph_amd/pacing.py)
-            inputs, y_true = next(loader)
-            y_pred = model(*inputs)
-            loss = 0
-            for n, fn in enumerate(losses):
-                cur = fn(y_true[n], y_pred[n]) * weights[n]
-                terms[n] += cur.detach()
-                loss = loss + cur
-            terms[-1] += loss.detach()
-            opt.zero_grad()
-            loss.backward()
-            opt.step()
+            if fresh:
+                inputs, y_true = next(loader)
+                for dst, src in zip(static_in + static_true, list(inputs) + list(y_true)):
+                    if torch.is_tensor(dst):
+                        dst.copy_(src)
+            fresh = True
+            step()
             pace.mark()
         torch.cuda.synchronize()
         dt = (time.time() - t0) / args.steps_per_epoch

@@ -33,6 +33,8 @@ class S3PackJob(_c.Structure):
 SIGNATURES = {
     "vxm_version": [],
     "vxm_last_error_string": [],
+    "vxm_workspace_bytes": [_I, _I, _I, _I, _I, _I, _I],
+    "vxm_conv3d_k3_bwd_data": [_P, _I, _L, _P, _I, _I, _I, _P, _P, _L, _P, _L, _F, _I, _I, _I, _I, _P],
     "vxm_warp3d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vxm_warp3d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vxm_vecint_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -134,6 +136,7 @@ SIGNATURES = {
     "vxm_adam_step_dev": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _F, _P],
 }
 _RESTYPES = {
+    "vxm_workspace_bytes": _S,
     "vxm_last_error_string": _c.c_char_p,
     "vxm_conv3d_k3_packed_elems": _S,
     "vxm_conv3d_k3_up_packed_elems": _S,

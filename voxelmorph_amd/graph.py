@@ -29,10 +29,12 @@ class GraphedStep:
         self.graph = None
         self.out = None
         self.replays = 0
-        # first eager step under the dynamic-range probe of the fp16-piece conv engine (voxelmorph_amd/diagnostics.py): a batch whose tensors
-        # it does not fit moves this process to the three-piece engine BEFORE anything is captured.  VXM_RANGE_GUARD=0 turns it off.
+        # range_guard (or VXM_RANGE_GUARD=1): the first eager step runs under the dynamic-range probe of the fp16-piece conv engine
+        # (voxelmorph_amd/diagnostics.py) and moves this process to the three-piece engine BEFORE anything is captured when a tensor of the
+        # batch has more than 0.1 % of its values in that engine's absolute-error regime.  Off by default: on the heavy-tailed full-size step
+        # the fp16-piece engine is as close to the fp64 arbiter as the exact engines (tests/test_gpu_parity.py), so the switch buys nothing there.
         import os
-        self.range_guard = (os.environ.get("VXM_RANGE_GUARD", "1") != "0") if range_guard is None else bool(range_guard)
+        self.range_guard = (os.environ.get("VXM_RANGE_GUARD", "0") == "1") if range_guard is None else bool(range_guard)
         self.range_report = None
 
     # the step, eagerly (also what is captured)
