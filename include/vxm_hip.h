@@ -366,6 +366,14 @@ int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W);
 #define VXM_S3_IN0_BLOCKED 0x100   /* first tensor operand  */
 #define VXM_S3_IN1_BLOCKED 0x200   /* second tensor operand */
 #define VXM_S3_OUT_BLOCKED 0x400   /* output tensor and, where there is one, the mask tensor of the fused leaky_relu_backward */
+/* Phase flags of the two backward-weight entry points of the split engine (vxm_conv3d_k3_s3_bwd_weight, vxm_conv3d_k3_s3u_bwd_weight), OR-ed
+ * into `pieces` like the layout flags.  A weight gradient is a contraction kernel (one partial sum per block into `work`) followed by a small
+ * reduction kernel (work -> gw, gb).  Run back to back on one stream, the few blocks of the reduction wait behind the persistent blocks of
+ * whatever shares the chip, and the NEXT contraction of that stream waits with them (measured: 450 - 585 us stalls, three per step).  With
+ * CONTRACT_ONLY the call stops after the contraction; a second call with REDUCE_ONLY (same arguments, same `work`, any stream that waits
+ * for the first) finishes it -- the fused U-Net backward sends the reductions to a third stream.  Neither flag: both, as before. */
+#define VXM_S3_BW_CONTRACT_ONLY 0x1000
+#define VXM_S3_BW_REDUCE_ONLY 0x2000
 int vxm_conv3d_k3_s3_layout_ok(int C0, int C1, int x0_up, int Cout, int H, int pieces);
 int vxm_conv3d_k3_s3_variant(int Cout);                     /* 10 * NCT + CB of the kernel instance (profiling labels) */
 int vxm_conv3d_k3_s3_tile_rows(int Cout, int pieces, int H); /* rows of its output tile: 8 x 8 x 16 on the fp16 scheme, else 8 x 4 x 16 */

@@ -519,8 +519,10 @@ def test_conv_bwd_data_and_workspace_umbrella_names(vxm):
         scratch = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda")
         gx = torch.full((B, n) + vol, float("nan"), dtype=torch.float32, device="cuda")
         mk = G(np.ascontiguousarray(mask[:, lo:lo + n])) if use_mask else None
-        _lib.call("vxm_conv3d_k3_bwd_data", _lib.ptr(G(dz)), cout, cout * V, _lib.ptr(G(w)), cin, lo, n, _lib.ptr(scratch), _lib.ptr(gx), n * V,
+        dz_d, w_d = G(dz), G(w)                 # (named: a temporary would be freed, and its memory reused, before the launch reads it)
+        _lib.call("vxm_conv3d_k3_bwd_data", _lib.ptr(dz_d), cout, cout * V, _lib.ptr(w_d), cin, lo, n, _lib.ptr(scratch), _lib.ptr(gx), n * V,
                   _lib.ptr(mk), n * V, 0.2, B, *vol, _lib.stream())
+        torch.cuda.synchronize()
         want = ref[:, lo:lo + n]
         if use_mask:
             want = want * np.where(mask[:, lo:lo + n] > 0, 1.0, 0.2)

@@ -1617,7 +1617,9 @@ size_t vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(int C, int Cout, int B, int D
 
 int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw, int gw_cin,
                                 int ci_off, float* gb, void* work, size_t work_bytes, int B, int D, int H, int W, int pieces_and_layout, void* stream) {
-    const int pieces = pieces_and_layout & 0xff, lay = pieces_and_layout & ~0xff;
+    const int pieces = pieces_and_layout & 0xff, phase = pieces_and_layout & (VXM_S3_BW_CONTRACT_ONLY | VXM_S3_BW_REDUCE_ONLY);
+    const int lay = pieces_and_layout & ~0xff & ~(VXM_S3_BW_CONTRACT_ONLY | VXM_S3_BW_REDUCE_ONLY);
+    VXM_REQUIRE(phase != (VXM_S3_BW_CONTRACT_ONLY | VXM_S3_BW_REDUCE_ONLY), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_bwd_weight: both phase flags set");
     VXM_REQUIRE(x && dz && gw && work, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3_bwd_weight: null pointer");
     VXM_REQUIRE(s3_pieces_ok(pieces), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_bwd_weight: pieces = %d (3: bf16, 2: fp16)", pieces);
     VXM_REQUIRE(lay == 0 || (pieces == 2 && (lay & ~(VXM_S3_IN0_BLOCKED | VXM_S3_IN1_BLOCKED)) == 0), VXM_ERR_BAD_SHAPE,
@@ -1645,7 +1647,8 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
     const char* te = getenv("VXM_S3_BW_TASKS");                 // developer A/B switch: range = a contiguous task range per block (rounds 3 / early 4)
     // (round-robin order: -8 .. -16 % at 160x192x224, +3 % at 80x96x112 -- same-box A/B, profiles/r04r_bw_task_order.txt)
     const int task_rr = ((te && te[0] == 'r' && te[1] == 'a') || (long long)D * H * W < (1ll << 21)) ? 0 : 1;
-    if (pieces == 2 && pe && pe[0] == '1')
+    if (phase == VXM_S3_BW_REDUCE_ONLY) {}
+    else if (pieces == 2 && pe && pe[0] == '1')
         hipLaunchKernelGGL((k_s3_bwd_weight<2, false>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
                            (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, lay, s3_dbg());
     else if (pieces == 2)
@@ -1655,7 +1658,8 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
         hipLaunchKernelGGL((k_s3_bwd_weight<3, true>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<3>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
                            (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, lay, s3_dbg());
     const int n = 16 * NCO * 16 * Q * 28;
-    hipLaunchKernelGGL(k_s3_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(1024), 0, s, part, gw, gb, C, Cout, gw_cin, ci_off, Q, NCO, NBLK);
+    if (phase != VXM_S3_BW_CONTRACT_ONLY)
+        hipLaunchKernelGGL(k_s3_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(1024), 0, s, part, gw, gb, C, Cout, gw_cin, ci_off, Q, NCO, NBLK);
     return vxm_check_launch("vxm_conv3d_k3_s3_bwd_weight");
 }
 

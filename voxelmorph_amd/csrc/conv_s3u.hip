@@ -1312,7 +1312,9 @@ size_t vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes(int C0, int Cout, int B, int
 
 int vxm_conv3d_k3_s3u_bwd_weight(const float* x0, int C0, int64_t x0_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw, int gw_cin,
                                  void* work, size_t work_bytes, int B, int D, int H, int W, int pieces_and_layout, void* stream) {
-    const int pieces = pieces_and_layout & 0xff, lay = pieces_and_layout & ~0xff;
+    const int pieces = pieces_and_layout & 0xff, phase = pieces_and_layout & (VXM_S3_BW_CONTRACT_ONLY | VXM_S3_BW_REDUCE_ONLY);
+    const int lay = pieces_and_layout & ~0xff & ~(VXM_S3_BW_CONTRACT_ONLY | VXM_S3_BW_REDUCE_ONLY);
+    VXM_REQUIRE(phase != (VXM_S3_BW_CONTRACT_ONLY | VXM_S3_BW_REDUCE_ONLY), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3u_bwd_weight: both phase flags set");
     VXM_REQUIRE(x0 && dz && gw && work, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3u_bwd_weight: null pointer");
     VXM_REQUIRE(lay == 0 || lay == VXM_S3_IN1_BLOCKED, VXM_ERR_BAD_SHAPE,
                 "vxm_conv3d_k3_s3u_bwd_weight: layout flags 0x%x (only dz, the second operand, may be channel-blocked)", lay);
@@ -1334,13 +1336,15 @@ int vxm_conv3d_k3_s3u_bwd_weight(const float* x0, int C0, int64_t x0_bstride, co
     const char* te = getenv("VXM_S3_BW_TASKS");
     // (round-robin order: -8 .. -16 % at 160x192x224, +3 % at 80x96x112 -- same-box A/B, profiles/r04r_bw_task_order.txt)
     const int task_rr = ((te && te[0] == 'r' && te[1] == 'a') || (long long)D * H * W < (1ll << 21)) ? 0 : 1;
-    if (NCI == 2)
+    if (phase == VXM_S3_BW_REDUCE_ONLY) {}
+    else if (NCI == 2)
         hipLaunchKernelGGL(k_s3u_bww<2>, dim3(tk.NBLK * NCOT), dim3(UW_THREADS), UwCfg<2>::LDS_BYTES, s, x0, (long long)x0_bstride, C0, dz,
                            (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw, task_rr, lay);
     else
         hipLaunchKernelGGL(k_s3u_bww<1>, dim3(tk.NBLK * NCOT), dim3(UW_THREADS), UwCfg<1>::LDS_BYTES, s, x0, (long long)x0_bstride, C0, dz,
                            (long long)dz_bstride, Cout, part, D, H, W, tk.NBLK, tk.ncol, tk.nseg, tk.seg_len, tk.nh, tk.nw, task_rr, lay);
-    hipLaunchKernelGGL(k_s3u_bww_reduce, dim3((unsigned)(NCOT * 27 * (16 * 16 * NCI / 64))), dim3(1024), 0, s, part, gw, C0, Cout, gw_cin, NCI, NCOT, tk.NBLK);
+    if (phase != VXM_S3_BW_CONTRACT_ONLY)
+        hipLaunchKernelGGL(k_s3u_bww_reduce, dim3((unsigned)(NCOT * 27 * (16 * 16 * NCI / 64))), dim3(1024), 0, s, part, gw, C0, Cout, gw_cin, NCI, NCOT, tk.NBLK);
     return vxm_check_launch("vxm_conv3d_k3_s3u_bwd_weight");
 }
 

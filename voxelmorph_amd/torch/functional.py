@@ -63,8 +63,8 @@ def fp32_engine_note():
             "v_mfma_f32_16x16x4_f32")
 
 
-def _side_stream(dev):
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+def _side_stream(dev, which=0):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), which)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _SIDE_STREAMS[key]
@@ -504,6 +504,7 @@ def s3u_bwd_low(dz, cout, w, c0, cin, gxl, mask, mask_slope, B, D, H, W, lay=0):
 
 # layout flags of include/vxm_hip.h (OR-ed into `pieces`): a flagged tensor is channel-blocked [B][C/8][D][H][W][8]
 S3_IN0_BLOCKED, S3_IN1_BLOCKED, S3_OUT_BLOCKED = 0x100, 0x200, 0x400
+S3_BW_CONTRACT_ONLY, S3_BW_REDUCE_ONLY = 0x1000, 0x2000       # phase flags of the split backward-weight entry points (include/vxm_hip.h)
 
 
 def to_blocked(x):
@@ -608,13 +609,18 @@ def _claim_sink(p):
 
 
 class _Workspace:
-    """Grow-only scratch shared by the bwd-weight launches of one backward pass."""
+    """Grow-only scratch shared by the bwd-weight launches of one backward pass.  `deferred`: a list that collects the reductions of the
+    split weight-gradient kernels instead of running them behind their contraction (each then keeps a buffer of its own until it has run:
+    UnetFn.backward sends them to a third stream, see VXM_S3_BW_CONTRACT_ONLY in include/vxm_hip.h)."""
 
-    def __init__(self, device):
+    def __init__(self, device, deferred=None):
         self.buf = None
         self.device = device
+        self.deferred = deferred
 
     def get(self, nbytes):
+        if self.deferred is not None:
+            return torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         if self.buf is None or self.buf.numel() < nbytes:
             self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self.buf
@@ -624,9 +630,12 @@ def s3_bwd_weight(ws, x, c, bs, dz, cout, gw, gw_cin, ci_off, gb, B, D, H, W, la
     """weight / bias gradient of one full-resolution tensor on the split kernel (vxm_conv3d_k3_s3_bwd_weight)"""
     need = _lib.lib().vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(c, cout, B, D, H, W)
     buf = ws.get(need)
+    args = (ptr(x), c, bs, ptr(dz), cout * D * H * W, cout, ptr(gw), gw_cin, ci_off, ptr(gb), ptr(buf), buf.numel(), B, D, H, W)
+    flags = s3_pieces() | lay
     with _prof.region("k_s3_bwd_weight<%d>" % s3_pieces(), flops=2.0 * 27 * c * cout * B * D * H * W):
-        call("vxm_conv3d_k3_s3_bwd_weight", ptr(x), c, bs, ptr(dz), cout * D * H * W, cout, ptr(gw), gw_cin, ci_off, ptr(gb), ptr(buf), buf.numel(),
-             B, D, H, W, s3_pieces() | lay, stream())
+        call("vxm_conv3d_k3_s3_bwd_weight", *args, flags | (S3_BW_CONTRACT_ONLY if ws.deferred is not None else 0), stream())
+    if ws.deferred is not None:
+        ws.deferred.append(("vxm_conv3d_k3_s3_bwd_weight", args, flags | S3_BW_REDUCE_ONLY, (x, dz, gw, gb, buf)))
 
 
 def s3u_bwd_weight_route(c0, cout, B, D, H, W):
@@ -638,9 +647,12 @@ def s3u_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, gw_cin, B, D, H, W, lay=0):
     """gw[:, 0:c0] of a [cout][gw_cin][27] array: weight gradient of the x2-upsampled segment x0 [B,c0,D/2,H/2,W/2] against dz [B,cout,D,H,W]"""
     need = _lib.lib().vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes(c0, cout, B, D, H, W)
     buf = ws.get(need)
+    args = (ptr(x0), c0, bs0, ptr(dz), cout * D * H * W, cout, ptr(gw), gw_cin, ptr(buf), buf.numel(), B, D, H, W)
+    flags = s3_pieces() | lay
     with _prof.region("k_s3u_bww<%d>" % (c0 // 16), flops=2.0 * 8 * c0 * cout * B * D * H * W, nominal=2.0 * 27 * c0 * cout * B * D * H * W):
-        call("vxm_conv3d_k3_s3u_bwd_weight", ptr(x0), c0, bs0, ptr(dz), cout * D * H * W, cout, ptr(gw), gw_cin, ptr(buf), buf.numel(),
-             B, D, H, W, s3_pieces() | lay, stream())
+        call("vxm_conv3d_k3_s3u_bwd_weight", *args, flags | (S3_BW_CONTRACT_ONLY if ws.deferred is not None else 0), stream())
+    if ws.deferred is not None:
+        ws.deferred.append(("vxm_conv3d_k3_s3u_bwd_weight", args, flags | S3_BW_REDUCE_ONLY, (x0, dz, gw, buf)))
 
 
 def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H, W, lay=0):
@@ -1100,9 +1112,15 @@ class UnetFn(torch.autograd.Function):
         dev, dt = gout.device, gout.dtype
         gout = _c(gout)
         ws = _Workspace(dev)
-        ws_side = _Workspace(dev)
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if OVERLAP_SMALL_LEVELS else None
+        # The weight gradients run on a second stream beside the backward-data chain.  Their small reduction kernels (partials -> gw, gb) go to
+        # a THIRD stream: behind a contraction on the second stream, the few blocks of a reduction waited for the persistent blocks of the main
+        # stream's kernel to leave the chip -- and the next contraction waited with them (rocprofv3 trace, round 5: 450 - 585 us, three times per
+        # step; the second stream ended the step 0.45 ms after the main one).
+        red = _side_stream(dev, 1) if side is not None else None
+        pending = []
+        ws_side = _Workspace(dev, deferred=pending if red is not None else None)
         n_in = plan.n_inputs
         grads = [None] * (n_in + len(params))
         DZ = {}      # tensor id -> gradient w.r.t. the pre-activation of its producing conv
@@ -1191,10 +1209,23 @@ class UnetFn(torch.autograd.Function):
                     with torch.cuda.stream(side):
                         conv_bwd_weight(ws_side, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
                                         gw, gb, B, D, H, W, lay=lay_w)
+                        if pending:
+                            ev2 = torch.cuda.Event()
+                            ev2.record(side)
                     dz.record_stream(side)          # dz is released by the main-stream chain before the side stream may be done
                     for g, sink in ((gw, gw_sink), (gb, gb_sink)):
                         if sink is None:            # allocated on the main stream, written on the side stream
                             g.record_stream(side)
+                    if pending:                     # the reductions of the contractions just launched: third stream, behind them
+                        red.wait_event(ev2)
+                        with torch.cuda.stream(red):
+                            for name, args, flags, keep in pending:
+                                call(name, *args, flags, stream())
+                        for _, _, _, keep in pending:
+                            for t in keep:
+                                if t is not None:
+                                    t.record_stream(red)
+                        pending.clear()
                 else:
                     conv_bwd_weight(ws, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
                                     gw, gb, B, D, H, W, lay=lay_w)
@@ -1266,6 +1297,7 @@ class UnetFn(torch.autograd.Function):
             # side-stream launches that are still writing parameter gradients
             if side is not None:
                 main.wait_stream(side)          # gradients (and the activations the side stream read) are final past this point
+                main.wait_stream(red)
         return (None,) + tuple(grads)
 
 
