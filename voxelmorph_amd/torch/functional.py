@@ -44,6 +44,7 @@ S3_UP = os.environ.get("VXM_S3_UP", "") == "1"
 S3U = os.environ.get("VXM_S3U", "1") != "0"
 # channel-blocked interior tensors of the fused U-Net (tensors that only split kernels write and read: _blocked_tensors); VXM_BLOCKED=0: all planar
 BLOCKED = os.environ.get("VXM_BLOCKED", "1") != "0"
+BW_REDUCE_STREAM = os.environ.get("VXM_BW_REDUCE_STREAM", "") == "1"     # UnetFn.backward: weight-gradient reductions on a third stream (A/B: slower)
 _SIDE_STREAMS = {}
 
 
@@ -1118,7 +1119,10 @@ class UnetFn(torch.autograd.Function):
         # a THIRD stream: behind a contraction on the second stream, the few blocks of a reduction waited for the persistent blocks of the main
         # stream's kernel to leave the chip -- and the next contraction waited with them (rocprofv3 trace, round 5: 450 - 585 us, three times per
         # step; the second stream ended the step 0.45 ms after the main one).
-        red = _side_stream(dev, 1) if side is not None else None
+        # (same-box A/B after the change: 84.6 -> 83.2 pairs/s eager, 82.5 -> 81.3 replayed.  The contractions then share the chip with the main
+        # chain ALL the time, both slow down, and the main chain ends 0.38 ms later: the chip is saturated either way, the stalls were not idle
+        # capacity.  Kept behind VXM_BW_REDUCE_STREAM=1 with its measurement; default: reductions behind their contraction, as before.)
+        red = _side_stream(dev, 1) if (side is not None and BW_REDUCE_STREAM) else None
         pending = []
         ws_side = _Workspace(dev, deferred=pending if red is not None else None)
         n_in = plan.n_inputs
@@ -1297,7 +1301,8 @@ class UnetFn(torch.autograd.Function):
             # side-stream launches that are still writing parameter gradients
             if side is not None:
                 main.wait_stream(side)          # gradients (and the activations the side stream read) are final past this point
-                main.wait_stream(red)
+                if red is not None:
+                    main.wait_stream(red)
         return (None,) + tuple(grads)
 
 
