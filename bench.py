@@ -180,9 +180,9 @@ def fetch_factor(kernel):
     return 1.0 if kernel.startswith(("vecint", "warp3d", "k_vecint", "k_warp3d")) else 2.0
 
 
-def shader_clock(kernel, suffix=""):
-    """Shader clock the kernel ran at under the profiler (GHz): GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same --pmc pass, written
-    by tools/rocprof_summary.py into profiles/*_mfma_counters.json (same staleness rule as hbm_traffic: the kernel sources must match)."""
+def _counter_field(kernel, field, suffix=""):
+    """Mean of a per-kernel field of profiles/*_mfma_counters.json over the template instances a region label names (weighted by their
+    dispatch counts), or None -- same staleness rule as hbm_traffic: the summary must have been collected on THESE kernel sources."""
     path = _counter_file("*_mfma_counters%s.json" % suffix)
     if path is None:
         return None
@@ -196,10 +196,43 @@ def shader_clock(kernel, suffix=""):
     kernel_ns = kernel.replace(" ", "")
     stem = kernel_ns[:-1] if kernel_ns.endswith(">") else kernel_ns
     hits = [v for k, v in ctr.items() if k != "_meta" and (k.replace(" ", "") == kernel_ns or k.replace(" ", "").startswith(stem + ","))]
-    hits = [v for v in hits if "shader_clock_ghz" in v]
+    hits = [v for v in hits if field in v]
     if not hits:
         return None
-    return sum(v["shader_clock_ghz"] for v in hits) / len(hits)
+    wts = [float((v.get("GRBM_GUI_ACTIVE") or {}).get("dispatches", 1)) for v in hits]
+    return sum(v[field] * w for v, w in zip(hits, wts)) / sum(wts)
+
+
+def shader_clock(kernel, suffix=""):
+    """Shader clock the kernel ran at under the profiler (GHz): GRBM_GUI_ACTIVE / 8 XCDs / kernel duration of the same --pmc pass, written
+    by tools/rocprof_summary.py into profiles/*_mfma_counters.json."""
+    return _counter_field(kernel, "shader_clock_ghz", suffix)
+
+
+def mfma_util(kernel, suffix=""):
+    """Matrix-pipe utilisation of the kernel from the counters: SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)."""
+    return _counter_field(kernel, "mfma_util", suffix)
+
+
+def conv_mfma_util(stats, suffix=""):
+    """The north star's "MFMA utilisation of the U-Net convs": counter utilisation of every conv kernel of the per-kernel pass, weighted by the
+    time it takes per step (regions with FLOPs = the conv products); None without counters of this tree."""
+    rows, tot_ms, tot = {}, 0.0, 0.0
+    for name, st in stats.items():
+        if not st["flops"]:
+            continue
+        u = mfma_util(name, suffix)
+        if u is None:
+            continue
+        rows[name] = {"mfma_util": u, "ms": st["ms"]}
+        tot_ms += st["ms"]
+        tot += u * st["ms"]
+    if not rows:
+        return None
+    conv_ms = sum(st["ms"] for st in stats.values() if st["flops"])
+    return {"time_weighted": tot / tot_ms, "covered_fraction_of_conv_time": tot_ms / conv_ms if conv_ms else 0.0,
+            "per_kernel": {k: round(v["mfma_util"], 4) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])},
+            "source": "SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8) per kernel from the committed rocprofv3 --pmc summary of this tree"}
 
 
 def binding_roofline(name, st):
@@ -366,7 +399,7 @@ def register_extra(vxm, shape, dev, reps=10):
 class Workload:
     """One benchmark configuration: model + optimiser + synthetic batch resident in HBM + the training step."""
 
-    def __init__(self, vxm, vdist, name, shape, B, dev, rank, int_steps=None, comm=None):
+    def __init__(self, vxm, vdist, name, shape, B, dev, rank, int_steps=None, comm=None, graph=None):
         from voxelmorph_amd.optim import FlatAdam
         self.name, self.B, self.shape = name, B, shape
         self.bf16 = name in ("dense_bf16", "diffeo_bf16")
@@ -398,7 +431,8 @@ class Workload:
         from voxelmorph_amd.graph import GraphedStep
         self.pace = InFlight(2)
         # the step is submitted as ONE hipGraph launch (voxelmorph_amd/graph.py) after two eager steps; VXM_GRAPH=0: every launch from Python
-        self.graphed = GraphedStep(self._forward_loss, self.opt, eager_steps=2, enabled=os.environ.get("VXM_GRAPH", "1") != "0")
+        self.graphed = GraphedStep(self._forward_loss, self.opt, eager_steps=2,
+                                   enabled=(os.environ.get("VXM_GRAPH", "1") != "0") if graph is None else bool(graph))
         if self.trained:
             self._make_trained_flow()
 
@@ -650,6 +684,7 @@ def main():
         torch.cuda.empty_cache()
         for key, name, eb, esteps in (("dense_bf16", "dense_bf16", 1, 8), ("diffeo_fp32_4_pairs_per_gpu", "diffeo_fp32", 4, 4),
                                       ("semisup_fp32", "semisup_fp32", 1, 8), ("diffeo_fp32_trained_flow", "diffeo_fp32_trained_flow", 1, 8),
+                                      ("diffeo_fp32_eager_submission", "diffeo_fp32", 1, 12),
                                       ("diffeo_fp32_bf16x3_engine", "diffeo_fp32", 1, 8),
                                       ("diffeo_fp32_native_engine", "diffeo_fp32", 1, 8)):
             engine = VF.FP32_ENGINE
@@ -662,7 +697,11 @@ def main():
                     if engine == "split":
                         continue
                     VF.FP32_ENGINE = "split"
-                w2 = Workload(vxm, vdist, name, shape, eb, dev, rank)
+                # (the headline step submitted launch by launch from Python instead of as one hipGraph launch: faster by ~2 % on a warm host --
+                # the replayed graph's branches overlap less -- and slower on a cold one; skipped when the headline itself ran that way)
+                if key == "diffeo_fp32_eager_submission" and os.environ.get("VXM_GRAPH", "1") == "0":
+                    continue
+                w2 = Workload(vxm, vdist, name, shape, eb, dev, rank, graph=False if key == "diffeo_fp32_eager_submission" else None)
                 # warm-up = the timed pattern itself (esteps steps enqueued back to back): the caching allocator only reaches its steady
                 # state under the run-ahead of the real loop (blocks held by the side stream's pending events are not reusable yet); with two
                 # synchronous warm-up steps a hipMalloc of several hundred ms could land inside the timed region
@@ -714,6 +753,7 @@ def main():
     roof["measured_in"] = "per-kernel pass: %d steps with HIP-event bracketing, %.3f ms/step (the `value` pass runs un-instrumented)" % (
         ksteps, 1e3 * elapsed_k / ksteps)
     roof["shader_clock_ghz"] = shader_clock(dom, "_bf16" if bf16 else "")     # under the profiler's counter pass; null without a matching profile
+    roof["mfma_util"] = mfma_util(dom, "_bf16" if bf16 else "")               # counter utilisation of the matrix pipe, beside `frac`
     stv = [k for k in stats if k.startswith(("warp3d", "vecint"))]
     st_bytes, st_ms = sum(stats[k]["bytes"] for k in stv), sum(stats[k]["ms"] for k in stv)
     out = {
@@ -734,6 +774,9 @@ def main():
         "host_enqueue_ms_per_step": host_ms,        # rank 0's host time per step of the value pass (hipGraphLaunch, or Python + launches when eager), without the pacing wait
         "submission": submission,                   # value pass: graph replays vs eager steps, caching-allocator activity inside the timed region
     }
+    cmu = conv_mfma_util(stats, "_bf16" if bf16 else "")
+    if cmu is not None:
+        out["conv_mfma_util"] = cmu
     if comm_ev is not None:
         out["comm"] = comm_ev
     if extra:
