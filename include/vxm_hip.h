@@ -372,6 +372,10 @@ int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W);
  * whatever shares the chip, and the NEXT contraction of that stream waits with them (measured: 450 - 585 us stalls, three per step).  With
  * CONTRACT_ONLY the call stops after the contraction; a second call with REDUCE_ONLY (same arguments, same `work`, any stream that waits
  * for the first) finishes it -- the fused U-Net backward sends the reductions to a third stream.  Neither flag: both, as before. */
+/* Scheduling hint of vxm_conv3d_k3_s3_fwd, OR-ed into `pieces` like the flags above: walk the output tiles from the END of the tensor.  Same
+ * results bit for bit; a launch that reads what the previous launch has just written starts where its producer stopped and finds that
+ * part of the tensor in the memory-side cache (256 MB against 440 - 880 MB tensors). */
+#define VXM_S3_REVERSE_TILES 0x4000
 #define VXM_S3_BW_CONTRACT_ONLY 0x1000
 #define VXM_S3_BW_REDUCE_ONLY 0x2000
 int vxm_conv3d_k3_s3_layout_ok(int C0, int C1, int x0_up, int Cout, int H, int pieces);

@@ -36,6 +36,10 @@
 namespace {
 
 constexpr int S3_TD = 8, S3_THREADS = 512, S3_HWV = 18;
+// launch flag VXM_S3_REVERSE_TILES (include/vxm_hip.h; travels inside `lay`): walk the tiles from the END of the tensor.  A layer that
+// reads what the previous launch has just written finds the last-written part of it in the memory-side cache (256 MB on MI355X, the tensors
+// are 440 - 880 MB) when it starts where its producer stopped; in the same direction the cache holds the wrong end.
+constexpr int S3_REVERSE_TILES = VXM_S3_REVERSE_TILES;
 
 // Which unit (kd, kw, 8-channel block) lane group kg multiplies in K-step s.  A ds_read_b128 is served in four groups of 16 lanes
 // that pair lanes of kg 0 with lanes of kg 1 (and kg 2 with kg 3; MI355X_MICROARCH.md, LDS): a group is conflict-free only when
@@ -124,7 +128,7 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
         int tid = tid_;
         asm volatile("" : "+v"(tid));
         const bool live = tile < t_hi;                        // past the block's last tile: every slot is padding, nothing is fetched
-        const int tl = live ? tile : t_lo;
+        const int tl = (lay & S3_REVERSE_TILES) ? ntiles - 1 - (live ? tile : t_lo) : (live ? tile : t_lo);
         int tw = tl % nw; int tq = tl / nw;
         int th = tq % nh; tq /= nh;
         int td = tq % nd;
@@ -466,7 +470,8 @@ k_s3p_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bi
     const int V = D * H * W;
     const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
     const int V0 = in.up0 ? Dl * Hl * Wl : V;
-    auto tile_origin = [&](int tl, int& bt, int& d0, int& h0, int& w0) __attribute__((always_inline)) {
+    auto tile_origin = [&](int tl_, int& bt, int& d0, int& h0, int& w0) __attribute__((always_inline)) {
+        const int tl = (lay & S3_REVERSE_TILES) ? ntiles - 1 - tl_ : tl_;       // walk the tensor from its end (see S3_REVERSE_TILES)
         const int tw = tl % nw; int tq = tl / nw;
         const int th = tq % nh; tq /= nh;
         const int td = tq % nd;
@@ -1552,7 +1557,8 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
     const int pieces = pieces_and_layout & 0xff, lay = pieces_and_layout & ~0xff;
     VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3_fwd: null pointer");
     VXM_REQUIRE(s3_pieces_ok(pieces), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_fwd: pieces = %d (3: bf16, 2: fp16)", pieces);
-    VXM_REQUIRE(lay == 0 || ((lay & ~(VXM_S3_IN0_BLOCKED | VXM_S3_OUT_BLOCKED)) == 0 && vxm_conv3d_k3_s3_layout_ok(C0, C1, x0_up, Cout, H, pieces)), VXM_ERR_BAD_SHAPE,
+    const int lay_ = lay & ~VXM_S3_REVERSE_TILES;                        // (a scheduling hint, not a layout: taken off before the layout checks)
+    VXM_REQUIRE(lay_ == 0 || ((lay_ & ~(VXM_S3_IN0_BLOCKED | VXM_S3_OUT_BLOCKED)) == 0 && vxm_conv3d_k3_s3_layout_ok(C0, C1, x0_up, Cout, H, pieces)), VXM_ERR_BAD_SHAPE,
                 "vxm_conv3d_k3_s3_fwd: layout flags 0x%x are not available for this launch (%d + %d -> %d channels, upsampled %d, H = %d, pieces %d)", lay, C0, C1,
                 Cout, x0_up, H, pieces);
     if (int e = check_conv("vxm_conv3d_k3_s3_fwd", C0, C1, x0_up, Cout, B, D, H, W)) return e;

@@ -505,6 +505,10 @@ def s3u_bwd_low(dz, cout, w, c0, cin, gxl, mask, mask_slope, B, D, H, W, lay=0):
 
 # layout flags of include/vxm_hip.h (OR-ed into `pieces`): a flagged tensor is channel-blocked [B][C/8][D][H][W][8]
 S3_IN0_BLOCKED, S3_IN1_BLOCKED, S3_OUT_BLOCKED = 0x100, 0x200, 0x400
+S3_REVERSE_TILES = 0x4000                                     # scheduling hint of vxm_conv3d_k3_s3_fwd (include/vxm_hip.h)
+# consecutive full-resolution launches of the fused U-Net walk their tensors in alternating directions (a consumer starts where its producer
+# stopped: the last-written part of a 440 - 880 MB tensor is what the 256 MB memory-side cache still holds); VXM_S3_SNAKE=0: all forward
+SNAKE = os.environ.get("VXM_S3_SNAKE", "1") != "0"
 S3_BW_CONTRACT_ONLY, S3_BW_REDUCE_ONLY = 0x1000, 0x2000       # phase flags of the split backward-weight entry points (include/vxm_hip.h)
 
 
@@ -584,11 +588,12 @@ def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W, w_lo=0, la
     bounds = _bwd_bounds(cin)
     for lo, hi in zip(bounds[:-1], bounds[1:]):         # w_lo: gx covers the input channels [w_lo, w_lo + cin) of w
         if s3_route(cout, False, 0, hi - lo, B, D, H, W):
-            if lay & S3_OUT_BLOCKED and (lo, hi) != (0, cin):
+            if lay & S3_OUT_BLOCKED and (lo, hi) != (0, cin):   # (S3_REVERSE_TILES needs no such care: every launch of the pair walks backwards)
                 raise RuntimeError("conv_bwd_data: a channel-blocked gradient is written by one launch")
             s3_launch(dz, cout, cout * V, False, None, 0, 0, s3_pack(w, True, w_lo + lo, w_lo + hi, cout), None, gx[:, lo:hi], cin * V, hi - lo,
                       1.0, mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W, lay=lay)
             continue
+        lay &= ~S3_REVERSE_TILES                         # a scheduling hint of the split kernels only
         _need_split_kernel(lay, "conv_bwd_data")
         conv_launch(dz, cout, cout * V, False, None, 0, 0, pack_weights(w, True, w_lo + lo, w_lo + hi), None, gx[:, lo:hi], cin * V, hi - lo, 1.0,
                     mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W)
@@ -1059,6 +1064,7 @@ class UnetFn(torch.autograd.Function):
                 _prepack_plan(plan, params, B, shape3, want_bwd, want_in)
                 _adopt_fresh_packs(None)
         blocked = _blocked_tensors(plan, B, shape3)
+        walked_back = set()          # tensors whose producer walked its tiles from the end (S3_REVERSE_TILES)
         for n_op, op in enumerate(plan.ops):
             if packs_ready is not None and n_op >= first_packed:
                 torch.cuda.current_stream(dev).wait_event(packs_ready)
@@ -1072,6 +1078,10 @@ class UnetFn(torch.autograd.Function):
                 w, b = params[2 * op["k"]], params[2 * op["k"] + 1]
                 x0, x1 = T[s0], (T[s1] if s1 is not None else None)
                 lay = (S3_IN0_BLOCKED if s0 in blocked else 0) | (S3_OUT_BLOCKED if dst in blocked else 0)
+                if SNAKE and not up0 and s1 is None and s0 >= plan.n_inputs and plan.lvl[dst] == 0 and plan.ch[dst] > 4 and s0 not in walked_back \
+                        and s3_route(plan.ch[s0], False, 0, plan.ch[dst], B, D, H, W):
+                    lay |= S3_REVERSE_TILES
+                    walked_back.add(dst)
                 conv_forward(x0, plan.ch[s0], x0[0].numel(), up0, x1, plan.ch[s1] if s1 is not None else 0,
                              x1[0].numel() if x1 is not None else 0, w, b, out, plan.ch[dst] * V, plan.ch[dst], op["slope"], B, D, H, W, lay=lay)
             elif op["kind"] == "pool":
@@ -1127,6 +1137,7 @@ class UnetFn(torch.autograd.Function):
         ws_side = _Workspace(dev, deferred=pending if red is not None else None)
         n_in = plan.n_inputs
         grads = [None] * (n_in + len(params))
+        dz_back = set()   # tensor ids whose gradient DZ[.] was written from the end (S3_REVERSE_TILES)
         DZ = {}      # tensor id -> gradient w.r.t. the pre-activation of its producing conv
         GP = {}      # pool-output id -> gradient w.r.t. the pooled tensor
         GS = {}      # tensor id -> (buffer, element offset, batch stride): skip-branch gradient view
@@ -1270,8 +1281,12 @@ class UnetFn(torch.autograd.Function):
                 gx = torch.empty((B, cin, D, H, W), dtype=dt, device=dev)
                 if fuse:   # dX * LeakyReLU'(y_prev) in the epilogue == DZ of the previous ConvBlock
                     pslope = plan.ops[plan.producer[s0]]["slope"]
+                    rev = 0
+                    if SNAKE and plan.lvl[dst] == 0 and dst not in dz_back and _bwd_bounds(cin) == [0, cin] and s3_route(cout, False, 0, cin, B, D, H, W):
+                        rev = S3_REVERSE_TILES          # (dropped by conv_bwd_data when the launch is not a split kernel's)
+                        dz_back.add(s0)
                     conv_bwd_data(dz, cout, w, gx, cin, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W,
-                                  lay=lay_d | (S3_OUT_BLOCKED if x_blk else 0))
+                                  lay=lay_d | (S3_OUT_BLOCKED if x_blk else 0) | rev)
                     DZ[s0] = gx
                     continue
                 if x_blk:
