@@ -316,7 +316,8 @@ int vxm_bf16_conv_pack_weights_batch(const VxmBf16PackJob* jobs, int n_jobs, voi
 /* conv3d(k3,p1) over the virtual concat [x0 (optionally nearest-x2 upsampled) | x1] + bias + LeakyReLU(leaky_slope).
  * out_planar_f32 = 0: y blocked bf16 with Cout (multiple of 16) channels, optionally multiplied by LeakyReLU'(mask)
  * (mask: blocked, Cout channels; the fused leaky_relu_backward of backward-data).  out_planar_f32 = 1: y fp32
- * [B][Cout <= 4][D][H][W] (the flow head).  Backward-data = this entry point with transpose_flip-packed weights. */
+ * [B][Cout <= 4][D][H][W] (the flow head).  Backward-data = this entry point with transpose_flip-packed weights.
+ * out_planar_f32 | 2: scheduling hint, walk the output tiles from the end of the tensor (as VXM_S3_REVERSE_TILES; same results). */
 int vxm_bf16_conv_fwd(const void* x0, int C0, int x0_up, const void* x1, int C1, const void* wpacked, const float* bias, void* y,
                       int Cout, int out_planar_f32, float leaky_slope, const void* mask, float mask_slope,
                       int B, int D, int H, int W, void* stream);

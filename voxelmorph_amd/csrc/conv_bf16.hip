@@ -38,6 +38,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t bf_rsrc(const void* p, unsigne
 struct BfIn {                  // virtual concat of two blocked tensors (channel counts in 8-channel blocks, both even)
     const void* x0; const void* x1;
     int CB0, CB1, up0;
+    int rev;                   // walk the output tiles from the end of the tensor (scheduling hint: see VXM_S3_REVERSE_TILES in include/vxm_hip.h)
 };
 
 constexpr int BF_TD = 8, BF_THREADS = 512, BF_HWV = 18, BF_STEPS = 5;
@@ -75,6 +76,7 @@ __global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x
     } else if (tile >= ntiles) {
         return;
     }
+    if (in.rev) tile = ntiles - 1 - tile;
     const int tw = tile % nw; int tq = tile / nw;
     const int th = tq % nh; tq /= nh;
     const int td = tq % nd; const int b = tq / nd;
@@ -859,9 +861,10 @@ int vxm_bf16_conv_fwd(const void* x0, int C0, int x0_up, const void* x1, int C1,
     VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_bf16_conv_fwd: null pointer");
     if (int e = bf_check("vxm_bf16_conv_fwd", C0, C1, x0_up, Cout, B, D, H, W)) return e;
     VXM_REQUIRE(bf_al16(x0) && bf_al16(x1) && bf_al16(wpacked) && bf_al16(y) && bf_al16(mask), VXM_ERR_BAD_SHAPE, "vxm_bf16_conv_fwd: 16-byte alignment");
-    VXM_REQUIRE(out_planar_f32 ? (Cout <= 4 && !mask) : (Cout % 16 == 0), VXM_ERR_BAD_SHAPE,
+    VXM_REQUIRE((out_planar_f32 & 1) ? (Cout <= 4 && !mask) : (Cout % 16 == 0), VXM_ERR_BAD_SHAPE,
                 "vxm_bf16_conv_fwd: %d output channels (blocked outputs: multiples of 16; planar fp32 outputs: at most 4, no mask)", Cout);
-    const BfIn in = {x0, x1, C0 / 8, C1 / 8, x0_up ? 1 : 0};
+    const BfIn in = {x0, x1, C0 / 8, C1 / 8, x0_up ? 1 : 0, (out_planar_f32 & 2) ? 1 : 0};
+    out_planar_f32 &= 1;
     hipStream_t s = VXM_STREAM(stream);
     if (out_planar_f32) bf_launch_conv<1, 8, 1>(in, wpacked, bias, y, Cout, leaky_slope, nullptr, 1.0f, B, D, H, W, s);
     else if (bf_nct(Cout) == 1) bf_launch_conv<1, 8, 0>(in, wpacked, bias, y, Cout, leaky_slope, mask, mask_slope, B, D, H, W, s);
@@ -875,7 +878,7 @@ int vxm_bf16_conv_bwd_data_up(const void* dz, int Cdz, const void* wpacked, void
     if (int e = bf_check("vxm_bf16_conv_bwd_data_up", Cdz, 0, 1, Cout, B, D, H, W)) return e;
     VXM_REQUIRE(Cout % 16 == 0, VXM_ERR_BAD_SHAPE, "vxm_bf16_conv_bwd_data_up: %d output channels (multiples of 16)", Cout);
     VXM_REQUIRE(bf_al16(dz) && bf_al16(wpacked) && bf_al16(dx_low) && bf_al16(mask_low), VXM_ERR_BAD_SHAPE, "vxm_bf16_conv_bwd_data_up: 16-byte alignment");
-    const BfIn in = {dz, nullptr, Cdz / 8, 0, 0};
+    const BfIn in = {dz, nullptr, Cdz / 8, 0, 0, 0};
     hipStream_t s = VXM_STREAM(stream);
     if (bf_nct(Cout) == 1) bf_launch_conv<1, 8, 2>(in, wpacked, nullptr, dx_low, Cout, 1.0f, mask_low, mask_slope, B, D, H, W, s);
     else bf_launch_conv<2, 6, 2>(in, wpacked, nullptr, dx_low, Cout, 1.0f, mask_low, mask_slope, B, D, H, W, s);
@@ -902,7 +905,7 @@ int vxm_bf16_conv_bwd_weight(const void* x0, int C0, int x0_up, const void* x1, 
     const BwbTasks tk = bwb_tasks(Q, B, D, H, W, NBLK);
     VXM_REQUIRE(work_bytes >= (size_t)NBLK * Q * BWB_TD * 28 * (16 * NCO) * 16 * sizeof(float), VXM_ERR_BAD_SHAPE,
                 "vxm_bf16_conv_bwd_weight: workspace too small");
-    const BfIn in = {x0, x1, C0 / 8, C1 / 8, x0_up ? 1 : 0};
+    const BfIn in = {x0, x1, C0 / 8, C1 / 8, x0_up ? 1 : 0, 0};
     hipStream_t s = VXM_STREAM(stream);
     float* part = static_cast<float*>(work);
     auto launch = [&](auto kern, int lds) {

@@ -149,15 +149,23 @@ def _pack_jobs(plan, params, cin0, with_backward, input_grads):
     return jobs
 
 
+_WALK_BACK = [False]       # direction of the last full-resolution conv launch (snake order: see functional.SNAKE)
+
+
 def conv(x0, c0, up0, x1, c1, wp, bias, y, cout, planar, slope, mask, mask_slope, B, D, H, W):
     nct = 1 if (planar or cout <= 16) else 2
     V = B * D * H * W
+    from . import functional as VF
+    rev = 0
+    if VF.SNAKE and D * H * W >= (1 << 21):          # consecutive full-resolution launches walk their tensors in alternating directions
+        _WALK_BACK[0] = not _WALK_BACK[0]
+        rev = 2 if _WALK_BACK[0] else 0
     # algorithmic bytes: every operand element read once (the upsampled segment at its own resolution), every result written once
     nbytes = 2.0 * (c0 * (V // 8 if up0 else V) + c1 * V) + (4.0 if planar else 2.0) * cout * V + (2.0 * cout * V if mask is not None else 0.0)
     with _prof.region("k_bf16_conv<%d,%d,%d>" % (nct, 6 if nct == 2 else 8, 1 if planar else 0),
                       flops=2.0 * 27 * (c0 + c1) * (16 * nct * ((cout + 16 * nct - 1) // (16 * nct))) * B * D * H * W,
                       nbytes=nbytes, nominal=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
-        call("vxm_bf16_conv_fwd", ptr(x0), c0, 1 if up0 else 0, ptr(x1), c1, ptr(wp), ptr(bias), ptr(y), cout, 1 if planar else 0,
+        call("vxm_bf16_conv_fwd", ptr(x0), c0, 1 if up0 else 0, ptr(x1), c1, ptr(wp), ptr(bias), ptr(y), cout, (1 if planar else 0) | rev,
              float(slope), ptr(mask), float(mask_slope), B, D, H, W, stream())
 
 
