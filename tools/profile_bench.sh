@@ -8,10 +8,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 STEPS=4; WARM=2
-# bench.py runs warm-up + the timed pass + the per-kernel pass (min(steps, 10) more steps): all of them are dispatches the profiler sees
-export VXM_PROFILED_STEPS=$((STEPS + WARM + (STEPS < 10 ? STEPS : 10)))
+# bench.py runs warm-up + the timed pass + one eager step that re-populates the allocator after the capture + the per-kernel pass
+# (min(steps, 10) more steps): all of them are dispatches the profiler sees (a replayed hipGraph dispatches the same kernels)
+export VXM_PROFILED_STEPS=$((STEPS + WARM + 1 + (STEPS < 10 ? STEPS : 10)))
 SUF=${VXM_PROFILE_SUFFIX:-}
-ARGS="--steps $STEPS --warmup $WARM --no-cpu-baseline --no-extra-configs $*"
+ARGS="--steps $STEPS --warmup $WARM --no-cpu-baseline --no-gpu-baseline --no-extra-configs $*"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py $ARGS > $OUT/bench_stats.log 2>&1
 # the same, with every launch on ONE stream (VXM_NO_OVERLAP=1): the sum of kernel time is the step, small kernels are not inflated by sharing
 # the chip with the second stream's weight-gradient launches
