@@ -195,8 +195,16 @@ def _counter_field(kernel, field, suffix=""):
         return None
     kernel_ns = kernel.replace(" ", "")
     stem = kernel_ns[:-1] if kernel_ns.endswith(">") else kernel_ns
-    hits = [v for k, v in ctr.items() if k != "_meta" and (k.replace(" ", "") == kernel_ns or k.replace(" ", "").startswith(stem + ","))]
-    hits = [v for v in hits if field in v]
+    hits = []
+    while True:            # a region label carries (some of) the template arguments of its kernel, not always in the instance's terms
+        # ("k_s3p_conv<1,2>" = NCT, pieces against the instance "k_s3p_conv<1, true>" = NCT, BLK): drop trailing arguments until something matches
+        hits = [v for k, v in ctr.items() if k != "_meta" and (k.replace(" ", "") == kernel_ns or k.replace(" ", "").startswith(stem + ",")
+                                                               or k.replace(" ", "").startswith(stem + ">") or k.replace(" ", "") == stem
+                                                               or ("<" not in stem and k.replace(" ", "").startswith(stem + "<")))]
+        hits = [v for v in hits if field in v]
+        if hits or "<" not in stem:
+            break
+        stem = stem[:stem.rindex(",")] if "," in stem[stem.index("<"):] else stem[:stem.index("<")]
     if not hits:
         return None
     wts = [float((v.get("GRBM_GUI_ACTIVE") or {}).get("dispatches", 1)) for v in hits]
