@@ -44,6 +44,12 @@ S3_UP = os.environ.get("VXM_S3_UP", "") == "1"
 S3U = os.environ.get("VXM_S3U", "1") != "0"
 # channel-blocked interior tensors of the fused U-Net (tensors that only split kernels write and read: _blocked_tensors); VXM_BLOCKED=0: all planar
 BLOCKED = os.environ.get("VXM_BLOCKED", "1") != "0"
+# UnetFn.backward: enqueue a layer's weight gradient (second stream) AFTER its backward-data launches (main stream) instead of before them.
+# Same dependencies; in a captured graph the order of node creation decides which child of the dz producer stays on its queue.
+# Default: "after" while a hipGraph is being captured (same-box A/B of the replayed step: 80.4 / 81.3 -> 83.4 / 82.4 pairs/s; the replay then keeps
+# the main chain on one queue and every weight gradient on a second one, as launch-by-launch submission does: 7.0 ms of overlap and 0.05 ms
+# idle per step instead of 3.7 and 0.14), "before" otherwise (launch by launch: 83.4 / 81.6 against 82.0 / 81.2).  VXM_DW_ORDER=before|after forces one.
+DW_ORDER = os.environ.get("VXM_DW_ORDER", "")
 BW_REDUCE_STREAM = os.environ.get("VXM_BW_REDUCE_STREAM", "") == "1"     # UnetFn.backward: weight-gradient reductions on a third stream (A/B: slower)
 _SIDE_STREAMS = {}
 
@@ -1163,7 +1169,11 @@ class UnetFn(torch.autograd.Function):
             GCAT = gout
 
         try:
+            deferred_dw = None
             for n in range(len(plan.ops) - 1, -1, -1):
+                if deferred_dw is not None:
+                    deferred_dw()
+                    deferred_dw = None
                 op = plan.ops[n]
                 dst = op["dst"]
                 D, H, W = _dims(shape3, plan.lvl[dst])
@@ -1219,28 +1229,35 @@ class UnetFn(torch.autograd.Function):
                     # Below full resolution neither product fills the chip (a few hundred tiles on 256 CUs): the weight gradient
                     # of this block runs on a second stream beside the backward-data chain it does not feed.
                     ev = torch.cuda.Event()
-                    ev.record(main)
-                    side.wait_event(ev)
-                    with torch.cuda.stream(side):
-                        conv_bwd_weight(ws_side, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
-                                        gw, gb, B, D, H, W, lay=lay_w)
-                        if pending:
-                            ev2 = torch.cuda.Event()
-                            ev2.record(side)
-                    dz.record_stream(side)          # dz is released by the main-stream chain before the side stream may be done
-                    for g, sink in ((gw, gw_sink), (gb, gb_sink)):
-                        if sink is None:            # allocated on the main stream, written on the side stream
-                            g.record_stream(side)
-                    if pending:                     # the reductions of the contractions just launched: third stream, behind them
-                        red.wait_event(ev2)
-                        with torch.cuda.stream(red):
-                            for name, args, flags, keep in pending:
-                                call(name, *args, flags, stream())
-                        for _, _, _, keep in pending:
-                            for t in keep:
-                                if t is not None:
-                                    t.record_stream(red)
-                        pending.clear()
+                    ev.record(main)                 # dz is final here: the weight gradient may start, whenever it is enqueued
+
+                    def launch_dw(ev=ev, x0=x0, c0=c0, up0=up0, x1=x1, c1=c1, dz=dz, cout=cout, gw=gw, gb=gb, gw_sink=gw_sink, gb_sink=gb_sink,
+                                  D=D, H=H, W=W, lay_w=lay_w):
+                        side.wait_event(ev)
+                        with torch.cuda.stream(side):
+                            conv_bwd_weight(ws_side, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
+                                            gw, gb, B, D, H, W, lay=lay_w)
+                            if pending:
+                                ev2 = torch.cuda.Event()
+                                ev2.record(side)
+                        dz.record_stream(side)          # dz is released by the main-stream chain before the side stream may be done
+                        for g, sink in ((gw, gw_sink), (gb, gb_sink)):
+                            if sink is None:            # allocated on the main stream, written on the side stream
+                                g.record_stream(side)
+                        if pending:                     # the reductions of the contractions just launched: third stream, behind them
+                            red.wait_event(ev2)
+                            with torch.cuda.stream(red):
+                                for name, args, flags, keep in pending:
+                                    call(name, *args, flags, stream())
+                            for _, _, _, keep in pending:
+                                for t in keep:
+                                    if t is not None:
+                                        t.record_stream(red)
+                            pending.clear()
+                    if DW_ORDER == "after" or (DW_ORDER != "before" and torch.cuda.is_current_stream_capturing()):
+                        deferred_dw = launch_dw     # enqueued behind this op's backward-data launches (top of the next iteration)
+                    else:
+                        launch_dw()
                 else:
                     conv_bwd_weight(ws, x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if x1 is not None else 0, dz, cout,
                                     gw, gb, B, D, H, W, lay=lay_w)
@@ -1311,6 +1328,8 @@ class UnetFn(torch.autograd.Function):
                     if not any(plan.ops[m]["kind"] == "pool" for m in plan.consumers[s1]):
                         g = GS.pop(s1)
                         finish_conv_output(s1, g[0].view(-1)[g[1]:], g[2])
+            if deferred_dw is not None:
+                deferred_dw()
         finally:
             # also on an exception half-way: later main-stream work (zero_grad, Adam on the bucket) must not race with
             # side-stream launches that are still writing parameter gradients
