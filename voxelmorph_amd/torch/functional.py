@@ -938,11 +938,12 @@ def _s3_jobs(plan, params, B, shape3, with_backward, input_grads):
     return jobs
 
 
-def _prepack_plan(plan, params, B, shape3, with_backward, input_grads):
+def _prepack_plan(plan, params, B, shape3, with_backward, input_grads, dry=False):
     """Every packed operator one pass over `plan` will ask for, built now: the split operators in one batched launch (_s3_jobs), the collapsed
     operators of the cat([upsample, skip]) layers (forward: k_s3u_conv; backward-data onto the low-resolution tensor: k_s3u_dlow) one by one.
-    Returns the index of the first op that reads one of them (len(ops) when none does)."""
-    s3_prepack(_s3_jobs(plan, params, B, shape3, with_backward, input_grads))
+    Returns the index of the first op that reads one of them (len(ops) when none does); dry: only that index, nothing is launched."""
+    if not dry:
+        s3_prepack(_s3_jobs(plan, params, B, shape3, with_backward, input_grads))
     first = len(plan.ops)
     for n, op in enumerate(plan.ops):
         if op["kind"] != "conv":
@@ -957,9 +958,10 @@ def _prepack_plan(plan, params, B, shape3, with_backward, input_grads):
         D, H, W = _dims(shape3, plan.lvl[op["dst"]])
         uses = cout > 4 and s3_route(c0, up0, c1, cout, B, D, H, W)
         if up0 and cout > 4 and s3u_route(c0, c1, cout, B, D, H, W):
-            s3u_pack(w, c0, c1)
+            if not dry:
+                s3u_pack(w, c0, c1)
             uses = True
-        if up0 and with_backward and s3u_bwd_low_route(c0, cout, B, D, H, W) and plan.ops[plan.producer[s0]]["kind"] == "conv" \
+        if not dry and up0 and with_backward and s3u_bwd_low_route(c0, cout, B, D, H, W) and plan.ops[plan.producer[s0]]["kind"] == "conv" \
                 and len(plan.consumers[s0]) == 1:
             s3u_bwd_low_pack(w, c0, c0 + c1)
         if uses:
@@ -1050,7 +1052,7 @@ class UnetFn(torch.autograd.Function):
         for i, t in T.items():
             if t.shape[1] != plan.ch[i] or t.shape[0] != B or tuple(t.shape[2:]) != shape3:
                 raise ValueError("Unet: input %d has shape %s, expected [%d,%d,%s]" % (i, tuple(t.shape), B, plan.ch[i], shape3))
-        packs_ready, first_packed = None, len(plan.ops)
+        packs_ready, first_packed, packs_late = None, len(plan.ops), False
         if split_engine():
             # The packed operators (weight scales, pre-split pieces, collapsed upsample operators: ~10 small launches, 0.25 ms in a row) are
             # rebuilt once per optimiser step.  They go to the second stream and run beside the first layers, which do not read them; the
@@ -1060,18 +1062,32 @@ class UnetFn(torch.autograd.Function):
                 main, side = torch.cuda.current_stream(dev), _side_stream(dev)
                 fork = torch.cuda.Event()
                 fork.record(main)
-                side.wait_event(fork)
-                with torch.cuda.stream(side):
-                    first_packed = _prepack_plan(plan, params, B, shape3, want_bwd, want_in)
-                    packs_ready = torch.cuda.Event()
-                    packs_ready.record(side)
-                _adopt_fresh_packs(main)
+
+                def launch_packs():
+                    side.wait_event(fork)
+                    with torch.cuda.stream(side):
+                        _prepack_plan(plan, params, B, shape3, want_bwd, want_in)
+                        ready = torch.cuda.Event()
+                        ready.record(side)
+                    _adopt_fresh_packs(main)
+                    return ready
+                first_packed = _prepack_plan(plan, params, B, shape3, want_bwd, want_in, dry=True)
+                # While a hipGraph is being captured the packs are enqueued BEHIND the layers that do not read them (a graph runs by its edges,
+                # not by enqueue order, and the first child created of a node keeps its queue: the main chain should, see DW_ORDER); launch by
+                # launch they must be enqueued first to run beside those layers.
+                packs_late = torch.cuda.is_current_stream_capturing() and first_packed > 0
+                if not packs_late:
+                    packs_ready = launch_packs()
             else:
+                packs_late = False
                 _prepack_plan(plan, params, B, shape3, want_bwd, want_in)
                 _adopt_fresh_packs(None)
         blocked = _blocked_tensors(plan, B, shape3)
         walked_back = set()          # tensors whose producer walked its tiles from the end (S3_REVERSE_TILES)
         for n_op, op in enumerate(plan.ops):
+            if packs_late and n_op >= first_packed:
+                packs_ready = launch_packs()
+                packs_late = False
             if packs_ready is not None and n_op >= first_packed:
                 torch.cuda.current_stream(dev).wait_event(packs_ready)
                 packs_ready = None
@@ -1103,6 +1119,8 @@ class UnetFn(torch.autograd.Function):
         # The returned tensor must not be reachable from ctx except through save_for_backward: out.grad_fn is this
         # node, so `ctx.T[plan.out] = out` would be a reference cycle that keeps EVERY activation of the step alive
         # until Python's cyclic GC runs (tens of GB per step at 160x192x224).
+        if packs_late:
+            packs_ready = launch_packs()
         if packs_ready is not None:             # no op of this plan read a packed operator: still join the second stream
             torch.cuda.current_stream(dev).wait_event(packs_ready)
         out = T.pop(plan.out)

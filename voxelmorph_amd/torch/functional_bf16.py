@@ -296,7 +296,11 @@ class UnetBf16Fn(torch.autograd.Function):
         call("vxm_bf16_to_blocked", ptr(gout), cout, gout[0].numel(), None, 0, 0, ptr(g_blk), _pad16(cout), B, D * H * W, stream())
         DZ[plan.out] = g_blk if ctx.planar_out else lrelu_bwd(g_blk, T[plan.out], out_op["slope"])
 
+        deferred_dw = None
         for n in range(len(plan.ops) - 1, -1, -1):
+            if deferred_dw is not None:
+                deferred_dw()
+                deferred_dw = None
             op = plan.ops[n]
             dst = op["dst"]
             D, H, W = _dims(shape3, plan.lvl[dst])
@@ -327,13 +331,20 @@ class UnetBf16Fn(torch.autograd.Function):
             if side is not None:
                 ev = torch.cuda.Event()
                 ev.record(main)
-                side.wait_event(ev)
-                with torch.cuda.stream(side):
-                    conv_bwd_weight(ws, x0, c0, up0, x1b, c1, dz, cdz, gw, gb, B, D, H, W)      # (ws is only ever used on the second stream then)
-                dz.record_stream(side)              # released by the main-stream chain before the second stream may be done
-                for g_, sink in ((gw, gw_sink), (gb, gb_sink)):
-                    if sink is None:
-                        g_.record_stream(side)
+
+                def launch_dw(ev=ev, x0=x0, c0=c0, up0=up0, x1b=x1b, c1=c1, dz=dz, cdz=cdz, gw=gw, gb=gb, gw_sink=gw_sink, gb_sink=gb_sink, D=D, H=H, W=W):
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        conv_bwd_weight(ws, x0, c0, up0, x1b, c1, dz, cdz, gw, gb, B, D, H, W)      # (ws is only ever used on the second stream then)
+                    dz.record_stream(side)              # released by the main-stream chain before the second stream may be done
+                    for g_, sink in ((gw, gw_sink), (gb, gb_sink)):
+                        if sink is None:
+                            g_.record_stream(side)
+                # under graph capture the weight gradient is enqueued behind this layer's backward-data launches (functional.DW_ORDER)
+                if VF.DW_ORDER == "after" or (VF.DW_ORDER != "before" and torch.cuda.is_current_stream_capturing()):
+                    deferred_dw = launch_dw
+                else:
+                    launch_dw()
             else:
                 conv_bwd_weight(ws, x0, c0, up0, x1b, c1, dz, cdz, gw, gb, B, D, H, W)
             grads[n_in + 2 * op["k"]] = None if gw_sink is not None else gw
@@ -387,6 +398,8 @@ class UnetBf16Fn(torch.autograd.Function):
                     GS[s1] = gs
                 else:
                     DZ[s1] = lrelu_bwd(gs, T[s1], plan.ops[plan.producer[s1]]["slope"])
+        if deferred_dw is not None:
+            deferred_dw()
         if side is not None:
             main.wait_stream(side)                  # parameter gradients (and the activations the second stream read) are final past this point
         return (None,) + tuple(grads)
