@@ -929,7 +929,18 @@ def _s3_jobs(plan, params, B, shape3, with_backward, input_grads):
             jobs.append((w, 0, c0 + c1, False, c0))
         if not with_backward or (s0 < plan.n_inputs and not input_grads):
             continue
-        ranges = [(c0, c1)] if (up0 and s1 is not None) else ([] if up0 else [(0, c0 + c1)])     # (first channel, count) handed to conv_bwd_data
+        if up0:
+            # UnetFn.backward: the upsampled segment goes straight onto the low-resolution tensor when one of the two fused kernels takes the
+            # shape (then only the skip segment needs an adjoint here); otherwise the adjoint of the WHOLE virtual concat runs at this level
+            # (round 5: that pack was missing from the list, and was built on demand in the middle of the backward-data chain -- 0.23 ms behind
+            # the persistent blocks of the weight gradients, every step, at the 40x48x56 level of the default U-Net)
+            V = D * H * W
+            up_fused = plan.ops[plan.producer[s0]]["kind"] == "conv" and len(plan.consumers[s0]) == 1 if s0 in plan.producer else False
+            low = up_fused and (s3u_bwd_low_route(c0, cout, B, D, H, W) or
+                                bool(_lib.lib().vxm_conv3d_k3_up_bwd_low_ok(256, cout * V, c0, cout, B, D, H, W)))     # (256: any 16-byte aligned address)
+            ranges = ([(c0, c1)] if s1 is not None else []) if low else [(0, c0 + c1)]
+        else:
+            ranges = [(0, c0 + c1)]                                 # (first channel, count) handed to conv_bwd_data
         for w_lo, cin in ranges:
             bounds = _bwd_bounds(cin)
             for lo, hi in zip(bounds[:-1], bounds[1:]):
@@ -1243,7 +1254,11 @@ class UnetFn(torch.autograd.Function):
                 gw_sink, gb_sink = _claim_sink(w), _claim_sink(b)
                 gw = gw_sink if gw_sink is not None else torch.empty_like(w)
                 gb = gb_sink if gb_sink is not None else torch.empty_like(b)
-                if side is not None and plan.lvl[dst] >= OVERLAP_MIN_LEVEL:
+                # the FIRST layer's weight gradient is the last launch of the pass (its dz is the last thing the backward-data chain produces, and
+                # when the inputs need no gradient nothing follows it): on the main stream it starts the moment that dz exists, beside whatever
+                # the second stream still has queued, instead of behind it (rocprofv3 trace, round 5: the step ended 0.38 ms after the main chain)
+                last_on_main = s0 < n_in and not any(ctx.needs_input_grad[1 + i] for i in range(n_in))
+                if side is not None and plan.lvl[dst] >= OVERLAP_MIN_LEVEL and not last_on_main:
                     # Below full resolution neither product fills the chip (a few hundred tiles on 256 CUs): the weight gradient
                     # of this block runs on a second stream beside the backward-data chain it does not feed.
                     ev = torch.cuda.Event()
