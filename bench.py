@@ -526,6 +526,7 @@ def timed_steps(wl, steps, vdist, dev, timer=None):
     # what the caching allocator did inside the region (hipMalloc / hipFree calls stall the host for 10+ ms each) and how the steps were submitted
     timed_steps.submission = {
         "graph_replays": wl.graphed.replays - replays0, "eager_steps": steps - (wl.graphed.replays - replays0),
+        "capture_error": wl.graphed.capture_error,
         "device_allocs": ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
         "device_frees": ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0),
         "alloc_retries": ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0),

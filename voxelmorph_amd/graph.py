@@ -29,6 +29,7 @@ class GraphedStep:
         self.graph = None
         self.out = None
         self.replays = 0
+        self.capture_error = None
         # range_guard (or VXM_RANGE_GUARD=1): the first eager step runs under the dynamic-range probe of the fp16-piece conv engine
         # (voxelmorph_amd/diagnostics.py) and moves this process to the three-piece engine BEFORE anything is captured when a tensor of the
         # batch has more than 0.1 % of its values in that engine's absolute-error regime.  Off by default: on the heavy-tailed full-size step
@@ -66,7 +67,10 @@ class GraphedStep:
         self.single = self.opt.world == 1
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # Multi-rank: a communicator library's own threads (RCCL's proxy) may touch the HIP runtime while this thread captures; only calls of
+        # the capturing thread may invalidate the capture then.  One rank: the strict default.
+        mode = "global" if self.single else "thread_local"
+        with torch.cuda.graph(g, capture_error_mode=mode):
             out = self._body(self.single)
         self.graph, self.out = g, out
         if self.single:
@@ -76,7 +80,17 @@ class GraphedStep:
         if not self.enabled or self.calls < self.eager_steps:
             return self.eager()
         if self.graph is None:
-            self._capture()
+            try:
+                self._capture()
+            except Exception as exc:       # a capture the runtime refuses must not take the training down: same kernels, launch by launch
+                import warnings
+                from .torch.functional_bf16 import invalidate_packs
+                warnings.warn("voxelmorph_amd.GraphedStep: hipGraph capture of the training step failed (%s: %s); continuing with "
+                              "launch-by-launch submission" % (type(exc).__name__, exc))
+                self.graph, self.enabled, self.capture_error = None, False, "%s: %s" % (type(exc).__name__, exc)
+                invalidate_packs(self.opt.params)      # operators "packed" inside the failed capture were never executed
+                torch.cuda.synchronize()
+                return self.eager()
         self.calls += 1
         self.replays += 1
         self.graph.replay()
