@@ -235,3 +235,32 @@ def test_range_report_separates_heavy_tails_from_ordinary_batches(vxm):
         assert gs.replays == 2
     finally:
         VF.FP32_ENGINE = keep
+
+
+def test_refused_capture_falls_back_to_launch_by_launch(vxm, monkeypatch):
+    """a hipGraph capture the runtime refuses must not take the training down: GraphedStep warns, drops the operators "packed" inside the
+    failed capture (they were never executed) and goes on launch by launch -- with the same weights as a run that never tried"""
+    import warnings
+    from voxelmorph_amd.graph import GraphedStep
+    shape, steps = (32, 32, 32), 5
+    _, opt_e, fwd_e, _ = _setup(vxm, shape, 1)
+    eager = GraphedStep(fwd_e, opt_e, enabled=False)
+    for _ in range(steps):
+        eager()
+    _, opt_g, fwd_g, _ = _setup(vxm, shape, 1)
+    step = GraphedStep(fwd_g, opt_g, eager_steps=2)
+    real_zero = opt_g.zero_grad
+
+    def refusing_zero_grad():
+        if torch.cuda.is_current_stream_capturing():          # something inside the captured region that the runtime does not take
+            raise RuntimeError("capture refused (test)")
+        real_zero()
+    monkeypatch.setattr(opt_g, "zero_grad", refusing_zero_grad)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        for _ in range(steps):
+            step()
+    torch.cuda.synchronize()
+    assert step.graph is None and step.replays == 0 and "capture refused" in step.capture_error
+    assert any("launch-by-launch" in str(w.message) for w in caught)
+    assert opt_g.step_count == steps and torch.equal(opt_e.flat_param, opt_g.flat_param)
