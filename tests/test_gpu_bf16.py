@@ -134,6 +134,34 @@ def test_bf16_conv_forward_and_mask_vs_oracle(vxm, c0, up0, c1, cout, vol, slope
     assert rel_l2(N(from_blocked(yb, cout)), (ref.numpy() * mk)) < 4e-3
 
 
+@pytest.mark.parametrize("c0,up0,c1,cout,vol", [(16, False, 0, 16, (16, 24, 48)), (32, True, 16, 32, (12, 10, 36)), (16, False, 0, 3, (9, 16, 40))])
+def test_bf16_conv_reversed_tile_order_bit_exact(vxm, c0, up0, c1, cout, vol):
+    """vxm_bf16_conv_fwd with `out_planar_f32 | 2` walks its output tiles from the end of the tensor (the snake order of consecutive
+    full-resolution launches): scheduling, not arithmetic -- the same bits, blocked and planar outputs, with and without the fused mask"""
+    from voxelmorph_amd import _lib
+    from voxelmorph_amd.torch import functional_bf16 as VB
+    rng = np.random.default_rng(7)
+    B = 2
+    D, H, W = vol
+    lo = tuple(s // 2 for s in vol)
+    x0b = to_blocked(G(rng.standard_normal((B, c0) + (lo if up0 else vol)).astype(np.float32)))
+    x1b = to_blocked(G(rng.standard_normal((B, c1) + vol).astype(np.float32))) if c1 else None
+    w = G((rng.standard_normal((cout, c0 + c1, 3, 3, 3)) / np.sqrt(27 * (c0 + c1))).astype(np.float32))
+    b = G(rng.standard_normal(cout).astype(np.float32) * 0.1)
+    wp = VB.pack_weights(w, 0, c0 + c1, False)
+    planar = cout <= 4
+    masks = [None] if planar else [None, to_blocked(G(rng.standard_normal((B, cout) + vol).astype(np.float32)))]
+    for mask in masks:
+        outs = []
+        for rev in (0, 2):
+            y = torch.full((B, cout, D, H, W), float("nan"), device="cuda") if planar else VB._blocked(B, cout, vol, "cuda")
+            _lib.call("vxm_bf16_conv_fwd", _lib.ptr(x0b), c0, 1 if up0 else 0, _lib.ptr(x1b), c1, _lib.ptr(wp), _lib.ptr(b), _lib.ptr(y), cout,
+                      (1 if planar else 0) | rev, 0.2, _lib.ptr(mask), 0.2, B, D, H, W, _lib.stream())
+            outs.append(y)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0].view(torch.int16) if not planar else outs[0], outs[1].view(torch.int16) if not planar else outs[1])
+
+
 @pytest.mark.parametrize("c0,up0,c1,cout,vol", [(16, False, 0, 16, (8, 8, 32)), (32, True, 16, 32, (12, 10, 36)), (16, False, 0, 3, (6, 16, 40)),
                                                 (32, False, 0, 32, (2, 2, 2)), (2, False, 0, 16, (8, 8, 16))])
 def test_bf16_conv_backward_data_and_weight_vs_oracle(vxm, c0, up0, c1, cout, vol):

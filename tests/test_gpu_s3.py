@@ -465,6 +465,62 @@ def _rerun(env_extra, select, files=("tests/test_gpu_s3.py",), timeout=900):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("vol,B", [((8, 16, 32), 1), ((9, 21, 37), 2), ((24, 24, 80), 1), ((40, 48, 64), 1)])
+@pytest.mark.parametrize("c0,cout", [(16, 16), (32, 16), (16, 32)])
+def test_s3_conv_reversed_tile_order_bit_exact(VF16, c0, cout, vol, B):
+    """include/vxm_hip.h VXM_S3_REVERSE_TILES: walking the output tiles from the end of the tensor is scheduling, not arithmetic -- the same
+    bits, forward operators and adjoints with a fused mask, alone and together with the channel-blocked layouts, small grids (one tile per
+    block) and persistent ones (the last shape: 1800 tiles of the 16-channel kernel, i.e. the producer / consumer kernel's range too)."""
+    VF = VF16
+    D, H, W = vol
+    V = D * H * W
+    torch.manual_seed(8)
+    for flip in (False, True):
+        x = torch.randn(B, c0, D, H, W, device="cuda")
+        w = torch.randn(*((c0, cout) if flip else (cout, c0)), 3, 3, 3, device="cuda") / (27 * c0) ** 0.5
+        bias = None if flip else torch.randn(cout, device="cuda")
+        mask = torch.randn(B, cout, D, H, W, device="cuda") if flip else None
+        wp = VF.s3_pack(w, flip, 0, cout if flip else c0, c0)
+        sl = 1.0 if flip else 0.2
+        y0 = torch.empty(B, cout, D, H, W, device="cuda")
+        VF.s3_launch(x, c0, c0 * V, False, None, 0, 0, wp, bias, y0, cout * V, cout, sl, mask, cout * V, 0.2, B, D, H, W)
+        for lay in (0, VF.S3_IN0_BLOCKED | VF.S3_OUT_BLOCKED):
+            xin = VF.to_blocked(x) if lay else x
+            mk = (VF.to_blocked(mask) if lay else mask) if mask is not None else None
+            y1 = torch.full_like(y0, float("nan"))
+            VF.s3_launch(xin, c0, c0 * V, False, None, 0, 0, wp, bias, y1, cout * V, cout, sl, mk, cout * V, 0.2, B, D, H, W, lay=lay | VF.S3_REVERSE_TILES)
+            assert _eq(y0, VF.from_blocked(y1) if lay else y1), (flip, hex(lay))
+
+
+@pytest.mark.parametrize("c,cout,vol,B", [(16, 16, (8, 16, 32), 2), (32, 16, (10, 20, 38), 1), (16, 32, (16, 24, 64), 1)])
+def test_s3_backward_weight_in_two_calls_bit_exact(VF16, c, cout, vol, B):
+    """include/vxm_hip.h VXM_S3_BW_CONTRACT_ONLY / VXM_S3_BW_REDUCE_ONLY: a weight gradient as two calls (contraction into the workspace,
+    then the reduction -- possibly on another stream) is the one call, bit for bit; same for the collapsed kernel of an upsampled segment."""
+    VF = VF16
+    D, H, W = vol
+    V = D * H * W
+    torch.manual_seed(9)
+    x, dz = torch.randn(B, c, D, H, W, device="cuda"), torch.randn(B, cout, D, H, W, device="cuda")
+    g0, b0 = torch.empty(cout, c, 3, 3, 3, device="cuda"), torch.empty(cout, device="cuda")
+    VF.s3_bwd_weight(VF._Workspace(x.device), x, c, c * V, dz, cout, g0, c, 0, b0, B, D, H, W)
+    pending = []
+    g1, b1 = torch.full_like(g0, float("nan")), torch.full_like(b0, float("nan"))
+    VF.s3_bwd_weight(VF._Workspace(x.device, deferred=pending), x, c, c * V, dz, cout, g1, c, 0, b1, B, D, H, W)
+    assert len(pending) == 1 and bool(torch.isnan(g1).all())           # nothing reduced yet
+    name, args, flags, keep = pending[0]
+    VF.call(name, *args, flags, VF.stream())
+    assert _eq(g0, g1) and _eq(b0, b1)
+    if VF.s3u_bwd_weight_route(c, cout, B, 2 * D, 2 * H, 2 * W):
+        dz2 = torch.randn(B, cout, 2 * D, 2 * H, 2 * W, device="cuda")
+        h0, h1 = torch.empty(cout, c, 3, 3, 3, device="cuda"), torch.full((cout, c, 3, 3, 3), float("nan"), device="cuda")
+        VF.s3u_bwd_weight(VF._Workspace(x.device), x, c, c * V, dz2, cout, h0, c, B, 2 * D, 2 * H, 2 * W)
+        pending = []
+        VF.s3u_bwd_weight(VF._Workspace(x.device, deferred=pending), x, c, c * V, dz2, cout, h1, c, B, 2 * D, 2 * H, 2 * W)
+        name, args, flags, keep = pending[0]
+        VF.call(name, *args, flags, VF.stream())
+        assert _eq(h0, h1)
+
+
 def test_s3_other_kernel_instances_in_subprocess():
     """The packed layout depends on the kernel instance, which is chosen once per process: 16-channel chunks (VXM_S3_CB=2) and
     32-channel operators as two 16-channel groups (VXM_S3_NCT=1) re-run the direct tests above."""
