@@ -9,5 +9,7 @@ from .torch import layers, losses, networks  # noqa: F401
 from .torch.networks import default_unet_features  # noqa: F401
 from . import torch  # noqa: F401
 from .torch.functional_bf16 import invalidate_packs  # noqa: F401
+from .graph import GraphedStep  # noqa: F401              (a training step as one hipGraph launch)
+from .diagnostics import range_report  # noqa: F401      (how the fp16-piece conv engine sees a model / batch)
 
-__version__ = "0.1.0"
+__version__ = "0.5.0"
