@@ -370,6 +370,28 @@ def pack_weights(w, flip, lo=0, hi=None):
     return wp
 
 
+def pack_weights_cached(w, flip, lo=0, hi=None):
+    """pack_weights with the packed operator cached on the weight tensor until its version moves (as the split operators): the fused U-Net
+    builds the ones it will ask for on the second stream at the start of a step (_prepack_plan) instead of one small launch in front of
+    every fp32-MFMA conv of the main chain"""
+    cin = w.shape[1]
+    hi = cin if hi is None else hi
+    cache = w.__dict__.setdefault("_vxm_s3_packs", {})
+    key = ("fp32", bool(flip), lo, hi)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == _pack_ver(w) and hit[1].device == w.device:
+        return hit[1]
+    cout = w.shape[0]
+    n = _lib.lib().vxm_conv3d_k3_packed_elems(cout if flip else hi - lo, hi - lo if flip else cout)
+    wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == n else None
+    if wp is None:
+        wp = torch.empty(n, dtype=w.dtype, device=w.device)
+        _FRESH_PACKS.append(wp)
+    call("vxm_conv3d_k3_pack_weights_range", ptr(_c(w)), ptr(wp), cin, cout, lo, hi - lo, 1 if flip else 0, stream())
+    cache[key] = (_pack_ver(w), wp)
+    return wp
+
+
 def _pack_ver(t):
     """cache key of a packed copy of weight tensor t: its version counter + the generation bumped by writers that bypass it"""
     from .functional_bf16 import _ver
@@ -582,7 +604,7 @@ def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B,
             call("vxm_conv3d_k3_up_fwd", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs, cout, float(slope),
                  B, D, H, W, stream())
         return
-    conv_launch(x0, c0, bs0, up0, x1, c1, bs1, pack_weights(w, False), bias, y, ybs, cout, slope, None, 0, 1.0, B, D, H, W)
+    conv_launch(x0, c0, bs0, up0, x1, c1, bs1, pack_weights_cached(w, False), bias, y, ybs, cout, slope, None, 0, 1.0, B, D, H, W)
 
 
 def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W, w_lo=0, lay=0):
@@ -601,7 +623,7 @@ def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W, w_lo=0, la
             continue
         lay &= ~S3_REVERSE_TILES                         # a scheduling hint of the split kernels only
         _need_split_kernel(lay, "conv_bwd_data")
-        conv_launch(dz, cout, cout * V, False, None, 0, 0, pack_weights(w, True, w_lo + lo, w_lo + hi), None, gx[:, lo:hi], cin * V, hi - lo, 1.0,
+        conv_launch(dz, cout, cout * V, False, None, 0, 0, pack_weights_cached(w, True, w_lo + lo, w_lo + hi), None, gx[:, lo:hi], cin * V, hi - lo, 1.0,
                     mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W)
 
 
@@ -977,6 +999,20 @@ def _prepack_plan(plan, params, B, shape3, with_backward, input_grads, dry=False
             s3u_bwd_low_pack(w, c0, c0 + c1)
         if uses:
             first = min(first, n)
+        # the fp32-MFMA operators of the convs the split engine does not take (coarse levels, first layer, flow head): packed here too, so
+        # that the main chain does not carry a 5 us pack launch in front of each of them.  A guess that turns out unused costs that launch on
+        # the second stream; one that is missing is packed on demand, as before.
+        if n > 0 and cout > 4 and not uses and not up0:      # (op 0 needs its operator at once: packed on demand on the main stream)
+            if not dry:
+                pack_weights_cached(w, False)
+            first = min(first, n)                             # the main stream must have joined the second one before this launch
+        if not dry and with_backward and s0 >= plan.n_inputs:
+            whole = not up0
+            for w_lo, cin_r in ([(0, c0 + c1)] if whole else ([(c0, c1)] if s1 is not None else [])):
+                bounds = _bwd_bounds(cin_r)
+                for lo, hi in zip(bounds[:-1], bounds[1:]):
+                    if not s3_route(cout, False, 0, hi - lo, B, D, H, W):
+                        pack_weights_cached(w, True, w_lo + lo, w_lo + hi)
     return first
 
 
