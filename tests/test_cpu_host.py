@@ -572,3 +572,25 @@ def test_nifti_and_mgz_io_without_nibabel(tmp_path):
     assert z.shape[-1] == 1 and z.shape[:3] == (2, 3, 4)                    # scipy's nearest-neighbour zoom rounds 2.5 -> 2, 3.5 -> 4
     with pytest.raises(ValueError):
         vdata.save_volfile(v, str(tmp_path / "x.mgz"))
+
+
+def test_pack_job_list_covers_the_whole_range_adjoint_of_unfused_upsampled_layers():
+    """Host logic, no device: the operators the fused U-Net packs at the start of a step (functional._s3_jobs) must contain every adjoint its
+    backward pass asks for.  Round 5 found one missing with a rocprofv3 trace -- the default VxmDense's decoder conv at 40x48x56 has no fused
+    low-resolution kernel, so its backward-data runs the adjoint of the WHOLE virtual concat (64 -> 32 outputs of w[32][64]) -- packed on demand
+    in the middle of the backward chain, 0.23 ms per step behind the weight gradients' persistent blocks."""
+    import voxelmorph_amd as vxm
+    from voxelmorph_amd.torch import functional as VF
+    shape = (160, 192, 224)
+    m = vxm.networks.VxmDense(shape, int_steps=7, int_downsize=2)
+    plan = m.unet_model.plan(m._feats, extra=((m.flow.out_channels, 1.0),))
+    params = m.unet_model.conv_params() + [m.flow.weight, m.flow.bias]
+    jobs = [(tuple(w.shape[:2]), lo, hi, flip, seg0) for w, lo, hi, flip, seg0 in VF._s3_jobs(plan, params, 1, shape, True, False)]
+    assert ((32, 64), 0, 64, True, 32) in jobs                 # decoder level 2: the adjoint of the whole 64-channel concat
+    assert ((32, 64), 32, 64, True, 32) in jobs                # decoder level 3: only its skip segment (the upsampled one has k_s3u_dlow)
+    assert ((32, 48), 32, 48, True, 32) in jobs                # remaining[0]: likewise
+    assert not any(j[0] == (32, 48) and j[1] == 0 and j[3] for j in jobs)
+    assert len(jobs) == len(set(jobs))
+    # inference asks for no adjoint at all, and the first launch that reads a packed operator is the second conv (op 2: conv, pool, conv)
+    assert not any(flip for _, _, _, flip, _ in VF._s3_jobs(plan, params, 1, shape, False, False))
+    assert VF._prepack_plan(plan, params, 1, shape, True, False, dry=True) == 2
