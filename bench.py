@@ -160,7 +160,7 @@ def hbm_traffic(kernel, launches_per_step, suffix=""):
     hits = {k: v for k, v in ctr.items() if k.replace(" ", "") == kernel_ns or k.replace(" ", "").startswith(stem + ",")}
     hits = {k: v for k, v in hits.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
     if not hits:
-        return None, "%s has no counters for %s: stale profile, re-run tools/profile_bench.sh" % (rel, kernel)
+        return None, "%s has no counters for %s (collected on another engine / configuration, or stale: tools/profile_bench.sh)" % (rel, kernel)
     n = sum(v["FETCH_SIZE"]["dispatches"] for v in hits.values())
     sha = (ctr.get("_meta") or {}).get("csrc_sha")
     if sha != csrc_sha():
@@ -725,9 +725,17 @@ def main():
                 VF.OVERLAP_SMALL_LEVELS = keep_overlap
                 st2 = tm.resolve()
                 d2 = max(st2, key=lambda k: st2[k]["ms"])
+                roof2 = binding_roofline(d2, st2[d2])
+                # counter traffic of the dominant kernel: the committed summaries were collected at ONE pair per GPU on the default engine
+                # (fp32 headline) and on the bf16 config; they describe an extra config only when its launches are those launches
+                if eb != 1:
+                    roof2["traffic"], roof2["traffic_unit"] = None, "the committed counters were collected at 1 pair per GPU: launches of %d pairs move other byte counts" % eb
+                else:
+                    roof2["traffic"], roof2["traffic_unit"] = hbm_traffic(d2, st2[d2]["launches"] / 2.0, "_bf16" if w2.bf16 else "")
+                    roof2["mfma_util"] = mfma_util(d2, "_bf16" if w2.bf16 else "")
                 extra[key] = {"value": eb * esteps / t2, "unit": "volume-pairs/s", "ms_per_step": 1e3 * t2 / esteps, "steps": esteps,
                               "dtype": "bf16" if w2.bf16 else "f32", "workload": w2.describe(), "final_loss": l2,
-                              "host_enqueue_ms_per_step": host2, "submission": sub2, "roofline": binding_roofline(d2, st2[d2])}
+                              "host_enqueue_ms_per_step": host2, "submission": sub2, "roofline": roof2}
                 if w2.trained:                             # the HBM-bound kernels in the regime they are in after training, with their own table
                     kt = kernel_table(st2, 2, shape, eb)
                     hb = {k: v for k, v in kt.items() if k.startswith(("warp3d", "vecint", "resize3d", "ncc", "gradloss"))}
