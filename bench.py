@@ -202,9 +202,9 @@ def _counter_field(kernel, field, suffix=""):
                                                                or k.replace(" ", "").startswith(stem + ">") or k.replace(" ", "") == stem
                                                                or ("<" not in stem and k.replace(" ", "").startswith(stem + "<")))]
         hits = [v for v in hits if field in v]
-        if hits or "<" not in stem:
-            break
-        stem = stem[:stem.rindex(",")] if "," in stem[stem.index("<"):] else stem[:stem.index("<")]
+        if hits or "<" not in stem or "," not in stem[stem.index("<"):]:
+            break                      # (the first template argument is never dropped: "k_s3_bwd_weight<3>" is not "k_s3_bwd_weight<2, true>")
+        stem = stem[:stem.rindex(",")]
     if not hits:
         return None
     wts = [float((v.get("GRBM_GUI_ACTIVE") or {}).get("dispatches", 1)) for v in hits]
