@@ -435,6 +435,7 @@ class Workload:
             self.dice = vxm.losses.Dice().loss
         self.img = vxm.losses.MSE().loss if self.dense else vxm.losses.NCC().loss
         self.reg = vxm.losses.Grad("l2", loss_mult=2).loss
+        self.wsum = vxm.losses.weighted_sum
         from voxelmorph_amd.pacing import InFlight
         from voxelmorph_amd.graph import GraphedStep
         self.pace = InFlight(2)
@@ -467,9 +468,10 @@ class Workload:
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):      # bf16: blocked-bf16 activations between the convs
             if self.semi:
                 y, pre, yseg = self.model(self.src, self.trg, self.seg_src)
-                return self.img(self.trg, y) + self.lam * self.reg(None, pre) + 0.01 * self.dice(self.seg_trg, yseg)
+                return self.wsum([self.img(self.trg, y), self.reg(None, pre), self.dice(self.seg_trg, yseg)], [1.0, self.lam, 0.01])
             y, pre = self.model(self.src, self.trg)
-            return self.img(self.trg, y) + self.lam * self.reg(None, pre)
+            # train.py:205-212 `loss += loss_function(...) * weights[n]`: one launch of this package (losses.weighted_sum), not two ATen ones per term
+            return self.wsum([self.img(self.trg, y), self.reg(None, pre)], [1.0, self.lam])
 
     def step(self):
         # One step = zero_grad + forward + loss + backward + (all-reduce) + Adam, submitted as one hipGraph launch (GraphedStep; eagerly --

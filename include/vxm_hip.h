@@ -40,7 +40,7 @@ typedef enum {
 enum { VXM_INTERP_LINEAR = 0, VXM_INTERP_NEAREST = 1 };   /* SpatialTransformer mode, layers.py:11 */
 enum { VXM_PENALTY_L1 = 0, VXM_PENALTY_L2 = 1 };          /* Grad penalty, losses.py:98 */
 
-int vxm_version(void);                 /* 10000 major + 100 minor + patch of this ABI: 400 = 0.4.0 (round 5) */
+int vxm_version(void);                 /* 10000 major + 100 minor + patch of this ABI: 500 = 0.5.0 (round 6; every 0.4 entry point kept) */
 const char* vxm_last_error_string(void);
 
 /* ---- the two umbrella names SURVEY.md section 8b lists.  Every op has its own *_workspace_bytes() query next to it; this one dispatches
@@ -75,6 +75,11 @@ int vxm_vecint_fwd(const float* vec, float* steps, int B, int D, int H, int W, i
  * tile into 64-bit fixed-point LDS accumulators -- so the result is bit-reproducible; only steps that displace a voxel by more than 24
  * voxels fall back to global float atomics).  nsteps < 31. */
 #define VXM_VECINT_WORK_EXTRA 128
+/* work_bytes: size of `work`, checked against vxm_workspace_bytes(VXM_WS_VECINT_BWD, ...) (VXM_ERR_WORKSPACE when short): the call clears
+ * VXM_VECINT_WORK_EXTRA words BEHIND the two gradient buffers, so a caller that sized the scratch by hand used to overrun silently. */
+int vxm_vecint_bwd_ws(const float* vec, const float* steps, const float* gout, float* gvec, float* work, size_t work_bytes,
+                      int B, int D, int H, int W, int nsteps, void* stream);
+/* ABI 0.4 name, kept: the same call for a caller that vouches for (2*B*3*D*H*W + VXM_VECINT_WORK_EXTRA) floats of scratch. */
 int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, float* gvec, float* work,
                    int B, int D, int H, int W, int nsteps, void* stream);
 
@@ -289,6 +294,17 @@ int vxm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 #define VXM_ADAM_STATE_BYTES 16
 int vxm_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                       float beta2, float eps, void* state, float gscale, void* stream);
+
+/* ---- the weighted sum of the loss terms, scripts/torch/train.py:205-212 (`loss += loss_function(y_true[n], y_pred[n]) * weights[n]`):
+ * total[0] = sum_n terms[n][0] * weights[n], products and running sum in that order in fp32, ONE launch instead of a mul + an add per term.
+ * terms: HOST array of n device pointers to the 0-dim loss tensors; weights: HOST array.  running (nullable, device, n + 1 floats):
+ * running[n'] += term n' * weight, running[n] += total -- the per-epoch log of train.py:215 without a read-back per step.
+ * _bwd: gterms[n'] (device, n floats) = gtotal[0] * weights[n'], the upstream gradient of each term's own backward kernel. */
+#define VXM_LOSS_TERMS_MAX 8
+int vxm_loss_combine_fwd(const float* const* terms, const float* weights, int n, float* total, float* running, void* stream);
+int vxm_loss_combine_bwd(const float* gtotal, const float* weights, int n, float* gterms, void* stream);
+/* zero `bytes` bytes on the stream (a memset node when captured): FlatAdam.zero_grad() without an ATen fill kernel */
+int vxm_fill_zero(void* p, size_t bytes, void* stream);
 
 /* ---- bf16 activations / fp32 accumulate path of the U-Net (BASELINE.json configs[1]); csrc/conv_bf16.hip.
  * What torch.autocast(bfloat16) over ConvBlock / flow conv / MaxPool3d / Upsample + cat (networks.py:83-85,130,137-138,211,257,

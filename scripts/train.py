@@ -131,13 +131,8 @@ def main(argv=None):
 
     def forward_loss():
         y_pred = model(*static_in)
-        loss = 0
-        for n, fn in enumerate(losses):
-            cur = fn(static_true[n], y_pred[n]) * weights[n]
-            terms[n] += cur.detach()
-            loss = loss + cur
-        terms[-1] += loss.detach()
-        return loss
+        # train.py:205-212 (`loss += loss_function(y_true[n], y_pred[n]) * weights[n]`): products, sum and the per-epoch accumulators in one launch
+        return vxm.losses.weighted_sum([fn(static_true[n], y_pred[n]) for n, fn in enumerate(losses)], weights, running=terms)
 
     step = GraphedStep(forward_loss, opt, eager_steps=2, enabled=os.environ.get('VXM_GRAPH', '1') != '0')
     fresh = False                            # the first batch is in the static tensors already
@@ -153,7 +148,17 @@ def main(argv=None):
                 inputs, y_true = next(loader)
                 for dst, src in zip(static_in + static_true, list(inputs) + list(y_true)):
                     if torch.is_tensor(dst):
+                        # the captured step reads these tensors by address: a batch of another shape / dtype (a short last batch, a loader
+                        # that changed its mind) must not be broadcast into them silently
+                        if not torch.is_tensor(src) or src.shape != dst.shape or src.dtype != dst.dtype:
+                            raise RuntimeError('train.py: the loader returned %s where the static batch tensor is %s %s -- the graphed step '
+                                               'needs batches of one shape (set VXM_GRAPH=0 for ragged batches)'
+                                               % ('%s %s' % (tuple(src.shape), src.dtype) if torch.is_tensor(src) else type(src).__name__,
+                                                  tuple(dst.shape), dst.dtype))
                         dst.copy_(src)
+                    elif dst is not src and dst != src:
+                        raise RuntimeError('train.py: a non-tensor entry of y_true changed between batches (%r -> %r); the graphed step '
+                                           'captured the first value' % (dst, src))
             fresh = True
             step()
             pace.mark()

@@ -117,12 +117,7 @@ def main(argv=None):
             pace.wait()                      # at most two steps in flight (voxelmorph_amd/pacing.py)
             inputs, y_true = next(loader)
             y_pred = model(*inputs)
-            loss = 0
-            for n, fn in enumerate(losses):
-                cur = fn(y_true[n], y_pred[n]) * weights[n]
-                terms[n] += cur.detach()
-                loss = loss + cur
-            terms[-1] += loss.detach()
+            loss = vxm.losses.weighted_sum([fn(y_true[n], y_pred[n]) for n, fn in enumerate(losses)], weights, running=terms)
             opt.zero_grad()
             loss.backward()
             opt.step()

@@ -192,6 +192,65 @@ def test_state_dict_and_checkpoint_format(g_network, tmp_path):
         assert torch.equal(a, b), k
 
 
+_SWITCH_WORKER = r"""
+import os, sys, types, importlib.util
+sys.path.insert(0, %(root)r)
+from oracle import ref_loader
+ref_root = ref_loader.REFERENCE_ROOT
+os.environ["VXM_BACKEND"] = "pytorch"
+os.environ["VXM_DEVICE"] = "mi355x"
+ne = types.ModuleType("neurite"); ne.__version__ = "0.2"; sys.modules["neurite"] = ne
+for name in ["pystrum", "pystrum.pynd", "pystrum.pynd.ndutils", "skimage", "skimage.measure"]:
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["pystrum"].pynd = sys.modules["pystrum.pynd"]; sys.modules["pystrum.pynd"].ndutils = sys.modules["pystrum.pynd.ndutils"]
+sys.modules["skimage"].measure = sys.modules["skimage.measure"]
+init = os.path.join(ref_root, "voxelmorph", "__init__.py")
+text = open(init).read()
+# INTEGRATION.md section A, applied to the text of the reference's package init in memory: one branch in front of `backend == 'pytorch'`
+old = "if backend == 'pytorch':"
+assert text.count(old) == 1
+switch = ("if backend == 'pytorch' and os.environ.get('VXM_DEVICE') == 'mi355x':\n"
+          "    import voxelmorph_amd\n"
+          "    from voxelmorph_amd.torch import layers, networks, losses\n"
+          "el" + old)
+spec = importlib.util.spec_from_file_location("voxelmorph", init, submodule_search_locations=[os.path.dirname(init)])
+mod = importlib.util.module_from_spec(spec)
+sys.modules["voxelmorph"] = mod
+exec(compile(text.replace(old, switch), init, "exec"), mod.__dict__)
+import voxelmorph as vxm
+import voxelmorph_amd
+from voxelmorph_amd.torch import layers, networks, losses
+assert vxm.networks is networks and vxm.layers is layers and vxm.losses is losses
+assert vxm.networks.VxmDense is voxelmorph_amd.networks.VxmDense
+assert "voxelmorph.torch" not in sys.modules                       # the reference's torch backend was never imported
+# what scripts/torch/train.py:140-181 and register.py:78-87 touch, through the switched package
+model = vxm.networks.VxmDense(inshape=(32, 32, 32), nb_unet_features=[[16, 32, 32, 32], [32, 32, 32, 32, 32, 16, 16]], bidir=False,
+                              int_steps=7, int_downsize=2)
+assert type(model).__module__ == "voxelmorph_amd.torch.networks"
+for cls in (vxm.losses.NCC, vxm.losses.MSE, vxm.losses.Grad, vxm.losses.Dice, vxm.layers.SpatialTransformer, vxm.layers.VecInt,
+            vxm.layers.ResizeTransform):
+    assert cls.__module__.startswith("voxelmorph_amd.torch."), cls
+assert callable(vxm.losses.Grad('l2', loss_mult=2).loss) and hasattr(model, "save") and hasattr(vxm.networks.VxmDense, "load")
+assert vxm.generators.scan_to_scan is not None and vxm.py.utils.default_unet_features() == [[16, 32, 32, 32], [32, 32, 32, 32, 32, 16, 16]]
+keys = sorted(k for k in model.state_dict() if not k.endswith(".grid"))
+print("SWITCH_OK", len(keys))
+"""
+
+
+@pytest.mark.skipif(not ref_loader.reference_available(), reason="reference tree not present")
+def test_integration_switch_binds_this_package_inside_the_reference(tmp_path):
+    """INTEGRATION.md section A exercised: the three-line branch a maintainer would add to voxelmorph/__init__.py:32-45, applied in memory to the
+    reference's own package init (read from /root/reference at run time, nothing copied), makes `vxm.networks / layers / losses` THIS
+    package's modules while `vxm.generators` and `vxm.py` stay the reference's; the reference's torch backend is never imported."""
+    script = os.path.join(tmp_path, "switch_worker.py")
+    with open(script, "w") as f:
+        f.write(_SWITCH_WORKER % dict(root=ROOT))
+    out = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "SWITCH_OK 24" in out.stdout, out.stdout[-500:]
+    # and the state_dict keys behind that count are the reference's (test_state_dict_and_checkpoint_format pins them to the golden list)
+
+
 @pytest.mark.skipif(not ref_loader.reference_available(), reason="reference tree not present")
 def test_checkpoint_interop_with_live_reference(tmp_path):
     ref = ref_loader.load_reference()

@@ -66,6 +66,25 @@ def test_graph_replay_changes_no_bit_of_the_training(vxm, shape, B):
     assert losses_e[-1] != losses_e[0]              # it trains
 
 
+def test_graph_follows_a_learning_rate_schedule(vxm):
+    """lr / betas / eps are by-value arguments of the captured Adam launch: GraphedStep re-captures when a schedule moves them, so a replayed
+    run equals the eager run of the same schedule bit for bit"""
+    from voxelmorph_amd.graph import GraphedStep
+    shape = (32, 32, 32)
+    runs = []
+    for enabled in (False, True):
+        _, opt, fwd, _ = _setup(vxm, shape, 1)
+        step = GraphedStep(fwd, opt, eager_steps=1, enabled=enabled)
+        for k in range(6):
+            if k == 3:
+                opt.lr = 1e-4
+            step()
+        torch.cuda.synchronize()
+        runs.append((opt.flat_param.clone(), step))
+    assert runs[1][1].recaptures == 1 and runs[1][1].replays == 5
+    assert torch.equal(runs[0][0], runs[1][0]), float((runs[0][0] - runs[1][0]).abs().max())
+
+
 def test_graph_sees_refilled_inputs_and_eager_code_after_replay(vxm):
     """inputs are static tensors refilled in place; an eager forward after replays must use the weights the graph left (the packed
     operators cached per parameter are re-derived: the graph bumps the parameters' version counters)"""
@@ -127,12 +146,12 @@ SRC = torch.rand((2, 1) + shape, device="cuda", generator=g)        # the global
 TRG = torch.rand((2, 1) + shape, device="cuda", generator=g)
 ncc, reg = vxm.losses.NCC().loss, vxm.losses.Grad("l2", loss_mult=2).loss
 
-def run(lo, hi, comm_world, graphed):
+def run(lo, hi, comm_world, graphed, direct=True):
     torch.manual_seed(5)
     model = vxm.networks.VxmDense(shape, int_steps=7, int_downsize=2).cuda()
     with torch.no_grad():
         model.flow.weight.mul_(2e4)
-    opt = FlatAdam(model, lr=1e-3)
+    opt = FlatAdam(model, lr=1e-3, direct_grads=direct)
     if comm_world == 1:
         opt.world, opt.group = 1, None
     opt.broadcast_params(0)
@@ -160,6 +179,15 @@ for graphed in (False, True):
         out["weights_vs_one_process_%%d" %% graphed] = float((p2 - p1).abs().max())
         out["first_grad_rel_%%d" %% graphed] = float((0.5 * g2[0] - g1[0]).norm() / g1[0].norm())
     vdist.barrier()
+# gradients that reach the optimiser through autograd's p.grad instead of the flat-bucket sink (FlatAdam(direct_grads=False); the 2-D network and
+# a parameter used twice take the same route): the replayed multi-rank step must keep handing them to opt.step() (ADVICE round 5)
+pe, _, _ = run(rank, rank + 1, 2, False, direct=False)
+pg, _, rp = run(rank, rank + 1, 2, True, direct=False)
+pd, _, _ = run(rank, rank + 1, 2, False, direct=True)
+out["autograd_grads_graph_vs_eager"] = float((pe - pg).abs().max())
+out["autograd_grads_vs_sink"] = float((pe - pd).abs().max())
+out["autograd_replays"] = rp
+vdist.barrier()
 if rank == 0:
     print("RESULT " + json.dumps(out))
 """
@@ -182,6 +210,8 @@ def test_two_rank_step_on_the_shared_device_equals_one_process_on_the_concatenat
         # the gradients (measured 2.1e-5 = 2 % of one step); a wrong average (sum instead of mean, a missing rank) would show as ~1e-3
         assert res["weights_vs_one_process_%d" % graphed] < 1e-4
     assert res["replays_0"] == 0 and res["replays_1"] == 3
+    # a replay that dropped the p.grad gradients would run Adam on zeros from the second replay on: ~1e-3 per step
+    assert res["autograd_replays"] == 3 and res["autograd_grads_graph_vs_eager"] < 1e-6 and res["autograd_grads_vs_sink"] < 1e-5, res
 
 
 def test_bench_two_ranks_on_the_shared_device(vxm):

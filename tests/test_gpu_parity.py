@@ -727,6 +727,43 @@ def test_vxm_dense_multi_feature_inputs_vs_oracle(vxm, src_feats, trg_feats):
         assert rel_l2(N(p.grad), sd[name].grad.numpy()) < 2e-4, name
 
 
+@pytest.mark.parametrize("feats,image_loss", [(1, "ncc"), (2, "mse")])
+def test_step_on_inputs_built_as_the_reference_training_loop_builds_them(vxm, feats, image_loss):
+    """Drop-in proof for the caller: scripts/torch/train.py:199-201 hands the model `torch.from_numpy(d).to(device).float().permute(0, 4, 1, 2, 3)`
+    of the generators' float64 [B, *vol, C] arrays -- a channels-last VIEW (non-contiguous for C > 1) -- and the same for y_true, including
+    the zero "true flow" that Grad ignores (generators.py:98-105, losses.py:122).  Model + losses + backward on exactly those tensors,
+    combined with the loop's weighted sum (train.py:205-212), against the oracle on the contiguous copies."""
+    inshape, B, lam = (16, 32, 32), 2, 0.02
+    torch.manual_seed(21)
+    model = vxm.networks.VxmDense(inshape, int_steps=3, int_downsize=2, src_feats=feats, trg_feats=feats).cuda()
+    with torch.no_grad():
+        model.flow.weight.normal_(0, 0.05)
+    sd = {k: v.detach().cpu().double().requires_grad_() for k, v in model.state_dict().items() if not k.endswith(".grid")}
+    rng = np.random.default_rng(40 + feats)
+    invols = [rng.random((B,) + inshape + (feats,)) for _ in range(2)]                       # float64, feature axis last (generators.py:89-95)
+    outvols = [invols[1], np.zeros((B,) + inshape + (3,))]
+    inputs = [torch.from_numpy(d).to("cuda").float().permute(0, 4, 1, 2, 3) for d in invols]      # train.py:200
+    y_true = [torch.from_numpy(d).to("cuda").float().permute(0, 4, 1, 2, 3) for d in outvols]     # train.py:201
+    assert feats == 1 or not inputs[0].is_contiguous()
+    img = vxm.losses.NCC().loss if image_loss == "ncc" else vxm.losses.MSE().loss
+    losses, weights = [img, vxm.losses.Grad("l2", loss_mult=2).loss], [1.0, lam]
+    y_pred = model(*inputs)
+    loss = vxm.losses.weighted_sum([fn(y_true[n], y_pred[n]) for n, fn in enumerate(losses)], weights)
+    ref_list = 0
+    for n, fn in enumerate(losses):                                                                # the loop of train.py:205-212 itself
+        ref_list = ref_list + fn(y_true[n], y_pred[n]) * weights[n]
+    assert abs(float(loss) - float(ref_list)) <= 1e-7 * max(1.0, abs(float(ref_list)))
+    loss.backward()
+    src, trg = (torch.from_numpy(np.ascontiguousarray(np.moveaxis(d, -1, 1))).float().double() for d in invols)
+    losso, (_, _, yo, preo) = orc.train_step_loss(src, trg, sd, image_loss, lam, int_steps=3, int_downsize=2)
+    losso.backward()
+    np.testing.assert_allclose(N(y_pred[0]), yo.detach().numpy(), atol=2e-5, rtol=0)
+    np.testing.assert_allclose(N(y_pred[1]), preo.detach().numpy(), atol=2e-5, rtol=0)
+    assert abs(float(loss) - float(losso)) < 2e-5, (float(loss), float(losso))
+    for name, p in model.named_parameters():
+        assert rel_l2(N(p.grad), sd[name].grad.numpy()) < 2e-4, name
+
+
 @pytest.mark.parametrize("int_downsize,int_steps,half_res", [(1, 2, False), (4, 3, False), (2, 3, True)])
 def test_vxm_dense_integration_variants_vs_oracle(vxm, int_downsize, int_steps, half_res):
     """networks.py:223-242: integration at full resolution (no resize), at quarter resolution (ResizeTransform 4 and 1/4), and with

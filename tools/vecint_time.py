@@ -61,7 +61,7 @@ def main():
             call("vxm_vecint_fwd", ptr(vec), ptr(steps), B, D, H, W, n, stream())
 
         def bwd():
-            call("vxm_vecint_bwd", ptr(vec), ptr(steps), ptr(gout), ptr(gvec), ptr(work), B, D, H, W, n, stream())
+            call("vxm_vecint_bwd_ws", ptr(vec), ptr(steps), ptr(gout), ptr(gvec), ptr(work), work.numel() * 4, B, D, H, W, n, stream())
         fwd()
         t_f = timed(fwd, args.iters)
         t_b = timed(bwd, args.iters)

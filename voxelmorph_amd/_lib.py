@@ -39,6 +39,7 @@ SIGNATURES = {
     "vxm_warp3d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vxm_vecint_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "vxm_vecint_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vxm_vecint_bwd_ws": [_P, _P, _P, _P, _P, _S, _I, _I, _I, _I, _I, _P],
     "vxm_resize3d_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "vxm_resize3d_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "vxm_conv3d_k3_packed_elems": [_I, _I],
@@ -132,6 +133,9 @@ SIGNATURES = {
     "vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes": [_I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3u_bwd_weight": [_P, _I, _L, _P, _L, _I, _P, _I, _P, _S, _I, _I, _I, _I, _I, _P],
     "vxm_s3_range_probe": [_P, _I, _L, _I, _I, _I, _I, _I, _P, _P],
+    "vxm_loss_combine_fwd": [_P, _P, _I, _P, _P, _P],
+    "vxm_loss_combine_bwd": [_P, _P, _I, _P, _P],
+    "vxm_fill_zero": [_P, _S, _P],
     "vxm_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
     "vxm_adam_step_dev": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _F, _P],
 }

@@ -613,6 +613,27 @@ __global__ void __launch_bounds__(256) k_dice_bwd(const float* __restrict__ yt, 
     }
 }
 
+// ------------------------------------------------------------------ weighted sum of the loss terms (scripts/torch/train.py:205-212)
+// `loss = 0; for n: loss += loss_function(y_true[n], y_pred[n]) * weights[n]` as ONE launch (the products and the running sum in the
+// reference's order, fp32) instead of a mul + an add of ATen per term; optionally the terms and the total are added to running sums the
+// training script reads back once per epoch (train.py:215 logs them per step with three .item() syncs).  Backward: one launch, g_n = g * w_n.
+struct LossTerms { const float* t[VXM_LOSS_TERMS_MAX]; float w[VXM_LOSS_TERMS_MAX]; int n; };
+__global__ void k_loss_combine_fwd(const LossTerms lt, float* __restrict__ total, float* __restrict__ running) {
+#pragma clang fp contract(off)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float sum = 0.0f;
+    for (int i = 0; i < lt.n; ++i) {
+        const float cur = lt.t[i][0] * lt.w[i];
+        sum = sum + cur;
+        if (running) running[i] += cur;
+    }
+    total[0] = sum;
+    if (running) running[lt.n] += sum;
+}
+__global__ void k_loss_combine_bwd(const float* __restrict__ gtotal, const LossTerms lt, float* __restrict__ gterms) {
+    if (threadIdx.x < lt.n && blockIdx.x == 0) gterms[threadIdx.x] = gtotal[0] * lt.w[threadIdx.x];
+}
+
 // ------------------------------------------------------------------ Adam (torch.optim.Adam defaults: no amsgrad / weight decay)
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                               long long n, float step_size, float beta1, float beta2, float eps, float bc2_sqrt, float gscale) {
@@ -940,6 +961,35 @@ int vxm_dice_bwd(const float* yt, const float* yp, const double* acc, const floa
     const unsigned nb = stream_blocks(V) > 256 ? 256 : stream_blocks(V);
     hipLaunchKernelGGL(k_dice_bwd, dim3(nb, B * C), dim3(256), 0, VXM_STREAM(stream), yt, yp, acc, gloss, gyt, gyp, B * C, (long long)V);
     return vxm_check_launch("vxm_dice_bwd");
+}
+
+int vxm_loss_combine_fwd(const float* const* terms, const float* weights, int n, float* total, float* running, void* stream) {
+    VXM_REQUIRE(terms && weights && total, VXM_ERR_NULL_POINTER, "vxm_loss_combine_fwd: null pointer");
+    VXM_REQUIRE(n >= 1 && n <= VXM_LOSS_TERMS_MAX, VXM_ERR_BAD_SHAPE, "vxm_loss_combine_fwd: %d terms (1 .. %d)", n, VXM_LOSS_TERMS_MAX);
+    LossTerms lt;
+    lt.n = n;
+    for (int i = 0; i < VXM_LOSS_TERMS_MAX; ++i) { lt.t[i] = i < n ? terms[i] : nullptr; lt.w[i] = i < n ? weights[i] : 0.0f; }
+    for (int i = 0; i < n; ++i) VXM_REQUIRE(lt.t[i], VXM_ERR_NULL_POINTER, "vxm_loss_combine_fwd: term %d is null", i);
+    hipLaunchKernelGGL(k_loss_combine_fwd, dim3(1), dim3(64), 0, VXM_STREAM(stream), lt, total, running);
+    return vxm_check_launch("vxm_loss_combine_fwd");
+}
+
+int vxm_loss_combine_bwd(const float* gtotal, const float* weights, int n, float* gterms, void* stream) {
+    VXM_REQUIRE(gtotal && weights && gterms, VXM_ERR_NULL_POINTER, "vxm_loss_combine_bwd: null pointer");
+    VXM_REQUIRE(n >= 1 && n <= VXM_LOSS_TERMS_MAX, VXM_ERR_BAD_SHAPE, "vxm_loss_combine_bwd: %d terms (1 .. %d)", n, VXM_LOSS_TERMS_MAX);
+    LossTerms lt;
+    lt.n = n;
+    for (int i = 0; i < VXM_LOSS_TERMS_MAX; ++i) { lt.t[i] = nullptr; lt.w[i] = i < n ? weights[i] : 0.0f; }
+    hipLaunchKernelGGL(k_loss_combine_bwd, dim3(1), dim3(64), 0, VXM_STREAM(stream), gtotal, lt, gterms);
+    return vxm_check_launch("vxm_loss_combine_bwd");
+}
+
+int vxm_fill_zero(void* p, size_t bytes, void* stream) {
+    VXM_REQUIRE(p || bytes == 0, VXM_ERR_NULL_POINTER, "vxm_fill_zero: null pointer");
+    if (bytes == 0) return VXM_OK;
+    const hipError_t e = hipMemsetAsync(p, 0, bytes, VXM_STREAM(stream));
+    if (e != hipSuccess) return vxm_fail(VXM_ERR_HIP, "vxm_fill_zero: %s", hipGetErrorString(e));
+    return VXM_OK;
 }
 
 int vxm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, int step,

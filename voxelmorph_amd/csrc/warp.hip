@@ -792,12 +792,15 @@ int vxm_vecint_fwd(const float* vec, float* steps, int B, int D, int H, int W, i
     return vxm_check_launch("vxm_vecint_fwd");
 }
 
-int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, float* gvec, float* work, int B, int D,
-                   int H, int W, int nsteps, void* stream) {
+int vxm_vecint_bwd_ws(const float* vec, const float* steps, const float* gout, float* gvec, float* work, size_t work_bytes, int B, int D,
+                      int H, int W, int nsteps, void* stream) {
     if (int e = check_vol("vxm_vecint_bwd", B, 3, D, H, W)) return e;
     VXM_REQUIRE(nsteps >= 1 && nsteps < 31, VXM_ERR_BAD_SHAPE, "vxm_vecint_bwd: nsteps should be >= 1, found: %d", nsteps);
     VXM_REQUIRE(vec && steps && gout && gvec && work, VXM_ERR_NULL_POINTER, "vxm_vecint_bwd: null pointer");
     const size_t n = (size_t)B * 3 * D * H * W;
+    VXM_REQUIRE(work_bytes >= (2 * n + VXM_VECINT_WORK_EXTRA) * sizeof(float), VXM_ERR_WORKSPACE,
+                "vxm_vecint_bwd: work holds %zu bytes, needs %zu (2 x B x 3 x D x H x W + VXM_VECINT_WORK_EXTRA floats)", work_bytes,
+                (2 * n + VXM_VECINT_WORK_EXTRA) * sizeof(float));
     const long long tiles = (long long)((W + VG_TW - 1) / VG_TW) * ((H + VG_TH - 1) / VG_TH) * ((D + VG_TD - 1) / VG_TD);
     VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_vecint_bwd: too many tiles");
     const dim3 grid_t((unsigned)tiles, B);
@@ -819,6 +822,12 @@ int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, floa
         g = gn;
     }
     return vxm_check_launch("vxm_vecint_bwd");
+}
+
+int vxm_vecint_bwd(const float* vec, const float* steps, const float* gout, float* gvec, float* work, int B, int D,
+                   int H, int W, int nsteps, void* stream) {
+    return vxm_vecint_bwd_ws(vec, steps, gout, gvec, work, B > 0 && D > 0 && H > 0 && W > 0 ? ((size_t)2 * B * 3 * D * H * W + VXM_VECINT_WORK_EXTRA) * sizeof(float) : 0,
+                             B, D, H, W, nsteps, stream);
 }
 
 static int resize_args(const char* fn, int B, int C, int D, int H, int W, int oD, int oH, int oW, float factor) {

@@ -28,7 +28,9 @@ class GraphedStep:
         self.calls = 0
         self.graph = None
         self.out = None
+        self._one = None
         self.replays = 0
+        self.recaptures = 0
         self.capture_error = None
         # range_guard (or VXM_RANGE_GUARD=1): the first eager step runs under the dynamic-range probe of the fp16-piece conv engine
         # (voxelmorph_amd/diagnostics.py) and moves this process to the three-piece engine BEFORE anything is captured when a tensor of the
@@ -43,7 +45,9 @@ class GraphedStep:
         self.opt.zero_grad()
         out = self.fn()
         loss = out[0] if isinstance(out, (tuple, list)) else out
-        loss.backward()
+        if self._one is None or self._one.device != loss.device or self._one.dtype != loss.dtype or self._one.shape != loss.shape:
+            self._one = torch.ones_like(loss)            # (eager steps only: loss.backward() would launch this fill on every step)
+        loss.backward(self._one)
         if with_update:
             self.opt.step()
         return out
@@ -73,12 +77,31 @@ class GraphedStep:
         with torch.cuda.graph(g, capture_error_mode=mode):
             out = self._body(self.single)
         self.graph, self.out = g, out
+        self._hyper = self._hyper_now()
+        # Multi-rank: opt.step() stays outside the graph, so gradients that reach the optimiser through autograd's `p.grad` (the per-op 2-D
+        # network, FlatAdam(direct_grads=False), a parameter used twice) are rewritten by every replay in the tensors the capture allocated --
+        # but the first eager opt.step() folds p.grad into the bucket and drops the reference.  Keep the captured tensors and hand them back
+        # to their parameters after each replay.
+        self._captured_grads = []
         if self.single:
             self.opt._stale = True
+        else:
+            for p, view in zip(self.opt.params, self.opt._views):
+                if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                    self._captured_grads.append((p, p.grad))
+
+    def _hyper_now(self):
+        """the optimiser's by-value kernel arguments (learning rate, betas, eps): frozen inside a captured Adam launch"""
+        return (float(self.opt.lr), tuple(float(b) for b in self.opt.betas), float(self.opt.eps))
 
     def __call__(self):
         if not self.enabled or self.calls < self.eager_steps:
             return self.eager()
+        if self.graph is not None and self.single and self._hyper != self._hyper_now():
+            # lr / betas / eps are by-value arguments of the captured Adam launch: a schedule that moved them needs a new capture
+            # (the eager and the multi-rank paths read them per step; ADVICE round 5)
+            self.graph = None
+            self.recaptures += 1
         if self.graph is None:
             try:
                 self._capture()
@@ -101,5 +124,7 @@ class GraphedStep:
             self.opt._stale = False
             for p in self.opt.params:          # the bucket was written by the graph: a second eager backward must not overwrite it
                 p._vxm_sink_written = True
+            for p, g in self._captured_grads:  # gradients the replay left in autograd's tensors: opt.step() folds them into the bucket
+                p.grad = g
             self.opt.step()
         return self.out

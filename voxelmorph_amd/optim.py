@@ -84,7 +84,10 @@ class FlatAdam:
         invalidate_packs(self.params)
 
     def zero_grad(self):
-        self.flat_grad.zero_()
+        if self.flat_grad.is_cuda:          # a memset on the stream (a memset node in a captured step), not an ATen fill kernel
+            call("vxm_fill_zero", ptr(self.flat_grad), self.flat_grad.numel() * 4, stream())
+        else:
+            self.flat_grad.zero_()
         self._stale = False
         for p in self.params:
             p.grad = None

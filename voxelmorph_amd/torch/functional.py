@@ -152,7 +152,7 @@ class VecIntFn(torch.autograd.Function):
         gvec = torch.empty_like(vec)
         work = torch.empty(vecint_work_elems(vec.numel()), dtype=vec.dtype, device=vec.device)
         with _prof.region("vecint_bwd", nbytes=36.0 * B * D * H * W * ctx.nsteps):
-            call("vxm_vecint_bwd", ptr(vec), ptr(steps), ptr(gout), ptr(gvec), ptr(work), B, D, H, W, ctx.nsteps, stream())
+            call("vxm_vecint_bwd_ws", ptr(vec), ptr(steps), ptr(gout), ptr(gvec), ptr(work), work.numel() * 4, B, D, H, W, ctx.nsteps, stream())
         return gvec, None
 
 
@@ -356,6 +356,40 @@ class DiceFn(torch.autograd.Function):
         gyp = torch.empty_like(yp) if ctx.needs_input_grad[1] else None
         call("vxm_dice_bwd", ptr(yt), ptr(yp), ptr(acc), ptr(_c(gloss)), ptr(gyt), ptr(gyp), B, C, yt[0, 0].numel(), stream())
         return gyt, gyp
+
+
+class WeightedSumFn(torch.autograd.Function):
+    """`loss = 0; loss += loss_function(y_true[n], y_pred[n]) * weights[n]` (scripts/torch/train.py:205-212) as one launch forward and one
+    backward (vxm_loss_combine_fwd / _bwd) instead of a mul + an add of ATen per term.  `running` (optional, n + 1 floats on the device)
+    accumulates the weighted terms and the total for a per-epoch log."""
+
+    @staticmethod
+    def forward(ctx, weights, running, *terms):
+        require_device(*terms)
+        n = len(terms)
+        if n < 1 or n > 8 or len(weights) != n or any(t.numel() != 1 for t in terms):
+            raise ValueError("weighted_sum: 1 .. 8 scalar loss terms with one weight each, got %d terms / %d weights" % (n, len(weights)))
+        if running is not None:
+            require_device(running)
+            if running.numel() < n + 1 or not running.is_contiguous():
+                raise ValueError("weighted_sum: running needs %d contiguous floats" % (n + 1))
+        terms = [_c(t) for t in terms]
+        tp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
+        wv = (ctypes.c_float * n)(*[float(w) for w in weights])
+        total = torch.empty((), dtype=terms[0].dtype, device=terms[0].device)
+        call("vxm_loss_combine_fwd", ctypes.cast(tp, ctypes.c_void_p), ctypes.cast(wv, ctypes.c_void_p), n, ptr(total), ptr(running), stream())
+        ctx.weights = [float(w) for w in weights]
+        ctx.shapes = [t.shape for t in terms]
+        return total
+
+    @staticmethod
+    def backward(ctx, gtotal):
+        n = len(ctx.weights)
+        gtotal = _c(gtotal)
+        wv = (ctypes.c_float * n)(*ctx.weights)
+        gterms = torch.empty(n, dtype=gtotal.dtype, device=gtotal.device)
+        call("vxm_loss_combine_bwd", ptr(gtotal), ctypes.cast(wv, ctypes.c_void_p), n, ptr(gterms), stream())
+        return (None, None) + tuple(gterms[i].view(ctx.shapes[i]) if ctx.needs_input_grad[2 + i] else None for i in range(n))
 
 
 # --------------------------------------------------------------------------- conv helpers

@@ -297,109 +297,113 @@ class UnetBf16Fn(torch.autograd.Function):
         DZ[plan.out] = g_blk if ctx.planar_out else lrelu_bwd(g_blk, T[plan.out], out_op["slope"])
 
         deferred_dw = None
-        for n in range(len(plan.ops) - 1, -1, -1):
+        try:
+            for n in range(len(plan.ops) - 1, -1, -1):
+                if deferred_dw is not None:
+                    deferred_dw()
+                    deferred_dw = None
+                op = plan.ops[n]
+                dst = op["dst"]
+                D, H, W = _dims(shape3, plan.lvl[dst])
+                if op["kind"] == "pool":
+                    src = op["src"]
+                    sD, sH, sW = _dims(shape3, plan.lvl[src])
+                    C = plan.ch[src]
+                    prod = plan.ops[plan.producer[src]]
+                    dz = _blocked(B, C, (sD, sH, sW), dev)
+                    call("vxm_bf16_maxpool2_bwd", ptr(T[src]), ptr(GP.pop(dst)), ptr(GS.pop(src, None)), ptr(dz),
+                         float(prod["slope"] if prod["kind"] == "conv" else 1.0), B, C, sD, sH, sW, stream())
+                    DZ[src] = dz
+                    continue
+                s0, up0, s1 = op["src"]
+                w, b = params[2 * op["k"]], params[2 * op["k"] + 1]
+                cout = plan.ch[dst]
+                dz = DZ.pop(dst)
+                cdz = dz.shape[1] * 8
+                feeds_inputs = s0 < n_in
+                if feeds_inputs:
+                    x0, c0, x1b, c1 = xin, _pad16(cin0), None, 0
+                else:
+                    x0, c0 = T[s0], plan.ch[s0]
+                    x1b, c1 = (T[s1], plan.ch[s1]) if s1 is not None else (None, 0)
+                gw_sink, gb_sink = _claim_sink(w), _claim_sink(b)
+                gw = gw_sink if gw_sink is not None else torch.empty_like(w)
+                gb = gb_sink if gb_sink is not None else torch.empty_like(b)
+                if side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+
+                    def launch_dw(ev=ev, x0=x0, c0=c0, up0=up0, x1b=x1b, c1=c1, dz=dz, cdz=cdz, gw=gw, gb=gb, gw_sink=gw_sink, gb_sink=gb_sink, D=D, H=H, W=W):
+                        side.wait_event(ev)
+                        with torch.cuda.stream(side):
+                            conv_bwd_weight(ws, x0, c0, up0, x1b, c1, dz, cdz, gw, gb, B, D, H, W)      # (ws is only ever used on the second stream then)
+                        dz.record_stream(side)              # released by the main-stream chain before the second stream may be done
+                        for g_, sink in ((gw, gw_sink), (gb, gb_sink)):
+                            if sink is None:
+                                g_.record_stream(side)
+                    # under graph capture the weight gradient is enqueued behind this layer's backward-data launches (functional.DW_ORDER)
+                    if VF.DW_ORDER == "after" or (VF.DW_ORDER != "before" and torch.cuda.is_current_stream_capturing()):
+                        deferred_dw = launch_dw
+                    else:
+                        launch_dw()
+                else:
+                    conv_bwd_weight(ws, x0, c0, up0, x1b, c1, dz, cdz, gw, gb, B, D, H, W)
+                grads[n_in + 2 * op["k"]] = None if gw_sink is not None else gw
+                grads[n_in + 2 * op["k"] + 1] = None if gb_sink is not None else gb
+                if feeds_inputs:
+                    if any(ctx.needs_input_grad[1 + i] for i in range(n_in)):
+                        gx = _blocked(B, _pad16(cin0), (D, H, W), dev)
+                        conv(dz, cdz, False, None, 0, pack_weights(w, 0, cin0, True), None, gx, _pad16(cin0), False, 1.0, None, 1.0, B, D, H, W)
+                        full = torch.empty((B, cin0, D, H, W), dtype=torch.float32, device=dev)
+                        call("vxm_bf16_from_blocked", ptr(gx), _pad16(cin0), ptr(full), cin0, B, D * H * W, stream())
+                        lo = 0
+                        for i in range(n_in):
+                            grads[i] = full[:, lo:lo + plan.ch[i]]
+                            lo += plan.ch[i]
+                    continue
+                # ---- backward-data per segment (the forward kernel with the adjoint weights of that channel range)
+                c0r = plan.ch[s0]
+                prod0 = plan.ops[plan.producer[s0]]
+                single = len(plan.consumers[s0]) == 1
+                if up0:
+                    lD, lH, lW = D // 2, H // 2, W // 2
+                    if prod0["kind"] != "conv" or not single:
+                        raise NotImplementedError("bf16 engine: upsampled tensors come from a decoder ConvBlock with one consumer")
+                    dzl = _blocked(B, c0r, (lD, lH, lW), dev)
+                    # adjoint conv + adjoint of the upsampling + leaky_relu_backward of the producer in one kernel: the full-resolution
+                    # gradient of the upsampled segment (440 MB at the top level) is never written
+                    nct = 1 if c0r <= 16 else 2
+                    with _prof.region("k_bf16_conv<%d,%d,2>" % (nct, 6 if nct == 2 else 8), flops=2.0 * 27 * cdz * c0r * B * D * H * W,
+                                      nbytes=2.0 * B * D * H * W * (cdz + c0r / 4.0), nominal=2.0 * 27 * cdz * c0r * B * D * H * W):
+                        call("vxm_bf16_conv_bwd_data_up", ptr(dz), cdz, ptr(pack_weights(w, 0, c0r, True)), ptr(dzl), c0r,
+                             ptr(T[s0]) if prod0["slope"] != 1.0 else None, float(prod0["slope"]), B, D, H, W, stream())
+                    DZ[s0] = dzl
+                elif prod0["kind"] == "conv" and single:
+                    gx = _blocked(B, c0r, (D, H, W), dev)
+                    fuse = prod0["slope"] != 1.0
+                    conv(dz, cdz, False, None, 0, pack_weights(w, 0, c0r, True), None, gx, c0r, False, 1.0, T[s0] if fuse else None,
+                         prod0["slope"], B, D, H, W)
+                    DZ[s0] = gx
+                else:
+                    gx = _blocked(B, c0r, (D, H, W), dev)
+                    conv(dz, cdz, False, None, 0, pack_weights(w, 0, c0r, True), None, gx, c0r, False, 1.0, None, 1.0, B, D, H, W)
+                    if prod0["kind"] == "pool":
+                        GP[s0] = gx
+                    else:
+                        DZ[s0] = lrelu_bwd(gx, T[s0], prod0["slope"])
+                if s1 is not None:
+                    c1r = plan.ch[s1]
+                    gs = _blocked(B, c1r, (D, H, W), dev)
+                    conv(dz, cdz, False, None, 0, pack_weights(w, c0r, c1r, True), None, gs, c1r, False, 1.0, None, 1.0, B, D, H, W)
+                    if any(plan.ops[m]["kind"] == "pool" for m in plan.consumers[s1]):
+                        GS[s1] = gs
+                    else:
+                        DZ[s1] = lrelu_bwd(gs, T[s1], plan.ops[plan.producer[s1]]["slope"])
             if deferred_dw is not None:
                 deferred_dw()
-                deferred_dw = None
-            op = plan.ops[n]
-            dst = op["dst"]
-            D, H, W = _dims(shape3, plan.lvl[dst])
-            if op["kind"] == "pool":
-                src = op["src"]
-                sD, sH, sW = _dims(shape3, plan.lvl[src])
-                C = plan.ch[src]
-                prod = plan.ops[plan.producer[src]]
-                dz = _blocked(B, C, (sD, sH, sW), dev)
-                call("vxm_bf16_maxpool2_bwd", ptr(T[src]), ptr(GP.pop(dst)), ptr(GS.pop(src, None)), ptr(dz),
-                     float(prod["slope"] if prod["kind"] == "conv" else 1.0), B, C, sD, sH, sW, stream())
-                DZ[src] = dz
-                continue
-            s0, up0, s1 = op["src"]
-            w, b = params[2 * op["k"]], params[2 * op["k"] + 1]
-            cout = plan.ch[dst]
-            dz = DZ.pop(dst)
-            cdz = dz.shape[1] * 8
-            feeds_inputs = s0 < n_in
-            if feeds_inputs:
-                x0, c0, x1b, c1 = xin, _pad16(cin0), None, 0
-            else:
-                x0, c0 = T[s0], plan.ch[s0]
-                x1b, c1 = (T[s1], plan.ch[s1]) if s1 is not None else (None, 0)
-            gw_sink, gb_sink = _claim_sink(w), _claim_sink(b)
-            gw = gw_sink if gw_sink is not None else torch.empty_like(w)
-            gb = gb_sink if gb_sink is not None else torch.empty_like(b)
+        finally:
+            # also on an exception half-way (the GraphedStep fallback goes straight on to zero_grad / Adam): later main-stream work must not race
+            # with second-stream launches that are still writing the flat gradient bucket -- as UnetFn.backward
             if side is not None:
-                ev = torch.cuda.Event()
-                ev.record(main)
-
-                def launch_dw(ev=ev, x0=x0, c0=c0, up0=up0, x1b=x1b, c1=c1, dz=dz, cdz=cdz, gw=gw, gb=gb, gw_sink=gw_sink, gb_sink=gb_sink, D=D, H=H, W=W):
-                    side.wait_event(ev)
-                    with torch.cuda.stream(side):
-                        conv_bwd_weight(ws, x0, c0, up0, x1b, c1, dz, cdz, gw, gb, B, D, H, W)      # (ws is only ever used on the second stream then)
-                    dz.record_stream(side)              # released by the main-stream chain before the second stream may be done
-                    for g_, sink in ((gw, gw_sink), (gb, gb_sink)):
-                        if sink is None:
-                            g_.record_stream(side)
-                # under graph capture the weight gradient is enqueued behind this layer's backward-data launches (functional.DW_ORDER)
-                if VF.DW_ORDER == "after" or (VF.DW_ORDER != "before" and torch.cuda.is_current_stream_capturing()):
-                    deferred_dw = launch_dw
-                else:
-                    launch_dw()
-            else:
-                conv_bwd_weight(ws, x0, c0, up0, x1b, c1, dz, cdz, gw, gb, B, D, H, W)
-            grads[n_in + 2 * op["k"]] = None if gw_sink is not None else gw
-            grads[n_in + 2 * op["k"] + 1] = None if gb_sink is not None else gb
-            if feeds_inputs:
-                if any(ctx.needs_input_grad[1 + i] for i in range(n_in)):
-                    gx = _blocked(B, _pad16(cin0), (D, H, W), dev)
-                    conv(dz, cdz, False, None, 0, pack_weights(w, 0, cin0, True), None, gx, _pad16(cin0), False, 1.0, None, 1.0, B, D, H, W)
-                    full = torch.empty((B, cin0, D, H, W), dtype=torch.float32, device=dev)
-                    call("vxm_bf16_from_blocked", ptr(gx), _pad16(cin0), ptr(full), cin0, B, D * H * W, stream())
-                    lo = 0
-                    for i in range(n_in):
-                        grads[i] = full[:, lo:lo + plan.ch[i]]
-                        lo += plan.ch[i]
-                continue
-            # ---- backward-data per segment (the forward kernel with the adjoint weights of that channel range)
-            c0r = plan.ch[s0]
-            prod0 = plan.ops[plan.producer[s0]]
-            single = len(plan.consumers[s0]) == 1
-            if up0:
-                lD, lH, lW = D // 2, H // 2, W // 2
-                if prod0["kind"] != "conv" or not single:
-                    raise NotImplementedError("bf16 engine: upsampled tensors come from a decoder ConvBlock with one consumer")
-                dzl = _blocked(B, c0r, (lD, lH, lW), dev)
-                # adjoint conv + adjoint of the upsampling + leaky_relu_backward of the producer in one kernel: the full-resolution
-                # gradient of the upsampled segment (440 MB at the top level) is never written
-                nct = 1 if c0r <= 16 else 2
-                with _prof.region("k_bf16_conv<%d,%d,2>" % (nct, 6 if nct == 2 else 8), flops=2.0 * 27 * cdz * c0r * B * D * H * W,
-                                  nbytes=2.0 * B * D * H * W * (cdz + c0r / 4.0), nominal=2.0 * 27 * cdz * c0r * B * D * H * W):
-                    call("vxm_bf16_conv_bwd_data_up", ptr(dz), cdz, ptr(pack_weights(w, 0, c0r, True)), ptr(dzl), c0r,
-                         ptr(T[s0]) if prod0["slope"] != 1.0 else None, float(prod0["slope"]), B, D, H, W, stream())
-                DZ[s0] = dzl
-            elif prod0["kind"] == "conv" and single:
-                gx = _blocked(B, c0r, (D, H, W), dev)
-                fuse = prod0["slope"] != 1.0
-                conv(dz, cdz, False, None, 0, pack_weights(w, 0, c0r, True), None, gx, c0r, False, 1.0, T[s0] if fuse else None,
-                     prod0["slope"], B, D, H, W)
-                DZ[s0] = gx
-            else:
-                gx = _blocked(B, c0r, (D, H, W), dev)
-                conv(dz, cdz, False, None, 0, pack_weights(w, 0, c0r, True), None, gx, c0r, False, 1.0, None, 1.0, B, D, H, W)
-                if prod0["kind"] == "pool":
-                    GP[s0] = gx
-                else:
-                    DZ[s0] = lrelu_bwd(gx, T[s0], prod0["slope"])
-            if s1 is not None:
-                c1r = plan.ch[s1]
-                gs = _blocked(B, c1r, (D, H, W), dev)
-                conv(dz, cdz, False, None, 0, pack_weights(w, c0r, c1r, True), None, gs, c1r, False, 1.0, None, 1.0, B, D, H, W)
-                if any(plan.ops[m]["kind"] == "pool" for m in plan.consumers[s1]):
-                    GS[s1] = gs
-                else:
-                    DZ[s1] = lrelu_bwd(gs, T[s1], plan.ops[plan.producer[s1]]["slope"])
-        if deferred_dw is not None:
-            deferred_dw()
-        if side is not None:
-            main.wait_stream(side)                  # parameter gradients (and the activations the second stream read) are final past this point
+                main.wait_stream(side)              # parameter gradients (and the activations the second stream read) are final past this point
         return (None,) + tuple(grads)

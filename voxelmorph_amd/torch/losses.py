@@ -58,3 +58,10 @@ class Grad:
         if y_pred.dim() == 4:
             return VP.GradLoss2dFn.apply(y_pred, self.penalty, mult)
         return VF.GradLossFn.apply(y_pred, self.penalty, mult)
+
+
+def weighted_sum(terms, weights, running=None):
+    """The reference loop's `loss += loss_function(y_true[n], y_pred[n]) * weights[n]` (scripts/torch/train.py:205-212) for terms already
+    evaluated: one HIP launch forward, one backward, no ATen kernel (`a + w * b` on 0-dim tensors costs a mul and an add launch each way).
+    `running`: optional device tensor of len(terms) + 1 floats that accumulates the weighted terms and the total (per-epoch logging)."""
+    return VF.WeightedSumFn.apply(tuple(float(w) for w in weights), running, *terms)
