@@ -67,6 +67,19 @@ int vxm_warp3d_fwd(const float* src, const float* flow, float* out, int B, int C
 int vxm_warp3d_bwd(const float* src, const float* flow, const float* gout, float* gsrc, float* gflow,
                    int B, int C, int D, int H, int W, int mode, void* stream);
 
+/* ---- `fullsize` + the final SpatialTransformer as one kernel, networks.py:275-280 (pos_flow = fullsize(integrate(v)); y = transformer(source,
+ * pos_flow)) with layers.py:85-97 and :30-48: out[b,c,p] = sample(src[b,c], p + U(flow_lo)[b,:,p]), U = `factor *` + upsample_trilinear3d
+ * (align_corners) of the integrated field flow_lo [B,3,lD,lH,lW].  The full-resolution displacement is evaluated in registers (the resize
+ * kernel's expression, then the warp kernel's coordinate arithmetic: results bit-identical to vxm_resize3d_fwd + vxm_warp3d_fwd) and only
+ * written when pos_flow != NULL (registration=True returns it).  vxm_warp3d_up_ok: the field is at most ~half as fine as the image per axis.
+ * _bwd: gflow_lo = dL/dflow_lo; work: B*3*D*H*W floats (the gradient w.r.t. the full-resolution displacement, consumed by vxm_resize3d_bwd
+ * inside the call).  src receives no gradient here (the image inputs of the path need none; callers that want one take the two-kernel path). */
+int vxm_warp3d_up_ok(int D, int H, int W, int lD, int lH, int lW);
+int vxm_warp3d_up_fwd(const float* src, const float* flow_lo, float* out, float* pos_flow, int B, int C, int D, int H, int W,
+                      int lD, int lH, int lW, float factor, int mode, void* stream);
+int vxm_warp3d_up_bwd(const float* src, const float* flow_lo, const float* gout, float* gflow_lo, float* work, size_t work_bytes,
+                      int B, int C, int D, int H, int W, int lD, int lH, int lW, float factor, int mode, void* stream);
+
 /* ---- VecInt.forward, layers.py:64-68: v0 = vec/2^n; v_{k+1} = v_k + warp(v_k, v_k).
  * steps: [nsteps][B,3,D,H,W]; steps[k] receives v_{k+1}; the result is steps[nsteps-1]. */
 int vxm_vecint_fwd(const float* vec, float* steps, int B, int D, int H, int W, int nsteps, void* stream);

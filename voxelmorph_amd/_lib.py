@@ -37,6 +37,9 @@ SIGNATURES = {
     "vxm_conv3d_k3_bwd_data": [_P, _I, _L, _P, _I, _I, _I, _P, _P, _L, _P, _L, _F, _I, _I, _I, _I, _P],
     "vxm_warp3d_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "vxm_warp3d_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "vxm_warp3d_up_ok": [_I, _I, _I, _I, _I, _I],
+    "vxm_warp3d_up_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "vxm_warp3d_up_bwd": [_P, _P, _P, _P, _P, _S, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "vxm_vecint_fwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "vxm_vecint_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vxm_vecint_bwd_ws": [_P, _P, _P, _P, _P, _S, _I, _I, _I, _I, _I, _P],

@@ -9,6 +9,7 @@
 // neighbouring lanes sample neighbouring source voxels for the smooth fields of this path.
 #include "vxm_common.h"
 #include "vxm_device.h"
+#include <type_traits>
 
 namespace {
 
@@ -533,6 +534,23 @@ __device__ __forceinline__ void axis_taps(int i, float ratio, int n_in, int n_ou
 // thread's w / h never need a div / mod.  Same arithmetic and summation order as the per-voxel kernels above.
 constexpr int RT_W = 32, RT_H = 8, RT_D = 4, RT_N = RT_W + RT_H + RT_D;
 
+// the trilinear combination of upsample_trilinear3d in ONE place (resize forward and the fused resize + warp kernels evaluate the same expression)
+// Roundings pinned (explicit fused multiply-adds, no contraction left to the compiler): a kernel that evaluates the in-plane part once per
+// staged plane and reuses it for several output depths (k_warp3d_up_*) gets the bits of one that evaluates the whole expression per voxel.
+__device__ __forceinline__ float rt_bilerp(float ly0, float ly1, float lx0, float lx1, float a00, float a01, float a10, float a11) {
+#pragma clang fp contract(off)
+    const float x0 = __builtin_fmaf(lx0, a00, lx1 * a01), x1 = __builtin_fmaf(lx0, a10, lx1 * a11);
+    return __builtin_fmaf(ly0, x0, ly1 * x1);
+}
+__device__ __forceinline__ float rt_zlerp(float lz0, float lz1, float y0, float y1) {
+#pragma clang fp contract(off)
+    return __builtin_fmaf(lz0, y0, lz1 * y1);
+}
+__device__ __forceinline__ float rt_trilerp(float lz0, float lz1, float ly0, float ly1, float lx0, float lx1, float a000, float a001, float a010,
+                                            float a011, float a100, float a101, float a110, float a111) {
+    return rt_zlerp(lz0, lz1, rt_bilerp(ly0, ly1, lx0, lx1, a000, a001, a010, a011), rt_bilerp(ly0, ly1, lx0, lx1, a100, a101, a110, a111));
+}
+
 __device__ __forceinline__ void rt_tile(int nW, int nH, int& d0, int& h0, int& w0) {
     const int tw = (nW + RT_W - 1) / RT_W, th = (nH + RT_H - 1) / RT_H;
     int t = blockIdx.x;
@@ -572,8 +590,8 @@ __global__ void __launch_bounds__(256) k_resize3d_fwd_tiled(const float* __restr
         const int z0 = si0[RT_W + RT_H + dd], z1 = si1[RT_W + RT_H + dd];
         const float lz0 = sl0[RT_W + RT_H + dd], lz1 = sl1[RT_W + RT_H + dd];
 #define AT(zz, yy, xx) (pre * s[((size_t)(zz) * H + (yy)) * W + (xx)])
-        const float v = lz0 * (ly0 * (lx0 * AT(z0, y0, x0) + lx1 * AT(z0, y0, x1)) + ly1 * (lx0 * AT(z0, y1, x0) + lx1 * AT(z0, y1, x1))) +
-                        lz1 * (ly0 * (lx0 * AT(z1, y0, x0) + lx1 * AT(z1, y0, x1)) + ly1 * (lx0 * AT(z1, y1, x0) + lx1 * AT(z1, y1, x1)));
+        const float v = rt_trilerp(lz0, lz1, ly0, ly1, lx0, lx1, AT(z0, y0, x0), AT(z0, y0, x1), AT(z0, y1, x0), AT(z0, y1, x1),
+                                   AT(z1, y0, x0), AT(z1, y0, x1), AT(z1, y1, x0), AT(z1, y1, x1));
 #undef AT
         out[bc * (size_t)oD * oH * oW + ((size_t)d * oH + h) * oW + w] = post * v;
     }
@@ -624,6 +642,63 @@ __global__ void __launch_bounds__(256) k_resize3d_bwd_gather_tiled(const float* 
             }
         }
         gx[bc * (size_t)D * H * W + ((size_t)d * H + h) * W + w] = acc * scale;
+    }
+}
+
+// ---- adjoint of a DOWN-sampling resize (every ratio >= 1: an input voxel is named by at most two outputs per axis, and by none when the
+// ratio skips it): the gather above with its loops resolved -- two taps per axis from the same axis_taps() records, eight unconditional
+// loads per voxel (clamped addresses, weight zero where a tap does not exist), same a -> e -> c summation order.  The general kernel ran
+// its three data-dependent loops at 47 us for the 10 -> 83 MB of the headline field (k_resize3d_bwd_gather_tiled, 2.0 TB/s).
+__global__ void __launch_bounds__(256) k_resize3d_bwd_down(const float* __restrict__ gout, float* __restrict__ gx, int D, int H, int W, int oD, int oH,
+                                                           int oW, float rd, float rh, float rw, float scale) {
+    // 16 depths per block (the 44 + 12 axis records cost as much as four voxels of a thread: amortised over sixteen)
+    constexpr int RD_D = 16, RD_N = RT_W + RT_H + RD_D;
+    __shared__ int so[RD_N];
+    __shared__ float s0[RD_N], s1[RD_N];
+    const int tw_ = (W + RT_W - 1) / RT_W, th_ = (H + RT_H - 1) / RT_H;
+    int t_ = blockIdx.x;
+    const int w0 = (t_ % tw_) * RT_W; t_ /= tw_;
+    const int h0 = (t_ % th_) * RT_H;
+    const int d0 = (t_ / th_) * RD_D;
+    const int tid = threadIdx.x;
+    if (tid < RD_N) {
+        const int ax = tid < RT_W ? 2 : (tid < RT_W + RT_H ? 1 : 0);
+        const int i = ax == 2 ? w0 + tid : (ax == 1 ? h0 + tid - RT_W : d0 + tid - RT_W - RT_H);
+        const int n_in = ax == 2 ? W : (ax == 1 ? H : D), n_out = ax == 2 ? oW : (ax == 1 ? oH : oD);
+        int olo;
+        float wt[RS_KC];
+        axis_taps(min(i, n_in - 1), ax == 2 ? rw : (ax == 1 ? rh : rd), n_in, n_out, olo, wt);
+        int klo = 0;
+        while (klo < RS_KC - 2 && wt[klo] == 0.0f) ++klo;                      // first tap that counts; at most one more follows (ratio >= 1)
+        float a = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int j = 0; j < RS_KC; ++j) { a = j == klo ? wt[j] : a; b = j == klo + 1 ? wt[j] : b; }
+        so[tid] = min(olo + klo, n_out - 1); s0[tid] = a; s1[tid] = olo + klo + 1 < n_out ? b : 0.0f;
+    }
+    __syncthreads();
+    const int tx = tid & 31, ty = tid >> 5;
+    const int w = w0 + tx, h = h0 + ty;
+    if (w >= W || h >= H) return;
+    const size_t bc = blockIdx.y;
+    const __amdgpu_buffer_rsrc_t rg = vxm_rsrc(gout + bc * (size_t)oD * oH * oW, (unsigned)oD * (unsigned)oH * (unsigned)oW * 4u);
+    const int ow0 = so[tx], ow1 = min(ow0 + 1, oW - 1), oh0 = so[RT_W + ty], oh1 = min(oh0 + 1, oH - 1);
+    const float wc[2] = {s0[tx], s1[tx]}, we[2] = {s0[RT_W + ty], s1[RT_W + ty]};
+    const int col[2] = {ow0, ow1}, row[2] = {oh0 * oW, oh1 * oW};
+    float* o = gx + bc * (size_t)D * H * W;
+#pragma unroll 4
+    for (int dd = 0; dd < RD_D; ++dd) {
+        const int d = d0 + dd;
+        if (d >= D) break;
+        const int od0 = so[RT_W + RT_H + dd], od1 = min(od0 + 1, oD - 1);
+        const float wa[2] = {s0[RT_W + RT_H + dd], s1[RT_W + RT_H + dd]};
+        const int pl[2] = {od0 * oH * oW, od1 * oH * oW};
+        float g[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = vxm_bload(rg, (pl[k >> 2] + row[(k >> 1) & 1] + col[k & 1]) << 2, 0);
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += (wa[k >> 2] * we[(k >> 1) & 1]) * wc[k & 1] * g[k];
+        o[((size_t)d * H + h) * W + w] = acc * scale;
     }
 }
 
@@ -735,6 +810,301 @@ __global__ void __launch_bounds__(RB_THREADS) k_resize3d_bwd_sep(const float* __
     }
 }
 
+// ---- `fullsize` fused into the final SpatialTransformer (networks.py:275-280: pos_flow = fullsize(integrate(v)); y = transformer(source, pos_flow)).
+// The warp reads flow[p] only at its own voxel, so the upsampled displacement is computed in registers from the half-resolution field (10 MB:
+// resident in the L2 / memory-side cache) and the full-resolution pos_flow (82.6 MB per pair) is never written or read.  A block owns a
+// 4 x 8 x 32 tile of OUTPUT voxels: its 44 per-axis interpolation records (k_resize3d_fwd_tiled's) and the (<= 4 x 6 x 18 x 3) block of the
+// low-resolution field its taps touch are staged in LDS once; a thread then evaluates rt_trilerp -- the resize kernel's expression --
+// and the warp of k_warp3d_fwd (same coordinate arithmetic: bit-identical to the two-kernel path).  Ratios up to 0.51 (factor >= 2).
+constexpr int WU_LZ = 4, WU_LY = 6, WU_LX = 18, WU_LN = WU_LZ * WU_LY * WU_LX;
+struct WuRec { int z0, z1, y0, y1, x0, x1; float lz0, lz1, ly0, ly1, lx0, lx1; };
+
+// stage the records and the low-resolution block of the tile at (d0, h0, w0); returns through LDS.  fl[c][.] holds pre * flow
+__device__ __forceinline__ void wu_stage(const float* __restrict__ flo, int lD, int lH, int lW, int oD, int oH, int oW, float rd, float rh, float rw,
+                                         float pre, int d0, int h0, int w0, int* si0, int* si1, float* sl0, float* sl1, float (*fl)[WU_LN]) {
+    const int tid = threadIdx.x;
+    if (tid < RT_N) {
+        const int ax = tid < RT_W ? 2 : (tid < RT_W + RT_H ? 1 : 0);
+        const int dst = ax == 2 ? w0 + tid : (ax == 1 ? h0 + tid - RT_W : d0 + tid - RT_W - RT_H);
+        const int n_out = ax == 2 ? oW : (ax == 1 ? oH : oD), n_in = ax == 2 ? lW : (ax == 1 ? lH : lD);
+        int i0, i1;
+        float l0, l1;
+        lin_src(min(dst, n_out - 1), ax == 2 ? rw : (ax == 1 ? rh : rd), n_in, i0, i1, l0, l1);
+        si0[tid] = i0; si1[tid] = i1; sl0[tid] = l0; sl1[tid] = l1;
+    }
+    __syncthreads();
+    const int xlo = si0[0], ylo = si0[RT_W], zlo = si0[RT_W + RT_H];
+    const int lHW = lH * lW, lV = lD * lHW;
+    const __amdgpu_buffer_rsrc_t rf = vxm_rsrc(flo, 3u * (unsigned)lV * 4u);
+    for (int i = tid; i < 3 * WU_LN; i += 256) {
+        const int c = i / WU_LN, r = i - c * WU_LN;
+        const int z = r / (WU_LY * WU_LX), r2 = r - z * (WU_LY * WU_LX), y = r2 / WU_LX, x = r2 - y * WU_LX;
+        const int gz = min(zlo + z, lD - 1), gy = min(ylo + y, lH - 1), gx = min(xlo + x, lW - 1);
+        fl[c][r] = pre * vxm_bload(rf, (gz * lHW + gy * lW + gx) << 2, (c * lV) << 2);
+    }
+    __syncthreads();
+}
+// in-plane part of the upsampled displacement for this thread's (h, w): one bilinear value per channel and staged low-resolution plane
+struct WuPlanes { float y[3][WU_LZ]; };
+__device__ __forceinline__ WuPlanes wu_planes(const int* si0, const int* si1, const float* sl0, const float* sl1, const float (*fl)[WU_LN], int tx, int ty) {
+    const int xlo = si0[0], ylo = si0[RT_W];
+    const int x0 = si0[tx] - xlo, x1 = si1[tx] - xlo, y0 = si0[RT_W + ty] - ylo, y1 = si1[RT_W + ty] - ylo;
+    const float lx0 = sl0[tx], lx1 = sl1[tx], ly0 = sl0[RT_W + ty], ly1 = sl1[RT_W + ty];
+    WuPlanes p;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int z = 0; z < WU_LZ; ++z) {
+            const float* q = fl[c] + z * (WU_LY * WU_LX);
+            p.y[c][z] = rt_bilerp(ly0, ly1, lx0, lx1, q[y0 * WU_LX + x0], q[y0 * WU_LX + x1], q[y1 * WU_LX + x0], q[y1 * WU_LX + x1]);
+        }
+    return p;
+}
+// upsampled displacement (3 channels) of the output voxel at depth record dd: the depth interpolation of the plane values
+__device__ __forceinline__ void wu_flow(const int* si0, const int* si1, const float* sl0, const float* sl1, const WuPlanes& p, int dd, float post,
+                                        float& f0, float& f1, float& f2) {
+    const int zlo = si0[RT_W + RT_H];
+    const int z0 = si0[RT_W + RT_H + dd] - zlo, z1 = si1[RT_W + RT_H + dd] - zlo;
+    const float lz0 = sl0[RT_W + RT_H + dd], lz1 = sl1[RT_W + RT_H + dd];
+    float f[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float a = p.y[c][0], b = p.y[c][0];
+#pragma unroll
+        for (int z = 1; z < WU_LZ; ++z) { a = z0 == z ? p.y[c][z] : a; b = z1 == z ? p.y[c][z] : b; }      // (register select: no dynamic indexing)
+        f[c] = post * rt_zlerp(lz0, lz1, a, b);
+    }
+    f0 = f[0]; f1 = f[1]; f2 = f[2];
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_warp3d_up_fwd(const float* __restrict__ src, const float* __restrict__ flo, float* __restrict__ out,
+                                                       float* __restrict__ pos, int C, int D, int H, int W, int lD, int lH, int lW, float rd, float rh,
+                                                       float rw, float pre, float post) {
+    __shared__ int si0[RT_N], si1[RT_N];
+    __shared__ float sl0[RT_N], sl1[RT_N];
+    __shared__ float fl[3][WU_LN];
+    int d0, h0, w0;
+    rt_tile(W, H, d0, h0, w0);
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int V = D * H * W, V4 = V << 2;
+    wu_stage(flo + (size_t)b * 3 * lD * lH * lW, lD, lH, lW, D, H, W, rd, rh, rw, pre, d0, h0, w0, si0, si1, sl0, sl1, fl);
+    const int tx = tid & 31, ty = tid >> 5;
+    const int w = w0 + tx, h = h0 + ty;
+    if (w >= W || h >= H) return;
+    const float* s = src + (size_t)b * C * V;
+    float* o = out + (size_t)b * C * V;
+    const __amdgpu_buffer_rsrc_t rp = vxm_rsrc(pos ? pos + (size_t)b * 3 * V : src, pos ? 3u * (unsigned)V * 4u : 0u);     // no pos: every store dropped
+    const WuPlanes pl = wu_planes(si0, si1, sl0, sl1, fl, tx, ty);
+#pragma unroll
+    for (int dd = 0; dd < RT_D; ++dd) {
+        const int d = d0 + dd;
+        if (d >= D) break;
+        float f0, f1, f2;
+        wu_flow(si0, si1, sl0, sl1, pl, dd, post, f0, f1, f2);
+        const int p4 = ((d * H + h) * W + w) << 2;
+        vxm_bstore(f0, rp, p4, 0); vxm_bstore(f1, rp, p4, V4); vxm_bstore(f2, rp, p4, 2 * V4);
+        const float z = vxm_src_coord(d, f0, D), y = vxm_src_coord(h, f1, H), x = vxm_src_coord(w, f2, W);
+        if (MODE == VXM_INTERP_NEAREST) {
+            const float rz = rintf(z), ry = rintf(y), rx = rintf(x);
+            const bool in = (rz >= 0.0f) & (rz <= (float)(D - 1)) & (ry >= 0.0f) & (ry <= (float)(H - 1)) & (rx >= 0.0f) & (rx <= (float)(W - 1));
+            const int idx4 = in ? (((int)rz * H + (int)ry) * W + (int)rx) << 2 : VXM_OOB;
+            for (int c = 0; c < C; ++c) {
+                const __amdgpu_buffer_rsrc_t rs = vxm_rsrc(s + (size_t)c * V, (unsigned)V4), ro = vxm_rsrc(o + (size_t)c * V, (unsigned)V4);
+                vxm_bstore(vxm_bload(rs, idx4, 0), ro, p4, 0);
+            }
+            continue;
+        }
+        const Corners8 cn = corners8(z, y, x, D, H, W);
+        for (int c = 0; c < C; ++c) {
+            const __amdgpu_buffer_rsrc_t rs = vxm_rsrc(s + (size_t)c * V, (unsigned)V4), ro = vxm_rsrc(o + (size_t)c * V, (unsigned)V4);
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = vxm_bload(rs, cn.idx[k] << 2, 0);
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += v[k] * cn.w[k];
+            vxm_bstore(acc, ro, p4, 0);
+        }
+    }
+}
+
+// backward of the fused kernel w.r.t. the DISPLACEMENT at full resolution: gpos [B,3,D,H,W] = d out / d pos_flow (k_warp3d_bwd's sum with
+// the displacement recomputed from the low-resolution field); vxm_resize3d_bwd then carries it onto the low-resolution grid.  (The two
+// are not one kernel: a block that contracts gpos for a tile of low-resolution voxels needs it on the tile grown by the tap span, 1.46 x
+// the voxels for the shapes of this path -- recomputing a vector-ALU-bound sum costs more than the 165 MB round trip it would save.)
+__global__ void __launch_bounds__(256) k_warp3d_up_bwd(const float* __restrict__ src, const float* __restrict__ flo, const float* __restrict__ gout,
+                                                       float* __restrict__ gpos, int C, int D, int H, int W, int lD, int lH, int lW, float rd, float rh,
+                                                       float rw, float pre, float post) {
+    __shared__ int si0[RT_N], si1[RT_N];
+    __shared__ float sl0[RT_N], sl1[RT_N];
+    __shared__ float fl[3][WU_LN];
+    int d0, h0, w0;
+    rt_tile(W, H, d0, h0, w0);
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int V = D * H * W, V4 = V << 2;
+    wu_stage(flo + (size_t)b * 3 * lD * lH * lW, lD, lH, lW, D, H, W, rd, rh, rw, pre, d0, h0, w0, si0, si1, sl0, sl1, fl);
+    const int tx = tid & 31, ty = tid >> 5;
+    const int w = w0 + tx, h = h0 + ty;
+    if (w >= W || h >= H) return;
+    const float* s = src + (size_t)b * C * V;
+    const float* go = gout + (size_t)b * C * V;
+    const __amdgpu_buffer_rsrc_t rg = vxm_rsrc(gpos + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
+    const WuPlanes pl = wu_planes(si0, si1, sl0, sl1, fl, tx, ty);
+#pragma unroll
+    for (int dd = 0; dd < RT_D; ++dd) {
+        const int d = d0 + dd;
+        if (d >= D) break;
+        float f0, f1, f2;
+        wu_flow(si0, si1, sl0, sl1, pl, dd, post, f0, f1, f2);
+        const int p4 = ((d * H + h) * W + w) << 2;
+        const Corners8 cn = corners8(vxm_src_coord(d, f0, D), vxm_src_coord(h, f1, H), vxm_src_coord(w, f2, W), D, H, W);
+        float gz = 0.0f, gy = 0.0f, gx = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            const __amdgpu_buffer_rsrc_t rs = vxm_rsrc(s + (size_t)c * V, (unsigned)V4), rgo = vxm_rsrc(go + (size_t)c * V, (unsigned)V4);
+            const float g = vxm_bload(rgo, p4, 0);
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = vxm_bload(rs, cn.idx[k] << 2, 0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int dz = (k >> 2) & 1, dy = (k >> 1) & 1, dx = k & 1;
+                const float vk = cn.ok[k] ? v[k] * g : 0.0f;
+                gz += (dz ? vk : -vk) * (cn.wy[dy] * cn.wx[dx]);
+                gy += (dy ? vk : -vk) * (cn.wz[dz] * cn.wx[dx]);
+                gx += (dx ? vk : -vk) * (cn.wz[dz] * cn.wy[dy]);
+            }
+        }
+        vxm_bstore(gz, rg, p4, 0); vxm_bstore(gy, rg, p4, V4); vxm_bstore(gx, rg, p4, 2 * V4);
+    }
+}
+
+// ---- adjoint of an UP-sampling resize, marching form (round 6; k_resize3d_bwd_sep ran at 0.8 TB/s: 1024-thread blocks, three block-wide
+// contractions of a 14 x 22 x 38 block of gradients per 4 x 8 x 16 tile, one tile in flight per CU).  A block of 256 threads owns an
+// 8 x 32 (H x W) tile of INPUT voxels -- one per thread -- over a segment of input depths and marches through the output planes that reach
+// it: plane od contributes to the two input depths lin_src(od) names, so a thread keeps two running sums and retires one whenever the
+// lower depth advances.  Per plane: the (<= 21 x 75) gradients the tile's taps touch go to LDS (requested one plane ahead), are contracted
+// along W (5 taps), then along H (5 taps), and the thread adds its value to its sums -- each gradient is read once per block, the depth
+// overlap between segments is 3 - 4 planes in ~ 40.  Same weights (axis_taps: the forward's index / lambda arithmetic) and the same
+// W -> H -> D, ascending-tap summation order as the separable kernel; deterministic.  Ratios in [0.45, 0.75).
+constexpr int RM_H = 8, RM_W = 32, RM_N = RM_W + RM_H, RM_T = 5, RM_SH = 21, RM_SW = 75, RM_NL = (RM_SH * RM_SW + 255) / 256;
+__global__ void __launch_bounds__(256) k_resize3d_bwd_march(const float* __restrict__ gout, float* __restrict__ gx, int D, int H, int W, int oD, int oH,
+                                                            int oW, float rd, float rh, float rw, float scale, int seg_len) {
+    __shared__ float G[RM_SH * RM_SW];
+    __shared__ float T[RM_SH * RM_W];
+    __shared__ float sw[RM_N][RM_T + 1];
+    __shared__ int so[RM_N];
+    const int tw = (W + RM_W - 1) / RM_W, th = (H + RM_H - 1) / RM_H;
+    int t = blockIdx.x;
+    const int w0 = (t % tw) * RM_W; t /= tw;
+    const int h0 = (t % th) * RM_H;
+    const int dlo = (t / th) * seg_len, dhi = min(D, dlo + seg_len);
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    if (tid < RM_N) {
+        const int ax = tid < RM_W ? 2 : 1;
+        const int i = ax == 2 ? w0 + tid : h0 + tid - RM_W;
+        const int n_in = ax == 2 ? W : H, n_out = ax == 2 ? oW : oH;
+        int olo;
+        float wt[RS_KC];
+        axis_taps(min(i, n_in - 1), ax == 2 ? rw : rh, n_in, n_out, olo, wt);
+        int klo = 0;
+        while (klo < RS_KC - RM_T && wt[klo] == 0.0f) ++klo;                   // first tap that counts; at most RM_T of them (ratio >= 0.4)
+#pragma unroll
+        for (int k = 0; k < RM_T; ++k) {
+            float v = 0.0f;
+#pragma unroll
+            for (int j = 0; j < RS_KC; ++j) v = (j == klo + k) ? wt[j] : v;
+            sw[tid][k] = i < n_in ? v : 0.0f;
+        }
+        so[tid] = olo + klo;
+    }
+    __syncthreads();
+    const int bw = so[0], bh = so[RM_W];
+    const int nw = min(RM_SW, oW - bw), nh = min(RM_SH, oH - bh);              // the block of output gradients the tile can touch (clipped)
+    const size_t bc = blockIdx.y;
+    const __amdgpu_buffer_rsrc_t rg = vxm_rsrc(gout + bc * (size_t)oD * oH * oW, (unsigned)oD * (unsigned)oH * (unsigned)oW * 4u);
+    // output planes that reach the input depths [dlo, dhi): those whose lower source depth is in [dlo - 1, dhi - 1]
+    int od0 = rd > 0.0f ? max(0, (int)floorf((float)(dlo - 1) / rd) - 1) : 0;
+    {
+        int i0, i1; float l0, l1;
+        for (;; ++od0) { lin_src(min(od0, oD - 1), rd, D, i0, i1, l0, l1); if (i1 >= dlo || od0 >= oD - 1) break; }
+    }
+    // THREE planes in flight per thread (the body of a plane is ~500 cycles, the latency of its loads several times that): register sets
+    // rotate through an unrolled-by-three plane loop
+    constexpr int RM_PF = 3;
+    float v[RM_PF][RM_NL];
+    int voff[RM_NL];
+#pragma unroll
+    for (int u = 0; u < RM_NL; ++u) {
+        const int i = tid + 256 * u, r = i / RM_SW, c = i - r * RM_SW;
+        voff[u] = (r < nh && c < nw && i < RM_SH * RM_SW) ? ((bh + r) * oW + bw + c) << 2 : VXM_OOB;
+    }
+    const int plane4 = (oH * oW) << 2;
+    auto request = [&](auto set_, int od) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_)::value;
+        const int gate = od < oD ? 0 : VXM_OOB;                                 // wave-uniform: past the last plane nothing is read
+#pragma unroll
+        for (int u = 0; u < RM_NL; ++u) v[S][u] = vxm_bload(rg, voff[u] | gate, od < oD ? od * plane4 : 0);
+    };
+    const int ch = so[RM_W + ty] - bh;
+    float wH[RM_T];
+#pragma unroll
+    for (int k = 0; k < RM_T; ++k) wH[k] = sw[RM_W + ty][k];
+    float* o = gx + bc * (size_t)D * H * W;
+    const bool own = h0 + ty < H && w0 + tx < W;
+    int dcur = dlo - 1;                                                        // depth accA belongs to; accB: dcur + 1
+    float accA = 0.0f, accB = 0.0f;
+    bool done = false;
+    auto plane = [&](auto set_, int od) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_)::value;
+        if (done || od >= oD) { done = true; return; }
+        int i0, i1;
+        float l0, l1;
+        lin_src(od, rd, D, i0, i1, l0, l1);
+        if (i0 >= dhi) { done = true; return; }                                 // block-uniform
+#pragma unroll
+        for (int u = 0; u < RM_NL; ++u) {
+            const int i = tid + 256 * u;
+            if (i < RM_SH * RM_SW) G[i] = v[S][u];
+        }
+        request(set_, od + RM_PF);
+        __syncthreads();
+        for (int i = tid; i < RM_SH * RM_W; i += 256) {                         // contract W: row r, input column i & 31
+            const int r = i >> 5, x = i & 31;
+            const int c0 = so[x] - bw;                                          // (taps past the clipped block have weight zero: clamped, not read out of bounds)
+            const float* g = G + r * RM_SW;
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < RM_T; ++k) a += sw[x][k] * g[min(c0 + k, RM_SW - 1)];
+            T[i] = a;
+        }
+        __syncthreads();
+        float val = 0.0f;
+#pragma unroll
+        for (int k = 0; k < RM_T; ++k) val += wH[k] * T[min(ch + k, RM_SH - 1) * RM_W + tx];
+        while (dcur < i0) {                                                     // the lower source depth advanced: accA is complete
+            if (own && dcur >= dlo) o[((size_t)dcur * H + h0 + ty) * W + w0 + tx] = accA * scale;
+            accA = accB; accB = 0.0f; ++dcur;
+        }
+        // dcur == i0 here (i0 >= dlo - 1 by the choice of od0)
+        if (i1 == i0) accA += (l0 + l1) * val;
+        else { accA += l0 * val; accB += l1 * val; }
+    };
+    using J0 = std::integral_constant<int, 0>;
+    using J1 = std::integral_constant<int, 1>;
+    using J2 = std::integral_constant<int, 2>;
+    request(J0{}, od0); request(J1{}, od0 + 1); request(J2{}, od0 + 2);
+    for (int od = od0; !done; od += RM_PF) {
+        plane(J0{}, od);
+        plane(J1{}, od + 1);
+        plane(J2{}, od + 2);
+    }
+    for (; dcur < dhi; ++dcur) {                                                // retire what is left
+        if (own && dcur >= dlo) o[((size_t)dcur * H + h0 + ty) * W + w0 + tx] = accA * scale;
+        accA = accB; accB = 0.0f;
+    }
+}
+
 int check_vol(const char* fn, int B, int C, int D, int H, int W) {
     VXM_REQUIRE(B > 0 && C > 0 && D > 1 && H > 1 && W > 1, VXM_ERR_BAD_SHAPE,
                 "%s: bad shape B=%d C=%d D=%d H=%d W=%d (3-D volumes with every extent > 1)", fn, B, C, D, H, W);
@@ -775,6 +1145,62 @@ int vxm_warp3d_bwd(const float* src, const float* flow, const float* gout, float
     else
         hipLaunchKernelGGL(k_warp3d_bwd<VXM_INTERP_LINEAR>, grid, dim3(256), 0, VXM_STREAM(stream), src, flow, gout, gsrc, gflow, C, D, H, W);
     return vxm_check_launch("vxm_warp3d_bwd");
+}
+
+static int warp_up_args(const char* fn, int B, int C, int D, int H, int W, int lD, int lH, int lW, float factor, float& rd, float& rh, float& rw) {
+    if (int e = check_vol(fn, B, C, D, H, W)) return e;
+    if (int e = check_vol(fn, B, 3, lD, lH, lW)) return e;
+    VXM_REQUIRE(factor > 0.0f, VXM_ERR_BAD_SHAPE, "%s: factor %g", fn, factor);
+    rd = (float)(lD - 1) / (float)(D - 1); rh = (float)(lH - 1) / (float)(H - 1); rw = (float)(lW - 1) / (float)(W - 1);
+    VXM_REQUIRE(rd <= 0.51f && rh <= 0.51f && rw <= 0.51f, VXM_ERR_UNSUPPORTED,
+                "%s: the fused kernel stages a 4 x 6 x 18 block of the low-resolution field per 4 x 8 x 32 output tile: it takes fields at most about "
+                "half as fine as the image per axis (%dx%dx%d -> %dx%dx%d); resize and warp separately otherwise (vxm_warp3d_up_ok)", fn, lD, lH, lW, D, H, W);
+    return VXM_OK;
+}
+
+int vxm_warp3d_up_ok(int D, int H, int W, int lD, int lH, int lW) {
+    if (D < 2 || H < 2 || W < 2 || lD < 2 || lH < 2 || lW < 2) return 0;
+    return (float)(lD - 1) / (float)(D - 1) <= 0.51f && (float)(lH - 1) / (float)(H - 1) <= 0.51f && (float)(lW - 1) / (float)(W - 1) <= 0.51f;
+}
+
+int vxm_warp3d_up_fwd(const float* src, const float* flow_lo, float* out, float* pos_flow, int B, int C, int D, int H, int W, int lD, int lH, int lW,
+                      float factor, int mode, void* stream) {
+    float rd, rh, rw;
+    if (int e = warp_up_args("vxm_warp3d_up_fwd", B, C, D, H, W, lD, lH, lW, factor, rd, rh, rw)) return e;
+    VXM_REQUIRE(src && flow_lo && out, VXM_ERR_NULL_POINTER, "vxm_warp3d_up_fwd: null pointer");
+    VXM_REQUIRE(mode == VXM_INTERP_LINEAR || mode == VXM_INTERP_NEAREST, VXM_ERR_UNSUPPORTED, "vxm_warp3d_up_fwd: mode %d", mode);
+    const float pre = factor > 1.0f ? factor : 1.0f, post = factor < 1.0f ? factor : 1.0f;
+    const long long tiles = (long long)((W + RT_W - 1) / RT_W) * ((H + RT_H - 1) / RT_H) * ((D + RT_D - 1) / RT_D);
+    VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_warp3d_up_fwd: too many tiles");
+    if (mode == VXM_INTERP_NEAREST)
+        hipLaunchKernelGGL(k_warp3d_up_fwd<VXM_INTERP_NEAREST>, dim3((unsigned)tiles, B), dim3(256), 0, VXM_STREAM(stream), src, flow_lo, out, pos_flow,
+                           C, D, H, W, lD, lH, lW, rd, rh, rw, pre, post);
+    else
+        hipLaunchKernelGGL(k_warp3d_up_fwd<VXM_INTERP_LINEAR>, dim3((unsigned)tiles, B), dim3(256), 0, VXM_STREAM(stream), src, flow_lo, out, pos_flow,
+                           C, D, H, W, lD, lH, lW, rd, rh, rw, pre, post);
+    return vxm_check_launch("vxm_warp3d_up_fwd");
+}
+
+int vxm_warp3d_up_bwd(const float* src, const float* flow_lo, const float* gout, float* gflow_lo, float* work, size_t work_bytes, int B, int C, int D,
+                      int H, int W, int lD, int lH, int lW, float factor, int mode, void* stream) {
+    float rd, rh, rw;
+    if (int e = warp_up_args("vxm_warp3d_up_bwd", B, C, D, H, W, lD, lH, lW, factor, rd, rh, rw)) return e;
+    VXM_REQUIRE(src && flow_lo && gout && gflow_lo && work, VXM_ERR_NULL_POINTER, "vxm_warp3d_up_bwd: null pointer");
+    VXM_REQUIRE(mode == VXM_INTERP_LINEAR || mode == VXM_INTERP_NEAREST, VXM_ERR_UNSUPPORTED, "vxm_warp3d_up_bwd: mode %d", mode);
+    const size_t nfull = (size_t)B * 3 * D * H * W;
+    VXM_REQUIRE(work_bytes >= nfull * sizeof(float), VXM_ERR_WORKSPACE, "vxm_warp3d_up_bwd: work holds %zu bytes, needs %zu (B x 3 x D x H x W floats)",
+                work_bytes, nfull * sizeof(float));
+    if (mode == VXM_INTERP_NEAREST) {            // nearest sampling has no gradient w.r.t. the displacement (k_warp3d_bwd writes zeros)
+        (void)hipMemsetAsync(gflow_lo, 0, sizeof(float) * (size_t)B * 3 * lD * lH * lW, VXM_STREAM(stream));
+        return vxm_check_launch("vxm_warp3d_up_bwd");
+    }
+    const float pre = factor > 1.0f ? factor : 1.0f, post = factor < 1.0f ? factor : 1.0f;
+    const long long tiles = (long long)((W + RT_W - 1) / RT_W) * ((H + RT_H - 1) / RT_H) * ((D + RT_D - 1) / RT_D);
+    VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_warp3d_up_bwd: too many tiles");
+    hipLaunchKernelGGL(k_warp3d_up_bwd, dim3((unsigned)tiles, B), dim3(256), 0, VXM_STREAM(stream), src, flow_lo, gout, work, C, D, H, W, lD, lH, lW,
+                       rd, rh, rw, pre, post);
+    if (int e = vxm_check_launch("vxm_warp3d_up_bwd")) return e;
+    return vxm_resize3d_bwd(work, gflow_lo, B, 3, lD, lH, lW, D, H, W, factor, stream);
 }
 
 int vxm_vecint_fwd(const float* vec, float* steps, int B, int D, int H, int W, int nsteps, void* stream) {
@@ -859,7 +1285,17 @@ int vxm_resize3d_bwd(const float* gout, float* gx, int B, int C, int D, int H, i
                 rw = oW > 1 ? (float)(W - 1) / (float)(oW - 1) : 0.0f;
     const float rmin = fminf(oD > 1 ? rd : 1.0f, fminf(oH > 1 ? rh : 1.0f, oW > 1 ? rw : 1.0f));
     const float rmax = fmaxf(rd, fmaxf(rh, rw));
-    if (rmin > 0.4f && rmax < 0.75f) {      // up-sampling by ~2: separable passes through LDS
+    static const bool use_march = [] { const char* e = getenv("VXM_RESIZE_BWD"); return !(e && e[0] == 's'); }();      // VXM_RESIZE_BWD=sep: the round-3 kernel (A/B)
+    if (use_march && rmin >= 0.47f && rmax < 0.75f) {      // up-sampling by ~2: one thread per input voxel marching through the output planes
+        const int tiles2 = ((W + RM_W - 1) / RM_W) * ((H + RM_H - 1) / RM_H);
+        int nseg = (1024 + tiles2 * B * C - 1) / (tiles2 * B * C);          // ~1000 blocks; a segment re-reads 3 - 4 output planes of its neighbour
+        nseg = nseg < 1 ? 1 : nseg;
+        int seg_len = (D + nseg - 1) / nseg;
+        seg_len = seg_len < 4 ? (D < 4 ? D : 4) : seg_len;
+        nseg = (D + seg_len - 1) / seg_len;
+        hipLaunchKernelGGL(k_resize3d_bwd_march, dim3((unsigned)(tiles2 * nseg), B * C), dim3(256), 0, VXM_STREAM(stream),
+                           gout, gx, D, H, W, oD, oH, oW, rd, rh, rw, factor, seg_len);
+    } else if (rmin > 0.4f && rmax < 0.75f) {      // separable passes through LDS
         const long long tiles = (long long)((W + RB_W - 1) / RB_W) * ((H + RB_H - 1) / RB_H) * ((D + RB_D - 1) / RB_D);
         VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_resize3d_bwd: too many tiles");
         constexpr int lds = (RB_SD * RB_SH * RB_SW + RB_SD * RB_SH * RB_W + RB_N * (RS_KC + 1) + RB_N) * 4;
@@ -869,6 +1305,11 @@ int vxm_resize3d_bwd(const float* gout, float* gx, int B, int C, int D, int H, i
         }();
         (void)attr;
         hipLaunchKernelGGL(k_resize3d_bwd_sep, dim3((unsigned)tiles, B * C), dim3(RB_THREADS), lds, VXM_STREAM(stream),
+                           gout, gx, D, H, W, oD, oH, oW, rd, rh, rw, factor);
+    } else if (use_march && rmin >= 1.0f) {      // down-sampling: at most two outputs per axis name an input voxel
+        const long long tiles = (long long)((W + RT_W - 1) / RT_W) * ((H + RT_H - 1) / RT_H) * ((D + 15) / 16);
+        VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_resize3d_bwd: too many tiles");
+        hipLaunchKernelGGL(k_resize3d_bwd_down, dim3((unsigned)tiles, B * C), dim3(256), 0, VXM_STREAM(stream),
                            gout, gx, D, H, W, oD, oH, oW, rd, rh, rw, factor);
     } else if (rmin > 0.4f) {       // floor(2/ratio) + 3 <= RS_KC: every contributing output is among the candidates
         const long long tiles = (long long)((W + RT_W - 1) / RT_W) * ((H + RT_H - 1) / RT_H) * ((D + RT_D - 1) / RT_D);

@@ -126,6 +126,59 @@ class WarpFn(torch.autograd.Function):
         return gsrc, gflow, None
 
 
+# VXM_FUSE_UPWARP=0: `fullsize` and the final SpatialTransformer of VxmDense as two kernels with the full-resolution pos_flow between them (rounds 1-5)
+FUSE_UPWARP = os.environ.get("VXM_FUSE_UPWARP", "1") != "0"
+
+
+def warp_up_ok(src, flow_lo):
+    """can `transformer(src, fullsize(flow_lo))` run as the fused kernel (vxm_warp3d_up_fwd)?  3-D, a field at most about half as fine as the
+    image, and no gradient wanted for src (the fused backward produces none: the images of the path need none)"""
+    return (FUSE_UPWARP and src.dim() == 5 and flow_lo.dim() == 5 and not (src.requires_grad and torch.is_grad_enabled())
+            and bool(_lib.lib().vxm_warp3d_up_ok(*[int(v) for v in src.shape[2:]], *[int(v) for v in flow_lo.shape[2:]])))
+
+
+class WarpUpFn(torch.autograd.Function):
+    """`transformer(source, fullsize(flow))` (voxelmorph/torch/networks.py:275-280 with layers.py:85-97 and :30-48) as ONE kernel: the
+    full-resolution displacement is evaluated in registers from the integrated half-resolution field and never stored.  Same values as
+    ResizeFn + WarpFn bit for bit.  Returns the moved image; `want_pos` also returns the displacement (registration=True)."""
+
+    @staticmethod
+    def forward(ctx, src, flow_lo, factor, mode, want_pos):
+        _vol3(src, "SpatialTransformer")
+        require_device(src, flow_lo)
+        src, flow_lo = _c(src), _c(flow_lo)
+        B, C, D, H, W = src.shape
+        lD, lH, lW = (int(v) for v in flow_lo.shape[2:])
+        if flow_lo.shape[0] != B or flow_lo.shape[1] != 3 or (D, H, W) != tuple(int(math.floor(s * factor)) for s in (lD, lH, lW)):
+            raise ValueError("flow %s resized by %g does not match src %s" % (tuple(flow_lo.shape), factor, tuple(src.shape)))
+        out = torch.empty_like(src)
+        pos = torch.empty((B, 3, D, H, W), dtype=src.dtype, device=src.device) if want_pos else None
+        V, lV = D * H * W, lD * lH * lW
+        with _prof.region("warp3d_up_fwd", nbytes=4.0 * B * (V * (2 * C + (3 if want_pos else 0)) + 3 * lV)):
+            call("vxm_warp3d_up_fwd", ptr(src), ptr(flow_lo), ptr(out), ptr(pos), B, C, D, H, W, lD, lH, lW, float(factor), INTERP[mode], stream())
+        ctx.save_for_backward(src, flow_lo)
+        ctx.args = (float(factor), mode)
+        if want_pos:
+            ctx.mark_non_differentiable(pos)
+            return out, pos
+        return out
+
+    @staticmethod
+    def backward(ctx, gout, *_):
+        src, flow_lo = ctx.saved_tensors
+        factor, mode = ctx.args
+        B, C, D, H, W = src.shape
+        lD, lH, lW = (int(v) for v in flow_lo.shape[2:])
+        gout = _c(gout)
+        gflow = torch.empty_like(flow_lo)
+        work = torch.empty((B, 3, D, H, W), dtype=src.dtype, device=src.device)
+        V, lV = D * H * W, lD * lH * lW
+        with _prof.region("warp3d_up_bwd", nbytes=4.0 * B * (V * (2 * C + 6) + 6 * lV)):
+            call("vxm_warp3d_up_bwd", ptr(src), ptr(flow_lo), ptr(gout), ptr(gflow), ptr(work), work.numel() * 4, B, C, D, H, W, lD, lH, lW,
+                 factor, INTERP[mode], stream())
+        return None, gflow, None, None, None
+
+
 class VecIntFn(torch.autograd.Function):
     """VecInt.forward (voxelmorph/torch/layers.py:64-68), nsteps >= 1."""
 

@@ -236,9 +236,11 @@ class VxmDense(LoadableModel):
         self.integrate = layers.VecInt([int(extent / int_downsize) for extent in inshape], int_steps) if integrating else None
         self.transformer = layers.SpatialTransformer(inshape)
 
-    def _forward_all(self, source, target):
+    def _forward_all(self, source, target, need_disp=True):
         """Everything `forward` can return (reference: networks.py:244-287): (moved source, moved target or None, the field
-        the smoothness loss sees, positive displacement, negative displacement or None)."""
+        the smoothness loss sees, positive displacement, negative displacement or None).  need_disp=False (the training outputs): the
+        full-resolution displacements are not returned, and when `fullsize` upsamples an integrated field they are never materialised --
+        `fullsize` + `transformer` run as one kernel (functional.WarpUpFn) on the half-resolution field."""
         if self.ndims == 2:
             field = self.flow(self.unet_model(torch.cat([source, target], dim=1)))
         else:
@@ -258,14 +260,27 @@ class VxmDense(LoadableModel):
                     v = self.fullsize(v)
             return v
 
-        forward_disp = displacement(velocity)
-        backward_disp = displacement(-velocity) if self.bidir else None
-        moved_source = self.transformer(source, forward_disp)
-        moved_target = self.transformer(target, backward_disp) if self.bidir else None
+        def moved(image, v):
+            """image warped by the displacement of velocity v -> (moved image, displacement or None)"""
+            if self.ndims == 3 and self.integrate is not None and self.fullsize is not None and self.fullsize.factor != 1:
+                low = self.integrate(v)
+                # (a displacement that is RETURNED while gradients are recorded must stay differentiable -- the semi-supervised head warps
+                # labels with it: that case keeps the two-kernel path, whose pos_flow is an autograd output)
+                if VF.warp_up_ok(image, low) and not (need_disp and torch.is_grad_enabled() and low.requires_grad):
+                    if need_disp:
+                        return VF.WarpUpFn.apply(image, low, self.fullsize.factor, self.transformer.mode, True)
+                    return VF.WarpUpFn.apply(image, low, self.fullsize.factor, self.transformer.mode, False), None
+                disp = self.fullsize(low)
+            else:
+                disp = displacement(v)
+            return self.transformer(image, disp), disp
+
+        moved_source, forward_disp = moved(source, velocity)
+        moved_target, backward_disp = moved(target, -velocity) if self.bidir else (None, None)
         return moved_source, moved_target, velocity, forward_disp, backward_disp
 
     def forward(self, source, target, registration=False):
-        moved_source, moved_target, velocity, forward_disp, _ = self._forward_all(source, target)
+        moved_source, moved_target, velocity, forward_disp, _ = self._forward_all(source, target, need_disp=registration)
         if registration:
             return moved_source, forward_disp
         return (moved_source, moved_target, velocity) if self.bidir else (moved_source, velocity)
