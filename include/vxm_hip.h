@@ -88,8 +88,11 @@ int vxm_vecint_fwd(const float* vec, float* steps, int B, int D, int H, int W, i
  * tile into 64-bit fixed-point LDS accumulators -- so the result is bit-reproducible; only steps that displace a voxel by more than 24
  * voxels fall back to global float atomics).  nsteps < 31. */
 #define VXM_VECINT_WORK_EXTRA 128
-/* work_bytes: size of `work`, checked against vxm_workspace_bytes(VXM_WS_VECINT_BWD, ...) (VXM_ERR_WORKSPACE when short): the call clears
- * VXM_VECINT_WORK_EXTRA words BEHIND the two gradient buffers, so a caller that sized the scratch by hand used to overrun silently. */
+/* work_bytes: size of `work` (VXM_ERR_WORKSPACE when below 2*B*3*D*H*W + VXM_VECINT_WORK_EXTRA floats: the call clears the statistics BEHIND
+ * the two gradient buffers, so a caller that sized the scratch by hand used to overrun silently).  With vxm_workspace_bytes(VXM_WS_VECINT_BWD,
+ * 0, 0, B, D, H, W) bytes the gather also records each 4 x 8 x 32 tile's largest far displacement and the deterministic pass grows an output
+ * tile by what the sender tiles around it need (a handful of outliers no longer make every tile walk the batch maximum); with less it uses
+ * the step's global maximum.  Same results either way. */
 int vxm_vecint_bwd_ws(const float* vec, const float* steps, const float* gout, float* gvec, float* work, size_t work_bytes,
                       int B, int D, int H, int W, int nsteps, void* stream);
 /* ABI 0.4 name, kept: the same call for a caller that vouches for (2*B*3*D*H*W + VXM_VECINT_WORK_EXTRA) floats of scratch. */

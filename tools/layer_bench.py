@@ -84,7 +84,7 @@ def main():
     for kind, amp in (("zero", 0.0), ("smooth2.5", 2.5)):
         vel = smooth_field(HALF, amp, 4.0, 1) if amp > 0 else torch.zeros((1, 3) + HALF, device="cuda")
         steps = torch.empty((7, 1, 3) + HALF, device="cuda")
-        gv, work, g7 = torch.empty_like(vel), torch.empty(VF.vecint_work_elems(n), device="cuda"), torch.randn_like(vel)
+        gv, work, g7 = torch.empty_like(vel), torch.empty(VF.vecint_work_elems(vel.shape), device="cuda"), torch.randn_like(vel)
         ms = timed(lambda: call("vxm_vecint_fwd", ptr(vel), ptr(steps), 1, *HALF, 7, stream()), args.iters)
         report("VecInt(7) fwd", kind, ms, 7 * 24.0 * Vh)
         ms = timed(lambda: call("vxm_vecint_bwd_ws", ptr(vel), ptr(steps), ptr(g7), ptr(gv), ptr(work), work.numel() * 4, 1, *HALF, 7, stream()), args.iters)

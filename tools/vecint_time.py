@@ -51,11 +51,21 @@ def main():
     if args.case in ("smooth", "both"):
         for amp in (1.6, 3.0):
             cases.append(("smooth field, max |v| %.1f voxels" % float(amp * smooth.abs().max()), (amp * smooth).contiguous()))
+    if args.case in ("smooth", "both"):
+        # the first smooth field + two localised ~20-voxel bumps (verdict round 5, item 5).  Before round 6 every tile of the far pass walked the
+        # batch maximum (~200 x its volume for a 20-voxel maximum); now a tile's radius is what the sender tiles around it need.  The second
+        # line of the case passes the ABI-0.4 scratch size, which selects the global radius: the old behaviour, for comparison.
+        zz, yy, xx = torch.meshgrid(*[torch.arange(s, dtype=torch.float32, device="cuda") for s in shape], indexing="ij")
+        bumpy = (1.6 * smooth).contiguous().clone()
+        for (fz, fy, fx, c, a) in ((0.2, 0.3, 0.25, 2, 20.0), (0.7, 0.6, 0.8, 0, -20.0)):
+            bumpy[:, c] += a * torch.exp(-((zz - fz * D) ** 2 + (yy - fy * H) ** 2 + (xx - fx * W) ** 2) / (2 * 5.0 ** 2))
+        cases.append(("the 5.2-voxel field + two 20-voxel bumps", bumpy))
+        cases.append(("  the same, global radius (ABI 0.4 scratch)", bumpy))
     for name, vec in cases:
         gout = torch.randn_like(vec)
         steps = torch.empty((n,) + tuple(vec.shape), device="cuda")
         gvec = torch.empty_like(vec)
-        work = torch.zeros(VF.vecint_work_elems(vec.numel()), device="cuda")
+        work = torch.zeros(2 * vec.numel() + 128 if "global radius" in name else VF.vecint_work_elems(vec.shape), device="cuda")
 
         def fwd():
             call("vxm_vecint_fwd", ptr(vec), ptr(steps), B, D, H, W, n, stream())

@@ -25,7 +25,9 @@ size_t vxm_workspace_bytes(int op, int Cin, int Cout, int B, int D, int H, int W
         case VXM_WS_S3U_BWD_WEIGHT: return vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes(Cin, Cout, B, D, H, W);
         case VXM_WS_BF16_BWD_WEIGHT: return vxm_bf16_conv_bwd_weight_workspace_bytes(Cin, Cout, B, D, H, W);
         case VXM_WS_CONV_BWD_DATA: return sizeof(float) * vxm_conv3d_k3_packed_elems(Cout, Cin);            /* the adjoint operator: Cout -> Cin */
-        case VXM_WS_VECINT_BWD: return sizeof(float) * (2 * (size_t)B * 3 * D * H * W + VXM_VECINT_WORK_EXTRA);
+        case VXM_WS_VECINT_BWD:         /* two gradient buffers + the per-step statistics + the per-tile (4 x 8 x 32) displacement records of up to 30 steps */
+            return sizeof(float) * (2 * (size_t)B * 3 * D * H * W + VXM_VECINT_WORK_EXTRA +
+                                    30 * (size_t)B * ((size_t)((D + 3) / 4) * ((H + 7) / 8) * ((W + 31) / 32)));
         default: return 0;
     }
 }

@@ -245,7 +245,8 @@ __device__ __forceinline__ VgStaged vg_stage(float v0, float v1, float v2, int p
     return s;
 }
 __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __restrict__ in, float scale, const float* __restrict__ gout,
-                                                                 float* __restrict__ gin, unsigned* __restrict__ far_count, int D, int H, int W) {
+                                                                 float* __restrict__ gin, unsigned* __restrict__ far_count, unsigned* __restrict__ tile_dm,
+                                                                 int D, int H, int W) {
     __shared__ f32x4 recA[VG_LN];                                 // {E_z, E_y, E_x, g_0 (0 when not near)}
     __shared__ vg_f32x2 recB[VG_LN];                              // {g_1, g_2}
     __shared__ float vL[3][VG_LN];                                // v = in * scale
@@ -317,6 +318,9 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_gather(const float* __
         unsigned cnt = 0, dm = 0, gm = 0;
         for (int i = 0; i < 16; ++i) { cnt += farw[i][0]; dm = max(dm, farw[i][1]); gm = max(gm, farw[i][2]); }       // (non-negative floats order as their bits)
         if (cnt) { atomicAdd(far_count, cnt); atomicMax(far_count + 1, dm); atomicMax(far_count + 2, gm); }
+        // the largest displacement among THIS tile's far senders (float bits, 0: none): the far pass grows an output tile by what the sender
+        // tiles around it need, not by the batch's maximum (round 6).  Every block writes its entry on every step: no zeroing.
+        if (tile_dm) tile_dm[(size_t)b * gridDim.x + blockIdx.x] = cnt ? dm : 0u;
     }
     if (!own_in) return;
     // ---- local part: identity + derivative through the sampling position (the 8 corners of x'(q) sampled from v itself)
@@ -398,11 +402,14 @@ constexpr int VF_RMAX = 24;
 // (far_count[2]): 2^46 <= max |g| 2^k < 2^47, i.e. 46 significant bits below the largest contribution and 16 bits of headroom above.
 // Every output voxel is then read-modify-written by exactly one thread.  Cost ~ (grown tile / tile) x the forward step's arithmetic.
 __global__ void __launch_bounds__(1024) k_vecint_step_bwd_far_tiles(const float* __restrict__ in, float scale, const float* __restrict__ gout,
-                                                                    float* __restrict__ gin, const unsigned* __restrict__ far_count, int B, int D, int H, int W) {
+                                                                    float* __restrict__ gin, const unsigned* __restrict__ far_count,
+                                                                    const unsigned* __restrict__ tile_dm, int B, int D, int H, int W) {
     if (far_count[0] == 0) return;                                // block-uniform: the regime of small steps (the launch is a small persistent grid)
     const float dm = __uint_as_float(far_count[1]);
     __shared__ unsigned long long acc[3][VG_TD * VG_TH * VG_TW];
-    __shared__ int poison;                                        // a far sender of this tile carried a non-finite gradient: its targets become NaN
+    __shared__ unsigned pmask[3][VG_TD * VG_TH * VG_TW / 32];      // targets that received a non-finite contribution: THEY become NaN (grid_sample's
+                                                                  // backward poisons the 8 corners of the sender, not the tile; ADVICE rounds 4 / 5)
+    __shared__ unsigned rtile;                                    // this output tile's radius (float bits)
     const int tid = threadIdx.x;
     const int tx = tid & 31, ty = (tid >> 5) & 7, dd = tid >> 8;
     int Eg = (int)(far_count[2] >> 23) & 255;
@@ -423,13 +430,38 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_far_tiles(const float*
             if (h < H && w < W && d < D) vecint_far_voxel(in, scale, gout, gin, b, d * HW + h * W + w, D, H, W);
             continue;
         }
-        const int R = (int)dm + 1;                                // corners of a sender lie within ceil(displacement) of it
         const __amdgpu_buffer_rsrc_t rv = vxm_rsrc(in + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
         const __amdgpu_buffer_rsrc_t rgo = vxm_rsrc(gout + (size_t)b * 3 * V, 3u * (unsigned)V * 4u);
         __syncthreads();                                          // the previous tile of this block is written back
         acc[0][tid] = 0ull; acc[1][tid] = 0ull; acc[2][tid] = 0ull;
-        if (tid == 0) poison = 0;
+        if (tid < 3 * (VG_TD * VG_TH * VG_TW / 32)) (&pmask[0][0])[tid] = 0u;
+        if (tid == 0) rtile = tile_dm ? 0u : far_count[1];
         __syncthreads();
+        if (tile_dm) {
+            // Radius of THIS tile: the largest displacement among the sender tiles that can reach it -- a sender tile S with largest
+            // displacement d_S reaches the voxels within ceil(d_S) of its box.  Candidates: the tiles within the step's global maximum.
+            // (One 20-voxel outlier used to make EVERY tile walk (4 + 42) x (8 + 42) x (32 + 42) voxels, ~200 x its volume.)
+            const int Rg = (int)dm + 1;
+            const int tz0 = d0 / VG_TD, ty0 = h0 / VG_TH, tx0 = w0 / VG_TW;
+            const int nz = (Rg + VG_TD - 1) / VG_TD, ny = (Rg + VG_TH - 1) / VG_TH, nx = (Rg + VG_TW - 1) / VG_TW;
+            const int cz = 2 * nz + 1, cy = 2 * ny + 1, cx = 2 * nx + 1;
+            unsigned best = 0u;
+            for (int i = tid; i < cz * cy * cx; i += 1024) {
+                const int oz = i / (cy * cx) - nz, r2 = i % (cy * cx), oy = r2 / cx - ny, ox = r2 % cx - nx;
+                const int sz = tz0 + oz, sy = ty0 + oy, sx = tx0 + ox;
+                if ((unsigned)sz >= (unsigned)ntd || (unsigned)sy >= (unsigned)nth || (unsigned)sx >= (unsigned)ntw) continue;
+                const unsigned dS = tile_dm[(size_t)b * ntile + (sz * nth + sy) * ntw + sx];
+                if (dS == 0u) continue;
+                const int reach = (int)__uint_as_float(dS) + 1;
+                // gap between the boxes along each axis (0 when they touch or overlap)
+                const int gz = max(0, (abs(oz) - 1) * VG_TD + 1), gy = max(0, (abs(oy) - 1) * VG_TH + 1), gx = max(0, (abs(ox) - 1) * VG_TW + 1);
+                if ((oz == 0 || gz <= reach) && (oy == 0 || gy <= reach) && (ox == 0 || gx <= reach)) best = max(best, dS);
+            }
+            if (best) atomicMax(&rtile, best);
+            __syncthreads();
+            if (rtile == 0u) continue;                            // no far sender reaches this tile (block-uniform)
+        }
+        const int R = (int)__uint_as_float(rtile) + 1;            // corners of a sender lie within ceil(displacement) of it
         const int gy = VG_TH + 2 * R, gx = VG_TW + 2 * R, ng = (VG_TD + 2 * R) * gy * gx;
         for (int i = tid; i < ng; i += 1024) {
             const int lz = i / (gy * gx), r2 = i - lz * gy * gx, ly = r2 / gx, lx = r2 - ly * gx;
@@ -461,7 +493,7 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_far_tiles(const float*
                 for (int c = 0; c < 3; ++c) {
                     const unsigned u = __float_as_uint(g[c] * wk);
                     const int ev = (int)(u >> 23) & 255;
-                    if (ev == 255) { poison = 1; continue; }          // NaN (fmaxf / atomicMax drop it from far_count[2]) or Inf: fixed point cannot carry it
+                    if (ev == 255) { atomicOr(&pmask[c][li >> 5], 1u << (li & 31)); continue; }      // NaN (fmaxf / atomicMax drop it from far_count[2]) or Inf: fixed point cannot carry it
                     int sh = ev - Eg + 23;                            // <= 24: |g wk| <= the step's largest |g| (+ one rounding)
                     if (ev == 0 || sh <= -24) continue;
                     sh = sh > 24 ? 24 : sh;
@@ -477,11 +509,11 @@ __global__ void __launch_bounds__(1024) k_vecint_step_bwd_far_tiles(const float*
         float* gi = gin + (size_t)b * 3 * V + (size_t)d * HW + h * W + w;
         // 2^(Eg - 173) as a double (exponent field 1023 + Eg - 173)
         const double unit = __longlong_as_double((long long)(1023 + Eg - 173) << 52);
-        const bool bad = poison != 0;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const long long sacc = (long long)acc[c][tid];
-            if (bad) gi[(size_t)c * V] = __uint_as_float(0x7fc00000u);        // a diverged step surfaces in dL/dvec instead of being masked
+            const bool bad = (pmask[c][tid >> 5] >> (tid & 31)) & 1u;
+            if (bad) gi[(size_t)c * V] = __uint_as_float(0x7fc00000u);        // a diverged step surfaces in dL/dvec, at the voxels the sender targets
             else if (sacc != 0) gi[(size_t)c * V] += (float)((double)sacc * unit) * scale;
         }
     }
@@ -1225,7 +1257,8 @@ int vxm_vecint_bwd_ws(const float* vec, const float* steps, const float* gout, f
     VXM_REQUIRE(vec && steps && gout && gvec && work, VXM_ERR_NULL_POINTER, "vxm_vecint_bwd: null pointer");
     const size_t n = (size_t)B * 3 * D * H * W;
     VXM_REQUIRE(work_bytes >= (2 * n + VXM_VECINT_WORK_EXTRA) * sizeof(float), VXM_ERR_WORKSPACE,
-                "vxm_vecint_bwd: work holds %zu bytes, needs %zu (2 x B x 3 x D x H x W + VXM_VECINT_WORK_EXTRA floats)", work_bytes,
+                "vxm_vecint_bwd: work holds %zu bytes, needs at least %zu (2 x B x 3 x D x H x W + VXM_VECINT_WORK_EXTRA floats; "
+                "vxm_workspace_bytes(VXM_WS_VECINT_BWD, ...) also covers the per-tile displacement records)", work_bytes,
                 (2 * n + VXM_VECINT_WORK_EXTRA) * sizeof(float));
     const long long tiles = (long long)((W + VG_TW - 1) / VG_TW) * ((H + VG_TH - 1) / VG_TH) * ((D + VG_TD - 1) / VG_TD);
     VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_vecint_bwd: too many tiles");
@@ -1236,15 +1269,20 @@ int vxm_vecint_bwd_ws(const float* vec, const float* steps, const float* gout, f
     // displacement, largest |g|} (float bits) per step
     unsigned* far = reinterpret_cast<unsigned*>(work + 2 * n);
     (void)hipMemsetAsync(far, 0, sizeof(unsigned) * VXM_VECINT_WORK_EXTRA, VXM_STREAM(stream));
+    // per-tile largest displacement of each step's far senders: [nsteps][B][tiles] words behind the statistics, when the caller's scratch holds
+    // them (vxm_workspace_bytes(VXM_WS_VECINT_BWD) asks for it; the ABI-0.4 size falls back to the step's global maximum as the radius)
+    const size_t rec_words = (size_t)nsteps * B * (size_t)tiles;
+    unsigned* const tdm = work_bytes >= (2 * n + VXM_VECINT_WORK_EXTRA + rec_words) * sizeof(float) ? far + VXM_VECINT_WORK_EXTRA : nullptr;
     const float* g = gout;
     for (int k = nsteps - 1; k >= 0; --k) {
         const float* in = k == 0 ? vec : steps + (size_t)(k - 1) * n;
         float* gn = k == 0 ? gvec : work + (size_t)(k & 1) * n;
         const float sc = k == 0 ? scale : 1.0f;
-        hipLaunchKernelGGL(k_vecint_step_bwd_gather, grid_t, dim3(1024), 0, VXM_STREAM(stream), in, sc, g, gn, far + 4 * k, D, H, W);
+        unsigned* const tdm_k = tdm ? tdm + (size_t)k * B * (size_t)tiles : nullptr;
+        hipLaunchKernelGGL(k_vecint_step_bwd_gather, grid_t, dim3(1024), 0, VXM_STREAM(stream), in, sc, g, gn, far + 4 * k, tdm_k, D, H, W);
         // ONE far launch per step (rounds 3-4: two, 4.8 us each when they had nothing to do): a persistent grid of at most two blocks per CU
         // that exits at once when the gather counted no far sender, walks the output tiles otherwise
-        hipLaunchKernelGGL(k_vecint_step_bwd_far_tiles, dim3(far_blocks), dim3(1024), 0, VXM_STREAM(stream), in, sc, g, gn, far + 4 * k, B, D, H, W);
+        hipLaunchKernelGGL(k_vecint_step_bwd_far_tiles, dim3(far_blocks), dim3(1024), 0, VXM_STREAM(stream), in, sc, g, gn, far + 4 * k, tdm_k, B, D, H, W);
         g = gn;
     }
     return vxm_check_launch("vxm_vecint_bwd");

@@ -89,9 +89,11 @@ def _vol3(t, what):
                                   "(2-D support is listed as 'next' in DESIGN.md)" % (what, t.dim() - 2))
 
 
-def vecint_work_elems(numel):
-    """floats of scratch vxm_vecint_bwd wants for a [B,3,D,H,W] field of `numel` elements: two gradient buffers + VXM_VECINT_WORK_EXTRA"""
-    return 2 * numel + 128
+def vecint_work_elems(shape):
+    """floats of scratch vxm_vecint_bwd_ws wants for a [B,3,D,H,W] field: two gradient buffers, the per-step statistics and the per-tile
+    displacement records (vxm_workspace_bytes(VXM_WS_VECINT_BWD, ...))"""
+    B, _, D, H, W = (int(v) for v in shape)
+    return int(_lib.lib().vxm_workspace_bytes(6, 0, 0, B, D, H, W)) // 4
 
 
 # --------------------------------------------------------------------------- layers
@@ -173,7 +175,9 @@ class WarpUpFn(torch.autograd.Function):
         gflow = torch.empty_like(flow_lo)
         work = torch.empty((B, 3, D, H, W), dtype=src.dtype, device=src.device)
         V, lV = D * H * W, lD * lH * lW
-        with _prof.region("warp3d_up_bwd", nbytes=4.0 * B * (V * (2 * C + 6) + 6 * lV)):
+        # algorithmic bytes of the fused op: src, gout, the low-resolution field and its gradient (the full-resolution gradient the call keeps in
+        # `work` between its two kernels is an implementation round trip, not counted)
+        with _prof.region("warp3d_up_bwd", nbytes=4.0 * B * (V * 2 * C + 6 * lV)):
             call("vxm_warp3d_up_bwd", ptr(src), ptr(flow_lo), ptr(gout), ptr(gflow), ptr(work), work.numel() * 4, B, C, D, H, W, lD, lH, lW,
                  factor, INTERP[mode], stream())
         return None, gflow, None, None, None
@@ -203,7 +207,7 @@ class VecIntFn(torch.autograd.Function):
         B, _, D, H, W = vec.shape
         gout = _c(gout)
         gvec = torch.empty_like(vec)
-        work = torch.empty(vecint_work_elems(vec.numel()), dtype=vec.dtype, device=vec.device)
+        work = torch.empty(vecint_work_elems(vec.shape), dtype=vec.dtype, device=vec.device)
         with _prof.region("vecint_bwd", nbytes=36.0 * B * D * H * W * ctx.nsteps):
             call("vxm_vecint_bwd_ws", ptr(vec), ptr(steps), ptr(gout), ptr(gvec), ptr(work), work.numel() * 4, B, D, H, W, ctx.nsteps, stream())
         return gvec, None
