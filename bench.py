@@ -529,6 +529,11 @@ def timed_steps(wl, steps, vdist, dev, timer=None):
     timed_steps.submission = {
         "graph_replays": wl.graphed.replays - replays0, "eager_steps": steps - (wl.graphed.replays - replays0),
         "capture_error": wl.graphed.capture_error,
+        # the dynamic-range guard of the fp16-piece engine ran on the first (eager) step of this workload: worst share of a tensor's values in the
+        # absolute-error regime, and the engine the process continued on (voxelmorph_amd/graph.py; off with VXM_RANGE_GUARD=0)
+        "range_guard": None if wl.graphed.range_report is None else {
+            "worst_share_below_2^-18_of_tile_max": (wl.graphed.range_report["worst"] or {}).get("share_below_2^-18_of_tile_max"),
+            "share_limit": wl.graphed.range_report["share_limit"], "engine": wl.graphed.range_report["recommended_engine"]},
         "device_allocs": ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
         "device_frees": ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0),
         "alloc_retries": ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0),

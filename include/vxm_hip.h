@@ -311,6 +311,17 @@ int vxm_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 int vxm_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                       float beta2, float eps, void* state, float gscale, void* stream);
 
+/* ---- weight / bias gradient of the layers with 1-3 channels on one side (first block 2 -> 16: x0 / x1 the two 1-channel images; flow conv
+ * 16 -> 3) on the fp16-piece scheme of the split engine (pieces = 2: two fp16 pieces per fp32 operand, per-tile power-of-two scales, three
+ * piece products on v_mfma_f32_16x16x32_f16, fp32 totals; csrc/conv_bwd_weight.hip k_fewch_bwd_weight_h) -- the convolution_backward
+ * (weight, bias) of networks.py:299,211 for those two layers.  Operands, results, determinism and workspace
+ * (vxm_conv3d_k3_bwd_weight_workspace_bytes) as vxm_conv3d_k3_bwd_weight, which computes the same product on the fp32 matrix pipe. */
+int vxm_conv3d_k3_fewch_bwd_weight_ok(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* dz,
+                                      int64_t dz_bstride, int Cout, int pieces, int W);
+int vxm_conv3d_k3_fewch_bwd_weight(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* dz,
+                                   int64_t dz_bstride, int Cout, float* gw, float* gb, void* workspace, size_t workspace_bytes, int B, int D, int H,
+                                   int W, int pieces, void* stream);
+
 /* ---- the weighted sum of the loss terms, scripts/torch/train.py:205-212 (`loss += loss_function(y_true[n], y_pred[n]) * weights[n]`):
  * total[0] = sum_n terms[n][0] * weights[n], products and running sum in that order in fp32, ONE launch instead of a mul + an add per term.
  * terms: HOST array of n device pointers to the 0-dim loss tensors; weights: HOST array.  running (nullable, device, n + 1 floats):

@@ -525,10 +525,25 @@ def test_conv_upsampled_segment_collapsed_weights(vxm, c0, c1, cout, vol):
 
 @pytest.mark.parametrize("c0,c1,cout,vol", [(1, 1, 16, (3, 9, 68)), (2, 0, 16, (5, 7, 20)), (2, 1, 16, (4, 8, 64)), (16, 0, 3, (3, 9, 68)), (16, 0, 2, (5, 17, 132)),
                                             (16, 0, 1, (4, 8, 64))])
-def test_few_channel_backward_weight_kernel(vxm, c0, c1, cout, vol):
-    """`k_fewch_bwd_weight` (first block: 1-3 input channels as a virtual concat of two tensors; flow conv: 1-3 output channels): weight
-    and bias gradient against fp64 autograd with two samples, rows that do not fill the 8-row tiles, more than one 64-column tile with a
-    partial last one, and the general kernel (VXM_FEWCH is read once per process, so the comparison partner here is fp64 only)."""
+@pytest.mark.parametrize("pieces", ["f16x2", "fp32"])
+def test_few_channel_backward_weight_kernel(vxm, c0, c1, cout, vol, pieces):
+    """`k_fewch_bwd_weight_h` (round 6: fp16 pieces on the 16-bit matrix pipe, the default engine's kernel) and `k_fewch_bwd_weight` (fp32
+    MFMA) -- first block: 1-3 input channels as a virtual concat of two tensors; flow conv: 1-3 output channels: weight and bias gradient
+    against fp64 autograd with two samples, rows that do not fill the tiles, more than one tile along W with a partial last one
+    (VXM_FEWCH is read once per process, so the comparison partner here is fp64 only).  Gates: 1e-6 on the pieces (as every split kernel), 1e-5 fp32."""
+    from voxelmorph_amd import _lib
+    from voxelmorph_amd.torch import functional as VF
+    if pieces == "f16x2" and VF.FP32_ENGINE != "f16x2":
+        pytest.skip("the fp16-piece few-channel kernel belongs to the f16x2 engine")
+    keep = VF.FEWCH_H
+    VF.FEWCH_H = pieces == "f16x2"
+    try:
+        _few_channel_backward_weight(vxm, c0, c1, cout, vol, 1e-6 if pieces == "f16x2" else 1e-5)
+    finally:
+        VF.FEWCH_H = keep
+
+
+def _few_channel_backward_weight(vxm, c0, c1, cout, vol, bound):
     from voxelmorph_amd import _lib
     from voxelmorph_amd.torch import functional as VF
     D, H, W = vol
@@ -545,7 +560,9 @@ def test_few_channel_backward_weight_kernel(vxm, c0, c1, cout, vol):
     wr = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
     br = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
     torch.nn.functional.conv3d(xin.cpu().double(), wr, br, padding=1).backward(dz.cpu().double())
-    assert rel_l2(N(gw), wr.grad.numpy()) < 1e-5 and rel_l2(N(gb), br.grad.numpy()) < 1e-5
+    gate("few-channel weight gradient %d+%d -> %d" % (c0, c1, cout), rel_l2(N(gw), wr.grad.numpy()), bound)
+    gate("few-channel bias gradient %d+%d -> %d" % (c0, c1, cout), rel_l2(N(gb), br.grad.numpy()), bound)
+    # inputs spread over 20 orders of magnitude per sample: the per-tile scales keep the relative accuracy (exact powers of two)
     gw2, gb2 = torch.empty_like(gw), torch.empty_like(gb)
     VF.conv_bwd_weight(VF._Workspace(x0.device), x0, c0, c0 * V, False, x1, c1, c1 * V, dz, cout, gw2, gb2, B, D, H, W)
     assert torch.equal(gw, gw2) and torch.equal(gb, gb2)           # fixed summation order

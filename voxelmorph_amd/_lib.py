@@ -136,6 +136,8 @@ SIGNATURES = {
     "vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes": [_I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3u_bwd_weight": [_P, _I, _L, _P, _L, _I, _P, _I, _P, _S, _I, _I, _I, _I, _I, _P],
     "vxm_s3_range_probe": [_P, _I, _L, _I, _I, _I, _I, _I, _P, _P],
+    "vxm_conv3d_k3_fewch_bwd_weight_ok": [_P, _I, _L, _P, _I, _L, _P, _L, _I, _I, _I],
+    "vxm_conv3d_k3_fewch_bwd_weight": [_P, _I, _L, _P, _I, _L, _P, _L, _I, _P, _P, _P, _S, _I, _I, _I, _I, _I, _P],
     "vxm_loss_combine_fwd": [_P, _P, _I, _P, _P, _P],
     "vxm_loss_combine_bwd": [_P, _P, _I, _P, _P],
     "vxm_fill_zero": [_P, _S, _P],

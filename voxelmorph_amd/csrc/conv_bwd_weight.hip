@@ -2,6 +2,7 @@
 // weight / bias of voxelmorph/torch/networks.py:299-305, 211 -- as fp32 MFMA implicit GEMMs (see conv_fwd.hip for the
 // forward / backward-data side and DESIGN.md section 4.1 for the measurements behind the design).
 #include "conv_common.h"
+#include "s3_pieces.h"
 
 namespace {
 
@@ -905,6 +906,244 @@ __global__ void __launch_bounds__(FC_THREADS, 2) k_fewch_bwd_weight(FcIn in, int
         part[(size_t)blockIdx.x * (16 * NT * 16) + i] = (red[i] + red[16 * NT * 16 + i]) + (red[2 * 16 * NT * 16 + i] + red[3 * 16 * NT * 16 + i]);
 }
 
+// ---- the same product on the 16-bit matrix pipe (round 6): fp16 pieces of both operands, three piece products (the "f16x2" scheme of
+// conv_s3.hip / s3_pieces.h: x s = h + l up to 2^-22, one power-of-two scale per staged tile and operand, per-tile MFMA chains folded into
+// fp32 totals by the vector ALU).  The fp32-MFMA kernel above spends 32 cycles per K = 4 voxels (62 % of its time with the matrix pipe busy:
+// 0.19 + 0.26 ms per step for 0.5 GB of operands each, and the first layer's launch is the last thing the step waits for); with K = 32
+// voxels per 16-cycle MFMA the three products cost a fifth of that.
+//   Tile 1 x 8 x 32 voxels, 4 waves, a wave owns two rows = two K-steps; three blocks per CU (31 KB of LDS each) hide each other's loads.
+// P (A operand): [piece][16 planes][8 rows x 32 + 8] halves -- lane (m, kq) reads the 8 consecutive voxels 8 kq .. 8 kq + 7 of its row with
+// one aligned ds_read_b128.  S (B operand): column n = (c, tap) wants 8 consecutive voxels SHIFTED by the tap: kd and kh move the plane /
+// row, kw = 0 / 1 / 2 halves would misalign the 16-byte read -- so a lane reads the aligned 12 halves 8 kq .. 8 kq + 11 of the haloed row
+// (b128 + b64) and funnel-shifts them by ITS kw in registers (v_alignbit with a per-lane shift: 2 vector instructions per dword).
+// (A first version kept three kw-shifted copies of S in LDS: 108 two-byte LDS writes per thread and tile, 77 KB, one block per CU -- slower
+// than the fp32 kernel.)  Partials in the fp32 kernel's format (k_fewch_reduce is shared); the bias gradient (first layer) from MFMAs
+// against a register of ones.
+constexpr int FH_TH = 8, FH_TW = 32, FH_WAVES = 4, FH_THREADS = 64 * FH_WAVES;
+constexpr int FH_PST = FH_TH * FH_TW + 8;                     // halves per P plane (528 bytes: the 16 planes of a fragment read spread over the banks)
+constexpr int FH_PPIECE = 16 * FH_PST * 2;                    // bytes of one piece of P
+constexpr int FH_SRW = FH_TW + 8, FH_SROWS = FH_TH + 2;       // halves per haloed S row (34 used); haloed rows
+constexpr int FH_SPLANE = FH_SROWS * FH_SRW * 2;              // bytes of one (c, plane) block
+constexpr int FH_SPIECE = 3 * 3 * FH_SPLANE;                  // bytes of one piece of S (cs <= 3)
+constexpr int FH_TAB = 64;                                    // floats: wave maxima of P [0..3] and S [4..7]
+constexpr int FH_STAGE = 2 * FH_PPIECE + 2 * FH_SPIECE + FH_TAB * 4;
+constexpr int FH_LDS = FH_STAGE > FH_WAVES * 16 * 96 * 4 ? FH_STAGE : FH_WAVES * 16 * 96 * 4;
+static_assert(FH_LDS <= 52 * 1024, "three blocks of k_fewch_bwd_weight_h per CU");
+
+template <int NT>
+__global__ void __launch_bounds__(FH_THREADS, 3) k_fewch_bwd_weight_h(FcIn in, int cs, int flip, int want_bias, float* __restrict__ part, int B, int D,
+                                                                     int H, int W) {
+    using P2 = S3P<2>;
+    VXM_DYN_SMEM(char, smem);
+    char* const Ps = smem;                                     // [2 pieces][16][FH_PST] halves
+    char* const Ss = smem + 2 * FH_PPIECE;                     // [2 pieces][3 c][3 planes][FH_SROWS][FH_SRW] halves
+    float* const Tab = reinterpret_cast<float*>(smem + 2 * FH_PPIECE + 2 * FH_SPIECE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, idx = lane & 15;
+    const int nw = (W + FH_TW - 1) / FH_TW, nh = (H + FH_TH - 1) / FH_TH;
+    const int ntiles = B * D * nh * nw;
+    const int V = D * H * W, HW = H * W;
+
+    // column n = c * 27 + tap of N-tile nt -> byte offset of (c, plane kd, row kh) inside a piece of S, and the lane's kw as a funnel shift:
+    // halves 8 kq + kw .. + 7 of the row.  Columns beyond 27 cs read column 0's data (finite; the reducer drops them -- column 27 cs is
+    // overwritten with the bias sums below)
+    int sbase[NT];
+    unsigned ksh[NT];                                          // bit 0..4: shift of v_alignbit (0 or 16), bit 8: start one dword on (kw = 2)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 16 + idx;
+        int c = n / 27, tap = n - c * 27;
+        if (n >= 27 * cs) { c = 0; tap = 13; }
+        int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        if (flip && n < 27 * cs) { kd = 2 - kd; kh = 2 - kh; kw = 2 - kw; }
+        sbase[nt] = ((c * 3 + kd) * FH_SROWS + kh) * (FH_SRW * 2) + kq * 16;
+        ksh[nt] = (kw == 1 ? 16u : 0u) | (kw == 2 ? 256u : 0u);
+    }
+    f32x4 tot[NT], totb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) tot[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const u32x4 ones = {P2::ONES, P2::ONES, P2::ONES, P2::ONES};
+
+    // staging roles.  P: 16 planes x 8 rows x 8 float4 = 1024 slots, four per thread (planes pm0 + 4 j: the plane step is a scalar offset);
+    // S: a haloed plane is 10 rows x 17 PAIRS of W neighbours = 170 slots, one per thread (8-byte loads: W is even and tiles start at
+    // multiples of 32, so a pair from the odd column w0 - 1 + 2 q is inside the volume or outside it per element), the same slot for each
+    // of the (up to) 9 (channel, depth plane) pairs
+    constexpr int NPV = 4;
+    f32x4 pv[NPV];
+    f32x2 sv[9];
+    const int pm0 = tid >> 6, prow = (tid >> 3) & 7, pw4 = tid & 7;
+    const int spr = tid / 17, spq = tid - spr * 17;                          // spr >= FH_SROWS: no slot
+    auto tile_coords = [&](int t, int& b, int& d, int& h0, int& w0) __attribute__((always_inline)) {
+        const int tw = t % nw; int q = t / nw;
+        const int th = q % nh; q /= nh;
+        d = q % D; b = q / D;
+        h0 = th * FH_TH; w0 = tw * FH_TW;
+    };
+    auto load_tile = [&](int t) __attribute__((always_inline)) {
+        int b, d, h0, w0;
+        tile_coords(t < ntiles ? t : 0, b, d, h0, w0);
+        int dead = t < ntiles ? 0 : VXM_OOB;                     // past the last tile: every lane out of range (branch-free)
+        asm volatile("" : "+v"(dead));
+        const __amdgpu_buffer_rsrc_t rp = vxm_rsrc(in.P + (size_t)b * in.p_bs, 16u * (unsigned)V * 4u);
+        const int gh = h0 + prow, gw = w0 + 4 * pw4;
+        const int pvoff = ((gh < H && gw < W) ? (pm0 * V + d * HW + gh * W + gw) << 2 : VXM_OOB) | dead;   // W % 4 == 0: a float4 is inside or outside the row
+#pragma unroll
+        for (int j = 0; j < NPV; ++j) pv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, pvoff, (4 * j * V) << 2, 0));
+        const __amdgpu_buffer_rsrc_t r0 = vxm_rsrc(in.S0 + (size_t)b * in.s0_bs, (unsigned)in.cs0 * (unsigned)V * 4u);
+        const __amdgpu_buffer_rsrc_t r1 = vxm_rsrc(cs > in.cs0 ? in.S1 + (size_t)b * in.s1_bs : in.S0, (unsigned)(cs > in.cs0 ? cs - in.cs0 : in.cs0) * (unsigned)V * 4u);
+        // the pair (w0 - 1 + 2 q, w0 + 2 q): the first element of pair 0 of the first tile column (w = -1) and the second of pair 16 of the
+        // last (w = W) are outside the row -- those pairs are fetched as single dwords into the half that exists
+        const int sh = h0 - 1 + spr, sw = w0 - 1 + 2 * spq;
+        const bool rok = spr < FH_SROWS && (unsigned)sh < (unsigned)H;
+        const bool ok0 = rok && (unsigned)sw < (unsigned)W, ok1 = rok && (unsigned)(sw + 1) < (unsigned)W;
+        const int svoff = ((ok0 && ok1) ? (sh * W + sw) << 2 : VXM_OOB) | dead;
+        const int svone = ((ok0 != ok1) ? (sh * W + (ok0 ? sw : sw + 1)) << 2 : VXM_OOB) | dead;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int pd = 0; pd < 3; ++pd) {
+                const int gd = d - 1 + pd;                       // wave-uniform
+                const bool first = c < in.cs0;
+                const __amdgpu_buffer_rsrc_t r = first ? r0 : r1;
+                const int cc = first ? c : c - in.cs0;
+                int bad = (c < cs && (unsigned)gd < (unsigned)D) ? 0 : VXM_OOB;
+                asm volatile("" : "+v"(bad));
+                const int soff = (c < cs && (unsigned)gd < (unsigned)D) ? (cc * V + gd * HW) << 2 : 0;
+                f32x2 v2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, svoff | bad, soff, 0));
+                const float one = vxm_bload(r, svone | bad, soff);         // (volume-edge pairs only: out of range for every other lane)
+                if (ok0 != ok1) { v2.x = ok0 ? one : 0.0f; v2.y = ok0 ? 0.0f : one; }
+                sv[c * 3 + pd] = v2;
+            }
+    };
+    // largest magnitudes this wave loaded for the tile in flight -> Tab (P: [wave], S: [4 + wave])
+    auto publish_max = [&]() __attribute__((always_inline)) {
+        float mp = 0.0f, ms = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NPV; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mp = fmaxf(mp, __builtin_fabsf(pv[j][e]));
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ms = fmaxf(ms, fmaxf(__builtin_fabsf(sv[i].x), __builtin_fabsf(sv[i].y)));
+        mp = s3_wave_max(mp); ms = s3_wave_max(ms);
+        if (lane == 0) { Tab[wave] = mp; Tab[4 + wave] = ms; }
+    };
+    float sP = 1.0f, sS = 1.0f, inv_next = 1.0f, invP_next = 1.0f;      // scales of the tile in flight; the inverse product / P inverse of it
+    auto take_scales = [&]() __attribute__((always_inline)) {
+        const f32x4* const t4 = reinterpret_cast<const f32x4*>(Tab);
+        const f32x4 a = t4[0], c2 = t4[1];
+        const float mp = fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w));
+        const float ms = fmaxf(fmaxf(c2.x, c2.y), fmaxf(c2.z, c2.w));
+        float iP, iS;
+        s3_scale_of(mp, sP, iP);
+        s3_scale_of(ms, sS, iS);
+        inv_next = iP * iS; invP_next = iP;
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NPV; ++j) {
+            unsigned h0_, l0_, h1_, l1_;
+            s3_split2_f16(pv[j].x, pv[j].y, sP, h0_, l0_);
+            s3_split2_f16(pv[j].z, pv[j].w, sP, h1_, l1_);
+            char* const dst = Ps + ((pm0 + 4 * j) * FH_PST + prow * FH_TW + 4 * pw4) * 2;
+            *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
+            *reinterpret_cast<u32x2*>(dst + FH_PPIECE) = (u32x2){l0_, l1_};
+        }
+        if (spr < FH_SROWS) {
+            char* const dst0 = Ss + spr * (FH_SRW * 2) + spq * 4;              // haloed columns 2 q, 2 q + 1: one aligned word
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int pd = 0; pd < 3; ++pd) {
+                    if (c < cs) {
+                        unsigned hh, ll;
+                        s3_split2_f16(sv[c * 3 + pd].x, sv[c * 3 + pd].y, sS, hh, ll);
+                        *reinterpret_cast<unsigned*>(dst0 + (c * 3 + pd) * FH_SPLANE) = hh;
+                        *reinterpret_cast<unsigned*>(dst0 + (c * 3 + pd) * FH_SPLANE + FH_SPIECE) = ll;
+                    }
+                }
+        }
+    };
+    // the 8 halves kw .. kw + 7 of the 12 a lane read (e[0..5]: b128 + b64), kw per lane: dword i = alignbit(e[i + 1], kw == 2 ? e[i + 1] : e[i], 16 (kw & 1))
+    auto shifted = [&](u32x4 lo, u32x2 hi, unsigned k) __attribute__((always_inline)) {
+        const unsigned e[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+        const bool two = (k & 256u) != 0u;
+        const unsigned sh = k & 31u;
+        u32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __builtin_amdgcn_alignbit(e[i + 1], two ? e[i + 1] : e[i], sh);
+        return o;
+    };
+
+    // pad halves of the S rows (34 .. 39) are read by kq = 3 (halves 24 .. 35): zero them once -- 0 x anything finite, and never rewritten
+    for (int i = tid; i < 2 * FH_SPIECE / 4; i += FH_THREADS) reinterpret_cast<unsigned*>(Ss)[i] = 0u;
+    __syncthreads();
+    int t = blockIdx.x;
+    load_tile(t);
+    publish_max();
+    __syncthreads();
+    take_scales();
+    store_tile();
+    float inv_cur = inv_next, invP_cur = invP_next;
+    __syncthreads();
+    for (; t < ntiles; t += gridDim.x) {
+        load_tile(t + gridDim.x);                                // unconditional (past the end every lane is out of range)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[NT], accb = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {                         // this wave's two rows = two K-steps of 32 voxels
+            const int row = 2 * wave + rr;
+            u32x4 af[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) af[p] = *reinterpret_cast<const u32x4*>(Ps + p * FH_PPIECE + (idx * FH_PST + row * FH_TW + 8 * kq) * 2);
+            if (want_bias) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) accb = P2::mfma(af[p], ones, accb);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                u32x4 bf[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const char* const q = Ss + p * FH_SPIECE + sbase[nt] + row * (FH_SRW * 2);
+                    bf[p] = shifted(*reinterpret_cast<const u32x4*>(q), *reinterpret_cast<const u32x2*>(q + 16), ksh[nt]);
+                }
+#pragma unroll
+                for (int tp = 0; tp < P2::NPROD; ++tp) acc[nt] = P2::mfma(af[P2::PA[tp]], bf[P2::PB[tp]], (rr == 0 && tp == 0) ? zero4 : acc[nt]);
+            }
+        }
+        // the chain of this tile carries the scales of its P and S tiles: undone here (exact powers of two), folded into the fp32 totals
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tot[nt][j] = __builtin_fmaf(acc[nt][j], inv_cur, tot[nt][j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) totb[j] = __builtin_fmaf(accb[j], invP_cur, totb[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        publish_max();                                           // (waits for the loads of the next tile: they had the MFMA phase, and two other blocks, to arrive)
+        __syncthreads();                                        // every wave is done reading this tile; the maxima of the next are visible
+        if (t + (int)gridDim.x < ntiles) { take_scales(); store_tile(); }
+        inv_cur = inv_next; invP_cur = invP_next;
+        __syncthreads();
+    }
+    // ---- partials: part[block][16 m][NT * 16 columns]; the four waves of a block are summed through LDS in a fixed order.  Column 27 cs carries
+    // the bias sums (every column of the ones product holds sum_v P[m][v]; S has x 1 there: only the P scale was applied)
+    float* const red = reinterpret_cast<float*>(smem);         // [4][16][NT * 16]
+    const int nb = 27 * cs;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool bias_col = want_bias && nt * 16 + idx == nb;
+            red[(wave * 16 + 4 * kq + r) * (NT * 16) + nt * 16 + idx] = bias_col ? totb[r] : tot[nt][r];
+        }
+    __syncthreads();
+    constexpr int NE = 16 * NT * 16;
+    for (int i = tid; i < NE; i += FH_THREADS)
+        part[(size_t)blockIdx.x * NE + i] = (red[i] + red[NE + i]) + (red[2 * NE + i] + red[3 * NE + i]);
+}
+
 // gw / gb from the per-block partials (fixed order: 16 slices of the blocks, then a tree)
 __global__ void __launch_bounds__(256) k_fewch_reduce(const float* __restrict__ part, int nblocks, int ncols, int cs, int flip, int Cw_in,
                                                       float* __restrict__ gw, float* __restrict__ gb) {
@@ -978,11 +1217,45 @@ size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D,
         const size_t alt = sizeof(float) * ((size_t)Cout * 64 * (4096 / (size_t)p.G + Cin + 16) + (size_t)Cout * CS_SLICES + (size_t)Cout * Cin * 64);
         if (alt > need) need = alt;
     }
-    {                                                  // few-channel kernel: 512 block partials of 16 x 96 (+ channel-sum scratch)
-        const size_t alt = sizeof(float) * ((size_t)512 * 16 * 96 + (size_t)Cout * CS_SLICES);
+    {                                                  // few-channel kernels: up to 768 block partials of 16 x 96 (+ channel-sum scratch)
+        const size_t alt = sizeof(float) * ((size_t)768 * 16 * 96 + (size_t)Cout * CS_SLICES);
         if ((Cin <= 3 || Cout <= 3) && alt > need) need = alt;
     }
     return 256 + need;
+}
+
+// few-channel layers on the fp16-piece scheme (k_fewch_bwd_weight_h): same operands, workspace and reducer as the fp32-MFMA few-channel path
+static int fewch_h_launch(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* dz, int64_t dz_bstride,
+                          int Cout, float* gw, float* gb, float* part, int B, int D, int H, int W, void* stream) {
+    const int Cin = C0 + C1;
+    const bool few_in = Cout == 16 && Cin <= 3;
+    const int cs = few_in ? Cin : Cout;
+    const int NT = (27 * cs + (few_in && gb ? 1 : 0) + 15) / 16;
+    FcIn fin;
+    if (few_in) fin = FcIn{dz, (long long)dz_bstride, x0, (long long)x0_bstride, C0, x1, (long long)x1_bstride};
+    else fin = FcIn{x0, (long long)x0_bstride, dz, (long long)dz_bstride, Cout, nullptr, 0};
+    const long long ntiles = (long long)B * D * ((H + FH_TH - 1) / FH_TH) * ((W + FH_TW - 1) / FH_TW);
+    const int nblk = (int)(ntiles < 768 ? ntiles : 768);              // three 4-wave blocks per CU (31 KB of LDS each; the workspace holds 512 x 16 x 96 partials)
+    static bool opt_in = false;
+    if (!opt_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<6>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
+        opt_in = true;
+    }
+#define FH_LAUNCH(NT_) hipLaunchKernelGGL(k_fewch_bwd_weight_h<NT_>, dim3(nblk), dim3(FH_THREADS), FH_LDS, VXM_STREAM(stream), fin, cs, few_in ? 0 : 1, \
+                                          few_in && gb ? 1 : 0, part, B, D, H, W)
+    if (NT <= 2) FH_LAUNCH(2); else if (NT <= 4) FH_LAUNCH(4); else FH_LAUNCH(6);
+#undef FH_LAUNCH
+    const int ncols = (NT <= 2 ? 2 : (NT <= 4 ? 4 : 6)) * 16;
+    hipLaunchKernelGGL(k_fewch_reduce, dim3((16 * ncols + 15) / 16), dim3(256), 0, VXM_STREAM(stream), part, nblk, ncols, cs, few_in ? 0 : 1, Cin, gw,
+                       few_in ? gb : nullptr);
+    if (!few_in && gb) {
+        float* cs_ws = part + (size_t)nblk * 16 * ncols;
+        hipLaunchKernelGGL(k_channel_sum_partial, dim3(Cout, CS_SLICES), dim3(256), 0, VXM_STREAM(stream), dz, (long long)dz_bstride, cs_ws, B, (size_t)D * H * W);
+        hipLaunchKernelGGL(k_channel_sum_finish, dim3(Cout), dim3(64), 0, VXM_STREAM(stream), cs_ws, gb);
+    }
+    return vxm_check_launch("vxm_conv3d_k3_fewch_bwd_weight");
 }
 
 static int bwd_weight_impl(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
@@ -1128,6 +1401,28 @@ int vxm_conv3d_k3_bwd_weight_up_segment(const float* x0, int C0, int64_t x0_bstr
                 VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_bwd_weight_up_segment: operands do not qualify for the collapsed kernel (use vxm_conv3d_k3_bwd_weight)");
     return bwd_weight_impl(x0, C0, x0_bstride, 1, x1, C1, x1_bstride, dz, dz_bstride, Cout, gw, nullptr, workspace, workspace_bytes, B, D, H, W, stream,
                            true);
+}
+
+/* few-channel layers (first block 2 -> 16, flow conv 16 -> 3) on the fp16-piece scheme: include/vxm_hip.h */
+int vxm_conv3d_k3_fewch_bwd_weight_ok(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* dz,
+                                      int64_t dz_bstride, int Cout, int pieces, int W) {
+    if (pieces != 2 || !fewch_enabled()) return 0;
+    if (!bwd_weight_wide_ok(x0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, W)) return 0;
+    return (Cout == 16 && C0 + C1 <= 3 && C0 >= 1) || (Cout <= 3 && Cout >= 1 && C0 == 16 && C1 == 0);
+}
+
+int vxm_conv3d_k3_fewch_bwd_weight(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* dz,
+                                   int64_t dz_bstride, int Cout, float* gw, float* gb, void* workspace, size_t workspace_bytes, int B, int D, int H,
+                                   int W, int pieces, void* stream) {
+    if (int e = check_conv("vxm_conv3d_k3_fewch_bwd_weight", C0, C1, 0, Cout, B, D, H, W)) return e;
+    VXM_REQUIRE(x0 && dz && gw && workspace && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_fewch_bwd_weight: null pointer");
+    VXM_REQUIRE(vxm_conv3d_k3_fewch_bwd_weight_ok(x0, C0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, Cout, pieces, W), VXM_ERR_UNSUPPORTED,
+                "vxm_conv3d_k3_fewch_bwd_weight: 1-3 channels against 16, W %% 4 == 0, 16-byte aligned tensors, pieces = 2 (got C0=%d C1=%d Cout=%d "
+                "pieces=%d W=%d)", C0, C1, Cout, pieces, W);
+    VXM_REQUIRE(workspace_bytes >= vxm_conv3d_k3_bwd_weight_workspace_bytes(C0 + C1, Cout, B, D, H, W), VXM_ERR_WORKSPACE,
+                "vxm_conv3d_k3_fewch_bwd_weight: workspace too small (%zu bytes; vxm_conv3d_k3_bwd_weight_workspace_bytes)", workspace_bytes);
+    const uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
+    return fewch_h_launch(x0, C0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, Cout, gw, gb, reinterpret_cast<float*>(base), B, D, H, W, stream);
 }
 
 }  // extern "C"

@@ -809,17 +809,20 @@ __global__ void __launch_bounds__(1024) k_s3_wmax(const S3PackBatch batch) {
     // one block per operator: 1024 threads, four independent loads in flight per thread (the first version -- 256 threads, one dependent
     // load per iteration -- took 57 us for the 41 k weights of rem0 and sat on the step's critical path twice)
     const int n = jb.Cw_out * jb.ci_n * 27, row = jb.ci_n * 27;
-    float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f, m3 = 0.0f;
+    float mm[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto at = [&](int i) __attribute__((always_inline)) {
         if (i >= n) return 0.0f;
         const int a = i / row, r = i - a * row;
         return __builtin_fabsf(jb.w[((size_t)a * jb.Cw_in + jb.ci_lo) * 27 + r]);
     };
-    for (int i = threadIdx.x; i < n; i += 4096) {
-        const float a0 = at(i), a1 = at(i + 1024), a2 = at(i + 2048), a3 = at(i + 3072);
-        m0 = fmaxf(m0, a0); m1 = fmaxf(m1, a1); m2 = fmaxf(m2, a2); m3 = fmaxf(m3, a3);
+    for (int i = threadIdx.x; i < n; i += 8192) {                     // eight independent loads in flight per thread (round 6: the launch sits on the main chain)
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = at(i + 1024 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mm[u] = fmaxf(mm[u], a[u]);
     }
-    const float m = s3_wave_max(fmaxf(fmaxf(m0, m1), fmaxf(m2, m3)));
+    const float m = s3_wave_max(fmaxf(fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3])), fmaxf(fmaxf(mm[4], mm[5]), fmaxf(mm[6], mm[7]))));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -11,9 +11,10 @@ bench workload; the worst tensor is a coarse-level gradient), 0.48 on the real s
 On that heavy-tailed step the three engines were compared against the fp64-NCC arbiter at full size
 (tests/test_gpu_parity.py::test_full_size_step_with_heavy_tailed_activations_on_all_three_engines): worst parameter gradient 9.0e-2 on the
 fp16 pieces, 1.0e-1 on three bf16 pieces, 1.8e-1 on the exact fp32 MFMA -- the step is ill-conditioned in fp32 whatever the engine, and the
-fp16-piece engine is the closest of the three.  So the report is a DIAGNOSTIC, and `guard_engine` / `GraphedStep(range_guard=True)` /
-`VXM_RANGE_GUARD=1` -- which move the process to the three-piece engine (fp32's exponent range, 25 % slower) when more than `share_limit` of
-a tensor is in the absolute-error regime -- are opt-in.
+fp16-piece engine is the closest of the three.  The guard -- `guard_engine`, which `GraphedStep` runs on its first eager step (default ON
+since round 6; `VXM_RANGE_GUARD=0` / `range_guard=False` switch it off) -- moves the process to the three-piece engine (fp32's exponent
+range, 25 % slower) when more than `share_limit` of a tensor is in the absolute-error regime: a one-off cost of one probe launch per
+tensor (~3 ms at 160x192x224), nothing in the captured step.
 """
 import torch
 

@@ -51,6 +51,8 @@ BLOCKED = os.environ.get("VXM_BLOCKED", "1") != "0"
 # idle per step instead of 3.7 and 0.14), "before" otherwise (launch by launch: 83.4 / 81.6 against 82.0 / 81.2).  VXM_DW_ORDER=before|after forces one.
 DW_ORDER = os.environ.get("VXM_DW_ORDER", "")
 BW_REDUCE_STREAM = os.environ.get("VXM_BW_REDUCE_STREAM", "") == "1"     # UnetFn.backward: weight-gradient reductions on a third stream (A/B: slower)
+# few-channel weight gradients (first block, flow conv) on the fp16 pieces (csrc/conv_bwd_weight.hip k_fewch_bwd_weight_h); VXM_FEWCH_H=0: fp32 MFMA
+FEWCH_H = os.environ.get("VXM_FEWCH_H", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -792,6 +794,16 @@ def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H
         s3_bwd_weight(ws, x1, c1, bs1, dz, cout, gw, c0 + c1, c0, gb, B, D, H, W, lay=lay & S3_IN1_BLOCKED)
         return
     _need_split_kernel(lay, "conv_bwd_weight")
+    if FEWCH_H and split_engine() and s3_pieces() == 2 and not up0 and _lib.lib().vxm_conv3d_k3_fewch_bwd_weight_ok(
+            ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, 2, W):
+        # first block (2 -> 16) / flow conv (16 -> 3): the few-channel kernel on the fp16 pieces (round 6; the fp32-MFMA form spent 62 % of its
+        # time with the matrix pipe busy, and the first block's launch is the last thing a step waits for)
+        need = _lib.lib().vxm_conv3d_k3_bwd_weight_workspace_bytes(c0 + c1, cout, B, D, H, W)
+        buf = ws.get(need)
+        with _prof.region("k_fewch_bwd_weight_h", flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+            call("vxm_conv3d_k3_fewch_bwd_weight", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, ptr(gw), ptr(gb), ptr(buf),
+                 buf.numel(), B, D, H, W, 2, stream())
+        return
     if split_engine() and up0 and x1 is not None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c1, cout, B, D, H, W) and \
             _lib.lib().vxm_conv3d_k3_bwd_weight_variant(ptr(x0), c0, bs0, 1, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, D, H, W) // 10 == 2:
         # cat([upsample(x0), x1]): the upsampled segment through the collapsed fp32-MFMA kernel, the full-resolution skip segment (and the
@@ -1062,13 +1074,19 @@ def _s3_jobs(plan, params, B, shape3, with_backward, input_grads):
     return jobs
 
 
-def _prepack_plan(plan, params, B, shape3, with_backward, input_grads, dry=False):
-    """Every packed operator one pass over `plan` will ask for, built now: the split operators in one batched launch (_s3_jobs), the collapsed
-    operators of the cat([upsample, skip]) layers (forward: k_s3u_conv; backward-data onto the low-resolution tensor: k_s3u_dlow) one by one.
-    Returns the index of the first op that reads one of them (len(ops) when none does); dry: only that index, nothing is launched."""
-    if not dry:
+def _prepack_plan(plan, params, B, shape3, with_backward, input_grads, dry=False, group=None):
+    """Every packed operator one pass over `plan` will ask for, built now, in three groups: "A" -- the split operators, in one batched launch
+    (_s3_jobs: weight scales + pre-split pieces, ~40 us); "B1" -- the fp32-MFMA operators of the forward convs the split engine does not take
+    (coarse levels: ~6 launches of 5 us); "B2" -- the collapsed operators of the cat([upsample, skip]) layers (forward: k_s3u_conv; backward-data
+    onto the low-resolution tensor: k_s3u_dlow) and the fp32-MFMA adjoints of the backward (~20 launches, ~150 us in a row).  group=None builds
+    all.  Returns the index of the first op that reads an operator of each group (A, B1, B2) -- len(ops) when none does; dry: only the indices.
+    Round 6: the groups have their own events.  In the default U-Net the first reader of A is the second layer (op 2), of B1 the first
+    coarse-level conv (op 6), of B2 the first cat([upsample, skip]) layer (op 11): with ONE event the main chain sat idle for 0.23 ms per
+    replayed step behind the first layer's pooling, waiting for all 27 launches (rocprofv3 dispatch list, profiles/r06q_dispatch_graph.txt)."""
+    do_a, do_b1, do_b = (not dry) and group in (None, "A"), (not dry) and group in (None, "B1"), (not dry) and group in (None, "B2")
+    if do_a:
         s3_prepack(_s3_jobs(plan, params, B, shape3, with_backward, input_grads))
-    first = len(plan.ops)
+    first_a = first_b1 = first_b = len(plan.ops)
     for n, op in enumerate(plan.ops):
         if op["kind"] != "conv":
             continue
@@ -1082,29 +1100,29 @@ def _prepack_plan(plan, params, B, shape3, with_backward, input_grads, dry=False
         D, H, W = _dims(shape3, plan.lvl[op["dst"]])
         uses = cout > 4 and s3_route(c0, up0, c1, cout, B, D, H, W)
         if up0 and cout > 4 and s3u_route(c0, c1, cout, B, D, H, W):
-            if not dry:
+            if do_b:
                 s3u_pack(w, c0, c1)
-            uses = True
-        if not dry and up0 and with_backward and s3u_bwd_low_route(c0, cout, B, D, H, W) and plan.ops[plan.producer[s0]]["kind"] == "conv" \
+            first_b = min(first_b, n)
+        elif uses:
+            first_a = min(first_a, n)
+        if do_b and up0 and with_backward and s3u_bwd_low_route(c0, cout, B, D, H, W) and plan.ops[plan.producer[s0]]["kind"] == "conv" \
                 and len(plan.consumers[s0]) == 1:
             s3u_bwd_low_pack(w, c0, c0 + c1)
-        if uses:
-            first = min(first, n)
         # the fp32-MFMA operators of the convs the split engine does not take (coarse levels, first layer, flow head): packed here too, so
         # that the main chain does not carry a 5 us pack launch in front of each of them.  A guess that turns out unused costs that launch on
         # the second stream; one that is missing is packed on demand, as before.
         if n > 0 and cout > 4 and not uses and not up0:      # (op 0 needs its operator at once: packed on demand on the main stream)
-            if not dry:
+            if do_b1:
                 pack_weights_cached(w, False)
-            first = min(first, n)                             # the main stream must have joined the second one before this launch
-        if not dry and with_backward and s0 >= plan.n_inputs:
+            first_b1 = min(first_b1, n)                       # the main stream must have joined the second one before this launch
+        if do_b and with_backward and s0 >= plan.n_inputs:
             whole = not up0
             for w_lo, cin_r in ([(0, c0 + c1)] if whole else ([(c0, c1)] if s1 is not None else [])):
                 bounds = _bwd_bounds(cin_r)
                 for lo, hi in zip(bounds[:-1], bounds[1:]):
                     if not s3_route(cout, False, 0, hi - lo, B, D, H, W):
                         pack_weights_cached(w, True, w_lo + lo, w_lo + hi)
-    return first
+    return first_a, first_b1, first_b
 
 
 def _blocked_tensors(plan, B, shape3):
@@ -1190,32 +1208,41 @@ class UnetFn(torch.autograd.Function):
         for i, t in T.items():
             if t.shape[1] != plan.ch[i] or t.shape[0] != B or tuple(t.shape[2:]) != shape3:
                 raise ValueError("Unet: input %d has shape %s, expected [%d,%d,%s]" % (i, tuple(t.shape), B, plan.ch[i], shape3))
-        packs_ready, first_packed, packs_late = None, len(plan.ops), False
+        ready = [None, None, None]               # events: the operators of group A / B1 / B2 are built (second stream, in that order)
+        first = [len(plan.ops)] * 3
+        packs_late = False
         if split_engine():
-            # The packed operators (weight scales, pre-split pieces, collapsed upsample operators: ~10 small launches, 0.25 ms in a row) are
-            # rebuilt once per optimiser step.  They go to the second stream and run beside the first layers, which do not read them; the
-            # main stream waits for them in front of the first launch that does.
+            # The packed operators (weight scales, pre-split pieces, collapsed upsample operators: ~27 small launches, 0.2 ms in a row) are
+            # rebuilt once per optimiser step.  They go to the second stream and run beside the layers that do not read them; the main stream
+            # waits for each GROUP (_prepack_plan) in front of the first launch that reads it.
             want_bwd, want_in = any(ctx.needs_input_grad[1:]), any(ctx.needs_input_grad[1:1 + plan.n_inputs])
             if OVERLAP_SMALL_LEVELS:
                 main, side = torch.cuda.current_stream(dev), _side_stream(dev)
                 fork = torch.cuda.Event()
                 fork.record(main)
 
-                def launch_packs():
+                def launch_packs(groups=("A", "B1", "B2")):
                     side.wait_event(fork)
+                    evs = [None] * (3 - len(groups))
                     with torch.cuda.stream(side):
-                        _prepack_plan(plan, params, B, shape3, want_bwd, want_in)
-                        ready = torch.cuda.Event()
-                        ready.record(side)
+                        for grp in groups:
+                            _prepack_plan(plan, params, B, shape3, want_bwd, want_in, group=grp)
+                            evs.append(torch.cuda.Event())
+                            evs[-1].record(side)
                     _adopt_fresh_packs(main)
-                    return ready
-                first_packed = _prepack_plan(plan, params, B, shape3, want_bwd, want_in, dry=True)
+                    return evs
+                first = list(_prepack_plan(plan, params, B, shape3, want_bwd, want_in, dry=True))
                 # While a hipGraph is being captured the packs are enqueued BEHIND the layers that do not read them (a graph runs by its edges,
                 # not by enqueue order, and the first child created of a node keeps its queue: the main chain should, see DW_ORDER); launch by
                 # launch they must be enqueued first to run beside those layers.
-                packs_late = torch.cuda.is_current_stream_capturing() and first_packed > 0
+                packs_late = torch.cuda.is_current_stream_capturing() and min(first) > 0
                 if not packs_late:
-                    packs_ready = launch_packs()
+                    ready = launch_packs()
+                else:
+                    # Group A (two launches, ~35 us) on the MAIN stream in front of the first layer: in a replayed graph the second branch does
+                    # not start before the first layer's pooling has run, whatever the creation order of its nodes (round 6, rocprofv3 dispatch
+                    # lists r06r / r06s), and the second layer then waited 82 us for these two launches
+                    _prepack_plan(plan, params, B, shape3, want_bwd, want_in, group="A")
             else:
                 packs_late = False
                 _prepack_plan(plan, params, B, shape3, want_bwd, want_in)
@@ -1223,12 +1250,17 @@ class UnetFn(torch.autograd.Function):
         blocked = _blocked_tensors(plan, B, shape3)
         walked_back = set()          # tensors whose producer walked its tiles from the end (S3_REVERSE_TILES)
         for n_op, op in enumerate(plan.ops):
-            if packs_late and n_op >= first_packed:
-                packs_ready = launch_packs()
+            if packs_late and n_op >= 1:
+                # (captured right behind the FIRST op: on this runtime a branch of a replayed graph starts once everything the main chain had
+                # enqueued before the branch's nodes were created has run -- created behind op 0 and its pooling, the packs began when the
+                # pooling ended and the second layer waited 47 us for group A; created between the two they run beside the pooling)
+                ready = launch_packs(("B1", "B2"))
                 packs_late = False
-            if packs_ready is not None and n_op >= first_packed:
-                torch.cuda.current_stream(dev).wait_event(packs_ready)
-                packs_ready = None
+            for g in (2, 1, 0):                      # a later group's event is recorded behind the earlier ones on the same stream
+                if ready[g] is not None and n_op >= first[g]:
+                    torch.cuda.current_stream(dev).wait_event(ready[g])
+                    for e in range(g + 1):
+                        ready[e] = None
             dst = op["dst"]
             D, H, W = _dims(shape3, plan.lvl[dst])
             V = D * H * W
@@ -1258,9 +1290,9 @@ class UnetFn(torch.autograd.Function):
         # node, so `ctx.T[plan.out] = out` would be a reference cycle that keeps EVERY activation of the step alive
         # until Python's cyclic GC runs (tens of GB per step at 160x192x224).
         if packs_late:
-            packs_ready = launch_packs()
-        if packs_ready is not None:             # no op of this plan read a packed operator: still join the second stream
-            torch.cuda.current_stream(dev).wait_event(packs_ready)
+            ready = launch_packs(("B1", "B2"))
+        if ready[2] is not None:                # no op of this plan read a group-B2 operator (the backward's are in it): still join the second stream
+            torch.cuda.current_stream(dev).wait_event(ready[2])
         out = T.pop(plan.out)
         ctx.save_for_backward(out)
         ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B, ctx.blocked = plan, T, params, shape3, B, blocked
