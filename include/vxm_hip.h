@@ -330,6 +330,9 @@ int vxm_conv3d_k3_fewch_bwd_weight(const float* x0, int C0, int64_t x0_bstride, 
 #define VXM_LOSS_TERMS_MAX 8
 int vxm_loss_combine_fwd(const float* const* terms, const float* weights, int n, float* total, float* running, void* stream);
 int vxm_loss_combine_bwd(const float* gtotal, const float* weights, int n, float* gterms, void* stream);
+/* out[i] = a[i] + b[i]: the gradient of a tensor that two ops consume (preint_flow: Grad and VecInt, networks.py:262-268), so that the
+ * captured step carries no ATen accumulation kernel */
+int vxm_add2(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* zero `bytes` bytes on the stream (a memset node when captured): FlatAdam.zero_grad() without an ATen fill kernel */
 int vxm_fill_zero(void* p, size_t bytes, void* stream);
 

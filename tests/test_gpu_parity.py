@@ -599,7 +599,8 @@ def test_conv_bwd_data_and_workspace_umbrella_names(vxm):
     assert L.vxm_workspace_bytes(2, 16, 32, 1, 40, 48, 56) == L.vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(16, 32, 1, 40, 48, 56)
     assert L.vxm_workspace_bytes(3, 32, 32, 1, 160, 192, 224) == L.vxm_conv3d_k3_s3u_bwd_weight_workspace_bytes(32, 32, 1, 160, 192, 224)
     assert L.vxm_workspace_bytes(4, 16, 32, 1, 40, 48, 56) == L.vxm_bf16_conv_bwd_weight_workspace_bytes(16, 32, 1, 40, 48, 56)
-    assert L.vxm_workspace_bytes(6, 0, 0, 2, 8, 8, 8) == 4 * (2 * 2 * 3 * 512 + 128) and L.vxm_workspace_bytes(99, 1, 1, 1, 1, 1, 1) == 0
+    # VecInt backward: two gradient buffers + the per-step statistics + (round 6) the per-tile displacement records of up to 30 steps (2 x 1 x 1 tiles x 2 samples)
+    assert L.vxm_workspace_bytes(6, 0, 0, 2, 8, 8, 8) == 4 * (2 * 2 * 3 * 512 + 128 + 30 * 2 * 2) and L.vxm_workspace_bytes(99, 1, 1, 1, 1, 1, 1) == 0
 
 
 def test_conv_bwd_weight_bitwise_deterministic(vxm):
@@ -1329,14 +1330,18 @@ def test_full_size_step_with_heavy_tailed_activations_on_all_three_engines(vxm):
     2^12 .. 2^20 (log-uniform) -- about one outlier per staged 8 x 8 x 16 tile, i.e. nearly every tile carries one (range_report: 48 % of
     the first layer's activations lie below 2^-18 of their tile's maximum).  Every engine (f16x2 = default, split = bf16x3, native = fp32
     MFMA) is compared with the oracle whose NCC term is evaluated in fp64.
-    Measured (round 5): the step is ill-conditioned for EVERY fp32 evaluation -- the reference-order fp32 oracle itself is 8e-3 from the
-    arbiter on flow.bias -- and the worst parameter gradient is 9.0e-2 (f16x2), 1.0e-1 (split), 1.8e-1 (native, exact fp32 MFMA); medians
-    2.0e-4 / 2.1e-4 / 3.3e-4.  The fp16-piece engine is the CLOSEST of the three: its absolute-error regime costs less than the exact
-    engines lose to their summation order.  Gates: forward field <= 1e-4 relative on every engine, and the default engine no further from
-    the arbiter than 1.5 x the better of the two engines that carry fp32's exponent range."""
+    Measured (round 6): worst parameter gradient (flow.bias, a sum
+    that cancels to 1e-4 of its terms; the reference-order fp32 oracle itself is 8.1e-3 from the arbiter) 1.3e-2 on split, 9.7e-3 on native,
+    8.9e-2 on f16x2; medians over the 24 parameters 3.4e-5 / 2.4e-5 / 1.9e-4.  (Round 5 read 1.0e-1 / 1.8e-1 / 9.0e-2: rounding
+    elsewhere in the step, removed since, hid the difference.)  So on THIS input the fp16 pieces cost about one digit, which is exactly what the engine guard is for.
+    Gates: forward field <= 1e-4 relative on every engine; the two engines that carry fp32's exponent range inside 1.5 x the gate of every
+    parameter; the fp16-piece engine within 40 x (its documented absolute-error regime, not a broken kernel) AND refused for this batch by
+    the guard every GraphedStep runs on its first step (diagnostics.guard_engine moves the process to `split`)."""
+    import warnings
     from voxelmorph_amd.torch import functional as VF
-    from voxelmorph_amd import invalidate_packs
+    from voxelmorph_amd import invalidate_packs, diagnostics
     torch.set_num_threads(min(32, os.cpu_count() or 1))
+    guard = None
     vol, _, _ = _real_scan()
     trg = vol[None, None].copy()
     src = c_oracle.warp3d(trg, _smooth_svf(FULL), mode="bilinear")
@@ -1363,9 +1368,22 @@ def test_full_size_step_with_heavy_tailed_activations_on_all_three_engines(vxm):
             model.load_state_dict(sd, strict=False)
             model = model.cuda()
             invalidate_packs(model)
-            y, pre = model(s, t)
-            loss = vxm.losses.NCC().loss(t, y) + vxm.losses.Grad("l2", loss_mult=2).loss(None, pre)
-            loss.backward()
+            box = []
+
+            def step():
+                y, pre = model(s, t)
+                loss = vxm.losses.NCC().loss(t, y) + vxm.losses.Grad("l2", loss_mult=2).loss(None, pre)
+                loss.backward()
+                box.append((y, pre, loss))
+            if engine == "f16x2":                  # under the probe of the guard: same launches, plus one probe per tensor
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    guard = diagnostics.guard_engine(step)
+                assert VF.FP32_ENGINE == "split"   # the guard moved the process off the fp16 pieces ...
+                VF.FP32_ENGINE = engine            # ... (this leg measures them anyway; the step above ran on them)
+            else:
+                step()
+            y, pre, loss = box[0]
             torch.cuda.synchronize()
             err_p = float((pre.detach().cpu() - pres.detach()).abs().max()) / max(float(pres.detach().abs().max()), 1e-30)
             errs = {n: rel_l2(N(p.grad), g64[n].numpy()) for n, p in model.named_parameters()}
@@ -1380,8 +1398,9 @@ def test_full_size_step_with_heavy_tailed_activations_on_all_three_engines(vxm):
             torch.cuda.empty_cache()
     finally:
         VF.FP32_ENGINE = keep
-    assert ratio["f16x2"] <= 1.5 * min(ratio["split"], ratio["native"]), ratio
-    assert max(ratio.values()) <= 40.0, ratio             # (a broken kernel is orders of magnitude out, not a factor)
+    assert max(ratio["split"], ratio["native"]) <= 1.5, ratio
+    assert ratio["f16x2"] <= 40.0, ratio                  # (a broken kernel is orders of magnitude out, not a factor)
+    assert guard is not None and guard["recommended_engine"] == "split" and guard["worst"]["share_below_2^-18_of_tile_max"] > 0.1, guard["worst"]
 
 
 @pytest.mark.parametrize("c0,up0,c1,cout", [(32, False, 0, 16), (16, False, 0, 32), (32, True, 16, 32), (2, False, 0, 16), (16, False, 0, 3)])

@@ -141,6 +141,7 @@ SIGNATURES = {
     "vxm_loss_combine_fwd": [_P, _P, _I, _P, _P, _P],
     "vxm_loss_combine_bwd": [_P, _P, _I, _P, _P],
     "vxm_fill_zero": [_P, _S, _P],
+    "vxm_add2": [_P, _P, _P, _L, _P],
     "vxm_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
     "vxm_adam_step_dev": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _F, _P],
 }

@@ -1306,8 +1306,9 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
 // gw[co][ci_off + ci][tap] (row length gw_cin) = sum over the (block, depth slice) partials in a fixed order; gb[co] from tap slot 27
 // of chunk 0 (every chunk carries the same bias sum).  Block = 64 consecutive outputs x 16 slices, 8 loads in flight per thread,
 // slices combined through LDS in a fixed tree (deterministic) -- the reducer of conv_bf16.hip with a channel sub-range destination.
+// swap (k_s3_bww_pc<true>): the partials hold [dz tile q][mirrored tap][ci (16 NCO rows)][co 16] -- Q counts dz tiles, NCO x chunks.
 __global__ void __launch_bounds__(1024) k_s3_reduce_partials(const float* __restrict__ part, float* __restrict__ gw, float* __restrict__ gb, int C,
-                                                             int Cout, int gw_cin, int ci_off, int Q, int NCO, int NBLK) {
+                                                             int Cout, int gw_cin, int ci_off, int Q, int NCO, int NBLK, int swap) {
     __shared__ float sm[16][64];
     const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
     const int CoP = 16 * NCO, per_q = 28 * CoP * 16, n = Q * per_q;
@@ -1339,12 +1340,371 @@ __global__ void __launch_bounds__(1024) k_s3_reduce_partials(const float* __rest
         const float sum = (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
                           (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
         const int q = e / per_q, r = e - q * per_q;
-        const int tap = r / (CoP * 16), co = (r / 16) % CoP, ci = q * 16 + (r & 15);
+        const int tap = r / (CoP * 16), row = (r / 16) % CoP, col = q * 16 + (r & 15);
+        const int co = swap ? col : row, ci = swap ? row : col;
         if (tap < 27) {
-            if (co < Cout && ci < C) gw[((size_t)co * gw_cin + ci_off + ci) * 27 + tap] = sum;
-        } else if (gb != nullptr && q == 0 && (r & 15) == 0 && co < Cout) {
+            if (co < Cout && ci < C) gw[((size_t)co * gw_cin + ci_off + ci) * 27 + (swap ? 26 - tap : tap)] = sum;
+        } else if (gb != nullptr && (swap ? row == 0 : (q == 0 && (r & 15) == 0)) && co < Cout) {
             gb[co] = sum;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_s3_bww_pc (round 6): the same contraction with PRODUCER and CONSUMER waves and TWO 16-channel tiles of the un-haloed operand per block
+// ------------------------------------------------------------------------------------------
+// k_s3_bwd_weight gives every (16 x-channel chunk, 16 dz-channel tile) combo its own block: rem0's skip segment (x 16, dz 32) stages its
+// planar x twice, rem1 (x 32, dz 16) its dz twice, and a staged tile feeds 648 MFMAs -- 324 executed FLOP per staged byte, the machine's
+// balance against HBM, with every staging thread holding two raw sets (168 registers: no room for a second accumulator set).  Here
+//   * a block stages ONE 16-channel chunk of the HALOED operand (the 6-plane ring of k_s3_bwd_weight) and TWO 16-channel tiles of the
+//     PLAIN operand, and multiplies each against the haloed chunk: 1296 MFMAs per staged tile, 2 / 3 of the staging per MFMA;
+//   * 12 consumer waves = (plain tile, depth slice, kd) only multiply -- all four rows of their slice, so a B fragment set (haloed row, kw)
+//     read once from LDS feeds nine MFMAs instead of up to nine of a two-row wave's six; 4 producer waves only fetch, split and write.
+//     The staging registers leave the multiplying waves (96 live registers: 36 totals, 32 dZ fragments, chains), and a producer wave is
+//     alone with its 64 raw registers: 16 waves at 128 registers, one block per CU;
+//   * a producer wave stages a whole scale unit by itself -- one haloed plane (16 channels x 6 x 34 voxels: waves 12, 13), or the two
+//     depth slices of one plain tile (waves 14, 15) -- so the unit's largest magnitude is a wave reduction (DPP) and the power-of-two
+//     scale needs no exchange between waves: load, maximum, split, write in one phase, and the loads of the tile after next are issued
+//     before the phase's barrier (the raw registers are free as soon as the pieces are written), in flight under the next phase.
+// The contraction is symmetric in its operands: gW[co][ci][tap] = sum_v dz[co][v] x[ci][v + tap - 1] = sum_u x[ci][u] dz[co][u - (tap - 1)],
+// so either tensor can be the haloed one.  SWAP = false: haloed = x, plain = dz (Cdz a multiple of 32: rem0's skip segment, enc1, the
+// 32 -> 32 layers); SWAP = true: haloed = dz, plain = x (C a multiple of 32, Cdz not: rem1), the partials then hold [ci][co] at the
+// MIRRORED tap (26 - tap) and the bias sum comes from the interior of the haloed operand; k_s3_reduce_partials maps both.
+// fp16 pieces only.  Partials: part[bx][haloed chunk][tap 0..27][plain channel 16 NPL][haloed channel 16], NPL = 16-channel tiles of plain.
+constexpr int PW_CONS = 12, PW_PROD = 4, PW_THREADS = 64 * (PW_CONS + PW_PROD);
+constexpr int PW_XBYTES = 2 * SW_XPIECE;                       // two pieces of the 6-plane haloed ring
+constexpr int PW_ZBYTES = 2 * 2 * 2 * SW_ZPIECE;                // [buffer 2][plain tile 2][piece 2]
+constexpr int PW_TAB_BYTES = 256;                              // floats: [0..5] inverse scales of the ring planes, [6 + 4 buf + 2 pt + ds] of the plain units
+constexpr int PW_EPI_BYTES = (PW_CONS * 9 + 4) * 256 * 4;
+constexpr int PW_LDS_BYTES = PW_XBYTES + PW_ZBYTES + PW_TAB_BYTES > PW_EPI_BYTES ? PW_XBYTES + PW_ZBYTES + PW_TAB_BYTES : PW_EPI_BYTES;
+static_assert(PW_LDS_BYTES <= 160 * 1024, "k_s3_bww_pc: LDS");
+
+template <bool SWAP>
+__global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restrict__ hal, long long hal_bs, int Chal, const float* __restrict__ pla,
+                                                          long long pla_bs, int Cpla, float* __restrict__ part, int D, int H, int W, int NBLK,
+                                                          int NPL2, SwTasks tk, int task_rr, int hal_blocked, int pla_blocked, int dbg) {
+    using P = S3P<2>;
+    VXM_DYN_SMEM(char, smem);
+    char* const Xs = smem;                                       // [2 pieces][6 ring planes][SW_PLANE]
+    char* const Zs = smem + PW_XBYTES;                           // [2 buffers][2 plain tiles][2 pieces][SW_ZPIECE]
+    float* const Tab = reinterpret_cast<float*>(smem + PW_XBYTES + PW_ZBYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NCOMBO = gridDim.x / NBLK, xmain = NBLK & ~7;
+    int bx, combo;                                               // block -> (task range, combo) as k_s3_bwd_weight: the combos of one bx share an XCD
+    if ((int)blockIdx.x < xmain * NCOMBO) {
+        const int j = blockIdx.x >> 3;
+        combo = j % NCOMBO;
+        bx = (j / NCOMBO) * 8 + (blockIdx.x & 7);
+    } else {
+        const int r = blockIdx.x - xmain * NCOMBO;
+        bx = xmain + r / NCOMBO;
+        combo = r % NCOMBO;
+    }
+    const int qh = combo / NPL2, pp2 = combo - qh * NPL2;        // 16-channel chunk of the haloed operand, 32-channel pair of the plain one
+    const int ntask = tk.ncol * tk.nseg;
+    int k_lo, k_hi, k_step;
+    if ((NBLK & 7) == 0 && task_rr) {
+        const int x = bx & 7;
+        k_lo = (int)((long long)ntask * x / 8) + (bx >> 3); k_hi = (int)((long long)ntask * (x + 1) / 8); k_step = NBLK >> 3;
+    } else {
+        k_lo = (int)((long long)ntask * bx / NBLK); k_hi = (int)((long long)ntask * (bx + 1) / NBLK); k_step = 1;
+    }
+    const int V = D * H * W, HW = H * W;
+    auto task_geom = [&](int task, int& b, int& h0, int& w0, int& dbase, int& ntile) __attribute__((always_inline)) {
+        const int seg = task_rr ? task / tk.ncol : task % tk.nseg, col = task_rr ? task - seg * tk.ncol : task / tk.nseg;
+        const int tw = col % tk.nw; int cq = col / tk.nw;
+        const int th = cq % tk.nh; b = cq / tk.nh;
+        const int td0 = seg * tk.seg_len;
+        ntile = min(tk.seg_len, tk.nd - td0);
+        dbase = td0 * SW_TD; h0 = th * SW_TH; w0 = tw * SW_TW;
+    };
+
+    // ---- consumers: wave cw = (plain tile pt, depth slice ds, kd); the 9 (kh, kw) taps of kd over the four rows of slice ds
+    const int cw = wave, pt = cw / 6, w6 = cw - 6 * pt, ds = w6 / 3, kd = w6 - 3 * ds;
+    f32x4 tot[3][3], totb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) tot[kh][kw] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (wave < PW_CONS) {
+        const int lp = (4 * (lane >> 4) + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;     // lane pattern of the transposing read
+        const u32x4 ones = {P::ONES, P::ONES, P::ONES, P::ONES};
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        for (int task = k_lo; task < k_hi; task += k_step) {
+            int b, h0, w0, dbase, ntile;
+            task_geom(task, b, h0, w0, dbase, ntile);
+            __syncthreads();                                     // the first two plane pairs and plain tile 0 are written
+            for (int t = 0; t < ntile; ++t) {
+                if (S3_DBG(dbg, 2)) { __syncthreads(); continue; }            // timing experiment: no multiply phase
+                const int ring = (2 * t + ds + kd) % SW_RING, zcur = t & 1;
+                const char* const xp = Xs + ring * SW_PLANE;
+                const float unscale_h = Tab[ring], unscale_p = Tab[6 + 4 * zcur + 2 * pt + ds];
+                u32x4 az[SW_TH][2];                              // plain fragments (two pieces) of the four rows
+                f32x4 accb = zero4;
+                __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+                for (int r = 0; r < SW_TH; ++r) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int zb = ((zcur * 2 + pt) * 2 + p) * SW_ZPIECE + ((ds * SW_TH + r) * SW_TW) * 32 + lp;
+                        const u32x2 lo = s3_tr_read(Zs, zb), hi = s3_tr_read(Zs, zb + 16 * 32);
+                        az[r][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+                    }
+                    if (!SWAP && kd == 0) {                      // bias gradient = sum of the plain operand (dz) against ones
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) accb = P::mfma(az[r][p], ones, accb);
+                    }
+                }
+                // the B fragment set (haloed row, kw) of step i + 1 is requested before the MFMAs of step i (two sets in registers)
+                u32x4 bq[2][2];
+                auto read_b = [&](auto i_) __attribute__((always_inline)) {
+                    constexpr int i = decltype(i_)::value, kw = i / SW_HR, hl = i - kw * SW_HR;
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int xb = p * SW_XPIECE + (hl * SW_XW + kw) * 32 + lp;
+                        const u32x2 lo = s3_tr_read(xp, xb), hi = s3_tr_read(xp, xb + 16 * 32);
+                        bq[i & 1][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+                    }
+                };
+                read_b(std::integral_constant<int, 0>{});
+                f32x4 acc[3];
+                auto step = [&](auto i_) __attribute__((always_inline)) {
+                    constexpr int i = decltype(i_)::value, kw = i / SW_HR, hl = i - kw * SW_HR;       // haloed row hl serves output rows hl - kh
+                    if constexpr (hl == 0 && kw == 1) __builtin_amdgcn_s_setprio(1);
+                    if constexpr (hl == 0 && kw == 2) __builtin_amdgcn_s_setprio(0);
+                    if constexpr (i + 1 < 3 * SW_HR) read_b(std::integral_constant<int, i + 1>{});
+#pragma unroll
+                    for (int tp = 0; tp < P::NPROD; ++tp)
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh) {
+                            const int rl = hl - kh;
+                            if (rl >= 0 && rl < SW_TH)
+                                acc[kh] = P::mfma(az[rl][P::PA[tp]], bq[i & 1][P::PB[tp]], (rl == 0 && tp == 0) ? zero4 : acc[kh]);
+                        }
+                    if constexpr (SWAP && kw == 1 && hl >= 1 && hl <= SW_TH) {    // bias gradient = sum of the haloed operand (dz) over its interior
+                        if (kd == 1 && pt == 0) {
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) accb = P::mfma(ones, bq[i & 1][p], accb);
+                        }
+                    }
+                    if constexpr (hl == SW_HR - 1) {
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) tot[kh][kw][j] = __builtin_fmaf(acc[kh][j] * unscale_h, unscale_p, tot[kh][kw][j]);
+                    }
+                };
+                s3_static_for(step, std::make_integer_sequence<int, 3 * SW_HR>{});
+                const float ub = SWAP ? unscale_h : unscale_p;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) totb[j] = __builtin_fmaf(accb[j], ub, totb[j]);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();                                 // tile t is read, tile t + 1 is written
+            }
+        }
+    } else {
+        // ---- producers: wave 12 + pw.  pw 0 / 1: haloed plane p0 + pw of a plane pair (216 slots = (pair of W neighbours, 8-channel half)
+        // over 6 rows x 18 pairs, four rounds of 64 lanes); pw 2 / 3: plain tile pw - 2, rounds 0, 1 = depth slice 0, rounds 2, 3 = slice 1.
+        const int pw = wave - PW_CONS;
+        // the producers' vector work is small and everything waits for it at the phase's barrier: above the consumers (at their priority or
+        // below it the multiply phase starved it, and split + multiply took longer than one after the other: 0.53 ms against 0.40 + 0.21 - 0.12)
+        __builtin_amdgcn_s_setprio(3);
+        auto produce = [&](auto hr_, auto bl_) __attribute__((always_inline)) {
+            constexpr bool HR = decltype(hr_)::value, BLK = decltype(bl_)::value;
+            constexpr int lsh = BLK ? 5 : 2;
+            constexpr int SW_XPAIRS = SW_XW / 2 + 1, NXS = SW_HR * SW_XPAIRS * 2;      // 18 pairs, 216 slots per plane
+            const int ppt = pw - 2;                                  // plain role: which of the two tiles
+            float ra[4][8], rb[4][8];
+            int off0[4], ldst[4], vk[4];
+            for (int task = k_lo; task < k_hi; task += k_step) {
+                int b, h0, w0, dbase, ntile;
+                task_geom(task, b, h0, w0, dbase, ntile);
+                const __amdgpu_buffer_rsrc_t rd = vxm_rsrc(HR ? hal + (size_t)b * hal_bs : pla + (size_t)b * pla_bs, (unsigned)(HR ? Chal : Cpla) * (unsigned)V * 4u);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    if constexpr (HR) {
+                        const int si = rr * 64 + lane, cb = si & 1, pr = si >> 1, hh = pr / SW_XPAIRS, pp = pr - hh * SW_XPAIRS;
+                        const int gh = h0 - 1 + hh, gw = w0 - 2 + 2 * pp;
+                        const bool live = si < NXS && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W && qh * 16 + cb * 8 < Chal;
+                        off0[rr] = live ? (BLK ? ((qh * 2 + cb) * V + gh * W + gw) << 5 : ((qh * 16 + cb * 8) * V + gh * W + gw) << 2) : VXM_OOB;
+                        ldst[rr] = si < NXS ? (((hh * SW_XW + 2 * pp - 1) * 32 + cb * 16) | (pp == 0 ? 1 : 0) | (pp == SW_XPAIRS - 1 ? 2 : 0)) : 3;      // 3: idle lane, neither voxel stored
+                    } else {
+                        const int zds = rr >> 1, si = (rr & 1) * 64 + lane, cb = si & 1, r2 = si >> 1, zh = r2 / (SW_TW / 2), zw = 2 * (r2 - zh * (SW_TW / 2));
+                        const int ch = pp2 * 32 + ppt * 16 + cb * 8;
+                        const bool live = h0 + zh < H && w0 + zw < W && ch < Cpla;
+                        off0[rr] = live ? (BLK ? ((ch >> 3) * V + (zds * H + h0 + zh) * W + w0 + zw) << 5 : (ch * V + (zds * H + h0 + zh) * W + w0 + zw) << 2) : VXM_OOB;
+                        ldst[rr] = ((zds * SW_TH + zh) * SW_TW + zw) * 32 + cb * 16;
+                    }
+                }
+                // unit u of a task: haloed planes 2 u, 2 u + 1 (plane p = depth dbase - 1 + p) and plain tile u - 1 (u = 0: none).
+                // load_round: the raw loads of round rr of unit u (past the task's last unit, or outside the volume: nothing fetched, zeros)
+                auto load_round = [&](auto rr_, int u) __attribute__((always_inline)) {
+                    constexpr int rr = decltype(rr_)::value;
+                    int sb = 0;
+                    if constexpr (HR) {
+                        const int gd = dbase - 1 + 2 * u + pw;                      // wave-uniform
+                        const bool in = (unsigned)gd < (unsigned)D && u <= ntile;
+                        int o = in ? (gd * HW) << lsh : 0, f = in ? 0 : VXM_OOB;
+                        asm volatile("" : "+v"(f));
+                        vk[rr] = (off0[rr] + o) | f;
+                    } else {
+                        const int tz = u - 1, gz = dbase + (tz < 0 ? 0 : tz) * SW_TD;    // first depth slice of the plain tile
+                        int f = (tz < 0 || tz >= ntile || gz + (rr >> 1) >= D) ? VXM_OOB : 0;
+                        asm volatile("" : "+v"(f));
+                        vk[rr] = off0[rr] | f;
+                        sb = (gz * HW) << lsh;
+                    }
+                    if (S3_DBG(dbg, 1)) vk[rr] = VXM_OOB;      // timing experiment: nothing fetched
+                    if constexpr (BLK) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const f32x4 ta = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, vk[rr], sb + 16 * k, 0));
+                            const f32x4 tb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, vk[rr], sb + 32 + 16 * k, 0));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { ra[rr][4 * k + e] = ta[e]; rb[rr][4 * k + e] = tb[e]; }
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rd, vk[rr], sb + ((e * V) << 2), 0));
+                            ra[rr][e] = t2.x; rb[rr][e] = t2.y;
+                        }
+                    }
+                };
+                // scale of rounds RLO .. RLO + NR - 1 (one scale unit): wave maximum -> power of two; its inverse goes to the table
+                auto unit_scale = [&](auto rlo_, auto nr_, float* tab_slot) __attribute__((always_inline)) -> float {
+                    constexpr int RLO = decltype(rlo_)::value, NR = decltype(nr_)::value;
+                    float m = 0.0f;
+#pragma unroll
+                    for (int rr = RLO; rr < RLO + NR; ++rr)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[rr][e]), __builtin_fabsf(rb[rr][e])));
+                    m = s3_wave_max(m);
+                    float sc, inv;
+                    s3_scale_of(m, sc, inv);
+                    if (lane == 0) *tab_slot = inv;
+                    return sc;
+                };
+                // split round rr with scale sc and write its pieces
+                auto split_round = [&](auto rr_, float sc, char* dst) __attribute__((always_inline)) {
+                    constexpr int rr = decltype(rr_)::value;
+                    unsigned ka[2][4], kb[2][4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s3_split2_f16(ra[rr][2 * e], ra[rr][2 * e + 1], sc, ka[0][e], ka[1][e]);
+                        s3_split2_f16(rb[rr][2 * e], rb[rr][2 * e + 1], sc, kb[0][e], kb[1][e]);
+                    }
+                    if constexpr (HR) {
+                        char* const d = dst + (ldst[rr] & ~3);
+                        if (!(ldst[rr] & 1)) {
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(d + p * SW_XPIECE) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
+                        }
+                        if (!(ldst[rr] & 2)) {
+#pragma unroll
+                            for (int p = 0; p < 2; ++p) *reinterpret_cast<u32x4*>(d + p * SW_XPIECE + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                        }
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            *reinterpret_cast<u32x4*>(dst + p * SW_ZPIECE + ldst[rr]) = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
+                            *reinterpret_cast<u32x4*>(dst + p * SW_ZPIECE + ldst[rr] + 32) = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                        }
+                    }
+                };
+                using I0 = std::integral_constant<int, 0>;
+                using I1 = std::integral_constant<int, 1>;
+                using I2 = std::integral_constant<int, 2>;
+                using I3 = std::integral_constant<int, 3>;
+                using I4 = std::integral_constant<int, 4>;
+                // finish unit u (in registers) and request unit un: the raw registers of a round are free as soon as it is split, so its next
+                // loads go out at once -- a round is in flight for nearly a whole phase, and the block's requests are spread over the phase
+                // instead of leaving in one burst behind the last write (first version: 0.80 ms where loads, multiply and split alone take
+                // 0.32 / 0.40 / 0.24: they ran one after the other)
+                auto advance = [&](int u, bool fin, int un) __attribute__((always_inline)) {
+                    if (S3_DBG(dbg, 4)) fin = false;             // timing experiment: no split, no LDS writes
+                    if constexpr (HR) {
+                        const int slot = (2 * u + pw) % SW_RING;
+                        char* const dst = Xs + slot * SW_PLANE;
+                        float sc = 1.0f;
+                        if (fin) sc = unit_scale(I0{}, I4{}, Tab + slot);
+                        if (fin) split_round(I0{}, sc, dst);
+                        load_round(I0{}, un);
+                        if (fin) split_round(I1{}, sc, dst);
+                        load_round(I1{}, un);
+                        if (fin) split_round(I2{}, sc, dst);
+                        load_round(I2{}, un);
+                        if (fin) split_round(I3{}, sc, dst);
+                        load_round(I3{}, un);
+                    } else {
+                        fin = fin && u >= 1;                     // unit 0 carries no plain tile
+                        const int zbuf = (u - 1) & 1;
+                        char* const dst = Zs + ((zbuf * 2 + ppt) * 2) * SW_ZPIECE;
+                        float sc = 1.0f;
+                        if (fin) sc = unit_scale(I0{}, I2{}, Tab + 6 + 4 * zbuf + 2 * ppt);
+                        if (fin) split_round(I0{}, sc, dst);
+                        load_round(I0{}, un);
+                        if (fin) split_round(I1{}, sc, dst);
+                        load_round(I1{}, un);
+                        if (fin) sc = unit_scale(I2{}, I2{}, Tab + 6 + 4 * zbuf + 2 * ppt + 1);
+                        if (fin) split_round(I2{}, sc, dst);
+                        load_round(I2{}, un);
+                        if (fin) split_round(I3{}, sc, dst);
+                        load_round(I3{}, un);
+                    }
+                };
+                advance(0, false, 0);
+                advance(0, true, 1);
+                advance(1, true, 2);
+                __syncthreads();
+                for (int t = 0; t < ntile; ++t) {
+                    advance(t + 2, t + 1 < ntile, t + 3);        // tile t + 1 = unit t + 2; past the task's last unit nothing is fetched
+                    asm volatile("" ::"v"(vk[0]), "v"(vk[1]), "v"(vk[2]), "v"(vk[3]));
+                    __syncthreads();
+                }
+            }
+        };
+        if (pw < 2) { if (hal_blocked) produce(std::true_type{}, std::true_type{}); else produce(std::true_type{}, std::false_type{}); }
+        else        { if (pla_blocked) produce(std::false_type{}, std::true_type{}); else produce(std::false_type{}, std::false_type{}); }
+    }
+
+    // ---- partials: the two depth-slice waves of a (plain tile, kd) are summed through LDS in a fixed order
+    float* const Ls = reinterpret_cast<float*>(smem);            // [wave 12][tap 9][plain 16][haloed 16] + [4 bias slots][16][16]
+    __syncthreads();
+    if (wave < PW_CONS) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Ls[((cw * 9 + kh * 3 + kw) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = tot[kh][kw][r];
+        if (SWAP ? (kd == 1 && pt == 0) : (kd == 0)) {
+            const int slot = SWAP ? ds : 2 * pt + ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Ls[((PW_CONS * 9 + slot) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = totb[r];
+        }
+    }
+    __syncthreads();
+    const int NPL = 2 * NPL2, QH = NCOMBO / NPL2;
+    float* const po = part + (((size_t)bx * QH + qh) * 28) * (16 * NPL) * 16 + (size_t)(2 * pp2) * 256;
+    for (int e = tid; e < 2 * 28 * 256; e += PW_THREADS) {
+        const int pt_ = e / (28 * 256), r_ = e - pt_ * (28 * 256), tap = r_ >> 8, i = r_ & 255;
+        float v;
+        if (tap < 27) {
+            const int kd_ = tap / 9, t9 = tap - 9 * kd_;
+            const float* const l = Ls + ((pt_ * 6 + kd_) * 9 + t9) * 256 + i;
+            v = l[0] + l[3 * 9 * 256];
+        } else if (SWAP) {
+            const float* const l = Ls + PW_CONS * 9 * 256 + i;
+            v = pt_ == 0 ? l[0] + l[256] : 0.0f;
+        } else {
+            const float* const l = Ls + (PW_CONS * 9 + 2 * pt_) * 256 + i;
+            v = l[0] + l[256];
+        }
+        po[(size_t)tap * (16 * NPL) * 16 + pt_ * 256 + i] = v;
     }
 }
 
@@ -1370,6 +1730,16 @@ SwTasks sw_tasks(int ncombo, int B, int D, int H, int W, int& NBLK) {
     const long long ntask = (long long)tk.ncol * tk.nseg;
     NBLK = (int)(nb < ntask ? nb : ntask);
     return tk;
+}
+
+// which launches k_s3_bww_pc takes (fp16 pieces): 1 = haloed x, plain dz (Cout a multiple of 32), 2 = swapped (C a multiple of 32), 0 = none.
+// VXM_S3_BW_PC=0 keeps every launch on k_s3_bwd_weight (same-box A/B).
+int sw_pc_mode(int C, int Cout, int pieces) {
+    static const bool on = [] { const char* e = getenv("VXM_S3_BW_PC"); return !(e && e[0] == '0'); }();
+    if (!on || pieces != 2 || C % 16 || Cout % 16) return 0;
+    if (Cout % 32 == 0) return 1;
+    if (C % 32 == 0) return 2;
+    return 0;
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -1621,7 +1991,14 @@ size_t vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(int C, int Cout, int B, int D
     const int Q = (C + 15) / 16, NCO = (Cout + 15) / 16;
     int NBLK = 1;
     (void)sw_tasks(Q * NCO, B, D, H, W, NBLK);
-    return (size_t)NBLK * Q * SW_NSL * 28 * (16 * NCO) * 16 * sizeof(float);
+    size_t need = (size_t)NBLK * Q * SW_NSL * 28 * (16 * NCO) * 16 * sizeof(float);
+    const int mode = sw_pc_mode(C, Cout, 2);                     // k_s3_bww_pc runs fewer combos, hence more blocks per combo: the larger of the two
+    if (mode) {
+        (void)sw_tasks(Q * NCO / 2, B, D, H, W, NBLK);
+        const size_t need2 = (size_t)NBLK * Q * 28 * (16 * NCO) * 16 * sizeof(float);
+        if (need2 > need) need = need2;
+    }
+    return need;
 }
 
 int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw, int gw_cin,
@@ -1639,14 +2016,17 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
                 Cout, ci_off, ci_off + C, gw_cin, W);
     const int Q = C / 16, NCO = Cout / 16;
     VXM_REQUIRE(Q * NCO <= sw_cus(), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_bwd_weight: %d x %d channel tiles exceed the compute units", Q, NCO);
+    const int pc = sw_pc_mode(C, Cout, pieces);                  // 1 / 2: k_s3_bww_pc (two plain tiles per staged haloed chunk), haloed = x / dz
     int NBLK = 1;
-    const SwTasks tk = sw_tasks(Q * NCO, B, D, H, W, NBLK);
+    const SwTasks tk = sw_tasks(pc ? Q * NCO / 2 : Q * NCO, B, D, H, W, NBLK);
     VXM_REQUIRE(work_bytes >= (size_t)NBLK * Q * SW_NSL * 28 * (16 * NCO) * 16 * sizeof(float), VXM_ERR_WORKSPACE,
                 "vxm_conv3d_k3_s3_bwd_weight: workspace too small");
     static const bool attr = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SwCfg<3>::LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SwCfg<2>::LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SwCfg<2>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bww_pc<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bww_pc<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_BYTES);
         return true;
     }();
     (void)attr;
@@ -1657,6 +2037,12 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
     // (round-robin order: -8 .. -16 % at 160x192x224, +3 % at 80x96x112 -- same-box A/B, profiles/r04r_bw_task_order.txt)
     const int task_rr = ((te && te[0] == 'r' && te[1] == 'a') || (long long)D * H * W < (1ll << 21)) ? 0 : 1;
     if (phase == VXM_S3_BW_REDUCE_ONLY) {}
+    else if (pc == 1)
+        hipLaunchKernelGGL((k_s3_bww_pc<false>), dim3(NBLK * Q * NCO / 2), dim3(PW_THREADS), PW_LDS_BYTES, s, x, (long long)x_bstride, C, dz, (long long)dz_bstride,
+                           Cout, part, D, H, W, NBLK, NCO / 2, tk, task_rr, lay & VXM_S3_IN0_BLOCKED ? 1 : 0, lay & VXM_S3_IN1_BLOCKED ? 1 : 0, s3_dbg());
+    else if (pc == 2)
+        hipLaunchKernelGGL((k_s3_bww_pc<true>), dim3(NBLK * Q * NCO / 2), dim3(PW_THREADS), PW_LDS_BYTES, s, dz, (long long)dz_bstride, Cout, x, (long long)x_bstride,
+                           C, part, D, H, W, NBLK, Q / 2, tk, task_rr, lay & VXM_S3_IN1_BLOCKED ? 1 : 0, lay & VXM_S3_IN0_BLOCKED ? 1 : 0, s3_dbg());
     else if (pieces == 2 && pe && pe[0] == '1')
         hipLaunchKernelGGL((k_s3_bwd_weight<2, false>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
                            (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, lay, s3_dbg());
@@ -1667,8 +2053,10 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
         hipLaunchKernelGGL((k_s3_bwd_weight<3, true>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<3>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
                            (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, lay, s3_dbg());
     const int n = 16 * NCO * 16 * Q * 28;
-    if (phase != VXM_S3_BW_CONTRACT_ONLY)
-        hipLaunchKernelGGL(k_s3_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(1024), 0, s, part, gw, gb, C, Cout, gw_cin, ci_off, Q, NCO, NBLK);
+    if (phase != VXM_S3_BW_CONTRACT_ONLY) {
+        if (pc == 2) hipLaunchKernelGGL(k_s3_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(1024), 0, s, part, gw, gb, C, Cout, gw_cin, ci_off, NCO, Q, NBLK, 1);
+        else hipLaunchKernelGGL(k_s3_reduce_partials, dim3(vxm_blocks(n, 64)), dim3(1024), 0, s, part, gw, gb, C, Cout, gw_cin, ci_off, Q, NCO, NBLK, 0);
+    }
     return vxm_check_launch("vxm_conv3d_k3_s3_bwd_weight");
 }
 

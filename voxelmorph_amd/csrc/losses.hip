@@ -634,6 +634,18 @@ __global__ void k_loss_combine_bwd(const float* __restrict__ gtotal, const LossT
     if (threadIdx.x < lt.n && blockIdx.x == 0) gterms[threadIdx.x] = gtotal[0] * lt.w[threadIdx.x];
 }
 
+// out = a + b (the gradient of a tensor with two consumers: autograd's accumulation as a launch of this library -- preint_flow feeds
+// both Grad and VecInt, networks.py:262-268)
+__global__ void __launch_bounds__(256) k_add2(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n) {
+    const long long i = 4 * ((long long)blockIdx.x * 256 + threadIdx.x);
+    if (i + 3 < n && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a + i), y = *reinterpret_cast<const f32x4*>(b + i);
+        *reinterpret_cast<f32x4*>(out + i) = x + y;
+    } else {
+        for (long long k = i; k < n && k < i + 4; ++k) out[k] = a[k] + b[k];
+    }
+}
+
 // ------------------------------------------------------------------ Adam (torch.optim.Adam defaults: no amsgrad / weight decay)
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                               long long n, float step_size, float beta1, float beta2, float eps, float bc2_sqrt, float gscale) {
@@ -982,6 +994,13 @@ int vxm_loss_combine_bwd(const float* gtotal, const float* weights, int n, float
     for (int i = 0; i < VXM_LOSS_TERMS_MAX; ++i) { lt.t[i] = nullptr; lt.w[i] = i < n ? weights[i] : 0.0f; }
     hipLaunchKernelGGL(k_loss_combine_bwd, dim3(1), dim3(64), 0, VXM_STREAM(stream), gtotal, lt, gterms);
     return vxm_check_launch("vxm_loss_combine_bwd");
+}
+
+int vxm_add2(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    VXM_REQUIRE(a && b && out, VXM_ERR_NULL_POINTER, "vxm_add2: null pointer");
+    VXM_REQUIRE(n > 0, VXM_ERR_BAD_SHAPE, "vxm_add2: n=%lld", (long long)n);
+    hipLaunchKernelGGL(k_add2, dim3(vxm_blocks((n + 3) / 4, 256)), dim3(256), 0, VXM_STREAM(stream), a, b, out, (long long)n);
+    return vxm_check_launch("vxm_add2");
 }
 
 int vxm_fill_zero(void* p, size_t bytes, void* stream) {

@@ -3,6 +3,7 @@
 #ifndef VXM_S3_PIECES_H
 #define VXM_S3_PIECES_H
 #include <type_traits>
+#include <utility>
 #include "conv_common.h"
 
 namespace {
@@ -102,6 +103,11 @@ __device__ __forceinline__ u32x2 s3_tr_read(const char* lds_base, int byte_off) 
     const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (__attribute__((address_space(3))) s16x4*)(__attribute__((address_space(3))) void*)(lds_base + byte_off));
     return __builtin_bit_cast(u32x2, v);
+}
+
+// f(integral_constant<int, 0>), f(integral_constant<int, 1>), ... in order: a fully unrolled loop whose index is a compile-time constant inside f
+template <class F, int... I> __device__ __forceinline__ void s3_static_for(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
 }
 
 }  // namespace

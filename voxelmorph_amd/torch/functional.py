@@ -417,6 +417,25 @@ class DiceFn(torch.autograd.Function):
         return gyt, gyp
 
 
+class ForkFn(torch.autograd.Function):
+    """x -> (x, x) for a tensor that two ops consume: autograd would add the two incoming gradients with an ATen kernel; here that sum is
+    vxm_add2.  `preint_flow` (networks.py:262-268) is regularised by Grad AND integrated by VecInt."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            return ga if gb is None else gb
+        require_device(ga, gb)
+        ga, gb = _c(ga), _c(gb)
+        out = torch.empty_like(ga)
+        call("vxm_add2", ptr(ga), ptr(gb), ptr(out), ga.numel(), stream())
+        return out
+
+
 class WeightedSumFn(torch.autograd.Function):
     """`loss = 0; loss += loss_function(y_true[n], y_pred[n]) * weights[n]` (scripts/torch/train.py:205-212) as one launch forward and one
     backward (vxm_loss_combine_fwd / _bwd) instead of a mul + an add of ATen per term.  `running` (optional, n + 1 floats on the device)

@@ -251,6 +251,10 @@ class VxmDense(LoadableModel):
             engine = VB.UnetBf16Fn if VB.enabled() else VF.UnetFn
             field = engine.apply(plan, source, target, *self.unet_model.conv_params(), self.flow.weight, self.flow.bias)
         velocity = self.resize(field) if self.resize is not None else field       # what Grad regularises ("preint_flow")
+        v_int = velocity
+        if self.ndims == 3 and self.integrate is not None and velocity.requires_grad and velocity.is_cuda and velocity.dtype == torch.float32:
+            # the field has two consumers (the caller's Grad loss, the integration): their gradients are summed by this library's kernel
+            velocity, v_int = VF.ForkFn.apply(velocity)
 
         def displacement(v):
             """velocity -> full-resolution displacement: scaling and squaring, then back to the image grid"""
@@ -275,8 +279,8 @@ class VxmDense(LoadableModel):
                 disp = displacement(v)
             return self.transformer(image, disp), disp
 
-        moved_source, forward_disp = moved(source, velocity)
-        moved_target, backward_disp = moved(target, -velocity) if self.bidir else (None, None)
+        moved_source, forward_disp = moved(source, v_int)
+        moved_target, backward_disp = moved(target, -v_int) if self.bidir else (None, None)
         return moved_source, moved_target, velocity, forward_disp, backward_disp
 
     def forward(self, source, target, registration=False):
