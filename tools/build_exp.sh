@@ -5,8 +5,10 @@ set -euo pipefail
 cd "$(dirname "$0")/../voxelmorph_amd/csrc"
 bash build.sh > /dev/null
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-comment"
-hipcc $FLAGS -DVXM_S3_EXP -c conv_s3.hip -o build/conv_s3_exp.o
+hipcc $FLAGS -DVXM_S3_EXP -c conv_s3.hip -o build/conv_s3_exp.o &
+hipcc $FLAGS -DVXM_S3_EXP -c conv_s3u.hip -o build/conv_s3u_exp.o &
+wait
 objs=""
-for s in api warp planar conv_fwd conv_bwd_weight conv_bf16 conv_s3u pool losses diag; do objs="$objs build/$s.o"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../libvxm_hip_exp.so $objs build/conv_s3_exp.o
+for s in api warp planar conv_fwd conv_bwd_weight conv_bf16 pool losses diag; do objs="$objs build/$s.o"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../libvxm_hip_exp.so $objs build/conv_s3_exp.o build/conv_s3u_exp.o
 echo "built $(realpath ../libvxm_hip_exp.so)"

@@ -139,6 +139,15 @@ def main():
             VF.conv_forward(x0, c0, x0[0].numel(), True, x1, c1, c1 * V, w, bias, y_nat, cout * V, cout, 0.2, B, D, H, W)
             VF.FP32_ENGINE = keep
         t_s3, t_nat = timed(run_s3, args.iters), timed(run_nat, args.iters)
+        if args.dbg:                                       # timing experiments of k_s3u_conv (SU_DBG in csrc/conv_s3u.hip; --lib build), blocked output as in the step
+            y_blk = torch.empty_like(y_s3)
+            res = {}
+            for v in [0] + [int(v) for v in args.dbg.split(",")]:
+                os.environ["VXM_S3_DBG"] = str(v)
+                res[v] = timed(lambda: VF.s3u_launch(x0, c0, x0[0].numel(), x1, c1, c1 * V, wp, bias, y_blk, cout * V, cout, 0.2, B, D, H, W, lay=VF.S3_OUT_BLOCKED), args.iters)
+            os.environ["VXM_S3_DBG"] = "0"
+            print("    dbg (blocked output): " + " | ".join("%d: %.3f" % kv for kv in res.items()), flush=True)
+            del y_blk
         gf = 2.0 * (8 * c0 + 27 * c1) * cout * B * V / 1e9
         diff = float((y_s3.double() - y_nat.double()).norm() / y_nat.double().norm())
         rows.append(dict(op=name, gflop_executed=gf, s3_ms=t_s3, s3_tflops=gf / t_s3, native_ms=t_nat, native_tflops=gf / t_nat, rel_l2_s3_vs_native=diff))

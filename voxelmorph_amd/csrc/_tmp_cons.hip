@@ -432,15 +432,11 @@ k_s3u_conv(const float* __restrict__ x0, long long bs0, int C0, const float* __r
 // into a four-slot table.  fp16 pieces only, W and W / 2 even.
 constexpr int SUP_CONS = 8, SUP_PROD = 4, SUP_THREADS = 64 * (SUP_CONS + SUP_PROD), SUP_PT = 64 * SUP_PROD;
 constexpr int SUP_CBU = 2;                                                                      // 8-channel blocks of an upsampled stage
-// a skip stage is one 8-channel chunk over HALF the tile's depth: output rows 4 hf .. 4 hf + 3, haloed planes 4 hf .. 4 hf + 5 (6 of the tile's 10;
-// planes 4, 5 are staged by both halves) -- 648 pair slots = three rounds of 16 raw registers per producer thread instead of five
-constexpr int SUP_SK_PLANES = 6;
-constexpr int SUP_XWORDS = SUP_CBU * SU_UP_CB > SUP_SK_PLANES * SU_SK_PLANE ? SUP_CBU * SU_UP_CB : SUP_SK_PLANES * SU_SK_PLANE;      // 1536 words per piece and buffer
+constexpr int SUP_XWORDS = SUP_CBU * SU_UP_CB > 10 * SU_SK_PLANE ? SUP_CBU * SU_UP_CB : 10 * SU_SK_PLANE;      // 2400 words per piece and buffer
 constexpr int SUP_UP_PAIRS = 10, SUP_UP_SLOTS = SUP_CBU * 6 * 4 * SUP_UP_PAIRS;                 // low-res haloed row w/2 - 2 .. w/2 + 17 as 10 pairs: 480 slots
-constexpr int SUP_SK_PAIRS = 18, SUP_SK_SLOTS = SUP_SK_PLANES * 6 * SUP_SK_PAIRS;               // full-res haloed row w0 - 2 .. w0 + 33 as 18 pairs: 648 slots
-constexpr int SUP_NRU = (SUP_UP_SLOTS + SUP_PT - 1) / SUP_PT, SUP_NRS = (SUP_SK_SLOTS + SUP_PT - 1) / SUP_PT;      // rounds: 2, 3
-constexpr int SUP_SKB_BYTES = SUP_CONS * 7 * 64 * 4;                                             // per class wave: LDS word offsets of its B fragments in the 7 skip K-steps
-constexpr int SUP_LDS_BYTES = 2 * 2 * SUP_XWORDS * 16 + 256 + SUP_SKB_BYTES;
+constexpr int SUP_SK_PAIRS = 18, SUP_SK_SLOTS = 10 * 6 * SUP_SK_PAIRS;                          // full-res haloed row w0 - 2 .. w0 + 33 as 18 pairs: 1080 slots
+constexpr int SUP_NRU = (SUP_UP_SLOTS + SUP_PT - 1) / SUP_PT, SUP_NRS = (SUP_SK_SLOTS + SUP_PT - 1) / SUP_PT;      // rounds: 2, 5
+constexpr int SUP_LDS_BYTES = 2 * 2 * SUP_XWORDS * 16 + 256;
 static_assert(SUP_LDS_BYTES <= 160 * 1024, "k_s3u_conv_pc: LDS");
 
 template <int NCT>
@@ -467,7 +463,7 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
     }
     const int g = blockIdx.y;
     const int V = D * H * W, Dl = D >> 1, Hl = H >> 1, Wl = W >> 1, V0 = Dl * Hl * Wl;
-    const int Q0 = C0 >> 3, Q1 = C1 >> 3, NU = (Q0 + CBU - 1) / CBU, NST = NU + 2 * Q1;      // skip stage NU + 2 q + hf
+    const int Q0 = C0 >> 3, Q1 = C1 >> 3, NU = (Q0 + CBU - 1) / CBU, NST = NU + Q1;
     const u32x4* const wg = wp + (size_t)g * ((size_t)Q0 * UPW + (size_t)Q1 * WSK);
     const int my_tiles = t_lo < t_hi ? (t_hi - t_lo + t_step - 1) / t_step : 0;
     const int nstage = my_tiles * NST;                           // stages this block walks; stage k: tile t_lo + (k / NST) t_step, step k % NST
@@ -480,24 +476,16 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
 
     if (wave < SUP_CONS) {
         // ================================================================ consumers: wave = parity class
-        // At three waves per SIMD (168 registers) the compiler selects the VGPR form of the MFMAs, whose destination may not overlap its
-        // accumulator operand: the 64 accumulators wander through the register file and the multiply loops spill (304 bytes of scratch).
-        // An (empty) asm with an accumulation-register operand makes it keep the AGPR form: accumulators in place in a[0:63].
-#ifdef SUP_AGPR_FORM
-        asm volatile("" ::: "a63");
-#endif
-        const int kg_ = lane >> 4, n_ = lane & 15;
+        const int kg = lane >> 4, n = lane & 15;
         const int pd = wave >> 2, ph = (wave >> 1) & 1, pw = wave & 1;
-        const int up_base = pd * SU_UP_PLANE + (ph + (kg_ & 1)) * SU_UP_ROW + pw + (kg_ >> 1) + n_;
-        // the seven skip-step bases of a lane live in LDS (one ds_read_b32 per K-step): as registers they were spilled to scratch, and the
-        // reload in front of every K-step waited for ALL vector memory -- the weight prefetch it had just issued included (5.9 ms)
-        int* const skb = reinterpret_cast<int*>(Tab + 64) + wave * (7 * 64) + lane;
+        const int up_base = pd * SU_UP_PLANE + (ph + (kg & 1)) * SU_UP_ROW + pw + (kg >> 1) + n;
+        int sk_base[7];
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
             const SuUnit u0 = su_skip_unit(s, 0), u1 = su_skip_unit(s, 1), u2 = su_skip_unit(s, 2), u3 = su_skip_unit(s, 3);
-            const SuUnit u = kg_ == 0 ? u0 : kg_ == 1 ? u1 : kg_ == 2 ? u2 : u3;
+            const SuUnit u = kg == 0 ? u0 : kg == 1 ? u1 : kg == 2 ? u2 : u3;
             const int hw = pw + u.kw;
-            skb[s * 64] = (pd + u.kd) * SU_SK_PLANE + (ph + u.kh) * SU_SK_ROW + (hw & 1) * SU_SK_HALF + (hw >> 1) + n_;
+            sk_base[s] = (pd + u.kd) * SU_SK_PLANE + (ph + u.kh) * SU_SK_ROW + (hw & 1) * SU_SK_HALF + (hw >> 1) + n;
         }
         const size_t GW = (size_t)Q0 * UPW + (size_t)Q1 * WSK;
         const __amdgpu_buffer_rsrc_t rwg = vxm_rsrc(reinterpret_cast<const float*>(wg), (unsigned)(GW * 16));
@@ -517,12 +505,11 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
                 const u32x4* const Xs = smem + (k & 1) * NP * XWORDS;
                 const float ratio = Tab[8 + 2 * (k & 3)];
                 inv_fin = Tab[9 + 2 * (k & 3)];
-                {                                               // ratio < 1: this stage raised the tile's running maximum (unconditional: a branch here
-                    const float rt = st > 0 ? ratio : 1.0f;     // makes the accumulators loop-carried through a phi and the allocator doubles them)
+                if (st > 0 && ratio != 1.0f) {                  // wave-uniform: this stage raised the tile's running maximum
 #pragma unroll
                     for (int r = 0; r < 8; ++r)
 #pragma unroll
-                        for (int ct = 0; ct < NCT; ++ct) acc[r][ct] *= rt;
+                        for (int ct = 0; ct < NCT; ++ct) acc[r][ct] *= ratio;
                 }
                 if (SU_DBG(dbg, 2)) {                           // timing experiment: no multiply phase
                 } else if (st < NU) {
@@ -570,51 +557,44 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
                         wa += UPW * 16;
                     }
                 } else {
-                    // ---- skip stage (chunk q, depth half hf): 7 K-steps over the 27 taps of 8 channels for output rows 4 hf .. 4 hf + 3; the
-                    // weights of a K-step from L2, one K-step ahead
-                    const int sq = st - NU, q = sq >> 1;
-                    const int wk = (Q0 * UPW + q * WSK) * 16;                            // byte offset of the chunk's step 0 (wave-uniform)
-                    auto skip_half = [&](auto hf_) __attribute__((always_inline)) {
-                        constexpr int HF = decltype(hf_)::value;
-                        u32x4 a0[NP][NCT], a1[NP][NCT];
+                    // ---- skip chunk: 7 K-steps over the 27 taps of 8 channels; the weights of a K-step from L2, one K-step ahead
+                    const int wk = (Q0 * UPW + (st - NU) * WSK) * 16;                  // byte offset of the chunk's step 0 (wave-uniform)
+                    u32x4 a0[NP][NCT], a1[NP][NCT];
 #pragma unroll
-                        for (int p = 0; p < NP; ++p)
+                    for (int p = 0; p < NP; ++p)
 #pragma unroll
-                            for (int ct = 0; ct < NCT; ++ct) a0[p][ct] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rwg, lane16, wk + (p * NCT + ct) * 1024, 0));
+                        for (int ct = 0; ct < NCT; ++ct) a0[p][ct] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rwg, lane16, wk + (p * NCT + ct) * 1024, 0));
 #pragma unroll
-                        for (int s = 0; s < 7; ++s) {
-                            u32x4 (&ac)[NP][NCT] = (s & 1) ? a1 : a0;
-                            u32x4 (&an)[NP][NCT] = (s & 1) ? a0 : a1;
-                            __builtin_amdgcn_sched_barrier(0);      // (without it the seven steps' weight loads are all hoisted to the top and spill)
-                            if (s + 1 < 7) {
+                    for (int s = 0; s < 7; ++s) {
+                        u32x4 (&ac)[NP][NCT] = (s & 1) ? a1 : a0;
+                        u32x4 (&an)[NP][NCT] = (s & 1) ? a0 : a1;
+                        __builtin_amdgcn_sched_barrier(0);      // (without it the seven steps' weight loads are all hoisted to the top and spill)
+                        if (s + 1 < 7) {
+#pragma unroll
+                            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                                for (int ct = 0; ct < NCT; ++ct)
+                                    an[p][ct] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rwg, lane16, wk + (((s + 1) * NP + p) * NCT + ct) * 1024, 0));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        u32x4 bf[2][NP];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) bf[0][p] = Xs[p * XWORDS + sk_base[s]];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            if (r + 1 < 8) {
 #pragma unroll
                                 for (int p = 0; p < NP; ++p)
-#pragma unroll
-                                    for (int ct = 0; ct < NCT; ++ct)
-                                        an[p][ct] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rwg, lane16, wk + (((s + 1) * NP + p) * NCT + ct) * 1024, 0));
+                                    bf[(r + 1) & 1][p] = Xs[p * XWORDS + sk_base[s] + ((r + 1) >> 1) * 2 * SU_SK_PLANE + ((r + 1) & 1) * 2 * SU_SK_ROW];
                             }
                             __builtin_amdgcn_sched_barrier(0);
-                            u32x4 bf[2][NP];
-                            const int sb = skb[s * 64];
 #pragma unroll
-                            for (int p = 0; p < NP; ++p) bf[0][p] = Xs[p * XWORDS + sb];
+                            for (int t = 0; t < P::NPROD; ++t)
 #pragma unroll
-                            for (int rl = 0; rl < 4; ++rl) {                             // local row rl = 2 ld' + lh of the half: accumulator row 4 HF + rl
-                                if (rl + 1 < 4) {
-#pragma unroll
-                                    for (int p = 0; p < NP; ++p)
-                                        bf[(rl + 1) & 1][p] = Xs[p * XWORDS + sb + ((rl + 1) >> 1) * 2 * SU_SK_PLANE + ((rl + 1) & 1) * 2 * SU_SK_ROW];
-                                }
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int t = 0; t < P::NPROD; ++t)
-#pragma unroll
-                                    for (int ct = 0; ct < NCT; ++ct) acc[4 * HF + rl][ct] = P::mfma(ac[P::PA[t]][ct], bf[rl & 1][P::PB[t]], acc[4 * HF + rl][ct]);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
+                                for (int ct = 0; ct < NCT; ++ct) acc[r][ct] = P::mfma(ac[P::PA[t]][ct], bf[r & 1][P::PB[t]], acc[r][ct]);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                    };
-                    if (sq & 1) skip_half(std::integral_constant<int, 1>{}); else skip_half(std::integral_constant<int, 0>{});
+                    }
                 }
                 __syncthreads();                                // stage k is read, stage k + 1 is written
             }
@@ -622,8 +602,6 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
             int cbt, cd0, ch0, cw0;
             tile_geom(tile, cbt, cd0, ch0, cw0);
             const float unscale = inv_fin * inv_w;
-            int kg = kg_, n = n_;                               // opaque per tile: the epilogue's addresses are computed here, not hoisted out of the tile loop
-            asm volatile("" : "+v"(kg), "+v"(n));               // (hoisted, they were spilled: 61 dwords of scratch)
             float bz[NCT][4];
             conv_load_bias<NCT>(bz, bias, Cout, g, kg);
             const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(y + (size_t)cbt * y_bs, SU_DBG(dbg, 8) ? 0u : (unsigned)Cout * (unsigned)V * 4u);
@@ -667,147 +645,6 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
                     }
                 }
             }
-        }
-    } else {
-        // ================================================================ producers
-        const int pwv = wave - SUP_CONS, ptid = tid - 64 * SUP_CONS;
-        __builtin_amdgcn_s_setprio(3);                           // little vector work, and every wave waits for it at the barrier (see k_s3_bww_pc)
-        // staging roles (tile-independent): slot i = ptid + 256 j is a PAIR of W neighbours, 8 channels.
-        //   upsampled stage: i = (cb, hd 6, hh 4, pp 10): low-res voxels hw = 2 pp - 1, 2 pp of the haloed row (hw = 0 .. 17 kept) -> LDS word cb 768 + hd 128 + hh 32 + hw
-        //   skip chunk:      i = (hd 10, hh 6, pp 18):    full-res voxels hw = 2 pp - 1, 2 pp (hw = 0 .. 33 kept)             -> LDS word hd 240 + hh 40 + (hw & 1) 20 + (hw >> 1)
-        // pos < 0: no slot.  lw: LDS word of the SECOND voxel of the pair (the first one: up lw - 1; skip: the other parity half)
-        int up_pos[SUP_NRU], up_lw[SUP_NRU], sk_pos[SUP_NRS], sk_lw[SUP_NRS];
-#pragma unroll
-        for (int j = 0; j < SUP_NRU; ++j) {
-            const int i = ptid + SUP_PT * j;
-            const int cb = i / (6 * 4 * SUP_UP_PAIRS), rem = i - cb * (6 * 4 * SUP_UP_PAIRS);
-            const int hd = rem / (4 * SUP_UP_PAIRS), r2 = rem - hd * (4 * SUP_UP_PAIRS), hh = r2 / SUP_UP_PAIRS, pp = r2 - hh * SUP_UP_PAIRS;
-            up_pos[j] = i < SUP_UP_SLOTS ? (cb << 16 | hd << 10 | hh << 5 | pp) : -1;
-            up_lw[j] = cb * SU_UP_CB + hd * SU_UP_PLANE + hh * SU_UP_ROW + 2 * pp;
-        }
-#pragma unroll
-        for (int j = 0; j < SUP_NRS; ++j) {
-            const int i = ptid + SUP_PT * j;
-            const int hd = i / (6 * SUP_SK_PAIRS), rem = i - hd * (6 * SUP_SK_PAIRS), hh = rem / SUP_SK_PAIRS, pp = rem - hh * SUP_SK_PAIRS;
-            sk_pos[j] = i < SUP_SK_SLOTS ? (hd << 10 | hh << 5 | pp) : -1;
-            sk_lw[j] = hd * SU_SK_PLANE + hh * SU_SK_ROW + pp;          // word of hw = 2 pp (parity 0); hw = 2 pp - 1 (parity 1) sits at + SU_SK_HALF - 1
-        }
-        float ra[SUP_NRS][8], rb[SUP_NRS][8];                    // first / second voxel of the pair
-        int voffs[SUP_NRS];
-        // the raw loads of stage k (past the block's last stage: nothing fetched)
-        auto load_stage = [&](int k) __attribute__((always_inline)) {
-            const bool any = k < nstage;
-            const int ti = any ? k / NST : 0, st = k - ti * NST;
-            int bt, d0, h0, w0;
-            tile_geom(t_lo + ti * t_step, bt, d0, h0, w0);
-            const bool up = st < NU;                             // wave-uniform
-            const __amdgpu_buffer_rsrc_t r = up ? vxm_rsrc(x0 + (size_t)bt * bs0, (unsigned)C0 * (unsigned)V0 * 4u)
-                                                : vxm_rsrc(C1 ? x1 + (size_t)bt * bs1 : x0, (unsigned)C1 * (unsigned)V * 4u);
-            const int Vs = up ? V0 : V;
-            const int cbg = up ? st * CBU : (st - NU) >> 1, nblk = up ? Q0 : Q1;
-            const int dh = up ? 0 : 4 * ((st - NU) & 1);         // first haloed plane of a skip stage's depth half
-#pragma unroll
-            for (int j = 0; j < SUP_NRS; ++j) {
-                if (j >= SUP_NRU && up) { voffs[j] = VXM_OOB; continue; }      // (wave-uniform: an upsampled stage has two rounds)
-                const int pos = up ? up_pos[j < SUP_NRU ? j : 0] : sk_pos[j];
-                int cb, gd, gh, gw, De, He, We;
-                if (up) { cb = pos >> 16; gd = (d0 >> 1) - 1 + ((pos >> 10) & 63); gh = (h0 >> 1) - 1 + ((pos >> 5) & 31); gw = (w0 >> 1) - 2 + 2 * (pos & 31); De = Dl; He = Hl; We = Wl; }
-                else { cb = 0; gd = d0 - 1 + dh + (pos >> 10); gh = h0 - 1 + ((pos >> 5) & 31); gw = w0 - 2 + 2 * (pos & 31); De = D; He = H; We = W; }
-                // a pair starts at an even w (tiles start at multiples of 32 / 16, W and W / 2 are even): inside the volume or outside it as a whole
-                const bool ok = any && pos >= 0 && cbg + cb < nblk && (unsigned)gd < (unsigned)De && (unsigned)gh < (unsigned)He && (unsigned)gw < (unsigned)We;
-                voffs[j] = ok ? ((cbg + cb) * 8 * Vs + (gd * He + gh) * We + gw) << 2 : VXM_OOB;
-                if (SU_DBG(dbg, 1)) voffs[j] = VXM_OOB;           // timing experiment: no input reads
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voffs[j], (e * Vs) << 2, 0));
-                    ra[j][e] = t2.x; rb[j][e] = t2.y;
-                }
-            }
-        };
-        auto publish_max = [&](int k) __attribute__((always_inline)) {
-            const bool up = (k % NST) < NU;                      // wave-uniform
-            float m = 0.0f;
-#pragma unroll
-            for (int j = 0; j < SUP_NRS; ++j) {
-                if (j >= SUP_NRU && up) continue;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[j][e]), __builtin_fabsf(rb[j][e])));
-            }
-            m = s3_wave_max(m);
-            if (lane == 0) Tab[(k & 1) * 4 + pwv] = m;
-        };
-        int E_run = 15;
-        // split the raw registers (stage k) into buffer k & 1 with the tile's running scale; table slot k & 3 gets {ratio, 1 / scale}
-        auto store_stage = [&](int k) __attribute__((always_inline)) {
-            if (k >= nstage) return;                             // wave-uniform
-            const int st = k % NST;
-            const bool up = st < NU, first = st == 0;
-            const f32x4 m4 = *reinterpret_cast<const f32x4*>(Tab + (k & 1) * 4);
-            const float mx = fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w));
-            int E = (int)(__float_as_uint(mx) >> 23) & 255;
-            E = E < 15 ? 15 : E;
-            const int E_new = first ? E : (E > E_run ? E : E_run);
-            const int dE = E_new - E_run;                                                          // >= 0 unless `first`
-            const float ratio = (first || dE == 0) ? 1.0f : (dE > 126 ? 0.0f : __uint_as_float((unsigned)(127 - dE) << 23));
-            E_run = E_new;
-            const float sc = __uint_as_float((unsigned)(268 - E_run) << 23);
-            if (ptid == 0) { Tab[8 + 2 * (k & 3)] = ratio; Tab[9 + 2 * (k & 3)] = __uint_as_float((unsigned)(E_run - 14) << 23); }
-            if (SU_DBG(dbg, 4)) return;                          // timing experiment: no split, no LDS writes
-            u32x4* const Xd = smem + (k & 1) * NP * XWORDS;
-#pragma unroll
-            for (int j = 0; j < SUP_NRS; ++j) {
-                if (j >= SUP_NRU && up) continue;
-                unsigned ka[NP][4], kb[NP][4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s3_split2_f16(ra[j][2 * e], ra[j][2 * e + 1], sc, ka[0][e], ka[1][e]);
-                    s3_split2_f16(rb[j][2 * e], rb[j][2 * e + 1], sc, kb[0][e], kb[1][e]);
-                }
-                const int pos = up ? up_pos[j < SUP_NRU ? j : 0] : sk_pos[j];
-                if (pos >= 0) {                                  // (padding voxels are written too: zeros from the out-of-range loads)
-                    const int pp = pos & 31;
-                    if (up) {
-                        const int lw = up_lw[j < SUP_NRU ? j : 0];
-                        if (pp > 0) {
-#pragma unroll
-                            for (int p = 0; p < NP; ++p) Xd[p * XWORDS + lw - 1] = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
-                        }
-                        if (pp < SUP_UP_PAIRS - 1) {
-#pragma unroll
-                            for (int p = 0; p < NP; ++p) Xd[p * XWORDS + lw] = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
-                        }
-                    } else {
-                        const int lw = sk_lw[j];
-                        if (pp > 0) {
-#pragma unroll
-                            for (int p = 0; p < NP; ++p) Xd[p * XWORDS + lw + SU_SK_HALF - 1] = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
-                        }
-                        if (pp < SUP_SK_PAIRS - 1) {
-#pragma unroll
-                            for (int p = 0; p < NP; ++p) Xd[p * XWORDS + lw] = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
-                        }
-                    }
-                }
-            }
-        };
-        auto keep_offsets = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < SUP_NRS; ++j) asm volatile("" ::"v"(voffs[j]));
-        };
-        load_stage(0);
-        publish_max(0);
-        __syncthreads();
-        store_stage(0);
-        load_stage(1);
-        publish_max(1);
-        keep_offsets();
-        __syncthreads();
-        for (int k = 0; k < nstage; ++k) {
-            store_stage(k + 1);
-            load_stage(k + 2);
-            publish_max(k + 2);
-            keep_offsets();
-            __syncthreads();
         }
     }
 }
