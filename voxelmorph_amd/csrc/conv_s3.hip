@@ -1379,11 +1379,15 @@ constexpr int PW_EPI_BYTES = (PW_CONS * 9 + 4) * 256 * 4;
 constexpr int PW_LDS_BYTES = PW_XBYTES + PW_ZBYTES + PW_TAB_BYTES > PW_EPI_BYTES ? PW_XBYTES + PW_ZBYTES + PW_TAB_BYTES : PW_EPI_BYTES;
 static_assert(PW_LDS_BYTES <= 160 * 1024, "k_s3_bww_pc: LDS");
 
-template <bool SWAP>
+// NPT = 1 (a 16 x 16 layer: rem2): ONE plain tile, consumer wave = (row half, depth slice, kd) with two rows each as in k_s3_bwd_weight;
+// producer wave 14 stages the plain tile's depth slice 0, wave 15 its slice 1.
+template <bool SWAP, int NPT = 2>
 __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restrict__ hal, long long hal_bs, int Chal, const float* __restrict__ pla,
                                                           long long pla_bs, int Cpla, float* __restrict__ part, int D, int H, int W, int NBLK,
                                                           int NPL2, SwTasks tk, int task_rr, int hal_blocked, int pla_blocked, int dbg) {
     using P = S3P<2>;
+    static_assert(NPT == 2 || !SWAP, "one plain tile: haloed = x only");
+    constexpr int RW = NPT == 2 ? SW_TH : 2, NHL = RW + 2;      // output rows / haloed rows of a consumer wave
     VXM_DYN_SMEM(char, smem);
     char* const Xs = smem;                                       // [2 pieces][6 ring planes][SW_PLANE]
     char* const Zs = smem + PW_XBYTES;                           // [2 buffers][2 plain tiles][2 pieces][SW_ZPIECE]
@@ -1401,7 +1405,7 @@ __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restric
         bx = xmain + r / NCOMBO;
         combo = r % NCOMBO;
     }
-    const int qh = combo / NPL2, pp2 = combo - qh * NPL2;        // 16-channel chunk of the haloed operand, 32-channel pair of the plain one
+    const int qh = combo / NPL2, pp2 = combo - qh * NPL2;        // 16-channel chunk of the haloed operand, 32-channel pair (NPT = 1: 16-channel tile) of the plain one
     const int ntask = tk.ncol * tk.nseg;
     int k_lo, k_hi, k_step;
     if ((NBLK & 7) == 0 && task_rr) {
@@ -1421,7 +1425,8 @@ __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restric
     };
 
     // ---- consumers: wave cw = (plain tile pt, depth slice ds, kd); the 9 (kh, kw) taps of kd over the four rows of slice ds
-    const int cw = wave, pt = cw / 6, w6 = cw - 6 * pt, ds = w6 / 3, kd = w6 - 3 * ds;
+    const int cw = wave, c6 = cw / 6, w6 = cw - 6 * c6, ds = w6 / 3, kd = w6 - 3 * ds;
+    const int pt = NPT == 2 ? c6 : 0, rb0 = NPT == 2 ? 0 : 2 * c6;      // plain tile / first output row of this wave
     f32x4 tot[3][3], totb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
@@ -1441,14 +1446,14 @@ __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restric
                 const int ring = (2 * t + ds + kd) % SW_RING, zcur = t & 1;
                 const char* const xp = Xs + ring * SW_PLANE;
                 const float unscale_h = Tab[ring], unscale_p = Tab[6 + 4 * zcur + 2 * pt + ds];
-                u32x4 az[SW_TH][2];                              // plain fragments (two pieces) of the four rows
+                u32x4 az[RW][2];                                 // plain fragments (two pieces) of the wave's rows
                 f32x4 accb = zero4;
                 __builtin_amdgcn_s_setprio(2);
 #pragma unroll
-                for (int r = 0; r < SW_TH; ++r) {
+                for (int r = 0; r < RW; ++r) {
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
-                        const int zb = ((zcur * 2 + pt) * 2 + p) * SW_ZPIECE + ((ds * SW_TH + r) * SW_TW) * 32 + lp;
+                        const int zb = ((zcur * NPT + pt) * 2 + p) * SW_ZPIECE + ((ds * SW_TH + rb0 + r) * SW_TW) * 32 + lp;
                         const u32x2 lo = s3_tr_read(Zs, zb), hi = s3_tr_read(Zs, zb + 16 * 32);
                         az[r][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
                     }
@@ -1460,10 +1465,10 @@ __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restric
                 // the B fragment set (haloed row, kw) of step i + 1 is requested before the MFMAs of step i (two sets in registers)
                 u32x4 bq[2][2];
                 auto read_b = [&](auto i_) __attribute__((always_inline)) {
-                    constexpr int i = decltype(i_)::value, kw = i / SW_HR, hl = i - kw * SW_HR;
+                    constexpr int i = decltype(i_)::value, kw = i / NHL, hl = i - kw * NHL;
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
-                        const int xb = p * SW_XPIECE + (hl * SW_XW + kw) * 32 + lp;
+                        const int xb = p * SW_XPIECE + ((rb0 + hl) * SW_XW + kw) * 32 + lp;
                         const u32x2 lo = s3_tr_read(xp, xb), hi = s3_tr_read(xp, xb + 16 * 32);
                         bq[i & 1][p] = (u32x4){lo.x, lo.y, hi.x, hi.y};
                     }
@@ -1471,16 +1476,16 @@ __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restric
                 read_b(std::integral_constant<int, 0>{});
                 f32x4 acc[3];
                 auto step = [&](auto i_) __attribute__((always_inline)) {
-                    constexpr int i = decltype(i_)::value, kw = i / SW_HR, hl = i - kw * SW_HR;       // haloed row hl serves output rows hl - kh
+                    constexpr int i = decltype(i_)::value, kw = i / NHL, hl = i - kw * NHL;       // haloed row rb0 + hl serves output rows rb0 + hl - kh
                     if constexpr (hl == 0 && kw == 1) __builtin_amdgcn_s_setprio(1);
                     if constexpr (hl == 0 && kw == 2) __builtin_amdgcn_s_setprio(0);
-                    if constexpr (i + 1 < 3 * SW_HR) read_b(std::integral_constant<int, i + 1>{});
+                    if constexpr (i + 1 < 3 * NHL) read_b(std::integral_constant<int, i + 1>{});
 #pragma unroll
                     for (int tp = 0; tp < P::NPROD; ++tp)
 #pragma unroll
                         for (int kh = 0; kh < 3; ++kh) {
                             const int rl = hl - kh;
-                            if (rl >= 0 && rl < SW_TH)
+                            if (rl >= 0 && rl < RW)
                                 acc[kh] = P::mfma(az[rl][P::PA[tp]], bq[i & 1][P::PB[tp]], (rl == 0 && tp == 0) ? zero4 : acc[kh]);
                         }
                     if constexpr (SWAP && kw == 1 && hl >= 1 && hl <= SW_TH) {    // bias gradient = sum of the haloed operand (dz) over its interior
@@ -1489,14 +1494,14 @@ __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restric
                             for (int p = 0; p < 2; ++p) accb = P::mfma(ones, bq[i & 1][p], accb);
                         }
                     }
-                    if constexpr (hl == SW_HR - 1) {
+                    if constexpr (hl == NHL - 1) {
 #pragma unroll
                         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) tot[kh][kw][j] = __builtin_fmaf(acc[kh][j] * unscale_h, unscale_p, tot[kh][kw][j]);
                     }
                 };
-                s3_static_for(step, std::make_integer_sequence<int, 3 * SW_HR>{});
+                s3_static_for(step, std::make_integer_sequence<int, 3 * NHL>{});
                 const float ub = SWAP ? unscale_h : unscale_p;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) totb[j] = __builtin_fmaf(accb[j], ub, totb[j]);
@@ -1516,7 +1521,7 @@ __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restric
             constexpr bool HR = decltype(hr_)::value, BLK = decltype(bl_)::value;
             constexpr int lsh = BLK ? 5 : 2;
             constexpr int SW_XPAIRS = SW_XW / 2 + 1, NXS = SW_HR * SW_XPAIRS * 2;      // 18 pairs, 216 slots per plane
-            const int ppt = pw - 2;                                  // plain role: which of the two tiles
+            const int ppt = NPT == 2 ? pw - 2 : 0;                   // plain role: which of the two tiles (NPT = 1: wave pw stages depth slice pw - 2)
             float ra[4][8], rb[4][8];
             int off0[4], ldst[4], vk[4];
             for (int task = k_lo; task < k_hi; task += k_step) {
@@ -1532,9 +1537,9 @@ __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restric
                         off0[rr] = live ? (BLK ? ((qh * 2 + cb) * V + gh * W + gw) << 5 : ((qh * 16 + cb * 8) * V + gh * W + gw) << 2) : VXM_OOB;
                         ldst[rr] = si < NXS ? (((hh * SW_XW + 2 * pp - 1) * 32 + cb * 16) | (pp == 0 ? 1 : 0) | (pp == SW_XPAIRS - 1 ? 2 : 0)) : 3;      // 3: idle lane, neither voxel stored
                     } else {
-                        const int zds = rr >> 1, si = (rr & 1) * 64 + lane, cb = si & 1, r2 = si >> 1, zh = r2 / (SW_TW / 2), zw = 2 * (r2 - zh * (SW_TW / 2));
-                        const int ch = pp2 * 32 + ppt * 16 + cb * 8;
-                        const bool live = h0 + zh < H && w0 + zw < W && ch < Cpla;
+                        const int zds = NPT == 2 ? rr >> 1 : pw - 2, si = (rr & 1) * 64 + lane, cb = si & 1, r2 = si >> 1, zh = r2 / (SW_TW / 2), zw = 2 * (r2 - zh * (SW_TW / 2));
+                        const int ch = pp2 * (16 * NPT) + ppt * 16 + cb * 8;
+                        const bool live = h0 + zh < H && w0 + zw < W && ch < Cpla && (NPT == 2 || rr < 2);
                         off0[rr] = live ? (BLK ? ((ch >> 3) * V + (zds * H + h0 + zh) * W + w0 + zw) << 5 : (ch * V + (zds * H + h0 + zh) * W + w0 + zw) << 2) : VXM_OOB;
                         ldst[rr] = ((zds * SW_TH + zh) * SW_TW + zw) * 32 + cb * 16;
                     }
@@ -1552,7 +1557,7 @@ __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restric
                         vk[rr] = (off0[rr] + o) | f;
                     } else {
                         const int tz = u - 1, gz = dbase + (tz < 0 ? 0 : tz) * SW_TD;    // first depth slice of the plain tile
-                        int f = (tz < 0 || tz >= ntile || gz + (rr >> 1) >= D) ? VXM_OOB : 0;
+                        int f = (tz < 0 || tz >= ntile || gz + (NPT == 2 ? rr >> 1 : pw - 2) >= D) ? VXM_OOB : 0;
                         asm volatile("" : "+v"(f));
                         vk[rr] = off0[rr] | f;
                         sb = (gz * HW) << lsh;
@@ -1642,18 +1647,20 @@ __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restric
                     } else {
                         fin = fin && u >= 1;                     // unit 0 carries no plain tile
                         const int zbuf = (u - 1) & 1;
-                        char* const dst = Zs + ((zbuf * 2 + ppt) * 2) * SW_ZPIECE;
+                        char* const dst = Zs + ((zbuf * NPT + ppt) * 2) * SW_ZPIECE;
                         float sc = 1.0f;
-                        if (fin) sc = unit_scale(I0{}, I2{}, Tab + 6 + 4 * zbuf + 2 * ppt);
+                        if (fin) sc = unit_scale(I0{}, I2{}, Tab + 6 + 4 * zbuf + 2 * ppt + (NPT == 2 ? 0 : pw - 2));
                         if (fin) split_round(I0{}, sc, dst);
                         load_round(I0{}, un);
                         if (fin) split_round(I1{}, sc, dst);
                         load_round(I1{}, un);
-                        if (fin) sc = unit_scale(I2{}, I2{}, Tab + 6 + 4 * zbuf + 2 * ppt + 1);
-                        if (fin) split_round(I2{}, sc, dst);
-                        load_round(I2{}, un);
-                        if (fin) split_round(I3{}, sc, dst);
-                        load_round(I3{}, un);
+                        if constexpr (NPT == 2) {
+                            if (fin) sc = unit_scale(I2{}, I2{}, Tab + 6 + 4 * zbuf + 2 * ppt + 1);
+                            if (fin) split_round(I2{}, sc, dst);
+                            load_round(I2{}, un);
+                            if (fin) split_round(I3{}, sc, dst);
+                            load_round(I3{}, un);
+                        }
                     }
                 };
                 advance(0, false, 0);
@@ -1682,18 +1689,27 @@ __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restric
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Ls[((cw * 9 + kh * 3 + kw) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = tot[kh][kw][r];
         if (SWAP ? (kd == 1 && pt == 0) : (kd == 0)) {
-            const int slot = SWAP ? ds : 2 * pt + ds;
+            const int slot = SWAP ? ds : 2 * c6 + ds;
 #pragma unroll
             for (int r = 0; r < 4; ++r) Ls[((PW_CONS * 9 + slot) * 16 + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = totb[r];
         }
     }
     __syncthreads();
-    const int NPL = 2 * NPL2, QH = NCOMBO / NPL2;
-    float* const po = part + (((size_t)bx * QH + qh) * 28) * (16 * NPL) * 16 + (size_t)(2 * pp2) * 256;
-    for (int e = tid; e < 2 * 28 * 256; e += PW_THREADS) {
+    const int NPL = NPT * NPL2, QH = NCOMBO / NPL2;
+    float* const po = part + (((size_t)bx * QH + qh) * 28) * (16 * NPL) * 16 + (size_t)(NPT * pp2) * 256;
+    for (int e = tid; e < NPT * 28 * 256; e += PW_THREADS) {
         const int pt_ = e / (28 * 256), r_ = e - pt_ * (28 * 256), tap = r_ >> 8, i = r_ & 255;
         float v;
-        if (tap < 27) {
+        if (NPT == 1) {                                      // the four (row half, depth slice) waves of a kd, in slice order 2 ds + rh as k_s3_bwd_weight
+            if (tap < 27) {
+                const int kd_ = tap / 9, t9 = tap - 9 * kd_;
+                const float* const l = Ls + (kd_ * 9 + t9) * 256 + i;
+                v = ((l[0] + l[6 * 9 * 256]) + (l[3 * 9 * 256] + l[9 * 9 * 256]));
+            } else {
+                const float* const l = Ls + PW_CONS * 9 * 256 + i;     // bias slots 2 rh + ds
+                v = ((l[0] + l[512]) + (l[256] + l[768]));
+            }
+        } else if (tap < 27) {
             const int kd_ = tap / 9, t9 = tap - 9 * kd_;
             const float* const l = Ls + ((pt_ * 6 + kd_) * 9 + t9) * 256 + i;
             v = l[0] + l[3 * 9 * 256];
@@ -1732,14 +1748,15 @@ SwTasks sw_tasks(int ncombo, int B, int D, int H, int W, int& NBLK) {
     return tk;
 }
 
-// which launches k_s3_bww_pc takes (fp16 pieces): 1 = haloed x, plain dz (Cout a multiple of 32), 2 = swapped (C a multiple of 32), 0 = none.
+// which launches k_s3_bww_pc takes (fp16 pieces): 1 = haloed x, two plain dz tiles (Cout a multiple of 32), 2 = swapped (C a multiple of 32),
+// 3 = haloed x, one plain dz tile, 0 = none.
 // VXM_S3_BW_PC=0 keeps every launch on k_s3_bwd_weight (same-box A/B).
 int sw_pc_mode(int C, int Cout, int pieces) {
     static const bool on = [] { const char* e = getenv("VXM_S3_BW_PC"); return !(e && e[0] == '0'); }();
     if (!on || pieces != 2 || C % 16 || Cout % 16) return 0;
     if (Cout % 32 == 0) return 1;
     if (C % 32 == 0) return 2;
-    return 0;
+    return 3;                                                    // one plain tile per block (16 x 16, 16 x 48 ...): the producer / consumer structure alone
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------
@@ -1994,7 +2011,7 @@ size_t vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(int C, int Cout, int B, int D
     size_t need = (size_t)NBLK * Q * SW_NSL * 28 * (16 * NCO) * 16 * sizeof(float);
     const int mode = sw_pc_mode(C, Cout, 2);                     // k_s3_bww_pc runs fewer combos, hence more blocks per combo: the larger of the two
     if (mode) {
-        (void)sw_tasks(Q * NCO / 2, B, D, H, W, NBLK);
+        (void)sw_tasks(mode == 3 ? Q * NCO : Q * NCO / 2, B, D, H, W, NBLK);
         const size_t need2 = (size_t)NBLK * Q * 28 * (16 * NCO) * 16 * sizeof(float);
         if (need2 > need) need = need2;
     }
@@ -2018,7 +2035,7 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
     VXM_REQUIRE(Q * NCO <= sw_cus(), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_bwd_weight: %d x %d channel tiles exceed the compute units", Q, NCO);
     const int pc = sw_pc_mode(C, Cout, pieces);                  // 1 / 2: k_s3_bww_pc (two plain tiles per staged haloed chunk), haloed = x / dz
     int NBLK = 1;
-    const SwTasks tk = sw_tasks(pc ? Q * NCO / 2 : Q * NCO, B, D, H, W, NBLK);
+    const SwTasks tk = sw_tasks(pc == 1 || pc == 2 ? Q * NCO / 2 : Q * NCO, B, D, H, W, NBLK);
     VXM_REQUIRE(work_bytes >= (size_t)NBLK * Q * SW_NSL * 28 * (16 * NCO) * 16 * sizeof(float), VXM_ERR_WORKSPACE,
                 "vxm_conv3d_k3_s3_bwd_weight: workspace too small");
     static const bool attr = [] {
@@ -2027,6 +2044,7 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bwd_weight<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SwCfg<2>::LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bww_pc<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bww_pc<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3_bww_pc<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS_BYTES);
         return true;
     }();
     (void)attr;
@@ -2043,6 +2061,9 @@ int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const 
     else if (pc == 2)
         hipLaunchKernelGGL((k_s3_bww_pc<true>), dim3(NBLK * Q * NCO / 2), dim3(PW_THREADS), PW_LDS_BYTES, s, dz, (long long)dz_bstride, Cout, x, (long long)x_bstride,
                            C, part, D, H, W, NBLK, Q / 2, tk, task_rr, lay & VXM_S3_IN1_BLOCKED ? 1 : 0, lay & VXM_S3_IN0_BLOCKED ? 1 : 0, s3_dbg());
+    else if (pc == 3)
+        hipLaunchKernelGGL((k_s3_bww_pc<false, 1>), dim3(NBLK * Q * NCO), dim3(PW_THREADS), PW_LDS_BYTES, s, x, (long long)x_bstride, C, dz, (long long)dz_bstride,
+                           Cout, part, D, H, W, NBLK, NCO, tk, task_rr, lay & VXM_S3_IN0_BLOCKED ? 1 : 0, lay & VXM_S3_IN1_BLOCKED ? 1 : 0, s3_dbg());
     else if (pieces == 2 && pe && pe[0] == '1')
         hipLaunchKernelGGL((k_s3_bwd_weight<2, false>), dim3(NBLK * Q * NCO), dim3(SW_THREADS), SwCfg<2>::LDS_BYTES, s, x, (long long)x_bstride, C, dz,
                            (long long)dz_bstride, Cout, part, D, H, W, NBLK, NCO, tk, task_rr, lay, s3_dbg());
