@@ -265,7 +265,7 @@ def binding_roofline(name, st):
     # split-fp32 kernels (csrc/conv_s3.hip) run on the 16-bit matrix pipe with `nprod` MFMAs per fp32-equivalent MAC block -- six
     # v_mfma_f32_16x16x32_bf16 (three bf16 pieces, region label ends in ",3>" / "<3>") or three v_mfma_f32_16x16x32_f16 (two fp16 pieces,
     # ",2>" / "<2>"): their ceiling in fp32-equivalent FLOPs is the dense 16-bit peak / nprod -- NOT the fp32-MFMA peak, which they exceed
-    nprod = 3.0 if (is_split and (name.rstrip(">").endswith("2") or name.startswith("k_s3u_bww"))) else 6.0
+    nprod = 3.0 if (is_split and (name.rstrip(">").endswith("2") or name.startswith(("k_s3u_bww", "k_s3_bww_pc", "k_s3u_conv_pc")))) else 6.0
     peak = BF16_MFMA_PEAK_TFLOPS if is_bf else (BF16_MFMA_PEAK_TFLOPS / nprod if is_split else FP32_MFMA_PEAK_TFLOPS)
     ach = alg / sec / 1e12
     if hbm is not None and st["bytes"] / (HBM_PEAK_GBS * 1e9) > alg / (peak * 1e12):

@@ -456,6 +456,9 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
  * VXM_S3_IN0_BLOCKED (x) and / or VXM_S3_IN1_BLOCKED (dz). */
 int vxm_conv3d_k3_s3_bwd_weight_ok(int C, int Cout, int B, int D, int H, int W);
 size_t vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(int C, int Cout, int B, int D, int H, int W);
+/* which kernel a launch of this shape runs (profiles, bench regions): 0 = k_s3_bwd_weight<pieces>; round 6, fp16 pieces: 1 = k_s3_bww_pc<false, 2>
+ * (haloed x, two dz tiles per block), 2 = k_s3_bww_pc<true, 2> (haloed dz, two x chunks), 3 = k_s3_bww_pc<false, 1> */
+int vxm_conv3d_k3_s3_bwd_weight_kernel(int C, int Cout, int pieces);
 int vxm_conv3d_k3_s3_bwd_weight(const float* x, int C, int64_t x_bstride, const float* dz, int64_t dz_bstride, int Cout, float* gw,
                                 int gw_cin, int ci_off, float* gb, void* work, size_t work_bytes, int B, int D, int H, int W,
                                 int pieces, void* stream);
@@ -473,6 +476,9 @@ int vxm_conv3d_k3_s3u_pack_weights(const float* w, void* wpacked, int C0, int C1
 int vxm_conv3d_k3_s3u_fwd(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const void* wpacked,
                           const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope, int B, int D, int H, int W, int pieces,
                           void* stream);
+/* 1 when _fwd runs this call on k_s3u_conv_pc (round 6: producer / consumer waves, double-buffered staging tile; fp16 pieces, W % 4 == 0,
+ * even batch strides), 0: k_s3u_conv -- for profiles and bench regions */
+int vxm_conv3d_k3_s3u_fwd_kernel(int64_t x0_bstride, int64_t x1_bstride, int D, int H, int W, int pieces);
 
 /* convolution_backward (input) of the UPSAMPLED segment of such a layer, straight onto the low-resolution tensor it was upsampled from:
  * conv backward + upsample_nearest3d_backward + leaky_relu_backward(mask_src) in one launch on the split arithmetic (csrc/conv_s3u.hip:

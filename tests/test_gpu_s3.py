@@ -524,20 +524,21 @@ def test_s3_backward_weight_in_two_calls_bit_exact(VF16, c, cout, vol, B):
 def test_s3_other_kernel_instances_in_subprocess():
     """The packed layout depends on the kernel instance, which is chosen once per process: 16-channel chunks (VXM_S3_CB=2) and
     32-channel operators as two 16-channel groups (VXM_S3_NCT=1) re-run the direct tests above."""
-    if any(os.environ.get(k) for k in ("VXM_S3_CB", "VXM_S3_NCT", "VXM_S3_PERSIST", "VXM_S3U_PERSIST", "VXM_S3_PC")):
+    if any(os.environ.get(k) for k in ("VXM_S3_CB", "VXM_S3_NCT", "VXM_S3_PERSIST", "VXM_S3U_PERSIST", "VXM_S3_PC", "VXM_S3_BW_PC", "VXM_S3U_PC")):
         pytest.skip("already inside a variant run")
     _rerun({"VXM_S3_CB": "2"}, "forward_vs_fp64 or fused_mask or scale_invariance")
     _rerun({"VXM_S3_NCT": "1"}, "forward_vs_fp64 or fused_mask")
-    # 16 blocks in all: every block walks several tiles of its XCD's range (the default grid only does so on volumes with > 2048 tiles)
-    _rerun({"VXM_S3_PERSIST": "-16"}, "forward_vs_fp64 or fused_mask or many_tiles")
-    _rerun({"VXM_S3_PERSIST": "0"}, "many_tiles")
+    # 16 blocks in all: every block walks several tiles of its XCD's range (the default grid only does so on volumes with > 2048 tiles);
+    # the same for the collapsed kernels (k_s3u_conv_pc / k_s3u_dlow)
+    _rerun({"VXM_S3_PERSIST": "-16", "VXM_S3U_PERSIST": "-16"}, "forward_vs_fp64 or fused_mask or many_tiles or s3u_collapsed")
+    _rerun({"VXM_S3_PERSIST": "0", "VXM_S3U_PERSIST": "0"}, "many_tiles")
     # the producer / consumer kernel (k_s3p_conv: by default from 2048 tiles of 8 x 8 x 16 up) on every eligible launch, with one block per
     # tile and with 16 blocks in all (every block streams several tiles through its two LDS buffers); and the alternating kernel everywhere
     _rerun({"VXM_S3_PC": "1"}, "forward_vs_fp64 or fused_mask or scale_invariance or dynamic_range or many_tiles or s3_conv_channel_blocked")
     _rerun({"VXM_S3_PC": "1", "VXM_S3P_BLOCKS": "16"}, "forward_vs_fp64 or fused_mask or dynamic_range or many_tiles")
-    _rerun({"VXM_S3_PC": "0"}, "many_tiles")
-    _rerun({"VXM_S3U_PERSIST": "-16"}, "s3u_collapsed")
-    _rerun({"VXM_S3U_PERSIST": "0"}, "s3u_collapsed_forward_many_tiles")
+    # the kernels the producer / consumer ones of round 6 replaced by default stay reachable (other piece scheme, odd extents, A/B):
+    # k_s3_bwd_weight<2> for k_s3_bww_pc, k_s3u_conv<., 2> for k_s3u_conv_pc, k_s3_conv for k_s3p_conv
+    _rerun({"VXM_S3_PC": "0", "VXM_S3_BW_PC": "0", "VXM_S3U_PC": "0"}, "many_tiles or backward_weight or s3u_collapsed or s3u_kernels")
 
 
 def test_s3_through_the_dispatcher_on_small_volumes_in_subprocess():

@@ -120,6 +120,7 @@ SIGNATURES = {
     "vxm_conv3d_k3_s3_fwd": [_P, _I, _L, _I, _P, _I, _L, _P, _P, _P, _L, _I, _F, _P, _L, _F, _I, _I, _I, _I, _I, _P],
     "vxm_conv3d_k3_s3_bwd_weight_ok": [_I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3_bwd_weight_workspace_bytes": [_I, _I, _I, _I, _I, _I],
+    "vxm_conv3d_k3_s3_bwd_weight_kernel": [_I, _I, _I],
     "vxm_conv3d_k3_s3_bwd_weight": [_P, _I, _L, _P, _L, _I, _P, _I, _I, _P, _P, _S, _I, _I, _I, _I, _I, _P],
     "vxm_ncc_win_elems": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "vxm_ncc_win_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -128,6 +129,7 @@ SIGNATURES = {
     "vxm_conv3d_k3_s3u_packed_bytes": [_I, _I, _I, _I],
     "vxm_conv3d_k3_s3u_pack_weights": [_P, _P, _I, _I, _I, _I, _P],
     "vxm_conv3d_k3_s3u_fwd": [_P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _I, _F, _I, _I, _I, _I, _I, _P],
+    "vxm_conv3d_k3_s3u_fwd_kernel": [_L, _L, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3u_bwd_low_ok": [_I, _I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3u_bwd_low_packed_bytes": [_I, _I, _I],
     "vxm_conv3d_k3_s3u_bwd_low_pack_weights": [_P, _P, _I, _I, _I, _I, _P],

@@ -2003,6 +2003,10 @@ int vxm_conv3d_k3_s3_bwd_weight_ok(int C, int Cout, int B, int D, int H, int W) 
     return ntiles >= s3_min_tiles() ? 1 : 0;
 }
 
+/* which kernel vxm_conv3d_k3_s3_bwd_weight launches for this shape (for profiles and bench regions): 0 = k_s3_bwd_weight<pieces>,
+ * 1 = k_s3_bww_pc<false, 2>, 2 = k_s3_bww_pc<true, 2>, 3 = k_s3_bww_pc<false, 1> */
+int vxm_conv3d_k3_s3_bwd_weight_kernel(int C, int Cout, int pieces) { return sw_pc_mode(C, Cout, pieces & 0xff); }
+
 size_t vxm_conv3d_k3_s3_bwd_weight_workspace_bytes(int C, int Cout, int B, int D, int H, int W) {
     if (C <= 0 || Cout <= 0 || B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     const int Q = (C + 15) / 16, NCO = (Cout + 15) / 16;

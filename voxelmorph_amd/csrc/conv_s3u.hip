@@ -1532,6 +1532,13 @@ int su_dbg() {
 #endif
 }
 
+// does k_s3u_conv_pc take this launch (fp16 pieces)?  Its staging loads W pairs of both resolutions: W and W / 2 even, even strides.
+// VXM_S3U_PC=0: k_s3u_conv everywhere (same-box A/B)
+bool su_pc_ok(long long bs0, long long bs1, int D, int H, int W) {
+    static const bool pc_on = [] { const char* e = getenv("VXM_S3U_PC"); return !(e && e[0] == '0'); }();
+    return pc_on && W % 4 == 0 && (bs0 & 1) == 0 && (bs1 & 1) == 0 && ((D / 2) * (H / 2) * (W / 2)) % 2 == 0;
+}
+
 template <int NCT, int NP>
 void su_launch(const float* x0, long long bs0, int C0, const float* x1, long long bs1, int C1, const void* wp, const float* bias, float* y,
                long long y_bs, int Cout, float slope, int B, int D, int H, int W, hipStream_t s, int lay) {
@@ -1552,9 +1559,8 @@ void su_launch(const float* x0, long long bs0, int C0, const float* x1, long lon
         if (cap < gx) gx = cap;
     }
     // fp16 pieces, W and W / 2 even (the staging loads W pairs of both resolutions): the producer / consumer kernel.  VXM_S3U_PC=0: k_s3u_conv (A/B)
-    static const bool pc_on = [] { const char* e = getenv("VXM_S3U_PC"); return !(e && e[0] == '0'); }();
     if constexpr (NP == 2) {
-        if (pc_on && W % 4 == 0 && (bs0 & 1) == 0 && (bs1 & 1) == 0 && ((D / 2) * (H / 2) * (W / 2)) % 2 == 0) {
+        if (su_pc_ok(bs0, bs1, D, H, W)) {
             static const bool attr2 = [] {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3u_conv_pc<NCT>), hipFuncAttributeMaxDynamicSharedMemorySize, SUP_LDS_BYTES);
                 return true;
@@ -1629,6 +1635,11 @@ int vxm_conv3d_k3_s3u_ok(int C0, int C1, int Cout, int B, int D, int H, int W, i
 size_t vxm_conv3d_k3_s3u_packed_bytes(int C0, int C1, int Cout, int pieces) {
     if (C0 <= 0 || C1 < 0 || Cout <= 0 || C0 % 8 || C1 % 8 || (pieces != 2 && pieces != 3)) return 0;
     return (su_words(C0, C1, Cout, pieces) + 1) * 16;
+}
+
+/* 1 when vxm_conv3d_k3_s3u_fwd launches the producer / consumer kernel k_s3u_conv_pc for this call (for profiles and bench regions), else 0 (k_s3u_conv) */
+int vxm_conv3d_k3_s3u_fwd_kernel(int64_t x0_bstride, int64_t x1_bstride, int D, int H, int W, int pieces) {
+    return ((pieces & 0xff) == 2 && su_pc_ok(x0_bstride, x1_bstride, D, H, W)) ? 1 : 0;
 }
 
 int vxm_conv3d_k3_s3u_pack_weights(const float* w, void* wpacked, int C0, int C1, int Cout, int pieces, void* stream) {

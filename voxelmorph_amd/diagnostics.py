@@ -10,7 +10,7 @@ fused U-Net and returns, per tensor, the share of its non-zero values in that re
 bench workload; the worst tensor is a coarse-level gradient), 0.48 on the real scan with 0.1 % of its voxels multiplied by 2^12 .. 2^20.
 On that heavy-tailed step the three engines were compared against the fp64-NCC arbiter at full size
 (tests/test_gpu_parity.py::test_full_size_step_with_heavy_tailed_activations_on_all_three_engines): worst parameter gradient 8.9e-2 on the
-fp16 pieces, 1.3e-2 on three bf16 pieces, 9.7e-3 on the exact fp32 MFMA (round 6; the reference-order fp32 oracle itself: 8.1e-3) -- on
+fp16 pieces, 1.3e-2 on three bf16 pieces, 9.7e-3 on the exact fp32 MFMA (round 6; a reference-order fp32 evaluation on the host: 8.1e-3) -- on
 such a batch the fp16 pieces cost about one digit.  The guard -- `guard_engine`, which `GraphedStep` runs on its first eager step (default ON
 since round 6; `VXM_RANGE_GUARD=0` / `range_guard=False` switch it off) -- moves the process to the three-piece engine (fp32's exponent
 range, 25 % slower) when more than `share_limit` of a tensor is in the absolute-error regime: a one-off cost of one probe launch per

@@ -607,8 +607,11 @@ def s3u_pack(w, c0, c1):
 
 
 def s3u_launch(x0, c0, bs0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, B, D, H, W, lay=0):
-    with _prof.region("k_s3u_conv<%d,%d>" % (1 if cout <= 16 else 2, s3_pieces()), flops=2.0 * (8 * c0 + 27 * c1) * cout * B * D * H * W,
-                      nominal=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
+    name = None
+    if _prof.ACTIVE is not None:
+        pc = _lib.lib().vxm_conv3d_k3_s3u_fwd_kernel(bs0, bs1, D, H, W, s3_pieces())
+        name = ("k_s3u_conv_pc<%d>" % (1 if cout <= 16 else 2)) if pc else "k_s3u_conv<%d,%d>" % (1 if cout <= 16 else 2, s3_pieces())
+    with _prof.region(name, flops=2.0 * (8 * c0 + 27 * c1) * cout * B * D * H * W, nominal=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_conv3d_k3_s3u_fwd", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W,
              s3_pieces() | lay, stream())
 
@@ -778,7 +781,11 @@ def s3_bwd_weight(ws, x, c, bs, dz, cout, gw, gw_cin, ci_off, gb, B, D, H, W, la
     buf = ws.get(need)
     args = (ptr(x), c, bs, ptr(dz), cout * D * H * W, cout, ptr(gw), gw_cin, ci_off, ptr(gb), ptr(buf), buf.numel(), B, D, H, W)
     flags = s3_pieces() | lay
-    with _prof.region("k_s3_bwd_weight<%d>" % s3_pieces(), flops=2.0 * 27 * c * cout * B * D * H * W):
+    name = None
+    if _prof.ACTIVE is not None:               # the region carries the name of the kernel the library launches for this shape (profiles/*_counters.json are keyed by it)
+        kern = _lib.lib().vxm_conv3d_k3_s3_bwd_weight_kernel(c, cout, s3_pieces())
+        name = {0: "k_s3_bwd_weight<%d>" % s3_pieces(), 1: "k_s3_bww_pc<false,2>", 2: "k_s3_bww_pc<true,2>", 3: "k_s3_bww_pc<false,1>"}[kern]
+    with _prof.region(name, flops=2.0 * 27 * c * cout * B * D * H * W):
         call("vxm_conv3d_k3_s3_bwd_weight", *args, flags | (S3_BW_CONTRACT_ONLY if ws.deferred is not None else 0), stream())
     if ws.deferred is not None:
         ws.deferred.append(("vxm_conv3d_k3_s3_bwd_weight", args, flags | S3_BW_REDUCE_ONLY, (x, dz, gw, gb, buf)))
