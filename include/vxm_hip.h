@@ -480,6 +480,18 @@ int vxm_conv3d_k3_s3u_fwd(const float* x0, int C0, int64_t x0_bstride, const flo
  * even batch strides), 0: k_s3u_conv -- for profiles and bench regions */
 int vxm_conv3d_k3_s3u_fwd_kernel(int64_t x0_bstride, int64_t x1_bstride, int D, int H, int W, int pieces);
 
+/* BOTH backward-data products of such a layer from one staging of dz (round 6, csrc/conv_s3u.hip k_s3u_bwd_pc; fp16 pieces): gxl as
+ * vxm_conv3d_k3_s3u_bwd_low below (operator `wlow` from vxm_conv3d_k3_s3u_bwd_low_pack_weights), and gx1 [B,C1,D,H,W] = convolution_backward
+ * (input) restricted to the skip channels [C0, C0 + C1) of the weights (operator `wskip` from _bwd_skip_pack_weights; no mask: the skip tensor's
+ * LeakyReLU' is applied where its gradients are summed).  C0, C1 <= 32, multiples of 8; W a multiple of 4; `pieces` may carry VXM_S3_IN0_BLOCKED (dz).
+ * _ok returns 0 unless VXM_S3U_BWD_PC=1: measured, the one launch is not faster than the two it replaces (callers keep those; csrc/conv_s3u.hip says why). */
+int vxm_conv3d_k3_s3u_bwd_data_ok(int C0, int C1, int Cout, int B, int D, int H, int W, int pieces);
+size_t vxm_conv3d_k3_s3u_bwd_skip_packed_bytes(int C1, int Cout, int pieces);
+int vxm_conv3d_k3_s3u_bwd_skip_pack_weights(const float* w, void* wpacked, int C0, int C1, int Cout, int pieces, void* stream);
+int vxm_conv3d_k3_s3u_bwd_data(const float* dz, int64_t dz_bstride, int Cout, const void* wlow, float* gxl, int64_t gxl_bstride, int C0, const float* mask,
+                               int64_t mask_bstride, float mask_slope, const void* wskip, float* gx1, int64_t gx1_bstride, int C1, int B, int D, int H, int W,
+                               int pieces, void* stream);
+
 /* convolution_backward (input) of the UPSAMPLED segment of such a layer, straight onto the low-resolution tensor it was upsampled from:
  * conv backward + upsample_nearest3d_backward + leaky_relu_backward(mask_src) in one launch on the split arithmetic (csrc/conv_s3u.hip:
  * a stride-2, 4x4x4-tap convolution of the full-resolution dz [B,Cout,D,H,W] with the transposed collapsed weights; the full-resolution

@@ -203,6 +203,46 @@ def test_s3u_backward_data_onto_the_low_resolution_tensor_vs_fp64(VF, c0, c1, co
     del gxl, big
 
 
+@pytest.mark.parametrize("c0,c1,cout,vol,B", [(32, 16, 32, (16, 8, 64), 2), (32, 32, 32, (8, 12, 36), 1), (16, 8, 24, (10, 6, 40), 2), (8, 16, 16, (4, 4, 32), 1),
+                                              (32, 16, 32, (24, 20, 72), 1)])
+def test_s3u_both_backward_data_products_from_one_staging_vs_fp64(VF, c0, c1, cout, vol, B):
+    """k_s3u_bwd_pc (round 6): the gradient of the low-resolution x0 (with LeakyReLU' of its activation) AND of the skip tensor x1 of
+    cat([upsample(x0), x1]) -> Conv3d from one staging of dz, against fp64 autograd of the reference's op sequence (networks.py:133-138, 299-305);
+    planar and channel-blocked dz give the same bits; partial tiles in every direction; several tiles per block in the subprocess re-run
+    (VXM_S3U_PERSIST=-16).  fp16 scheme only.  The fused step does not route to this kernel by default (measured: no faster than the two launches
+    it replaces, csrc/conv_s3u.hip vxm_conv3d_k3_s3u_bwd_data_ok); the entry point is called directly here."""
+    from voxelmorph_amd import _lib
+    D, H, W = vol
+    V = D * H * W
+    assert _lib.lib().vxm_conv3d_k3_s3u_bwd_data_ok(c0, c1, cout, B, 64, 64, 64, 3) == 0
+    if VF.FP32_ENGINE != "f16x2":
+        pytest.skip("k_s3u_bwd_pc runs the fp16 scheme")
+    torch.manual_seed(4100 + c0 + c1 + cout)
+    lo = tuple(s // 2 for s in vol)
+    w = torch.randn(cout, c0 + c1, 3, 3, 3, device="cuda") / (27 * (c0 + c1)) ** 0.5
+    dz = torch.randn(B, cout, *vol, device="cuda")
+    dz[:, : max(8, cout // 2)] *= 2.0 ** 9                             # chunks of very different magnitude: the running scale moves between stages
+    act = torch.randn(B, c0, *lo, device="cuda")
+    gxl, gx1 = torch.full((B, c0) + lo, 7.25, device="cuda"), torch.full((B, c1) + tuple(vol), 7.25, device="cuda")
+    VF.s3u_bwd_data(dz, cout, w, c0, c1, gxl, act, 0.2, gx1, B, D, H, W)
+    xl = torch.zeros(B, c0, *lo, dtype=torch.float64, requires_grad=True)
+    xs = torch.zeros(B, c1, *vol, dtype=torch.float64, requires_grad=True)
+    xin = torch.cat([torch.nn.functional.interpolate(xl, scale_factor=2, mode="nearest"), xs], 1)
+    torch.nn.functional.conv3d(xin, w.cpu().double(), None, padding=1).backward(dz.cpu().double())
+    want_l = xl.grad * torch.where(act.cpu().double() > 0, 1.0, 0.2)
+    e_l, e_s = rel_l2(gxl.cpu().numpy(), want_l.numpy()), rel_l2(gx1.cpu().numpy(), xs.grad.numpy())
+    print("s3u backward-data, both products [%s] (%d^+%d <- %d, %s, B=%d): rel-L2 vs fp64 low %.2e skip %.2e"
+          % (VF.FP32_ENGINE, c0, c1, cout, "x".join(map(str, vol)), B, e_l, e_s))
+    assert e_l <= 1e-6 and e_s <= 1e-6, (e_l, e_s)
+    for lay, dzz in ((0, dz), (VF.S3_IN0_BLOCKED, VF.to_blocked(dz))):
+        g2, s2 = torch.full_like(gxl, float("nan")), torch.full_like(gx1, float("nan"))
+        VF.s3u_bwd_data(dzz, cout, w, c0, c1, g2, act, 0.2, s2, B, D, H, W, lay=lay)
+        assert torch.equal(g2, gxl) and torch.equal(s2, gx1), hex(lay)
+    g3, s3 = torch.empty_like(gxl), torch.empty_like(gx1)              # no mask: LeakyReLU slope 1 of the producer
+    VF.s3u_bwd_data(dz, cout, w, c0, c1, g3, None, 1.0, s3, B, D, H, W)
+    assert rel_l2(g3.cpu().numpy(), xl.grad.numpy()) <= 1e-6 and torch.equal(s3, gx1)
+
+
 @pytest.mark.parametrize("c0,cout,vol,B", [(32, 32, (8, 8, 64), 2), (16, 16, (6, 12, 36), 1), (32, 16, (10, 4, 32), 2), (16, 48, (4, 6, 68), 1)])
 def test_s3u_backward_weight_of_the_upsampled_segment_vs_fp64(VF, c0, cout, vol, B):
     """k_s3u_bww: weight gradient of the x2-upsampled segment (64 offset contractions on the low-resolution grid, mapped onto the 27 taps)
@@ -530,7 +570,7 @@ def test_s3_other_kernel_instances_in_subprocess():
     _rerun({"VXM_S3_NCT": "1"}, "forward_vs_fp64 or fused_mask")
     # 16 blocks in all: every block walks several tiles of its XCD's range (the default grid only does so on volumes with > 2048 tiles);
     # the same for the collapsed kernels (k_s3u_conv_pc / k_s3u_dlow)
-    _rerun({"VXM_S3_PERSIST": "-16", "VXM_S3U_PERSIST": "-16"}, "forward_vs_fp64 or fused_mask or many_tiles or s3u_collapsed")
+    _rerun({"VXM_S3_PERSIST": "-16", "VXM_S3U_PERSIST": "-16"}, "forward_vs_fp64 or fused_mask or many_tiles or s3u_collapsed or both_backward_data")
     _rerun({"VXM_S3_PERSIST": "0", "VXM_S3U_PERSIST": "0"}, "many_tiles")
     # the producer / consumer kernel (k_s3p_conv: by default from 2048 tiles of 8 x 8 x 16 up) on every eligible launch, with one block per
     # tile and with 16 blocks in all (every block streams several tiles through its two LDS buffers); and the alternating kernel everywhere

@@ -180,6 +180,30 @@ def main():
         rows.append(dict(op=name, gflop_executed=gf, s3_ms=t_s3, s3_tflops=gf / t_s3, native_ms=t_nat, native_tflops=gf / t_nat, rel_l2_s3_vs_native=diff))
         print("%-34s %7.1f GFLOP executed | split %.3f ms = %6.1f TF-eq | fp32-MFMA %.3f ms = %6.1f TF | x%.2f | rel-L2 %.2e"
               % (name, gf, t_s3, gf / t_s3, t_nat, gf / t_nat, t_nat / t_s3, diff), flush=True)
+        # round 6: both backward-data products from one staging (k_s3u_bwd_pc) against the two separate launches, dz channel-blocked as in the step
+        if os.environ.get("VXM_S3U_BWD_PC") == "1" and VF.s3u_bwd_data_route(c0, c1, cout, B, D, H, W):
+            dzb = VF.to_blocked(dz)
+            gxs, gxs2, g2 = torch.empty(B, c1, D, H, W, device="cuda"), torch.empty(B, c1, D, H, W, device="cuda"), torch.empty_like(act)
+
+            def run_two():
+                VF.s3u_bwd_low(dzb, cout, w, c0, c0 + c1, g_s3, act, 0.2, B, D, H, W, lay=VF.S3_IN0_BLOCKED)
+                VF.conv_bwd_data(dzb, cout, w, gxs, c1, None, 1.0, B, D, H, W, w_lo=c0, lay=VF.S3_IN0_BLOCKED)
+
+            def run_one():
+                VF.s3u_bwd_data(dzb, cout, w, c0, c1, g2, act, 0.2, gxs2, B, D, H, W, lay=VF.S3_IN0_BLOCKED)
+            t2, t1 = timed(run_two, args.iters), timed(run_one, args.iters)
+            t2b, t1b = timed(run_two, args.iters), timed(run_one, args.iters)
+            if args.dbg:
+                res = {}
+                for v in [0] + [int(v) for v in args.dbg.split(",")]:
+                    os.environ["VXM_S3_DBG"] = str(v)
+                    res[v] = timed(run_one, args.iters)
+                os.environ["VXM_S3_DBG"] = "0"
+                print("    dbg k_s3u_bwd_pc: " + " | ".join("%d: %.3f" % kv for kv in res.items()), flush=True)
+            print("    %-30s low + skip in two launches %.3f / %.3f ms | k_s3u_bwd_pc %.3f / %.3f ms | rel-L2 low %.2e skip %.2e"
+                  % (name.split(" dlow")[0] + " bwd-data", t2, t2b, t1, t1b, float((g2.double() - g_s3.double()).norm() / g_s3.double().norm()),
+                     float((gxs2.double() - gxs.double()).norm() / gxs.double().norm())), flush=True)
+            del dzb, gxs, gxs2, g2
         del dz, act, g_s3, g_nat
     # weight gradient of the upsampled segment: k_s3u_bww against k_conv3d_k3_bwd_weight_up
     for name, c0, c1, cout, lvl in (("rem0 bww-up 32^ x 32 s3u", 32, 16, 32, 0), ("dec3 bww-up 32^ x 32 s3u (L1)", 32, 32, 32, 1)):

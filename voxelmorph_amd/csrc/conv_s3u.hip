@@ -812,12 +812,419 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_s3u_bwd_pc (round 6): BOTH backward-data products of a cat([upsample(x0), x1]) layer from ONE staging of dz.
+// k_s3u_dlow (gradient of the low-resolution x0, 0.59 ms at rem0) and the adjoint onto the skip tensor (k_s3p_conv, 0.60 ms) each staged the
+// same 0.88 GB dz -- haloed, 1.75 + 1.55 GB through the vector L1, which is what bounds both (section 4.6 of DESIGN.md).  Here a stage is one
+// 8-channel chunk of dz over a 4 x 4 x 32 tile (6 x 6 x 34 haloed, the W-parity de-interleaved layout of the forward kernel's skip chunk),
+// fetched and split by four producer waves into a double-buffered tile; the eight consumer waves multiply it twice:
+//   * wave = (a_h, low-res depth) for the stride-2 4 x 4 x 4 adjoint onto x0 (the arithmetic of k_s3u_dlow: four K-steps a_w, lane group
+//     = a_d, two low-res rows per wave; the four a_h partial sums of a row meet in LDS at the end of the tile, fixed order);
+//   * wave = parity class for the 27-tap adjoint onto the skip tensor (the arithmetic of the forward kernel's skip segment with the
+//     mirrored, transposed operator: SuPack kind 2), four rows per wave.
+// 32 accumulator registers in all; the weights of a K-step come from the two packed operators in L2, one K-step ahead.  One barrier per
+// stage (protocol of k_s3u_conv_pc) plus one per tile for the a_h exchange.  fp16 pieces, C0 <= 32, C1 <= 32.
+constexpr int SBP_PLANES = 6, SBP_XWORDS = SBP_PLANES * SU_SK_PLANE;                              // 1440 words per piece and buffer
+constexpr int SBP_VSLOTS = SBP_PLANES * 6 * 34, SBP_PSLOTS = SBP_PLANES * 6 * 18;                 // voxel slots (blocked dz) / W-pair slots (planar dz)
+constexpr int SBP_NRV = (SBP_VSLOTS + SUP_PT - 1) / SUP_PT, SBP_NRP = (SBP_PSLOTS + SUP_PT - 1) / SUP_PT;      // rounds: 5 / 3
+constexpr int SBP_RS_WORDS = 4 * 4 * 2 * 64;                                                      // a_h exchange: [a_h 4][row 4][ct 2][lane] 16-byte words
+constexpr int SBP_LDS_BYTES = 2 * 2 * SBP_XWORDS * 16 + SBP_RS_WORDS * 16 + 256 + SUP_CONS * 7 * 4 * 4;
+static_assert(SBP_LDS_BYTES <= 160 * 1024, "k_s3u_bwd_pc: LDS");
+
+template <int NCTL, int NCTS, bool BLK>
+__global__ void __launch_bounds__(SUP_THREADS)
+k_s3u_bwd_pc(const float* __restrict__ dz, long long dz_bs, int Cout, const u32x4* __restrict__ wlow, float* __restrict__ gxl, long long gxl_bs, int C0,
+             const float* __restrict__ mask, long long mask_bs, float mask_slope, const u32x4* __restrict__ wskip, float* __restrict__ gx1,
+             long long gx1_bs, int C1, int B, int D, int H, int W, int dbg) {
+    constexpr int NP = 2;
+    using P = S3P<NP>;
+    VXM_DYN_SMEM(u32x4, smem);
+    constexpr int XWORDS = SBP_XWORDS;
+    constexpr int WCH = 16 * NP * NCTL * 64, WSK = 7 * NP * NCTS * 64;       // words of one dz chunk in the two operators
+    f32x4* const Rs = reinterpret_cast<f32x4*>(smem + 2 * NP * XWORDS);
+    float* const Tab = reinterpret_cast<float*>(Rs + SBP_RS_WORDS);          // [0..7] wave maxima (two stage slots), [8 + 2 (k & 3)] ratio, [9 + ..] inverse scale
+    int* const Skb = reinterpret_cast<int*>(Tab + 64);                        // [wave 8][step 7][kg 4]: B-fragment bases of the skip adjoint
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1, V = D * H * W, Vl = Dl * Hl * Wl;
+    const int nw = (W + 31) / 32, nh = (H + 3) / 4, nd = (D + 3) / 4;
+    const int ntiles = B * nd * nh * nw;
+    int t_lo, t_hi, t_step;
+    if (ntiles >= 64) {
+        const int x = blockIdx.x & 7;
+        t_lo = (int)((long long)ntiles * x / 8) + (int)(blockIdx.x >> 3); t_hi = (int)((long long)ntiles * (x + 1) / 8); t_step = (int)(gridDim.x >> 3);
+    } else {
+        t_lo = blockIdx.x; t_hi = ntiles; t_step = gridDim.x;
+    }
+    const int Q = (Cout + 7) >> 3;                               // stages of a tile = 8-channel chunks of dz
+    const int my_tiles = t_lo < t_hi ? (t_hi - t_lo + t_step - 1) / t_step : 0;
+    const int nstage = my_tiles * Q;
+    auto tile_geom = [&](int tile, int& bt, int& d0, int& h0, int& w0) __attribute__((always_inline)) {
+        const int tw = tile % nw; int tq = tile / nw;
+        const int th = tq % nh; tq /= nh;
+        const int td = tq % nd;
+        bt = tq / nd; d0 = td * 4; h0 = th * 4; w0 = tw * 32;
+    };
+
+    if (wave < SUP_CONS) {
+        // ================================================================ consumers
+        const int kg_ = lane >> 4, n_ = lane & 15;
+        const int kq = wave & 3, rp = wave >> 2;                 // low-resolution adjoint: this wave's a_h index and low-res depth (rows 2 rp, 2 rp + 1)
+        const int pd = wave >> 2, ph = (wave >> 1) & 1, pw = wave & 1;       // skip adjoint: this wave's parity class
+        // lane group kg = a_d index reads haloed voxel (2 rp + kg, 2 lh + kq, 2 n + a_w) in K-step a_w
+        int xb[4];
+#pragma unroll
+        for (int aw = 0; aw < 4; ++aw) xb[aw] = (2 * rp + kg_) * SU_SK_PLANE + kq * SU_SK_ROW + (aw & 1) * SU_SK_HALF + (aw >> 1) + n_;
+        if (lane < 28) {                                         // (s, kg) -> base of the unit lane group kg multiplies in skip K-step s, without n
+            const int s = lane >> 2, kg = lane & 3;
+            int base = 0;
+#pragma unroll
+            for (int ss = 0; ss < 7; ++ss)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const SuUnit u = su_skip_unit(ss, kk);
+                    const int hw = pw + u.kw;
+                    if (ss == s && kk == kg) base = (pd + u.kd) * SU_SK_PLANE + (ph + u.kh) * SU_SK_ROW + (hw & 1) * SU_SK_HALF + (hw >> 1);
+                }
+            Skb[wave * 28 + lane] = base;
+        }
+        const int* const skb = Skb + wave * 28 + kg_;
+        const __amdgpu_buffer_rsrc_t rwl = vxm_rsrc(reinterpret_cast<const float*>(wlow), (unsigned)((size_t)Q * WCH * 16));
+        const __amdgpu_buffer_rsrc_t rws = vxm_rsrc(reinterpret_cast<const float*>(wskip), (unsigned)((size_t)Q * WSK * 16));
+        const int lane16 = lane * 16;
+        const float inv_wl = __uint_as_float(__builtin_amdgcn_readfirstlane((int)wlow[(size_t)Q * WCH].x));
+        const float inv_ws = __uint_as_float(__builtin_amdgcn_readfirstlane((int)wskip[(size_t)Q * WSK].x));
+        __syncthreads();                                        // (start-up: the maxima of stage 0 are published)
+        __syncthreads();                                        // stage 0 is in buffer 0
+        int k = 0;
+        constexpr int RS = NCTS == 1 ? 3 : 2;                   // ring depth of the skip adjoint's weight K-steps
+        u32x4 al[4][NP][NCTL], as[RS][NP][NCTS];
+        {                                                       // chunk 0's four K-steps of the low-resolution adjoint
+            const int wo = (kq * 4 * NP * NCTL * 64) * 16;
+#pragma unroll
+            for (int aw = 0; aw < 4; ++aw)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int ct = 0; ct < NCTL; ++ct)
+                        al[aw][p][ct] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rwl, lane16, wo + ((aw * NP + p) * NCTL + ct) * 1024, 0));
+        }
+        for (int tile = t_lo; tile < t_hi; tile += t_step) {
+            f32x4 accl[2][NCTL], accs[4][NCTS];                 // low-res rows (rp, lh) / skip rows rl = 2 ld + lh of this class
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int ct = 0; ct < NCTL; ++ct) accl[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ct = 0; ct < NCTS; ++ct) accs[r][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float inv_fin = 1.0f;
+            for (int q = 0; q < Q; ++q, ++k) {
+                const u32x4* const Xs = smem + (k & 1) * NP * XWORDS;
+                const float rt = q > 0 ? Tab[8 + 2 * (k & 3)] : 1.0f;       // < 1: this stage raised the tile's running maximum
+                inv_fin = Tab[9 + 2 * (k & 3)];
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < NCTL; ++ct) accl[r][ct] *= rt;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < NCTS; ++ct) accs[r][ct] *= rt;
+                // The weights of a K-step come from L2 (~600 cycles) and a K-step is 12 MFMAs of a wave (~200 cycles): one K-step ahead leaves the
+                // latency open (first version: 0.91 ms with the dz loads compiled out, for 0.42 ms of MFMAs).  So: the four K-steps of the
+                // low-resolution adjoint are requested a whole stage ahead (behind the previous stage's use of the same registers), the skip
+                // adjoint's run RS K-steps ahead in a ring, its first RS requested at the top of the stage.
+                const int wos = q * WSK * 16;
+#pragma unroll
+                for (int s = 0; s < RS; ++s)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+#pragma unroll
+                        for (int ct = 0; ct < NCTS; ++ct)
+                            as[s][p][ct] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, wos + ((s * NP + p) * NCTS + ct) * 1024, 0));
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- adjoint onto the low-resolution tensor: K-steps a_w = 0 .. 3 of this wave's a_h
+                if (!SU_DBG(dbg, 2)) {
+#pragma unroll
+                    for (int aw = 0; aw < 4; ++aw) {
+                        u32x4 bf[2][NP];
+#pragma unroll
+                        for (int lh = 0; lh < 2; ++lh)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) bf[lh][p] = Xs[p * XWORDS + xb[aw] + lh * 2 * SU_SK_ROW];
+#pragma unroll
+                        for (int lh = 0; lh < 2; ++lh)
+#pragma unroll
+                            for (int t = 0; t < P::NPROD; ++t)
+#pragma unroll
+                                for (int ct = 0; ct < NCTL; ++ct) accl[lh][ct] = P::mfma(al[aw][P::PA[t]][ct], bf[lh][P::PB[t]], accl[lh][ct]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {                                               // the next stage's (chunk (q + 1) % Q: the next tile starts over) four K-steps
+                    const int qn = q + 1 < Q ? q + 1 : 0;
+                    const int wo = (qn * WCH + kq * 4 * NP * NCTL * 64) * 16;
+                    if (!SU_DBG(dbg, 16)) {
+#pragma unroll
+                        for (int aw = 0; aw < 4; ++aw)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                                for (int ct = 0; ct < NCTL; ++ct)
+                                    al[aw][p][ct] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rwl, lane16, wo + ((aw * NP + p) * NCTL + ct) * 1024, 0));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- adjoint onto the skip tensor: 7 K-steps over the 27 taps
+                if (!SU_DBG(dbg, 4)) {
+#pragma unroll
+                    for (int s = 0; s < 7; ++s) {
+                        const int sb = skb[s * 4] + n_;
+                        u32x4 bf[2][NP];
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) bf[0][p] = Xs[p * XWORDS + sb];
+#pragma unroll
+                        for (int rl = 0; rl < 4; ++rl) {
+                            if (rl + 1 < 4) {
+#pragma unroll
+                                for (int p = 0; p < NP; ++p)
+                                    bf[(rl + 1) & 1][p] = Xs[p * XWORDS + sb + ((rl + 1) >> 1) * 2 * SU_SK_PLANE + ((rl + 1) & 1) * 2 * SU_SK_ROW];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int t = 0; t < P::NPROD; ++t)
+#pragma unroll
+                                for (int ct = 0; ct < NCTS; ++ct) accs[rl][ct] = P::mfma(as[s % RS][P::PA[t]][ct], bf[rl & 1][P::PB[t]], accs[rl][ct]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (s + RS < 7 && !SU_DBG(dbg, 32)) {      // K-step s + RS into the ring slot this one has just left
+#pragma unroll
+                            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                                for (int ct = 0; ct < NCTS; ++ct)
+                                    as[s % RS][p][ct] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, lane16, wos + (((s + RS) * NP + p) * NCTS + ct) * 1024, 0));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __syncthreads();                                // stage k is read, stage k + 1 is written
+            }
+            // ---- epilogue.  Skip adjoint: lane (kg, n) holds channel 16 ct + 4 kg + j of voxel (d0 + 2 ld + pd, h0 + 2 lh + ph, w0 + 2 n + pw): planar store
+            int bt, d0, h0, w0;
+            tile_geom(tile, bt, d0, h0, w0);
+            int kg = kg_, n = n_;                               // opaque per tile: the epilogue's addresses are computed here, not hoisted and spilled
+            asm volatile("" : "+v"(kg), "+v"(n));
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int ct = 0; ct < NCTL; ++ct) Rs[((kq * 4 + 2 * rp + r) * 2 + ct) * 64 + lane] = accl[r][ct];
+            {
+                const float unscale = inv_fin * inv_ws;
+                const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(gx1 + (size_t)bt * gx1_bs, SU_DBG(dbg, 8) ? 0u : (unsigned)C1 * (unsigned)V * 4u);
+                const int wv_ = w0 + 2 * n + pw;
+#pragma unroll
+                for (int rl = 0; rl < 4; ++rl) {
+                    const int dd = d0 + 2 * (rl >> 1) + pd, hh = h0 + 2 * (rl & 1) + ph;       // wave-uniform
+                    if (dd < D && hh < H) {
+                        const int vox = (dd * H + hh) * W + wv_;
+#pragma unroll
+                        for (int ct = 0; ct < NCTS; ++ct)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int ch = 16 * ct + 4 * kg + j;
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accs[rl][ct][j] * unscale), ry, (wv_ < W && ch < C1) ? (ch * V + vox) << 2 : VXM_OOB, 0, 0);
+                            }
+                    }
+                }
+            }
+            __syncthreads();                                    // the a_h partial sums of the tile are in LDS
+            // low-resolution adjoint: wave w finishes (row = w >> 1 = (ld, lh), ct = w & 1): the four a_h sums in a fixed order, unscale, LeakyReLU'(mask)
+            if ((wave & 1) < NCTL) {
+                const int row = wave >> 1, ct = wave & 1;
+                const f32x4 p0 = Rs[((0 * 4 + row) * 2 + ct) * 64 + lane], p1 = Rs[((1 * 4 + row) * 2 + ct) * 64 + lane];
+                const f32x4 p2 = Rs[((2 * 4 + row) * 2 + ct) * 64 + lane], p3 = Rs[((3 * 4 + row) * 2 + ct) * 64 + lane];
+                const f32x4 sum = (p0 + p1) + (p2 + p3);
+                const float unscale = inv_fin * inv_wl;
+                const int dd = (d0 >> 1) + (row >> 1), hh = (h0 >> 1) + (row & 1), ww = (w0 >> 1) + n;
+                const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(gxl + (size_t)bt * gxl_bs, (unsigned)C0 * (unsigned)Vl * 4u);
+                const __amdgpu_buffer_rsrc_t rm = vxm_rsrc(mask ? mask + (size_t)bt * mask_bs : gxl, (unsigned)C0 * (unsigned)Vl * 4u);
+                const bool vok = dd < Dl && hh < Hl && ww < Wl;
+                const int vox = (dd * Hl + hh) * Wl + ww;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ch = ct * 16 + kg * 4 + j;
+                    const int off = (vok && ch < C0) ? (ch * Vl + vox) << 2 : VXM_OOB;
+                    float v = sum[j] * unscale;
+                    if (mask) v *= vxm_lrelu_grad(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rm, off, 0, 0)), mask_slope);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, off, 0, 0);
+                }
+            }
+        }
+    } else {
+        // ================================================================ producers (protocol of k_s3u_conv_pc)
+        const int pwv = wave - SUP_CONS, ptid = tid - 64 * SUP_CONS;
+        __builtin_amdgcn_s_setprio(3);
+        constexpr int NR = BLK ? SBP_NRV : SBP_NRP, RW = BLK ? 8 : 16;          // rounds / raw registers of a round
+        // slot i = ptid + 256 j.  Blocked dz: a voxel (hd 6, hh 6, hw 34), 8 channels = two 16-byte loads -> LDS word hd 240 + hh 40 + (hw & 1) 20 + (hw >> 1).
+        // Planar dz: a PAIR of W neighbours (hd, hh, pp 18) = voxels hw = 2 pp - 1, 2 pp, one 8-byte load per channel.
+        int pos[NR], lw[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int i = ptid + SUP_PT * j;
+            if constexpr (BLK) {
+                const int hd = i / 204, rem = i - hd * 204, hh = rem / 34, hw = rem - hh * 34;
+                pos[j] = i < SBP_VSLOTS ? (hd << 10 | hh << 6 | hw) : -1;
+                lw[j] = hd * SU_SK_PLANE + hh * SU_SK_ROW + (hw & 1) * SU_SK_HALF + (hw >> 1);
+            } else {
+                const int hd = i / 108, rem = i - hd * 108, hh = rem / 18, pp = rem - hh * 18;
+                pos[j] = i < SBP_PSLOTS ? (hd << 10 | hh << 6 | pp) : -1;
+                lw[j] = hd * SU_SK_PLANE + hh * SU_SK_ROW + pp;       // word of hw = 2 pp (parity 0); hw = 2 pp - 1 sits at + SU_SK_HALF - 1
+            }
+        }
+        // TWO raw sets (set = stage & 1): a stage is requested two phases before it is split, so a phase never waits for its own loads --
+        // with one set the producers' chain was split + request + WAIT + maximum in every phase, longer than the consumers' multiply phase
+        // (timing experiment: 0.36 ms of the 1.11 with loads, multiplies and stores compiled out)
+        float raw[2][NR][RW];
+        int voffs[2][NR];
+        auto load_stage = [&](auto set_, int k) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value;
+            const bool any = k < nstage;
+            const int ti = any ? k / Q : 0, q = k - ti * Q;
+            int bt, d0, h0, w0;
+            tile_geom(t_lo + ti * t_step, bt, d0, h0, w0);
+            const __amdgpu_buffer_rsrc_t r = vxm_rsrc(dz + (size_t)bt * dz_bs, (unsigned)Cout * (unsigned)V * 4u);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                const int gd = d0 - 1 + (pos[j] >> 10), gh = h0 - 1 + ((pos[j] >> 6) & 15);
+                if constexpr (BLK) {
+                    const int gw = w0 - 1 + (pos[j] & 63);
+                    const bool ok = any && pos[j] >= 0 && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+                    voffs[S][j] = (ok && !SU_DBG(dbg, 1)) ? (q * V + (gd * H + gh) * W + gw) << 5 : VXM_OOB;
+                    const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[S][j], 0, 0));
+                    const f32x4 hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[S][j], 16, 0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { raw[S][j][e] = lo[e]; raw[S][j][4 + e] = hi[e]; }
+                } else {
+                    const int gw = w0 - 2 + 2 * (pos[j] & 63);
+                    const bool ok = any && pos[j] >= 0 && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+                    voffs[S][j] = (ok && !SU_DBG(dbg, 1)) ? (q * 8 * V + (gd * H + gh) * W + gw) << 2 : VXM_OOB;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const f32x2 t2 = (q * 8 + e < Cout) ? __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voffs[S][j], (e * V) << 2, 0)) : (f32x2){0.f, 0.f};
+                        raw[S][j][e] = t2.x; raw[S][j][8 + e] = t2.y;
+                    }
+                }
+            }
+        };
+        auto publish_max = [&](auto set_, int k) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value;
+            float m = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                if constexpr (BLK) {
+#pragma unroll
+                    for (int e = 0; e < RW; ++e) m = fmaxf(m, __builtin_fabsf(raw[S][j][e]));
+                } else {                                         // the voxels a row's first / last pair drops (hw = -1, 34) stay out of the maximum:
+                    const int pp = pos[j] & 63;                  // the blocked staging never sees them -- same scale, same bits in both layouts
+                    float m0 = 0.0f, m1 = 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { m0 = fmaxf(m0, __builtin_fabsf(raw[S][j][e])); m1 = fmaxf(m1, __builtin_fabsf(raw[S][j][8 + e])); }
+                    m = fmaxf(m, fmaxf(pp > 0 ? m0 : 0.0f, pp < 17 ? m1 : 0.0f));
+                }
+            }
+            m = s3_wave_max(m);
+            if (lane == 0) Tab[(k & 1) * 4 + pwv] = m;
+        };
+        int E_run = 15;
+        auto store_stage = [&](auto set_, int k) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value;
+            if (k >= nstage) return;                             // wave-uniform
+            const bool first = (k % Q) == 0;
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(Tab + (k & 1) * 4);
+            const float mx = fmaxf(fmaxf(m4.x, m4.y), fmaxf(m4.z, m4.w));
+            int E = (int)(__float_as_uint(mx) >> 23) & 255;
+            E = E < 15 ? 15 : E;
+            const int E_new = first ? E : (E > E_run ? E : E_run);
+            const int dE = E_new - E_run;
+            const float ratio = (first || dE == 0) ? 1.0f : (dE > 126 ? 0.0f : __uint_as_float((unsigned)(127 - dE) << 23));
+            E_run = E_new;
+            const float sc = __uint_as_float((unsigned)(268 - E_run) << 23);
+            if (ptid == 0) { Tab[8 + 2 * (k & 3)] = ratio; Tab[9 + 2 * (k & 3)] = __uint_as_float((unsigned)(E_run - 14) << 23); }
+            u32x4* const Xd = smem + (k & 1) * NP * XWORDS;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                if (pos[j] < 0) continue;
+                if constexpr (BLK) {
+                    unsigned ka[NP][4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s3_split2_f16(raw[S][j][2 * e], raw[S][j][2 * e + 1], sc, ka[0][e], ka[1][e]);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) Xd[p * XWORDS + lw[j]] = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
+                } else {
+                    unsigned ka[NP][4], kb[NP][4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s3_split2_f16(raw[S][j][2 * e], raw[S][j][2 * e + 1], sc, ka[0][e], ka[1][e]);
+                        s3_split2_f16(raw[S][j][8 + 2 * e], raw[S][j][8 + 2 * e + 1], sc, kb[0][e], kb[1][e]);
+                    }
+                    const int pp = pos[j] & 63;
+                    if (pp > 0) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) Xd[p * XWORDS + lw[j] + SU_SK_HALF - 1] = (u32x4){ka[p][0], ka[p][1], ka[p][2], ka[p][3]};
+                    }
+                    if (pp < 17) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) Xd[p * XWORDS + lw[j]] = (u32x4){kb[p][0], kb[p][1], kb[p][2], kb[p][3]};
+                    }
+                }
+            }
+        };
+        auto keep_offsets = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) asm volatile("" ::"v"(voffs[0][j]), "v"(voffs[1][j]));
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        load_stage(S0{}, 0);
+        publish_max(S0{}, 0);
+        __syncthreads();
+        store_stage(S0{}, 0);
+        load_stage(S1{}, 1);
+        publish_max(S1{}, 1);                                  // (the one place a phase waits for its own loads)
+        load_stage(S0{}, 2);
+        keep_offsets();
+        __syncthreads();
+        // phase k: split stage k + 1 (set (k + 1) & 1; its maxima were published in phase k - 1), publish the maxima of stage k + 2 (set k & 1,
+        // requested in phase k - 1), request stage k + 3 into the set the split has just freed
+        auto phase = [&](auto par_, int k) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_)::value;           // = k & 1
+            using SA = std::integral_constant<int, PAR>;
+            using SB = std::integral_constant<int, PAR ^ 1>;
+            store_stage(SB{}, k + 1);
+            publish_max(SA{}, k + 2);
+            load_stage(SB{}, k + 3);
+            keep_offsets();
+            __syncthreads();
+            if ((k + 1) % Q == 0) __syncthreads();              // the consumers' a_h exchange at the end of a tile
+        };
+        for (int k = 0; k < nstage; k += 2) {
+            phase(S0{}, k);
+            if (k + 1 < nstage) phase(S1{}, k + 1);
+        }
+    }
+}
+
 // ---- packed operator.  w: [Cout][C0 + C1][27] fp32 (reference layout).
 struct SuPack {
     const float* w; u32x4* wp;
     int C0, C1, Cout, NCT, NP, Q0, Q1, G;
     unsigned words;                          // 16-byte words of the operator proper; the trailer follows
-    int kind;                                // 0: forward operator (k_s3u_conv), 1: adjoint onto the low-resolution tensor (k_s3u_dlow)
+    int kind;                                // 0: forward operator (k_s3u_conv), 1: adjoint onto the low-resolution tensor (k_s3u_dlow),
+                                             // 2: adjoint onto the skip tensor in the forward kernel's skip-chunk format (k_s3u_bwd_pc): C0 = 0, C1 = the
+                                             //    layer's OUTPUT channels (dz), Cout = its skip channels; adj_lo / adj_cin: first skip channel / row length of w
+    int adj_lo, adj_cin;
 };
 // the 8 values (8 consecutive input channels) of packed word i
 __device__ __forceinline__ void su_word_values(const SuPack& jb, size_t i, float (&v)[8], int& piece) {
@@ -862,7 +1269,9 @@ __device__ __forceinline__ void su_word_values(const SuPack& jb, size_t i, float
         if (!u.valid || o >= jb.Cout) return;
         for (int e = 0; e < 8; ++e) {
             const int ci = q * 8 + e;
-            if (ci < jb.C1) v[e] = jb.w[((size_t)o * Cin + jb.C0 + ci) * 27 + u.kd * 9 + u.kh * 3 + u.kw];
+            if (ci >= jb.C1) continue;
+            if (jb.kind == 2) v[e] = jb.w[((size_t)ci * jb.adj_cin + jb.adj_lo + o) * 27 + 26 - (u.kd * 9 + u.kh * 3 + u.kw)];      // W_adj[o][ci][tap] = w[ci][lo + o][mirrored tap]
+            else v[e] = jb.w[((size_t)o * Cin + jb.C0 + ci) * 27 + u.kd * 9 + u.kh * 3 + u.kw];
         }
     }
 }
@@ -900,7 +1309,7 @@ __device__ __forceinline__ void su_dlow_word_values(const SuPack& jb, size_t i, 
     }
 }
 __device__ __forceinline__ void su_values(const SuPack& jb, size_t i, float (&v)[8], int& piece) {
-    if (jb.kind == 0) su_word_values(jb, i, v, piece); else su_dlow_word_values(jb, i, v, piece);
+    if (jb.kind == 1) su_dlow_word_values(jb, i, v, piece); else su_word_values(jb, i, v, piece);
 }
 // PHASE 0: largest magnitude of the packed values -> trailer.z (float bits, zeroed by the host side first).  PHASE 1: the words.
 template <int PHASE>
@@ -1603,6 +2012,26 @@ void sd_launch(const float* dz, long long dz_bs, int Cout, const void* wp, float
 }
 
 
+template <int NCTL, int NCTS, bool BLK>
+void sbp_launch(const float* dz, long long dz_bs, int Cout, const void* wlow, float* gxl, long long gxl_bs, int C0, const float* mask, long long mask_bs,
+                float mask_slope, const void* wskip, float* gx1, long long gx1_bs, int C1, int B, int D, int H, int W, hipStream_t s) {
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3u_bwd_pc<NCTL, NCTS, BLK>), hipFuncAttributeMaxDynamicSharedMemorySize, SBP_LDS_BYTES);
+        return true;
+    }();
+    (void)attr;
+    const long long ntiles = (long long)B * ((D + 3) / 4) * ((H + 3) / 4) * ((W + 31) / 32);
+    unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
+    static const int persist = [] { const char* e = getenv("VXM_S3U_PERSIST"); return e ? atoi(e) : 1; }();
+    if (persist != 0 && ntiles >= 64) {
+        const unsigned want = persist > 0 ? (unsigned)(su_cus() * persist) : (unsigned)(-persist);
+        const unsigned cap = 8 * ((want + 7) / 8);
+        if (cap < gx) gx = cap;
+    }
+    hipLaunchKernelGGL((k_s3u_bwd_pc<NCTL, NCTS, BLK>), dim3(gx), dim3(SUP_THREADS), SBP_LDS_BYTES, s, dz, dz_bs, Cout, static_cast<const u32x4*>(wlow), gxl,
+                       gxl_bs, C0, mask, mask_bs, mask_slope, static_cast<const u32x4*>(wskip), gx1, gx1_bs, C1, B, D, H, W, su_dbg());
+}
+
 struct UwTasks { int ncol, nseg, seg_len, nh, nw, NBLK; };
 UwTasks uw_tasks(int ncot, int B, int D, int H, int W) {
     UwTasks tk;
@@ -1649,7 +2078,7 @@ int vxm_conv3d_k3_s3u_pack_weights(const float* w, void* wpacked, int C0, int C1
                 "vxm_conv3d_k3_s3u_pack_weights: %d + %d -> %d channels (segments in multiples of 8), pieces %d, 16-byte aligned destination", C0, C1, Cout, pieces);
     const int NCT = su_nct(Cout);
     SuPack jb = {w, static_cast<u32x4*>(wpacked), C0, C1, Cout, NCT, pieces, C0 / 8, C1 / 8, (Cout + 16 * NCT - 1) / (16 * NCT),
-                 (unsigned)su_words(C0, C1, Cout, pieces), 0};
+                 (unsigned)su_words(C0, C1, Cout, pieces), 0, 0, 0};
     hipStream_t s = VXM_STREAM(stream);
     (void)hipMemsetAsync(jb.wp + jb.words, 0, 16, s);
     const unsigned blocks = (jb.words + 255) / 256;
@@ -1702,7 +2131,7 @@ int vxm_conv3d_k3_s3u_bwd_low_pack_weights(const float* w, void* wpacked, int C0
                 "vxm_conv3d_k3_s3u_bwd_low_pack_weights: %d of %d input channels, %d outputs, pieces %d (2), 16-byte aligned destination", C0, Cin, Cout, pieces);
     const int NCT = su_nct(C0);
     SuPack jb = {w, static_cast<u32x4*>(wpacked), C0, Cin - C0, Cout, NCT, pieces, 0, 0, (C0 + 16 * NCT - 1) / (16 * NCT),
-                 (unsigned)sd_words(C0, Cout, pieces, NCT), 1};
+                 (unsigned)sd_words(C0, Cout, pieces, NCT), 1, 0, 0};
     hipStream_t s = VXM_STREAM(stream);
     (void)hipMemsetAsync(jb.wp + jb.words, 0, 16, s);
     const unsigned blocks = (jb.words + 255) / 256;
@@ -1729,6 +2158,67 @@ int vxm_conv3d_k3_s3u_bwd_low(const float* dz, int64_t dz_bstride, int Cout, con
         else sd_launch<1, 2>(dz, dz_bstride, Cout, wpacked, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, B, D, H, W, s);
     }
     return vxm_check_launch("vxm_conv3d_k3_s3u_bwd_low");
+}
+
+/* both backward-data products of a cat([upsample(x0), x1]) layer from one staging of dz (k_s3u_bwd_pc): the gradient of the low-resolution x0
+ * (what _bwd_low computes) and of the skip tensor x1 (what vxm_conv3d_k3_s3_fwd computes with the flipped operator of w[:, C0:]) */
+int vxm_conv3d_k3_s3u_bwd_data_ok(int C0, int C1, int Cout, int B, int D, int H, int W, int pieces) {
+    // OFF by default: measured at 160 x 192 x 224 (tools/s3_bench.py --only dlow) the one launch takes 1.11 - 1.14 ms against 1.13 - 1.26 ms for
+    // k_s3u_dlow + k_s3p_conv, and in the replayed step, beside the weight gradients of the second stream, it is SLOWER (91.7 against 92.5
+    // pairs/s, same box).  Why: with 16 skip channels a B fragment read from LDS (1 KB per wave) feeds three MFMAs -- 128 LDS cycles against 96
+    // matrix-pipe cycles per K-step row over the CU, so the skip product is bound by LDS reads whatever feeds the tile, and the 4 x 4 x 32 tiles the
+    // double buffer allows are re-staged with 2.4 x halo.  VXM_S3U_BWD_PC=1 switches it on (tests call the entry point directly).
+    static const bool on = [] { const char* e = getenv("VXM_S3U_BWD_PC"); return e && e[0] == '1'; }();
+    if (!on || !vxm_conv3d_k3_s3u_bwd_low_ok(C0, Cout, B, D, H, W, pieces)) return 0;
+    if (C0 > 32 || C1 <= 0 || C1 > 32 || C1 % 8 || Cout % 8 || (W & 3)) return 0;
+    if ((long long)C1 * D * H * W >= (1ll << 29)) return 0;
+    return 1;
+}
+
+size_t vxm_conv3d_k3_s3u_bwd_skip_packed_bytes(int C1, int Cout, int pieces) {
+    if (C1 <= 0 || Cout <= 0 || Cout % 8 || pieces != 2) return 0;
+    const int NCT = su_nct(C1);
+    return ((size_t)(Cout / 8) * (7 * 2 * NCT * 64) + 1) * 16;
+}
+
+/* w: [Cout][Cin][27] (reference layout); the operator of the skip channels [C0, C0 + C1) transposed and mirrored, in the forward kernel's skip-chunk format */
+int vxm_conv3d_k3_s3u_bwd_skip_pack_weights(const float* w, void* wpacked, int C0, int C1, int Cout, int pieces, void* stream) {
+    VXM_REQUIRE(w && wpacked, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3u_bwd_skip_pack_weights: null pointer");
+    VXM_REQUIRE(C0 >= 0 && C1 > 0 && Cout > 0 && Cout % 8 == 0 && pieces == 2 && (reinterpret_cast<uintptr_t>(wpacked) & 15) == 0, VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3u_bwd_skip_pack_weights: skip channels [%d, %d) of %d outputs (multiple of 8), pieces %d (2), 16-byte aligned destination",
+                C0, C0 + C1, Cout, pieces);
+    const int NCT = su_nct(C1);
+    SuPack jb = {w, static_cast<u32x4*>(wpacked), 0, Cout, C1, NCT, 2, 0, Cout / 8, 1, (unsigned)((size_t)(Cout / 8) * (7 * 2 * NCT * 64)), 2, C0, C0 + C1};
+    VXM_REQUIRE(C1 <= 16 * NCT, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3u_bwd_skip_pack_weights: at most 32 skip channels (got %d)", C1);
+    hipStream_t s = VXM_STREAM(stream);
+    (void)hipMemsetAsync(jb.wp + jb.words, 0, 16, s);
+    const unsigned blocks = (jb.words + 255) / 256;
+    hipLaunchKernelGGL(k_s3u_pack<0>, dim3(blocks), dim3(256), 0, s, jb);
+    hipLaunchKernelGGL(k_s3u_pack<1>, dim3(blocks), dim3(256), 0, s, jb);
+    return vxm_check_launch("vxm_conv3d_k3_s3u_bwd_skip_pack_weights");
+}
+
+int vxm_conv3d_k3_s3u_bwd_data(const float* dz, int64_t dz_bstride, int Cout, const void* wlow, float* gxl, int64_t gxl_bstride, int C0, const float* mask,
+                               int64_t mask_bstride, float mask_slope, const void* wskip, float* gx1, int64_t gx1_bstride, int C1, int B, int D, int H, int W,
+                               int pieces_and_layout, void* stream) {
+    const int pieces = pieces_and_layout & 0xff, lay = pieces_and_layout & ~0xff;
+    VXM_REQUIRE(dz && wlow && gxl && wskip && gx1, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3u_bwd_data: null pointer");
+    VXM_REQUIRE(lay == 0 || lay == VXM_S3_IN0_BLOCKED, VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3u_bwd_data: layout flags 0x%x (only dz, the first operand, may be channel-blocked)", lay);
+    if (int e = check_conv("vxm_conv3d_k3_s3u_bwd_data", C0, C1, 1, Cout, B, D, H, W)) return e;
+    VXM_REQUIRE(pieces == 2 && C0 % 8 == 0 && C0 <= 32 && C1 % 8 == 0 && C1 <= 32 && Cout % 8 == 0 && W % 4 == 0 && (dz_bstride & 1) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(wlow) | reinterpret_cast<uintptr_t>(wskip)) & 15) == 0, VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3u_bwd_data: fp16 pieces, %d + %d -> %d channels (segments <= 32, multiples of 8), W = %d (multiple of 4), 16-byte aligned operators",
+                C0, C1, Cout, W);
+    hipStream_t s = VXM_STREAM(stream);
+    const int nl = su_nct(C0), ns = su_nct(C1);
+#define SBP_GO(NL, NS)                                                                                                                                      \
+    do {                                                                                                                                                    \
+        if (lay) sbp_launch<NL, NS, true>(dz, dz_bstride, Cout, wlow, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, wskip, gx1, gx1_bstride, C1, B, D, H, W, s); \
+        else sbp_launch<NL, NS, false>(dz, dz_bstride, Cout, wlow, gxl, gxl_bstride, C0, mask, mask_bstride, mask_slope, wskip, gx1, gx1_bstride, C1, B, D, H, W, s);  \
+    } while (0)
+    if (nl == 2 && ns == 2) SBP_GO(2, 2); else if (nl == 2) SBP_GO(2, 1); else if (ns == 2) SBP_GO(1, 2); else SBP_GO(1, 1);
+#undef SBP_GO
+    return vxm_check_launch("vxm_conv3d_k3_s3u_bwd_data");
 }
 
 /* backward-weight of the upsampled segment, collapsed, on the fp16 scheme (k_s3u_bww): gw[co][0:C0][tap] inside a [Cout][gw_cin][27] array */

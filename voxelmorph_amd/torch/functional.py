@@ -646,6 +646,37 @@ def s3u_bwd_low(dz, cout, w, c0, cin, gxl, mask, mask_slope, B, D, H, W, lay=0):
              B, D, H, W, s3_pieces() | lay, stream())
 
 
+def s3u_bwd_data_route(c0, c1, cout, B, D, H, W):
+    """do BOTH backward-data products of a cat([upsample(x0), x1]) layer come from one staging of dz (csrc/conv_s3u.hip: k_s3u_bwd_pc)?"""
+    return S3U and split_engine() and bool(_lib.lib().vxm_conv3d_k3_s3u_bwd_data_ok(c0, c1, cout, B, D, H, W, s3_pieces()))
+
+
+def s3u_bwd_skip_pack(w, c0, c1):
+    """packed adjoint operator of the skip channels [c0, c0 + c1) of w [cout][c0 + c1][27] for k_s3u_bwd_pc, cached on the weight tensor until its
+    version moves"""
+    cout = w.shape[0]
+    cache = w.__dict__.setdefault("_vxm_s3_packs", {})
+    key = ("s3u_skip_adj", c0, c1, s3_pieces())
+    hit = cache.get(key)
+    if hit is None or hit[0] != _pack_ver(w) or hit[1].device != w.device:
+        nbytes = _lib.lib().vxm_conv3d_k3_s3u_bwd_skip_packed_bytes(c1, cout, s3_pieces())
+        wp = hit[1] if hit is not None and hit[1].device == w.device and hit[1].numel() == nbytes else _new_pack(nbytes, w.device)
+        call("vxm_conv3d_k3_s3u_bwd_skip_pack_weights", ptr(_c(w)), ptr(wp), c0, c1, cout, s3_pieces(), stream())
+        cache[key] = hit = (_pack_ver(w), wp)
+    return hit[1]
+
+
+def s3u_bwd_data(dz, cout, w, c0, c1, gxl, mask, mask_slope, gx1, B, D, H, W, lay=0):
+    """gxl [B,c0,D/2,H/2,W/2] as s3u_bwd_low, and gx1 [B,c1,D,H,W] = conv backward of dz onto the skip channels of w [cout][c0 + c1][27], from one
+    staging of dz [B,cout,D,H,W]"""
+    wl, wk = s3u_bwd_low_pack(w, c0, c0 + c1), s3u_bwd_skip_pack(w, c0, c1)
+    V = D * H * W
+    with _prof.region("k_s3u_bwd_pc<%d,%d>" % (1 if c0 <= 16 else 2, 1 if c1 <= 16 else 2), flops=2.0 * (8 * c0 + 27 * c1) * cout * B * V,
+                      nominal=2.0 * 27 * (c0 + c1) * cout * B * V):
+        call("vxm_conv3d_k3_s3u_bwd_data", ptr(dz), cout * V, cout, ptr(wl), ptr(gxl), c0 * (V // 8), c0, ptr(mask), c0 * (V // 8), float(mask_slope),
+             ptr(wk), ptr(gx1), c1 * V, c1, B, D, H, W, s3_pieces() | lay, stream())
+
+
 # layout flags of include/vxm_hip.h (OR-ed into `pieces`): a flagged tensor is channel-blocked [B][C/8][D][H][W][8]
 S3_IN0_BLOCKED, S3_IN1_BLOCKED, S3_OUT_BLOCKED = 0x100, 0x200, 0x400
 S3_REVERSE_TILES = 0x4000                                     # scheduling hint of vxm_conv3d_k3_s3_fwd (include/vxm_hip.h)
@@ -1090,6 +1121,8 @@ def _s3_jobs(plan, params, B, shape3, with_backward, input_grads):
             low = up_fused and (s3u_bwd_low_route(c0, cout, B, D, H, W) or
                                 bool(_lib.lib().vxm_conv3d_k3_up_bwd_low_ok(256, cout * V, c0, cout, B, D, H, W)))     # (256: any 16-byte aligned address)
             ranges = ([(c0, c1)] if s1 is not None else []) if low else [(0, c0 + c1)]
+            if low and s1 is not None and up_fused and s3u_bwd_data_route(c0, c1, cout, B, D, H, W):
+                ranges = []                                         # k_s3u_bwd_pc computes the skip segment's gradient too (its operator: _prepack_plan, group B2)
         else:
             ranges = [(0, c0 + c1)]                                 # (first channel, count) handed to conv_bwd_data
         for w_lo, cin in ranges:
@@ -1134,6 +1167,8 @@ def _prepack_plan(plan, params, B, shape3, with_backward, input_grads, dry=False
         if do_b and up0 and with_backward and s3u_bwd_low_route(c0, cout, B, D, H, W) and plan.ops[plan.producer[s0]]["kind"] == "conv" \
                 and len(plan.consumers[s0]) == 1:
             s3u_bwd_low_pack(w, c0, c0 + c1)
+            if s1 is not None and s3u_bwd_data_route(c0, c1, cout, B, D, H, W):
+                s3u_bwd_skip_pack(w, c0, c1)
         # the fp32-MFMA operators of the convs the split engine does not take (coarse levels, first layer, flow head): packed here too, so
         # that the main chain does not carry a 5 us pack launch in front of each of them.  A guess that turns out unused costs that launch on
         # the second stream; one that is missing is packed on demand, as before.
@@ -1495,7 +1530,12 @@ class UnetFn(torch.autograd.Function):
                     pslope = plan.ops[plan.producer[s0]]["slope"]
                     lD, lH, lW = D // 2, H // 2, W // 2
                     dzl = torch.empty((B, c0, lD, lH, lW), dtype=dt, device=dev)
-                    if s3u_bwd_low_route(c0, cout, B, D, H, W):
+                    gxs = None
+                    if s1 is not None and s3u_bwd_data_route(c0, c1, cout, B, D, H, W):
+                        # both products from one staging of dz (k_s3u_bwd_pc): the skip segment's gradient comes with it
+                        gxs = torch.empty((B, c1, D, H, W), dtype=dt, device=dev)
+                        s3u_bwd_data(dz, cout, w, c0, c1, dzl, T[s0] if pslope != 1.0 else None, pslope, gxs, B, D, H, W, lay=lay_d)
+                    elif s3u_bwd_low_route(c0, cout, B, D, H, W):
                         s3u_bwd_low(dz, cout, w, c0, cin, dzl, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W, lay=lay_d)
                     else:
                         _need_split_kernel(lay_d, "backward-data onto the low-resolution tensor")
@@ -1506,8 +1546,9 @@ class UnetFn(torch.autograd.Function):
                                  ptr(T[s0]) if pslope != 1.0 else None, c0 * lD * lH * lW, float(pslope), B, D, H, W, stream())
                     DZ[s0] = dzl
                     if s1 is not None:                       # skip segment: regular backward-data of its channels only
-                        gxs = torch.empty((B, c1, D, H, W), dtype=dt, device=dev)
-                        conv_bwd_data(dz, cout, w, gxs, c1, None, 1.0, B, D, H, W, w_lo=c0, lay=lay_d)
+                        if gxs is None:
+                            gxs = torch.empty((B, c1, D, H, W), dtype=dt, device=dev)
+                            conv_bwd_data(dz, cout, w, gxs, c1, None, 1.0, B, D, H, W, w_lo=c0, lay=lay_d)
                         GS[s1] = (gxs, 0, c1 * V)
                         if not any(plan.ops[m]["kind"] == "pool" for m in plan.consumers[s1]):
                             g = GS.pop(s1)
