@@ -692,10 +692,12 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
             sk_pos[j] = i < SUP_SK_SLOTS ? (hd << 10 | hh << 5 | pp) : -1;
             sk_lw[j] = hd * SU_SK_PLANE + hh * SU_SK_ROW + pp;          // word of hw = 2 pp (parity 0); hw = 2 pp - 1 (parity 1) sits at + SU_SK_HALF - 1
         }
-        float ra[SUP_NRS][8], rb[SUP_NRS][8];                    // first / second voxel of the pair
-        int voffs[SUP_NRS];
+        // TWO raw sets (set = stage & 1): a stage is requested two phases before it is split, so that no phase waits for the loads it issued itself
+        float ra[2][SUP_NRS][8], rb[2][SUP_NRS][8];              // first / second voxel of the pair
+        int voffs[2][SUP_NRS];
         // the raw loads of stage k (past the block's last stage: nothing fetched)
-        auto load_stage = [&](int k) __attribute__((always_inline)) {
+        auto load_stage = [&](auto set_, int k) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value;
             const bool any = k < nstage;
             const int ti = any ? k / NST : 0, st = k - ti * NST;
             int bt, d0, h0, w0;
@@ -708,37 +710,39 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
             const int dh = up ? 0 : 4 * ((st - NU) & 1);         // first haloed plane of a skip stage's depth half
 #pragma unroll
             for (int j = 0; j < SUP_NRS; ++j) {
-                if (j >= SUP_NRU && up) { voffs[j] = VXM_OOB; continue; }      // (wave-uniform: an upsampled stage has two rounds)
+                if (j >= SUP_NRU && up) { voffs[S][j] = VXM_OOB; continue; }      // (wave-uniform: an upsampled stage has two rounds)
                 const int pos = up ? up_pos[j < SUP_NRU ? j : 0] : sk_pos[j];
                 int cb, gd, gh, gw, De, He, We;
                 if (up) { cb = pos >> 16; gd = (d0 >> 1) - 1 + ((pos >> 10) & 63); gh = (h0 >> 1) - 1 + ((pos >> 5) & 31); gw = (w0 >> 1) - 2 + 2 * (pos & 31); De = Dl; He = Hl; We = Wl; }
                 else { cb = 0; gd = d0 - 1 + dh + (pos >> 10); gh = h0 - 1 + ((pos >> 5) & 31); gw = w0 - 2 + 2 * (pos & 31); De = D; He = H; We = W; }
                 // a pair starts at an even w (tiles start at multiples of 32 / 16, W and W / 2 are even): inside the volume or outside it as a whole
                 const bool ok = any && pos >= 0 && cbg + cb < nblk && (unsigned)gd < (unsigned)De && (unsigned)gh < (unsigned)He && (unsigned)gw < (unsigned)We;
-                voffs[j] = ok ? ((cbg + cb) * 8 * Vs + (gd * He + gh) * We + gw) << 2 : VXM_OOB;
-                if (SU_DBG(dbg, 1)) voffs[j] = VXM_OOB;           // timing experiment: no input reads
+                voffs[S][j] = ok ? ((cbg + cb) * 8 * Vs + (gd * He + gh) * We + gw) << 2 : VXM_OOB;
+                if (SU_DBG(dbg, 1)) voffs[S][j] = VXM_OOB;           // timing experiment: no input reads
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voffs[j], (e * Vs) << 2, 0));
-                    ra[j][e] = t2.x; rb[j][e] = t2.y;
+                    const f32x2 t2 = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voffs[S][j], (e * Vs) << 2, 0));
+                    ra[S][j][e] = t2.x; rb[S][j][e] = t2.y;
                 }
             }
         };
-        auto publish_max = [&](int k) __attribute__((always_inline)) {
+        auto publish_max = [&](auto set_, int k) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value;
             const bool up = (k % NST) < NU;                      // wave-uniform
             float m = 0.0f;
 #pragma unroll
             for (int j = 0; j < SUP_NRS; ++j) {
                 if (j >= SUP_NRU && up) continue;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[j][e]), __builtin_fabsf(rb[j][e])));
+                for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[S][j][e]), __builtin_fabsf(rb[S][j][e])));
             }
             m = s3_wave_max(m);
             if (lane == 0) Tab[(k & 1) * 4 + pwv] = m;
         };
         int E_run = 15;
         // split the raw registers (stage k) into buffer k & 1 with the tile's running scale; table slot k & 3 gets {ratio, 1 / scale}
-        auto store_stage = [&](int k) __attribute__((always_inline)) {
+        auto store_stage = [&](auto set_, int k) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_)::value;
             if (k >= nstage) return;                             // wave-uniform
             const int st = k % NST;
             const bool up = st < NU, first = st == 0;
@@ -760,8 +764,8 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
                 unsigned ka[NP][4], kb[NP][4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    s3_split2_f16(ra[j][2 * e], ra[j][2 * e + 1], sc, ka[0][e], ka[1][e]);
-                    s3_split2_f16(rb[j][2 * e], rb[j][2 * e + 1], sc, kb[0][e], kb[1][e]);
+                    s3_split2_f16(ra[S][j][2 * e], ra[S][j][2 * e + 1], sc, ka[0][e], ka[1][e]);
+                    s3_split2_f16(rb[S][j][2 * e], rb[S][j][2 * e + 1], sc, kb[0][e], kb[1][e]);
                 }
                 const int pos = up ? up_pos[j < SUP_NRU ? j : 0] : sk_pos[j];
                 if (pos >= 0) {                                  // (padding voxels are written too: zeros from the out-of-range loads)
@@ -792,22 +796,34 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
         };
         auto keep_offsets = [&]() __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < SUP_NRS; ++j) asm volatile("" ::"v"(voffs[j]));
+            for (int j = 0; j < SUP_NRS; ++j) asm volatile("" ::"v"(voffs[0][j]), "v"(voffs[1][j]));
         };
-        load_stage(0);
-        publish_max(0);
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        load_stage(S0{}, 0);
+        publish_max(S0{}, 0);
         __syncthreads();
-        store_stage(0);
-        load_stage(1);
-        publish_max(1);
+        store_stage(S0{}, 0);
+        load_stage(S1{}, 1);
+        publish_max(S1{}, 1);                                  // (the one place a phase waits for its own loads)
+        load_stage(S0{}, 2);
         keep_offsets();
         __syncthreads();
-        for (int k = 0; k < nstage; ++k) {
-            store_stage(k + 1);
-            load_stage(k + 2);
-            publish_max(k + 2);
+        // phase k: split stage k + 1 (set (k + 1) & 1; its maxima were published in phase k - 1), publish the maxima of stage k + 2 (set k & 1,
+        // requested in phase k - 1), request stage k + 3 into the set the split has just freed
+        auto phase = [&](auto par_, int k) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_)::value;           // = k & 1
+            using SA = std::integral_constant<int, PAR>;
+            using SB = std::integral_constant<int, PAR ^ 1>;
+            store_stage(SB{}, k + 1);
+            publish_max(SA{}, k + 2);
+            load_stage(SB{}, k + 3);
             keep_offsets();
             __syncthreads();
+        };
+        for (int k = 0; k < nstage; k += 2) {
+            phase(S0{}, k);
+            if (k + 1 < nstage) phase(S1{}, k + 1);
         }
     }
 }
