@@ -423,6 +423,13 @@ int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W);
  * results bit for bit; a launch that reads what the previous launch has just written starts where its producer stopped and finds that
  * part of the tensor in the memory-side cache (256 MB against 440 - 880 MB tensors). */
 #define VXM_S3_REVERSE_TILES 0x4000
+/* SIGN tensors (round 6), OR-ed into `pieces` of vxm_conv3d_k3_s3_fwd (and written by vxm_conv3d_k3_s3u_fwd_signs): leaky_relu_backward needs
+ * one bit of the activation it is taken at.  A sign tensor is [B][C/4][D][H][W] BYTES, bit j of byte (q, v) = (y[4 q + j][v] > 0); batch stride in bytes.
+ * VXM_S3_OUT_SIGNS: a forward launch with a channel-blocked output also writes the sign tensor of that output, passed in the `mask_src` /
+ * `mask_bstride` arguments (which a forward launch does not otherwise use).  VXM_S3_MASK_SIGNS: `mask_src` of a backward-data launch with a
+ * channel-blocked output IS such a sign tensor (C = Cout of the launch) instead of the fp32 activation: same products, 1/32 of the mask bytes. */
+#define VXM_S3_MASK_SIGNS 0x8000
+#define VXM_S3_OUT_SIGNS 0x10000
 #define VXM_S3_BW_CONTRACT_ONLY 0x1000
 #define VXM_S3_BW_REDUCE_ONLY 0x2000
 int vxm_conv3d_k3_s3_layout_ok(int C0, int C1, int x0_up, int Cout, int H, int pieces);
@@ -476,6 +483,10 @@ int vxm_conv3d_k3_s3u_pack_weights(const float* w, void* wpacked, int C0, int C1
 int vxm_conv3d_k3_s3u_fwd(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const void* wpacked,
                           const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope, int B, int D, int H, int W, int pieces,
                           void* stream);
+/* _fwd, and with signs != NULL (channel-blocked y only) the sign tensor of y beside it: [B][Cout/4][D][H][W] bytes, batch stride signs_bstride bytes */
+int vxm_conv3d_k3_s3u_fwd_signs(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const void* wpacked,
+                                const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope, int B, int D, int H, int W, int pieces,
+                                unsigned char* signs, int64_t signs_bstride, void* stream);
 /* 1 when _fwd runs this call on k_s3u_conv_pc (round 6: producer / consumer waves, double-buffered staging tile; fp16 pieces, W % 4 == 0,
  * even batch strides), 0: k_s3u_conv -- for profiles and bench regions */
 int vxm_conv3d_k3_s3u_fwd_kernel(int64_t x0_bstride, int64_t x1_bstride, int D, int H, int W, int pieces);

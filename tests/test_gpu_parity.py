@@ -1231,7 +1231,7 @@ def test_channel_blocked_interior_tensors_change_no_bit_of_the_step(vxm):
     from voxelmorph_amd.torch import functional as VF
     if VF.FP32_ENGINE != "f16x2":
         pytest.skip("channel-blocked tensors exist on the fp16 piece scheme only")
-    keep = VF.BLOCKED
+    keep, keep_signs = VF.BLOCKED, VF.SIGNS
     try:
         for shape, B, expect in ((FULL, 1, 2), ((64, 96, 128), 2, 1)):
             rng = np.random.default_rng(77)
@@ -1244,20 +1244,22 @@ def test_channel_blocked_interior_tensors_change_no_bit_of_the_step(vxm):
             VF.BLOCKED = True
             assert len(VF._blocked_tensors(plan, B, shape)) >= expect, (shape, VF._blocked_tensors(plan, B, shape))
             results = []
-            for flag in (False, True):
-                VF.BLOCKED = flag
+            for flag, signs in ((False, True), (True, True), (True, False)):
+                # (round 6: the blocked activations' LeakyReLU' is read from their SIGN tensors, functional.SIGNS -- one bit is all the product
+                # takes from the activation, so that changes no bit either)
+                VF.BLOCKED, VF.SIGNS = flag, signs
                 for p in model.parameters():
                     p.grad = None
                 moved, field = model(src, trg)
                 loss = vxm.losses.NCC().loss(trg, moved) + vxm.losses.Grad("l2", loss_mult=2).loss(None, field)
                 loss.backward()
                 results.append([moved.detach().clone(), field.detach().clone(), loss.detach().clone()] + [p.grad.clone() for p in model.parameters()])
-            for a, b in zip(*results):
-                assert torch.equal(a, b)
+            for a, b, c in zip(*results):
+                assert torch.equal(a, b) and torch.equal(b, c)
             del model, results, src, trg
             torch.cuda.empty_cache()
     finally:
-        VF.BLOCKED = keep
+        VF.BLOCKED, VF.SIGNS = keep, keep_signs
 
 
 def test_full_size_train_step_batch_of_two_vs_oracle(vxm):

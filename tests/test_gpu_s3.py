@@ -430,6 +430,54 @@ def test_s3_conv_channel_blocked_operands_bit_exact(VF16, c0, cout, vol):
                 assert _eq(y0, VF.from_blocked(y1) if lay & VF.S3_OUT_BLOCKED else y1), (flip, B, hex(lay))
 
 
+@pytest.mark.parametrize("c0,cout", [(16, 32), (16, 16), (32, 16)])
+def test_s3_sign_tensors_written_by_forward_and_read_by_backward_data_epilogues(VF16, c0, cout):
+    """include/vxm_hip.h VXM_S3_OUT_SIGNS / VXM_S3_MASK_SIGNS (round 6): a forward launch with a channel-blocked output writes, beside it, one
+    byte per four channels and voxel with the signs of what it stored -- the output itself unchanged; a backward-data launch that reads those
+    bytes instead of the fp32 activation produces the same bits (LeakyReLU' takes nothing else from the activation).  k_s3_conv here, k_s3p_conv in
+    the subprocess re-run with VXM_S3_PC=1, and the collapsed forward (k_s3u_conv_pc / k_s3u_conv); one and two samples, partial tiles."""
+    VF = VF16
+    D, H, W = 12, 20, 40
+    V = D * H * W
+    torch.manual_seed(11 + c0 + cout)
+
+    def signs_of(y):
+        return sum(((y[:, j::4] > 0).to(torch.uint8) << j) for j in range(4)).contiguous()
+    for B in (1, 2):
+        x = torch.randn(B, c0, D, H, W, device="cuda")
+        w = torch.randn(cout, c0, 3, 3, 3, device="cuda") / (27 * c0) ** 0.5
+        bias = torch.randn(cout, device="cuda")
+        y0, y1 = torch.empty(B, cout, D, H, W, device="cuda"), torch.empty(B, cout, D, H, W, device="cuda")
+        sg = torch.full((B, cout // 4, D, H, W), 255, dtype=torch.uint8, device="cuda")
+        wp = VF.s3_pack(w, False, 0, c0, c0)
+        VF.s3_launch(x, c0, c0 * V, False, None, 0, 0, wp, bias, y0, cout * V, cout, 0.2, None, 0, 1.0, B, D, H, W, lay=VF.S3_OUT_BLOCKED)
+        VF.s3_launch(x, c0, c0 * V, False, None, 0, 0, wp, bias, y1, cout * V, cout, 0.2, sg, (cout // 4) * V, 1.0, B, D, H, W,
+                     lay=VF.S3_OUT_BLOCKED | VF.S3_OUT_SIGNS)
+        assert torch.equal(y0, y1) and torch.equal(sg, signs_of(VF.from_blocked(y0))), (B, "forward")
+        dz = VF.to_blocked(torch.randn(B, cout, D, H, W, device="cuda"))
+        wa = torch.randn(cout, c0, 3, 3, 3, device="cuda") / (27 * cout) ** 0.5
+        act = torch.randn(B, c0, D, H, W, device="cuda")
+        act[:, :, ::3] = 0.0                                           # exact zeros take the slope, as y > 0 ? 1 : slope does
+        g0, g1 = torch.empty(B, c0, D, H, W, device="cuda"), torch.full((B, c0, D, H, W), float("nan"), device="cuda")
+        wpa = VF.s3_pack(wa, True, 0, c0, cout)
+        lay = VF.S3_IN0_BLOCKED | VF.S3_OUT_BLOCKED
+        VF.s3_launch(dz, cout, cout * V, False, None, 0, 0, wpa, None, g0, c0 * V, c0, 1.0, VF.to_blocked(act), c0 * V, 0.2, B, D, H, W, lay=lay)
+        VF.s3_launch(dz, cout, cout * V, False, None, 0, 0, wpa, None, g1, c0 * V, c0, 1.0, signs_of(act), (c0 // 4) * V, 0.2, B, D, H, W,
+                     lay=lay | VF.S3_MASK_SIGNS)
+        assert torch.equal(g0, g1), (B, "backward-data")
+    if cout == 32:
+        c1, B = 16, 2
+        x0, x1 = torch.randn(B, c0, D // 2, H // 2, W // 2, device="cuda"), torch.randn(B, c1, D, H, W, device="cuda")
+        w = torch.randn(cout, c0 + c1, 3, 3, 3, device="cuda") / (27 * (c0 + c1)) ** 0.5
+        bias = torch.randn(cout, device="cuda")
+        y0, y1 = torch.empty(B, cout, D, H, W, device="cuda"), torch.empty(B, cout, D, H, W, device="cuda")
+        sg = torch.full((B, cout // 4, D, H, W), 255, dtype=torch.uint8, device="cuda")
+        wp = VF.s3u_pack(w, c0, c1)
+        VF.s3u_launch(x0, c0, x0[0].numel(), x1, c1, c1 * V, wp, bias, y0, cout * V, cout, 0.2, B, D, H, W, lay=VF.S3_OUT_BLOCKED)
+        VF.s3u_launch(x0, c0, x0[0].numel(), x1, c1, c1 * V, wp, bias, y1, cout * V, cout, 0.2, B, D, H, W, lay=VF.S3_OUT_BLOCKED, signs=sg)
+        assert torch.equal(y0, y1) and torch.equal(sg, signs_of(VF.from_blocked(y0))), "collapsed forward"
+
+
 def test_s3_layout_flags_are_refused_where_no_blocked_variant_exists(VF16):
     VF = VF16
     x = torch.randn(1, 16, 8, 4, 32, device="cuda")               # H = 4: the 4-row instance
@@ -574,11 +622,11 @@ def test_s3_other_kernel_instances_in_subprocess():
     _rerun({"VXM_S3_PERSIST": "0", "VXM_S3U_PERSIST": "0"}, "many_tiles")
     # the producer / consumer kernel (k_s3p_conv: by default from 2048 tiles of 8 x 8 x 16 up) on every eligible launch, with one block per
     # tile and with 16 blocks in all (every block streams several tiles through its two LDS buffers); and the alternating kernel everywhere
-    _rerun({"VXM_S3_PC": "1"}, "forward_vs_fp64 or fused_mask or scale_invariance or dynamic_range or many_tiles or s3_conv_channel_blocked")
+    _rerun({"VXM_S3_PC": "1"}, "forward_vs_fp64 or fused_mask or scale_invariance or dynamic_range or many_tiles or s3_conv_channel_blocked or sign_tensors")
     _rerun({"VXM_S3_PC": "1", "VXM_S3P_BLOCKS": "16"}, "forward_vs_fp64 or fused_mask or dynamic_range or many_tiles")
     # the kernels the producer / consumer ones of round 6 replaced by default stay reachable (other piece scheme, odd extents, A/B):
     # k_s3_bwd_weight<2> for k_s3_bww_pc, k_s3u_conv<., 2> for k_s3u_conv_pc, k_s3_conv for k_s3p_conv
-    _rerun({"VXM_S3_PC": "0", "VXM_S3_BW_PC": "0", "VXM_S3U_PC": "0"}, "many_tiles or backward_weight or s3u_collapsed or s3u_kernels")
+    _rerun({"VXM_S3_PC": "0", "VXM_S3_BW_PC": "0", "VXM_S3U_PC": "0"}, "many_tiles or backward_weight or s3u_collapsed or s3u_kernels or sign_tensors")
 
 
 def test_s3_through_the_dispatcher_on_small_volumes_in_subprocess():

@@ -129,6 +129,7 @@ SIGNATURES = {
     "vxm_conv3d_k3_s3u_packed_bytes": [_I, _I, _I, _I],
     "vxm_conv3d_k3_s3u_pack_weights": [_P, _P, _I, _I, _I, _I, _P],
     "vxm_conv3d_k3_s3u_fwd": [_P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _I, _F, _I, _I, _I, _I, _I, _P],
+    "vxm_conv3d_k3_s3u_fwd_signs": [_P, _I, _L, _P, _I, _L, _P, _P, _P, _L, _I, _F, _I, _I, _I, _I, _I, _P, _L, _P],
     "vxm_conv3d_k3_s3u_fwd_kernel": [_L, _L, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3u_bwd_data_ok": [_I, _I, _I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3u_bwd_skip_packed_bytes": [_I, _I, _I],

@@ -177,14 +177,20 @@ __device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS * HAL
 // ---- the same epilogue for a CHANNEL-BLOCKED output tensor [Cout / 8][voxel][8] (and mask, same layout): the 4 channels a lane holds per
 // 16-channel tile are 16 contiguous bytes of a voxel's 32-byte group -- one 16-byte store (and mask load) per row, 512 contiguous bytes
 // per pair of lane groups.  Cout % 8 == 0 (so a lane's 4 channels exist or not together).  Same arithmetic as conv_epilogue_store.
+// Round 6, SIGN tensors (include/vxm_hip.h VXM_S3_MASK_SIGNS / VXM_S3_OUT_SIGNS): LeakyReLU' needs one bit of the activation it is taken at, and
+// the fp32 mask was 35 % of what rem1's backward-data launch moves (0.12 of its 0.68 ms, tools/mask_ab.py).  A sign tensor is [Cout / 4][voxel]
+// bytes, bit j of byte (q, v) = (y[4 q + j][v] > 0): exactly the four channels a lane holds, so a forward epilogue writes one byte per row
+// beside its 16-byte store (lay & OUT_SIGNS: `maskb` is that OUTPUT) and a backward-data epilogue reads one (lay & MASK_SIGNS).  Same products.
 template <int NCT, int ROWS>
 __device__ __forceinline__ void conv_epilogue_store_blocked(f32x4 (&acc)[NCT][ROWS], float* __restrict__ yb, const float (&bz)[NCT][4],
                                                             const float* __restrict__ maskb, float act_slope, float mask_slope, int Cout, int g, int kq,
-                                                            bool vox_ok, int vox, int h0, int H, int W, int V) {
+                                                            bool vox_ok, int vox, int h0, int H, int W, int V, int lay = 0) {
+    const bool sg_out = maskb != nullptr && (lay & VXM_S3_OUT_SIGNS) != 0, sg_in = maskb != nullptr && (lay & VXM_S3_MASK_SIGNS) != 0;      // wave-uniform
     const __amdgpu_buffer_rsrc_t ry = vxm_rsrc(yb, (unsigned)Cout * (unsigned)V * 4u);
-    const __amdgpu_buffer_rsrc_t rm = vxm_rsrc(maskb ? maskb : yb, (unsigned)Cout * (unsigned)V * 4u);
+    const __amdgpu_buffer_rsrc_t rm = vxm_rsrc(maskb ? maskb : yb, (sg_out || sg_in) ? (unsigned)(Cout >> 2) * (unsigned)V : (unsigned)Cout * (unsigned)V * 4u);
     const int cbase = g * NCT * 16 + kq * 4;
     const int voff = (((cbase >> 3) * V + vox) << 5) + ((kq & 1) << 4);
+    const int boff = (cbase >> 2) * V + vox;                     // byte of this lane's four channels in a sign tensor
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
         const bool ok = vox_ok && cbase + 16 * ct < Cout;
@@ -192,7 +198,15 @@ __device__ __forceinline__ void conv_epilogue_store_blocked(f32x4 (&acc)[NCT][RO
         f32x4 mk[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) mk[r] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
-        if (maskb) {
+        if (sg_in) {
+            unsigned sb[ROWS];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) sb[r] = __builtin_amdgcn_raw_buffer_load_b8(rm, ok ? boff : VXM_OOB, 2 * soff_ct + r * W, 0);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mk[r][j] = ((sb[r] >> j) & 1u) ? 1.0f : mask_slope;
+        } else if (maskb && !sg_out) {
 #pragma unroll
             for (int r = 0; r < ROWS; ++r)
                 mk[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, ok ? voff : VXM_OOB, (soff_ct + r * W) << 5, 0));
@@ -211,6 +225,10 @@ __device__ __forceinline__ void conv_epilogue_store_blocked(f32x4 (&acc)[NCT][RO
                     o[j] = (v > 0.0f ? v : v * act_slope) * mk[row][j];
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, ok ? voff : VXM_OOB, (soff_ct + row * W) << 5, 0);
+                if (sg_out) {
+                    const unsigned nib = (o[0] > 0.0f ? 1u : 0u) | (o[1] > 0.0f ? 2u : 0u) | (o[2] > 0.0f ? 4u : 0u) | (o[3] > 0.0f ? 8u : 0u);
+                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, rm, ok ? boff : VXM_OOB, 2 * soff_ct + row * W, 0);
+                }
             }
         }
     }

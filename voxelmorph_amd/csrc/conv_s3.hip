@@ -52,6 +52,12 @@ constexpr int S3_REVERSE_TILES = VXM_S3_REVERSE_TILES;
 //       s0: (0,0) (1,0) | (0,1) (1,1)      s1: (0,2) (1,2) | (2,0) (2,1)      (the last pair is 1 word apart: 6 instead of 4 LDS cycles)
 //   and the remaining unit (kd, kw) = (2, 2) in one ROW-TAP step per output row: lane group kg multiplies tap kh = kg of haloed row
 //   r + kg (kg = 3: zero weights, kg 2's address) -- 7 instead of 9 MFMA sets per output row and 8-channel chunk.
+// mask tensor of sample b: fp32 elements, or -- lay & (VXM_S3_MASK_SIGNS | VXM_S3_OUT_SIGNS) -- the BYTES of a sign tensor (batch stride in bytes)
+__device__ __forceinline__ const float* s3_mask_of_sample(const float* mask, int b, long long mask_bs, int lay) {
+    if (mask == nullptr) return nullptr;
+    if (lay & (VXM_S3_MASK_SIGNS | VXM_S3_OUT_SIGNS)) return reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(mask) + (size_t)b * mask_bs);
+    return mask + (size_t)b * mask_bs;
+}
 struct S3Unit { int kd, kw, cb, valid; };
 __host__ __device__ constexpr S3Unit s3_unit(int CB, int s, int kg) {
     if (CB == 2) {
@@ -403,8 +409,8 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     conv_load_bias<NCT>(bz, bias, Cout, g, kg);
     if (lay & VXM_S3_OUT_BLOCKED) {
         if constexpr (NP == 2 && CB == 1)
-            conv_epilogue_store_blocked<NCT, ROWS>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g,
-                                                   kg, d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V);
+            conv_epilogue_store_blocked<NCT, ROWS>(acc, y + (size_t)cbt * y_bs, bz, s3_mask_of_sample(mask, cbt, mask_bs, lay), act_slope, mask_slope, Cout, g,
+                                                   kg, d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V, lay);
     } else if (S3_DBG(dbg, 8))
         conv_epilogue_store<NCT, ROWS, 1, 2>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
                                              d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V);
@@ -722,8 +728,8 @@ k_s3p_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bi
             for (int r = 0; r < ROWS; ++r) acc[ct][r] *= fin;
         const int d = cd0 + wave, w = cw0 + n;
         if (lay & VXM_S3_OUT_BLOCKED) {
-            conv_epilogue_store_blocked<NCT, ROWS>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g,
-                                                   kg, d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V);
+            conv_epilogue_store_blocked<NCT, ROWS>(acc, y + (size_t)cbt * y_bs, bz, s3_mask_of_sample(mask, cbt, mask_bs, lay), act_slope, mask_slope, Cout, g,
+                                                   kg, d < D && w < W, (d * H + ch0) * W + w, ch0, H, W, V, lay);
         } else
         conv_epilogue_store<NCT, ROWS, 1>(acc, y + (size_t)cbt * y_bs, bz, mask ? mask + (size_t)cbt * mask_bs : nullptr, act_slope, mask_slope, Cout, g, kg,
                                           d < D && w < W && !S3_DBG(dbg, 4), (d * H + ch0) * W + w, ch0, H, W, V);
@@ -1947,7 +1953,10 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
     const int pieces = pieces_and_layout & 0xff, lay = pieces_and_layout & ~0xff;
     VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3_fwd: null pointer");
     VXM_REQUIRE(s3_pieces_ok(pieces), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_s3_fwd: pieces = %d (3: bf16, 2: fp16)", pieces);
-    const int lay_ = lay & ~VXM_S3_REVERSE_TILES;                        // (a scheduling hint, not a layout: taken off before the layout checks)
+    const int sg = lay & (VXM_S3_MASK_SIGNS | VXM_S3_OUT_SIGNS);         // `mask` is a sign tensor (read by a backward-data epilogue / written by a forward one)
+    VXM_REQUIRE(sg == 0 || (sg != (VXM_S3_MASK_SIGNS | VXM_S3_OUT_SIGNS) && mask && (lay & VXM_S3_OUT_BLOCKED) && pieces == 2 && Cout % 8 == 0), VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3_fwd: sign-tensor flags 0x%x need one of the two, a sign tensor in `mask_src`, a channel-blocked output and the fp16 pieces", sg);
+    const int lay_ = lay & ~VXM_S3_REVERSE_TILES & ~sg;                  // (scheduling hint / mask format, not layouts: taken off before the layout checks)
     VXM_REQUIRE(lay_ == 0 || ((lay_ & ~(VXM_S3_IN0_BLOCKED | VXM_S3_OUT_BLOCKED)) == 0 && vxm_conv3d_k3_s3_layout_ok(C0, C1, x0_up, Cout, H, pieces)), VXM_ERR_BAD_SHAPE,
                 "vxm_conv3d_k3_s3_fwd: layout flags 0x%x are not available for this launch (%d + %d -> %d channels, upsampled %d, H = %d, pieces %d)", lay, C0, C1,
                 Cout, x0_up, H, pieces);
@@ -1981,7 +1990,7 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
         // 32 -> 16 0.848 -> 0.809; backward-data launches, whose epilogue waits for the mask it reads, 0.493 -> 0.500 and 0.813 -> 0.836: not routed;
         // requesting the mask under the MFMAs of the tile's last chunk cost the forward launches their gain and did not help these).
         // VXM_S3_PC=0: the alternating kernel everywhere, =1: k_s3p_conv on every eligible launch (tests)
-        if (s3_use_pc(B, D, H, W, mask != nullptr)) {
+        if (s3_use_pc(B, D, H, W, mask != nullptr && sg == 0)) {
             if (blk_in) s3p_launch<1, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s, lay);
             else s3p_launch<1>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s, lay);
         } else {

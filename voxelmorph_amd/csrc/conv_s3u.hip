@@ -80,7 +80,8 @@ struct SuCfg {
 template <int NCT, int NP>
 __global__ void __launch_bounds__(SU_THREADS, 2)
 k_s3u_conv(const float* __restrict__ x0, long long bs0, int C0, const float* __restrict__ x1, long long bs1, int C1, const u32x4* __restrict__ wp,
-           const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout, float act_slope, int B, int D, int H, int W, int lay, int dbg) {
+           const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout, float act_slope, int B, int D, int H, int W, int lay, int dbg,
+           unsigned char* __restrict__ signs, long long signs_bs) {
     using C = SuCfg<NCT, NP>;
     using P = S3P<NP>;
     VXM_DYN_SMEM(u32x4, smem);
@@ -388,6 +389,11 @@ k_s3u_conv(const float* __restrict__ x0, long long bs0, int C0, const float* __r
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry,
                                                            (wv_ < W && ch < Cout) ? ((((ch >> 3) * V + vox) << 5) + ((kg & 1) << 4)) : VXM_OOB, 0, 0);
+                    if (signs) {                                 // the sign tensor of y (include/vxm_hip.h): one byte for this lane's four channels
+                        const unsigned nib = (o[0] > 0.0f ? 1u : 0u) | (o[1] > 0.0f ? 2u : 0u) | (o[2] > 0.0f ? 4u : 0u) | (o[3] > 0.0f ? 8u : 0u);
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(signs + (size_t)cbt * signs_bs, 0, (Cout >> 2) * V, 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, rs, (wv_ < W && ch < Cout) ? (ch >> 2) * V + vox : VXM_OOB, 0, 0);
+                    }
                 }
             }
         }
@@ -446,7 +452,8 @@ static_assert(SUP_LDS_BYTES <= 160 * 1024, "k_s3u_conv_pc: LDS");
 template <int NCT>
 __global__ void __launch_bounds__(SUP_THREADS)
 k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* __restrict__ x1, long long bs1, int C1, const u32x4* __restrict__ wp,
-              const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout, float act_slope, int B, int D, int H, int W, int lay, int dbg) {
+              const float* __restrict__ bias, float* __restrict__ y, long long y_bs, int Cout, float act_slope, int B, int D, int H, int W, int lay, int dbg,
+              unsigned char* __restrict__ signs, long long signs_bs) {
     constexpr int NP = 2;
     using P = S3P<NP>;
     VXM_DYN_SMEM(u32x4, smem);
@@ -646,6 +653,11 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
                             }
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry,
                                                                    (wv_ < W && ch < Cout) ? ((((ch >> 3) * V + vox) << 5) + ((kg & 1) << 4)) : VXM_OOB, 0, 0);
+                            if (signs) {                         // the sign tensor of y (include/vxm_hip.h): one byte for this lane's four channels
+                                const unsigned nib = (o[0] > 0.0f ? 1u : 0u) | (o[1] > 0.0f ? 2u : 0u) | (o[2] > 0.0f ? 4u : 0u) | (o[3] > 0.0f ? 8u : 0u);
+                                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(signs + (size_t)cbt * signs_bs, 0, (Cout >> 2) * V, 0x00020000);
+                                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, rs, (wv_ < W && ch < Cout) ? (ch >> 2) * V + vox : VXM_OOB, 0, 0);
+                            }
                         }
                     }
                 }
@@ -1966,7 +1978,7 @@ bool su_pc_ok(long long bs0, long long bs1, int D, int H, int W) {
 
 template <int NCT, int NP>
 void su_launch(const float* x0, long long bs0, int C0, const float* x1, long long bs1, int C1, const void* wp, const float* bias, float* y,
-               long long y_bs, int Cout, float slope, int B, int D, int H, int W, hipStream_t s, int lay) {
+               long long y_bs, int Cout, float slope, int B, int D, int H, int W, hipStream_t s, int lay, unsigned char* signs = nullptr, long long signs_bs = 0) {
     using C = SuCfg<NCT, NP>;
     static const bool attr = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_s3u_conv<NCT, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
@@ -1992,12 +2004,12 @@ void su_launch(const float* x0, long long bs0, int C0, const float* x1, long lon
             }();
             (void)attr2;
             hipLaunchKernelGGL((k_s3u_conv_pc<NCT>), dim3(gx, G), dim3(SUP_THREADS), SUP_LDS_BYTES, s, x0, bs0, C0, x1, bs1, C1, static_cast<const u32x4*>(wp),
-                               bias, y, y_bs, Cout, slope, B, D, H, W, lay, su_dbg());
+                               bias, y, y_bs, Cout, slope, B, D, H, W, lay, su_dbg(), signs, signs_bs);
             return;
         }
     }
     hipLaunchKernelGGL((k_s3u_conv<NCT, NP>), dim3(gx, G), dim3(SU_THREADS), C::LDS_BYTES, s, x0, bs0, C0, x1, bs1, C1, static_cast<const u32x4*>(wp),
-                       bias, y, y_bs, Cout, slope, B, D, H, W, lay, su_dbg());
+                       bias, y, y_bs, Cout, slope, B, D, H, W, lay, su_dbg(), signs, signs_bs);
 }
 
 
@@ -2106,8 +2118,17 @@ int vxm_conv3d_k3_s3u_pack_weights(const float* w, void* wpacked, int C0, int C1
 int vxm_conv3d_k3_s3u_fwd(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const void* wpacked,
                           const float* bias, float* y, int64_t y_bstride, int Cout, float leaky_slope, int B, int D, int H, int W, int pieces_and_layout,
                           void* stream) {
+    return vxm_conv3d_k3_s3u_fwd_signs(x0, C0, x0_bstride, x1, C1, x1_bstride, wpacked, bias, y, y_bstride, Cout, leaky_slope, B, D, H, W, pieces_and_layout,
+                                       nullptr, 0, stream);
+}
+
+int vxm_conv3d_k3_s3u_fwd_signs(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const void* wpacked,
+                                const float* bias, float* y, int64_t y_bstride, int Cout, float leaky_slope, int B, int D, int H, int W, int pieces_and_layout,
+                                unsigned char* signs, int64_t signs_bstride, void* stream) {
     const int pieces = pieces_and_layout & 0xff, lay = pieces_and_layout & ~0xff;
     VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_s3u_fwd: null pointer");
+    VXM_REQUIRE(signs == nullptr || (lay == VXM_S3_OUT_BLOCKED && Cout % 8 == 0), VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_s3u_fwd_signs: the sign tensor goes with a channel-blocked output");
     VXM_REQUIRE(lay == 0 || (lay == VXM_S3_OUT_BLOCKED && Cout % 8 == 0), VXM_ERR_BAD_SHAPE,
                 "vxm_conv3d_k3_s3u_fwd: layout flags 0x%x (only the output may be channel-blocked; Cout = %d in multiples of 8)", lay, Cout);
     if (int e = check_conv("vxm_conv3d_k3_s3u_fwd", C0, C1, 1, Cout, B, D, H, W)) return e;
@@ -2118,8 +2139,8 @@ int vxm_conv3d_k3_s3u_fwd(const float* x0, int C0, int64_t x0_bstride, const flo
     const int NCT = su_nct(Cout);
 #define SU_GO(NCT_)                                                                                                                  \
     do {                                                                                                                             \
-        if (pieces == 2) su_launch<NCT_, 2>(x0, x0_bstride, C0, x1, x1_bstride, C1, wpacked, bias, y, y_bstride, Cout, leaky_slope, B, D, H, W, s, lay); \
-        else su_launch<NCT_, 3>(x0, x0_bstride, C0, x1, x1_bstride, C1, wpacked, bias, y, y_bstride, Cout, leaky_slope, B, D, H, W, s, lay);            \
+        if (pieces == 2) su_launch<NCT_, 2>(x0, x0_bstride, C0, x1, x1_bstride, C1, wpacked, bias, y, y_bstride, Cout, leaky_slope, B, D, H, W, s, lay, signs, signs_bstride); \
+        else su_launch<NCT_, 3>(x0, x0_bstride, C0, x1, x1_bstride, C1, wpacked, bias, y, y_bstride, Cout, leaky_slope, B, D, H, W, s, lay, signs, signs_bstride);            \
     } while (0)
     if (NCT == 2) SU_GO(2); else SU_GO(1);
 #undef SU_GO

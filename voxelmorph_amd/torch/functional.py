@@ -606,14 +606,18 @@ def s3u_pack(w, c0, c1):
     return wp
 
 
-def s3u_launch(x0, c0, bs0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, B, D, H, W, lay=0):
+def s3u_launch(x0, c0, bs0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, B, D, H, W, lay=0, signs=None):
     name = None
     if _prof.ACTIVE is not None:
         pc = _lib.lib().vxm_conv3d_k3_s3u_fwd_kernel(bs0, bs1, D, H, W, s3_pieces())
         name = ("k_s3u_conv_pc<%d>" % (1 if cout <= 16 else 2)) if pc else "k_s3u_conv<%d,%d>" % (1 if cout <= 16 else 2, s3_pieces())
     with _prof.region(name, flops=2.0 * (8 * c0 + 27 * c1) * cout * B * D * H * W, nominal=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
-        call("vxm_conv3d_k3_s3u_fwd", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W,
-             s3_pieces() | lay, stream())
+        if signs is not None:
+            call("vxm_conv3d_k3_s3u_fwd_signs", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W,
+                 s3_pieces() | lay, ptr(signs), (cout // 4) * D * H * W, stream())
+        else:
+            call("vxm_conv3d_k3_s3u_fwd", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W,
+                 s3_pieces() | lay, stream())
 
 
 def s3u_bwd_low_route(c0, cout, B, D, H, W):
@@ -680,6 +684,10 @@ def s3u_bwd_data(dz, cout, w, c0, c1, gxl, mask, mask_slope, gx1, B, D, H, W, la
 # layout flags of include/vxm_hip.h (OR-ed into `pieces`): a flagged tensor is channel-blocked [B][C/8][D][H][W][8]
 S3_IN0_BLOCKED, S3_IN1_BLOCKED, S3_OUT_BLOCKED = 0x100, 0x200, 0x400
 S3_REVERSE_TILES = 0x4000                                     # scheduling hint of vxm_conv3d_k3_s3_fwd (include/vxm_hip.h)
+S3_MASK_SIGNS, S3_OUT_SIGNS = 0x8000, 0x10000                 # sign tensors (include/vxm_hip.h): [B][C/4][D][H][W] bytes, bit j = (y[4 q + j] > 0)
+# channel-blocked activations of the fused U-Net get a sign tensor from their forward epilogue; the backward-data epilogue that applies their
+# LeakyReLU' reads it instead of the fp32 activation (round 6: that mask was 0.12 of rem1's 0.68 ms and 0.045 of rem2's 0.375).  VXM_S3_SIGNS=0: off
+SIGNS = os.environ.get("VXM_S3_SIGNS", "1") != "0"
 # consecutive full-resolution launches of the fused U-Net walk their tensors in alternating directions (a consumer starts where its producer
 # stopped: the last-written part of a 440 - 880 MB tensor is what the 256 MB memory-side cache still holds); VXM_S3_SNAKE=0: all forward
 SNAKE = os.environ.get("VXM_S3_SNAKE", "1") != "0"
@@ -702,7 +710,7 @@ def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask
     name = None
     if _prof.ACTIVE is not None:          # label the region with the kernel the C ABI will dispatch to
         rows = _lib.lib().vxm_conv3d_k3_s3_tile_rows(cout, s3_pieces(), H)
-        pc = _lib.lib().vxm_conv3d_k3_s3_producer_consumer(cout, s3_pieces(), 0 if mask is None else 1, B, D, H, W)
+        pc = _lib.lib().vxm_conv3d_k3_s3_producer_consumer(cout, s3_pieces(), 0 if (mask is None or lay & (S3_MASK_SIGNS | S3_OUT_SIGNS)) else 1, B, D, H, W)
         name = "k_s3p_conv<%d,%d>" % (v // 10, s3_pieces()) if pc else "k_s3_conv<%d,%d,%d,%d>" % (v // 10, rows, v % 10, s3_pieces())
     with _prof.region(name, flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         call("vxm_conv3d_k3_s3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
@@ -726,7 +734,7 @@ def _need_split_kernel(lay, what):
                            "tensors whose producer and consumers run on them" % (what, lay))
 
 
-def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B, D, H, W, lay=0):
+def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B, D, H, W, lay=0, signs=None):
     """ConvBlock / flow conv forward (networks.py:299-305, 211,257) from the reference-layout weights: the MFMA implicit
     GEMM (weights packed per call), or the vector-ALU kernel when there are at most 4 output channels (flow conv).
     lay: S3_IN0_BLOCKED (x0) / S3_OUT_BLOCKED (y) for channel-blocked tensors between split kernels (fused U-Net only)."""
@@ -734,11 +742,17 @@ def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B,
         with _prof.region("k_conv3d_k3_fewout<%d>" % cout, flops=2.0 * 27 * c0 * cout * B * D * H * W):
             call("vxm_conv3d_k3_fewout_fwd", ptr(x0), c0, bs0, ptr(_c(w)), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W, stream())
         return
+    if signs is not None and not (lay & S3_OUT_BLOCKED):
+        raise RuntimeError("conv_forward: a sign tensor goes with a channel-blocked output")
     if up0 and s3u_route(c0, c1, cout, B, D, H, W):
-        s3u_launch(x0, c0, bs0, x1, c1, bs1, s3u_pack(w, c0, c1), bias, y, ybs, cout, slope, B, D, H, W, lay=lay)
+        s3u_launch(x0, c0, bs0, x1, c1, bs1, s3u_pack(w, c0, c1), bias, y, ybs, cout, slope, B, D, H, W, lay=lay, signs=signs)
         return
     if s3_route(c0, up0, c1, cout, B, D, H, W):
-        s3_launch(x0, c0, bs0, up0, x1, c1, bs1, s3_pack(w, False, 0, c0 + c1, c0), bias, y, ybs, cout, slope, None, 0, 1.0, B, D, H, W, lay=lay)
+        if signs is not None:        # (a forward launch has no mask: the sign tensor of its output travels in that argument, flag OUT_SIGNS)
+            s3_launch(x0, c0, bs0, up0, x1, c1, bs1, s3_pack(w, False, 0, c0 + c1, c0), bias, y, ybs, cout, slope, signs, (cout // 4) * D * H * W, 1.0,
+                      B, D, H, W, lay=lay | S3_OUT_SIGNS)
+        else:
+            s3_launch(x0, c0, bs0, up0, x1, c1, bs1, s3_pack(w, False, 0, c0 + c1, c0), bias, y, ybs, cout, slope, None, 0, 1.0, B, D, H, W, lay=lay)
         return
     _need_split_kernel(lay, "conv_forward")
     if up0 and _lib.lib().vxm_conv3d_k3_up_ok(ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(y), cout, B, D, H, W):
@@ -764,6 +778,10 @@ def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W, w_lo=0, la
         if s3_route(cout, False, 0, hi - lo, B, D, H, W):
             if lay & S3_OUT_BLOCKED and (lo, hi) != (0, cin):   # (S3_REVERSE_TILES needs no such care: every launch of the pair walks backwards)
                 raise RuntimeError("conv_bwd_data: a channel-blocked gradient is written by one launch")
+            if lay & S3_MASK_SIGNS:      # `mask` is the sign tensor [B][cin / 4][D][H][W] (bytes) of the activation; one launch (blocked output)
+                s3_launch(dz, cout, cout * V, False, None, 0, 0, s3_pack(w, True, w_lo + lo, w_lo + hi, cout), None, gx, cin * V, cin,
+                          1.0, mask, (cin // 4) * V, mask_slope, B, D, H, W, lay=lay)
+                continue
             s3_launch(dz, cout, cout * V, False, None, 0, 0, s3_pack(w, True, w_lo + lo, w_lo + hi, cout), None, gx[:, lo:hi], cin * V, hi - lo,
                       1.0, mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W, lay=lay)
             continue
@@ -1272,6 +1290,7 @@ class UnetFn(torch.autograd.Function):
         ready = [None, None, None]               # events: the operators of group A / B1 / B2 are built (second stream, in that order)
         first = [len(plan.ops)] * 3
         packs_late = False
+        want_bwd = any(ctx.needs_input_grad[1:])
         if split_engine():
             # The packed operators (weight scales, pre-split pieces, collapsed upsample operators: ~27 small launches, 0.2 ms in a row) are
             # rebuilt once per optimiser step.  They go to the second stream and run beside the layers that do not read them; the main stream
@@ -1309,6 +1328,7 @@ class UnetFn(torch.autograd.Function):
                 _prepack_plan(plan, params, B, shape3, want_bwd, want_in)
                 _adopt_fresh_packs(None)
         blocked = _blocked_tensors(plan, B, shape3)
+        SG = {}                      # tensor id -> sign tensor of a channel-blocked activation (S3_OUT_SIGNS / S3_MASK_SIGNS)
         walked_back = set()          # tensors whose producer walked its tiles from the end (S3_REVERSE_TILES)
         for n_op, op in enumerate(plan.ops):
             if packs_late and n_op >= 1:
@@ -1335,8 +1355,13 @@ class UnetFn(torch.autograd.Function):
                         and s3_route(plan.ch[s0], False, 0, plan.ch[dst], B, D, H, W):
                     lay |= S3_REVERSE_TILES
                     walked_back.add(dst)
+                sg = None
+                if SIGNS and want_bwd and dst in blocked and op["slope"] != 1.0 and plan.ch[dst] % 8 == 0 and s3_pieces() == 2:
+                    # the one reader of this activation's sign is the backward-data epilogue of its consumer (a blocked split launch, or it
+                    # would not be in `blocked`): one byte per four channels and voxel instead of the fp32 tensor there
+                    sg = SG[dst] = torch.empty((B, plan.ch[dst] // 4, D, H, W), dtype=torch.uint8, device=dev)
                 conv_forward(x0, plan.ch[s0], x0[0].numel(), up0, x1, plan.ch[s1] if s1 is not None else 0,
-                             x1[0].numel() if x1 is not None else 0, w, b, out, plan.ch[dst] * V, plan.ch[dst], op["slope"], B, D, H, W, lay=lay)
+                             x1[0].numel() if x1 is not None else 0, w, b, out, plan.ch[dst] * V, plan.ch[dst], op["slope"], B, D, H, W, lay=lay, signs=sg)
             elif op["kind"] == "pool":
                 src = T[op["src"]]
                 sD, sH, sW = src.shape[2:]
@@ -1356,7 +1381,7 @@ class UnetFn(torch.autograd.Function):
             torch.cuda.current_stream(dev).wait_event(ready[2])
         out = T.pop(plan.out)
         ctx.save_for_backward(out)
-        ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B, ctx.blocked = plan, T, params, shape3, B, blocked
+        ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B, ctx.blocked, ctx.SG = plan, T, params, shape3, B, blocked, SG
         # activations and parameters are held as plain attributes (the returned tensor alone goes through
         # save_for_backward, see above), so autograd's version-counter check is done by hand in backward
         # (inference tensors -- torch.inference_mode() -- carry no version counter and can never reach backward)
@@ -1365,7 +1390,7 @@ class UnetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        plan, params, shape3, B, blocked = ctx.plan, ctx.params, ctx.shape3, ctx.B, ctx.blocked
+        plan, params, shape3, B, blocked, SG = ctx.plan, ctx.params, ctx.shape3, ctx.B, ctx.blocked, ctx.SG
         if ctx.T is None:
             raise RuntimeError("UnetFn: backward a second time: the saved activations were released by the first pass "
                                "(a retained graph is not supported by the fused engine)")
@@ -1561,8 +1586,11 @@ class UnetFn(torch.autograd.Function):
                     if SNAKE and plan.lvl[dst] == 0 and dst not in dz_back and _bwd_bounds(cin) == [0, cin] and s3_route(cout, False, 0, cin, B, D, H, W):
                         rev = S3_REVERSE_TILES          # (dropped by conv_bwd_data when the launch is not a split kernel's)
                         dz_back.add(s0)
-                    conv_bwd_data(dz, cout, w, gx, cin, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W,
-                                  lay=lay_d | (S3_OUT_BLOCKED if x_blk else 0) | rev)
+                    if x_blk and pslope != 1.0 and s0 in SG and _bwd_bounds(cin) == [0, cin] and s3_route(cout, False, 0, cin, B, D, H, W):
+                        conv_bwd_data(dz, cout, w, gx, cin, SG[s0], pslope, B, D, H, W, lay=lay_d | S3_OUT_BLOCKED | S3_MASK_SIGNS | rev)
+                    else:
+                        conv_bwd_data(dz, cout, w, gx, cin, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W,
+                                      lay=lay_d | (S3_OUT_BLOCKED if x_blk else 0) | rev)
                     DZ[s0] = gx
                     continue
                 if x_blk:
