@@ -157,8 +157,13 @@ def hbm_traffic(kernel, launches_per_step, suffix=""):
         return None, "%s unreadable" % rel
     kernel_ns = kernel.replace(" ", "")
     stem = kernel_ns[:-1] if kernel_ns.endswith(">") else kernel_ns
-    hits = {k: v for k, v in ctr.items() if k.replace(" ", "") == kernel_ns or k.replace(" ", "").startswith(stem + ",")}
-    hits = {k: v for k, v in hits.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+    while True:            # a region label carries (some of) the template arguments of its kernel, not always in the instance's terms ("k_s3p_conv<1,2>" =
+        # NCT, pieces against the instances "k_s3p_conv<1, true>" / "<1, false>" = NCT, BLK): drop trailing arguments until something matches -- never the first
+        hits = {k: v for k, v in ctr.items() if k.replace(" ", "") == kernel_ns or k.replace(" ", "").startswith(stem + ",") or k.replace(" ", "").startswith(stem + ">")}
+        hits = {k: v for k, v in hits.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+        if hits or "<" not in stem or "," not in stem[stem.index("<"):]:
+            break
+        stem = stem[:stem.rindex(",")]
     if not hits:
         return None, "%s has no counters for %s (collected on another engine / configuration, or stale: tools/profile_bench.sh)" % (rel, kernel)
     n = sum(v["FETCH_SIZE"]["dispatches"] for v in hits.values())
