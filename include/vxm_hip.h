@@ -432,6 +432,22 @@ int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W);
 #define VXM_S3_OUT_SIGNS 0x10000
 #define VXM_S3_BW_CONTRACT_ONLY 0x1000
 #define VXM_S3_BW_REDUCE_ONLY 0x2000
+/* Round 6, late: the layout flags at the few-channel kernels either side of the LAST ConvBlock of the fused U-Net (networks.py:211,257: the
+ * 16 -> 3 flow conv reads that block's output; its backward-data writes the block's gradient; its weight gradient reads the output again), so
+ * that this activation, its gradient and its LeakyReLU mask can take the channel-blocked / sign-tensor form too.  Same values, same arithmetic
+ * in the same order as the planar launches: bit-identical results.
+ *   vxm_conv3d_k3_fewout_fwd_layout: vxm_conv3d_k3_fewout_fwd with `layout` = VXM_S3_IN0_BLOCKED (x channel-blocked; Cin % 8 == 0) or 0.
+ *   vxm_conv3d_k3_fwd_layout: vxm_conv3d_k3_fwd with `layout` = VXM_S3_OUT_BLOCKED (y channel-blocked, and mask_src in the same layout) optionally
+ *     | VXM_S3_MASK_SIGNS (mask_src is the sign tensor of the activation, mask_bstride in bytes), or 0.  Flags are accepted where
+ *     vxm_conv3d_k3_fwd_layout_ok returns 1: launches the few-input-channel kernel takes (C0 + C1 <= 4, W % 4 == 0, aligned) with Cout % 8 == 0.
+ *   vxm_conv3d_k3_fewch_bwd_weight: `pieces` may carry VXM_S3_IN0_BLOCKED when x0 is the 16-channel operand (flow conv: C0 = 16, C1 = 0, Cout <= 3). */
+int vxm_conv3d_k3_fewout_fwd_layout(const float* x, int Cin, int64_t x_bstride, const float* w, const float* bias, float* y,
+                                    int64_t y_bstride, int Cout, float act_slope, int B, int D, int H, int W, int layout, void* stream);
+int vxm_conv3d_k3_fwd_layout_ok(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* wpacked,
+                                int Cout, int B, int D, int H, int W);
+int vxm_conv3d_k3_fwd_layout(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
+                             const float* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope,
+                             const float* mask_src, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, int layout, void* stream);
 int vxm_conv3d_k3_s3_layout_ok(int C0, int C1, int x0_up, int Cout, int H, int pieces);
 int vxm_conv3d_k3_s3_variant(int Cout);                     /* 10 * NCT + CB of the kernel instance (profiling labels) */
 int vxm_conv3d_k3_s3_tile_rows(int Cout, int pieces, int H); /* rows of its output tile: 8 x 8 x 16 on the fp16 scheme, else 8 x 4 x 16 */

@@ -1233,7 +1233,7 @@ def test_channel_blocked_interior_tensors_change_no_bit_of_the_step(vxm):
         pytest.skip("channel-blocked tensors exist on the fp16 piece scheme only")
     keep, keep_signs = VF.BLOCKED, VF.SIGNS
     try:
-        for shape, B, expect in ((FULL, 1, 2), ((64, 96, 128), 2, 1)):
+        for shape, B, expect in ((FULL, 1, 3), ((64, 96, 128), 2, 1)):          # (3: rem0, rem1 and -- round 6, late -- the last activation, read by the flow conv)
             rng = np.random.default_rng(77)
             src, trg = G(rng.random((B, 1) + shape)), G(rng.random((B, 1) + shape))
             torch.manual_seed(3)

@@ -512,6 +512,76 @@ def test_s3_backward_weight_channel_blocked_operands_bit_exact(VF16, c, cout, vo
             assert _eq(g0, g1) and _eq(b0, b1), (B, hex(lay))
 
 
+@pytest.mark.parametrize("vol,B", [((16, 32, 64), 2), ((24, 36, 72), 1), ((9, 50, 96), 1)])
+def test_few_channel_kernels_channel_blocked_operands_bit_exact(VF16, vol, B):
+    """Round 6, late: the kernels either side of the LAST ConvBlock of the fused U-Net take the layout flags, so that its activation, gradient and
+    LeakyReLU mask can be channel-blocked / a sign tensor too (include/vxm_hip.h: vxm_conv3d_k3_fewout_fwd_layout, vxm_conv3d_k3_fwd_layout,
+    VXM_S3_IN0_BLOCKED of vxm_conv3d_k3_fewch_bwd_weight).  The 16 -> 1..3 forward (networks.py:211,257) from a blocked x, its adjoint 3 -> 16 onto
+    a blocked gradient with the mask blocked or as signs (8 x 4 x 16 and 8 x 2 x 32 tiles, partial tiles), and its weight gradient from a blocked
+    x: every result bit-identical to the planar launch."""
+    VF = VF16
+    from voxelmorph_amd import _lib
+    D, H, W = vol
+    V = D * H * W
+    torch.manual_seed(D + H + W)
+    x = torch.randn(B, 16, D, H, W, device="cuda")
+    xb = VF.to_blocked(x)
+    for cout in (3, 1, 2):
+        w = torch.randn(cout, 16, 3, 3, 3, device="cuda") / (27 * 16) ** 0.5
+        bias = torch.randn(cout, device="cuda")
+        y0, y1 = torch.empty(B, cout, D, H, W, device="cuda"), torch.full((B, cout, D, H, W), float("nan"), device="cuda")
+        VF.conv_forward(x, 16, 16 * V, False, None, 0, 0, w, bias, y0, cout * V, cout, 1.0, B, D, H, W)
+        VF.conv_forward(xb, 16, 16 * V, False, None, 0, 0, w, bias, y1, cout * V, cout, 1.0, B, D, H, W, lay=VF.S3_IN0_BLOCKED)
+        assert torch.equal(y0, y1), ("forward", cout)
+        # the adjoint onto the 16 channels, LeakyReLU'(act) in the epilogue
+        dz = torch.randn(B, cout, D, H, W, device="cuda")
+        act = torch.randn(B, 16, D, H, W, device="cuda")
+        act[:, :, ::3] = 0.0
+        signs = sum(((act[:, j::4] > 0).to(torch.uint8) << j) for j in range(4)).contiguous()
+        wpk = VF.pack_weights_cached(w, True, 0, 16)
+        assert _lib.lib().vxm_conv3d_k3_fwd_variant(VF.ptr(dz), cout, cout * V, None, 0, 0, VF.ptr(wpk), 16, B, D, H, W) >= 200      # the few-input-channel kernel
+        g0 = torch.empty(B, 16, D, H, W, device="cuda")
+        VF.conv_bwd_data(dz, cout, w, g0, 16, act, 0.2, B, D, H, W)
+        for lay, mk in ((VF.S3_OUT_BLOCKED, VF.to_blocked(act)), (VF.S3_OUT_BLOCKED | VF.S3_MASK_SIGNS, signs), (VF.S3_OUT_BLOCKED, None)):
+            g1 = torch.full((B, 16, D, H, W), float("nan"), device="cuda")
+            if mk is None:
+                gref = torch.empty(B, 16, D, H, W, device="cuda")
+                VF.conv_bwd_data(dz, cout, w, gref, 16, None, 1.0, B, D, H, W)
+            else:
+                gref = g0
+            VF.conv_bwd_data(dz, cout, w, g1, 16, mk, 0.2 if mk is not None else 1.0, B, D, H, W, lay=lay)
+            assert torch.equal(gref, VF.from_blocked(g1)), ("backward-data", cout, hex(lay), mk is None)
+        # weight / bias gradient
+        ws = VF._Workspace(x.device)
+        gw0, gb0 = torch.empty_like(w), torch.empty_like(bias)
+        gw1, gb1 = torch.full_like(w, float("nan")), torch.full_like(bias, float("nan"))
+        VF.conv_bwd_weight(ws, x, 16, 16 * V, False, None, 0, 0, dz, cout, gw0, gb0, B, D, H, W)
+        VF.conv_bwd_weight(ws, xb, 16, 16 * V, False, None, 0, 0, dz, cout, gw1, gb1, B, D, H, W, lay=VF.S3_IN0_BLOCKED)
+        assert torch.equal(gw0, gw1) and torch.equal(gb0, gb1), ("backward-weight", cout)
+        assert rel_l2(gw0.cpu(), torch.nn.grad.conv3d_weight(x.double().cpu(), w.shape, dz.double().cpu(), padding=1)) < 1e-5
+
+
+def test_few_channel_layout_flags_are_refused_where_they_do_not_apply(VF16):
+    VF = VF16
+    D, H, W = 8, 8, 32
+    V = D * H * W
+    x = torch.randn(1, 12, D, H, W, device="cuda")
+    w = torch.randn(3, 12, 3, 3, 3, device="cuda")
+    y = torch.empty(1, 3, D, H, W, device="cuda")
+    with pytest.raises(Exception, match="layout flags"):
+        VF.call("vxm_conv3d_k3_fewout_fwd_layout", VF.ptr(x), 12, 12 * V, VF.ptr(w), None, VF.ptr(y), 3 * V, 3, 1.0, 1, D, H, W, VF.S3_IN0_BLOCKED, VF.stream())
+    x = torch.randn(1, 16, D, H, W, device="cuda")                 # 16 input channels: not the few-input-channel kernel
+    w = torch.randn(16, 16, 3, 3, 3, device="cuda")
+    y = torch.empty(1, 16, D, H, W, device="cuda")
+    with pytest.raises(Exception, match="layout flags"):
+        VF.conv_launch(x, 16, 16 * V, False, None, 0, 0, VF.pack_weights(w, False), None, y, 16 * V, 16, 0.2, None, 0, 1.0, 1, D, H, W, lay=VF.S3_OUT_BLOCKED)
+    x2, dz = torch.randn(1, 1, D, H, W, device="cuda"), torch.randn(1, 16, D, H, W, device="cuda")
+    ws = VF._Workspace(x.device)
+    with pytest.raises(Exception, match="layout flags|channel-blocked"):   # the first block (2 -> 16): its 16-channel operand is dz, not x0
+        VF.conv_bwd_weight(ws, x2, 1, V, False, x2, 1, V, dz, 16, torch.empty(16, 2, 3, 3, 3, device="cuda"), torch.empty(16, device="cuda"), 1, D, H, W,
+                           lay=VF.S3_IN0_BLOCKED)
+
+
 @pytest.mark.parametrize("vol", [(8, 8, 32), (10, 12, 36), (16, 24, 64)])
 @pytest.mark.parametrize("c0,c1,cout", [(32, 16, 32), (16, 16, 16), (32, 32, 32), (16, 8, 24)])
 def test_s3u_kernels_channel_blocked_operands_bit_exact(VF16, c0, c1, cout, vol):

@@ -58,6 +58,9 @@ SIGNATURES = {
     "vxm_conv3d_k3_up_bwd_low": [_P, _L, _I, _P, _I, _I, _P, _P, _L, _P, _L, _F, _I, _I, _I, _I, _P],
     "vxm_conv3d_k3_fewout_ok": [_P, _L, _P, _L, _I, _I, _I],
     "vxm_conv3d_k3_fewout_fwd": [_P, _I, _L, _P, _P, _P, _L, _I, _F, _I, _I, _I, _I, _P],
+    "vxm_conv3d_k3_fewout_fwd_layout": [_P, _I, _L, _P, _P, _P, _L, _I, _F, _I, _I, _I, _I, _I, _P],
+    "vxm_conv3d_k3_fwd_layout_ok": [_P, _I, _L, _P, _I, _L, _P, _I, _I, _I, _I, _I],
+    "vxm_conv3d_k3_fwd_layout": [_P, _I, _L, _I, _P, _I, _L, _P, _P, _P, _L, _I, _F, _P, _L, _F, _I, _I, _I, _I, _I, _P],
     "vxm_conv3d_k3_fwd_variant": [_P, _I, _L, _P, _I, _L, _P, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_bwd_weight_variant": [_P, _I, _L, _I, _P, _I, _L, _P, _L, _I, _I, _I, _I],
     "vxm_conv3d_k3_bwd_weight_workspace_bytes": [_I, _I, _I, _I, _I, _I],

@@ -930,7 +930,11 @@ constexpr int FH_STAGE = 2 * FH_PPIECE + 2 * FH_SPIECE + FH_TAB * 4;
 constexpr int FH_LDS = FH_STAGE > FH_WAVES * 16 * 96 * 4 ? FH_STAGE : FH_WAVES * 16 * 96 * 4;
 static_assert(FH_LDS <= 52 * 1024, "three blocks of k_fewch_bwd_weight_h per CU");
 
-template <int NT>
+// PBLK (round 6, late): P is CHANNEL-BLOCKED [2][voxel][8] (VXM_S3_IN0_BLOCKED: the flow conv's x when the fused U-Net keeps its last activation
+// blocked).  A thread then fetches the 16 channels of ONE voxel (four 16-byte loads, as many as before); W-neighbour lanes swap halves of
+// their channels (DPP quad_perm), so that the even lane owns channels 0 .. 7 and the odd lane channels 8 .. 15 of the voxel PAIR and each writes
+// the same packed fp16 words to the same LDS places as the planar staging -- every later instruction and every bit of the result is unchanged.
+template <int NT, bool PBLK = false>
 __global__ void __launch_bounds__(FH_THREADS, 3) k_fewch_bwd_weight_h(FcIn in, int cs, int flip, int want_bias, float* __restrict__ part, int B, int D,
                                                                      int H, int W) {
     using P2 = S3P<2>;
@@ -986,10 +990,17 @@ __global__ void __launch_bounds__(FH_THREADS, 3) k_fewch_bwd_weight_h(FcIn in, i
         int dead = t < ntiles ? 0 : VXM_OOB;                     // past the last tile: every lane out of range (branch-free)
         asm volatile("" : "+v"(dead));
         const __amdgpu_buffer_rsrc_t rp = vxm_rsrc(in.P + (size_t)b * in.p_bs, 16u * (unsigned)V * 4u);
+        if constexpr (PBLK) {                                   // thread = voxel (row tid >> 5, column tid & 31): pv[j] = its channels 4 j .. 4 j + 3
+            const int gh = h0 + (tid >> 5), gw = w0 + (tid & 31);
+            const int pvoff = ((gh < H && gw < W) ? (d * HW + gh * W + gw) << 5 : VXM_OOB) | dead;
+#pragma unroll
+            for (int j = 0; j < NPV; ++j) pv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, pvoff, ((j >> 1) * V << 5) + ((j & 1) << 4), 0));
+        } else {
         const int gh = h0 + prow, gw = w0 + 4 * pw4;
         const int pvoff = ((gh < H && gw < W) ? (pm0 * V + d * HW + gh * W + gw) << 2 : VXM_OOB) | dead;   // W % 4 == 0: a float4 is inside or outside the row
 #pragma unroll
         for (int j = 0; j < NPV; ++j) pv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, pvoff, (4 * j * V) << 2, 0));
+        }
         const __amdgpu_buffer_rsrc_t r0 = vxm_rsrc(in.S0 + (size_t)b * in.s0_bs, (unsigned)in.cs0 * (unsigned)V * 4u);
         const __amdgpu_buffer_rsrc_t r1 = vxm_rsrc(cs > in.cs0 ? in.S1 + (size_t)b * in.s1_bs : in.S0, (unsigned)(cs > in.cs0 ? cs - in.cs0 : in.cs0) * (unsigned)V * 4u);
         // the pair (w0 - 1 + 2 q, w0 + 2 q): the first element of pair 0 of the first tile column (w = -1) and the second of pair 16 of the
@@ -1040,6 +1051,20 @@ __global__ void __launch_bounds__(FH_THREADS, 3) k_fewch_bwd_weight_h(FcIn in, i
         inv_next = iP * iS; invP_next = iP;
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
+        if constexpr (PBLK) {
+            const bool odd = (tid & 1) != 0;
+            char* const dst0 = Ps + ((odd ? 8 : 0) * FH_PST + (tid >> 5) * FH_TW + (tid & 30)) * 2;     // channel 0 / 8 of the voxel pair (w & ~1, w | 1)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float mine_lo = pv[i >> 2][i & 3], mine_hi = pv[2 + (i >> 2)][i & 3];             // this voxel's channels i and 8 + i
+                const float give = odd ? mine_lo : mine_hi;
+                const float got = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(give), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+                unsigned h_, l_;
+                s3_split2_f16(odd ? got : mine_lo, odd ? mine_hi : got, sP, h_, l_);                    // (voxel w & ~1, voxel w | 1) of channel i + (odd ? 8 : 0)
+                *reinterpret_cast<unsigned*>(dst0 + i * FH_PST * 2) = h_;
+                *reinterpret_cast<unsigned*>(dst0 + i * FH_PST * 2 + FH_PPIECE) = l_;
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < NPV; ++j) {
             unsigned h0_, l0_, h1_, l1_;
@@ -1048,6 +1073,7 @@ __global__ void __launch_bounds__(FH_THREADS, 3) k_fewch_bwd_weight_h(FcIn in, i
             char* const dst = Ps + ((pm0 + 4 * j) * FH_PST + prow * FH_TW + 4 * pw4) * 2;
             *reinterpret_cast<u32x2*>(dst) = (u32x2){h0_, h1_};
             *reinterpret_cast<u32x2*>(dst + FH_PPIECE) = (u32x2){l0_, l1_};
+        }
         }
         if (spr < FH_SROWS) {
             char* const dst0 = Ss + spr * (FH_SRW * 2) + spq * 4;              // haloed columns 2 q, 2 q + 1: one aligned word
@@ -1226,7 +1252,7 @@ size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D,
 
 // few-channel layers on the fp16-piece scheme (k_fewch_bwd_weight_h): same operands, workspace and reducer as the fp32-MFMA few-channel path
 static int fewch_h_launch(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* dz, int64_t dz_bstride,
-                          int Cout, float* gw, float* gb, float* part, int B, int D, int H, int W, void* stream) {
+                          int Cout, float* gw, float* gb, float* part, int B, int D, int H, int W, void* stream, bool p_blocked = false) {
     const int Cin = C0 + C1;
     const bool few_in = Cout == 16 && Cin <= 3;
     const int cs = few_in ? Cin : Cout;
@@ -1241,11 +1267,15 @@ static int fewch_h_launch(const float* x0, int C0, int64_t x0_bstride, const flo
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<2>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<4>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<6>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
         opt_in = true;
     }
-#define FH_LAUNCH(NT_) hipLaunchKernelGGL(k_fewch_bwd_weight_h<NT_>, dim3(nblk), dim3(FH_THREADS), FH_LDS, VXM_STREAM(stream), fin, cs, few_in ? 0 : 1, \
+#define FH_LAUNCH(...) hipLaunchKernelGGL((k_fewch_bwd_weight_h<__VA_ARGS__>), dim3(nblk), dim3(FH_THREADS), FH_LDS, VXM_STREAM(stream), fin, cs, few_in ? 0 : 1, \
                                           few_in && gb ? 1 : 0, part, B, D, H, W)
-    if (NT <= 2) FH_LAUNCH(2); else if (NT <= 4) FH_LAUNCH(4); else FH_LAUNCH(6);
+    if (p_blocked) { if (NT <= 2) FH_LAUNCH(2, true); else if (NT <= 4) FH_LAUNCH(4, true); else FH_LAUNCH(6, true); }
+    else if (NT <= 2) FH_LAUNCH(2); else if (NT <= 4) FH_LAUNCH(4); else FH_LAUNCH(6);
 #undef FH_LAUNCH
     const int ncols = (NT <= 2 ? 2 : (NT <= 4 ? 4 : 6)) * 16;
     hipLaunchKernelGGL(k_fewch_reduce, dim3((16 * ncols + 15) / 16), dim3(256), 0, VXM_STREAM(stream), part, nblk, ncols, cs, few_in ? 0 : 1, Cin, gw,
@@ -1413,7 +1443,10 @@ int vxm_conv3d_k3_fewch_bwd_weight_ok(const float* x0, int C0, int64_t x0_bstrid
 
 int vxm_conv3d_k3_fewch_bwd_weight(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* dz,
                                    int64_t dz_bstride, int Cout, float* gw, float* gb, void* workspace, size_t workspace_bytes, int B, int D, int H,
-                                   int W, int pieces, void* stream) {
+                                   int W, int pieces_and_layout, void* stream) {
+    const int pieces = pieces_and_layout & 0xff, lay = pieces_and_layout & ~0xff;
+    VXM_REQUIRE(lay == 0 || (lay == VXM_S3_IN0_BLOCKED && C0 == 16 && C1 == 0 && Cout <= 3), VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_fewch_bwd_weight: layout flags 0x%x (VXM_S3_IN0_BLOCKED for the 16-channel x0 of a 16 -> 1..3 layer only)", lay);
     if (int e = check_conv("vxm_conv3d_k3_fewch_bwd_weight", C0, C1, 0, Cout, B, D, H, W)) return e;
     VXM_REQUIRE(x0 && dz && gw && workspace && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_fewch_bwd_weight: null pointer");
     VXM_REQUIRE(vxm_conv3d_k3_fewch_bwd_weight_ok(x0, C0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, Cout, pieces, W), VXM_ERR_UNSUPPORTED,
@@ -1422,7 +1455,7 @@ int vxm_conv3d_k3_fewch_bwd_weight(const float* x0, int C0, int64_t x0_bstride, 
     VXM_REQUIRE(workspace_bytes >= vxm_conv3d_k3_bwd_weight_workspace_bytes(C0 + C1, Cout, B, D, H, W), VXM_ERR_WORKSPACE,
                 "vxm_conv3d_k3_fewch_bwd_weight: workspace too small (%zu bytes; vxm_conv3d_k3_bwd_weight_workspace_bytes)", workspace_bytes);
     const uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
-    return fewch_h_launch(x0, C0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, Cout, gw, gb, reinterpret_cast<float*>(base), B, D, H, W, stream);
+    return fewch_h_launch(x0, C0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, Cout, gw, gb, reinterpret_cast<float*>(base), B, D, H, W, stream, lay != 0);
 }
 
 }  // extern "C"

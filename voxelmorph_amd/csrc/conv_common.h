@@ -181,8 +181,9 @@ __device__ __forceinline__ void conv_epilogue_store(f32x4 (&acc)[NCT][ROWS * HAL
 // the fp32 mask was 35 % of what rem1's backward-data launch moves (0.12 of its 0.68 ms, tools/mask_ab.py).  A sign tensor is [Cout / 4][voxel]
 // bytes, bit j of byte (q, v) = (y[4 q + j][v] > 0): exactly the four channels a lane holds, so a forward epilogue writes one byte per row
 // beside its 16-byte store (lay & OUT_SIGNS: `maskb` is that OUTPUT) and a backward-data epilogue reads one (lay & MASK_SIGNS).  Same products.
-template <int NCT, int ROWS>
-__device__ __forceinline__ void conv_epilogue_store_blocked(f32x4 (&acc)[NCT][ROWS], float* __restrict__ yb, const float (&bz)[NCT][4],
+// HALVES = 16-voxel MFMA tiles side by side along W (acc index m = row * HALVES + half), as in conv_epilogue_store.
+template <int NCT, int ROWS, int HALVES = 1>
+__device__ __forceinline__ void conv_epilogue_store_blocked(f32x4 (&acc)[NCT][ROWS * HALVES], float* __restrict__ yb, const float (&bz)[NCT][4],
                                                             const float* __restrict__ maskb, float act_slope, float mask_slope, int Cout, int g, int kq,
                                                             bool vox_ok, int vox, int h0, int H, int W, int V, int lay = 0) {
     const bool sg_out = maskb != nullptr && (lay & VXM_S3_OUT_SIGNS) != 0, sg_in = maskb != nullptr && (lay & VXM_S3_MASK_SIGNS) != 0;      // wave-uniform
@@ -195,39 +196,44 @@ __device__ __forceinline__ void conv_epilogue_store_blocked(f32x4 (&acc)[NCT][RO
     for (int ct = 0; ct < NCT; ++ct) {
         const bool ok = vox_ok && cbase + 16 * ct < Cout;
         const int soff_ct = ((g * NCT + ct) * 16 < Cout ? 2 * ct : 0) * V;      // wave-uniform, kept inside the tensor (see conv_epilogue_store); a tile beyond Cout is dropped by `ok`
-        f32x4 mk[ROWS];
+        constexpr int MT = ROWS * HALVES;
+        f32x4 mk[MT];
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) mk[r] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
+        for (int r = 0; r < MT; ++r) mk[r] = (f32x4){1.0f, 1.0f, 1.0f, 1.0f};
         if (sg_in) {
-            unsigned sb[ROWS];
+            unsigned sb[MT];
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) sb[r] = __builtin_amdgcn_raw_buffer_load_b8(rm, ok ? boff : VXM_OOB, 2 * soff_ct + r * W, 0);
+            for (int r = 0; r < MT; ++r) sb[r] = __builtin_amdgcn_raw_buffer_load_b8(rm, ok ? boff : VXM_OOB, 2 * soff_ct + (r / HALVES) * W + (r % HALVES) * 16, 0);
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r)
+            for (int r = 0; r < MT; ++r)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mk[r][j] = ((sb[r] >> j) & 1u) ? 1.0f : mask_slope;
         } else if (maskb && !sg_out) {
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-                mk[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, ok ? voff : VXM_OOB, (soff_ct + r * W) << 5, 0));
+            for (int r = 0; r < MT; ++r)
+                mk[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, ok ? voff : VXM_OOB, (soff_ct + (r / HALVES) * W + (r % HALVES) * 16) << 5, 0));
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r)
+            for (int r = 0; r < MT; ++r)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mk[r][j] = vxm_lrelu_grad(mk[r][j], mask_slope);
         }
 #pragma unroll
         for (int row = 0; row < ROWS; ++row) {
             if (h0 + row < H) {                      // wave-uniform
-                f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[ct][row][j] + bz[ct][j];
-                    o[j] = (v > 0.0f ? v : v * act_slope) * mk[row][j];
-                }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, ok ? voff : VXM_OOB, (soff_ct + row * W) << 5, 0);
-                if (sg_out) {
-                    const unsigned nib = (o[0] > 0.0f ? 1u : 0u) | (o[1] > 0.0f ? 2u : 0u) | (o[2] > 0.0f ? 4u : 0u) | (o[3] > 0.0f ? 8u : 0u);
-                    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, rm, ok ? boff : VXM_OOB, 2 * soff_ct + row * W, 0);
+                for (int half = 0; half < HALVES; ++half) {
+                    const int r = row * HALVES + half, vrel = row * W + half * 16;
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[ct][r][j] + bz[ct][j];
+                        o[j] = (v > 0.0f ? v : v * act_slope) * mk[r][j];
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ry, ok ? voff : VXM_OOB, (soff_ct + vrel) << 5, 0);
+                    if (sg_out) {
+                        const unsigned nib = (o[0] > 0.0f ? 1u : 0u) | (o[1] > 0.0f ? 2u : 0u) | (o[2] > 0.0f ? 4u : 0u) | (o[3] > 0.0f ? 8u : 0u);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)nib, rm, ok ? boff : VXM_OOB, 2 * soff_ct + vrel, 0);
+                    }
                 }
             }
         }

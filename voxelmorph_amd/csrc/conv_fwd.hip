@@ -807,7 +807,12 @@ __global__ void __launch_bounds__(256) k_pack_weights_dlow(const float* __restri
 constexpr int FO_TD = 4, FO_TH = 8, FO_TW = 32, FO_CK = 4;
 constexpr int FO_RS = 36, FO_ROWS = (FO_TD + 2) * (FO_TH + 2), FO_PS = FO_ROWS * FO_RS;   // 60 rows, plane 2160 floats
 
-template <int CO>
+// BLK (round 6): x is CHANNEL-BLOCKED [Cin / 8][voxel][8] (include/vxm_hip.h VXM_S3_IN0_BLOCKED; Cin % 8 == 0) -- the output of the last ConvBlock
+// of the fused U-Net when the flow conv reads it.  A staging slot is then one voxel of the haloed tile (6 x 10 x 34 = 2040 slots, 8 per thread):
+// an EVEN chunk fetches the voxel's 32 bytes with two 16-byte loads, writes channels 0 .. 3 into the planar LDS planes (four ds_write_b32, lanes
+// on consecutive columns) and KEEPS channels 4 .. 7 in registers; the ODD chunk writes those and issues no load.  Sector requests per 8 channels
+// and tile: 1020 (every byte of every sector used) against 1920 for the planar rows (2 interior + 2 halo sectors per row and channel).
+template <int CO, bool BLK = false>
 __global__ void __launch_bounds__(256) k_conv3d_k3_fewout(const float* __restrict__ x, long long x_bs, int Cin, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y, long long y_bs, float act_slope,
                                                           int D, int H, int W) {
@@ -835,9 +840,39 @@ __global__ void __launch_bounds__(256) k_conv3d_k3_fewout(const float* __restric
     for (int co = 0; co < CO; ++co)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[co][j] = 0.0f;
+    [[maybe_unused]] f32x4 held[BLK ? (FO_ROWS * (FO_TW + 2) + 255) / 256 : 1];      // channels 4 .. 7 of this thread's voxels, between an even chunk and the odd one
 
     const int Q = (Cin + FO_CK - 1) / FO_CK;
     for (int q = 0; q < Q; ++q) {
+        if constexpr (BLK) {
+            constexpr int NSL = FO_ROWS * (FO_TW + 2), NJ = (NSL + 255) / 256;
+            if ((q & 1) == 0) {                              // block-uniform
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int slot = tid + 256 * j;
+                    const int rr = slot / (FO_TW + 2), col = slot - rr * (FO_TW + 2);
+                    const int gd = d0 - 1 + rr / (FO_TH + 2), gh = h0 - 1 + rr % (FO_TH + 2), gw = w0 - 1 + col;
+                    const bool ok = slot < NSL && 4 * q < Cin && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+                    const int vo = ok ? ((q >> 1) * V + (gd * H + gh) * W + gw) << 5 : VXM_OOB;
+                    const f32x4 lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 0, 0));
+                    held[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo, 16, 0));
+                    if (slot < NSL) {
+                        float* dst = Xs + rr * FO_RS + col;
+                        dst[0] = lo.x; dst[FO_PS] = lo.y; dst[2 * FO_PS] = lo.z; dst[3 * FO_PS] = lo.w;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int slot = tid + 256 * j;
+                    const int rr = slot / (FO_TW + 2), col = slot - rr * (FO_TW + 2);
+                    if (slot < NSL) {
+                        float* dst = Xs + rr * FO_RS + col;
+                        dst[0] = held[j].x; dst[FO_PS] = held[j].y; dst[2 * FO_PS] = held[j].z; dst[3 * FO_PS] = held[j].w;
+                    }
+                }
+            }
+        } else {
         // ---- stage chunk q: 4 planes x 60 rows x (8 interior float4 + 2 halo columns)
         for (int slot = tid; slot < FO_CK * FO_ROWS * 8; slot += 256) {
             const int c = slot / (FO_ROWS * 8), rr = (slot / 8) % FO_ROWS, g4 = slot & 7;
@@ -856,6 +891,7 @@ __global__ void __launch_bounds__(256) k_conv3d_k3_fewout(const float* __restric
             const bool ok = cg < Cin && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
             const int vo = ok ? (cg * V + (gd * H + gh) * W + gw) << 2 : VXM_OOB;
             Xs[c * FO_PS + rr * FO_RS + (side ? FO_TW + 1 : 0)] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vo, 0, 0));
+        }
         }
         __syncthreads();
         // ---- 4 channels x 9 (kd, kh) x [6 inputs, 3 x CO weights] -> 12 CO FMAs
@@ -920,7 +956,7 @@ template <int CIN, int TWX = 16>
 __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_kpack(ConvIn in, const float* __restrict__ wk, const float* __restrict__ bias,
                                                                  float* __restrict__ y, long long y_bs, int Cout, float act_slope,
                                                                  const float* __restrict__ mask, long long mask_bs, float mask_slope,
-                                                                 int B, int D, int H, int W) {
+                                                                 int B, int D, int H, int W, int lay) {
     constexpr int HALVES = TWX / 16, ROWS = 4 / HALVES, MT = ROWS * HALVES, RS = TWX + 4, HR = ROWS + 2, NROW = (T8_TD + 2) * HR;
     constexpr int PS = NROW * RS + ((NROW * RS) % 32 == 16 ? 0 : 16), NS = kpack_steps(CIN), GPR = TWX / 4, RPL = 64 / GPR;
     constexpr int NI = (NROW * GPR + 63) / 64, NHL = (NROW * 2 + 63) / 64;
@@ -1044,6 +1080,12 @@ __global__ void __launch_bounds__(T8_THREADS, 4) k_conv3d_k3_kpack(ConvIn in, co
             const int ln = opaque(lane), ekq = ln >> 4, en = ln & 15;
             const int d = cur.d0 + wave, w = cur.w0 + en;
             f32x4 (&acc1)[1][MT] = *reinterpret_cast<f32x4 (*)[1][MT]>(&acc);
+            if (lay & VXM_S3_OUT_BLOCKED)            // (round 6) channel-blocked y [Cout / 8][voxel][8]; the mask in the same layout, or a sign tensor (VXM_S3_MASK_SIGNS)
+                conv_epilogue_store_blocked<1, ROWS, HALVES>(acc1, y + (size_t)cur.b * y_bs, bz,
+                                                             mask ? ((lay & VXM_S3_MASK_SIGNS) ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(mask) + (size_t)cur.b * mask_bs)
+                                                                                               : mask + (size_t)cur.b * mask_bs) : nullptr,
+                                                             act_slope, mask_slope, Cout, g, ekq, d < D && w < W, (d * H + cur.h0) * W + w, cur.h0, H, W, V, lay);
+            else
             conv_epilogue_store<1, ROWS, HALVES>(acc1, y + (size_t)cur.b * y_bs, bz, mask ? mask + (size_t)cur.b * mask_bs : nullptr, act_slope, mask_slope,
                                          Cout, g, ekq, d < D && w < W, (d * H + cur.h0) * W + w, cur.h0, H, W, V);
 #pragma unroll
@@ -1166,8 +1208,25 @@ int vxm_conv3d_k3_pack_weights(const float* w, float* wpacked, int Cin, int Cout
 int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
                       const float* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope,
                       const float* mask_src, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, void* stream) {
+    return vxm_conv3d_k3_fwd_layout(x0, C0, x0_bstride, x0_up, x1, C1, x1_bstride, wpacked, bias, y, y_bstride, Cout, act_slope, mask_src, mask_bstride,
+                                    mask_slope, B, D, H, W, 0, stream);
+}
+
+int vxm_conv3d_k3_fwd_layout_ok(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* wpacked, int Cout,
+                                int B, int D, int H, int W) {
+    return (C0 > 0 && C1 >= 0 && Cout > 0 && Cout % 8 == 0 && kpack_ok(C0, C1, 0, x0, x0_bstride, x1, x1_bstride, wpacked, B, D, H, W)) ? 1 : 0;
+}
+
+int vxm_conv3d_k3_fwd_layout(const float* x0, int C0, int64_t x0_bstride, int x0_up, const float* x1, int C1, int64_t x1_bstride,
+                             const float* wpacked, const float* bias, float* y, int64_t y_bstride, int Cout, float act_slope,
+                             const float* mask_src, int64_t mask_bstride, float mask_slope, int B, int D, int H, int W, int layout, void* stream) {
     if (int e = check_conv("vxm_conv3d_k3_fwd", C0, C1, x0_up, Cout, B, D, H, W)) return e;
     VXM_REQUIRE(x0 && wpacked && y && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_fwd: null pointer");
+    VXM_REQUIRE(layout == 0 || ((layout & ~(VXM_S3_OUT_BLOCKED | VXM_S3_MASK_SIGNS)) == 0 && (layout & VXM_S3_OUT_BLOCKED) && !x0_up &&
+                                (!(layout & VXM_S3_MASK_SIGNS) || mask_src) &&
+                                vxm_conv3d_k3_fwd_layout_ok(x0, C0, x0_bstride, x1, C1, x1_bstride, wpacked, Cout, B, D, H, W)),
+                VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_fwd_layout: layout flags 0x%x need VXM_S3_OUT_BLOCKED (+ VXM_S3_MASK_SIGNS with a sign tensor), Cout %% 8 == 0 "
+                "and a launch the few-input-channel kernel takes (vxm_conv3d_k3_fwd_layout_ok); %d + %d -> %d channels", layout, C0, C1, Cout);
     const ConvCfg c = conv_cfg(C0 + C1, Cout);
     ConvIn in{x0, x1, (long long)x0_bstride, (long long)x1_bstride, C0, C1, x0_up};
     if (kpack_ok(C0, C1, x0_up, x0, x0_bstride, x1, x1_bstride, wpacked, B, D, H, W)) {      // few input channels: dense-K MFMA kernel
@@ -1178,7 +1237,7 @@ int vxm_conv3d_k3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up, co
         const dim3 gridk((unsigned)nb, (Cout + 15) / 16);
         const float* wk = wpacked + c.elems;
 #define LAUNCHK(...) hipLaunchKernelGGL((k_conv3d_k3_kpack<__VA_ARGS__>), gridk, dim3(T8_THREADS), 0, VXM_STREAM(stream), in, wk, bias, y, (long long)y_bstride, \
-        Cout, act_slope, mask_src, (long long)mask_bstride, mask_slope, B, D, H, W)
+        Cout, act_slope, mask_src, (long long)mask_bstride, mask_slope, B, D, H, W, layout)
         switch ((C0 + C1) * 2 + (wide32 ? 1 : 0)) {
             case 2: LAUNCHK(1); break;
             case 3: LAUNCHK(1, 32); break;
@@ -1355,7 +1414,14 @@ int vxm_conv3d_k3_fewout_ok(const float* x, int64_t x_bstride, float* y, int64_t
 
 int vxm_conv3d_k3_fewout_fwd(const float* x, int Cin, int64_t x_bstride, const float* w, const float* bias, float* y, int64_t y_bstride,
                              int Cout, float act_slope, int B, int D, int H, int W, void* stream) {
+    return vxm_conv3d_k3_fewout_fwd_layout(x, Cin, x_bstride, w, bias, y, y_bstride, Cout, act_slope, B, D, H, W, 0, stream);
+}
+
+int vxm_conv3d_k3_fewout_fwd_layout(const float* x, int Cin, int64_t x_bstride, const float* w, const float* bias, float* y, int64_t y_bstride,
+                                    int Cout, float act_slope, int B, int D, int H, int W, int layout, void* stream) {
     if (int e = check_conv("vxm_conv3d_k3_fewout_fwd", Cin, 0, 0, Cout, B, D, H, W)) return e;
+    VXM_REQUIRE((layout & ~VXM_S3_IN0_BLOCKED) == 0 && (layout == 0 || Cin % 8 == 0), VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_fewout_fwd_layout: layout flags 0x%x (VXM_S3_IN0_BLOCKED with Cin %% 8 == 0 only; Cin = %d)", layout, Cin);
     VXM_REQUIRE(x && w && y, VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_fewout_fwd: null pointer");
     VXM_REQUIRE(vxm_conv3d_k3_fewout_ok(x, x_bstride, y, y_bstride, Cin, Cout, W), VXM_ERR_UNSUPPORTED,
                 "vxm_conv3d_k3_fewout_fwd: needs Cout <= 4, W %% 4 == 0 and 16-byte aligned tensors (use vxm_conv3d_k3_fwd)");
@@ -1364,13 +1430,17 @@ int vxm_conv3d_k3_fewout_fwd(const float* x, int Cin, int64_t x_bstride, const f
     VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_fewout_fwd: too many tiles");
     const size_t lds = sizeof(float) * (size_t)FO_CK * FO_PS;
     const dim3 grid((unsigned)(8 * ((tiles + 7) / 8)), B);          // XCD-contiguous tile ranges: see the kernel
-#define FO_LAUNCH(CO_) hipLaunchKernelGGL(k_conv3d_k3_fewout<CO_>, grid, dim3(256), lds, VXM_STREAM(stream), x, (long long)x_bstride, Cin, w, bias, y, \
+#define FO_LAUNCH(...) hipLaunchKernelGGL((k_conv3d_k3_fewout<__VA_ARGS__>), grid, dim3(256), lds, VXM_STREAM(stream), x, (long long)x_bstride, Cin, w, bias, y, \
         (long long)y_bstride, act_slope, D, H, W)
-    switch (Cout) {
+    switch (Cout + (layout ? 4 : 0)) {
         case 1: FO_LAUNCH(1); break;
         case 2: FO_LAUNCH(2); break;
         case 3: FO_LAUNCH(3); break;
-        default: FO_LAUNCH(4); break;
+        case 4: FO_LAUNCH(4); break;
+        case 5: FO_LAUNCH(1, true); break;
+        case 6: FO_LAUNCH(2, true); break;
+        case 7: FO_LAUNCH(3, true); break;
+        default: FO_LAUNCH(4, true); break;
     }
 #undef FO_LAUNCH
     return vxm_check_launch("vxm_conv3d_k3_fewout_fwd");

@@ -44,6 +44,9 @@ S3_UP = os.environ.get("VXM_S3_UP", "") == "1"
 S3U = os.environ.get("VXM_S3U", "1") != "0"
 # channel-blocked interior tensors of the fused U-Net (tensors that only split kernels write and read: _blocked_tensors); VXM_BLOCKED=0: all planar
 BLOCKED = os.environ.get("VXM_BLOCKED", "1") != "0"
+# ... and the LAST activation of the fused U-Net (read by the 16 -> 3 flow conv), its gradient and its sign tensor, through the layout flags of the
+# few-channel kernels (round 6, late); VXM_BLOCKED_LAST=0: that tensor stays planar
+BLOCKED_LAST = os.environ.get("VXM_BLOCKED_LAST", "1") != "0"
 # UnetFn.backward: enqueue a layer's weight gradient (second stream) AFTER its backward-data launches (main stream) instead of before them.
 # Same dependencies; in a captured graph the order of node creation decides which child of the dz producer stays on its queue.
 # Default: "after" while a hipGraph is being captured (same-box A/B of the replayed step: 80.4 / 81.3 -> 83.4 / 82.4 pairs/s; the replay then keeps
@@ -717,15 +720,20 @@ def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask
              cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, s3_pieces() | lay, stream())
 
 
-def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W):
+def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask, mask_bs, mask_slope, B, D, H, W, lay=0):
+    """lay: S3_OUT_BLOCKED (| S3_MASK_SIGNS) on launches the few-input-channel kernel takes (vxm_conv3d_k3_fwd_layout_ok), else 0"""
     name = None
     if _prof.ACTIVE is not None:          # label the region with the kernel the C ABI will dispatch to
         v = _lib.lib().vxm_conv3d_k3_fwd_variant(ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), cout, B, D, H, W)
         name = "k_conv3d_k3_kpack<%d>" % (v - 200) if v >= 200 else (
             "k_conv3d_k3_t8<%d>" % (v % 10) if v >= 100 else "k_conv3d_k3<%d,%d>" % (v // 10, v % 10))
     with _prof.region(name, flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
-        call("vxm_conv3d_k3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
-             cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, stream())
+        if lay:
+            call("vxm_conv3d_k3_fwd_layout", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
+                 cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, lay, stream())
+        else:
+            call("vxm_conv3d_k3_fwd", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
+                 cout, float(slope), ptr(mask), mask_bs, float(mask_slope), B, D, H, W, stream())
 
 
 def _need_split_kernel(lay, what):
@@ -738,9 +746,12 @@ def conv_forward(x0, c0, bs0, up0, x1, c1, bs1, w, bias, y, ybs, cout, slope, B,
     """ConvBlock / flow conv forward (networks.py:299-305, 211,257) from the reference-layout weights: the MFMA implicit
     GEMM (weights packed per call), or the vector-ALU kernel when there are at most 4 output channels (flow conv).
     lay: S3_IN0_BLOCKED (x0) / S3_OUT_BLOCKED (y) for channel-blocked tensors between split kernels (fused U-Net only)."""
-    if lay == 0 and cout <= 4 and x1 is None and not up0 and _lib.lib().vxm_conv3d_k3_fewout_ok(ptr(x0), bs0, ptr(y), ybs, c0, cout, W):
+    if (lay & ~S3_IN0_BLOCKED) == 0 and cout <= 4 and x1 is None and not up0 and _lib.lib().vxm_conv3d_k3_fewout_ok(ptr(x0), bs0, ptr(y), ybs, c0, cout, W):
         with _prof.region("k_conv3d_k3_fewout<%d>" % cout, flops=2.0 * 27 * c0 * cout * B * D * H * W):
-            call("vxm_conv3d_k3_fewout_fwd", ptr(x0), c0, bs0, ptr(_c(w)), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W, stream())
+            if lay:      # x0 channel-blocked: the last activation of the fused U-Net (_blocked_tensors)
+                call("vxm_conv3d_k3_fewout_fwd_layout", ptr(x0), c0, bs0, ptr(_c(w)), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W, lay, stream())
+            else:
+                call("vxm_conv3d_k3_fewout_fwd", ptr(x0), c0, bs0, ptr(_c(w)), ptr(bias), ptr(y), ybs, cout, float(slope), B, D, H, W, stream())
         return
     if signs is not None and not (lay & S3_OUT_BLOCKED):
         raise RuntimeError("conv_forward: a sign tensor goes with a channel-blocked output")
@@ -786,6 +797,14 @@ def conv_bwd_data(dz, cout, w, gx, cin, mask, mask_slope, B, D, H, W, w_lo=0, la
                       1.0, mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W, lay=lay)
             continue
         lay &= ~S3_REVERSE_TILES                         # a scheduling hint of the split kernels only
+        if lay & S3_OUT_BLOCKED and not (lay & S3_IN0_BLOCKED) and (lo, hi) == (0, cin):
+            # the flow conv's adjoint (3 -> 16, few-input-channel kernel) onto a channel-blocked gradient, LeakyReLU' from the activation in the
+            # same layout or from its sign tensor
+            wpk = pack_weights_cached(w, True, w_lo, w_lo + cin)
+            if _lib.lib().vxm_conv3d_k3_fwd_layout_ok(ptr(dz), cout, cout * V, None, 0, 0, ptr(wpk), cin, B, D, H, W):
+                conv_launch(dz, cout, cout * V, False, None, 0, 0, wpk, None, gx, cin * V, cin, 1.0, mask,
+                            ((cin // 4) * V if lay & S3_MASK_SIGNS else cin * V) if mask is not None else 0, mask_slope, B, D, H, W, lay=lay)
+                continue
         _need_split_kernel(lay, "conv_bwd_data")
         conv_launch(dz, cout, cout * V, False, None, 0, 0, pack_weights_cached(w, True, w_lo + lo, w_lo + hi), None, gx[:, lo:hi], cin * V, hi - lo, 1.0,
                     mask[:, lo:hi] if mask is not None else None, cin * V, mask_slope, B, D, H, W)
@@ -868,17 +887,19 @@ def conv_bwd_weight(ws, x0, c0, bs0, up0, x1, c1, bs1, dz, cout, gw, gb, B, D, H
         s3u_bwd_weight(ws, x0, c0, bs0, dz, cout, gw, c0 + c1, B, D, H, W, lay=lay & S3_IN1_BLOCKED)
         s3_bwd_weight(ws, x1, c1, bs1, dz, cout, gw, c0 + c1, c0, gb, B, D, H, W, lay=lay & S3_IN1_BLOCKED)
         return
-    _need_split_kernel(lay, "conv_bwd_weight")
     if FEWCH_H and split_engine() and s3_pieces() == 2 and not up0 and _lib.lib().vxm_conv3d_k3_fewch_bwd_weight_ok(
             ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, 2, W):
+        if lay & ~S3_IN0_BLOCKED or (lay and not (c0 == 16 and c1 == 0 and cout <= 3)):
+            _need_split_kernel(lay, "conv_bwd_weight")
         # first block (2 -> 16) / flow conv (16 -> 3): the few-channel kernel on the fp16 pieces (round 6; the fp32-MFMA form spent 62 % of its
         # time with the matrix pipe busy, and the first block's launch is the last thing a step waits for)
         need = _lib.lib().vxm_conv3d_k3_bwd_weight_workspace_bytes(c0 + c1, cout, B, D, H, W)
         buf = ws.get(need)
         with _prof.region("k_fewch_bwd_weight_h", flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
             call("vxm_conv3d_k3_fewch_bwd_weight", ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, ptr(gw), ptr(gb), ptr(buf),
-                 buf.numel(), B, D, H, W, 2, stream())
+                 buf.numel(), B, D, H, W, 2 | lay, stream())
         return
+    _need_split_kernel(lay, "conv_bwd_weight")
     if split_engine() and up0 and x1 is not None and _lib.lib().vxm_conv3d_k3_s3_bwd_weight_ok(c1, cout, B, D, H, W) and \
             _lib.lib().vxm_conv3d_k3_bwd_weight_variant(ptr(x0), c0, bs0, 1, ptr(x1), c1, bs1, ptr(dz), cout * D * H * W, cout, D, H, W) // 10 == 2:
         # cat([upsample(x0), x1]): the upsampled segment through the collapsed fp32-MFMA kernel, the full-resolution skip segment (and the
@@ -1214,7 +1235,7 @@ def _blocked_tensors(plan, B, shape3):
     DZ[t]) runs on the split kernels too.  In the default VxmDense U-Net: the outputs of remaining[0] and remaining[1]."""
     if not (BLOCKED and split_engine() and s3_pieces() == 2):
         return frozenset()
-    key = (B, tuple(shape3), FP32_ENGINE, S3U, S3_UP, SPLIT_48)          # (the route predicates below depend on these switches)
+    key = (B, tuple(shape3), FP32_ENGINE, S3U, S3_UP, SPLIT_48, BLOCKED_LAST, FEWCH_H)          # (the route predicates below depend on these switches)
     cache = plan.__dict__.setdefault("_blocked_cache", {})
     if key in cache:
         return cache[key]
@@ -1238,7 +1259,15 @@ def _blocked_tensors(plan, B, shape3):
         if C % 16 or _bwd_bounds(C) != [0, C]:
             continue
         # the consumer: forward (reads t), weight gradient (x = t), fused backward-data (mask t, writes DZ[t])
-        if not (plain_ok(C, cc, D, H, W) and L.vxm_conv3d_k3_s3_bwd_weight_ok(C, cc, B, D, H, W) and plain_ok(cc, C, D, H, W)):
+        if cc <= 4:
+            # a few-output-channel conv (the flow conv, networks.py:211,257): k_conv3d_k3_fewout / k_fewch_bwd_weight_h / k_conv3d_k3_kpack take the
+            # layout flags (round 6, late); the *_ok predicates only look at alignment, which every torch allocation has (a stand-in address)
+            V = D * H * W
+            if not (BLOCKED_LAST and C == 16 and FEWCH_H and L.vxm_conv3d_k3_fewout_ok(256, C * V, 256, cc * V, C, cc, W)
+                    and L.vxm_conv3d_k3_fewch_bwd_weight_ok(256, C, C * V, None, 0, 0, 256, cc * V, cc, 2, W)
+                    and L.vxm_conv3d_k3_fwd_layout_ok(256, cc, cc * V, None, 0, 0, 256, C, B, D, H, W)):
+                continue
+        elif not (plain_ok(C, cc, D, H, W) and L.vxm_conv3d_k3_s3_bwd_weight_ok(C, cc, B, D, H, W) and plain_ok(cc, C, D, H, W)):
             continue
         # the producer: forward (writes t), weight gradient (dz = DZ[t]), backward-data (reads DZ[t])
         s0, up0, s1 = prod["src"]
@@ -1586,7 +1615,7 @@ class UnetFn(torch.autograd.Function):
                     if SNAKE and plan.lvl[dst] == 0 and dst not in dz_back and _bwd_bounds(cin) == [0, cin] and s3_route(cout, False, 0, cin, B, D, H, W):
                         rev = S3_REVERSE_TILES          # (dropped by conv_bwd_data when the launch is not a split kernel's)
                         dz_back.add(s0)
-                    if x_blk and pslope != 1.0 and s0 in SG and _bwd_bounds(cin) == [0, cin] and s3_route(cout, False, 0, cin, B, D, H, W):
+                    if x_blk and pslope != 1.0 and s0 in SG and _bwd_bounds(cin) == [0, cin] and (cout <= 4 or s3_route(cout, False, 0, cin, B, D, H, W)):
                         conv_bwd_data(dz, cout, w, gx, cin, SG[s0], pslope, B, D, H, W, lay=lay_d | S3_OUT_BLOCKED | S3_MASK_SIGNS | rev)
                     else:
                         conv_bwd_data(dz, cout, w, gx, cin, T[s0] if pslope != 1.0 else None, pslope, B, D, H, W,
