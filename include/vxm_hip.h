@@ -403,6 +403,10 @@ int vxm_bf16_lrelu_bwd(const void* g, const void* y, void* dz, float slope, int6
  * difference is range: inside ONE staged tile, values below 2^-18 of the tile's largest magnitude lose relative precision (absolute
  * error 2^-40 of that magnitude), which bf16's 8-bit exponent does not.  The packed weights of the two schemes differ (pass the same
  * `pieces` to packed_bytes / the pack job / the launch).
+ * Non-finite values (round 6): a staged unit's scale is taken over its FINITE values, so an Inf / NaN among the activations or gradients stays
+ * an Inf / NaN piece and poisons exactly the outputs whose 3 x 3 x 3 window contains it (for a weight gradient: its channel's slice), as ATen's
+ * convolution does; the other outputs of the unit keep their fp32-level values.  (Which outputs a non-finite value next to the volume border
+ * reaches through the zero padding -- 0 x Inf = NaN -- depends on which operand a kernel pads; ATen's vol2col has the same freedom.)
  * vxm_conv3d_k3_s3_ok: 1 when the split kernel takes a launch of this shape (otherwise use vxm_conv3d_k3_fwd). */
 int vxm_conv3d_k3_s3_ok(int C0, int C1, int Cout, int B, int D, int H, int W);
 /* Layout flags, OR-ed into the `pieces` argument of the launch entry points of the split engine (fp16 scheme only).  A flagged tensor is

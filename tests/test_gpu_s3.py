@@ -345,6 +345,81 @@ def test_s3_dynamic_range_inside_one_tile(VF):
         assert err <= 2.0 ** -38 * 2.0 ** 24 * l1              # 2^-40 of the tile maximum per term (x2 for the two roundings), summed against |w|
 
 
+def _same_footprint_and_finite_values(y, ref, what, gate=1e-6):
+    """non-finite exactly where the fp64 evaluation of the reference operator is non-finite; everything else at the fp32-level gate"""
+    y, ref = y.detach().cpu().double(), ref.detach().cpu().double()
+    fy, fr = torch.isfinite(y), torch.isfinite(ref)
+    assert torch.equal(fy, fr), "%s: %d non-finite outputs, the reference has %d (%d differ)" % (what, int((~fy).sum()), int((~fr).sum()), int((fy != fr).sum()))
+    assert int((~fr).sum()) > 0, what
+    e = rel_l2(y[fr].numpy(), ref[fr].numpy())
+    assert e <= gate, (what, e)
+    return int((~fr).sum())
+
+
+def test_s3_non_finite_values_poison_what_the_reference_poisons(VF):
+    """Round-5 verdict item 6: an Inf (or NaN) among the activations used to set the power-of-two scale of its whole staged unit on the fp16
+    scheme (exponent field 255 -> 2^-114: every finite value of the unit flushed), where ATen's convolution confines it to the outputs whose
+    3 x 3 x 3 window contains it.  The unit's scale is now taken over its FINITE values (s3_pieces.h s3_unit_max): forward (plain, two segments,
+    upsample + cat), backward-data onto the low-resolution tensor and both weight gradients produce non-finite results exactly where the fp64
+    reference does, and the fp32-level result everywhere else -- on both piece schemes."""
+    torch.manual_seed(5)
+    B, vol = 1, (16, 16, 32)
+    D, H, W = vol
+    V = D * H * W
+
+    def poison(t, corner=True):
+        t = t.clone()
+        t[0, 3, t.shape[2] // 2, 2, 5] = float("inf")
+        t[0, 9 % t.shape[1], 1, t.shape[3] - 3, t.shape[4] - 7] = float("nan")
+        if corner:
+            t[0, 5, 0, 0, 0] = float("-inf")
+        return t
+    # plain forward (k_s3_conv; k_s3p_conv in the VXM_S3_PC=1 re-run), 16 and 32 output channels
+    for c0, cout in ((16, 16), (32, 16), (16, 32)):
+        x = poison(torch.randn(B, c0, *vol, device="cuda"))
+        w = torch.randn(cout, c0, 3, 3, 3, device="cuda") / (27 * c0) ** 0.5
+        bias = torch.randn(cout, device="cuda")
+        n = _same_footprint_and_finite_values(_s3_forward(VF, x, False, None, w, bias, 0.2, cout, vol, B), _ref_conv(x.cpu(), False, None, w.cpu(), bias.cpu(), 0.2),
+                                              "forward %d -> %d" % (c0, cout))
+        assert n <= 3 * 27 * cout
+    # cat([upsample(x0), x1]) forward on the collapsed kernel: a poisoned low-resolution voxel reaches the windows of its eight children
+    c0, c1, cout = 32, 16, 32
+    x0 = poison(torch.randn(B, c0, D // 2, H // 2, W // 2, device="cuda"))
+    x1 = poison(torch.randn(B, c1, *vol, device="cuda"))
+    w = torch.randn(cout, c0 + c1, 3, 3, 3, device="cuda") / (27 * (c0 + c1)) ** 0.5
+    bias = torch.randn(cout, device="cuda")
+    _same_footprint_and_finite_values(_s3u_forward(VF, x0, x1, w, bias, 0.2, cout, vol, B), _ref_conv(x0.cpu(), True, x1.cpu(), w.cpu(), bias.cpu(), 0.2),
+                                      "upsample + cat forward")
+    # weight gradients: a poisoned x poisons its input channel's slice of gw, a poisoned dz its output channel's slice (and gb entry).  (Poison
+    # away from the volume border here: a product of a non-finite value with the ZERO PADDING of the other operand is NaN, and which operand a
+    # kernel -- or ATen's vol2col -- pads is an implementation choice; k_s3_bww_pc<true> pads dz, the reference formula pads x.)
+    for c, co in ((16, 16), (32, 16), (16, 32)):
+        x, dz = poison(torch.randn(B, c, *vol, device="cuda"), corner=False), torch.randn(B, co, *vol, device="cuda")
+        dz[0, 2, 3, 4, 5] = float("inf")
+        ws = VF._Workspace(x.device)
+        gw, gb = torch.empty(co, c, 3, 3, 3, device="cuda"), torch.empty(co, device="cuda")
+        VF.s3_bwd_weight(ws, x, c, c * V, dz, co, gw, c, 0, gb, B, D, H, W)
+        ref = torch.nn.grad.conv3d_weight(x.double().cpu(), (co, c, 3, 3, 3), dz.double().cpu(), padding=1)
+        _same_footprint_and_finite_values(gw, ref, "weight gradient %d x %d" % (c, co), gate=3e-6)
+        _same_footprint_and_finite_values(gb, dz.double().cpu().sum(dim=(0, 2, 3, 4)), "bias gradient %d" % co, gate=3e-6)
+    if VF.s3u_bwd_weight_route(32, 32, B, D, H, W):
+        x0, dz = poison(torch.randn(B, 32, D // 2, H // 2, W // 2, device="cuda"), corner=False), poison(torch.randn(B, 32, *vol, device="cuda"), corner=False)
+        ws = VF._Workspace(x0.device)
+        gw = torch.zeros(32, 48, 3, 3, 3, device="cuda")
+        VF.s3u_bwd_weight(ws, x0, 32, x0[0].numel(), dz, 32, gw, 48, B, D, H, W)
+        up = torch.nn.functional.interpolate(x0.double().cpu(), scale_factor=2, mode="nearest")
+        ref = torch.nn.grad.conv3d_weight(up, (32, 32, 3, 3, 3), dz.double().cpu(), padding=1)
+        _same_footprint_and_finite_values(gw[:, :32], ref, "weight gradient of the upsampled segment", gate=3e-6)
+    if VF.s3u_bwd_low_route(32, 32, B, D, H, W):
+        dz = poison(torch.randn(B, 32, *vol, device="cuda"))
+        w = torch.randn(32, 48, 3, 3, 3, device="cuda") / (27 * 48) ** 0.5
+        gxl = torch.empty(B, 32, D // 2, H // 2, W // 2, device="cuda")
+        VF.s3u_bwd_low(dz, 32, w, 32, 48, gxl, None, 1.0, B, D, H, W)
+        gup = torch.nn.grad.conv3d_input((B, 48) + vol, w.double().cpu(), dz.double().cpu(), padding=1)[:, :32]
+        ref = gup.reshape(B, 32, D // 2, 2, H // 2, 2, W // 2, 2).sum(dim=(3, 5, 7))
+        _same_footprint_and_finite_values(gxl, ref, "backward-data onto the low-resolution tensor", gate=3e-6)
+
+
 def test_s3_forward_many_tiles(VF):
     """a volume of 2 x 3 x 9 x 5 = 270 tiles (partial in every direction) against the fp64 reference: with VXM_S3_PERSIST=-16 (subprocess
     test below) each of the 16 blocks walks ~17 tiles of its XCD's range"""
@@ -692,11 +767,11 @@ def test_s3_other_kernel_instances_in_subprocess():
     _rerun({"VXM_S3_PERSIST": "0", "VXM_S3U_PERSIST": "0"}, "many_tiles")
     # the producer / consumer kernel (k_s3p_conv: by default from 2048 tiles of 8 x 8 x 16 up) on every eligible launch, with one block per
     # tile and with 16 blocks in all (every block streams several tiles through its two LDS buffers); and the alternating kernel everywhere
-    _rerun({"VXM_S3_PC": "1"}, "forward_vs_fp64 or fused_mask or scale_invariance or dynamic_range or many_tiles or s3_conv_channel_blocked or sign_tensors")
+    _rerun({"VXM_S3_PC": "1"}, "forward_vs_fp64 or fused_mask or scale_invariance or dynamic_range or non_finite or many_tiles or s3_conv_channel_blocked or sign_tensors")
     _rerun({"VXM_S3_PC": "1", "VXM_S3P_BLOCKS": "16"}, "forward_vs_fp64 or fused_mask or dynamic_range or many_tiles")
     # the kernels the producer / consumer ones of round 6 replaced by default stay reachable (other piece scheme, odd extents, A/B):
     # k_s3_bwd_weight<2> for k_s3_bww_pc, k_s3u_conv<., 2> for k_s3u_conv_pc, k_s3_conv for k_s3p_conv
-    _rerun({"VXM_S3_PC": "0", "VXM_S3_BW_PC": "0", "VXM_S3U_PC": "0"}, "many_tiles or backward_weight or s3u_collapsed or s3u_kernels or sign_tensors")
+    _rerun({"VXM_S3_PC": "0", "VXM_S3_BW_PC": "0", "VXM_S3U_PC": "0"}, "many_tiles or backward_weight or s3u_collapsed or s3u_kernels or sign_tensors or non_finite")
 
 
 def test_s3_through_the_dispatcher_on_small_volumes_in_subprocess():

@@ -1029,14 +1029,16 @@ __global__ void __launch_bounds__(FH_THREADS, 3) k_fewch_bwd_weight_h(FcIn in, i
     };
     // largest magnitudes this wave loaded for the tile in flight -> Tab (P: [wave], S: [4 + wave])
     auto publish_max = [&]() __attribute__((always_inline)) {
-        float mp = 0.0f, ms = 0.0f;
+        const float mp = s3_unit_max([&](auto&& f) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < NPV; ++j)
+            for (int j = 0; j < NPV; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) mp = fmaxf(mp, __builtin_fabsf(pv[j][e]));
+                for (int e = 0; e < 4; ++e) f(pv[j][e]);
+        });
+        const float ms = s3_unit_max([&](auto&& f) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) ms = fmaxf(ms, fmaxf(__builtin_fabsf(sv[i].x), __builtin_fabsf(sv[i].y)));
-        mp = s3_wave_max(mp); ms = s3_wave_max(ms);
+            for (int i = 0; i < 9; ++i) { f(sv[i].x); f(sv[i].y); }
+        });
         if (lane == 0) { Tab[wave] = mp; Tab[4 + wave] = ms; }
     };
     float sP = 1.0f, sS = 1.0f, inv_next = 1.0f, invP_next = 1.0f;      // scales of the tile in flight; the inverse product / P inverse of it

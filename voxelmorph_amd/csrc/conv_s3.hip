@@ -213,12 +213,12 @@ k_s3_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bia
     // MFMA loop (the loads have had the whole phase to land), i.e. before the barrier that ends the phase anyway: no extra barrier.
     auto publish_max = [&]() __attribute__((always_inline)) {
         if constexpr (NP == 2) {
-            float m = 0.0f;
+            const float m = s3_unit_max([&](auto&& f) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
+                for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m = fmaxf(m, __builtin_fabsf(xr[j][e]));
-            m = s3_wave_max(m);
+                    for (int e = 0; e < 8; ++e) f(xr[j][e]);
+            });
             if (lane == 0) Wm[wave] = m;
         }
     };
@@ -535,12 +535,12 @@ k_s3p_conv(ConvIn in, const u32x4* __restrict__ wp, const float* __restrict__ bi
         };
         auto publish_max = [&](auto set_) __attribute__((always_inline)) {
             constexpr int S = decltype(set_)::value;
-            float m = 0.0f;
+            const float m = s3_unit_max([&](auto&& f) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
+                for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m = fmaxf(m, __builtin_fabsf(xr[S][j][e]));
-            m = s3_wave_max(m);
+                    for (int e = 0; e < 8; ++e) f(xr[S][j][e]);
+            });
             if (lane == 0) Tab[8 * S + pw] = m;
         };
         int E_run = 15;
@@ -819,7 +819,7 @@ __global__ void __launch_bounds__(1024) k_s3_wmax(const S3PackBatch batch) {
     auto at = [&](int i) __attribute__((always_inline)) {
         if (i >= n) return 0.0f;
         const int a = i / row, r = i - a * row;
-        return __builtin_fabsf(jb.w[((size_t)a * jb.Cw_in + jb.ci_lo) * 27 + r]);
+        return s3_finite_mag(jb.w[((size_t)a * jb.Cw_in + jb.ci_lo) * 27 + r]);
     };
     for (int i = threadIdx.x; i < n; i += 8192) {                     // eight independent loads in flight per thread (round 6: the launch sits on the main chain)
         float a[8];
@@ -1022,10 +1022,10 @@ __global__ void __launch_bounds__(SW_THREADS, 3) k_s3_bwd_weight(const float* __
             auto publish_max = [&](auto set_, int slot) __attribute__((always_inline)) {
                 constexpr int S = decltype(set_)::value;
                 if constexpr (NP == 2) {
-                    float m = 0.0f;
+                    const float m = s3_unit_max([&](auto&& f) __attribute__((always_inline)) {
     #pragma unroll
-                    for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[S][e]), __builtin_fabsf(rb[S][e])));
-                    m = s3_wave_max(m);
+                        for (int e = 0; e < 8; ++e) { f(ra[S][e]); f(rb[S][e]); }
+                    });
                     if (lane == 0) Tab[8 + 12 * slot + wave] = m;
                 }
             };
@@ -1588,12 +1588,12 @@ __global__ void __launch_bounds__(PW_THREADS) k_s3_bww_pc(const float* __restric
                 // scale of rounds RLO .. RLO + NR - 1 (one scale unit): wave maximum -> power of two; its inverse goes to the table
                 auto unit_scale = [&](auto rlo_, auto nr_, float* tab_slot) __attribute__((always_inline)) -> float {
                     constexpr int RLO = decltype(rlo_)::value, NR = decltype(nr_)::value;
-                    float m = 0.0f;
+                    const float m = s3_unit_max([&](auto&& f) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int rr = RLO; rr < RLO + NR; ++rr)
+                        for (int rr = RLO; rr < RLO + NR; ++rr)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[rr][e]), __builtin_fabsf(rb[rr][e])));
-                    m = s3_wave_max(m);
+                            for (int e = 0; e < 8; ++e) { f(ra[rr][e]); f(rb[rr][e]); }
+                    });
                     float sc, inv;
                     s3_scale_of(m, sc, inv);
                     if (lane == 0) *tab_slot = inv;

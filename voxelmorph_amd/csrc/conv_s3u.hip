@@ -186,12 +186,12 @@ k_s3u_conv(const float* __restrict__ x0, long long bs0, int C0, const float* __r
     };
     auto publish_max = [&]() __attribute__((always_inline)) {
         if constexpr (NP == 2) {
-            float m = 0.0f;
+            const float m = s3_unit_max([&](auto&& f) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < SU_NI; ++j)
+                for (int j = 0; j < SU_NI; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m = fmaxf(m, __builtin_fabsf(xr[j][e]));
-            m = s3_wave_max(m);
+                    for (int e = 0; e < 8; ++e) f(xr[j][e]);
+            });
             if (lane == 0) Wm[wave] = m;
         }
     };
@@ -741,14 +741,14 @@ k_s3u_conv_pc(const float* __restrict__ x0, long long bs0, int C0, const float* 
         auto publish_max = [&](auto set_, int k) __attribute__((always_inline)) {
             constexpr int S = decltype(set_)::value;
             const bool up = (k % NST) < NU;                      // wave-uniform
-            float m = 0.0f;
+            const float m = s3_unit_max([&](auto&& f) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < SUP_NRS; ++j) {
-                if (j >= SUP_NRU && up) continue;
+                for (int j = 0; j < SUP_NRS; ++j) {
+                    if (j >= SUP_NRU && up) continue;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[S][j][e]), __builtin_fabsf(rb[S][j][e])));
-            }
-            m = s3_wave_max(m);
+                    for (int e = 0; e < 8; ++e) { f(ra[S][j][e]); f(rb[S][j][e]); }
+                }
+            });
             if (lane == 0) Tab[(k & 1) * 4 + pwv] = m;
         };
         int E_run = 15;
@@ -1148,21 +1148,19 @@ k_s3u_bwd_pc(const float* __restrict__ dz, long long dz_bs, int Cout, const u32x
         };
         auto publish_max = [&](auto set_, int k) __attribute__((always_inline)) {
             constexpr int S = decltype(set_)::value;
-            float m = 0.0f;
+            const float m = s3_unit_max([&](auto&& f) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NR; ++j) {
-                if constexpr (BLK) {
+                for (int j = 0; j < NR; ++j) {
+                    if constexpr (BLK) {
 #pragma unroll
-                    for (int e = 0; e < RW; ++e) m = fmaxf(m, __builtin_fabsf(raw[S][j][e]));
-                } else {                                         // the voxels a row's first / last pair drops (hw = -1, 34) stay out of the maximum:
-                    const int pp = pos[j] & 63;                  // the blocked staging never sees them -- same scale, same bits in both layouts
-                    float m0 = 0.0f, m1 = 0.0f;
+                        for (int e = 0; e < RW; ++e) f(raw[S][j][e]);
+                    } else {                                     // the voxels a row's first / last pair drops (hw = -1, 34) stay out of the maximum:
+                        const int pp = pos[j] & 63;              // the blocked staging never sees them -- same scale, same bits in both layouts
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { m0 = fmaxf(m0, __builtin_fabsf(raw[S][j][e])); m1 = fmaxf(m1, __builtin_fabsf(raw[S][j][8 + e])); }
-                    m = fmaxf(m, fmaxf(pp > 0 ? m0 : 0.0f, pp < 17 ? m1 : 0.0f));
+                        for (int e = 0; e < 8; ++e) { f(pp > 0 ? raw[S][j][e] : 0.0f); f(pp < 17 ? raw[S][j][8 + e] : 0.0f); }
+                    }
                 }
-            }
-            m = s3_wave_max(m);
+            });
             if (lane == 0) Tab[(k & 1) * 4 + pwv] = m;
         };
         int E_run = 15;
@@ -1350,7 +1348,7 @@ __global__ void __launch_bounds__(256) k_s3u_pack(const SuPack jb) {
         if (i < jb.words) {
             su_values(jb, i, v, piece);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) m = fmaxf(m, __builtin_fabsf(v[e]));
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, s3_finite_mag(v[e]));
         }
         m = s3_wave_max(m);
         if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(&jb.wp[jb.words]) + 2, __float_as_uint(m));
@@ -1480,12 +1478,12 @@ k_s3u_dlow(const float* __restrict__ dz, long long dz_bs, int Cout, const u32x4*
     };
     auto publish_max = [&]() __attribute__((always_inline)) {
         if constexpr (NP == 2) {
-            float m = 0.0f;
+            const float m = s3_unit_max([&](auto&& f) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < SU_NI; ++j)
+                for (int j = 0; j < SU_NI; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m = fmaxf(m, __builtin_fabsf(xr[j][e]));
-            m = s3_wave_max(m);
+                    for (int e = 0; e < 8; ++e) f(xr[j][e]);
+            });
             if (lane == 0) Wm[wave] = m;
         }
     };
@@ -1773,10 +1771,10 @@ __global__ void __launch_bounds__(UW_THREADS, 4) k_s3u_bww(const float* __restri
                 }
             };
             auto publish_max = [&](int slot) __attribute__((always_inline)) {
-                float m = 0.0f;
+                const float m = s3_unit_max([&](auto&& f) __attribute__((always_inline)) {
     #pragma unroll
-                for (int e = 0; e < 8; ++e) m = fmaxf(m, fmaxf(__builtin_fabsf(ra[e]), __builtin_fabsf(rb[e])));
-                m = s3_wave_max(m);
+                    for (int e = 0; e < 8; ++e) { f(ra[e]); f(rb[e]); }
+                });
                 if (lane == 0) Tab[16 + 16 * slot + wave] = m;
             };
             float sc_role = 1.0f;

@@ -79,6 +79,31 @@ __device__ __forceinline__ float s3_wave_max(float v) {
     const float r2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 32)), r3 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 48));
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
+// Largest FINITE magnitude of what a wave staged for one scale unit, in every lane.  each(f) calls f(value) for every element of the lane.
+// Fast path: one v_max per element (NaN operands are ignored by the maximum, an Inf dominates it).  When the wave's maximum comes out as Inf --
+// wave-uniform, rare: a diverged step -- the maximum is taken again over the finite elements only, so that the unit's power-of-two scale is that
+// of its finite values and a non-finite element stays what it is (h = Inf / NaN, l = NaN): like the reference's convolution, it then poisons
+// exactly the outputs whose 3 x 3 x 3 window contains it, instead of pushing the whole unit's scale to 2^-114 (round 6, late; round-5 verdict item 6).
+template <class Each>
+__device__ __forceinline__ float s3_unit_max(Each&& each) {
+    float m = 0.0f;
+    each([&](float v) __attribute__((always_inline)) { m = fmaxf(m, __builtin_fabsf(v)); });
+    m = s3_wave_max(m);
+    if (__builtin_expect((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(m)) >= 0x7f800000u, 0)) {
+        m = 0.0f;
+        each([&](float v) __attribute__((always_inline)) {
+            const float a = __builtin_fabsf(v);
+            m = fmaxf(m, a < __builtin_inff() ? a : 0.0f);
+        });
+        m = s3_wave_max(m);
+    }
+    return m;
+}
+// (pack kernels: the same filter per element, their cost does not matter)
+__device__ __forceinline__ float s3_finite_mag(float v) {
+    const float a = __builtin_fabsf(v);
+    return a < __builtin_inff() ? a : 0.0f;
+}
 // piece scheme NP: 3 = bf16 (h, m, l), six products; 2 = fp16 (h, l), three products.  PA / PB: piece of the A / B operand of product t,
 // small terms first.
 template <bool FIRST, class T> __device__ __forceinline__ T& s3_sel(T& a, T& b) { if constexpr (FIRST) return a; else return b; }
