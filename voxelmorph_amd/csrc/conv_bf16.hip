@@ -50,51 +50,59 @@ constexpr int bf_lds_bytes(int nct, int rows) { return 2 * bf_cbs(rows) + bf_wch
 //      1 = planar fp32 [B][Cout<=4][D][H][W] (the flow head: bias only)
 //      2 = blocked bf16 at HALF resolution: the sum over each voxel's 2 x 2 x 2 children (adjoint of nearest-x2 upsampling; no bias /
 //          activation; optional LeakyReLU' mask of the low-resolution block) -- backward-data onto an upsampled segment
+// Round 6 (late): PERSISTENT blocks with the next chunk in flight.  Rounds 2 - 5 ran one tile per block and, per 16-channel chunk,
+// load -> LDS -> barrier -> MFMA -> barrier with nothing in flight during the multiplies (most full-resolution launches have one or two
+// chunks per tile, so there was nothing to pipeline inside a tile either).  Now a block walks its XCD's tile range (as the fp32 split kernels,
+// conv_s3.hip) and the chunk stream (tile, q) is software-pipelined: the 16-byte words of chunk c + 1 -- and its weights -- are requested into
+// registers before the MFMAs of chunk c and written to LDS after them (16-channel operators: two blocks per CU, one LDS buffer each).  The
+// 32-channel operators are persistent too but fetch in the store phase (PF below; DB, a double-buffered tile with one block per CU, is kept as a
+// compile-time switch with its measurement).  Same tiles, same packed operators, same arithmetic in the same order: results are bit-identical to
+// the round-2 kernel.  Measured at 160x192x224 (dense_bf16 step): k_bf16_conv<1,8,0> 1.33 -> 1.11 ms per step.
+constexpr bool bf_db(int nct) { (void)nct; return false; }      // (see the header comment of k_bf16_conv: the double-buffered form measured slower)
+constexpr int bf_lds_bytes_p(int nct, int rows) { return (bf_db(nct) ? 2 : 1) * bf_lds_bytes(nct, rows); }
+
 template <int NCT, int ROWS, int OUT>
-__global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
+__global__ void __launch_bounds__(BF_THREADS, (bf_db(NCT) ? 2 : 4)) k_bf16_conv(BfIn in, const u32x4* __restrict__ wp, const float* __restrict__ bias,
                                                           void* __restrict__ y, int Cout, float act_slope, const void* __restrict__ mask,
                                                           float mask_slope, int B, int D, int H, int W, int Q) {
     VXM_DYN_SMEM(u32x4, smem);
+    constexpr bool DB = bf_db(NCT);
     constexpr int HR = ROWS + 2, CBS = bf_cbs(ROWS) / 16, PLANE = HR * BF_HWV;     // in 16-byte words
     constexpr int NSLOT = 2 * (BF_TD + 2) * PLANE, NI = (NSLOT + BF_THREADS - 1) / BF_THREADS;
     constexpr int WCH = bf_wchunk(NCT), WIT = (WCH + BF_THREADS - 1) / BF_THREADS;
-    u32x4* const Xs = smem;                 // [2][CBS]: [cb][hd][hr][hw]
-    u32x4* const Ws = smem + 2 * CBS;       // [5][3][NCT][64]
+    constexpr bool PF = NCT == 1;           // the next chunk in flight under the MFMAs: the 16-channel instances.  The 32-channel ones have no registers
+                                            // for it at two blocks per CU (154 needed, 128 there: the spilled prefetch waited for its loads at once), and
+                                            // with one block per CU and a double-buffered tile they measured 7 % slower than two unpipelined blocks
+                                            // that cover each other's loads: they keep that form (fetch in the store phase), persistent
+    constexpr bool WPF = PF;                // (the weights of a one-chunk operator stay in LDS for every tile of the block)
+    constexpr int BUF = 2 * CBS + WCH;      // 16-byte words of one buffer: [2][CBS] activations ([cb][hd][hr][hw]), then [5][3][NCT][64] weights
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = lane >> 4, n = lane & 15;
 
-    // tile of this block: block b runs on XCD b % 8 (observed; speed only), XCD x takes a contiguous tile range
+    // tiles of this block: block b runs on XCD b % 8 (observed; speed only); XCD x owns a contiguous tile range, its blocks take the tiles round-robin
     const int nw = (W + 15) / 16, nh = (H + ROWS - 1) / ROWS, nd = (D + BF_TD - 1) / BF_TD;
     const int ntiles = B * nd * nh * nw;
-    int tile = blockIdx.x;
+    int t_lo, t_hi, t_step;
     if (ntiles >= 64) {
-        const int x = tile & 7, j = tile >> 3;
-        const int lo = (int)((long long)ntiles * x / 8), hi = (int)((long long)ntiles * (x + 1) / 8);
-        tile = lo + j;
-        if (tile >= hi) return;
-    } else if (tile >= ntiles) {
-        return;
+        const int x = blockIdx.x & 7;
+        t_lo = (int)((long long)ntiles * x / 8) + (int)(blockIdx.x >> 3); t_hi = (int)((long long)ntiles * (x + 1) / 8); t_step = (int)(gridDim.x >> 3);
+    } else {
+        t_lo = blockIdx.x; t_hi = ntiles; t_step = gridDim.x;
     }
-    if (in.rev) tile = ntiles - 1 - tile;
-    const int tw = tile % nw; int tq = tile / nw;
-    const int th = tq % nh; tq /= nh;
-    const int td = tq % nd; const int b = tq / nd;
-    const int d0 = td * BF_TD, h0 = th * ROWS, w0 = tw * 16;
+    if (t_lo >= t_hi) return;
+    const int nchunks = ((t_hi - t_lo + t_step - 1) / t_step) * Q;
     const int g = blockIdx.y;
-
     const int V = D * H * W;
     const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
     const int V0 = in.up0 ? Dl * Hl * Wl : V;
-    const __amdgpu_buffer_rsrc_t r0 = bf_rsrc(static_cast<const char*>(in.x0) + (size_t)b * in.CB0 * V0 * 16, (unsigned)in.CB0 * (unsigned)V0 * 16u);
-    const __amdgpu_buffer_rsrc_t r1 = bf_rsrc(in.CB1 ? static_cast<const char*>(in.x1) + (size_t)b * in.CB1 * V * 16 : in.x0,
-                                              (unsigned)in.CB1 * (unsigned)V * 16u);
-
-    f32x4 acc[NCT][ROWS];
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    struct Org { int b, d0, h0, w0; };
+    auto origin = [&](int t) __attribute__((always_inline)) -> Org {
+        if (in.rev) t = ntiles - 1 - t;
+        const int tw = t % nw; int tq = t / nw;
+        const int th = tq % nh; tq /= nh;
+        return Org{tq / nd, (tq % nd) * BF_TD, th * ROWS, tw * 16};
+    };
 
     // per-lane LDS word offset of the unit this lane group reads in K-step s: unit u = 4 s + kg = 2 (3 kd + kw) + cb
     int xoff[BF_STEPS];
@@ -105,35 +113,88 @@ __global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x
         xoff[s] = cb * CBS + (wave + kd) * PLANE + kw + n;
     }
 
-    for (int q = 0; q < Q; ++q) {
-        // ---- stage chunk q: 2 blocks x haloed tile, 16 bytes per slot, zero padding through the buffer descriptor
-        const bool s0 = 2 * q < in.CB0;
+    // ---- the chunk in flight: 2 blocks x haloed tile, 16 bytes per slot (zero padding through the buffer descriptor), and its weights
+    u32x4 xr[NI];
+    [[maybe_unused]] u32x4 wr[WPF ? WIT : 1];
+    int voffs[NI];
+    auto load_chunk = [&](int t, int q, bool in_store_phase) __attribute__((always_inline)) {
+        if (PF == in_store_phase) return;                     // (compile-time after inlining)
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));                        // (keeps the slot arithmetic inside the loop: registers)
+        const Org o = origin(t);
+        const bool s0 = 2 * q < in.CB0;                       // block-uniform
         const bool up = s0 && in.up0;
-        const __amdgpu_buffer_rsrc_t r = s0 ? r0 : r1;
-        const int cbg = s0 ? 2 * q : 2 * q - in.CB0;
-        const int Vs = up ? V0 : V;
-        if (q) __syncthreads();                         // every wave is done reading chunk q - 1
+        const int cbg = s0 ? 2 * q : 2 * q - in.CB0, Vs = up ? V0 : V;
+        const __amdgpu_buffer_rsrc_t r = s0 ? bf_rsrc(static_cast<const char*>(in.x0) + (size_t)o.b * in.CB0 * V0 * 16, (unsigned)in.CB0 * (unsigned)V0 * 16u)
+                                            : bf_rsrc(static_cast<const char*>(in.x1) + (size_t)o.b * in.CB1 * V * 16, (unsigned)in.CB1 * (unsigned)V * 16u);
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            const int i = tid + BF_THREADS * j;
-            if (i < NSLOT) {
-                const int cb = i / ((BF_TD + 2) * PLANE), rem = i - cb * (BF_TD + 2) * PLANE;
-                const int hd = rem / PLANE, r2 = rem - hd * PLANE, hh = r2 / BF_HWV, hw = r2 - hh * BF_HWV;
-                const int gd = d0 - 1 + hd, gh = h0 - 1 + hh, gw = w0 - 1 + hw;
-                const bool ok = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-                const int vox = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
-                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, ok ? vox << 4 : VXM_OOB, (cbg + cb) * Vs * 16, 0));
-                Xs[cb * CBS + rem] = v;
+            const int i = tid_ + BF_THREADS * j;
+            const int cb = i / ((BF_TD + 2) * PLANE), rem = i - cb * (BF_TD + 2) * PLANE;
+            const int hd = rem / PLANE, r2 = rem - hd * PLANE, hh = r2 / BF_HWV, hw = r2 - hh * BF_HWV;
+            const int gd = o.d0 - 1 + hd, gh = o.h0 - 1 + hh, gw = o.w0 - 1 + hw;
+            const bool ok = i < NSLOT && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const int vox = up ? ((gd >> 1) * Hl + (gh >> 1)) * Wl + (gw >> 1) : (gd * H + gh) * W + gw;
+            voffs[j] = ok ? ((cbg + cb) * Vs + vox) << 4 : VXM_OOB;
+            xr[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voffs[j], 0, 0));
+        }
+        if constexpr (WPF) {
+            const __amdgpu_buffer_rsrc_t rw = bf_rsrc(wp + ((size_t)g * Q + q) * WCH, WCH * 16u);
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) wr[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tid_ + BF_THREADS * it) * 16, 0, 0));
+        }
+    };
+    auto store_chunk = [&](int buf, int t, int q, bool first) __attribute__((always_inline)) {
+        load_chunk(t, q, true);
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+        u32x4* const Xd = smem + buf * BUF;
+        if constexpr (!WPF) {
+            if (first || Q > 1) {                             // block-uniform; a one-chunk operator stays in LDS for every tile of the block
+                const __amdgpu_buffer_rsrc_t rw = bf_rsrc(wp + ((size_t)g * Q + q) * WCH, WCH * 16u);
+#pragma unroll
+                for (int it = 0; it < WIT; ++it) {
+                    const int i = tid_ + BF_THREADS * it;
+                    if (i < WCH) Xd[2 * CBS + i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, i * 16, 0, 0));
+                }
             }
         }
-        const __amdgpu_buffer_rsrc_t rw = bf_rsrc(wp + ((size_t)g * Q + q) * WCH, WCH * 16u);
 #pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int i = tid + BF_THREADS * it;
-            if (i < WCH) Ws[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, i * 16, 0, 0));
+        for (int j = 0; j < NI; ++j) {
+            const int i = tid_ + BF_THREADS * j;
+            if (i < NSLOT) {
+                const int cb = i / ((BF_TD + 2) * PLANE), rem = i - cb * (BF_TD + 2) * PLANE;
+                Xd[cb * CBS + rem] = xr[j];
+            }
         }
-        __syncthreads();
+        if constexpr (WPF) {
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int i = tid_ + BF_THREADS * it;
+                if (i < WCH) Xd[2 * CBS + i] = wr[it];
+            }
+        }
+    };
 
+    f32x4 acc[NCT][ROWS];
+    int tile = t_lo, q = 0;
+    load_chunk(tile, 0, false);
+    store_chunk(0, tile, 0, true);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const bool has_next = c + 1 < nchunks;                // block-uniform
+        const bool last_q = q + 1 == Q;
+        const int tile_n = last_q ? tile + t_step : tile, q_n = last_q ? 0 : q + 1;
+        if (has_next) load_chunk(tile_n, q_n, false);         // in flight under the MFMAs below
+        const int buf = DB ? (c & 1) : 0;
+        const u32x4* const Xs = smem + buf * BUF;
+        const u32x4* const Ws = Xs + 2 * CBS;
+        if (q == 0) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) acc[ct][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         // ---- 5 K-steps x (ROWS + 2) haloed rows: one B read per row, up to 3 NCT MFMAs per read
 #pragma unroll
         for (int s = 0; s < BF_STEPS; ++s) {
@@ -155,120 +216,132 @@ __global__ void __launch_bounds__(BF_THREADS, 4) k_bf16_conv(BfIn in, const u32x
                 }
             }
         }
-    }
+        // (the address VGPR of a buffer load that is still in flight must not be handed to the LDS reads above: see keep_offsets in conv_s3.hip)
+        if constexpr (PF) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(voffs[j]));
+        }
 
-    // ---- epilogue.  D layout: lane (kg, n) holds output channels 16 ct + 4 kg + j (j = 0..3) of voxel (d, h0 + row, w0 + n).
-    const int d = d0 + wave, w = w0 + n;
-    const bool vok = d < D && w < W;
-    if constexpr (OUT == 1) {
-        float* const yp = static_cast<float*>(y) + (size_t)b * Cout * V;
-        if (kg == 0 && vok) {
+        if (last_q) {
+        // ---- epilogue.  D layout: lane (kg, n) holds output channels 16 ct + 4 kg + j (j = 0..3) of voxel (d, h0 + row, w0 + n).
+        const Org o = origin(tile);
+        const int b = o.b, d0 = o.d0, h0 = o.h0, w0 = o.w0;
+        const int d = d0 + wave, w = w0 + n;
+        const bool vok = d < D && w < W;
+        if constexpr (OUT == 1) {
+            float* const yp = static_cast<float*>(y) + (size_t)b * Cout * V;
+            if (kg == 0 && vok) {
 #pragma unroll
-            for (int row = 0; row < ROWS; ++row)
-                if (h0 + row < H) {
+                for (int row = 0; row < ROWS; ++row)
+                    if (h0 + row < H) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < Cout) {
-                            float v = acc[0][row][j] + (bias ? bias[j] : 0.0f);
-                            v = v > 0.0f ? v : v * act_slope;
-                            yp[(size_t)j * V + (d * H + h0 + row) * W + w] = v;
-                        }
-                }
-        }
-        return;
-    } else if constexpr (OUT == 2) {
-        // the adjoint of nearest-x2 upsampling fused in: every voxel's result is rounded to bf16 (the value the unfused pair of
-        // kernels stored), the 2 x 2 x 2 children are added in fp32 -- h pairs in registers, w pairs across lanes n ^ 1, d pairs
-        // across waves through LDS -- and the sum, times LeakyReLU'(mask) of the LOW-resolution block, is stored at low resolution.
-        __syncthreads();                                        // every wave is done reading Xs
-        f32x4* const ex = reinterpret_cast<f32x4*>(Xs);         // [4 odd waves][NCT][ROWS / 2][64]
-        f32x4 sum[NCT][ROWS / 2];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-            for (int hp = 0; hp < ROWS / 2; ++hp) {
-                const f32x4 a0 = acc[ct][2 * hp], a1 = acc[ct][2 * hp + 1];
-                const unsigned p0 = bf_pack2(a0[0], a0[1]), p1 = bf_pack2(a0[2], a0[3]), p2 = bf_pack2(a1[0], a1[1]), p3 = bf_pack2(a1[2], a1[3]);
-                f32x4 t = {bf_lo(p0) + bf_lo(p2), bf_hi(p0) + bf_hi(p2), bf_lo(p1) + bf_lo(p3), bf_hi(p1) + bf_hi(p3)};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[j] += __shfl_xor(t[j], 1);
-                sum[ct][hp] = t;
-                if (wave & 1) ex[(((wave >> 1) * NCT + ct) * (ROWS / 2) + hp) * 64 + lane] = t;
-            }
-        __syncthreads();
-        if ((wave & 1) || (n & 1)) return;
-        const int Vl = Dl * Hl * Wl, CBo = Cout >> 3;
-        const int dl = (d0 + wave) >> 1, wl = (w0 + n) >> 1;
-        const __amdgpu_buffer_rsrc_t ry = bf_rsrc(static_cast<char*>(y) + (size_t)b * CBo * Vl * 16, (unsigned)CBo * (unsigned)Vl * 16u);
-        const __amdgpu_buffer_rsrc_t rm = bf_rsrc(mask ? static_cast<const char*>(mask) + (size_t)b * CBo * Vl * 16 : y, (unsigned)CBo * (unsigned)Vl * 16u);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const int co = (g * NCT + ct) * 16 + 4 * kg, pb = co >> 3;
-            const bool cok = dl < Dl && wl < Wl && pb < CBo;
-#pragma unroll
-            for (int hp = 0; hp < ROWS / 2; ++hp) {
-                const int hl = (h0 >> 1) + hp;
-                if (hl < Hl) {                                  // wave-uniform
-                    const f32x4 o = ex[(((wave >> 1) * NCT + ct) * (ROWS / 2) + hp) * 64 + lane];
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = sum[ct][hp][j] + o[j];
-                    const int voff = cok ? (((pb * Dl + dl) * Hl + hl) * Wl + wl) * 16 + (kg & 1) * 8 : VXM_OOB;
-                    if (mask) {
-                        const u32x2 m = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, voff, 0, 0));
-                        v[0] *= vxm_lrelu_grad(bf_lo(m.x), mask_slope); v[1] *= vxm_lrelu_grad(bf_hi(m.x), mask_slope);
-                        v[2] *= vxm_lrelu_grad(bf_lo(m.y), mask_slope); v[3] *= vxm_lrelu_grad(bf_hi(m.y), mask_slope);
+                        for (int j = 0; j < 4; ++j)
+                            if (j < Cout) {
+                                float v = acc[0][row][j] + (bias ? bias[j] : 0.0f);
+                                v = v > 0.0f ? v : v * act_slope;
+                                yp[(size_t)j * V + (d * H + h0 + row) * W + w] = v;
+                            }
                     }
-                    const u32x2 st = {bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3])};
-                    __builtin_amdgcn_raw_buffer_store_b64(st, ry, voff, 0, 0);
+            }
+        } else if constexpr (OUT == 2) {
+            // the adjoint of nearest-x2 upsampling fused in: every voxel's result is rounded to bf16 (the value the unfused pair of
+            // kernels stored), the 2 x 2 x 2 children are added in fp32 -- h pairs in registers, w pairs across lanes n ^ 1, d pairs
+            // across waves through LDS -- and the sum, times LeakyReLU'(mask) of the LOW-resolution block, is stored at low resolution.
+            __syncthreads();                                        // every wave is done reading this buffer
+            f32x4* const ex = reinterpret_cast<f32x4*>(smem + buf * BUF);         // [4 odd waves][NCT][ROWS / 2][64]
+            f32x4 sum[NCT][ROWS / 2];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+                for (int hp = 0; hp < ROWS / 2; ++hp) {
+                    const f32x4 a0 = acc[ct][2 * hp], a1 = acc[ct][2 * hp + 1];
+                    const unsigned p0 = bf_pack2(a0[0], a0[1]), p1 = bf_pack2(a0[2], a0[3]), p2 = bf_pack2(a1[0], a1[1]), p3 = bf_pack2(a1[2], a1[3]);
+                    f32x4 t = {bf_lo(p0) + bf_lo(p2), bf_hi(p0) + bf_hi(p2), bf_lo(p1) + bf_lo(p3), bf_hi(p1) + bf_hi(p3)};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] += __shfl_xor(t[j], 1);
+                    sum[ct][hp] = t;
+                    if (wave & 1) ex[(((wave >> 1) * NCT + ct) * (ROWS / 2) + hp) * 64 + lane] = t;
+                }
+            __syncthreads();
+            if (!((wave & 1) || (n & 1))) {
+                const int Vl = Dl * Hl * Wl, CBo = Cout >> 3;
+                const int dl = (d0 + wave) >> 1, wl = (w0 + n) >> 1;
+                const __amdgpu_buffer_rsrc_t ry = bf_rsrc(static_cast<char*>(y) + (size_t)b * CBo * Vl * 16, (unsigned)CBo * (unsigned)Vl * 16u);
+                const __amdgpu_buffer_rsrc_t rm = bf_rsrc(mask ? static_cast<const char*>(mask) + (size_t)b * CBo * Vl * 16 : y, (unsigned)CBo * (unsigned)Vl * 16u);
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) {
+                    const int co = (g * NCT + ct) * 16 + 4 * kg, pb = co >> 3;
+                    const bool cok = dl < Dl && wl < Wl && pb < CBo;
+#pragma unroll
+                    for (int hp = 0; hp < ROWS / 2; ++hp) {
+                        const int hl = (h0 >> 1) + hp;
+                        if (hl < Hl) {                                  // wave-uniform
+                            const f32x4 ov = ex[(((wave >> 1) * NCT + ct) * (ROWS / 2) + hp) * 64 + lane];
+                            float v[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = sum[ct][hp][j] + ov[j];
+                            const int voff = cok ? (((pb * Dl + dl) * Hl + hl) * Wl + wl) * 16 + (kg & 1) * 8 : VXM_OOB;
+                            if (mask) {
+                                const u32x2 m = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, voff, 0, 0));
+                                v[0] *= vxm_lrelu_grad(bf_lo(m.x), mask_slope); v[1] *= vxm_lrelu_grad(bf_hi(m.x), mask_slope);
+                                v[2] *= vxm_lrelu_grad(bf_lo(m.y), mask_slope); v[3] *= vxm_lrelu_grad(bf_hi(m.y), mask_slope);
+                            }
+                            const u32x2 st = {bf_pack2(v[0], v[1]), bf_pack2(v[2], v[3])};
+                            __builtin_amdgcn_raw_buffer_store_b64(st, ry, voff, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+            const int CBo = Cout >> 3;
+            const __amdgpu_buffer_rsrc_t ry = bf_rsrc(static_cast<char*>(y) + (size_t)b * CBo * V * 16, (unsigned)CBo * (unsigned)V * 16u);
+            const __amdgpu_buffer_rsrc_t rm = bf_rsrc(mask ? static_cast<const char*>(mask) + (size_t)b * CBo * V * 16 : y, (unsigned)CBo * (unsigned)V * 16u);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const int co = (g * NCT + ct) * 16 + 4 * kg;           // first of this lane's 4 channels
+                const int pb = co >> 3;                                // its 8-channel block
+                const bool cok = vok && pb < CBo;
+                float bz[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bz[j] = (bias && co + j < Cout) ? bias[co + j] : 0.0f;
+                // rows in pairs: the lane groups kg and kg ^ 1 hold the two halves of an 8-channel block; v_permlane16_swap (gfx950; lane
+                // pattern probed in tools/probe/permlane_swap_probe.hip) hands the even group the other half of row 2 rp and the odd group
+                // the other half of row 2 rp + 1, so that every lane stores ONE full 16-byte word (half the store instructions: the
+                // epilogue was 8 % store issue + 12 % store traffic of these launches, measured with the stores dropped)
+#pragma unroll
+                for (int rp = 0; rp < ROWS / 2; ++rp) {
+                    unsigned pk[2][2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int row = 2 * rp + e;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = acc[ct][row][j] + bz[j];
+                            v[j] = v[j] > 0.0f ? v[j] : v[j] * act_slope;
+                        }
+                        if (mask) {
+                            const int moff = (cok && h0 + row < H) ? (((pb * D + d) * H + h0 + row) * W + w) * 16 + (kg & 1) * 8 : VXM_OOB;
+                            const u32x2 m = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, moff, 0, 0));
+                            v[0] *= vxm_lrelu_grad(bf_lo(m.x), mask_slope); v[1] *= vxm_lrelu_grad(bf_hi(m.x), mask_slope);
+                            v[2] *= vxm_lrelu_grad(bf_lo(m.y), mask_slope); v[3] *= vxm_lrelu_grad(bf_hi(m.y), mask_slope);
+                        }
+                        pk[e][0] = bf_pack2(v[0], v[1]);
+                        pk[e][1] = bf_pack2(v[2], v[3]);
+                    }
+                    const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                    const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                    const int hrow = h0 + 2 * rp + (kg & 1);
+                    const int voff = (cok && hrow < H) ? (((pb * D + d) * H + hrow) * W + w) * 16 : VXM_OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){s0.x, s1.x, s0.y, s1.y}, ry, voff, 0, 0);
                 }
             }
         }
-        return;
-    } else {
-    const int CBo = Cout >> 3;
-    const __amdgpu_buffer_rsrc_t ry = bf_rsrc(static_cast<char*>(y) + (size_t)b * CBo * V * 16, (unsigned)CBo * (unsigned)V * 16u);
-    const __amdgpu_buffer_rsrc_t rm = bf_rsrc(mask ? static_cast<const char*>(mask) + (size_t)b * CBo * V * 16 : y, (unsigned)CBo * (unsigned)V * 16u);
-#pragma unroll
-    for (int ct = 0; ct < NCT; ++ct) {
-        const int co = (g * NCT + ct) * 16 + 4 * kg;           // first of this lane's 4 channels
-        const int pb = co >> 3;                                // its 8-channel block
-        const bool cok = vok && pb < CBo;
-        float bz[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bz[j] = (bias && co + j < Cout) ? bias[co + j] : 0.0f;
-        // rows in pairs: the lane groups kg and kg ^ 1 hold the two halves of an 8-channel block; v_permlane16_swap (gfx950; lane
-        // pattern probed in tools/probe/permlane_swap_probe.hip) hands the even group the other half of row 2 rp and the odd group
-        // the other half of row 2 rp + 1, so that every lane stores ONE full 16-byte word (half the store instructions: the
-        // epilogue was 8 % store issue + 12 % store traffic of these launches, measured with the stores dropped)
-#pragma unroll
-        for (int rp = 0; rp < ROWS / 2; ++rp) {
-            unsigned pk[2][2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int row = 2 * rp + e;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = acc[ct][row][j] + bz[j];
-                    v[j] = v[j] > 0.0f ? v[j] : v[j] * act_slope;
-                }
-                if (mask) {
-                    const int moff = (cok && h0 + row < H) ? (((pb * D + d) * H + h0 + row) * W + w) * 16 + (kg & 1) * 8 : VXM_OOB;
-                    const u32x2 m = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rm, moff, 0, 0));
-                    v[0] *= vxm_lrelu_grad(bf_lo(m.x), mask_slope); v[1] *= vxm_lrelu_grad(bf_hi(m.x), mask_slope);
-                    v[2] *= vxm_lrelu_grad(bf_lo(m.y), mask_slope); v[3] *= vxm_lrelu_grad(bf_hi(m.y), mask_slope);
-                }
-                pk[e][0] = bf_pack2(v[0], v[1]);
-                pk[e][1] = bf_pack2(v[2], v[3]);
-            }
-            const u32x2 s0 = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
-            const u32x2 s1 = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
-            const int hrow = h0 + 2 * rp + (kg & 1);
-            const int voff = (cok && hrow < H) ? (((pb * D + d) * H + hrow) * W + w) * 16 : VXM_OOB;
-            __builtin_amdgcn_raw_buffer_store_b128((u32x4){s0.x, s1.x, s0.y, s1.y}, ry, voff, 0, 0);
         }
-    }
+        if (!DB) __syncthreads();                               // every wave is done reading the one buffer
+        if (has_next) store_chunk(DB ? ((c + 1) & 1) : 0, tile_n, q_n, false);      // (waits for the requests issued in front of the MFMAs)
+        __syncthreads();
+        tile = tile_n; q = q_n;
     }
 }
 
@@ -747,23 +820,6 @@ int bf_check(const char* fn, int C0, int C1, int up0, int Cout, int B, int D, in
 int bf_nct(int OutC) { return OutC <= 16 ? 1 : 2; }
 bool bf_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <int NCT, int ROWS, int OUT>
-void bf_launch_conv(const BfIn& in, const void* wp, const float* bias, void* y, int Cout, float slope, const void* mask, float mask_slope,
-                    int B, int D, int H, int W, hipStream_t s) {
-    static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf16_conv<NCT, ROWS, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  bf_lds_bytes(NCT, ROWS));
-        return true;
-    }();
-    (void)attr;
-    const int Q = (in.CB0 + in.CB1) / 2;
-    const long long ntiles = (long long)B * ((D + BF_TD - 1) / BF_TD) * ((H + ROWS - 1) / ROWS) * ((W + 15) / 16);
-    const unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
-    const int G = (Cout + 16 * NCT - 1) / (16 * NCT);
-    hipLaunchKernelGGL((k_bf16_conv<NCT, ROWS, OUT>), dim3(gx, G), dim3(BF_THREADS), bf_lds_bytes(NCT, ROWS), s, in,
-                       static_cast<const u32x4*>(wp), bias, y, Cout, slope, mask, mask_slope, B, D, H, W, Q);
-}
-
 int bwb_cus() {
     static const int cus = [] {
         int dev = 0; hipDeviceProp_t p;
@@ -772,6 +828,32 @@ int bwb_cus() {
     }();
     return cus;
 }
+
+template <int NCT, int ROWS, int OUT>
+void bf_launch_conv(const BfIn& in, const void* wp, const float* bias, void* y, int Cout, float slope, const void* mask, float mask_slope,
+                    int B, int D, int H, int W, hipStream_t s) {
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bf16_conv<NCT, ROWS, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  bf_lds_bytes_p(NCT, ROWS));
+        return true;
+    }();
+    (void)attr;
+    const int Q = (in.CB0 + in.CB1) / 2;
+    const long long ntiles = (long long)B * ((D + BF_TD - 1) / BF_TD) * ((H + ROWS - 1) / ROWS) * ((W + 15) / 16);
+    unsigned gx = ntiles >= 64 ? (unsigned)(8 * ((ntiles + 7) / 8)) : (unsigned)ntiles;
+    const int G = (Cout + 16 * NCT - 1) / (16 * NCT);
+    // persistent blocks: as many as fit the chip at once (two per CU for the 16-channel instances, one for the double-buffered 32-channel ones),
+    // each walking its XCD's tile range; VXM_BF16_PERSIST=n: n blocks per CU, 0: one tile per block, < 0: that many blocks in all (tests)
+    static const int persist = [] { const char* e = getenv("VXM_BF16_PERSIST"); return e ? atoi(e) : (bf_db(NCT) ? 1 : 2); }();
+    if (persist != 0 && ntiles >= 64) {
+        const unsigned want = persist > 0 ? (unsigned)(bwb_cus() * persist / G) : (unsigned)(-persist);
+        const unsigned cap = 8 * ((want + 7) / 8);
+        if (cap < gx) gx = cap;
+    }
+    hipLaunchKernelGGL((k_bf16_conv<NCT, ROWS, OUT>), dim3(gx, G), dim3(BF_THREADS), bf_lds_bytes_p(NCT, ROWS), s, in,
+                       static_cast<const u32x4*>(wp), bias, y, Cout, slope, mask, mask_slope, B, D, H, W, Q);
+}
+
 // one persistent block per CU over all chunks; columns are cut into depth segments until there are ~4 tasks per block
 // (a segment start re-fetches two planes: 1 / seg_len overhead)
 BwbTasks bwb_tasks(int Q, int B, int D, int H, int W, int& NBLK) {
