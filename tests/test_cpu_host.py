@@ -471,15 +471,20 @@ def test_split_engine_enumerates_its_operators(monkeypatch):
 def test_channel_blocked_tensor_rule(monkeypatch):
     """`functional._blocked_tensors`: which activations of the fused U-Net are kept channel-blocked between the split kernels.  With every
     shape test of the C side answering yes for multiples-of-8 channels at the two finest levels (stand-ins below), the default VxmDense plan
-    yields exactly the outputs of remaining[0] and remaining[1]: the last ConvBlock feeds the flow conv (3 channels: not a split kernel),
-    the first layer's output and the encoder / decoder outputs are read by MaxPool / as skip or upsampled segments.  A U-Net with two
+    yields the outputs of remaining[0], remaining[1] and -- round 6, late: the three few-channel kernels around the flow conv take the layout
+    flags -- remaining[2], whose consumer is the 3-channel flow conv (VXM_BLOCKED_LAST=0, or a predicate of those kernels saying no, leaves it
+    planar); the first layer's output and the encoder / decoder outputs are read by MaxPool / as skip or upsampled segments.  A U-Net with two
     convolutions per level also keeps the first output of every encoder / decoder pair -- except the first layer's, whose producer is the
     few-input-channel kernel -- and VXM_BLOCKED=0 / the other engines keep everything planar."""
     import types
     from voxelmorph_amd.torch import functional as VF
     stub = types.SimpleNamespace(
         vxm_conv3d_k3_s3_layout_ok=lambda c0, c1, up, cout, H, pieces: int(pieces == 2 and c1 == 0 and not up and c0 % 8 == 0 and cout % 8 == 0 and H >= 8),
-        vxm_conv3d_k3_s3_bwd_weight_ok=lambda c, cout, B, D, H, W: int(c % 16 == 0 and cout % 16 == 0 and D >= 80))
+        vxm_conv3d_k3_s3_bwd_weight_ok=lambda c, cout, B, D, H, W: int(c % 16 == 0 and cout % 16 == 0 and D >= 80),
+        vxm_conv3d_k3_fewout_ok=lambda x, xbs, y, ybs, cin, cout, W: int(cout <= 4 and W % 4 == 0),
+        vxm_conv3d_k3_fewch_bwd_weight_ok=lambda x0, c0, bs0, x1, c1, bs1, dz, dzbs, cout, pieces, W: int(pieces == 2 and c0 == 16 and c1 == 0 and cout <= 3 and few["bw"]),
+        vxm_conv3d_k3_fwd_layout_ok=lambda x0, c0, bs0, x1, c1, bs1, wp, cout, B, D, H, W: int(c0 + c1 <= 4 and cout % 8 == 0))
+    few = {"bw": True}
     monkeypatch.setattr(VF, "_lib", types.SimpleNamespace(lib=lambda: stub))
     monkeypatch.setattr(VF, "FP32_ENGINE", "f16x2")
     monkeypatch.setattr(VF, "BLOCKED", True)
@@ -491,10 +496,19 @@ def test_channel_blocked_tensor_rule(monkeypatch):
     m = vxm.networks.VxmDense(shape, int_steps=0)
     plan = m.unet_model.plan(m._feats, extra=((m.flow.out_channels, 1.0),))
     convs = [op for op in plan.ops if op["kind"] == "conv"]
-    rem0, rem1 = convs[8]["dst"], convs[9]["dst"]        # execution order: 4 encoder, 4 decoder, 3 remaining, flow
-    assert (plan.ch[rem0], plan.ch[rem1], plan.lvl[rem0], plan.lvl[rem1]) == (32, 16, 0, 0)
+    rem0, rem1, rem2 = convs[8]["dst"], convs[9]["dst"], convs[10]["dst"]        # execution order: 4 encoder, 4 decoder, 3 remaining, flow
+    assert (plan.ch[rem0], plan.ch[rem1], plan.ch[rem2], plan.lvl[rem0], plan.lvl[rem1], plan.lvl[rem2]) == (32, 16, 16, 0, 0, 0)
+    assert plan.consumers[rem2] == [plan.producer[plan.out]] and plan.ch[plan.out] == 3
+    assert VF._blocked_tensors(plan, 1, shape) == frozenset({rem0, rem1, rem2})
+    assert VF._blocked_tensors(plan, 4, shape) == frozenset({rem0, rem1, rem2})
+    monkeypatch.setattr(VF, "BLOCKED_LAST", False)
     assert VF._blocked_tensors(plan, 1, shape) == frozenset({rem0, rem1})
-    assert VF._blocked_tensors(plan, 4, shape) == frozenset({rem0, rem1})
+    monkeypatch.setattr(VF, "BLOCKED_LAST", True)
+    few["bw"] = False                                    # the flow conv's weight gradient would not take a blocked x: the tensor stays planar
+    plan.__dict__.pop("_blocked_cache", None)
+    assert VF._blocked_tensors(plan, 1, shape) == frozenset({rem0, rem1})
+    few["bw"] = True
+    plan.__dict__.pop("_blocked_cache", None)
     monkeypatch.setattr(VF, "BLOCKED", False)
     assert VF._blocked_tensors(plan, 1, shape) == frozenset()
     monkeypatch.setattr(VF, "BLOCKED", True)
