@@ -252,8 +252,9 @@ class VxmDense(LoadableModel):
             field = engine.apply(plan, source, target, *self.unet_model.conv_params(), self.flow.weight, self.flow.bias)
         velocity = self.resize(field) if self.resize is not None else field       # what Grad regularises ("preint_flow")
         v_int = velocity
-        if self.ndims == 3 and self.integrate is not None and velocity.requires_grad and velocity.is_cuda and velocity.dtype == torch.float32:
-            # the field has two consumers (the caller's Grad loss, the integration): their gradients are summed by this library's kernel
+        if self.ndims == 3 and velocity.requires_grad and velocity.is_cuda and velocity.dtype == torch.float32:
+            # the field has two consumers (the caller's Grad loss; the integration or, with int_steps = 0, the warp itself): their gradients are
+            # summed by this library's kernel instead of autograd's ATen add
             velocity, v_int = VF.ForkFn.apply(velocity)
 
         def displacement(v):
