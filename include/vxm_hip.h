@@ -159,7 +159,10 @@ int vxm_conv3d_k3_fewout_ok(const float* x, int64_t x_bstride, float* y, int64_t
 int vxm_conv3d_k3_fewout_fwd(const float* x, int Cin, int64_t x_bstride, const float* w, const float* bias, float* y,
                              int64_t y_bstride, int Cout, float act_slope, int B, int D, int H, int W, void* stream);
 /* Which kernel a vxm_conv3d_k3_fwd call with these operands dispatches to (for profiling labels):
- * 100 * wide + 10 * CK + NCT, wide = 1: the 8-wave wide-load kernel (k_conv3d_k3_t8<NCT>), 0: k_conv3d_k3<CK,NCT>. */
+ * 100 * wide + 10 * CK + NCT, wide = 1: the 8-wave wide-load kernel (k_conv3d_k3_t8<NCT>), 0: k_conv3d_k3<CK,NCT>;
+ * 200 + Cin: the few-input-channel kernel (k_conv3d_k3_kpack<Cin>); 300 + NW: the small-volume kernel whose NW waves per block split
+ * the input channels (k_conv3d_k3_sm<NW>: grids that would leave more than half of the CUs without a block, i.e. the U-Net levels
+ * at 1/8 and 1/16 resolution; VXM_CONV_SMALL_MAX_BLOCKS=0 keeps k_conv3d_k3 there). */
 int vxm_conv3d_k3_fwd_variant(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride,
                               const float* wpacked, int Cout, int B, int D, int H, int W);
 /* Same for vxm_conv3d_k3_bwd_weight: 10 * kind + NCT, kind = 0: k_conv3d_k3_bwd_weight_dma, 1: ..._vec, 2: collapsed
@@ -455,6 +458,8 @@ int vxm_conv3d_k3_fwd_layout(const float* x0, int C0, int64_t x0_bstride, int x0
 int vxm_conv3d_k3_s3_layout_ok(int C0, int C1, int x0_up, int Cout, int H, int pieces);
 int vxm_conv3d_k3_s3_variant(int Cout);                     /* 10 * NCT + CB of the kernel instance (profiling labels) */
 int vxm_conv3d_k3_s3_tile_rows(int Cout, int pieces, int H); /* rows of its output tile: 8 x 8 x 16 on the fp16 scheme, else 8 x 4 x 16 */
+int vxm_conv3d_k3_s3_tile_rows_at(int Cout, int pieces, int B, int D, int H, int W); /* ... of a launch of this shape on planar tensors (a 32-channel
+                                                                                       * operator takes 4 rows where 8 would leave CUs without a block) */
 /* 1 when the launch runs k_s3p_conv (the same tile, operator pack and results with producer and consumer waves: 16-output-channel
  * forward launches of the fp16 scheme on large volumes; profiling labels) */
 int vxm_conv3d_k3_s3_producer_consumer(int Cout, int pieces, int has_mask, int B, int D, int H, int W);

@@ -116,6 +116,7 @@ SIGNATURES = {
     "vxm_conv3d_k3_s3_ok": [_I, _I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3_variant": [_I],
     "vxm_conv3d_k3_s3_tile_rows": [_I, _I, _I],
+    "vxm_conv3d_k3_s3_tile_rows_at": [_I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3_producer_consumer": [_I, _I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3_layout_ok": [_I, _I, _I, _I, _I, _I],
     "vxm_conv3d_k3_s3_packed_bytes": [_I, _I, _I, _I],

@@ -124,6 +124,136 @@ __global__ void __launch_bounds__(256) k_conv3d_k3(ConvIn in, const float* __res
                                 d < D && w < W, (d * H + h0) * W + w, h0, H, W, V);
 }
 
+// ------------------------------------------------------------------------------------------
+// forward / backward-data kernel for SMALL volumes (the U-Net levels at 1/8 and 1/16 resolution: 20x24x28, 10x12x14)
+// ------------------------------------------------------------------------------------------
+// k_conv3d_k3 covers such a level with <= 60 blocks of four waves, and every wave walks all Cin x 27 taps of its depth slice: 432 Q
+// dependent-issue MFMAs of 32 cycles on 240 of the chip's 1024 SIMDs -- 38 - 75 us per launch for 0.7 - 1.5 GFLOP (round 6 dispatch trace),
+// six launches on the step's critical path.  Here the SAME implicit GEMM (same packed operator, same fragments) is cut four ways more:
+//  * output tile 2(D) x 4(H) x 16(W) voxels x ONE 16-channel output tile (blockIdx.y), so a 32-channel layer at 20x24x28 is 240 blocks;
+//  * the input channels are split over the NW waves of a block (wave v multiplies the 8-channel chunks q = v, v + NW, ...): each wave
+//    stages its own chunk into its own LDS region (no block barrier while multiplying) and keeps the chunk's 54 weight fragments in
+//    registers, straight from the packed operator in L2;
+//  * the NW partial tiles meet in LDS and are added in wave order 0 .. NW - 1 (deterministic), wave v finishing 8 / NW of the tile's rows.
+// The sum over the input channels is therefore associated differently from k_conv3d_k3 (per-wave fp32 chains, then NW - 1 adds):
+// same accuracy class (tests/test_gpu_parity.py gates both against fp64), not the same bits.
+constexpr int SM_TD = 2, SM_HD = SM_TD + 2;
+constexpr int SM_PS = 496;                      // channel plane [SM_HD][6][20] = 480 floats, padded to 16 mod 32 (as FWD_PS)
+constexpr int SM_XW = 8 * SM_PS;                // LDS floats of one wave: its haloed 8-channel chunk, later its partial tile (8 x 64 x 4 floats)
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW) k_conv3d_k3_sm(ConvIn in, const float* __restrict__ wp, const float* __restrict__ bias,
+                                                         float* __restrict__ y, long long y_bs, int Cout, float act_slope,
+                                                         const float* __restrict__ mask, long long mask_bs, float mask_slope,
+                                                         int D, int H, int W, int Q, int PNCT) {
+    VXM_DYN_SMEM(float, smem);
+    constexpr int PER = 8 / NW;                     // rows of the tile a wave finishes
+    static_assert(NW == 2 || NW == 4 || NW == 8, "a wave finishes rows of ONE depth slice");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, n = lane & 15;
+    const int nw = (W + TW - 1) / TW, nh = (H + TH - 1) / TH, nd = (D + SM_TD - 1) / SM_TD;
+    int t = blockIdx.x;
+    const int tw = t % nw; t /= nw;
+    const int th = t % nh; t /= nh;
+    const int td = t % nd; const int b = t / nd;
+    const int d0 = td * SM_TD, h0 = th * TH, w0 = tw * TW;
+    const int gc = blockIdx.y, g = gc / PNCT, ct = gc - g * PNCT;       // 16-channel output tile gc = tile ct of the operator's group g
+    float* const Xs = smem + wave * SM_XW;
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging addresses: the lane part (row, column of a 3-row slab: byte offset inside a depth plane, full-resolution and through the x2
+    // upsampling gather; beyond the volume -> out of the descriptor's range -> 0.0) is computed once, channel / depth are scalar offsets
+    const SlabLane L = make_slab_lane(lane, h0, w0, W);
+    const int lds_lane = L.rr * FWD_TWP + L.wx;
+    const int bbase = kq * SM_PS + n;
+    const int Dl = D >> 1, Hl = H >> 1, Wl = W >> 1;
+    int voffF[2], voffU[2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        const int gh = L.gh0 + 3 * hb;
+        const bool ok = L.wok && (unsigned)gh < (unsigned)H;
+        voffF[hb] = ok ? (gh * W + L.gw) << 2 : VXM_OOB;
+        voffU[hb] = ok ? ((gh >> 1) * Wl + (L.gw >> 1)) << 2 : VXM_OOB;
+    }
+    const int Vfull = D * H * W, V0 = in.up0 ? Dl * Hl * Wl : Vfull;
+    const __amdgpu_buffer_rsrc_t r0 = vxm_rsrc(in.x0 + (size_t)b * in.bs0, (unsigned)in.C0 * (unsigned)V0 * 4u);
+    const __amdgpu_buffer_rsrc_t r1 = vxm_rsrc(in.C1 ? in.x1 + (size_t)b * in.bs1 : in.x0, (unsigned)in.C1 * (unsigned)Vfull * 4u);
+    const int wchunk = 27 * 2 * PNCT * 64;
+    for (int q = wave; q < Q; q += NW) {
+        float a[54];
+        const __amdgpu_buffer_rsrc_t rw = vxm_rsrc(wp + ((size_t)g * Q + q) * wchunk, (unsigned)wchunk * 4u);
+#pragma unroll
+        for (int i = 0; i < 54; ++i) a[i] = vxm_bload(rw, (ct * 64 + lane) << 2, (i * PNCT) << 8);
+        constexpr int XIT = 8 * SM_HD * 2;
+        float xv[XIT];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int cg = q * 8 + c;                                   // wave-uniform
+            const bool s0 = cg < in.C0, up = s0 && in.up0;
+            const __amdgpu_buffer_rsrc_t r = s0 ? r0 : r1;
+            const int cc = s0 ? cg : cg - in.C0;
+            const int Ds = up ? Dl : D, PV = up ? Hl * Wl : H * W;
+#pragma unroll
+            for (int dz = 0; dz < SM_HD; ++dz) {
+                const int d = d0 + dz - 1;
+                const bool ok = cg < in.C0 + in.C1 && (unsigned)d < (unsigned)D;
+                const int soff = ok ? ((cc * Ds + (up ? d >> 1 : d)) * PV) << 2 : 0;
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb)
+                    xv[(c * SM_HD + dz) * 2 + hb] = vxm_bload(r, ok ? (up ? voffU[hb] : voffF[hb]) : VXM_OOB, soff);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // (second chunk of a wave: its reads of the first are done)
+        if (L.act) {
+#pragma unroll
+            for (int it = 0; it < XIT; ++it) {
+                const int c = it / (SM_HD * 2), dz = (it >> 1) % SM_HD, hb = it & 1;
+                Xs[c * SM_PS + (dz * HH + hb * 3) * FWD_TWP + lds_lane] = xv[it];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // the region is this wave's own: no block barrier
+#pragma unroll
+        for (int tp = 0; tp < 27; ++tp) {
+            const int kd = tp / 9, kh = (tp / 3) % 3, kw = tp % 3;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float bv[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) bv[m] = Xs[bbase + s * 4 * SM_PS + (((m >> 2) + kd) * HH + (m & 3) + kh) * FWD_TWP + kw];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[m] = vxm_mfma16(a[tp * 2 + s], bv[m], acc[m]);
+            }
+        }
+    }
+
+    // ---- the NW partial tiles meet in LDS (each wave's own region, its chunk is read), added in wave order
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int m = 0; m < 8; ++m) reinterpret_cast<f32x4*>(Xs)[m * 64 + lane] = acc[m];
+    __syncthreads();
+    f32x4 fin[1][PER];
+#pragma unroll
+    for (int p = 0; p < PER; ++p) {
+        const int m = wave * PER + p;
+        f32x4 sum = reinterpret_cast<const f32x4*>(smem)[m * 64 + lane];
+#pragma unroll
+        for (int v = 1; v < NW; ++v) sum += reinterpret_cast<const f32x4*>(smem + v * SM_XW)[m * 64 + lane];
+        fin[0][p] = sum;
+    }
+    // ---- epilogue of rows [row0, row0 + PER) of depth slice dd: bias + LeakyReLU (+ fused leaky_relu_backward mask), NCDHW store
+    const int dd = (wave * PER) >> 2, row0 = (wave * PER) & 3;
+    const int d = d0 + dd, w = w0 + n;
+    const int V = Vfull;
+    float bz[1][4];
+    conv_load_bias<1>(bz, bias, Cout, gc, kq);
+    conv_epilogue_store<1, PER>(fin, y + (size_t)b * y_bs, bz, mask ? mask + (size_t)b * mask_bs : nullptr, act_slope, mask_slope, Cout, gc, kq,
+                                d < D && w < W, (d * H + h0 + row0) * W + w, h0 + row0, H, W, V);
+}
+
 
 // ------------------------------------------------------------------------------------------
 // forward / backward-data kernel, 8-wave version for the large layers (W % 4 == 0, 16-byte aligned tensors)
@@ -1149,6 +1279,15 @@ bool kpack_ok(int C0, int C1, int x0_up, const float* x0, int64_t bs0, const flo
            (((long long)D * H * W) & 3) == 0 && al16(wpacked) && tiles8 >= wide_min_tiles() && tiles8 < (1ll << 30) && !bw_force_generic();
 }
 
+// k_conv3d_k3_sm replaces k_conv3d_k3 where that kernel's grid (4 x 4 x 16 tiles x output-channel groups) has at most this many blocks, i.e.
+// leaves more than half of the 256 CUs without a block; VXM_CONV_SMALL_MAX_BLOCKS overrides (0: never -- the tests' A/B switch)
+long long small_max_blocks() {
+    static const long long v = [] { const char* e = getenv("VXM_CONV_SMALL_MAX_BLOCKS"); return e ? atoll(e) : 128ll; }();
+    return v;
+}
+
+bool small_ok(const ConvCfg& c, long long tiles) { return c.CK == 8 && c.Q >= 4 && tiles * c.G <= small_max_blocks() && !bw_force_generic(); }
+
 // rows per wave of the 8-wave kernel
 int fwd_wide_rows(const ConvCfg& c) { (void)c; return 4; }     // 6 rows with one output tile measured 4 % slower than 4
 bool fwd_wide_ok(const ConvCfg& c, const float* x0, int64_t bs0, const float* x1, int C1, int64_t bs1, const float* wpacked,
@@ -1287,6 +1426,22 @@ int vxm_conv3d_k3_fwd_layout(const float* x0, int C0, int64_t x0_bstride, int x0
     }
     const long long tiles = (long long)B * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
     VXM_REQUIRE(tiles < (1ll << 31), VXM_ERR_BAD_SHAPE, "vxm_conv3d_k3_fwd: too many tiles");
+    // small volumes: input channels split over the waves of a block, 2 x 4 x 16 tiles, one 16-channel output tile per block
+    if (small_ok(c, tiles)) {
+        const long long tsm = (long long)B * ((D + SM_TD - 1) / SM_TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+        const dim3 gsm((unsigned)tsm, (Cout + 15) / 16);
+        static bool opt_in_sm = false;
+        if (!opt_in_sm) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3d_k3_sm<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SM_XW * 4);
+            opt_in_sm = true;
+        }
+#define LAUNCHS(NW_) hipLaunchKernelGGL((k_conv3d_k3_sm<NW_>), gsm, dim3(64 * NW_), sizeof(float) * NW_ * SM_XW, VXM_STREAM(stream), in, wpacked, bias, y, \
+        (long long)y_bstride, Cout, act_slope, mask_src, (long long)mask_bstride, mask_slope, D, H, W, c.Q, c.NCT)
+        if (c.Q >= 8) LAUNCHS(8);
+        else LAUNCHS(4);
+#undef LAUNCHS
+        return vxm_check_launch("vxm_conv3d_k3_fwd");
+    }
     const dim3 grid((unsigned)tiles, c.G);
     const size_t lds = sizeof(float) * ((size_t)c.CK * FWD_PS + 27 * (c.CK / 4) * c.NCT * 64);
 #define LAUNCH(CK_, NCT_) hipLaunchKernelGGL((k_conv3d_k3<CK_, NCT_>), grid, dim3(256), lds, VXM_STREAM(stream), in, wpacked, bias, y, \
@@ -1313,7 +1468,10 @@ int vxm_conv3d_k3_fwd_variant(const float* x0, int C0, int64_t x0_bstride, const
     if (C0 <= 0 || C1 < 0 || Cout <= 0) return -1;
     const ConvCfg c = conv_cfg(C0 + C1, Cout);
     if (kpack_ok(C0, C1, 0, x0, x0_bstride, x1, x1_bstride, wpacked, B, D, H, W)) return 200 + C0 + C1;
-    return (fwd_wide_ok(c, x0, x0_bstride, x1, C1, x1_bstride, wpacked, B, D, H, W) ? 100 : 0) + 10 * c.CK + c.NCT;
+    if (fwd_wide_ok(c, x0, x0_bstride, x1, C1, x1_bstride, wpacked, B, D, H, W)) return 100 + 10 * c.CK + c.NCT;
+    const long long tiles = (long long)B * ((D + TD - 1) / TD) * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+    if (small_ok(c, tiles)) return 300 + (c.Q >= 8 ? 8 : 4);
+    return 10 * c.CK + c.NCT;
 }
 
 int vxm_conv3d_k3_up_ok(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, float* y,

@@ -1840,6 +1840,13 @@ void s3_launch(const ConvIn& in, const void* wp, const float* bias, float* y, lo
                        Cout, slope, mask, mask_bs, mask_slope, B, D, H, W, Q0, Q, lay, s3_dbg());
 }
 
+// VXM_S3_ROWS8_MIN_BLOCKS: smallest grid (8 x 8 x 16 tiles x 32-channel output groups) for which a 32-channel operator keeps the 8-row instance
+bool s3_rows8_fills_chip(int Cout, int B, int D, int H, int W) {
+    static const long long rows8_min = [] { const char* e = getenv("VXM_S3_ROWS8_MIN_BLOCKS"); return e ? atoll(e) : 256ll; }();
+    const long long nb8 = (long long)B * ((D + S3_TD - 1) / S3_TD) * ((H + 7) / 8) * ((W + 15) / 16) * ((Cout + 31) / 32);
+    return nb8 >= rows8_min;
+}
+
 bool s3_use_pc(int B, int D, int H, int W, bool has_mask) {
     static const int pc = [] { const char* e = getenv("VXM_S3_PC"); return e ? atoi(e) : -1; }();
     const long long nt8 = (long long)B * ((D + 7) / 8) * ((H + 7) / 8) * ((W + 15) / 16);
@@ -1906,6 +1913,11 @@ int vxm_conv3d_k3_s3_producer_consumer(int Cout, int pieces, int has_mask, int B
 int vxm_conv3d_k3_s3_tile_rows(int Cout, int pieces, int H) {
     static const bool rows8 = [] { const char* e = getenv("VXM_S3_ROWS"); return !(e && e[0] == '4'); }();
     return (pieces == 2 && rows8 && H >= 8 && s3_variant(Cout).CB == 1) ? 8 : 4;
+}
+/* the same for a launch of this shape on planar tensors: a 32-channel operator whose 8 x 8 x 16 tiles would leave CUs without a block takes 4 rows */
+int vxm_conv3d_k3_s3_tile_rows_at(int Cout, int pieces, int B, int D, int H, int W) {
+    const int r = vxm_conv3d_k3_s3_tile_rows(Cout, pieces, H);
+    return (r == 8 && s3_variant(Cout).NCT == 2 && !s3_rows8_fills_chip(Cout, B, D, H, W)) ? 4 : r;
 }
 
 size_t vxm_conv3d_k3_s3_packed_bytes(int seg0, int seg1, int OutC, int pieces) {
@@ -1979,7 +1991,10 @@ int vxm_conv3d_k3_s3_fwd(const float* x0, int C0, int64_t x0_bstride, int x0_up,
     // scale; VXM_S3_ROWS=4 keeps the 8 x 4 x 16 tiles (A/B)
     static const bool rows8 = [] { const char* e = getenv("VXM_S3_ROWS"); return !(e && e[0] == '4'); }();
     const bool blk_in = (lay & VXM_S3_IN0_BLOCKED) != 0;
-    if (v.NCT == 2 && pieces == 2 && rows8 && H >= 8 && v.CB == 1) {
+    // 32-channel operators whose 8 x 8 x 16 tiles x output-channel groups do not give every CU a block (the 40x48x56 level: 120 tiles for 256
+    // CUs) take the 8 x 4 x 16 instance: enc2 forward 46 -> 33 us, its backward-data 44 -> 31, dec2 forward 76 -> 52 (round 6, rocprof); with two
+    // output-channel groups (240 blocks) the 8-row instance stays ahead (47 against 54 us).  VXM_S3_ROWS8_MIN_BLOCKS overrides the threshold.
+    if (v.NCT == 2 && pieces == 2 && rows8 && H >= 8 && v.CB == 1 && (s3_rows8_fills_chip(Cout, B, D, H, W) || lay != 0)) {
         if (blk_in) s3_launch<2, 8, 1, 2, true, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s, lay);
         else s3_launch<2, 8, 1, 2, true>(in, wpacked, bias, y, y_bstride, Cout, leaky_slope, mask, mask_bstride, mask_slope, B, D, H, W, s, lay);
     }

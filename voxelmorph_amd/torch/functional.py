@@ -712,7 +712,7 @@ def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask
     v = _lib.lib().vxm_conv3d_k3_s3_variant(cout)
     name = None
     if _prof.ACTIVE is not None:          # label the region with the kernel the C ABI will dispatch to
-        rows = _lib.lib().vxm_conv3d_k3_s3_tile_rows(cout, s3_pieces(), H)
+        rows = _lib.lib().vxm_conv3d_k3_s3_tile_rows(cout, s3_pieces(), H) if lay else _lib.lib().vxm_conv3d_k3_s3_tile_rows_at(cout, s3_pieces(), B, D, H, W)
         pc = _lib.lib().vxm_conv3d_k3_s3_producer_consumer(cout, s3_pieces(), 0 if (mask is None or lay & (S3_MASK_SIGNS | S3_OUT_SIGNS)) else 1, B, D, H, W)
         name = "k_s3p_conv<%d,%d>" % (v // 10, s3_pieces()) if pc else "k_s3_conv<%d,%d,%d,%d>" % (v // 10, rows, v % 10, s3_pieces())
     with _prof.region(name, flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
@@ -725,8 +725,9 @@ def conv_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, ma
     name = None
     if _prof.ACTIVE is not None:          # label the region with the kernel the C ABI will dispatch to
         v = _lib.lib().vxm_conv3d_k3_fwd_variant(ptr(x0), c0, bs0, ptr(x1), c1, bs1, ptr(wp), cout, B, D, H, W)
-        name = "k_conv3d_k3_kpack<%d>" % (v - 200) if v >= 200 else (
-            "k_conv3d_k3_t8<%d>" % (v % 10) if v >= 100 else "k_conv3d_k3<%d,%d>" % (v // 10, v % 10))
+        name = "k_conv3d_k3_kpack<%d>" % (v - 200) if 200 <= v < 300 else (
+            "k_conv3d_k3_sm<%d>" % (v - 300) if v >= 300 else (
+            "k_conv3d_k3_t8<%d>" % (v % 10) if v >= 100 else "k_conv3d_k3<%d,%d>" % (v // 10, v % 10)))
     with _prof.region(name, flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
         if lay:
             call("vxm_conv3d_k3_fwd_layout", ptr(x0), c0, bs0, 1 if up0 else 0, ptr(x1), c1, bs1, ptr(wp), ptr(bias), ptr(y), ybs,
