@@ -204,6 +204,9 @@ int vxm_upsample3d_k_bwd(const float* gy, int Ctot, int C0, float* gx0, int B, i
 /* ---- MaxPool3d(2), networks.py:83-84,130.  x [B,C,D,H,W] (x_bstride) -> y [B,C,D/2,H/2,W/2]. */
 int vxm_maxpool2_fwd(const float* x, int64_t x_bstride, float* y, int B, int C, int D, int H, int W,
                      void* stream);
+/* The same, and one 16-bit word per pooled voxel and channel (code [B,C,D/2,H/2,W/2]) with what the backward pass reads of its 2x2x2 block:
+ * bit k = 4 dz + 2 dy + dx: x[k] > 0; bits 8..10: the arg-max (first maximum in scan order, a NaN wins).  Even D, H, W. */
+int vxm_maxpool2_fwd_code(const float* x, int64_t x_bstride, float* y, uint16_t* code, int B, int C, int D, int H, int W, void* stream);
 /* fused backward of {max_pool3d, the skip branch of the concat, leaky_relu}:
  * dz[b,c,p] = (gskip[b,c,p] + (p is the arg-max of its 2x2x2 block ? gpool[b,c,p>>1] : 0)) * LeakyReLU'(x[b,c,p])
  * gskip nullable; slope = 1 gives the plain max-pool backward.  First max in scan order wins ties,
@@ -324,6 +327,15 @@ int vxm_conv3d_k3_fewch_bwd_weight_ok(const float* x0, int C0, int64_t x0_bstrid
 int vxm_conv3d_k3_fewch_bwd_weight(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* dz,
                                    int64_t dz_bstride, int Cout, float* gw, float* gb, void* workspace, size_t workspace_bytes, int B, int D, int H,
                                    int W, int pieces, void* stream);
+/* The first ConvBlock's weight / bias gradient straight from the operands of vxm_maxpool2_bwd (networks.py:130,299-305 autograd twins:
+ * max_pool3d backward + the skip branch of the concat + leaky_relu_backward + convolution_backward(weight, bias) in one launch): the gradient at the
+ * block's pre-activation, dz = (gskip + routed gpool) * LeakyReLU'(y), is formed while its tiles are staged -- from gskip [B,16,D,H,W]
+ * (gskip_bstride), gpool [B,16,D/2,H/2,W/2] and the code words of vxm_maxpool2_fwd_code -- instead of being written (0.44 GB at 160x192x224) and
+ * read back.  Same arithmetic in the same order as vxm_maxpool2_bwd followed by vxm_conv3d_k3_fewch_bwd_weight: bit-identical gw / gb.
+ * Cout = 16, C0 + C1 <= 3, even D, H, W, W % 4 == 0, pieces = 2; workspace as vxm_conv3d_k3_bwd_weight_workspace_bytes(C0 + C1, 16, ...). */
+int vxm_conv3d_k3_fewch_bwd_weight_pool(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* gskip,
+                                        int64_t gskip_bstride, const float* gpool, const uint16_t* code, float slope, float* gw, float* gb, void* workspace,
+                                        size_t workspace_bytes, int B, int D, int H, int W, int pieces, void* stream);
 
 /* ---- the weighted sum of the loss terms, scripts/torch/train.py:205-212 (`loss += loss_function(y_true[n], y_pred[n]) * weights[n]`):
  * total[0] = sum_n terms[n][0] * weights[n], products and running sum in that order in fp32, ONE launch instead of a mul + an add per term.

@@ -1262,6 +1262,52 @@ def test_channel_blocked_interior_tensors_change_no_bit_of_the_step(vxm):
         VF.BLOCKED, VF.SIGNS = keep, keep_signs
 
 
+def test_pooling_backward_fused_into_the_first_weight_gradient_changes_no_bit(vxm):
+    """Round 6: the gradient at the first ConvBlock's pre-activation -- max_pool3d backward + the skip branch + leaky_relu_backward, 0.44 GB at
+    160x192x224 with ONE reader -- is formed inside that reader (vxm_conv3d_k3_fewch_bwd_weight_pool, from the 16-bit codes of
+    vxm_maxpool2_fwd_code) instead of by vxm_maxpool2_bwd.  Same operations in the same order: every parameter gradient of the headline step must
+    be BIT-IDENTICAL with and without the fusion (functional.POOL_FUSE), with one and two pairs, on noise and with ties / negatives / a NaN in play
+    (an image of zeros makes every first-block activation of a channel equal: the arg-max is then decided by scan order alone)."""
+    from voxelmorph_amd.torch import functional as VF
+    if VF.FP32_ENGINE != "f16x2":
+        pytest.skip("the few-channel fp16-piece weight gradient exists on the fp16 piece scheme only")
+    keep = VF.POOL_FUSE
+    try:
+        for shape, B, kind in ((FULL, 1, "noise"), ((32, 48, 64), 2, "noise"), ((32, 48, 64), 1, "flat"), ((32, 48, 64), 1, "nan")):
+            rng = np.random.default_rng(5)
+            src, trg = G(rng.random((B, 1) + shape)), G(rng.random((B, 1) + shape))
+            if kind == "flat":
+                src[:, :, :16] = 0.0
+                trg[:, :, :16] = 0.0
+            if kind == "nan":
+                src[0, 0, 9, 13, 21] = float("nan")
+            torch.manual_seed(3)
+            model = vxm.networks.VxmDense(shape, int_steps=7, int_downsize=2).cuda()
+            with torch.no_grad():
+                model.flow.weight.normal_(0, 0.02)
+            plan = model.unet_model.plan(model._feats, extra=((model.flow.out_channels, 1.0),))
+            VF.POOL_FUSE = True
+            fus = [t for t in range(plan.n_tensors) if VF._pool_fusable(plan, t, shape, False, VF._blocked_tensors(plan, B, shape))]
+            assert len(fus) == 1 and plan.lvl[fus[0]] == 0 and plan.ch[fus[0]] == 16, fus
+            results = []
+            for flag in (False, True):
+                VF.POOL_FUSE = flag
+                for p in model.parameters():
+                    p.grad = None
+                moved, field = model(src, trg)
+                loss = vxm.losses.NCC().loss(trg, moved) + vxm.losses.Grad("l2", loss_mult=2).loss(None, field)
+                loss.backward()
+                results.append([loss.detach().clone()] + [p.grad.clone() for p in model.parameters()])
+            for a, b in zip(*results):
+                assert torch.equal(a, b) or (kind == "nan" and torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(a.nan_to_num(), b.nan_to_num()))
+            if kind == "noise":
+                assert all(bool(torch.isfinite(g).all()) for g in results[1])
+            del model, results, src, trg
+            torch.cuda.empty_cache()
+    finally:
+        VF.POOL_FUSE = keep
+
+
 def test_full_size_train_step_batch_of_two_vs_oracle(vxm):
     """The same step with TWO pairs in the batch (scripts/torch/train.py:128-129,200-220: the per-GPU batch of BASELINE
     configs[3] is > 1): batch strides, 32-bit buffer offsets of the second sample and the batch mean of both losses at the

@@ -68,6 +68,7 @@ SIGNATURES = {
     "vxm_conv3d_k3_bwd_weight_up_segment": [_P, _I, _L, _P, _I, _L, _P, _L, _I, _P, _P, _S, _I, _I, _I, _I, _P],
     "vxm_lrelu_bwd": [_P, _L, _P, _L, _P, _L, _F, _I, _I, _L, _P],
     "vxm_maxpool2_fwd": [_P, _L, _P, _I, _I, _I, _I, _I, _P],
+    "vxm_maxpool2_fwd_code": [_P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
     "vxm_maxpool3d_k_fwd": [_P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "vxm_maxpool3d_k_bwd": [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "vxm_upsample3d_k_cat": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -149,6 +150,7 @@ SIGNATURES = {
     "vxm_s3_range_probe": [_P, _I, _L, _I, _I, _I, _I, _I, _P, _P],
     "vxm_conv3d_k3_fewch_bwd_weight_ok": [_P, _I, _L, _P, _I, _L, _P, _L, _I, _I, _I],
     "vxm_conv3d_k3_fewch_bwd_weight": [_P, _I, _L, _P, _I, _L, _P, _L, _I, _P, _P, _P, _S, _I, _I, _I, _I, _I, _P],
+    "vxm_conv3d_k3_fewch_bwd_weight_pool": [_P, _I, _L, _P, _I, _L, _P, _L, _P, _P, _F, _P, _P, _P, _S, _I, _I, _I, _I, _I, _P],
     "vxm_loss_combine_fwd": [_P, _P, _I, _P, _P, _P],
     "vxm_loss_combine_bwd": [_P, _P, _I, _P, _P],
     "vxm_fill_zero": [_P, _S, _P],

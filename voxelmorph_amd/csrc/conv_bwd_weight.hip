@@ -770,6 +770,8 @@ struct FcIn {
     const float* P; long long p_bs;            // [B][16][D][H][W]
     const float* S0; long long s0_bs; int cs0;  // small operand: virtual concat of S0 (cs0 channels) and S1 (cs - cs0 channels)
     const float* S1; long long s1_bs;
+    // k_fewch_bwd_weight_h<.., POOL>: P is the skip-branch gradient and the operand is formed from it on the fly (see the kernel)
+    const float* gpool = nullptr; const unsigned short* code = nullptr; float slope = 1.0f;
 };
 
 template <int NT>
@@ -934,9 +936,16 @@ static_assert(FH_LDS <= 52 * 1024, "three blocks of k_fewch_bwd_weight_h per CU"
 // blocked).  A thread then fetches the 16 channels of ONE voxel (four 16-byte loads, as many as before); W-neighbour lanes swap halves of
 // their channels (DPP quad_perm), so that the even lane owns channels 0 .. 7 and the odd lane channels 8 .. 15 of the voxel PAIR and each writes
 // the same packed fp16 words to the same LDS places as the planar staging -- every later instruction and every bit of the result is unchanged.
-template <int NT, bool PBLK = false>
+// POOL (round 6, last): the 16-channel operand is the gradient at the first ConvBlock's pre-activation, which vxm_maxpool2_bwd used to write
+// (0.44 GB at full resolution, 0.24 ms) for this kernel alone to read: dz[c][p] = (gskip[c][p] + (p is the arg-max of its 2x2x2 block ?
+// gpool[c][p >> 1] : 0)) * LeakyReLU'(y[c][p]).  in.P is gskip; a thread's four W-neighbours are two pooled blocks, whose routed gradients (one
+// 8-byte load) and 16-bit codes (vxm_maxpool2_fwd_code: sign bits of the block's eight activations + arg-max; one 4-byte load) arrive with the
+// tile and are folded into pv[] before the maximum is taken -- the same three operations in the same order as k_maxpool2_bwd_v4, hence the same
+// bits in every later instruction.  Even D, H, W; W % 4 == 0.
+template <int NT, bool PBLK = false, bool POOL = false>
 __global__ void __launch_bounds__(FH_THREADS, 3) k_fewch_bwd_weight_h(FcIn in, int cs, int flip, int want_bias, float* __restrict__ part, int B, int D,
                                                                      int H, int W) {
+    static_assert(!(PBLK && POOL), "the pooled-gradient operand is planar");
     using P2 = S3P<2>;
     VXM_DYN_SMEM(char, smem);
     char* const Ps = smem;                                     // [2 pieces][16][FH_PST] halves
@@ -976,6 +985,9 @@ __global__ void __launch_bounds__(FH_THREADS, 3) k_fewch_bwd_weight_h(FcIn in, i
     constexpr int NPV = 4;
     f32x4 pv[NPV];
     f32x2 sv[9];
+    [[maybe_unused]] f32x2 gpv[POOL ? NPV : 1];                      // POOL: routed gradients / codes of the two pooled blocks under pv[j]
+    [[maybe_unused]] unsigned cdv[POOL ? NPV : 1];
+    [[maybe_unused]] unsigned kbase = 0u;                            // position of this thread's voxels inside their block: 4 (d & 1) + 2 (h & 1)
     const int pm0 = tid >> 6, prow = (tid >> 3) & 7, pw4 = tid & 7;
     const int spr = tid / 17, spq = tid - spr * 17;                          // spr >= FH_SROWS: no slot
     auto tile_coords = [&](int t, int& b, int& d, int& h0, int& w0) __attribute__((always_inline)) {
@@ -1000,6 +1012,20 @@ __global__ void __launch_bounds__(FH_THREADS, 3) k_fewch_bwd_weight_h(FcIn in, i
         const int pvoff = ((gh < H && gw < W) ? (pm0 * V + d * HW + gh * W + gw) << 2 : VXM_OOB) | dead;   // W % 4 == 0: a float4 is inside or outside the row
 #pragma unroll
         for (int j = 0; j < NPV; ++j) pv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, pvoff, (4 * j * V) << 2, 0));
+        if constexpr (POOL) {
+            const int V2 = V >> 3, W2 = W >> 1;
+            const __amdgpu_buffer_rsrc_t rg = vxm_rsrc(in.gpool + (size_t)b * 16 * V2, 16u * (unsigned)V2 * 4u);
+            const __amdgpu_buffer_rsrc_t rc = vxm_rsrc(reinterpret_cast<const float*>(in.code + (size_t)b * 16 * V2), 16u * (unsigned)V2 * 2u);
+            const int cell = pm0 * V2 + ((d >> 1) * (H >> 1) + (gh >> 1)) * W2 + (gw >> 1);       // the first of the two blocks (gw % 4 == 0: even)
+            const bool in_vol = gh < H && gw < W;
+            const int goff = (in_vol ? cell << 2 : VXM_OOB) | dead, coff = (in_vol ? cell << 1 : VXM_OOB) | dead;
+#pragma unroll
+            for (int j = 0; j < NPV; ++j) {
+                gpv[j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rg, goff, (4 * j * V2) << 2, 0));
+                cdv[j] = __builtin_amdgcn_raw_buffer_load_b32(rc, coff, (4 * j * V2) << 1, 0);
+            }
+            kbase = (unsigned)(((d & 1) << 2) | ((gh & 1) << 1));
+        }
         }
         const __amdgpu_buffer_rsrc_t r0 = vxm_rsrc(in.S0 + (size_t)b * in.s0_bs, (unsigned)in.cs0 * (unsigned)V * 4u);
         const __amdgpu_buffer_rsrc_t r1 = vxm_rsrc(cs > in.cs0 ? in.S1 + (size_t)b * in.s1_bs : in.S0, (unsigned)(cs > in.cs0 ? cs - in.cs0 : in.cs0) * (unsigned)V * 4u);
@@ -1027,8 +1053,22 @@ __global__ void __launch_bounds__(FH_THREADS, 3) k_fewch_bwd_weight_h(FcIn in, i
                 sv[c * 3 + pd] = v2;
             }
     };
+    // POOL: pv[] = gskip -> the gradient at the pre-activation (k_maxpool2_bwd_v4's arithmetic: (routed or 0) + skip, times LeakyReLU')
+    auto fold_pool = [&]() __attribute__((always_inline)) {
+        if constexpr (POOL) {
+#pragma unroll
+            for (int j = 0; j < NPV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned cd = (cdv[j] >> (16 * (e >> 1))) & 0xffffu, k = kbase | (unsigned)(e & 1);
+                    const float g = (((cd >> 8) & 7u) == k ? gpv[j][e >> 1] : 0.0f) + pv[j][e];
+                    pv[j][e] = g * (((cd >> k) & 1u) ? 1.0f : in.slope);
+                }
+        }
+    };
     // largest magnitudes this wave loaded for the tile in flight -> Tab (P: [wave], S: [4 + wave])
     auto publish_max = [&]() __attribute__((always_inline)) {
+        fold_pool();
         const float mp = s3_unit_max([&](auto&& f) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < NPV; ++j)
@@ -1254,7 +1294,8 @@ size_t vxm_conv3d_k3_bwd_weight_workspace_bytes(int Cin, int Cout, int B, int D,
 
 // few-channel layers on the fp16-piece scheme (k_fewch_bwd_weight_h): same operands, workspace and reducer as the fp32-MFMA few-channel path
 static int fewch_h_launch(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* dz, int64_t dz_bstride,
-                          int Cout, float* gw, float* gb, float* part, int B, int D, int H, int W, void* stream, bool p_blocked = false) {
+                          int Cout, float* gw, float* gb, float* part, int B, int D, int H, int W, void* stream, bool p_blocked = false,
+                          const float* gpool = nullptr, const uint16_t* code = nullptr, float slope = 1.0f) {
     const int Cin = C0 + C1;
     const bool few_in = Cout == 16 && Cin <= 3;
     const int cs = few_in ? Cin : Cout;
@@ -1262,6 +1303,7 @@ static int fewch_h_launch(const float* x0, int C0, int64_t x0_bstride, const flo
     FcIn fin;
     if (few_in) fin = FcIn{dz, (long long)dz_bstride, x0, (long long)x0_bstride, C0, x1, (long long)x1_bstride};
     else fin = FcIn{x0, (long long)x0_bstride, dz, (long long)dz_bstride, Cout, nullptr, 0};
+    fin.gpool = gpool; fin.code = code; fin.slope = slope;
     const long long ntiles = (long long)B * D * ((H + FH_TH - 1) / FH_TH) * ((W + FH_TW - 1) / FH_TW);
     const int nblk = (int)(ntiles < 768 ? ntiles : 768);              // three 4-wave blocks per CU (31 KB of LDS each; the workspace holds 512 x 16 x 96 partials)
     static bool opt_in = false;
@@ -1272,11 +1314,15 @@ static int fewch_h_launch(const float* x0, int C0, int64_t x0_bstride, const flo
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fewch_bwd_weight_h<6, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS);
         opt_in = true;
     }
 #define FH_LAUNCH(...) hipLaunchKernelGGL((k_fewch_bwd_weight_h<__VA_ARGS__>), dim3(nblk), dim3(FH_THREADS), FH_LDS, VXM_STREAM(stream), fin, cs, few_in ? 0 : 1, \
                                           few_in && gb ? 1 : 0, part, B, D, H, W)
     if (p_blocked) { if (NT <= 2) FH_LAUNCH(2, true); else if (NT <= 4) FH_LAUNCH(4, true); else FH_LAUNCH(6, true); }
+    else if (code) { if (NT <= 2) FH_LAUNCH(2, false, true); else if (NT <= 4) FH_LAUNCH(4, false, true); else FH_LAUNCH(6, false, true); }
     else if (NT <= 2) FH_LAUNCH(2); else if (NT <= 4) FH_LAUNCH(4); else FH_LAUNCH(6);
 #undef FH_LAUNCH
     const int ncols = (NT <= 2 ? 2 : (NT <= 4 ? 4 : 6)) * 16;
@@ -1458,6 +1504,23 @@ int vxm_conv3d_k3_fewch_bwd_weight(const float* x0, int C0, int64_t x0_bstride, 
                 "vxm_conv3d_k3_fewch_bwd_weight: workspace too small (%zu bytes; vxm_conv3d_k3_bwd_weight_workspace_bytes)", workspace_bytes);
     const uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
     return fewch_h_launch(x0, C0, x0_bstride, x1, C1, x1_bstride, dz, dz_bstride, Cout, gw, gb, reinterpret_cast<float*>(base), B, D, H, W, stream, lay != 0);
+}
+
+int vxm_conv3d_k3_fewch_bwd_weight_pool(const float* x0, int C0, int64_t x0_bstride, const float* x1, int C1, int64_t x1_bstride, const float* gskip,
+                                        int64_t gskip_bstride, const float* gpool, const uint16_t* code, float slope, float* gw, float* gb, void* workspace,
+                                        size_t workspace_bytes, int B, int D, int H, int W, int pieces, void* stream) {
+    if (int e = check_conv("vxm_conv3d_k3_fewch_bwd_weight_pool", C0, C1, 0, 16, B, D, H, W)) return e;
+    VXM_REQUIRE(x0 && gskip && gpool && code && gw && workspace && (C1 == 0 || x1), VXM_ERR_NULL_POINTER, "vxm_conv3d_k3_fewch_bwd_weight_pool: null pointer");
+    VXM_REQUIRE(!((D | H | W) & 1) && (reinterpret_cast<uintptr_t>(gpool) & 7) == 0 && (reinterpret_cast<uintptr_t>(code) & 3) == 0, VXM_ERR_BAD_SHAPE,
+                "vxm_conv3d_k3_fewch_bwd_weight_pool: even extents, gpool 8-byte and code 4-byte aligned (got %dx%dx%d)", D, H, W);
+    VXM_REQUIRE(vxm_conv3d_k3_fewch_bwd_weight_ok(x0, C0, x0_bstride, x1, C1, x1_bstride, gskip, gskip_bstride, 16, pieces, W), VXM_ERR_UNSUPPORTED,
+                "vxm_conv3d_k3_fewch_bwd_weight_pool: 1-3 input channels against 16, W %% 4 == 0, 16-byte aligned tensors, pieces = 2 (got C0=%d C1=%d "
+                "pieces=%d W=%d)", C0, C1, pieces, W);
+    VXM_REQUIRE(workspace_bytes >= vxm_conv3d_k3_bwd_weight_workspace_bytes(C0 + C1, 16, B, D, H, W), VXM_ERR_WORKSPACE,
+                "vxm_conv3d_k3_fewch_bwd_weight_pool: workspace too small (%zu bytes; vxm_conv3d_k3_bwd_weight_workspace_bytes)", workspace_bytes);
+    const uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
+    return fewch_h_launch(x0, C0, x0_bstride, x1, C1, x1_bstride, gskip, gskip_bstride, 16, gw, gb, reinterpret_cast<float*>(base), B, D, H, W, stream, false,
+                          gpool, code, slope);
 }
 
 }  // extern "C"

@@ -18,8 +18,13 @@ __global__ void __launch_bounds__(256) k_lrelu_bwd(const float* __restrict__ g, 
         dz[b * dz_bs + i] = g[b * g_bs + i] * vxm_lrelu_grad(y[b * y_bs + i], slope);
 }
 
-// one thread per pooled voxel
-__global__ void __launch_bounds__(256) k_maxpool2_fwd(const float* __restrict__ x, long long x_bs, float* __restrict__ y, int C, int D, int H, int W) {
+// one thread per pooled voxel.  CODE (round 6): also one 16-bit word per pooled voxel and channel that holds everything the backward pass reads of
+// the 2x2x2 block -- bit k (k = 4 dz + 2 dy + dx): x[k] > 0 (LeakyReLU' of the pooled tensor), bits 8..10: the arg-max the gradient is routed to
+// (first maximum in ATen's scan order, a NaN wins) -- so that the consumer of the block's gradient can form it on the fly
+// (vxm_conv3d_k3_fewch_bwd_weight_pool) instead of reading one written by vxm_maxpool2_bwd.
+template <bool CODE>
+__global__ void __launch_bounds__(256) k_maxpool2_fwd(const float* __restrict__ x, long long x_bs, float* __restrict__ y, unsigned short* __restrict__ code,
+                                                      int C, int D, int H, int W) {
     const int D2 = D >> 1, H2 = H >> 1, W2 = W >> 1;
     const long long V2 = (long long)D2 * H2 * W2;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -30,12 +35,15 @@ __global__ void __launch_bounds__(256) k_maxpool2_fwd(const float* __restrict__ 
     const int w = q % W2, t = q / W2, h = t % H2, d = t / H2;
     const float* p = x + b * x_bs + ((size_t)c * D + 2 * d) * H * W + (size_t)(2 * h) * W + 2 * w;
     float m = p[0];
+    unsigned arg = 0u, pos = m > 0.0f ? 1u : 0u;
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
         const float v = p[(size_t)((k >> 2) & 1) * H * W + (size_t)((k >> 1) & 1) * W + (k & 1)];
-        m = (v > m || v != v) ? v : m;              // ATen: (val > maxval) || isnan(val)
+        if (v > m || v != v) { m = v; arg = (unsigned)k; }   // ATen: (val > maxval) || isnan(val)
+        if (CODE) pos |= (v > 0.0f ? 1u : 0u) << k;
     }
     y[b * (size_t)C * V2 + i] = m;
+    if (CODE) code[b * (size_t)C * V2 + i] = (unsigned short)(pos | (arg << 8));
 }
 
 // one thread per pooled voxel: routes gpool to the first arg-max of its 2x2x2 block, adds the
@@ -271,8 +279,17 @@ int vxm_maxpool2_fwd(const float* x, int64_t x_bstride, float* y, int B, int C, 
     VXM_REQUIRE(x && y, VXM_ERR_NULL_POINTER, "vxm_maxpool2_fwd: null pointer");
     VXM_REQUIRE(B > 0 && B <= 65535 && C > 0 && D >= 2 && H >= 2 && W >= 2, VXM_ERR_BAD_SHAPE, "vxm_maxpool2_fwd: bad shape %dx%dx%d", D, H, W);
     const long long n = (long long)C * (D / 2) * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(k_maxpool2_fwd, dim3(vxm_blocks(n, 256), B), dim3(256), 0, VXM_STREAM(stream), x, (long long)x_bstride, y, C, D, H, W);
+    hipLaunchKernelGGL(k_maxpool2_fwd<false>, dim3(vxm_blocks(n, 256), B), dim3(256), 0, VXM_STREAM(stream), x, (long long)x_bstride, y, nullptr, C, D, H, W);
     return vxm_check_launch("vxm_maxpool2_fwd");
+}
+
+int vxm_maxpool2_fwd_code(const float* x, int64_t x_bstride, float* y, uint16_t* code, int B, int C, int D, int H, int W, void* stream) {
+    VXM_REQUIRE(x && y && code, VXM_ERR_NULL_POINTER, "vxm_maxpool2_fwd_code: null pointer");
+    VXM_REQUIRE(B > 0 && B <= 65535 && C > 0 && D >= 2 && H >= 2 && W >= 2 && !((D | H | W) & 1), VXM_ERR_BAD_SHAPE,
+                "vxm_maxpool2_fwd_code: bad shape %dx%dx%d (even extents: every voxel belongs to a pooled block)", D, H, W);
+    const long long n = (long long)C * (D / 2) * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(k_maxpool2_fwd<true>, dim3(vxm_blocks(n, 256), B), dim3(256), 0, VXM_STREAM(stream), x, (long long)x_bstride, y, code, C, D, H, W);
+    return vxm_check_launch("vxm_maxpool2_fwd_code");
 }
 
 int vxm_maxpool2_bwd(const float* x, int64_t x_bstride, const float* gpool, const float* gskip, int64_t gskip_bstride, float* dz,

@@ -56,6 +56,9 @@ DW_ORDER = os.environ.get("VXM_DW_ORDER", "")
 BW_REDUCE_STREAM = os.environ.get("VXM_BW_REDUCE_STREAM", "") == "1"     # UnetFn.backward: weight-gradient reductions on a third stream (A/B: slower)
 # few-channel weight gradients (first block, flow conv) on the fp16 pieces (csrc/conv_bwd_weight.hip k_fewch_bwd_weight_h); VXM_FEWCH_H=0: fp32 MFMA
 FEWCH_H = os.environ.get("VXM_FEWCH_H", "1") != "0"
+# the first block's weight gradient forms the gradient at its pre-activation on the fly from the operands of the pooling backward (16-bit codes from
+# the forward pooling, vxm_conv3d_k3_fewch_bwd_weight_pool): no vxm_maxpool2_bwd launch, no 0.44 GB tensor written and read back; VXM_POOL_FUSE=0: off
+POOL_FUSE = os.environ.get("VXM_POOL_FUSE", "1") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -1359,6 +1362,7 @@ class UnetFn(torch.autograd.Function):
                 _adopt_fresh_packs(None)
         blocked = _blocked_tensors(plan, B, shape3)
         SG = {}                      # tensor id -> sign tensor of a channel-blocked activation (S3_OUT_SIGNS / S3_MASK_SIGNS)
+        PC = {}                      # tensor id -> 16-bit codes of its pooling (vxm_maxpool2_fwd_code), for the fused pooling backward + weight gradient
         walked_back = set()          # tensors whose producer walked its tiles from the end (S3_REVERSE_TILES)
         for n_op, op in enumerate(plan.ops):
             if packs_late and n_op >= 1:
@@ -1395,7 +1399,11 @@ class UnetFn(torch.autograd.Function):
             elif op["kind"] == "pool":
                 src = T[op["src"]]
                 sD, sH, sW = src.shape[2:]
-                call("vxm_maxpool2_fwd", ptr(src), src[0].numel(), ptr(out), B, plan.ch[dst], sD, sH, sW, stream())
+                if want_bwd and _pool_fusable(plan, op["src"], shape3, any(ctx.needs_input_grad[1:1 + plan.n_inputs]), blocked):
+                    PC[op["src"]] = torch.empty((B, plan.ch[dst], sD // 2, sH // 2, sW // 2), dtype=torch.int16, device=dev)
+                    call("vxm_maxpool2_fwd_code", ptr(src), src[0].numel(), ptr(out), ptr(PC[op["src"]]), B, plan.ch[dst], sD, sH, sW, stream())
+                else:
+                    call("vxm_maxpool2_fwd", ptr(src), src[0].numel(), ptr(out), B, plan.ch[dst], sD, sH, sW, stream())
             else:
                 s0, up0, s1 = op["src"]
                 call("vxm_upsample2_cat", ptr(T[s0]), plan.ch[s0], ptr(T[s1]), plan.ch[s1], ptr(out), B, D, H, W, stream())
@@ -1411,7 +1419,7 @@ class UnetFn(torch.autograd.Function):
             torch.cuda.current_stream(dev).wait_event(ready[2])
         out = T.pop(plan.out)
         ctx.save_for_backward(out)
-        ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B, ctx.blocked, ctx.SG = plan, T, params, shape3, B, blocked, SG
+        ctx.plan, ctx.T, ctx.params, ctx.shape3, ctx.B, ctx.blocked, ctx.SG, ctx.PC = plan, T, params, shape3, B, blocked, SG, PC
         # activations and parameters are held as plain attributes (the returned tensor alone goes through
         # save_for_backward, see above), so autograd's version-counter check is done by hand in backward
         # (inference tensors -- torch.inference_mode() -- carry no version counter and can never reach backward)
@@ -1420,7 +1428,7 @@ class UnetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        plan, params, shape3, B, blocked, SG = ctx.plan, ctx.params, ctx.shape3, ctx.B, ctx.blocked, ctx.SG
+        plan, params, shape3, B, blocked, SG, PC = ctx.plan, ctx.params, ctx.shape3, ctx.B, ctx.blocked, ctx.SG, ctx.PC
         if ctx.T is None:
             raise RuntimeError("UnetFn: backward a second time: the saved activations were released by the first pass "
                                "(a retained graph is not supported by the fused engine)")
@@ -1493,7 +1501,6 @@ class UnetFn(torch.autograd.Function):
                     src = op["src"]
                     sD, sH, sW = _dims(shape3, plan.lvl[src])
                     C = plan.ch[src]
-                    dz = torch.empty((B, C, sD, sH, sW), dtype=dt, device=dev)
                     gs = GS.get(src)
                     prod = plan.ops[plan.producer[src]] if src in plan.producer else None
                     slope = prod["slope"] if prod is not None and prod["kind"] == "conv" else 1.0
@@ -1502,6 +1509,11 @@ class UnetFn(torch.autograd.Function):
                     if gs is not None:
                         gskip = gs[0].view(-1)[gs[1]:]
                         gs_bs = gs[2]
+                    if src in PC and gskip is not None:
+                        # the one reader of this gradient is the first block's weight gradient, which forms it on the fly (conv op below)
+                        DZ[src] = _PoolGrad(gskip, gs_bs, GP[dst], PC[src], float(slope), gs[0])
+                        continue
+                    dz = torch.empty((B, C, sD, sH, sW), dtype=dt, device=dev)
                     call("vxm_maxpool2_bwd", ptr(T[src]), T[src][0].numel(), ptr(GP[dst]), ptr(gskip), gs_bs, ptr(dz),
                          float(slope), B, C, sD, sH, sW, stream())
                     DZ[src] = dz
@@ -1514,9 +1526,23 @@ class UnetFn(torch.autograd.Function):
                 c1 = plan.ch[s1] if s1 is not None else 0
                 cin = c0 + c1
                 dz = DZ.pop(dst)
+                x0, x1 = T[s0], (T[s1] if s1 is not None else None)
+                if isinstance(dz, _PoolGrad):
+                    # first block, nothing behind it: weight / bias gradient from the pooling backward's operands in one launch (main stream: the
+                    # last launch of the pass, see last_on_main below)
+                    gw_sink, gb_sink = _claim_sink(w), _claim_sink(b)
+                    gw = gw_sink if gw_sink is not None else torch.empty_like(w)
+                    gb = gb_sink if gb_sink is not None else torch.empty_like(b)
+                    need = _lib.lib().vxm_conv3d_k3_bwd_weight_workspace_bytes(cin, cout, B, D, H, W)
+                    buf = ws.get(need)
+                    with _prof.region("k_fewch_bwd_weight_h+pool", flops=2.0 * 27 * cin * cout * B * V):
+                        call("vxm_conv3d_k3_fewch_bwd_weight_pool", ptr(x0), c0, x0[0].numel(), ptr(x1), c1, x1[0].numel() if x1 is not None else 0,
+                             ptr(dz.gskip), dz.gs_bs, ptr(dz.gpool), ptr(dz.code), dz.slope, ptr(gw), ptr(gb), ptr(buf), buf.numel(), B, D, H, W, 2, stream())
+                    grads[n_in + 2 * op["k"]] = None if gw_sink is not None else gw
+                    grads[n_in + 2 * op["k"] + 1] = None if gb_sink is not None else gb
+                    continue
                 if _RANGE_PROBE is not None:
                     _probe("gradient at conv %d (%d channels, level %d)" % (op["k"], cout, plan.lvl[dst]), dz, cout, dst in blocked)
-                x0, x1 = T[s0], (T[s1] if s1 is not None else None)
                 # channel-blocked tensors (_blocked_tensors): the activation s0 of a plain conv and / or this conv's own output, whose DZ shares its layout
                 dz_blk, x_blk = dst in blocked, s0 in blocked
                 lay_w = (S3_IN0_BLOCKED if x_blk else 0) | (S3_IN1_BLOCKED if dz_blk else 0)
@@ -1655,6 +1681,36 @@ class UnetFn(torch.autograd.Function):
                 if red is not None:
                     main.wait_stream(red)
         return (None,) + tuple(grads)
+
+
+class _PoolGrad:
+    """The gradient at the pre-activation of a pooled ConvBlock, not materialised: the operands of vxm_maxpool2_bwd, handed to the one kernel
+    that reads it (vxm_conv3d_k3_fewch_bwd_weight_pool)."""
+    __slots__ = ("gskip", "gs_bs", "gpool", "code", "slope", "keep")
+
+    def __init__(self, gskip, gs_bs, gpool, code, slope, keep):
+        self.gskip, self.gs_bs, self.gpool, self.code, self.slope, self.keep = gskip, gs_bs, gpool, code, slope, keep
+
+
+def _pool_fusable(plan, src, shape3, inputs_need_grad, blocked):
+    """True when the gradient of tensor `src` (pooled AND a skip connection) has exactly one reader that can form it on the fly: the weight
+    gradient of the FIRST ConvBlock (its inputs are network inputs that need no gradient) on the few-channel fp16-piece kernel."""
+    if not (POOL_FUSE and FEWCH_H and split_engine() and s3_pieces() == 2 and _RANGE_PROBE is None) or inputs_need_grad or src in blocked:
+        return False
+    if src not in plan.producer:
+        return False
+    prod = plan.ops[plan.producer[src]]
+    if prod["kind"] != "conv":
+        return False
+    s0, up0, s1 = prod["src"]
+    if up0 or s0 >= plan.n_inputs or (s1 is not None and s1 >= plan.n_inputs):
+        return False
+    cin = plan.ch[s0] + (plan.ch[s1] if s1 is not None else 0)
+    D, H, W = _dims(shape3, plan.lvl[src])
+    cons = [plan.ops[m] for m in plan.consumers[src]]        # its pooling and the conv that reads it as the skip segment of a virtual concat
+    if sorted(o["kind"] for o in cons) != ["conv", "pool"] or [o for o in cons if o["kind"] == "conv"][0]["src"][2] != src:
+        return False
+    return plan.ch[src] == 16 and cin <= 3 and not ((D | H | W) & 1) and W % 4 == 0
 
 
 def _resolve_decoder(plan, T, DZ, GC, tid, B, shape3, dt, dev):
