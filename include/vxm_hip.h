@@ -470,8 +470,8 @@ int vxm_conv3d_k3_fwd_layout(const float* x0, int C0, int64_t x0_bstride, int x0
 int vxm_conv3d_k3_s3_layout_ok(int C0, int C1, int x0_up, int Cout, int H, int pieces);
 int vxm_conv3d_k3_s3_variant(int Cout);                     /* 10 * NCT + CB of the kernel instance (profiling labels) */
 int vxm_conv3d_k3_s3_tile_rows(int Cout, int pieces, int H); /* rows of its output tile: 8 x 8 x 16 on the fp16 scheme, else 8 x 4 x 16 */
-int vxm_conv3d_k3_s3_tile_rows_at(int Cout, int pieces, int B, int D, int H, int W); /* ... of a launch of this shape on planar tensors (a 32-channel
-                                                                                       * operator takes 4 rows where 8 would leave CUs without a block) */
+int vxm_conv3d_k3_s3_tile_rows_at(int Cout, int pieces, int B, int D, int H, int W); /* ... of a launch of this shape (a 32-channel operator takes
+                                                                                       * 4 rows where 8 would leave CUs without a block) */
 /* 1 when the launch runs k_s3p_conv (the same tile, operator pack and results with producer and consumer waves: 16-output-channel
  * forward launches of the fp16 scheme on large volumes; profiling labels) */
 int vxm_conv3d_k3_s3_producer_consumer(int Cout, int pieces, int has_mask, int B, int D, int H, int W);

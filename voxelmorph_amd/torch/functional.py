@@ -715,7 +715,7 @@ def s3_launch(x0, c0, bs0, up0, x1, c1, bs1, wp, bias, y, ybs, cout, slope, mask
     v = _lib.lib().vxm_conv3d_k3_s3_variant(cout)
     name = None
     if _prof.ACTIVE is not None:          # label the region with the kernel the C ABI will dispatch to
-        rows = _lib.lib().vxm_conv3d_k3_s3_tile_rows(cout, s3_pieces(), H) if lay else _lib.lib().vxm_conv3d_k3_s3_tile_rows_at(cout, s3_pieces(), B, D, H, W)
+        rows = _lib.lib().vxm_conv3d_k3_s3_tile_rows_at(cout, s3_pieces(), B, D, H, W)
         pc = _lib.lib().vxm_conv3d_k3_s3_producer_consumer(cout, s3_pieces(), 0 if (mask is None or lay & (S3_MASK_SIGNS | S3_OUT_SIGNS)) else 1, B, D, H, W)
         name = "k_s3p_conv<%d,%d>" % (v // 10, s3_pieces()) if pc else "k_s3_conv<%d,%d,%d,%d>" % (v // 10, rows, v % 10, s3_pieces())
     with _prof.region(name, flops=2.0 * 27 * (c0 + c1) * cout * B * D * H * W):
