@@ -40,7 +40,7 @@ typedef enum {
 enum { VXM_INTERP_LINEAR = 0, VXM_INTERP_NEAREST = 1 };   /* SpatialTransformer mode, layers.py:11 */
 enum { VXM_PENALTY_L1 = 0, VXM_PENALTY_L2 = 1 };          /* Grad penalty, losses.py:98 */
 
-int vxm_version(void);                 /* 10000 major + 100 minor + patch of this ABI: 500 = 0.5.0 (round 6; every 0.4 entry point kept) */
+int vxm_version(void);                 /* 10000 major + 100 minor + patch of this ABI: 501 = 0.5.1 (round 6; every 0.4 / 0.5.0 entry point kept) */
 const char* vxm_last_error_string(void);
 
 /* ---- the two umbrella names SURVEY.md section 8b lists.  Every op has its own *_workspace_bytes() query next to it; this one dispatches

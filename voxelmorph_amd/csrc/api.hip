@@ -4,7 +4,7 @@
 thread_local char vxm_err_buf[512] = "";
 
 extern "C" {
-int vxm_version(void) { return 500; }                       /* 0.5.0: round 6 (vecint_bwd_ws, fused upsample + warp, weighted loss finishers); 0.4.0: round 5 (capturable Adam, range probe, bwd_data / workspace_bytes names); 0.3.0: split-fp32 convs */
+int vxm_version(void) { return 501; }                       /* 0.5.1: pooling codes + fused pooling backward / first weight gradient, small-volume conv kernel (additive); 0.5.0: round 6 (vecint_bwd_ws, fused upsample + warp, weighted loss finishers); 0.4.0: round 5 (capturable Adam, range probe, bwd_data / workspace_bytes names); 0.3.0: split-fp32 convs */
 const char* vxm_last_error_string(void) { return vxm_err_buf; }
 
 /* convolution_backward w.r.t. the input under its SURVEY name: pack the transposed / flipped operator into the caller's scratch and run the
