@@ -676,6 +676,92 @@ def test_maxpool_ties_first_index(vxm):
     assert torch.equal(dz.cpu(), xo.grad)
 
 
+def test_maxpool_forward_codes_hold_what_the_backward_reads(vxm):
+    """vxm_maxpool2_fwd_code (round 6): the pooled tensor is max_pool3d's, and the 16-bit word of a pooled voxel holds the sign bits of its
+    2x2x2 block (bit k = 4 dz + 2 dy + dx: x > 0) and the arg-max ATen routes the gradient to (first maximum in scan order; a NaN wins) --
+    on noise, on exact ties, with negatives, zeros and NaNs in the blocks, two samples."""
+    from voxelmorph_amd._lib import call, ptr, stream
+    torch.manual_seed(12)
+    B, C, D, H, W = 2, 3, 6, 8, 10
+    x = torch.randn(B, C, D, H, W, device="cuda")
+    x[0, 0, :2] = 0.5                      # ties: the first element wins
+    x[0, 1, 2:4] = -1.0                    # ties among negatives
+    x[1, 2, 4:, :4] = 0.0                  # zeros are not > 0
+    x[1, 0, 1, 3, 5] = float("nan")        # a NaN is the maximum of its block ...
+    x[1, 0, 1, 3, 4] = float("nan")        # ... and a later NaN replaces an earlier one (ATen: val > max || isnan(val))
+    y = torch.empty(B, C, D // 2, H // 2, W // 2, device="cuda")
+    code = torch.empty(B, C, D // 2, H // 2, W // 2, dtype=torch.int16, device="cuda")
+    call("vxm_maxpool2_fwd_code", ptr(x), x[0].numel(), ptr(y), ptr(code), B, C, D, H, W, stream())
+    y0 = torch.empty_like(y)
+    call("vxm_maxpool2_fwd", ptr(x), x[0].numel(), ptr(y0), B, C, D, H, W, stream())
+    assert torch.equal(y.nan_to_num(nan=7.0), y0.nan_to_num(nan=7.0))
+    blocks = x.cpu().reshape(B, C, D // 2, 2, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 6, 3, 5, 7).reshape(B, C, D // 2, H // 2, W // 2, 8)
+    cd = code.cpu().to(torch.int32) & 0xffff
+    bits = sum(((blocks[..., k] > 0).to(torch.int32) << k) for k in range(8))
+    assert torch.equal(cd & 0xff, bits)
+    arg = torch.zeros(blocks.shape[:-1], dtype=torch.int32)
+    m = blocks[..., 0].clone()
+    for k in range(1, 8):
+        v = blocks[..., k]
+        take = (v > m) | torch.isnan(v)
+        m = torch.where(take, v, m)
+        arg = torch.where(take, torch.full_like(arg, k), arg)
+    assert torch.equal((cd >> 8) & 7, arg) and int((cd >> 11).max()) == 0
+    # and the routed gradient of the reference agrees with that arg-max where the block has no NaN
+    xo = x.cpu().nan_to_num(nan=9.0).requires_grad_()
+    gp = torch.rand(B, C, D // 2, H // 2, W // 2) + 1.0
+    torch.nn.functional.max_pool3d(xo, 2).backward(gp)
+    routed = xo.grad.reshape(B, C, D // 2, 2, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 6, 3, 5, 7).reshape(B, C, D // 2, H // 2, W // 2, 8)
+    clean = ~torch.isnan(blocks).any(-1)
+    assert torch.equal(routed.argmax(-1).to(torch.int32)[clean], arg[clean])
+    with pytest.raises(Exception, match="even"):
+        call("vxm_maxpool2_fwd_code", ptr(x), x[0].numel(), ptr(y), ptr(code), B, C, D - 1, H, W, stream())
+
+
+@pytest.mark.parametrize("c0,up0,c1,cout,vol,B,with_mask", [(32, False, 0, 32, (20, 24, 28), 1, False), (32, False, 0, 32, (10, 12, 14), 2, True),
+                                                           (32, True, 32, 32, (20, 24, 28), 1, False), (32, False, 0, 64, (20, 24, 28), 1, True),
+                                                           (40, False, 0, 24, (9, 11, 13), 1, True), (24, True, 16, 40, (6, 10, 18), 2, False)])
+def test_small_volume_conv_kernel_vs_fp64(vxm, c0, up0, c1, cout, vol, B, with_mask):
+    """k_conv3d_k3_sm (round 6): the conv launches of the U-Net levels at 1/8 and 1/16 resolution -- input channels split over the waves of a
+    block, partial tiles added in wave order -- forward (bias, LeakyReLU, virtual concat with an x2-upsampled segment) and backward-data (fused
+    LeakyReLU' mask) against an fp64 evaluation on the host: the shapes of the default network, two output-channel groups, channel counts that
+    are not multiples of 8 / 16, odd extents, two samples; the dispatcher must actually have chosen it (variant code 300 + waves)."""
+    from voxelmorph_amd import _lib
+    from voxelmorph_amd.torch import functional as VF
+    if os.environ.get("VXM_CONV_SMALL_MAX_BLOCKS") == "0" or os.environ.get("VXM_CONV_GENERIC") == "1":
+        pytest.skip("the small-volume kernel is switched off in this process")
+    import torch.nn.functional as F
+    D, H, W = vol
+    V, cin = D * H * W, c0 + c1
+    torch.manual_seed(40 + cout)
+    x0 = torch.randn(B, c0, *((D // 2, H // 2, W // 2) if up0 else vol), device="cuda")
+    x1 = torch.randn(B, c1, D, H, W, device="cuda") if c1 else None
+    w = torch.randn(cout, cin, 3, 3, 3, device="cuda") / (27 * cin) ** 0.5
+    b = torch.randn(cout, device="cuda")
+    y = torch.full((B, cout, D, H, W), float("nan"), device="cuda")
+    dz = torch.randn(B, cout, D, H, W, device="cuda")
+    gx = torch.full((B, cin, D, H, W), float("nan"), device="cuda")
+    mask = torch.randn(B, cin, D, H, W, device="cuda") if with_mask else None
+    wpk = VF.pack_weights_cached(w, False, 0, cin)
+    assert not VF.s3_route(c0, up0, c1, cout, B, D, H, W) and not (up0 and VF.s3u_route(c0, c1, cout, B, D, H, W))      # (levels below the split engine)
+    code = _lib.lib().vxm_conv3d_k3_fwd_variant(VF.ptr(x0), c0, x0[0].numel(), VF.ptr(x1), c1, x1[0].numel() if c1 else 0, VF.ptr(wpk), cout, B, D, H, W)
+    assert code == (308 if cin >= 64 else 304), code
+    VF.conv_forward(x0, c0, x0[0].numel(), up0, x1, c1, x1[0].numel() if c1 else 0, w, b, y, cout * V, cout, 0.2, B, D, H, W)
+    VF.conv_bwd_data(dz, cout, w, gx, cin, mask, 0.2, B, D, H, W)
+    xin = x0.cpu().double()
+    if up0:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    if c1:
+        xin = torch.cat([xin, x1.cpu().double()], 1)
+    ref = F.leaky_relu(F.conv3d(xin, w.cpu().double(), b.cpu().double(), padding=1), 0.2)
+    gref = F.conv_transpose3d(dz.cpu().double(), w.cpu().double(), padding=1)
+    if mask is not None:
+        gref = gref * torch.where(mask.cpu() > 0, 1.0, 0.2).double()
+    ey, eg = rel_l2(N(y).astype(np.float64), ref.numpy()), rel_l2(N(gx).astype(np.float64), gref.numpy())
+    print("small-volume conv %d%s+%d -> %d at %s, B=%d: rel-L2 vs fp64 forward %.2e, backward-data %.2e" % (c0, "^" if up0 else "", c1, cout, vol, B, ey, eg))
+    assert ey <= 1e-6 and eg <= 1e-6, (ey, eg)
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(nb_features=[[4, 8], [8, 8, 4]]), dict(nb_features=8, nb_levels=3, nb_conv_per_level=2),
                                 dict(half_res=True), dict(nb_features=[[8, 8], [8, 8]])])
 def test_unet_vs_oracle(vxm, kw):
