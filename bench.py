@@ -550,11 +550,12 @@ def timed_steps(wl, steps, vdist, dev, timer=None):
 # Vector-ALU issue roofline of the fused NCC march (csrc/losses.hip k_ncc_fused_fwd/bwd<4>): NOT an HBM kernel, although SURVEY.md section 8d
 # lists it as one -- its 55 / 83 MB of algorithmic traffic would take 7 / 10 us, its arithmetic (direct 9-tap box sums of five products in
 # three directions, no running sums: fp32 accuracy) takes ten times that.  Wave-instructions per (block, slice) counted in the gfx950 ISA of
-# this tree (static count of the march's body + its two inner loops at 3 and 2 trips): forward 4 waves x 417 = 1668 VALU (+ 376 LDS),
-# backward 4 x 248 = 992 (+ 212 LDS); a wave-instruction occupies its SIMD for 4 cycles (the model that matched the VecInt gather within
+# this tree (static count of the march's body + its two inner loops -- staging, and the W pass with its 16-byte LDS reads -- at 3 / 3 and 3 / 2
+# trips): forward 4 waves x 327 = 1308 VALU (+ 176 LDS; before the 16-byte reads and the hoisted staging addresses: 417 + 94 per wave),
+# backward 4 x 168 = 672 (+ 136 LDS; before: 248 + 53); a wave-instruction occupies its SIMD for 4 cycles (the model that matched the VecInt gather within
 # 25 %); 1024 SIMDs at 2.4 GHz.  (block, slice) pairs of a launch: columns of 8 x 32 pixels x depth segments x
 # (segment + 8 halo slices), csrc/losses.hip ncc_segment.
-NCC_VALU_PER_BLOCK_SLICE = {"ncc_fwd": 1668.0, "ncc_bwd": 992.0}
+NCC_VALU_PER_BLOCK_SLICE = {"ncc_fwd": 1308.0, "ncc_bwd": 672.0}
 
 
 def ncc_valu_roofline(name, st, shape, B):

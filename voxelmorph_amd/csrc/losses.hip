@@ -219,13 +219,33 @@ __global__ void __launch_bounds__(256) k_ncc_win_grad_w(const float* __restrict_
 // (a, b, c) = d cc / d(J sum, J^2 sum, IJ sum) that backward box-filters.  HBM traffic: I, J once (+ L2-served halo),
 // 3 planes written -- instead of 5 planes x 3 passes.
 constexpr int NF_TH = 8, NF_TW = 32, NF_SEG = 40;     // tile, and (at most) slices per block along D
+constexpr int NF_PWP = 44;                            // floats per row of the haloed products tile: >= 32 + 2 R (R <= 4) + the 12-float reads below, rows 16-byte aligned
+
+// W box sums of FOUR neighbouring columns of one (plane, row) from three 16-byte LDS reads instead of 4 x WIN 4-byte ones (round 6, last): the
+// kernel is bound by vector-instruction issue, and the W pass was 90 of its 417 wave-instructions per slice.  Every sum is
+// still t = 0; t += p[c + k], k = 0 .. WIN - 1: the same operations in the same order, the same bits.
+template <int WIN>
+__device__ __forceinline__ void ncc_wpass4(const float* __restrict__ prow, float* __restrict__ rrow, int cg) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(prow + 4 * cg), b = *reinterpret_cast<const f32x4*>(prow + 4 * cg + 4),
+                c = *reinterpret_cast<const f32x4*>(prow + 4 * cg + 8);
+    const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float t = 0.0f;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) t += v[j + k];
+        o[j] = t;
+    }
+    *reinterpret_cast<f32x4*>(rrow + 4 * cg) = o;
+}
 
 template <int R>
 __global__ void __launch_bounds__(256) k_ncc_fused_fwd(const float* __restrict__ I, const float* __restrict__ J, float* __restrict__ abc,
                                                        double* __restrict__ acc, int D, int H, int W, long long BV, int seg) {
-    constexpr int WIN = 2 * R + 1, PH = NF_TH + 2 * R, PW = NF_TW + 2 * R, PWP = PW + 1;
-    __shared__ float P[5][PH][PWP];
-    __shared__ float Rw[5][PH][NF_TW];
+    constexpr int WIN = 2 * R + 1, PH = NF_TH + 2 * R, PW = NF_TW + 2 * R, PWP = NF_PWP;
+    __shared__ __attribute__((aligned(16))) float P[5][PH][PWP];
+    __shared__ __attribute__((aligned(16))) float Rw[5][PH][NF_TW];
     __shared__ double red[4];
     const int tid = threadIdx.x, wx = tid & 31, hy = tid >> 5;
     const int ntw = (W + NF_TW - 1) / NF_TW;
@@ -238,6 +258,16 @@ __global__ void __launch_bounds__(256) k_ncc_fused_fwd(const float* __restrict__
     const float n = (float)(WIN * WIN * WIN);
     const int gh = h0 + hy, gw = w0 + wx;
     const bool pix_ok = gh < H && gw < W;
+    // staging slots of this thread: element idx = tid + 256 t of the haloed PH x PW tile -> its LDS word and its offset inside a slice (-1: padding)
+    constexpr int NST = (PH * PW + 255) / 256;
+    int st_lds[NST], st_g[NST];
+#pragma unroll
+    for (int t = 0; t < NST; ++t) {
+        const int idx = tid + 256 * t, r = idx / PW, c = idx - r * PW;
+        const int y = h0 - R + r, x = w0 - R + c;
+        st_lds[t] = idx < PH * PW ? r * PWP + c : -1;
+        st_g[t] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? y * W + x : -1;
+    }
     float ring[WIN][5];
 #pragma unroll
     for (int k = 0; k < WIN; ++k)
@@ -249,24 +279,17 @@ __global__ void __launch_bounds__(256) k_ncc_fused_fwd(const float* __restrict__
         if (z >= 0 && z < D) {                              // block-uniform; slices outside the volume are zero padding
             const float* Iz = I + vol + (size_t)z * HW;
             const float* Jz = J + vol + (size_t)z * HW;
-            for (int idx = tid; idx < PH * PW; idx += 256) {
-                const int r = idx / PW, c = idx - r * PW;
-                const int y = h0 - R + r, x = w0 - R + c;
-                float a = 0.0f, b = 0.0f;
-                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) { a = Iz[(size_t)y * W + x]; b = Jz[(size_t)y * W + x]; }
-                P[0][r][c] = a; P[1][r][c] = b; P[2][r][c] = a * a; P[3][r][c] = b * b; P[4][r][c] = a * b;
-            }
-            __syncthreads();
-            for (int idx = tid; idx < PH * NF_TW; idx += 256) {
-                const int r = idx >> 5, c = idx & 31;
 #pragma unroll
-                for (int q = 0; q < 5; ++q) {
-                    float t = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < WIN; ++k) t += P[q][r][c + k];
-                    Rw[q][r][c] = t;
+            for (int t = 0; t < NST; ++t) {
+                if (st_lds[t] >= 0) {                            // (the slots of a thread and their addresses do not depend on the slice: set up once)
+                    float a = 0.0f, b = 0.0f;
+                    if (st_g[t] >= 0) { a = Iz[st_g[t]]; b = Jz[st_g[t]]; }
+                    float* const p = &P[0][0][0] + st_lds[t];
+                    p[0] = a; p[PH * PWP] = b; p[2 * PH * PWP] = a * a; p[3 * PH * PWP] = b * b; p[4 * PH * PWP] = a * b;
                 }
             }
+            __syncthreads();
+            for (int idx = tid; idx < 5 * PH * (NF_TW / 4); idx += 256) ncc_wpass4<WIN>(&P[0][0][0] + (idx >> 3) * PWP, &Rw[0][0][0] + (idx >> 3) * NF_TW, idx & 7);
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 5; ++q)
@@ -311,9 +334,9 @@ template <int R>
 __global__ void __launch_bounds__(256) k_ncc_fused_bwd(const float* __restrict__ I, const float* __restrict__ J, const float* __restrict__ abc,
                                                        const float* __restrict__ gloss, float* __restrict__ gJ, int D, int H, int W,
                                                        long long BV, int seg) {
-    constexpr int WIN = 2 * R + 1, PH = NF_TH + 2 * R, PW = NF_TW + 2 * R, PWP = PW + 1;
-    __shared__ float P[3][PH][PWP];
-    __shared__ float Rw[3][PH][NF_TW];
+    constexpr int WIN = 2 * R + 1, PH = NF_TH + 2 * R, PW = NF_TW + 2 * R, PWP = NF_PWP;
+    __shared__ __attribute__((aligned(16))) float P[3][PH][PWP];
+    __shared__ __attribute__((aligned(16))) float Rw[3][PH][NF_TW];
     const int tid = threadIdx.x, wx = tid & 31, hy = tid >> 5;
     const int ntw = (W + NF_TW - 1) / NF_TW;
     // pixel column of this block: block ids go to the XCDs round-robin, so (when the count allows) XCD x takes a contiguous eighth of the
@@ -325,6 +348,15 @@ __global__ void __launch_bounds__(256) k_ncc_fused_bwd(const float* __restrict__
     const int gh = h0 + hy, gw = w0 + wx;
     const bool pix_ok = gh < H && gw < W;
     const float scale = -gloss[0] / (float)BV;
+    constexpr int NST = (PH * PW + 255) / 256;                 // staging slots of this thread (as k_ncc_fused_fwd)
+    int st_lds[NST], st_g[NST];
+#pragma unroll
+    for (int t = 0; t < NST; ++t) {
+        const int idx = tid + 256 * t, r = idx / PW, c = idx - r * PW;
+        const int y = h0 - R + r, x = w0 - R + c;
+        st_lds[t] = idx < PH * PW ? r * PWP + c : -1;
+        st_g[t] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? y * W + x : -1;
+    }
     float ring[WIN][3];
 #pragma unroll
     for (int k = 0; k < WIN; ++k)
@@ -334,25 +366,16 @@ __global__ void __launch_bounds__(256) k_ncc_fused_bwd(const float* __restrict__
         float s2[3] = {0.f, 0.f, 0.f};
         if (z >= 0 && z < D) {
             const size_t zoff = vol + (size_t)z * HW;
-            for (int idx = tid; idx < PH * PW; idx += 256) {
-                const int r = idx / PW, c = idx - r * PW;
-                const int y = h0 - R + r, x = w0 - R + c;
-                const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-                const size_t p = zoff + (size_t)y * W + x;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) P[q][r][c] = ok ? abc[q * BV + p] : 0.0f;
-            }
-            __syncthreads();
-            for (int idx = tid; idx < PH * NF_TW; idx += 256) {
-                const int r = idx >> 5, c = idx & 31;
+            for (int t = 0; t < NST; ++t) {
+                if (st_lds[t] >= 0) {
+                    float* const p = &P[0][0][0] + st_lds[t];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    float t = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < WIN; ++k) t += P[q][r][c + k];
-                    Rw[q][r][c] = t;
+                    for (int q = 0; q < 3; ++q) p[q * PH * PWP] = st_g[t] >= 0 ? abc[q * BV + zoff + st_g[t]] : 0.0f;
                 }
             }
+            __syncthreads();
+            for (int idx = tid; idx < 3 * PH * (NF_TW / 4); idx += 256) ncc_wpass4<WIN>(&P[0][0][0] + (idx >> 3) * PWP, &Rw[0][0][0] + (idx >> 3) * NF_TW, idx & 7);
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < 3; ++q)
