@@ -720,7 +720,8 @@ def test_maxpool_forward_codes_hold_what_the_backward_reads(vxm):
 
 @pytest.mark.parametrize("c0,up0,c1,cout,vol,B,with_mask", [(32, False, 0, 32, (20, 24, 28), 1, False), (32, False, 0, 32, (10, 12, 14), 2, True),
                                                            (32, True, 32, 32, (20, 24, 28), 1, False), (32, False, 0, 64, (20, 24, 28), 1, True),
-                                                           (40, False, 0, 24, (9, 11, 13), 1, True), (24, True, 16, 40, (6, 10, 18), 2, False)])
+                                                           (40, False, 0, 24, (9, 11, 13), 1, True), (24, True, 16, 40, (6, 10, 18), 2, False),
+                                                           (20, False, 12, 32, (7, 12, 20), 1, True)])           # (a chunk that straddles the two segments)
 def test_small_volume_conv_kernel_vs_fp64(vxm, c0, up0, c1, cout, vol, B, with_mask):
     """k_conv3d_k3_sm (round 6): the conv launches of the U-Net levels at 1/8 and 1/16 resolution -- input channels split over the waves of a
     block, partial tiles added in wave order -- forward (bias, LeakyReLU, virtual concat with an x2-upsampled segment) and backward-data (fused
